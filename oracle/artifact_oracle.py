@@ -1,0 +1,349 @@
+"""CPU oracle for the Permutect artifact-model hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain PyTorch-CPU fp32 restatement of what the reference executes for
+ArtifactModel.compute_batch_output / compute_batch_losses / backpropagate.  It is the checker for the HIP
+kernels; nothing in the product path (permutect_amd/) may import it.  Only tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg use it.
+
+Parity status: PINNED.  tests/golden/*.npz were produced by importing the reference itself
+(tests/golden/make_golden.py, run in the build container where /root/reference is mounted) and
+tests/test_oracle_golden.py checks this restatement against every one of those vectors.
+
+The functions are purely functional: they take a reference-format state_dict (name -> tensor) and a `Config`
+describing layer sizes.  Backward passes come from torch autograd over this forward, which is the same ATen
+composition the reference differentiates.
+
+Each function cites the reference lines it restates (paths relative to the reference checkout).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+SD = Dict[str, Tensor]
+
+MAX_LOGIT = 20.0  # architecture/feature_clustering.py:20
+MAX_OUTLIER_LOGIT = 10.0  # architecture/artifact_model.py:32
+MAX_ALT_COUNT = 15  # data/count_binning.py:11
+MIN_STDEV, MAX_STDEV = 0.01, 100.0  # architecture/feature_clustering.py:44-46
+MIN_LAMBDA, MAX_LAMBDA = 0.01, 100.0  # architecture/exponentially_modified_gaussian.py:17-19
+LOG2PI = math.log(2.0 * math.pi)
+
+# Data enum offsets, data/datum.py:51-89
+REF_COUNT, ALT_COUNT, LABEL, VARIANT_TYPE, SOURCE = 0, 1, 2, 3, 4
+HAPLOTYPES_START, INFO_START = 16, 6
+NUM_PACKED_BYTES = 7  # data/datum.py:35
+LABEL_ARTIFACT, LABEL_VARIANT, LABEL_UNLABELED = 0, 1, 2  # utils/enums.py:36-39
+
+
+@dataclass
+class Config:
+    read_layers: List[int]
+    info_layers: List[int]
+    aggregation_layers: List[int]
+    d_ffn: int
+    num_blocks: int
+    num_clusters: int
+    cnn_layers: List[str]
+    num_read_features: int
+    num_info_features: int
+    haplotypes_length: int
+    alt_count_layers: List[int] = field(default_factory=lambda: [30, -1, -1, -1, 1])  # artifact_model.py:180-183
+    num_sources: int = 1
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# input decode (data/batch.py:41-62, data/plain_text_data.py:510-511)
+# ----------------------------------------------------------------------------------------------------------------
+def decode_packed_reads(packed_u8: np.ndarray) -> np.ndarray:
+    """uint8 [R, 7+nf] -> float16 [R, 56+nf].  Bits are unpacked MSB first; the float columns are decoded as
+    (u - 128)/32 computed IN uint8, i.e. ((u + 128) & 0xFF)/32: bytes below 128 wrap (the reference quirk)."""
+    bits = np.unpackbits(packed_u8[:, :NUM_PACKED_BYTES], axis=1).astype(np.float16)
+    wrapped = (packed_u8[:, NUM_PACKED_BYTES:].astype(np.uint16) + 128) & 0xFF
+    floats = (wrapped.astype(np.float32) / 32.0).astype(np.float16)
+    return np.hstack((bits, floats))
+
+
+def one_hot_haplotypes(haplotypes_bh: Tensor) -> Tensor:
+    """[B, H] ints in 0..4 -> [B, 10, H/2] float; channel order refA, altA, refC, altC, ... (data/batch.py:115-130)."""
+    b, h = haplotypes_bh.shape
+    oh = F.one_hot(haplotypes_bh.long(), num_classes=5)  # [B, H, 5]
+    return oh.permute(0, 2, 1).reshape(b, 10, h // 2).to(torch.float32)
+
+
+def downsampled_read_indices(keep_ref_mask: Tensor, keep_alt_mask: Tensor) -> Tensor:
+    """data/batch.py:436-439: the alt indices are indices into the alt-only mask, used UN-OFFSET into reads_re."""
+    return torch.hstack((torch.nonzero(keep_ref_mask).view(-1), torch.nonzero(keep_alt_mask).view(-1)))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# building blocks
+# ----------------------------------------------------------------------------------------------------------------
+def mlp(sd: SD, prefix: str, layer_sizes: List[int], x: Tensor, prepend_activation: bool = False) -> Tensor:
+    """architecture/mlp.py:32-67 (Sequential index bookkeeping included, it defines the key names)."""
+    idx = 0
+    if prepend_activation:
+        x = F.selu(x)
+        idx += 1
+    width = layer_sizes[0]
+    last = len(layer_sizes) - 2
+    for k, out in enumerate(layer_sizes[1:]):
+        if out < 0:  # DenseSkipBlock, mlp.py:15-22
+            p = f"{prefix}._model.{idx}"
+            inner = mlp(sd, p + ".mlp", (-out + 1) * [width], x, prepend_activation=True)
+            x = x + sd[p + ".alpha"] * inner
+            idx += 1
+            continue
+        x = F.linear(x, sd[f"{prefix}._model.{idx}.weight"], sd[f"{prefix}._model.{idx}.bias"])
+        idx += 1
+        if k < last:
+            x = F.selu(x)
+            idx += 1
+        width = out
+    return x
+
+
+def mlp_output_dim(layer_sizes: List[int]) -> int:
+    width = layer_sizes[0]
+    for out in layer_sizes[1:]:
+        if out > 0:
+            width = out
+    return width
+
+
+def cnn(sd: SD, prefix: str, layer_strings: List[str], x: Tensor) -> Tensor:
+    """architecture/dna_sequence_convolution.py:49-111."""
+    for idx, spec in enumerate(layer_strings):
+        kind, *rest = spec.split("/")
+        kw = {k: int(v) for k, v in (t.split("=") for t in rest)}
+        p = f"{prefix}._model.{idx}"
+        if kind == "convolution":
+            x = F.conv1d(x, sd[p + ".weight"], sd[p + ".bias"], stride=kw.get("stride", 1),
+                         padding=kw.get("padding", 0), dilation=kw.get("dilation", 1))
+        elif kind == "pool":
+            x = F.max_pool1d(x, kw["kernel_size"], stride=kw.get("stride"), padding=kw.get("padding", 0))
+        elif kind == "leaky_relu":
+            x = F.leaky_relu(x)
+        elif kind == "selu":
+            x = F.selu(x)
+        elif kind == "flatten":
+            x = x.flatten(1)
+        elif kind == "linear":
+            x = F.linear(x, sd[p + ".weight"], sd[p + ".bias"])
+        else:
+            raise ValueError(kind)
+    return x
+
+
+def segment_sum(x_nf: Tensor, lengths_b: Tensor) -> Tensor:
+    """sets/ragged_sets.py:157 (torch.segment_reduce 'sum'; empty segments give 0)."""
+    return torch.segment_reduce(x_nf, lengths=lengths_b, reduce="sum", axis=0)
+
+
+def segment_mean(x_nf: Tensor, lengths_b: Tensor, regularizer_f: Optional[Tensor] = None,
+                 regularizer_weight=1e-4) -> Tensor:
+    """sets/ragged_sets.py:144-155."""
+    sums = segment_sum(x_nf, lengths_b)
+    reg = 0 if regularizer_f is None else (regularizer_weight * regularizer_f).view(1, -1)
+    return (sums + reg) / (lengths_b + regularizer_weight).view(-1, 1)
+
+
+def expand(x_bf: Tensor, lengths_b: Tensor) -> Tensor:
+    return torch.repeat_interleave(x_bf, repeats=lengths_b, dim=0)  # sets/ragged_sets.py:43-50
+
+
+def bounded(x: Tensor, lo: float, hi: float) -> Tensor:
+    return (hi - lo) * torch.sigmoid(x) + lo  # architecture/parameterizations.py:79-81
+
+
+def rotation_matrix(sd: SD, prefix: str) -> Tensor:
+    """torch orthogonal parametrization with the matrix_exp map and a stored base (euclidean_transformation.py:17)."""
+    x = sd[prefix + ".parametrizations.weight.original"].tril()
+    return sd[prefix + ".parametrizations.weight.0.base"] @ torch.matrix_exp(x - x.mT)
+
+
+def gated_block(sd: SD, p: str, ref: Tensor, alt: Tensor, nref: Tensor, nalt: Tensor) -> Tuple[Tensor, Tensor]:
+    """architecture/gated_mlp.py:177-200 and 228-251."""
+    d = ref.shape[-1]
+    nw, nb = sd[p + ".norm.weight"], sd[p + ".norm.bias"]
+    zr = F.selu(F.linear(F.layer_norm(ref, (d,), nw, nb), sd[p + ".proj1_ref.weight"], sd[p + ".proj1_ref.bias"]))
+    za = F.selu(F.linear(F.layer_norm(alt, (d,), nw, nb), sd[p + ".proj1_alt.weight"], sd[p + ".proj1_alt.bias"]))
+    s = p + ".sgu"
+    z1r, z2r = torch.chunk(zr, 2, dim=-1)
+    z1a, z2a = torch.chunk(za, 2, dim=-1)
+    h = z2r.shape[-1]
+    z2r = F.layer_norm(z2r, (h,), sd[s + ".norm.weight"], sd[s + ".norm.bias"])
+    z2a = F.layer_norm(z2a, (h,), sd[s + ".norm.weight"], sd[s + ".norm.bias"])
+    reg_weight = torch.exp(sd[s + ".parametrizations.reg_weight.original"])  # PositiveNumber
+    m_ref = segment_mean(z2r, nref, sd[s + ".ref_regularizer"], reg_weight + 0.25)
+    m_alt = segment_mean(z2a, nalt)
+    g_ref = (z2r * sd[s + ".alpha_ref"] + 1) + expand(sd[s + ".beta_ref"] * m_ref, nref)
+    g_alt = ((z2a * sd[s + ".alpha_alt"] + 1) + expand(sd[s + ".beta_alt"] * m_alt, nalt)) + expand(sd[s + ".gamma"] * m_ref, nalt)
+    ref_out = ref + F.linear(z1r * g_ref, sd[p + ".proj2_ref.weight"], sd[p + ".proj2_ref.bias"])
+    alt_out = alt + F.linear(z1a * g_alt, sd[p + ".proj2_alt.weight"], sd[p + ".proj2_alt.bias"])
+    return ref_out, alt_out
+
+
+def logerfc(z: Tensor) -> Tensor:
+    """architecture/exponentially_modified_gaussian.py:30-55."""
+    z_clip = torch.clip(z, min=2)
+    z2 = z_clip * z_clip
+    z4 = z2 * z2
+    z6 = z2 * z4
+    asymptotic = -z2 - torch.log(z_clip * math.sqrt(math.pi)) + torch.log1p(-1 / (2 * z2) + 3 / (4 * z4) - 15 / (8 * z6))
+    built_in = torch.log(torch.clip(torch.erfc(z), min=1.0e-12))
+    return torch.where(z > 5, asymptotic, built_in)
+
+
+def emg_log_likelihood(sd: SD, p: str, x_rk: Tensor) -> Tensor:
+    """architecture/exponentially_modified_gaussian.py:82-89."""
+    mu = sd[p + ".mu_k"]
+    sigma = bounded(sd[p + ".parametrizations.sigma_k.original"], MIN_STDEV, MAX_STDEV)
+    lam = bounded(sd[p + ".parametrizations.lambda_k.original"], MIN_LAMBDA, MAX_LAMBDA)
+    var = torch.square(sigma)
+    return (torch.log(lam / 2) + logerfc((mu + lam * var - x_rk) / (math.sqrt(2.0) * sigma))
+            + (lam / 2) * (2 * mu + lam * var - 2 * x_rk))
+
+
+def diag_gaussian_ll(x_rf: Tensor, stdev_f: Tensor) -> Tensor:
+    """architecture/feature_clustering.py:42-46."""
+    fdim = x_rf.shape[-1]
+    return (-(fdim / 2) * LOG2PI - torch.sum(torch.log(stdev_f), dim=-1)
+            - torch.sum(torch.square(x_rf / stdev_f), dim=-1) / 2)
+
+
+def clustering_head(sd: SD, p: str, alt_re: Tensor, nalt: Tensor) -> Tuple[Tensor, Tensor]:
+    """architecture/feature_clustering.py:82-135 -> (capped logits_b, log_lks_bk)."""
+    e = alt_re.shape[-1]
+    stdev_e = bounded(sd[p + ".parametrizations.nonartifact_stdev_e.original"], MIN_STDEV, MAX_STDEV)
+    dirs = sd[p + ".parametrizations.artifact_directions_ke.original"]
+    dirs = dirs / torch.norm(dirs, dim=-1, keepdim=True)  # UnitVector parametrization
+    art_stdev_k = bounded(sd[p + ".parametrizations.artifact_stdev_k.original"], MIN_STDEV, MAX_STDEV)
+    log_w_k = torch.log_softmax(sd[p + ".parametrizations.log_cluster_weights_k.original"], dim=-1)
+
+    nonart_r = diag_gaussian_ll(alt_re, stdev_e[None, :])
+    outlier_r = diag_gaussian_ll(alt_re, 2 * stdev_e[None, :])
+    unit = dirs / torch.norm(dirs, dim=-1, keepdim=True)  # feature_clustering.py:24 normalises again
+    par_rk = alt_re.matmul(unit.t())
+    orth_rke = alt_re[:, None, :] - par_rk[:, :, None] * unit[None, :, :]
+    orth_dist_rk = torch.norm(orth_rke, dim=-1)
+    orth_ll_rk = (-((e - 1) / 2) * LOG2PI - (e - 1) * torch.log(art_stdev_k)[None, :]
+                  - torch.square(orth_dist_rk) / (2 * torch.square(art_stdev_k[None, :])))
+    art_rk = orth_ll_rk + emg_log_likelihood(sd, p + ".artifact_emg", par_rk)
+    ll_bk = torch.cat((segment_sum(nonart_r[:, None], nalt), segment_sum(outlier_r[:, None], nalt),
+                       segment_sum(art_rk, nalt) + log_w_k[None, :]), dim=-1)
+    logits = torch.logsumexp(ll_bk[:, 2:], dim=-1) - ll_bk[:, 0]
+    return MAX_LOGIT * torch.tanh(logits / MAX_LOGIT), ll_bk
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# the hot path
+# ----------------------------------------------------------------------------------------------------------------
+def calculate_features(sd: SD, cfg: Config, reads_re: Tensor, nref: Tensor, nalt: Tensor, info_be: Tensor,
+                       haplotypes_bh: Tensor):
+    """architecture/artifact_model.py:239-265 -> (final_ref_re, final_alt_re, ref_seq_embeddings_be)."""
+    total_ref = int(nref.sum())
+    read_emb = mlp(sd, "read_embedding", [cfg.num_read_features] + cfg.read_layers, reads_re.to(torch.float32))
+    info_emb = mlp(sd, "info_embedding", [cfg.num_info_features] + cfg.info_layers, info_be.to(torch.float32))
+    hap_emb = cnn(sd, "haplotypes_cnn", cfg.cnn_layers, one_hot_haplotypes(haplotypes_bh))
+    info_seq = torch.hstack((info_emb, hap_emb))
+    x = torch.hstack((read_emb, torch.vstack((expand(info_seq, nref), expand(info_seq, nalt)))))
+    ref, alt = x[:total_ref], x[total_ref:]
+    for i in range(cfg.num_blocks):
+        ref, alt = gated_block(sd, f"ref_alt_reads_encoder.blocks.{i}", ref, alt, nref, nalt)
+    red_sizes = [ref.shape[-1]] + cfg.aggregation_layers
+    q = rotation_matrix(sd, "pre_clustering_transform.rotation_ee")
+    t = sd["pre_clustering_transform.translation_e"]
+    final = lambda r: F.linear(mlp(sd, "reducer", red_sizes, r) + t[None, :], q)  # euclidean_transformation.py:19-20
+    return final(ref), final(alt), hap_emb
+
+
+def compute_batch_output(sd: SD, cfg: Config, reads_re, nref, nalt, info_be, haplotypes_bh) -> Dict[str, Tensor]:
+    """architecture/artifact_model.py:281-297 with balancer=None, plus BatchOutput.__init__ (:44-73)."""
+    ref_re, alt_re, hap_emb = calculate_features(sd, cfg, reads_re, nref, nalt, info_be, haplotypes_bh)
+    logits_b, logits_bk = clustering_head(sd, "feature_clustering", alt_re, nalt)
+    nonoutlier = torch.logsumexp(torch.cat((logits_bk[:, 0:1], logits_bk[:, 2:]), dim=-1), dim=-1)
+    return dict(
+        features_be=segment_mean(alt_re, nalt), ref_features_be=segment_mean(ref_re, nref),
+        logits_b=logits_b, logits_bk=logits_bk, artifact_probs_b=torch.sigmoid(logits_b),
+        outlier_binary_logits=logits_bk[:, 1] - nonoutlier, ref_seq_embeddings_be=hap_emb,
+        final_ref_re=ref_re, final_alt_re=alt_re,
+    )
+
+
+def compute_batch_losses(sd: SD, cfg: Config, out: Dict[str, Tensor], labels_enum_b: Tensor, nalt: Tensor,
+                         sources_b: Optional[Tensor] = None, weights_b: Optional[Tensor] = None,
+                         source_weights_b: Optional[Tensor] = None, alt_adv_strength: float = 0.01,
+                         source_adv_strength: float = 0.01) -> Dict[str, Tensor]:
+    """architecture/artifact_model.py:299-325, :267-279, data/batch.py:100-106.  Gradient reversal
+    (gradient_reversal/functional.py:11-22) is expressed as  x*(-a) + (x*(1+a)).detach()  : identity forward,
+    -a * grad backward."""
+    logits_b = out["logits_b"]
+    w = torch.ones_like(logits_b) if weights_b is None else weights_b
+    sw = w if source_weights_b is None else source_weights_b
+    labels_b = 1.0 * (labels_enum_b == LABEL_ARTIFACT) + 0.5 * (labels_enum_b == LABEL_UNLABELED)
+    is_labeled = (labels_enum_b != LABEL_UNLABELED).int()
+    bce = lambda lg, tg: F.binary_cross_entropy_with_logits(lg, tg, reduction="none")
+    supervised = is_labeled * bce(logits_b, labels_b.to(logits_b.dtype))
+    clipped = torch.clip(out["outlier_binary_logits"], max=MAX_OUTLIER_LOGIT)
+    unsupervised = (1 - is_labeled) * bce(clipped, torch.zeros_like(clipped))
+
+    def revgrad(x, a):
+        return x * (-a) + (x * (1 + a)).detach()
+
+    feats = out["features_be"]
+    e = feats.shape[-1]
+    pred = torch.sigmoid(mlp(sd, "alt_count_predictor.wrapped_module", [e] + cfg.alt_count_layers,
+                             revgrad(feats, alt_adv_strength)).view(-1))
+    alt_count = torch.square(pred - nalt.to(pred.dtype) / MAX_ALT_COUNT)
+    if cfg.num_sources > 1:
+        hidden = [-1, -1]
+        src_logits = mlp(sd, "source_predictor.wrapped_module", [e] + hidden + [cfg.num_sources],
+                         revgrad(feats, source_adv_strength))
+        probs = torch.softmax(src_logits, dim=-1)
+        source = torch.sum(torch.square(probs - F.one_hot(sources_b.long(), cfg.num_sources)), dim=-1)
+    else:
+        source = torch.zeros_like(logits_b)
+    total_b = w * (supervised + unsupervised + alt_count) + sw * source
+    return dict(supervised_losses_b=supervised, unsupervised_losses_b=unsupervised, alt_count_losses_b=alt_count,
+                source_prediction_losses_b=source, total_losses_b=total_b, total_loss=torch.sum(total_b))
+
+
+def clip_and_adamw(params: List[Tensor], grads: List[Tensor], exp_avg: List[Tensor], exp_avg_sq: List[Tensor],
+                   step: int, lr: float, weight_decay: float, max_norm: float = 1.0, betas=(0.9, 0.999),
+                   eps: float = 1e-8) -> float:
+    """misc_utils.py:125-129: clip_grad_norm_(max_norm=1.0) over all params, then torch.optim.AdamW.step
+    (decoupled weight decay, bias correction; torch defaults betas=(0.9,0.999), eps=1e-8).  In place; returns the
+    pre-clip global norm.  `step` is the 1-based step count after this update."""
+    total = torch.sqrt(sum(torch.sum(g.double() ** 2) for g in grads)).float()
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    b1, b2 = betas
+    for p, g, m, v in zip(params, grads, exp_avg, exp_avg_sq):
+        g = g * coef
+        p.mul_(1 - lr * weight_decay)
+        m.mul_(b1).add_(g, alpha=1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        denom = (v.sqrt() / math.sqrt(1 - b2 ** step)).add_(eps)
+        p.addcdiv_(m, denom, value=-lr / (1 - b1 ** step))
+    return float(total)
+
+
+def train_step_grads(sd: SD, cfg: Config, batch: Dict[str, Tensor], **loss_kw):
+    """Forward + losses + autograd backward; returns (outputs, losses, {name: grad}).  Leaves = every floating
+    tensor in sd except the orthogonal `base` buffer."""
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()
+              if v.is_floating_point() and not k.endswith(".base")}
+    full = dict(sd)
+    full.update(leaves)
+    out = compute_batch_output(full, cfg, batch["reads_re"], batch["nref"], batch["nalt"], batch["info_be"],
+                               batch["haplotypes_bh"])
+    losses = compute_batch_losses(full, cfg, out, batch["labels"], batch["nalt"], batch.get("sources"), **loss_kw)
+    losses["total_loss"].backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}
+    return out, losses, grads

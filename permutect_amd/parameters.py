@@ -1,0 +1,96 @@
+"""Model hyperparameters.
+
+`ModelParameters` has the same constructor signature and attribute names as the reference class
+(reference permutect/parameters.py:16-40) because instances are pickled into the .pt checkpoint under the
+key "hyperparams" (reference architecture/artifact_model.py:327-337).  `install_pickle_alias()` makes this
+class resolvable as `permutect.parameters.ModelParameters` when the reference package is not installed, so
+reference-written checkpoints unpickle here and checkpoints written here unpickle in the reference.
+"""
+from __future__ import annotations
+
+import sys
+import types
+from typing import List
+
+
+class ModelParameters:
+    def __init__(
+        self,
+        read_layers: List[int],
+        self_attention_hidden_dimension: int,
+        num_self_attention_layers: int,
+        info_layers: List[int],
+        aggregation_layers: List[int],
+        num_artifact_clusters: int,
+        calibration_layers: List[int],
+        ref_seq_layers_strings: List[str],
+        dropout_p: float,
+        reweighting_range: float,
+        batch_normalize: bool = False,
+    ):
+        self.read_layers = read_layers
+        self.info_layers = info_layers
+        self.ref_seq_layer_strings = ref_seq_layers_strings
+        self.self_attention_hidden_dimension = self_attention_hidden_dimension
+        self.num_self_attention_layers = num_self_attention_layers
+        self.aggregation_layers = aggregation_layers
+        self.num_artifact_clusters = num_artifact_clusters
+        self.calibration_layers = calibration_layers
+        self.dropout_p = dropout_p
+        self.reweighting_range = reweighting_range
+        self.batch_normalize = batch_normalize
+
+
+# Pickle writes the defining module path.  Advertise the reference path so that checkpoints are portable both ways.
+ModelParameters.__module__ = "permutect.parameters"
+
+
+def install_pickle_alias() -> None:
+    """Make `permutect.parameters.ModelParameters` importable (no-op if the reference package is installed)."""
+    try:
+        import permutect.parameters  # noqa: F401  (the real one, if present)
+
+        return
+    except Exception:
+        pass
+    pkg = sys.modules.get("permutect")
+    if pkg is None:
+        pkg = types.ModuleType("permutect")
+        pkg.__path__ = []  # mark as package
+        sys.modules["permutect"] = pkg
+    mod = types.ModuleType("permutect.parameters")
+    mod.ModelParameters = ModelParameters
+    sys.modules["permutect.parameters"] = mod
+    pkg.parameters = mod
+
+
+# ---- named configurations used by tests / bench ------------------------------------------
+P0_CNN = [
+    "convolution/kernel_size=3/out_channels=32",
+    "pool/kernel_size=2",
+    "leaky_relu",
+    "convolution/kernel_size=3/out_channels=32",
+    "leaky_relu",
+    "flatten",
+    "linear/out_features=10",
+]
+T0_CNN = [
+    "convolution/kernel_size=3/out_channels=64",
+    "pool/kernel_size=2",
+    "leaky_relu",
+    "flatten",
+    "linear/out_features=10",
+]
+
+
+def p0_params() -> ModelParameters:
+    """Production-shaped hyperparameters: 59 845 parameters with F=61, I=71, H=42."""
+    return ModelParameters([30, -2, -2, -2], 20, 6, [20, -2, -2, -2], [-2, -2, 10], 4, [10, 10], list(P0_CNN), 0.0, 0.3)
+
+
+def t0_params() -> ModelParameters:
+    """The reference's own test configuration (reference test/tools/test_train_permutect_model.py:19-35)."""
+    return ModelParameters([10, 10, 10], 20, 2, [10, 10], [20, 20, 20], 4, [10, 10, 10], list(T0_CNN), 0.0, 0.3)
+
+
+P0_DIMS = dict(num_read_features=61, num_info_features=71, haplotypes_length=42)

@@ -1,0 +1,200 @@
+"""Generate golden vectors by running the REFERENCE implementation (build container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Imports /root/reference/permutect with three in-process stubs for I/O-only third-party modules that are not
+installed here (cyvcf2, intervaltree, torch.utils.tensorboard); none of them carries arithmetic.
+Writes tests/golden/*.npz: inputs in the reference's on-disk dtypes (uint8 packed reads, int16 int array, float16
+float array), the full state_dict, and the reference's outputs / losses / gradients / post-AdamW parameters.
+Only data is written -- no reference source text.  The fixtures travel to the GPU box; the reference does not.
+"""
+import os
+import random
+import sys
+import types
+
+REFERENCE = os.environ.get("PERMUTECT_REFERENCE", "/root/reference")
+sys.path.insert(0, REFERENCE)
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+cy = types.ModuleType("cyvcf2"); cy.VCF = cy.Variant = cy.Writer = object; sys.modules["cyvcf2"] = cy
+it = types.ModuleType("intervaltree"); it.IntervalTree = dict; sys.modules["intervaltree"] = it
+tb = types.ModuleType("torch.utils.tensorboard")
+
+
+class SummaryWriter:
+    def __init__(self, *a, **k):
+        pass
+
+    def __getattr__(self, n):
+        return lambda *a, **k: None
+
+
+tb.SummaryWriter = SummaryWriter
+sys.modules["torch.utils.tensorboard"] = tb
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from permutect.architecture.artifact_model import ArtifactModel  # noqa: E402
+from permutect.data.batch import Batch, DownsampledBatch  # noqa: E402
+from permutect.data.datum import Data, Datum  # noqa: E402
+from permutect.misc_utils import backpropagate  # noqa: E402
+from permutect.parameters import ModelParameters  # noqa: E402
+
+from permutect_amd.parameters import P0_CNN, T0_CNN  # noqa: E402  (plain lists of layer strings)
+
+CPU = torch.device("cpu")
+
+
+def make_model(kind, seed, perturb=0.05, num_sources=1):
+    torch.manual_seed(seed)
+    if kind == "T0":
+        p = ModelParameters([10, 10, 10], 20, 2, [10, 10], [20, 20, 20], 4, [10, 10, 10], list(T0_CNN), 0.0, 0.3, False)
+    else:
+        p = ModelParameters([30, -2, -2, -2], 20, 6, [20, -2, -2, -2], [-2, -2, 10], 4, [10, 10], list(P0_CNN), 0.0, 0.3, False)
+    m = ArtifactModel(p, 61, 71, 42, device=CPU)
+    if num_sources > 1:
+        m.reset_source_predictor(num_sources)
+    with torch.no_grad():
+        for q in m.parameters():
+            q.add_(perturb * torch.randn_like(q))
+    return m
+
+
+def make_data(rng, counts, labels=None, sources=None, info_scale=1.0, byte_lo=0, byte_hi=256):
+    data = []
+    for i, (nr, na) in enumerate(counts):
+        ints = np.zeros(16 + 42, dtype=np.int16)
+        ints[16:] = rng.integers(0, 5, size=42)
+        floats = np.zeros(6 + 71, dtype=np.float16)
+        floats[6:] = (info_scale * rng.standard_normal(71)).astype(np.float16)
+        reads = rng.integers(byte_lo, byte_hi, size=(nr + na, 12), dtype=np.uint8)
+        d = Datum(ints, floats, reads, compressed=True)
+        d.set(Data.REF_COUNT, nr)
+        d.set(Data.ALT_COUNT, na)
+        d.set(Data.LABEL, (i % 3) if labels is None else labels[i])
+        d.set(Data.VARIANT_TYPE, i % 5)
+        d.set(Data.SOURCE, 0 if sources is None else sources[i])
+        data.append(d)
+    return data
+
+
+def run_case(name, model, data, train=True, lr=1e-3, wd=0.01, source_strength=None):
+    batch = Batch(data)
+    ref_counts = batch.get(Data.REF_COUNT)
+    total_ref = int(ref_counts.sum())
+    packed = np.vstack([d.get_ref_reads_re() for d in data] + [d.get_alt_reads_re() for d in data])
+    assert packed.shape[0] == batch.get_reads_re().shape[0]
+    out = {"packed_reads": packed, "int_array": batch.int_tensor.numpy().astype(np.int16),
+           "float_array": batch.float_tensor.numpy().astype(np.float16),
+           "reads_re_f16": batch.get_reads_re().numpy(), "total_ref": np.int64(total_ref)}
+    for k, v in model.state_dict().items():
+        out["sd/" + k] = v.detach().numpy().copy()
+    if source_strength is not None:
+        model.source_predictor.set_adversarial_strength(source_strength)
+        out["source_strength"] = np.float64(source_strength)
+    model.train(True)
+    output = model.compute_batch_output(batch, None)
+    losses = model.compute_batch_losses(output, batch)
+    ref_bre, alt_bre, hap = model.calculate_features(batch)
+    for k in ("features_be", "ref_features_be", "logits_b", "logits_bk", "artifact_probs_b", "outlier_binary_logits"):
+        out["out/" + k] = getattr(output, k).detach().numpy()
+    out["out/final_ref_re"] = ref_bre.flattened_tensor_nf.detach().numpy()
+    out["out/final_alt_re"] = alt_bre.flattened_tensor_nf.detach().numpy()
+    out["out/ref_seq_embeddings_be"] = hap.detach().numpy()
+    for k in ("supervised_losses_b", "unsupervised_losses_b", "alt_count_losses_b", "source_prediction_losses_b",
+              "total_losses_b", "total_loss"):
+        out["loss/" + k] = getattr(losses, k).detach().numpy()
+    if train:
+        opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=wd)
+        # backpropagate() = zero_grad, backward, clip_grad_norm_(1.0), step.  Capture raw grads first by hooks.
+        raw = {}
+        handles = [q.register_hook(lambda g, n=n: raw.__setitem__(n, g.detach().clone()))
+                   for n, q in model.named_parameters()]
+        backpropagate(opt, losses.total_loss, params_to_clip=model.parameters())
+        for h in handles:
+            h.remove()
+        for n, q in model.named_parameters():
+            g = raw.get(n)
+            out["grad/" + n] = (torch.zeros_like(q) if g is None else g).numpy()
+            out["after/" + n] = q.detach().numpy().copy()
+        out["lr"], out["weight_decay"] = np.float64(lr), np.float64(wd)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "B", len(data), "R", packed.shape[0], "total_loss", float(losses.total_loss),
+          "logits", output.logits_b.detach().numpy()[:4])
+
+
+def main():
+    rng = np.random.default_rng(0)
+    random.seed(0)
+
+    # -- case 1: reference test configuration, small batch with n_ref = 0 and n_alt = 1 members
+    counts = [(3, 2), (0, 1), (10, 15), (1, 1), (0, 4), (7, 3), (2, 9), (5, 5)]
+    run_case("t0_b8", make_model("T0", 1), make_data(rng, counts))
+
+    # -- case 2: production-shaped configuration
+    counts = [(int(rng.integers(0, 11)), int(rng.integers(1, 16))) for _ in range(16)]
+    run_case("p0_b16", make_model("P0", 2), make_data(rng, counts))
+
+    # -- case 3: P0, every variant has zero ref reads (artifact_model.py:253 TODO), forward + train
+    counts = [(0, int(rng.integers(1, 16))) for _ in range(6)]
+    try:
+        run_case("p0_zero_ref", make_model("P0", 3), make_data(rng, counts))
+    except Exception as exc:  # record that the reference itself cannot do it
+        print("p0_zero_ref: reference raised", type(exc).__name__, exc)
+
+    # -- case 4: large-magnitude embeddings: logits saturate the +-20 tanh cap, EMG argument on both sides of z = 5
+    m = make_model("P0", 4, perturb=0.05)
+    with torch.no_grad():
+        m.pre_clustering_transform.translation_e.add_(3.0)
+        m.feature_clustering.artifact_emg.mu_k.copy_(torch.tensor([6.0, -4.0, 1.0, 12.0]))
+    counts = [(int(rng.integers(0, 11)), int(rng.integers(1, 16))) for _ in range(12)]
+    run_case("p0_saturated", m, make_data(rng, counts, info_scale=3.0))
+
+    # -- case 5: deeper sets than the reference pipeline produces (count-agnostic math), forward + train
+    counts = [(40, 70), (0, 33), (64, 1), (17, 48)]
+    run_case("p0_deep", make_model("P0", 5), make_data(rng, counts))
+
+    # -- case 6: two sources -> source predictor with hidden skip blocks and the adversarial source loss
+    counts = [(int(rng.integers(0, 11)), int(rng.integers(1, 16))) for _ in range(10)]
+    srcs = [i % 2 for i in range(10)]
+    run_case("t0_two_sources", make_model("T0", 6, num_sources=2), make_data(rng, counts, sources=srcs),
+             source_strength=0.3)
+
+    # -- quirk A: uint8 decode of every byte value in a float column, and of every bit pattern byte
+    reads = np.zeros((256, 12), dtype=np.uint8)
+    reads[:, 0] = np.arange(256)
+    reads[:, 6] = np.arange(256)[::-1]
+    reads[:, 7] = np.arange(256)
+    reads[:, 11] = np.arange(256)[::-1]
+    ints = np.zeros(16 + 42, dtype=np.int16)
+    floats = np.zeros(6 + 71, dtype=np.float16)
+    d = Datum(ints, floats, reads, compressed=True)
+    d.set(Data.REF_COUNT, 128)
+    d.set(Data.ALT_COUNT, 128)
+    b = Batch([d])
+    np.savez_compressed(os.path.join(HERE, "quirk_decode.npz"), packed_reads=reads, reads_re_f16=b.get_reads_re().numpy())
+
+    # -- quirk B: DownsampledBatch gathers alt rows un-offset
+    counts = [(10, 3), (8, 5), (6, 2)]
+    data = make_data(rng, counts)
+    parent = Batch(data)
+    db = DownsampledBatch(parent, torch.ones(3), torch.ones(3))
+    torch.manual_seed(11)
+    random.seed(11)
+    db2 = DownsampledBatch(parent, torch.tensor([0.5, 0.3, 0.9]), torch.tensor([0.5, 0.5, 0.5]))
+    np.savez_compressed(
+        os.path.join(HERE, "quirk_downsample.npz"),
+        ref_counts=np.array([c[0] for c in counts]), alt_counts=np.array([c[1] for c in counts]),
+        read_indices_all_kept=db.read_indices.numpy(), new_ref_counts_all_kept=db.ref_counts.numpy(),
+        new_alt_counts_all_kept=db.alt_counts.numpy(),
+        read_indices_half=db2.read_indices.numpy(), new_ref_counts_half=db2.ref_counts.numpy(),
+        new_alt_counts_half=db2.alt_counts.numpy(),
+        gathered_reads_half=db2.get_reads_re().numpy(), parent_reads=parent.get_reads_re().numpy(),
+    )
+    print("quirks written")
+
+
+if __name__ == "__main__":
+    main()

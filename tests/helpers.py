@@ -1,0 +1,36 @@
+"""Shared test helpers: load golden fixtures, build oracle inputs."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import artifact_oracle as O
+from permutect_amd.parameters import P0_CNN, T0_CNN
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = ["t0_b8", "p0_b16", "p0_zero_ref", "p0_saturated", "p0_deep", "t0_two_sources"]
+
+
+def config_for(name: str) -> O.Config:
+    if name.startswith("t0"):
+        cfg = O.Config([10, 10, 10], [10, 10], [20, 20, 20], 20, 2, 4, list(T0_CNN), 61, 71, 42)
+    else:
+        cfg = O.Config([30, -2, -2, -2], [20, -2, -2, -2], [-2, -2, 10], 20, 6, 4, list(P0_CNN), 61, 71, 42)
+    if name == "t0_two_sources":
+        cfg.num_sources = 2
+    return cfg
+
+
+def load_case(name: str):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    ints = torch.from_numpy(z["int_array"].astype(np.int64))
+    floats = torch.from_numpy(z["float_array"].astype(np.float32))
+    batch = dict(
+        packed_reads=z["packed_reads"],
+        reads_re=torch.from_numpy(O.decode_packed_reads(z["packed_reads"]).astype(np.float32)),
+        nref=ints[:, O.REF_COUNT], nalt=ints[:, O.ALT_COUNT], labels=ints[:, O.LABEL], sources=ints[:, O.SOURCE],
+        info_be=floats[:, O.INFO_START:], haplotypes_bh=ints[:, O.HAPLOTYPES_START:],
+        int_array=z["int_array"], float_array=z["float_array"],
+    )
+    return z, sd, batch
