@@ -1,0 +1,228 @@
+/*
+ * permutect_amd.h -- C ABI of the MI355X (gfx950) engine for the Permutect artifact-model hot path.
+ *
+ * The reference (broadinstitute/permutect) is pure Python on PyTorch and has no FFI or operator registry; the seam
+ * this library plugs into is the Python object boundary of `ArtifactModel`
+ * (reference permutect/architecture/artifact_model.py:239-325) plus `backpropagate`
+ * (reference permutect/misc_utils.py:125-129).  Each entry point below names the reference code it replaces.
+ * INTEGRATION.md shows the ctypes binding a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes only.  Device pointers are raw HBM addresses; `stream` is a hipStream_t passed as
+ *     void* (NULL = default stream).  The caller owns every buffer; the library allocates nothing on the device
+ *     and keeps no global state, so it is thread-safe per stream and graph-capturable.
+ *   - every function returns 0 on success or a negative PMT_E_* code; it never throws and never falls back to a
+ *     CPU path.
+ *   - offsets inside descriptors are in units of floats into the buffer named in the field comment.
+ */
+#ifndef PERMUTECT_AMD_H
+#define PERMUTECT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMT_ABI_VERSION 1
+
+/* error codes */
+#define PMT_OK 0
+#define PMT_E_INVALID (-1)      /* bad argument / descriptor out of supported range */
+#define PMT_E_UNSUPPORTED (-2)  /* configuration the gfx950 kernels do not cover (stated in DESIGN.md) */
+#define PMT_E_CAPACITY (-3)     /* a read set does not fit the register-resident group capacity */
+#define PMT_E_LAUNCH (-4)       /* HIP launch failure (hipGetLastError is left set) */
+#define PMT_E_WORKSPACE (-5)    /* workspace too small */
+
+/* compile-time limits of the kernels */
+#define PMT_MAX_WIDTH 64        /* widest activation (features) kept register-resident: 4 tiles of 16 */
+#define PMT_MAX_HALF_FFN 16     /* d_ffn / 2 */
+#define PMT_MAX_CLUSTERS 16
+#define PMT_MAX_OPS 8           /* top-level ops per MLP program */
+#define PMT_MAX_SKIP_LAYERS 4
+#define PMT_MAX_BLOCKS 16
+#define PMT_MAX_LINEAR 96
+#define PMT_GROUP_WAVES 8       /* waves per workgroup */
+#define PMT_GROUP_TILES 16      /* 16-read tiles per group (8 waves x 2 tiles) */
+#define PMT_GROUP_MAX_SETS 64   /* read sets (variants) per group */
+#define PMT_TILE 16
+
+/* read-row formats accepted at the boundary (reference data/batch.py:41-62, data/datum.py:35) */
+#define PMT_READS_PACKED_U8 0   /* [R][7 + nf] uint8: 7 MSB-first bit-packed bytes, then nf quantile bytes */
+#define PMT_READS_F16 1         /* [R][F] float16 (Batch.reads_re as the reference collates it) */
+#define PMT_READS_F32 2         /* [R][F] float32 (Batch.copy_to(device, float32)) */
+
+/* One nn.Linear.  Weights are consumed in MFMA fragment order from the packed buffer. */
+typedef struct PmtLinear {
+    int32_t in_dim, out_dim;
+    int32_t w_frag;      /* packed: A fragments of W   [out][in]  (forward, y = W x + b)            */
+    int32_t wt_frag;     /* packed: A fragments of W^T [in][out]  (backward, dx = W^T dy)           */
+    int32_t b_pvec;      /* packed: bias in tile-position order, -1 = no bias                       */
+    int32_t w_src;       /* natural-layout source of W: offset into theta (>=0) or phi (<= -2: -(off+2)) */
+    int32_t b_src;       /* same for the bias, -1 = none                                            */
+    int32_t out_split;   /* 0, or h: the 2h output rows are laid out as two 16-row tiles (rows 0..h-1 -> tile 0,
+                            rows h..2h-1 -> tile 1) so that z1 / z2 of the gating unit are tile aligned       */
+} PmtLinear;
+
+#define PMT_OP_LINEAR 0         /* y = W x + b, optional SELU after   (reference mlp.py:55-61)          */
+#define PMT_OP_SKIP 1           /* y = x + alpha * f(x), f = (SELU, Linear) x n   (reference mlp.py:15-22) */
+typedef struct PmtOp {
+    int32_t kind;
+    int32_t n_layers;                       /* SKIP: number of (SELU, Linear) pairs; LINEAR: 1 */
+    int32_t selu_after;                     /* LINEAR only */
+    int32_t alpha_src;                      /* SKIP: theta offset of the scalar alpha */
+    int32_t lin[PMT_MAX_SKIP_LAYERS];       /* indices into PmtModel.lin */
+} PmtOp;
+
+typedef struct PmtMlp {
+    int32_t n_ops, in_dim, out_dim, reserved;
+    PmtOp ops[PMT_MAX_OPS];
+} PmtMlp;
+
+/* One GatedRefAltMLPBlock (reference gated_mlp.py:148-251). */
+typedef struct PmtBlock {
+    int32_t norm_w_pvec, norm_b_pvec;       /* packed LayerNorm(D) weight / bias */
+    int32_t norm_w_src, norm_b_src;         /* theta offsets */
+    int32_t proj1[2], proj2[2];             /* linear ids, [0] = ref, [1] = alt; proj1 rows are permuted so
+                                               that z1 and z2 each start on a 16-row tile */
+    int32_t sgu_norm_w_pvec, sgu_norm_b_pvec;
+    int32_t sgu_norm_w_src, sgu_norm_b_src;
+    int32_t alpha_src[2], beta_src[2];      /* theta offsets of alpha_ref/alt, beta_ref/alt */
+    int32_t gamma_src;
+    int32_t ref_reg_pvec, ref_reg_src;      /* ref_regularizer [h] */
+    int32_t reg_weight_phi;                 /* phi offset of exp(reg_weight.original) (the +0.25 is applied in-kernel) */
+} PmtBlock;
+
+/* FeatureClustering + EMG head (reference feature_clustering.py:82-135, exponentially_modified_gaussian.py:30-89).
+ * All entries are offsets into phi (materialised values) except mu (theta). */
+typedef struct PmtHead {
+    int32_t stdev_e_phi;        /* [E] nonartifact stdev                                   */
+    int32_t dirs_ke_phi;        /* [K][E] unit direction vectors (already normalised)      */
+    int32_t art_stdev_k_phi;    /* [K]                                                     */
+    int32_t log_w_k_phi;        /* [K] log_softmax cluster weights                         */
+    int32_t mu_k_src;           /* [K] theta offset                                        */
+    int32_t sigma_k_phi;        /* [K]                                                     */
+    int32_t lambda_k_phi;       /* [K]                                                     */
+    int32_t reserved;
+} PmtHead;
+
+typedef struct PmtModel {
+    int32_t abi_version;
+    int32_t num_read_features;  /* F */
+    int32_t read_embed_dim;     /* E_r */
+    int32_t variant_embed_dim;  /* E_v = info embedding + haplotype embedding widths */
+    int32_t d_model;            /* D = E_r + E_v */
+    int32_t d_ffn;              /* 2 h */
+    int32_t num_blocks;         /* L */
+    int32_t feature_dim;        /* E */
+    int32_t num_clusters;       /* K */
+    int32_t n_linear;
+    int32_t theta_size, phi_size, packed_size; /* floats */
+    int32_t translation_src;    /* theta offset of pre_clustering_transform.translation_e [E] */
+    int32_t translation_pvec;
+    int32_t rotation_lin;       /* linear id, weight source = phi (materialised Q), no bias */
+    PmtMlp read_mlp;            /* read_embedding  */
+    PmtMlp reducer;             /* reducer         */
+    PmtBlock blocks[PMT_MAX_BLOCKS];
+    PmtHead head;
+    PmtLinear lin[PMT_MAX_LINEAR];
+} PmtModel;
+
+/* Inputs of one forward / backward pass.  Reads are ordered as the reference's Batch orders them: all ref reads
+ * of all variants, then all alt reads (reference data/batch.py:45-47). */
+typedef struct PmtBatch {
+    int32_t num_variants;           /* B */
+    int32_t num_groups;             /* G */
+    int32_t read_format;            /* PMT_READS_* */
+    int32_t read_row_bytes;         /* stride of one read row */
+    const void* reads;              /* device */
+    const int64_t* read_index;      /* device, optional gather (DownsampledBatch.read_indices), NULL = identity */
+    const int32_t* ref_offsets;     /* device [B+1] exclusive scan of ref counts; [B] = total ref reads */
+    const int32_t* alt_offsets;     /* device [B+1] exclusive scan of alt counts */
+    const float* variant_embed;     /* device [B][E_v]: info embedding | haplotype embedding */
+    const int32_t* group_start;     /* device [G+1] first variant of each group (pmt_plan_groups) */
+    const int32_t* group_tile_base; /* device [G+1] first stash tile of each group (pmt_plan_groups) */
+    int64_t total_tiles;            /* host value of group_tile_base[G] (sizes the stash)             */
+} PmtBatch;
+
+typedef struct PmtOutputs {
+    float* logits_b;                /* [B]            capped artifact logit                    */
+    float* logits_bk;               /* [B][K+2]       nonartifact, outlier, K clusters         */
+    float* features_be;             /* [B][E]         alt-set mean embedding                   */
+    float* ref_features_be;         /* [B][E]         ref-set mean embedding                   */
+} PmtOutputs;
+
+/* dL/d(outputs), same shapes as PmtOutputs; any pointer may be NULL (= zero). */
+typedef struct PmtOutputGrads {
+    const float* d_logits_b;
+    const float* d_logits_bk;
+    const float* d_features_be;
+    const float* d_ref_features_be;
+} PmtOutputGrads;
+
+typedef struct PmtAdamW {
+    float lr, beta1, beta2, eps, weight_decay, max_grad_norm;
+    int32_t step;                   /* 1-based step number of this update */
+    int32_t reserved;
+} PmtAdamW;
+
+/* ---- host-side helpers (no GPU needed) ------------------------------------------------------------------- */
+
+int pmt_abi_version(void);
+
+/* sizeof() of the ABI structs as compiled into the library, for binding self-checks:
+ * 0 PmtModel, 1 PmtBatch, 2 PmtOutputs, 3 PmtOutputGrads, 4 PmtAdamW, 5 PmtLinear, 6 PmtOp, 7 PmtMlp, 8 PmtBlock, 9 PmtHead */
+int pmt_struct_bytes(int which);
+
+/* Validates a descriptor against the kernels' limits. */
+int pmt_model_check(const PmtModel* model);
+
+/* Partition variants into register-resident groups: greedy over consecutive variants so that each group has
+ * <= PMT_GROUP_TILES tiles (ceil(ref/16) + ceil(alt/16)) and <= PMT_GROUP_MAX_SETS sets.  Counts are HOST arrays
+ * (upper bounds are fine: a DownsampledBatch reuses its parent's plan).  group_start / group_tile_base must hold
+ * num_variants + 1 ints.  Returns the number of groups, or PMT_E_CAPACITY if one variant alone exceeds a group
+ * (*bad_variant receives its index). */
+int pmt_plan_groups(const int32_t* ref_counts, const int32_t* alt_counts, int32_t num_variants,
+                    int32_t* group_start, int32_t* group_tile_base, int32_t* bad_variant);
+
+/* Bytes of activation stash a training forward needs for `total_tiles` tiles (group_tile_base[G]) and B variants. */
+size_t pmt_stash_bytes(const PmtModel* model, int64_t total_tiles, int32_t num_variants);
+
+/* ---- device entry points ---------------------------------------------------------------------------------- */
+
+/* Re-pack natural-layout parameters (theta: the flat leaf buffer the optimizer updates; phi: materialised
+ * parametrizations) into MFMA fragment order.  Run after every optimizer step.  `model_dev` is a device copy of
+ * the descriptor. */
+int pmt_pack_params(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* phi,
+                    float* packed, void* stream);
+
+/* Exclusive scans of per-variant counts (int32 or int64, device) into ref_offsets/alt_offsets [B+1].
+ * Replaces the host-synchronising torch.sum(...).item() of reference artifact_model.py:241. */
+int pmt_scan_counts(const void* ref_counts, const void* alt_counts, int32_t count_elem_bytes, int64_t count_stride,
+                    int32_t num_variants, int32_t* ref_offsets, int32_t* alt_offsets, void* stream);
+
+/* Fused read-set forward: decode -> read MLP -> concat -> L gated ref/alt blocks -> reducer -> rotation ->
+ * clustering head + per-set sums.  Replaces ArtifactModel.calculate_features + FeatureClustering.calculate_logits
+ * + RaggedSets.means_over_sets (reference artifact_model.py:239-297).  `stash` = NULL for inference; otherwise the
+ * activations the backward pass re-reads are written there (pmt_stash_bytes). */
+int pmt_forward(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* phi,
+                const float* packed, const PmtBatch* batch, const PmtOutputs* out, float* stash, void* stream);
+
+/* Fused backward of pmt_forward.  Accumulates (atomic adds) into grad_theta / grad_phi (same layouts as theta /
+ * phi; the caller zeroes them) and writes grad_variant_embed [B][E_v].  Replaces autograd over the same graph
+ * (reference misc_utils.py:127). */
+int pmt_backward(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* phi,
+                 const float* packed, const PmtBatch* batch, const PmtOutputGrads* dout, const float* stash,
+                 float* grad_theta, float* grad_phi, float* grad_variant_embed, void* stream);
+
+/* Global-norm clip + AdamW over the flat parameter buffer, one launch sequence, no host sync.
+ * Replaces nn.utils.clip_grad_norm_(max_norm=1.0) + torch.optim.AdamW.step (reference misc_utils.py:128-129).
+ * `scratch` holds >= 1024 floats.  grad_norm_out (device, optional) receives the pre-clip global L2 norm. */
+int pmt_clip_adamw(float* theta, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   const PmtAdamW* hyper, float* scratch, float* grad_norm_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PERMUTECT_AMD_H */

@@ -1,0 +1,227 @@
+"""ArtifactModel: drop-in for the reference class of the same name, computed on MI355X by hand-written HIP kernels.
+
+Same constructor, method names, return containers, state_dict keys and `.pt` dictionary as
+reference permutect/architecture/artifact_model.py:97-369.  What is different is where the
+arithmetic runs: `calculate_features` + `FeatureClustering.calculate_logits` + `RaggedSets.means_over_sets` are ONE fused
+HIP launch (permutect_amd/csrc/pmt_forward.hip) and their backward is one fused launch (pmt_backward.hip), behind
+`ReadSetFunction`.  The per-variant branches (info MLP, haplotype CNN, adversaries, losses) are O(B) work evaluated with
+torch ops on the same ROCm device.  There is no CPU compute path: on a CPU device the compute methods raise.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import Tensor, nn
+
+from permutect_amd import constants
+from permutect_amd.architecture import modules as M
+from permutect_amd.data.batch import Batch
+from permutect_amd.data.datum import Data
+from permutect_amd.engine.runtime import ReadSetEngine, ReadSetFunction
+from permutect_amd.enums import Epoch
+from permutect_amd.parameters import ModelParameters, install_pickle_alias
+
+_BCE = nn.BCEWithLogitsLoss(reduction="none")
+
+
+def gpu_if_available() -> torch.device:
+    return torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+
+class BatchOutput:
+    """reference artifact_model.py:38-73"""
+
+    def __init__(self, features_be: Tensor, ref_features_be: Tensor, logits_b: Tensor, logits_bk: Tensor,
+                 weights: Tensor, source_weights: Tensor):
+        self.features_be = features_be
+        self.ref_features_be = ref_features_be
+        self.logits_b = logits_b
+        self.artifact_probs_b = torch.sigmoid(logits_b)
+        self.logits_bk = logits_bk
+        self.weights = weights
+        self.source_weights = source_weights
+        nonoutlier = torch.logsumexp(torch.cat((logits_bk[:, 0:1], logits_bk[:, 2:]), dim=-1), dim=-1)
+        self.outlier_binary_logits = logits_bk[:, 1] - nonoutlier
+
+
+class BatchLosses:
+    """reference artifact_model.py:76-90 (total_loss is a SUM over the batch)"""
+
+    def __init__(self, supervised_losses_b, unsupervised_losses_b, alt_count_losses_b, source_prediction_losses_b,
+                 total_losses_b):
+        self.supervised_losses_b = supervised_losses_b
+        self.unsupervised_losses_b = unsupervised_losses_b
+        self.alt_count_losses_b = alt_count_losses_b
+        self.source_prediction_losses_b = source_prediction_losses_b
+        self.total_losses_b = total_losses_b
+        self.total_loss = torch.sum(total_losses_b)
+
+
+class SetMeansView:
+    """What callers of `calculate_features` consume from the reference's RaggedSets: the per-set means."""
+
+    def __init__(self, means_be: Tensor, lengths_b: Tensor):
+        self._means, self.lengths_b = means_be, lengths_b
+
+    def means_over_sets(self) -> Tensor:
+        return self._means
+
+    def batch_size(self) -> int:
+        return len(self.lengths_b)
+
+
+class ArtifactModel(nn.Module):
+    def __init__(self, params: ModelParameters, num_read_features: int, num_info_features: int,
+                 haplotypes_length: int, device=None):
+        super().__init__()
+        if device is None:
+            device = gpu_if_available()
+        self._device = torch.device(device)
+        self._dtype = torch.float32  # reference data/datum.py:37-38: fp32 on every device
+        self._haplotypes_length = haplotypes_length
+        self._params = params
+
+        self.read_embedding = M.MLP([num_read_features] + params.read_layers, params.batch_normalize, params.dropout_p)
+        self.info_embedding = M.MLP([num_info_features] + params.info_layers, params.batch_normalize, params.dropout_p)
+        self.haplotypes_cnn = M.DNASequenceConvolution(params.ref_seq_layer_strings, haplotypes_length // 2)
+        embedding_dim = (self.read_embedding.output_dimension() + self.info_embedding.output_dimension()
+                         + self.haplotypes_cnn.output_dimension())
+        self.ref_alt_reads_encoder = M.GatedRefAltMLP(embedding_dim, params.self_attention_hidden_dimension,
+                                                      params.num_self_attention_layers)
+        self.reducer = M.MLP([embedding_dim] + params.aggregation_layers, params.batch_normalize, params.dropout_p)
+        e = self.reducer.output_dimension()
+        self.pre_clustering_transform = M.EuclideanTransformation(e)
+        self.feature_clustering = M.FeatureClustering(e, params.num_artifact_clusters)
+        self.alt_count_predictor = M.Adversarial(M.MLP([e] + [30, -1, -1, -1, 1]), adversarial_strength=0.01)
+        self.alt_count_loss_func = nn.MSELoss(reduction="none")
+        self.source_predictor = M.Adversarial(M.MLP([e] + [1], params.batch_normalize, params.dropout_p), 0.01)
+        self.num_sources = 1
+
+        self.to(device=self._device, dtype=self._dtype)
+        self._engine: Optional[ReadSetEngine] = None
+
+    # ---- engine ---------------------------------------------------------------------------------------------------
+    def engine(self) -> ReadSetEngine:
+        """Flattens the parameters into one buffer and lowers the model to the device descriptor (once)."""
+        if self._engine is None:
+            self._engine = ReadSetEngine(self, self._device)
+        return self._engine
+
+    def _invalidate_engine(self):
+        self._engine = None
+
+    def reset_source_predictor(self, num_sources: int = 1):
+        hidden = [] if num_sources == 1 else [-1, -1]
+        layers = [self.reducer.output_dimension()] + hidden + [num_sources]
+        self.source_predictor = M.Adversarial(
+            M.MLP(layers, self._params.batch_normalize, self._params.dropout_p), 0.01
+        ).to(device=self._device, dtype=self._dtype)
+        self.num_sources = num_sources
+        self._invalidate_engine()  # new leaves: the flat parameter space is rebuilt on next use
+
+    def ref_alt_seq_embedding_dimension(self) -> int:
+        return self.haplotypes_cnn.output_dimension()
+
+    def haplotypes_length(self) -> int:
+        return self._haplotypes_length
+
+    def calibration_parameters(self):
+        fc = self.feature_clustering
+        return [fc.parametrizations.nonartifact_stdev_e.original, fc.parametrizations.artifact_stdev_k.original]
+
+    def set_epoch_type(self, epoch_type: Epoch):
+        train = epoch_type == Epoch.TRAIN
+        self.train(train)
+        for p in self.parameters():
+            p.requires_grad_(train)
+
+    def forward(self, batch: Batch):
+        pass
+
+    # ---- forward ------------------------------------------------------------------------------------------------------
+    def variant_embedding(self, batch: Batch) -> Tensor:
+        """[B, E_info + E_hap]: the per-variant part of every read's input (reference artifact_model.py:244-246)."""
+        info = self.info_embedding(batch.get_info_be().to(dtype=self._dtype))
+        hap = self.haplotypes_cnn(batch.get_one_hot_haplotypes_bcs().to(dtype=self._dtype))
+        return torch.hstack((info, hap))
+
+    def _encode(self, batch: Batch):
+        eng = self.engine()
+        variant_embed = self.variant_embedding(batch)
+        phi = eng.plan.materialize_phi(self)
+        outs = ReadSetFunction.apply(eng, batch, phi, variant_embed)
+        return outs, variant_embed
+
+    def calculate_features(self, batch: Batch, weight_range: float = 0):
+        (logits_b, logits_bk, feats, ref_feats), ve = self._encode(batch)
+        e_hap = self.haplotypes_cnn.output_dimension()
+        return (SetMeansView(ref_feats, batch.get(Data.REF_COUNT)), SetMeansView(feats, batch.get(Data.ALT_COUNT)),
+                ve[:, ve.shape[1] - e_hap:])
+
+    def compute_batch_output(self, batch: Batch, balancer=None) -> BatchOutput:
+        (logits_b, logits_bk, feats, ref_feats), _ = self._encode(batch)
+        if balancer is None:
+            weights_b, source_weights_b = torch.ones_like(logits_b), torch.ones_like(logits_b)
+        else:
+            weights_b, source_weights_b = balancer.process_batch_and_compute_weights(
+                batch, artifact_probs_b=torch.sigmoid(logits_b).detach())
+        return BatchOutput(features_be=feats, ref_features_be=ref_feats, logits_b=logits_b, logits_bk=logits_bk,
+                           weights=weights_b, source_weights=weights_b * source_weights_b)
+
+    # ---- losses (reference artifact_model.py:267-325) --------------------------------------------------------------------
+    def compute_source_prediction_losses(self, features_be: Tensor, batch: Batch) -> Tensor:
+        if self.num_sources > 1:
+            logits = self.source_predictor.adversarial_forward(features_be)
+            probs = torch.softmax(logits, dim=-1)
+            targets = torch.nn.functional.one_hot(batch.get(Data.SOURCE).long(), self.num_sources)
+            return torch.sum(torch.square(probs - targets), dim=-1)
+        return torch.zeros(batch.size(), device=self._device, dtype=self._dtype)
+
+    def compute_alt_count_losses(self, features_be: Tensor, batch: Batch) -> Tensor:
+        pred = torch.sigmoid(self.alt_count_predictor.adversarial_forward(features_be).view(-1))
+        target = batch.get(Data.ALT_COUNT).to(dtype=pred.dtype) / constants.MAX_ALT_COUNT
+        return self.alt_count_loss_func(pred, target)
+
+    def compute_batch_losses(self, output: BatchOutput, batch: Batch) -> BatchLosses:
+        labels_b = batch.get_training_labels()
+        is_labeled_b = batch.get_is_labeled_mask()
+        supervised = is_labeled_b * _BCE(output.logits_b, labels_b)
+        clipped = torch.clip(output.outlier_binary_logits, max=constants.MAX_OUTLIER_LOGIT)
+        unsupervised = (1 - is_labeled_b) * _BCE(clipped, torch.zeros_like(clipped))
+        alt_count = self.compute_alt_count_losses(output.features_be, batch)
+        source = self.compute_source_prediction_losses(output.features_be, batch)
+        total = output.weights * (supervised + unsupervised + alt_count) + output.source_weights * source
+        return BatchLosses(supervised, unsupervised, alt_count, source, total)
+
+    # ---- checkpoint format (reference artifact_model.py:327-369) ---------------------------------------------------------
+    def make_dict_for_saving(self, artifact_log_priors=None, artifact_spectra=None):
+        # clone: the live tensors are views into one flat buffer and torch.save would serialise the whole storage
+        state = {k: v.detach().clone() for k, v in self.state_dict().items()}
+        return {
+            constants.STATE_DICT_NAME: state,
+            constants.HYPERPARAMS_NAME: self._params,
+            constants.NUM_READ_FEATURES_NAME: self.read_embedding.input_dimension(),
+            constants.NUM_INFO_FEATURES_NAME: self.info_embedding.input_dimension(),
+            constants.REF_SEQUENCE_LENGTH_NAME: self.haplotypes_length(),
+            constants.ARTIFACT_LOG_PRIORS_NAME: artifact_log_priors,
+            constants.ARTIFACT_SPECTRA_STATE_DICT_NAME: None if artifact_spectra is None else artifact_spectra.state_dict(),
+        }
+
+    def save_model(self, path, artifact_log_priors=None, artifact_spectra=None):
+        self.reset_source_predictor()
+        install_pickle_alias()
+        torch.save(self.make_dict_for_saving(artifact_log_priors, artifact_spectra), path)
+
+
+def load_model(path, device: torch.device = None):
+    if device is None:
+        device = gpu_if_available()
+    install_pickle_alias()
+    saved = torch.load(path, map_location=device, weights_only=False)
+    model = ArtifactModel(saved[constants.HYPERPARAMS_NAME], num_read_features=saved[constants.NUM_READ_FEATURES_NAME],
+                          num_info_features=saved[constants.NUM_INFO_FEATURES_NAME],
+                          haplotypes_length=saved[constants.REF_SEQUENCE_LENGTH_NAME], device=device)
+    model.load_state_dict(saved[constants.STATE_DICT_NAME])
+    model.to(model._dtype)
+    return model, saved[constants.ARTIFACT_LOG_PRIORS_NAME], saved[constants.ARTIFACT_SPECTRA_STATE_DICT_NAME]

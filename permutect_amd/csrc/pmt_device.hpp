@@ -1,0 +1,229 @@
+// Device-side building blocks shared by the forward and backward read-set kernels (gfx950 / CDNA4 only).
+//
+// Data layout in registers ("tile-position layout")
+// -------------------------------------------------
+// A wave owns up to PMT_RT tiles of 16 reads.  An activation of width d (<= 64) for one tile is NT = 4 float4
+// registers per lane.  With lane = 16*g + r (r = read within the tile, g = lane group 0..3), register [t][j] holds
+//        feature f = 16*t + 4*j + g          of read r.
+// This is exactly the C/D layout of v_mfma_f32_16x16x4_f32 when features are the M (row) dimension and reads the
+// N (column) dimension  (C: col = lane & 15, row = 4*(lane >> 4) + reg), with the rows of each 16-row tile
+// permuted so that k-step j of a following MFMA contracts features {16t + 4j + g : g = 0..3}.  A layer output is
+// therefore directly the B operand of the next layer: activations never leave registers between layers.
+// Weights are pre-packed (pmt_pack.hip) into A-fragment order with the same permutation:
+//        frag[((mt * nkt + kt) * 64 + lane) * 4 + j] = W[16*mt + 4*(m & 3) + (m >> 2)][16*kt + 4*j + g],  m = lane & 15
+// so one 16-byte load per lane (1 KiB per wave, fully coalesced) feeds four MFMAs per read tile.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "permutect_amd.h"
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+#define PMT_NT 4                 // feature tiles per activation (PMT_MAX_WIDTH / 16)
+#define PMT_RT 2                 // read tiles per wave
+#define PMT_THREADS (PMT_GROUP_WAVES * 64)
+
+#define PMT_SELU_ALPHA 1.6732632423543772848170429916717f
+#define PMT_SELU_SCALE 1.0507009873554804934193349852946f
+#define PMT_LN_EPS 1e-5f
+#define PMT_LOG2PI 1.8378770664093453f
+#define PMT_MAX_LOGIT_F 20.0f
+
+static_assert(PMT_GROUP_TILES == PMT_GROUP_WAVES * PMT_RT, "group capacity");
+
+#define DEV __device__ __forceinline__
+
+DEV float uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// sum over the 4 lane groups (lanes r, r+16, r+32, r+48): completes a per-read reduction over features
+DEV float group_sum(float v) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+DEV f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+DEV float selu1(float x) {
+    // scale * (x > 0 ? x : alpha * (exp(x) - 1)); torch evaluates the negative branch as expm1(x) * (alpha*scale)
+    float neg = (PMT_SELU_ALPHA * PMT_SELU_SCALE) * expm1f(x);
+    return x > 0.f ? PMT_SELU_SCALE * x : neg;
+}
+DEV f4 selu4(f4 v) { return f4{selu1(v[0]), selu1(v[1]), selu1(v[2]), selu1(v[3])}; }
+
+// d selu(a) / da expressed through the OUTPUT s = selu(a):  s > 0 ? scale : s + alpha*scale
+DEV float selu_grad_from_out(float s) { return s > 0.f ? PMT_SELU_SCALE : s + PMT_SELU_ALPHA * PMT_SELU_SCALE; }
+
+// feature index held by register j of tile t for this lane's group g
+DEV int feat_of(int t, int j, int g) { return 16 * t + 4 * j + g; }
+
+// load a tile-position vector ("pvec"): 4 consecutive floats for (tile t, group g)
+DEV f4 load_pvec(const float* __restrict__ p, int t, int g) { return *reinterpret_cast<const f4*>(p + 16 * t + 4 * g); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// acc[rt][mt] += sum_k W[m][k] * in[rt][k]   for the tiles selected by tile_mask (wave-uniform).
+// `frag` = packed A fragments of W ([out_dim][in_dim]).  SELU_IN applies SELU to the input on the fly.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NTI, int NTO, bool SELU_IN>
+DEV void linear_acc(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], const float* __restrict__ frag, int in_dim,
+                    int out_dim, unsigned tile_mask, float in_scale = 1.0f) {
+    const int nkt = (in_dim + 15) >> 4, nmt = (out_dim + 15) >> 4;
+    const f4* __restrict__ fp = reinterpret_cast<const f4*>(frag) + (threadIdx.x & 63);
+#pragma unroll
+    for (int kt = 0; kt < NTI; ++kt) {
+        if (kt < nkt) {
+            const int ksteps = min(4, (in_dim - 16 * kt + 3) >> 2);
+            f4 b[PMT_RT];
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt) b[rt] = SELU_IN ? selu4(in[rt][kt]) * in_scale : in[rt][kt];
+#pragma unroll
+            for (int mt = 0; mt < NTO; ++mt) {
+                if (mt < nmt) {
+                    const f4 a = fp[(mt * nkt + kt) * 64];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (j < ksteps) {
+#pragma unroll
+                            for (int rt = 0; rt < PMT_RT; ++rt)
+                                if (tile_mask & (1u << rt)) acc[rt][mt] = mfma16(a[j], b[rt][j], acc[rt][mt]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// acc[rt][mt] = bias (tile-position order) for every tile; rows beyond out_dim are zero in the packed bias
+template <int NTO>
+DEV void init_bias(f4 (&acc)[PMT_RT][NTO], const float* __restrict__ bias_pvec, int out_dim, int g) {
+    const int nmt = (out_dim + 15) >> 4;
+#pragma unroll
+    for (int mt = 0; mt < NTO; ++mt) {
+        f4 b = f4{0.f, 0.f, 0.f, 0.f};
+        if (bias_pvec != nullptr && mt < nmt) b = load_pvec(bias_pvec, mt, g);
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt) acc[rt][mt] = b;
+    }
+}
+
+// LayerNorm over the feature axis of one read tile.  Returns the normalised value BEFORE the affine in `xhat`
+// (needed by the backward pass) and y = xhat * w + b.  Positions >= dim produce 0.
+template <int NT>
+DEV void layernorm_tile(f4 (&y)[NT], f4 (&xhat)[NT], float& rstd, const f4 (&x)[NT], int dim, const f4 (&w)[NT],
+                        const f4 (&b)[NT], int g) {
+    const int nt = (dim + 15) >> 4;
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        if (t < nt) s += (x[t][0] + x[t][1]) + (x[t][2] + x[t][3]);
+    const float mean = group_sum(s) / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = (t < nt && feat_of(t, j, g) < dim) ? x[t][j] - mean : 0.f;
+            xhat[t][j] = d;
+            q += d * d;
+        }
+    }
+    rstd = rsqrtf(group_sum(q) / (float)dim + PMT_LN_EPS);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        xhat[t] = xhat[t] * rstd;
+        y[t] = xhat[t] * w[t] + b[t];
+    }
+}
+
+// ---- model-descriptor access helpers (all wave-uniform scalar loads) -------------------------------------------
+DEV const float* src_ptr(int src, const float* theta, const float* phi) {
+    // >= 0: theta offset; <= -2: phi offset -(src + 2)
+    return src >= 0 ? theta + src : phi + (-(src + 2));
+}
+DEV float* grad_ptr(int src, float* gtheta, float* gphi) { return src >= 0 ? gtheta + src : gphi + (-(src + 2)); }
+
+// ---- stash layout (floats per 16-read tile) ---------------------------------------------------------------------
+// slots: [read-MLP op boundaries 1..n-1][x_0 .. x_L][reducer op boundaries 1..n-1], each slot NT*256 floats
+DEV int stash_num_slots(const PmtModel* M) { return (M->read_mlp.n_ops - 1) + (M->num_blocks + 1) + (M->reducer.n_ops - 1); }
+#define PMT_SLOT_FLOATS (PMT_NT * 256)
+
+template <int NT>
+DEV void stash_store(float* __restrict__ base, const f4 (&v)[NT]) {
+    f4* p = reinterpret_cast<f4*>(base) + (threadIdx.x & 63);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) p[t * 64] = v[t];
+}
+template <int NT>
+DEV void stash_load(const float* __restrict__ base, f4 (&v)[NT]) {
+    const f4* p = reinterpret_cast<const f4*>(base) + (threadIdx.x & 63);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) v[t] = p[t * 64];
+}
+
+// ---- group geometry ----------------------------------------------------------------------------------------------
+struct GroupGeom {
+    int v0, nsets;           // first variant, number of sets
+    int ref_base, nref;      // first ref row (in the ref region) and ref rows of the group
+    int alt_base, nalt;      // first alt row (absolute row = total_ref + alt_base) and alt rows
+    int total_ref;
+    int tiles_ref, tiles_alt, ntiles;
+    int tile_begin, tile_count;  // this wave's contiguous tile range
+};
+
+DEV GroupGeom group_geometry(const PmtBatch& bt, int group) {
+    GroupGeom gg;
+    gg.v0 = bt.group_start[group];
+    const int v1 = bt.group_start[group + 1];
+    gg.nsets = v1 - gg.v0;
+    gg.ref_base = bt.ref_offsets[gg.v0];
+    gg.nref = bt.ref_offsets[v1] - gg.ref_base;
+    gg.alt_base = bt.alt_offsets[gg.v0];
+    gg.nalt = bt.alt_offsets[v1] - gg.alt_base;
+    gg.total_ref = bt.ref_offsets[bt.num_variants];
+    gg.tiles_ref = (gg.nref + 15) >> 4;
+    gg.tiles_alt = (gg.nalt + 15) >> 4;
+    gg.ntiles = gg.tiles_ref + gg.tiles_alt;
+    const int wave = uniform((int)(threadIdx.x >> 6));
+    const int q = gg.ntiles / PMT_GROUP_WAVES, rem = gg.ntiles % PMT_GROUP_WAVES;
+    gg.tile_begin = wave * q + min(wave, rem);
+    gg.tile_count = q + (wave < rem ? 1 : 0);
+    return gg;
+}
+
+// per-tile metadata for this lane
+struct TileMeta {
+    int side;       // 0 = ref, 1 = alt (wave-uniform), -1 = tile not present
+    int row;        // global row in the batch's read order (before the optional gather), -1 = padding lane
+    int set;        // local set index within the group (0 if padding)
+    bool valid;
+};
+
+// s_off: LDS array [2][PMT_GROUP_MAX_SETS + 1] of group-local exclusive offsets per side
+DEV TileMeta tile_meta(const GroupGeom& gg, int rt, const int* s_off) {
+    TileMeta tm;
+    const int r = threadIdx.x & 15;
+    if (rt >= gg.tile_count) {
+        tm.side = -1; tm.row = -1; tm.set = 0; tm.valid = false;
+        return tm;
+    }
+    const int tau = gg.tile_begin + rt;
+    tm.side = tau < gg.tiles_ref ? 0 : 1;
+    const int local = (tm.side == 0 ? tau : tau - gg.tiles_ref) * 16 + r;
+    const int n_side = tm.side == 0 ? gg.nref : gg.nalt;
+    tm.valid = local < n_side;
+    tm.row = tm.valid ? (tm.side == 0 ? gg.ref_base + local : gg.total_ref + gg.alt_base + local) : -1;
+    // binary search: largest s with off[s] <= local
+    const int* off = s_off + tm.side * (PMT_GROUP_MAX_SETS + 1);
+    int lo = 0, hi = gg.nsets;  // invariant off[lo] <= local < off[hi] (for valid lanes)
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (off[mid] <= local) lo = mid; else hi = mid;
+    }
+    tm.set = tm.valid ? lo : 0;
+    return tm;
+}
+
+extern "C" int pmt_stash_slots(const PmtModel* m);  // host helper (pmt_host.hip)

@@ -1,0 +1,457 @@
+// Fused read-set forward for gfx950: one workgroup (8 waves) owns a group of whole read sets; activations stay in
+// registers from the packed input bytes to the per-set outputs.  See pmt_device.hpp for the register layout.
+//
+// Replaces (reference paths): data/batch.py:51-56 (decode), architecture/mlp.py:75-76, artifact_model.py:243-263,
+// gated_mlp.py:177-251, sets/ragged_sets.py:144-158, euclidean_transformation.py:19-20,
+// feature_clustering.py:82-135, exponentially_modified_gaussian.py:30-89, artifact_model.py:291-292.
+#include "pmt_device.hpp"
+
+struct FwdShared {
+    int off[2][PMT_GROUP_MAX_SETS + 1];
+    float zsum[3][PMT_GROUP_MAX_SETS][2][16];
+    float fsum[PMT_GROUP_MAX_SETS][2][PMT_MAX_WIDTH];
+    float hsum[PMT_GROUP_MAX_SETS][PMT_MAX_CLUSTERS + 2];
+};
+
+// ---- input decode ------------------------------------------------------------------------------------------------
+// value of read feature f for the row at `row` (reference data/batch.py:51-56; uint8 wrap quirk of
+// data/plain_text_data.py:510-511: (u - 128) / 32 evaluated in uint8).
+DEV float read_feature(const unsigned char* __restrict__ row, int fmt, int f, int F) {
+    if (f >= F) return 0.f;
+    if (fmt == PMT_READS_PACKED_U8) {
+        if (f < 56) return (float)((row[f >> 3] >> (7 - (f & 7))) & 1);
+        const unsigned u = row[7 + (f - 56)];
+        return (float)((u + 128u) & 0xFFu) * (1.0f / 32.0f);
+    } else if (fmt == PMT_READS_F16) {
+        return (float)reinterpret_cast<const _Float16*>(row)[f];
+    } else {
+        return reinterpret_cast<const float*>(row)[f];
+    }
+}
+
+// ---- MLP program interpreter (reference architecture/mlp.py) ------------------------------------------------------
+// x (in place): in_dim -> out_dim.  When stash != nullptr the INPUT of every op with index >= first_stashed_op is
+// written to consecutive slots starting at *slot.
+template <bool TRAIN>
+DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_RT][PMT_NT],
+                 const float* __restrict__ packed, const float* __restrict__ theta, int g, unsigned tile_mask,
+                 float* const (&stash_tile)[PMT_RT], int& slot, int first_stashed_op) {
+    const int n_ops = uniform(mlp.n_ops);
+    for (int op = 0; op < n_ops; ++op) {
+        const PmtOp& o = mlp.ops[op];
+        if (TRAIN && op >= first_stashed_op) {
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt)
+                if (tile_mask & (1u << rt)) stash_store<PMT_NT>(stash_tile[rt] + slot * PMT_SLOT_FLOATS, x[rt]);
+            ++slot;
+        }
+        f4 y[PMT_RT][PMT_NT];
+        if (uniform(o.kind) == PMT_OP_LINEAR) {
+            const PmtLinear& L = M->lin[uniform(o.lin[0])];
+            const int b_pvec = uniform(L.b_pvec);
+            init_bias<PMT_NT>(y, b_pvec >= 0 ? packed + b_pvec : nullptr, uniform(L.out_dim), g);
+            linear_acc<PMT_NT, PMT_NT, false>(y, x, packed + uniform(L.w_frag), uniform(L.in_dim), uniform(L.out_dim), tile_mask);
+            const bool act = uniform(o.selu_after) != 0;
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                for (int t = 0; t < PMT_NT; ++t) x[rt][t] = act ? selu4(y[rt][t]) : y[rt][t];
+        } else {
+            // x + alpha * f(x) with one or two (SELU, Linear) layers.  Only two register arrays are live: the last
+            // layer accumulates straight into x, with alpha folded into its B operand and bias.
+            const int nl = uniform(o.n_layers);
+            const int width = uniform(M->lin[uniform(o.lin[0])].in_dim);
+            if (nl == 1) {
+#pragma unroll
+                for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                    for (int t = 0; t < PMT_NT; ++t) y[rt][t] = x[rt][t];
+            } else {
+                const PmtLinear& L1 = M->lin[uniform(o.lin[0])];
+                init_bias<PMT_NT>(y, packed + uniform(L1.b_pvec), width, g);
+                linear_acc<PMT_NT, PMT_NT, true>(y, x, packed + uniform(L1.w_frag), width, width, tile_mask);
+            }
+            const PmtLinear& L2 = M->lin[uniform(o.lin[nl - 1])];
+            const float alpha = uniform(theta[uniform(o.alpha_src)]);
+            const int nmt = (width + 15) >> 4;
+#pragma unroll
+            for (int t = 0; t < PMT_NT; ++t) {
+                if (t < nmt) {
+                    const f4 b = alpha * load_pvec(packed + uniform(L2.b_pvec), t, g);
+#pragma unroll
+                    for (int rt = 0; rt < PMT_RT; ++rt) x[rt][t] = x[rt][t] + b;
+                }
+            }
+            linear_acc<PMT_NT, PMT_NT, true>(x, y, packed + uniform(L2.w_frag), width, width, tile_mask, alpha);
+        }
+    }
+}
+
+// log erfc with the asymptotic branch for z > 5 (reference exponentially_modified_gaussian.py:30-55)
+DEV float logerfc_dev(float z) {
+    const float zc = fmaxf(z, 2.f);
+    const float z2 = zc * zc, z4 = z2 * z2, z6 = z2 * z4;
+    const float asym = -z2 - logf(zc * 1.7724538509055159f) + log1pf(-1.f / (2.f * z2) + 3.f / (4.f * z4) - 15.f / (8.f * z6));
+    const float builtin = logf(fmaxf(erfcf(z), 1.0e-12f));
+    return z > 5.f ? asym : builtin;
+}
+
+template <bool TRAIN>
+__global__ __launch_bounds__(PMT_THREADS, 2) void pmt_forward_kernel(const PmtModel* __restrict__ M,
+                                                                      const float* __restrict__ theta,
+                                                                      const float* __restrict__ phi,
+                                                                      const float* __restrict__ packed, PmtBatch bt,
+                                                                      PmtOutputs out, float* __restrict__ stash,
+                                                                      float* __restrict__ zsum_stash) {
+    __shared__ __attribute__((aligned(16))) FwdShared sh;
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+    const GroupGeom gg = group_geometry(bt, blockIdx.x);
+
+    const int D = uniform(M->d_model), E = uniform(M->feature_dim), K = uniform(M->num_clusters);
+    const int Er = uniform(M->read_embed_dim), Ev = uniform(M->variant_embed_dim);
+    const int h = uniform(M->d_ffn) >> 1, L = uniform(M->num_blocks), F = uniform(M->num_read_features);
+
+    // ---- group setup: local offsets, zero the per-set accumulators -------------------------------------------
+    for (int i = tid; i <= gg.nsets; i += PMT_THREADS) {
+        sh.off[0][i] = bt.ref_offsets[gg.v0 + i] - gg.ref_base;
+        sh.off[1][i] = bt.alt_offsets[gg.v0 + i] - gg.alt_base;
+    }
+    for (int i = tid; i < 3 * PMT_GROUP_MAX_SETS * 32; i += PMT_THREADS) (&sh.zsum[0][0][0][0])[i] = 0.f;
+    for (int i = tid; i < PMT_GROUP_MAX_SETS * 2 * PMT_MAX_WIDTH; i += PMT_THREADS) (&sh.fsum[0][0][0])[i] = 0.f;
+    for (int i = tid; i < PMT_GROUP_MAX_SETS * (PMT_MAX_CLUSTERS + 2); i += PMT_THREADS) (&sh.hsum[0][0])[i] = 0.f;
+    __syncthreads();
+
+    TileMeta tm[PMT_RT];
+    unsigned mask_all = 0, mask_side[2] = {0, 0};
+    float* stash_tile[PMT_RT];
+#pragma unroll
+    for (int rt = 0; rt < PMT_RT; ++rt) {
+        tm[rt] = tile_meta(gg, rt, &sh.off[0][0]);
+        if (tm[rt].side >= 0) {
+            mask_all |= 1u << rt;
+            if (tm[rt].side == 0) mask_side[0] |= 1u << rt; else mask_side[1] |= 1u << rt;
+        }
+        stash_tile[rt] = nullptr;
+        if (TRAIN)
+            stash_tile[rt] = stash + (size_t)(bt.group_tile_base[blockIdx.x] + gg.tile_begin + rt) * (size_t)(stash_num_slots(M) * PMT_SLOT_FLOATS);
+    }
+
+    // ---- decode the packed read rows straight into the B-operand layout -----------------------------------------
+    f4 x[PMT_RT][PMT_NT];
+    {
+        const int fmt = bt.read_format;
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt) {
+            const unsigned char* rowp = nullptr;
+            if (tm[rt].valid) {
+                const long long src = bt.read_index ? bt.read_index[tm[rt].row] : (long long)tm[rt].row;
+                rowp = reinterpret_cast<const unsigned char*>(bt.reads) + (size_t)src * (size_t)bt.read_row_bytes;
+            }
+#pragma unroll
+            for (int t = 0; t < PMT_NT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[rt][t][j] = rowp ? read_feature(rowp, fmt, feat_of(t, j, g), F) : 0.f;
+        }
+    }
+
+    int slot = 0;
+    run_mlp<TRAIN>(M, M->read_mlp, x, packed, theta, g, mask_all, stash_tile, slot, 1);
+
+    // ---- broadcast-concat of the per-variant embedding (reference artifact_model.py:246-251) --------------------
+#pragma unroll
+    for (int rt = 0; rt < PMT_RT; ++rt) {
+        const float* vrow = bt.variant_embed + (size_t)(gg.v0 + tm[rt].set) * (size_t)Ev;
+#pragma unroll
+        for (int t = 0; t < PMT_NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int f = feat_of(t, j, g);
+                if (tm[rt].side >= 0 && f >= Er && f < D) x[rt][t][j] = vrow[f - Er];
+            }
+    }
+
+    // ---- L gated ref/alt blocks ---------------------------------------------------------------------------------
+    for (int l = 0; l < L; ++l) {
+        const PmtBlock& B = M->blocks[l];
+        if (TRAIN) {
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt)
+                if (mask_all & (1u << rt)) stash_store<PMT_NT>(stash_tile[rt] + slot * PMT_SLOT_FLOATS, x[rt]);
+            ++slot;
+        }
+        f4 z[PMT_RT][2];
+        {
+            f4 lw[PMT_NT], lb[PMT_NT];
+#pragma unroll
+            for (int t = 0; t < PMT_NT; ++t) {
+                lw[t] = load_pvec(packed + uniform(B.norm_w_pvec), t, g);
+                lb[t] = load_pvec(packed + uniform(B.norm_b_pvec), t, g);
+            }
+            f4 n[PMT_RT][PMT_NT];
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt) {
+                f4 xhat[PMT_NT];
+                float rstd;
+                layernorm_tile<PMT_NT>(n[rt], xhat, rstd, x[rt], D, lw, lb, g);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (mask_side[s]) {
+                    const PmtLinear& P1 = M->lin[uniform(B.proj1[s])];
+                    const f4 b0 = load_pvec(packed + uniform(P1.b_pvec), 0, g), b1 = load_pvec(packed + uniform(P1.b_pvec), 1, g);
+#pragma unroll
+                    for (int rt = 0; rt < PMT_RT; ++rt)
+                        if (mask_side[s] & (1u << rt)) { z[rt][0] = b0; z[rt][1] = b1; }
+                    linear_acc<PMT_NT, 2, false>(z, n, packed + uniform(P1.w_frag), D, 16 + h, mask_side[s]);
+                }
+            }
+        }
+        // SELU, LayerNorm(h) on z2, per-set sums (reference gated_mlp.py:228-239)
+        const int buf = l % 3;
+        {
+            f4 sw[1], sb[1];
+            sw[0] = load_pvec(packed + uniform(B.sgu_norm_w_pvec), 0, g);
+            sb[0] = load_pvec(packed + uniform(B.sgu_norm_b_pvec), 0, g);
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt) {
+                if (mask_all & (1u << rt)) {
+                    z[rt][0] = selu4(z[rt][0]);
+                    f4 zin[1] = {selu4(z[rt][1])}, zo[1], zh[1];
+                    float rstd;
+                    layernorm_tile<1>(zo, zh, rstd, zin, h, sw, sb, g);
+                    z[rt][1] = zo[0];
+                    if (tm[rt].valid) {
+                        float* dst = &sh.zsum[buf][tm[rt].set][tm[rt].side][4 * g];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (feat_of(0, j, g) < h) atomicAdd(dst + j, z[rt][1][j]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (TRAIN) {
+            for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS)
+                zsum_stash[((size_t)(gg.v0 + (i >> 5)) * L + l) * 32 + (i & 31)] = (&sh.zsum[buf][0][0][0])[i];
+        }
+        {
+            const int zb = (l + 2) % 3;
+            for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS) (&sh.zsum[zb][0][0][0])[i] = 0.f;
+        }
+        // gate and second projection with the residual as the accumulator input
+        {
+            const float w = uniform(phi[uniform(B.reg_weight_phi)]) + 0.25f;
+            const f4 rho = load_pvec(packed + uniform(B.ref_reg_pvec), 0, g);
+            const float alpha_ref = uniform(theta[uniform(B.alpha_src[0])]), alpha_alt = uniform(theta[uniform(B.alpha_src[1])]);
+            const float beta_ref = uniform(theta[uniform(B.beta_src[0])]), beta_alt = uniform(theta[uniform(B.beta_src[1])]);
+            const float gamma = uniform(theta[uniform(B.gamma_src)]);
+            f4 u[PMT_RT][1];
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt) {
+                u[rt][0] = f4{0.f, 0.f, 0.f, 0.f};
+                if (mask_all & (1u << rt)) {
+                    const int set = tm[rt].set, s = tm[rt].side;
+                    const float n_ref = (float)(sh.off[0][set + 1] - sh.off[0][set]);
+                    const float n_alt = (float)(sh.off[1][set + 1] - sh.off[1][set]);
+                    const f4 s_ref = *reinterpret_cast<const f4*>(&sh.zsum[buf][set][0][4 * g]);
+                    const f4 m_ref = (s_ref + w * rho) / (n_ref + w);
+                    f4 gate = z[rt][1] * (s == 0 ? alpha_ref : alpha_alt) + 1.0f;
+                    if (s == 0) {
+                        gate = gate + beta_ref * m_ref;
+                    } else {
+                        const f4 s_alt = *reinterpret_cast<const f4*>(&sh.zsum[buf][set][1][4 * g]);
+                        const f4 m_alt = s_alt / (n_alt + 1e-4f);
+                        gate = (gate + beta_alt * m_alt) + gamma * m_ref;
+                    }
+                    u[rt][0] = z[rt][0] * gate;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (mask_side[s]) {
+                    const PmtLinear& P2 = M->lin[uniform(B.proj2[s])];
+#pragma unroll
+                    for (int t = 0; t < PMT_NT; ++t) {
+                        const f4 b = load_pvec(packed + uniform(P2.b_pvec), t, g);
+#pragma unroll
+                        for (int rt = 0; rt < PMT_RT; ++rt)
+                            if (mask_side[s] & (1u << rt)) x[rt][t] = x[rt][t] + b;
+                    }
+                    linear_acc<1, PMT_NT, false>(x, u, packed + uniform(P2.w_frag), h, D, mask_side[s]);
+                }
+            }
+        }
+    }
+    if (TRAIN) {  // x_L, the reducer's input
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt)
+            if (mask_all & (1u << rt)) stash_store<PMT_NT>(stash_tile[rt] + slot * PMT_SLOT_FLOATS, x[rt]);
+        ++slot;
+    }
+
+    // ---- reducer MLP, then translation + rotation ----------------------------------------------------------------
+    run_mlp<TRAIN>(M, M->reducer, x, packed, theta, g, mask_all, stash_tile, slot, 1);
+    f4 a[PMT_RT][PMT_NT];
+    {
+        const PmtLinear& R = M->lin[uniform(M->rotation_lin)];
+#pragma unroll
+        for (int t = 0; t < PMT_NT; ++t) {
+            const f4 tr = load_pvec(packed + uniform(M->translation_pvec), t, g);
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt) {
+                x[rt][t] = x[rt][t] + tr;
+                a[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        linear_acc<PMT_NT, PMT_NT, false>(a, x, packed + uniform(R.w_frag), E, E, mask_all);
+    }
+
+    // ---- per-set feature sums (both sides) and the clustering head (alt reads) -------------------------------------
+    const int nte = (E + 15) >> 4;
+    {
+        const float* hp = phi;  // head parameters live in phi (materialised parametrizations), mu in theta
+        f4 sig[PMT_NT];
+        float sum_log_sig = 0.f, sum_log_2sig = 0.f;
+#pragma unroll
+        for (int t = 0; t < PMT_NT; ++t) {
+            sig[t] = f4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int f = feat_of(t, j, g);
+                if (t < nte && f < E) {
+                    sig[t][j] = hp[uniform(M->head.stdev_e_phi) + f];
+                    sum_log_sig += logf(sig[t][j]);
+                    sum_log_2sig += logf(2.f * sig[t][j]);
+                }
+            }
+        }
+        sum_log_sig = group_sum(sum_log_sig);
+        sum_log_2sig = group_sum(sum_log_2sig);
+        const float c0 = -(0.5f * (float)E) * PMT_LOG2PI - sum_log_sig;
+        const float c1 = -(0.5f * (float)E) * PMT_LOG2PI - sum_log_2sig;
+
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt) {
+            if (!(mask_all & (1u << rt))) continue;
+            const int set = tm[rt].set, s = tm[rt].side;
+            if (tm[rt].valid) {
+#pragma unroll
+                for (int t = 0; t < PMT_NT; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (t < nte && feat_of(t, j, g) < E) atomicAdd(&sh.fsum[set][s][16 * t + 4 * g + j], a[rt][t][j]);
+            }
+            if (s != 1) continue;
+            // nonartifact / outlier diagonal Gaussians
+            float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+            for (int t = 0; t < PMT_NT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (t < nte && feat_of(t, j, g) < E) {
+                        const float r0 = a[rt][t][j] / sig[t][j], r1 = a[rt][t][j] / (2.f * sig[t][j]);
+                        q0 += r0 * r0;
+                        q1 += r1 * r1;
+                    }
+            q0 = group_sum(q0);
+            q1 = group_sum(q1);
+            if (tm[rt].valid && g == 0) {
+                atomicAdd(&sh.hsum[set][0], c0 - 0.5f * q0);
+                atomicAdd(&sh.hsum[set][1], c1 - 0.5f * q1);
+            }
+            // artifact clusters: projection on the unit direction, orthogonal distance, EMG along the direction
+            for (int k = 0; k < K; ++k) {
+                const float* vk = hp + uniform(M->head.dirs_ke_phi) + k * E;
+                f4 v[PMT_NT];
+                float p = 0.f;
+#pragma unroll
+                for (int t = 0; t < PMT_NT; ++t) {
+                    v[t] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int f = feat_of(t, j, g);
+                        if (t < nte && f < E) {
+                            v[t][j] = vk[f];
+                            p += a[rt][t][j] * v[t][j];
+                        }
+                    }
+                }
+                p = group_sum(p);
+                float o2 = 0.f;
+#pragma unroll
+                for (int t = 0; t < PMT_NT; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (t < nte && feat_of(t, j, g) < E) {
+                            const float d = a[rt][t][j] - p * v[t][j];
+                            o2 += d * d;
+                        }
+                o2 = group_sum(o2);
+                if (tm[rt].valid && g == (k & 3)) {
+                    const float tau = uniform(hp[uniform(M->head.art_stdev_k_phi) + k]);
+                    const float mu = uniform(theta[uniform(M->head.mu_k_src) + k]);
+                    const float sg = uniform(hp[uniform(M->head.sigma_k_phi) + k]);
+                    const float lam = uniform(hp[uniform(M->head.lambda_k_phi) + k]);
+                    const float od = sqrtf(o2);
+                    const float orth = -(0.5f * (float)(E - 1)) * PMT_LOG2PI - (float)(E - 1) * logf(tau) - (od * od) / (2.f * (tau * tau));
+                    const float var = sg * sg;
+                    const float zz = (mu + lam * var - p) / (1.4142135623730951f * sg);
+                    const float par = logf(lam * 0.5f) + logerfc_dev(zz) + (lam * 0.5f) * (2.f * mu + lam * var - 2.f * p);
+                    atomicAdd(&sh.hsum[set][2 + k], orth + par);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- per-set finalisation (reference feature_clustering.py:121-135, ragged_sets.py:144-155) -----------------
+    for (int i = tid; i < gg.nsets; i += PMT_THREADS) {
+        const int b = gg.v0 + i;
+        float* lk = out.logits_bk + (size_t)b * (K + 2);
+        const float l0 = sh.hsum[i][0];
+        lk[0] = l0;
+        lk[1] = sh.hsum[i][1];
+        float mx = -INFINITY;
+        for (int k = 0; k < K; ++k) {
+            const float v = sh.hsum[i][2 + k] + phi[M->head.log_w_k_phi + k];
+            lk[2 + k] = v;
+            mx = fmaxf(mx, v);
+        }
+        float se = 0.f;
+        for (int k = 0; k < K; ++k) se += expf(lk[2 + k] - mx);
+        const float logit = (mx + logf(se)) - l0;
+        out.logits_b[b] = PMT_MAX_LOGIT_F * tanhf(logit / PMT_MAX_LOGIT_F);
+    }
+    for (int i = tid; i < gg.nsets * 2 * E; i += PMT_THREADS) {
+        const int set = i / (2 * E), rem = i - set * 2 * E, s = rem / E, f = rem - s * E;
+        const int pos = 16 * (f >> 4) + 4 * (f & 3) + ((f & 15) >> 2);
+        const float n = (float)(sh.off[s][set + 1] - sh.off[s][set]);
+        const float v = sh.fsum[set][s][pos] / (n + 1e-4f);
+        (s == 1 ? out.features_be : out.ref_features_be)[(size_t)(gg.v0 + set) * E + f] = v;
+    }
+}
+
+// ---- host launcher ---------------------------------------------------------------------------------------------------
+extern "C" int pmt_forward(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* phi,
+                           const float* packed, const PmtBatch* batch, const PmtOutputs* out, float* stash,
+                           void* stream) {
+    if (!model_host || !model_dev || !batch || !out) return PMT_E_INVALID;
+    const int rc = pmt_model_check(model_host);
+    if (rc != PMT_OK) return rc;
+    if (batch->num_groups <= 0) return batch->num_groups == 0 ? PMT_OK : PMT_E_INVALID;
+    if (!batch->reads || !batch->ref_offsets || !batch->alt_offsets || !batch->variant_embed || !batch->group_start ||
+        !out->logits_b || !out->logits_bk || !out->features_be || !out->ref_features_be)
+        return PMT_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (stash) {
+        if (!batch->group_tile_base || batch->total_tiles <= 0) return PMT_E_INVALID;
+        // per-set z2 sums follow the per-tile activation slots (layout: pmt_stash_bytes)
+        float* zsum_stash = stash + (size_t)batch->total_tiles * (size_t)pmt_stash_slots(model_host) * PMT_SLOT_FLOATS;
+        hipLaunchKernelGGL(pmt_forward_kernel<true>, dim3(batch->num_groups), dim3(PMT_THREADS), 0, s, model_dev, theta,
+                           phi, packed, *batch, *out, stash, zsum_stash);
+        return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(pmt_forward_kernel<false>, dim3(batch->num_groups), dim3(PMT_THREADS), 0, s, model_dev, theta, phi,
+                       packed, *batch, *out, (float*)nullptr, (float*)nullptr);
+    return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
+}

@@ -1,0 +1,357 @@
+// Host helpers of the C ABI plus the small utility kernels: parameter re-pack into MFMA fragment order, exclusive
+// scans of the per-variant read counts, fused global-norm clip + AdamW.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+
+#include "pmt_device.hpp"
+
+extern "C" int pmt_abi_version(void) { return PMT_ABI_VERSION; }
+
+extern "C" int pmt_struct_bytes(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(PmtModel);
+        case 1: return (int)sizeof(PmtBatch);
+        case 2: return (int)sizeof(PmtOutputs);
+        case 3: return (int)sizeof(PmtOutputGrads);
+        case 4: return (int)sizeof(PmtAdamW);
+        case 5: return (int)sizeof(PmtLinear);
+        case 6: return (int)sizeof(PmtOp);
+        case 7: return (int)sizeof(PmtMlp);
+        case 8: return (int)sizeof(PmtBlock);
+        case 9: return (int)sizeof(PmtHead);
+        default: return PMT_E_INVALID;
+    }
+}
+
+extern "C" int pmt_stash_slots(const PmtModel* m) { return (m->read_mlp.n_ops - 1) + (m->num_blocks + 1) + (m->reducer.n_ops - 1); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// descriptor validation
+// ---------------------------------------------------------------------------------------------------------------------
+static int check_linear(const PmtModel* m, int id, int in_dim, int out_dim) {
+    if (id < 0 || id >= m->n_linear) return PMT_E_INVALID;
+    const PmtLinear* l = &m->lin[id];
+    if (l->in_dim != in_dim || l->out_dim != out_dim) return PMT_E_INVALID;
+    if (in_dim < 1 || out_dim < 1 || in_dim > PMT_MAX_WIDTH || out_dim > PMT_MAX_WIDTH) return PMT_E_UNSUPPORTED;
+    if (l->w_frag < 0 || l->wt_frag < 0 || (l->w_frag & 3) || (l->wt_frag & 3)) return PMT_E_INVALID;
+    if (l->b_pvec >= 0 && (l->b_pvec & 3)) return PMT_E_INVALID;
+    return PMT_OK;
+}
+
+static int check_mlp(const PmtModel* m, const PmtMlp* mlp) {
+    if (mlp->n_ops < 1 || mlp->n_ops > PMT_MAX_OPS) return PMT_E_UNSUPPORTED;
+    int width = mlp->in_dim;
+    for (int i = 0; i < mlp->n_ops; ++i) {
+        const PmtOp* o = &mlp->ops[i];
+        if (o->kind == PMT_OP_LINEAR) {
+            if (o->lin[0] < 0 || o->lin[0] >= m->n_linear) return PMT_E_INVALID;
+            const int out = m->lin[o->lin[0]].out_dim;
+            const int rc = check_linear(m, o->lin[0], width, out);
+            if (rc) return rc;
+            width = out;
+        } else if (o->kind == PMT_OP_SKIP) {
+            if (o->n_layers < 1 || o->n_layers > 2) return PMT_E_UNSUPPORTED;  /* two live register arrays */
+            if (o->alpha_src < 0) return PMT_E_INVALID;
+            for (int k = 0; k < o->n_layers; ++k) {
+                const int rc = check_linear(m, o->lin[k], width, width);
+                if (rc) return rc;
+                if (m->lin[o->lin[k]].b_pvec < 0) return PMT_E_INVALID;
+            }
+        } else {
+            return PMT_E_INVALID;
+        }
+    }
+    return width == mlp->out_dim ? PMT_OK : PMT_E_INVALID;
+}
+
+extern "C" int pmt_model_check(const PmtModel* m) {
+    if (!m || m->abi_version != PMT_ABI_VERSION) return PMT_E_INVALID;
+    if (m->n_linear < 1 || m->n_linear > PMT_MAX_LINEAR) return PMT_E_UNSUPPORTED;
+    if (m->num_read_features < 1 || m->num_read_features > PMT_MAX_WIDTH) return PMT_E_UNSUPPORTED;
+    if (m->d_model != m->read_embed_dim + m->variant_embed_dim || m->d_model > PMT_MAX_WIDTH) return PMT_E_UNSUPPORTED;
+    if (m->d_ffn < 2 || (m->d_ffn & 1) || m->d_ffn / 2 > PMT_MAX_HALF_FFN) return PMT_E_UNSUPPORTED;
+    if (m->num_blocks < 0 || m->num_blocks > PMT_MAX_BLOCKS) return PMT_E_UNSUPPORTED;
+    if (m->feature_dim < 2 || m->feature_dim > PMT_MAX_WIDTH) return PMT_E_UNSUPPORTED;
+    if (m->num_clusters < 1 || m->num_clusters > PMT_MAX_CLUSTERS) return PMT_E_UNSUPPORTED;
+    if (m->read_mlp.in_dim != m->num_read_features || m->read_mlp.out_dim != m->read_embed_dim) return PMT_E_INVALID;
+    if (m->reducer.in_dim != m->d_model || m->reducer.out_dim != m->feature_dim) return PMT_E_INVALID;
+    int rc = check_mlp(m, &m->read_mlp);
+    if (rc) return rc;
+    rc = check_mlp(m, &m->reducer);
+    if (rc) return rc;
+    const int h = m->d_ffn / 2;
+    for (int l = 0; l < m->num_blocks; ++l) {
+        const PmtBlock* b = &m->blocks[l];
+        for (int s = 0; s < 2; ++s) {
+            if ((rc = check_linear(m, b->proj1[s], m->d_model, m->d_ffn))) return rc;
+            if (m->lin[b->proj1[s]].out_split != h || m->lin[b->proj1[s]].b_pvec < 0) return PMT_E_INVALID;
+            if ((rc = check_linear(m, b->proj2[s], h, m->d_model))) return rc;
+            if (m->lin[b->proj2[s]].b_pvec < 0) return PMT_E_INVALID;
+        }
+    }
+    if ((rc = check_linear(m, m->rotation_lin, m->feature_dim, m->feature_dim))) return rc;
+    return PMT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// group planning (host)
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int pmt_plan_groups(const int32_t* ref_counts, const int32_t* alt_counts, int32_t num_variants,
+                               int32_t* group_start, int32_t* group_tile_base, int32_t* bad_variant) {
+    if (!ref_counts || !alt_counts || !group_start || !group_tile_base || num_variants < 0) return PMT_E_INVALID;
+    int groups = 0;
+    long long ref = 0, alt = 0;
+    int sets = 0;
+    long long tile_base = 0;
+    group_start[0] = 0;
+    group_tile_base[0] = 0;
+    for (int b = 0; b < num_variants; ++b) {
+        const long long r = ref_counts[b], a = alt_counts[b];
+        if (r < 0 || a < 0) return PMT_E_INVALID;
+        if ((r + 15) / 16 + (a + 15) / 16 > PMT_GROUP_TILES) {
+            if (bad_variant) *bad_variant = b;
+            return PMT_E_CAPACITY;
+        }
+        const long long tiles_if_added = (ref + r + 15) / 16 + (alt + a + 15) / 16;
+        if (sets > 0 && (tiles_if_added > PMT_GROUP_TILES || sets + 1 > PMT_GROUP_MAX_SETS)) {
+            tile_base += (ref + 15) / 16 + (alt + 15) / 16;
+            ++groups;
+            group_start[groups] = b;
+            group_tile_base[groups] = (int32_t)tile_base;
+            ref = alt = 0;
+            sets = 0;
+        }
+        ref += r;
+        alt += a;
+        ++sets;
+    }
+    if (sets > 0) {
+        tile_base += (ref + 15) / 16 + (alt + 15) / 16;
+        ++groups;
+        group_start[groups] = num_variants;
+        group_tile_base[groups] = (int32_t)tile_base;
+    }
+    return groups;
+}
+
+extern "C" size_t pmt_stash_bytes(const PmtModel* m, int64_t total_tiles, int32_t num_variants) {
+    if (!m) return 0;
+    const size_t tile_part = (size_t)total_tiles * (size_t)pmt_stash_slots(m) * PMT_SLOT_FLOATS;
+    const size_t zsum_part = (size_t)num_variants * (size_t)(m->num_blocks > 0 ? m->num_blocks : 1) * 32;
+    return (tile_part + zsum_part) * sizeof(float);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// parameter re-pack: natural layouts (theta / phi) -> MFMA A-fragment order and tile-position vectors
+// ---------------------------------------------------------------------------------------------------------------------
+// virtual row -> source row for a linear whose output rows are split into two 16-row tiles (out_split = h)
+DEV int split_row(int v, int h) {
+    if (h <= 0) return v;
+    if (v < 16) return v < h ? v : -1;
+    return (v - 16) < h ? h + (v - 16) : -1;
+}
+
+// one job per workgroup: (lin, 0) forward frags, (lin, 1) transposed frags, (lin, 2) bias, then per-block vectors
+__global__ void pmt_pack_kernel(const PmtModel* __restrict__ M, const float* __restrict__ theta,
+                                const float* __restrict__ phi, float* __restrict__ packed) {
+    const int job = blockIdx.x;
+    const int n_lin_jobs = M->n_linear * 3;
+    if (job < n_lin_jobs) {
+        const PmtLinear& L = M->lin[job / 3];
+        const int kind = job % 3;
+        const int h = L.out_split;
+        const int out_v = h > 0 ? 16 + h : L.out_dim;  // virtual output rows
+        if (kind == 2) {
+            if (L.b_pvec < 0) return;
+            const float* b = src_ptr(L.b_src, theta, phi);
+            const int n = ((out_v + 15) >> 4) * 16;
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const int t = i >> 4, g = (i >> 2) & 3, j = i & 3;
+                const int v = 16 * t + 4 * j + g;
+                const int r = v < out_v ? split_row(v, h) : -1;
+                packed[L.b_pvec + i] = (r >= 0 && r < L.out_dim) ? b[r] : 0.f;
+            }
+            return;
+        }
+        const float* W = src_ptr(L.w_src, theta, phi);
+        // forward: A_v[m][k] = W[row(m)][k], Mv = out_v, Kv = in_dim; transposed: A_v[m][k] = W[row(k)][m]
+        const int Mv = kind == 0 ? out_v : L.in_dim, Kv = kind == 0 ? L.in_dim : out_v;
+        const int nmt = (Mv + 15) >> 4, nkt = (Kv + 15) >> 4;
+        float* dst = packed + (kind == 0 ? L.w_frag : L.wt_frag);
+        const int total = nmt * nkt * 256;
+        for (int i = threadIdx.x; i < total; i += blockDim.x) {
+            const int j = i & 3, lane = (i >> 2) & 63, tile = i >> 8;
+            const int kt = tile % nkt, mt = tile / nkt;
+            const int m = lane & 15, g = lane >> 4;
+            const int mv = 16 * mt + 4 * (m & 3) + (m >> 2);
+            const int kv = 16 * kt + 4 * j + g;
+            float val = 0.f;
+            if (mv < Mv && kv < Kv) {
+                const int orow = kind == 0 ? split_row(mv, h) : split_row(kv, h);
+                const int icol = kind == 0 ? kv : mv;
+                if (orow >= 0 && orow < L.out_dim && icol < L.in_dim) val = W[(size_t)orow * L.in_dim + icol];
+            }
+            dst[i] = val;
+        }
+        return;
+    }
+    int v = job - n_lin_jobs;  // vector jobs
+    int src = -1, dst = -1, n = 0;
+    if (v < M->num_blocks * 5) {
+        const PmtBlock& B = M->blocks[v / 5];
+        const int hh = M->d_ffn / 2;
+        switch (v % 5) {
+            case 0: src = B.norm_w_src; dst = B.norm_w_pvec; n = M->d_model; break;
+            case 1: src = B.norm_b_src; dst = B.norm_b_pvec; n = M->d_model; break;
+            case 2: src = B.sgu_norm_w_src; dst = B.sgu_norm_w_pvec; n = hh; break;
+            case 3: src = B.sgu_norm_b_src; dst = B.sgu_norm_b_pvec; n = hh; break;
+            default: src = B.ref_reg_src; dst = B.ref_reg_pvec; n = hh; break;
+        }
+    } else {
+        src = M->translation_src; dst = M->translation_pvec; n = M->feature_dim;
+    }
+    const int padded = ((n + 15) >> 4) * 16;
+    const float* s = src_ptr(src, theta, phi);
+    for (int i = threadIdx.x; i < padded; i += blockDim.x) {
+        const int t = i >> 4, g = (i >> 2) & 3, j = i & 3;
+        const int f = 16 * t + 4 * j + g;
+        packed[dst + i] = f < n ? s[f] : 0.f;
+    }
+}
+
+extern "C" int pmt_pack_params(const PmtModel* model_host, const PmtModel* model_dev, const float* theta,
+                               const float* phi, float* packed, void* stream) {
+    if (!model_host || !model_dev || !theta || !packed) return PMT_E_INVALID;
+    const int rc = pmt_model_check(model_host);
+    if (rc) return rc;
+    const int jobs = model_host->n_linear * 3 + model_host->num_blocks * 5 + 1;
+    hipLaunchKernelGGL(pmt_pack_kernel, dim3(jobs), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), model_dev, theta,
+                       phi, packed);
+    return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// exclusive scans of ref / alt counts: one 1024-thread workgroup per array walks it in 4096-element chunks
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(1024) void pmt_scan_kernel(const T* __restrict__ c0, const T* __restrict__ c1,
+                                                        long long stride, int n, int* __restrict__ o0,
+                                                        int* __restrict__ o1) {
+    const T* c = blockIdx.x == 0 ? c0 : c1;
+    int* o = blockIdx.x == 0 ? o0 : o1;
+    __shared__ int wave_tot[16];
+    __shared__ int carry_sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_sh = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 4096) {
+        int v[4], local = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = base + tid * 4 + k;
+            v[k] = i < n ? (int)c[(size_t)i * stride] : 0;
+            local += v[k];
+        }
+        int incl = local;  // inclusive scan of `local` across the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int wave_prefix = 0;
+        for (int w = 0; w < wave; ++w) wave_prefix += wave_tot[w];
+        int run = carry_sh + wave_prefix + incl - local;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = base + tid * 4 + k;
+            if (i < n) o[i] = run;
+            run += v[k];
+        }
+        __syncthreads();
+        if (tid == 1023) carry_sh = run;
+        __syncthreads();
+    }
+    if (tid == 0) o[n] = carry_sh;
+}
+
+extern "C" int pmt_scan_counts(const void* ref_counts, const void* alt_counts, int32_t count_elem_bytes,
+                               int64_t count_stride, int32_t num_variants, int32_t* ref_offsets, int32_t* alt_offsets,
+                               void* stream) {
+    if (!ref_counts || !alt_counts || !ref_offsets || !alt_offsets || num_variants < 0 || count_stride < 1) return PMT_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (count_elem_bytes == 4)
+        hipLaunchKernelGGL(pmt_scan_kernel<int32_t>, dim3(2), dim3(1024), 0, s, (const int32_t*)ref_counts,
+                           (const int32_t*)alt_counts, (long long)count_stride, num_variants, ref_offsets, alt_offsets);
+    else if (count_elem_bytes == 8)
+        hipLaunchKernelGGL(pmt_scan_kernel<int64_t>, dim3(2), dim3(1024), 0, s, (const int64_t*)ref_counts,
+                           (const int64_t*)alt_counts, (long long)count_stride, num_variants, ref_offsets, alt_offsets);
+    else
+        return PMT_E_INVALID;
+    return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fused clip_grad_norm_(max_norm) + AdamW over one flat buffer (reference misc_utils.py:128-129)
+// ---------------------------------------------------------------------------------------------------------------------
+#define PMT_OPT_BLOCKS 256
+__global__ __launch_bounds__(256) void pmt_sumsq_kernel(const float* __restrict__ g, long long n, float* __restrict__ partial) {
+    double acc = 0.0;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += 256ll * gridDim.x) acc += (double)g[i] * (double)g[i];
+    __shared__ double sh[256];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = (float)sh[0];
+}
+
+__global__ __launch_bounds__(256) void pmt_adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, long long n,
+                                                        PmtAdamW hp, const float* __restrict__ partial, int n_partial,
+                                                        float* __restrict__ norm_out) {
+    __shared__ double sh[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n_partial; i += 256) acc += (double)partial[i];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
+        __syncthreads();
+    }
+    const float total = (float)sqrt(sh[0]);
+    if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) *norm_out = total;
+    const float coef = hp.max_grad_norm > 0.f ? fminf(hp.max_grad_norm / (total + 1e-6f), 1.0f) : 1.0f;
+    const float bc1 = 1.f - powf(hp.beta1, (float)hp.step);
+    const float bc2_sqrt = sqrtf(1.f - powf(hp.beta2, (float)hp.step));
+    const float step_size = hp.lr / bc1;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += 256ll * gridDim.x) {
+        const float gi = g[i] * coef;
+        float pi = p[i] * (1.f - hp.lr * hp.weight_decay);
+        const float mi = hp.beta1 * m[i] + (1.f - hp.beta1) * gi;
+        const float vi = hp.beta2 * v[i] + (1.f - hp.beta2) * gi * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + hp.eps;
+        pi -= step_size * (mi / denom);
+        p[i] = pi;
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+extern "C" int pmt_clip_adamw(float* theta, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                              const PmtAdamW* hyper, float* scratch, float* grad_norm_out, void* stream) {
+    if (!theta || !grad || !exp_avg || !exp_avg_sq || !hyper || !scratch || n < 0 || hyper->step < 1) return PMT_E_INVALID;
+    if (n == 0) return PMT_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int blocks = (int)((n + 1023) / 1024);
+    if (blocks > PMT_OPT_BLOCKS) blocks = PMT_OPT_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(pmt_sumsq_kernel, dim3(blocks), dim3(256), 0, s, grad, (long long)n, scratch);
+    hipLaunchKernelGGL(pmt_adamw_kernel, dim3(blocks), dim3(256), 0, s, theta, grad, exp_avg, exp_avg_sq, (long long)n,
+                       *hyper, (const float*)scratch, blocks, grad_norm_out);
+    return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
+}

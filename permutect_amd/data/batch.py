@@ -1,0 +1,248 @@
+"""Batch / DownsampledBatch: the input contract of the hot path (reference permutect/data/batch.py:41-174, 383-459).
+
+Differences that matter on MI355X, none of which change results:
+  * compressed reads stay PACKED (uint8 [R, 7 + nf]) all the way into HBM; the HIP forward kernel decodes them in its
+    load stage (12 B/read over PCIe and HBM instead of 244 B/read as fp32).  `get_reads_re()` still returns the
+    reference's float16 view for callers that want it.
+  * the batch carries a host-side *group plan* (pmt_plan_groups) computed from the counts it already has on the host
+    at collate time, so the forward needs no device->host sync (the reference syncs twice per forward,
+    artifact_model.py:241 and sets/ragged_sets.py:37).
+The two reference quirks at this boundary are reproduced bit-exactly: the uint8 decode wrap
+(data/plain_text_data.py:510-511) and DownsampledBatch's un-offset alt gather (data/batch.py:436-439).
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+from random import randint
+from typing import List, Optional
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from permutect_amd.data.datum import Data, Datum, HAPLOTYPES_START_IDX, INFO_START_IDX, NUMBER_OF_BYTES_IN_PACKED_READ
+from permutect_amd.engine import lib as L
+from permutect_amd.enums import Label
+
+
+def decode_packed_reads(packed: np.ndarray) -> np.ndarray:
+    """uint8 [R, 7 + nf] -> float16 [R, 56 + nf] exactly as the reference collate does (including the uint8 wrap)."""
+    bits = np.unpackbits(packed[:, :NUMBER_OF_BYTES_IN_PACKED_READ], axis=1).astype(np.float16)
+    wrapped = (packed[:, NUMBER_OF_BYTES_IN_PACKED_READ:] - np.uint8(128)).astype(np.float32)  # uint8 arithmetic wraps
+    return np.hstack((bits, (wrapped / 32.0).astype(np.float16)))
+
+
+class GroupPlan:
+    """Partition of the batch's variants into register-resident groups (host arrays + device copies)."""
+
+    def __init__(self, ref_counts: np.ndarray, alt_counts: np.ndarray):
+        lib = L.load()
+        b = len(ref_counts)
+        rc = np.ascontiguousarray(ref_counts, dtype=np.int32)
+        ac = np.ascontiguousarray(alt_counts, dtype=np.int32)
+        gs = np.zeros(b + 1, dtype=np.int32)
+        gt = np.zeros(b + 1, dtype=np.int32)
+        bad = C.c_int32(-1)
+        n = lib.pmt_plan_groups(rc.ctypes.data, ac.ctypes.data, b, gs.ctypes.data, gt.ctypes.data, C.byref(bad))
+        if n == L.E_CAPACITY:
+            raise L.PmtError(
+                f"variant {bad.value} has {int(rc[bad.value])} ref / {int(ac[bad.value])} alt reads: more than the "
+                f"{L.GROUP_TILES * L.TILE}-read register-resident group capacity of the gfx950 kernels")
+        L.check(n, "pmt_plan_groups")
+        self.num_groups = n
+        self.group_start = gs[: n + 1].copy()
+        self.group_tile_base = gt[: n + 1].copy()
+        self.total_tiles = int(gt[n])
+        self._dev = {}
+
+    def on(self, device: torch.device):
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = (torch.from_numpy(self.group_start).to(device), torch.from_numpy(self.group_tile_base).to(device))
+        return self._dev[key]
+
+
+class Batch:
+    def __init__(self, data: List[Datum]):
+        ints = np.vstack([d.get_int_array() for d in data])
+        floats = np.vstack([d.get_float_array() for d in data])
+        reads = np.vstack([d.get_ref_reads_re() for d in data] + [d.get_alt_reads_re() for d in data])
+        self._init_from_arrays(ints, floats, reads)
+
+    @classmethod
+    def from_arrays(cls, int_array: np.ndarray, float_array: np.ndarray, reads: np.ndarray) -> "Batch":
+        """int_array [B, 16+H] (int16), float_array [B, 6+I] (float16), reads in batch order (all ref rows of all
+        variants, then all alt rows): uint8 [R, 7+nf] packed, or float16 [R, F]."""
+        self = cls.__new__(cls)
+        self._init_from_arrays(int_array, float_array, reads)
+        return self
+
+    def _init_from_arrays(self, ints: np.ndarray, floats: np.ndarray, reads: np.ndarray):
+        self.int_tensor = torch.from_numpy(np.ascontiguousarray(ints)).to(torch.long)
+        self.float_tensor = torch.from_numpy(np.ascontiguousarray(floats)).to(torch.float)
+        if reads.dtype == np.uint8:
+            self.packed_reads: Optional[Tensor] = torch.from_numpy(np.ascontiguousarray(reads))
+            self.reads_re: Optional[Tensor] = None
+            self._num_read_features = 8 * NUMBER_OF_BYTES_IN_PACKED_READ + reads.shape[1] - NUMBER_OF_BYTES_IN_PACKED_READ
+        else:
+            self.packed_reads = None
+            self.reads_re = torch.from_numpy(np.ascontiguousarray(reads))
+            self._num_read_features = reads.shape[1]
+        self._size = len(self.int_tensor)
+        ref = self.int_tensor[:, Data.REF_COUNT.idx].numpy()
+        alt = self.int_tensor[:, Data.ALT_COUNT.idx].numpy()
+        assert int(ref.sum() + alt.sum()) == reads.shape[0], "read rows do not match the counts"
+        self._host_counts = (ref.astype(np.int32), alt.astype(np.int32))
+        self._plan: Optional[GroupPlan] = None
+        self._offsets = None
+
+    # ---- reference accessors ---------------------------------------------------------------------------------------
+    def get(self, field: Data) -> Tensor:
+        return (self.int_tensor if field.kind == "int" else self.float_tensor)[:, field.idx]
+
+    def get_training_labels(self) -> Tensor:
+        labels = self.get(Data.LABEL)
+        return 1.0 * (labels == Label.ARTIFACT) + 0.5 * (labels == Label.UNLABELED)
+
+    def get_is_labeled_mask(self) -> Tensor:
+        return (self.get(Data.LABEL) != Label.UNLABELED).int()
+
+    def get_info_be(self) -> Tensor:
+        return self.float_tensor[:, INFO_START_IDX:]
+
+    def get_haplotypes_bs(self) -> Tensor:
+        return self.int_tensor[:, HAPLOTYPES_START_IDX:]
+
+    def get_one_hot_haplotypes_bcs(self) -> Tensor:
+        hap = self.get_haplotypes_bs()
+        b, h = hap.shape
+        one_hot = torch.nn.functional.one_hot(hap, num_classes=5)  # [B, H, 5]
+        return one_hot.permute(0, 2, 1).reshape(b, 10, h // 2)  # refA, altA, refC, altC, ...
+
+    def get_reads_re(self) -> Tensor:
+        """float view of the reads, [R, F] (decoded on demand when the batch holds packed bytes)."""
+        if self.reads_re is not None:
+            return self.reads_re
+        dec = decode_packed_reads(self.packed_reads.cpu().numpy())
+        return torch.from_numpy(dec).to(self.packed_reads.device)
+
+    def num_read_features(self) -> int:
+        return self._num_read_features
+
+    def size(self) -> int:
+        return self._size
+
+    def pin_memory(self):
+        self.int_tensor = self.int_tensor.pin_memory()
+        self.float_tensor = self.float_tensor.pin_memory()
+        if self.packed_reads is not None:
+            self.packed_reads = self.packed_reads.pin_memory()
+        if self.reads_re is not None:
+            self.reads_re = self.reads_re.pin_memory()
+        return self
+
+    def copy_to(self, device, dtype=torch.float32) -> "Batch":
+        nb = device.type == "cuda"
+        new = copy.copy(self)
+        new.int_tensor = self.int_tensor.to(device, non_blocking=nb)
+        new.float_tensor = self.float_tensor.to(device, non_blocking=nb)
+        if self.packed_reads is not None:
+            new.packed_reads = self.packed_reads.to(device, non_blocking=nb)
+        if self.reads_re is not None:
+            new.reads_re = self.reads_re.to(device=device, dtype=dtype, non_blocking=nb)
+        new._offsets = None
+        return new
+
+    # ---- engine-side views -----------------------------------------------------------------------------------------
+    def host_counts(self):
+        if self._host_counts is None:  # a batch assembled on the device: one sync, like the reference's .item()
+            ints = self.int_tensor[:, :2].cpu().numpy()
+            self._host_counts = (ints[:, 0].astype(np.int32), ints[:, 1].astype(np.int32))
+        return self._host_counts
+
+    def plan(self) -> GroupPlan:
+        if self._plan is None:
+            self._plan = GroupPlan(*self.host_counts())
+        return self._plan
+
+    def device_counts(self):
+        """(ref_counts, alt_counts, elem_bytes, stride_elems) as device tensors for pmt_scan_counts."""
+        return self.int_tensor[:, Data.REF_COUNT.idx], self.int_tensor[:, Data.ALT_COUNT.idx], 8, self.int_tensor.stride(0)
+
+    def read_rows(self):
+        """(tensor, format, row_bytes, gather_index or None)"""
+        if self.packed_reads is not None:
+            return self.packed_reads, L.READS_PACKED_U8, self.packed_reads.shape[1], None
+        r = self.reads_re
+        if r.dtype == torch.float16:
+            return r, L.READS_F16, 2 * r.shape[1], None
+        if r.dtype == torch.float32:
+            return r, L.READS_F32, 4 * r.shape[1], None
+        raise L.PmtError(f"unsupported reads dtype {r.dtype}")
+
+
+class DownsampledBatch(Batch):
+    """Bernoulli read subsampling of a parent batch without copying reads (reference data/batch.py:383-459).
+
+    The kept-alt indices index the alt-only mask but are used un-offset into the full read array, exactly like the
+    reference; `fix_alt_gather=True` opts into the offset (intended) behaviour."""
+
+    def __init__(self, original_batch: Batch, ref_fracs_b: Tensor, alt_fracs_b: Tensor, fix_alt_gather: bool = False):
+        self.int_tensor = original_batch.int_tensor
+        self.float_tensor = original_batch.float_tensor
+        self.device = self.int_tensor.device
+        self.packed_reads = original_batch.packed_reads
+        self.reads_re = original_batch.reads_re
+        self._num_read_features = original_batch._num_read_features
+        self._size = original_batch._size
+        self._parent = original_batch
+        self._offsets = None
+
+        old_ref, old_alt = original_batch.get(Data.REF_COUNT), original_batch.get(Data.ALT_COUNT)
+        ref_host, alt_host = original_batch.host_counts()
+        total_ref, total_alt = int(ref_host.sum()), int(alt_host.sum())
+        ref_probs = torch.repeat_interleave(ref_fracs_b, repeats=old_ref, dim=0, output_size=total_ref)
+        alt_probs = torch.repeat_interleave(alt_fracs_b, repeats=old_alt, dim=0, output_size=total_alt)
+        keep_ref = torch.zeros(total_ref, device=self.device, dtype=torch.int64)
+        keep_ref.bernoulli_(p=ref_probs)
+        keep_alt = torch.zeros(total_alt, device=self.device, dtype=torch.int64)
+        keep_alt.bernoulli_(p=alt_probs)
+        # guarantee one alt read per variant: force one pseudo-randomly chosen alt of each set
+        random_int = randint(0, 100)
+        alt_ends = torch.cumsum(old_alt, dim=0)
+        override = alt_ends - torch.remainder(torch.tensor([random_int], device=self.device, dtype=torch.int64), old_alt) - 1
+        keep_alt[override] = 1
+        self.ref_counts = torch.segment_reduce(keep_ref.float(), reduce="sum", lengths=old_ref).round().int()
+        self.alt_counts = torch.segment_reduce(keep_alt.float(), reduce="sum", lengths=old_alt).round().int()
+        kept_ref = torch.nonzero(keep_ref).view(-1)
+        kept_alt = torch.nonzero(keep_alt).view(-1)
+        if fix_alt_gather:
+            kept_alt = kept_alt + total_ref
+        self.read_indices = torch.hstack((kept_ref, kept_alt))
+        self._host_counts = None
+
+    def get(self, field: Data) -> Tensor:
+        if field == Data.REF_COUNT:
+            return self.ref_counts
+        if field == Data.ALT_COUNT:
+            return self.alt_counts
+        return super().get(field)
+
+    def get_reads_re(self) -> Tensor:
+        return self._parent.get_reads_re()[self.read_indices]
+
+    def plan(self) -> GroupPlan:
+        return self._parent.plan()  # parent counts are upper bounds of the downsampled counts
+
+    def host_counts(self):
+        if self._host_counts is None:
+            self._host_counts = (self.ref_counts.cpu().numpy().astype(np.int32), self.alt_counts.cpu().numpy().astype(np.int32))
+        return self._host_counts
+
+    def device_counts(self):
+        return self.ref_counts, self.alt_counts, 4, 1
+
+    def read_rows(self):
+        t, fmt, row_bytes, _ = self._parent.read_rows()
+        return t, fmt, row_bytes, self.read_indices

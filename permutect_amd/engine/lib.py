@@ -1,0 +1,136 @@
+"""ctypes binding of the C ABI in include/permutect_amd.h.
+
+The shared library is built in-tree (permutect_amd/libpermutect_amd.so, see __graft_entry__.build or
+permutect_amd/csrc/Makefile).  There is no fallback: if the library is missing, `load()` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_HERE, "libpermutect_amd.so")
+
+# ---- limits (must match the header) -------------------------------------------------------------------------------
+ABI_VERSION = 1
+MAX_WIDTH, MAX_HALF_FFN, MAX_CLUSTERS = 64, 16, 16
+MAX_OPS, MAX_SKIP_LAYERS, MAX_BLOCKS, MAX_LINEAR = 8, 4, 16, 96
+GROUP_WAVES, GROUP_TILES, GROUP_MAX_SETS, TILE = 8, 16, 64, 16
+READS_PACKED_U8, READS_F16, READS_F32 = 0, 1, 2
+OP_LINEAR, OP_SKIP = 0, 1
+SLOT_FLOATS = 4 * 256
+
+E_INVALID, E_UNSUPPORTED, E_CAPACITY, E_LAUNCH, E_WORKSPACE = -1, -2, -3, -4, -5
+_ERR = {-1: "invalid argument/descriptor", -2: "configuration not supported by the gfx950 kernels",
+        -3: "a read set exceeds the register-resident group capacity", -4: "HIP launch failure",
+        -5: "workspace too small"}
+
+i32, i64, vp = C.c_int32, C.c_int64, C.c_void_p
+
+
+class PmtLinear(C.Structure):
+    _fields_ = [("in_dim", i32), ("out_dim", i32), ("w_frag", i32), ("wt_frag", i32), ("b_pvec", i32),
+                ("w_src", i32), ("b_src", i32), ("out_split", i32)]
+
+
+class PmtOp(C.Structure):
+    _fields_ = [("kind", i32), ("n_layers", i32), ("selu_after", i32), ("alpha_src", i32),
+                ("lin", i32 * MAX_SKIP_LAYERS)]
+
+
+class PmtMlp(C.Structure):
+    _fields_ = [("n_ops", i32), ("in_dim", i32), ("out_dim", i32), ("reserved", i32), ("ops", PmtOp * MAX_OPS)]
+
+
+class PmtBlock(C.Structure):
+    _fields_ = [("norm_w_pvec", i32), ("norm_b_pvec", i32), ("norm_w_src", i32), ("norm_b_src", i32),
+                ("proj1", i32 * 2), ("proj2", i32 * 2),
+                ("sgu_norm_w_pvec", i32), ("sgu_norm_b_pvec", i32), ("sgu_norm_w_src", i32), ("sgu_norm_b_src", i32),
+                ("alpha_src", i32 * 2), ("beta_src", i32 * 2), ("gamma_src", i32),
+                ("ref_reg_pvec", i32), ("ref_reg_src", i32), ("reg_weight_phi", i32)]
+
+
+class PmtHead(C.Structure):
+    _fields_ = [("stdev_e_phi", i32), ("dirs_ke_phi", i32), ("art_stdev_k_phi", i32), ("log_w_k_phi", i32),
+                ("mu_k_src", i32), ("sigma_k_phi", i32), ("lambda_k_phi", i32), ("reserved", i32)]
+
+
+class PmtModel(C.Structure):
+    _fields_ = [("abi_version", i32), ("num_read_features", i32), ("read_embed_dim", i32),
+                ("variant_embed_dim", i32), ("d_model", i32), ("d_ffn", i32), ("num_blocks", i32),
+                ("feature_dim", i32), ("num_clusters", i32), ("n_linear", i32),
+                ("theta_size", i32), ("phi_size", i32), ("packed_size", i32),
+                ("translation_src", i32), ("translation_pvec", i32), ("rotation_lin", i32),
+                ("read_mlp", PmtMlp), ("reducer", PmtMlp), ("blocks", PmtBlock * MAX_BLOCKS), ("head", PmtHead),
+                ("lin", PmtLinear * MAX_LINEAR)]
+
+
+class PmtBatch(C.Structure):
+    _fields_ = [("num_variants", i32), ("num_groups", i32), ("read_format", i32), ("read_row_bytes", i32),
+                ("reads", vp), ("read_index", vp), ("ref_offsets", vp), ("alt_offsets", vp), ("variant_embed", vp),
+                ("group_start", vp), ("group_tile_base", vp), ("total_tiles", i64)]
+
+
+class PmtOutputs(C.Structure):
+    _fields_ = [("logits_b", vp), ("logits_bk", vp), ("features_be", vp), ("ref_features_be", vp)]
+
+
+class PmtOutputGrads(C.Structure):
+    _fields_ = [("d_logits_b", vp), ("d_logits_bk", vp), ("d_features_be", vp), ("d_ref_features_be", vp)]
+
+
+class PmtAdamW(C.Structure):
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("max_grad_norm", C.c_float), ("step", i32), ("reserved", i32)]
+
+
+EXPORTS = ["pmt_abi_version", "pmt_struct_bytes", "pmt_model_check", "pmt_plan_groups", "pmt_stash_bytes", "pmt_pack_params",
+           "pmt_scan_counts", "pmt_forward", "pmt_backward", "pmt_clip_adamw"]
+
+_lib = None
+
+
+class PmtError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str) -> int:
+    if rc < 0:
+        raise PmtError(f"{what} failed: {_ERR.get(rc, rc)} (code {rc})")
+    return rc
+
+
+def load() -> C.CDLL:
+    """Load libpermutect_amd.so (once).  Raises if it has not been built -- there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PmtError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       f"or `make -C permutect_amd/csrc`.  permutect_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    lib.pmt_abi_version.restype = i32
+    lib.pmt_model_check.argtypes = [P(PmtModel)]
+    lib.pmt_plan_groups.argtypes = [vp, vp, i32, vp, vp, P(i32)]
+    lib.pmt_stash_bytes.argtypes = [P(PmtModel), i64, i32]
+    lib.pmt_stash_bytes.restype = C.c_size_t
+    lib.pmt_pack_params.argtypes = [P(PmtModel), vp, vp, vp, vp, vp]
+    lib.pmt_scan_counts.argtypes = [vp, vp, i32, i64, i32, vp, vp, vp]
+    lib.pmt_forward.argtypes = [P(PmtModel), vp, vp, vp, vp, P(PmtBatch), P(PmtOutputs), vp, vp]
+    lib.pmt_backward.argtypes = [P(PmtModel), vp, vp, vp, vp, P(PmtBatch), P(PmtOutputGrads), vp, vp, vp, vp, vp]
+    lib.pmt_clip_adamw.argtypes = [vp, vp, vp, vp, i64, P(PmtAdamW), vp, vp, vp]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name not in ("pmt_abi_version", "pmt_stash_bytes"):
+            fn.restype = i32
+    lib.pmt_struct_bytes.argtypes = [i32]
+    if lib.pmt_abi_version() != ABI_VERSION:
+        raise PmtError("libpermutect_amd.so ABI version mismatch; rebuild it")
+    for which, st in enumerate([PmtModel, PmtBatch, PmtOutputs, PmtOutputGrads, PmtAdamW, PmtLinear, PmtOp, PmtMlp,
+                                PmtBlock, PmtHead]):
+        if lib.pmt_struct_bytes(which) != C.sizeof(st):
+            raise PmtError(f"ctypes layout of {st.__name__} ({C.sizeof(st)} B) does not match the library "
+                           f"({lib.pmt_struct_bytes(which)} B)")
+    _lib = lib
+    return lib

@@ -1,0 +1,217 @@
+"""Lowering of an ArtifactModel module tree to the device-side representation.
+
+  * `theta`  : ONE flat fp32 buffer holding every learnable leaf tensor in natural layout.  The nn.Parameters of the
+               model are re-bound as views into it, so the fused optimizer, the RCCL gradient all-reduce and the HIP
+               kernels all address the same memory, and state_dict()/load_state_dict() keep working unchanged.
+  * `gtheta` : same layout, gradients.  `param.grad` of every leaf is a view into it.
+  * `phi`    : small buffer of materialised parametrizations (exp / bounded sigmoid / unit vectors / log_softmax /
+               orthogonal matrix), produced by torch each step so that autograd carries d(phi) back to the
+               `.original` leaves (reference architecture/parameterizations.py).
+  * `packed` : weights in MFMA A-fragment order + per-feature vectors in tile-position order (csrc/pmt_device.hpp),
+               rebuilt on device by pmt_pack_params after every parameter update.
+  * `PmtModel` descriptor with all offsets (include/permutect_amd.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List
+
+import torch
+from torch import nn
+
+from permutect_amd.architecture import modules as M
+from permutect_amd.engine import lib as L
+
+
+def _ceil16(n: int) -> int:
+    return (n + 15) // 16 * 16
+
+
+class ParamSpace:
+    """Flat parameter / gradient buffers with the model's Parameters re-bound as views."""
+
+    def __init__(self, module: nn.Module, device: torch.device):
+        params = [p for p in module.parameters()]
+        self.offsets: Dict[int, int] = {}
+        off = 0
+        for p in params:
+            assert p.dtype == torch.float32, "the engine computes in fp32 (reference data/datum.py:37-38)"
+            self.offsets[id(p)] = off
+            off += (p.numel() + 3) // 4 * 4  # keep every tensor 16-byte aligned
+        self.size = max(off, 4)
+        self.theta = torch.zeros(self.size, dtype=torch.float32, device=device)
+        self.gtheta = torch.zeros(self.size, dtype=torch.float32, device=device)
+        self.params = params
+        with torch.no_grad():
+            for p in params:
+                o, n = self.offsets[id(p)], p.numel()
+                self.theta[o:o + n].copy_(p.detach().reshape(-1))
+                p.data = self.theta[o:o + n].view(p.shape)
+        self.bind_grads()
+
+    def bind_grads(self):
+        for p in self.params:
+            o, n = self.offsets[id(p)], p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.gtheta.data_ptr() + 4 * o:
+                p.grad = self.gtheta[o:o + n].view(p.shape)
+
+    def offset_of(self, p: nn.Parameter) -> int:
+        return self.offsets[id(p)]
+
+
+class EnginePlan:
+    """Descriptor + buffers for one ArtifactModel instance on one device."""
+
+    def __init__(self, model, space: ParamSpace, device: torch.device):
+        self.device = device
+        self.space = space
+        d = L.PmtModel()
+        d.abi_version = L.ABI_VERSION
+        self.desc = d
+        self._packed_off = 0
+        self._n_lin = 0
+        self._phi_off = 0
+        self.phi_layout: List[tuple] = []  # (name, offset, numel)
+
+        read_mlp: M.MLP = model.read_embedding
+        enc: M.GatedRefAltMLP = model.ref_alt_reads_encoder
+        reducer: M.MLP = model.reducer
+        fc: M.FeatureClustering = model.feature_clustering
+        d.num_read_features = read_mlp.input_dimension()
+        d.read_embed_dim = read_mlp.output_dimension()
+        d.d_model = enc.dimension
+        d.variant_embed_dim = d.d_model - d.read_embed_dim
+        d.d_ffn = enc.d_ffn
+        d.num_blocks = len(enc.blocks)
+        d.feature_dim = reducer.output_dimension()
+        d.num_clusters = fc.num_artifact_clusters
+        h, e, k = d.d_ffn // 2, d.feature_dim, d.num_clusters
+        if d.num_blocks > L.MAX_BLOCKS:
+            raise L.PmtError(f"{d.num_blocks} gated blocks exceed the kernel limit {L.MAX_BLOCKS}")
+
+        self._lower_mlp(d.read_mlp, read_mlp)
+        for i, blk in enumerate(enc.blocks):
+            b = d.blocks[i]
+            b.norm_w_src, b.norm_b_src = space.offset_of(blk.norm.weight), space.offset_of(blk.norm.bias)
+            b.norm_w_pvec, b.norm_b_pvec = self._alloc_packed(_ceil16(d.d_model)), self._alloc_packed(_ceil16(d.d_model))
+            b.proj1[0] = self._add_linear(blk.proj1_ref, out_split=h)
+            b.proj1[1] = self._add_linear(blk.proj1_alt, out_split=h)
+            b.proj2[0] = self._add_linear(blk.proj2_ref)
+            b.proj2[1] = self._add_linear(blk.proj2_alt)
+            s = blk.sgu
+            b.sgu_norm_w_src, b.sgu_norm_b_src = space.offset_of(s.norm.weight), space.offset_of(s.norm.bias)
+            b.sgu_norm_w_pvec, b.sgu_norm_b_pvec = self._alloc_packed(_ceil16(h)), self._alloc_packed(_ceil16(h))
+            b.alpha_src[0], b.alpha_src[1] = space.offset_of(s.alpha_ref), space.offset_of(s.alpha_alt)
+            b.beta_src[0], b.beta_src[1] = space.offset_of(s.beta_ref), space.offset_of(s.beta_alt)
+            b.gamma_src = space.offset_of(s.gamma)
+            b.ref_reg_src, b.ref_reg_pvec = space.offset_of(s.ref_regularizer), self._alloc_packed(_ceil16(h))
+            b.reg_weight_phi = self._alloc_phi(f"reg_weight.{i}", 1)
+        self._lower_mlp(d.reducer, reducer)
+
+        tr = model.pre_clustering_transform
+        d.translation_src = space.offset_of(tr.translation_e)
+        d.translation_pvec = self._alloc_packed(_ceil16(e))
+        q_phi = self._alloc_phi("rotation", e * e)
+        d.rotation_lin = self._add_raw_linear(e, e, w_src=-(q_phi + 2), b_src=-1, has_bias=False)
+
+        hd = d.head
+        hd.stdev_e_phi = self._alloc_phi("stdev_e", e)
+        hd.dirs_ke_phi = self._alloc_phi("dirs_ke", k * e)
+        hd.art_stdev_k_phi = self._alloc_phi("art_stdev_k", k)
+        hd.log_w_k_phi = self._alloc_phi("log_w_k", k)
+        hd.sigma_k_phi = self._alloc_phi("sigma_k", k)
+        hd.lambda_k_phi = self._alloc_phi("lambda_k", k)
+        hd.mu_k_src = space.offset_of(fc.artifact_emg.mu_k)
+
+        d.n_linear = self._n_lin
+        d.theta_size, d.phi_size, d.packed_size = space.size, max(self._phi_off, 4), max(self._packed_off, 4)
+
+        lib = L.load()
+        L.check(lib.pmt_model_check(C.byref(d)), "pmt_model_check")
+        self.packed = torch.zeros(d.packed_size, dtype=torch.float32, device=device)
+        self.gphi_size = d.phi_size
+        raw = bytes(d)
+        self.desc_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        self.stash_slots = (d.read_mlp.n_ops - 1) + (d.num_blocks + 1) + (d.reducer.n_ops - 1)
+
+    # ---- allocation helpers --------------------------------------------------------------------------------------
+    def _alloc_packed(self, n: int) -> int:
+        off = self._packed_off
+        self._packed_off += (n + 3) // 4 * 4
+        return off
+
+    def _alloc_phi(self, name: str, n: int) -> int:
+        off = self._phi_off
+        self.phi_layout.append((name, off, n))
+        self._phi_off += n
+        return off
+
+    def _add_raw_linear(self, in_dim: int, out_dim: int, w_src: int, b_src: int, has_bias: bool, out_split: int = 0) -> int:
+        if self._n_lin >= L.MAX_LINEAR:
+            raise L.PmtError("too many linear layers for the kernel descriptor")
+        if in_dim > L.MAX_WIDTH or out_dim > L.MAX_WIDTH:
+            raise L.PmtError(f"layer width {in_dim}->{out_dim} exceeds the register-resident limit {L.MAX_WIDTH}")
+        lin = self.desc.lin[self._n_lin]
+        out_v = 16 + out_split if out_split else out_dim
+        nmt, nkt = (out_v + 15) // 16, (in_dim + 15) // 16
+        lin.in_dim, lin.out_dim, lin.out_split = in_dim, out_dim, out_split
+        lin.w_frag = self._alloc_packed(nmt * nkt * 256)
+        lin.wt_frag = self._alloc_packed(nmt * nkt * 256)
+        lin.b_pvec = self._alloc_packed(nmt * 16) if has_bias else -1
+        lin.w_src, lin.b_src = w_src, b_src
+        self._n_lin += 1
+        return self._n_lin - 1
+
+    def _add_linear(self, layer: nn.Linear, out_split: int = 0) -> int:
+        b_src = self.space.offset_of(layer.bias) if layer.bias is not None else -1
+        return self._add_raw_linear(layer.in_features, layer.out_features, self.space.offset_of(layer.weight), b_src,
+                                    layer.bias is not None, out_split)
+
+    def _lower_mlp(self, dst: L.PmtMlp, mlp: M.MLP):
+        children = list(mlp._model.children())
+        ops = []
+        i = 0
+        while i < len(children):
+            c = children[i]
+            if isinstance(c, nn.Linear):
+                selu_after = i + 1 < len(children) and isinstance(children[i + 1], nn.SELU)
+                ops.append(("lin", c, selu_after))
+                i += 2 if selu_after else 1
+            elif isinstance(c, M.DenseSkipBlock):
+                inner = list(c.mlp._model.children())  # (SELU, Linear) * n
+                lins = [m for m in inner if isinstance(m, nn.Linear)]
+                assert len(inner) == 2 * len(lins) and all(isinstance(m, nn.SELU) for m in inner[0::2])
+                ops.append(("skip", c, lins))
+                i += 1
+            else:
+                raise L.PmtError(f"unsupported layer in MLP: {type(c).__name__}")
+        if len(ops) > L.MAX_OPS:
+            raise L.PmtError(f"MLP with {len(ops)} top-level ops exceeds the kernel limit {L.MAX_OPS}")
+        dst.n_ops, dst.in_dim, dst.out_dim = len(ops), mlp.input_dimension(), mlp.output_dimension()
+        for j, op in enumerate(ops):
+            o = dst.ops[j]
+            if op[0] == "lin":
+                o.kind, o.n_layers, o.selu_after, o.alpha_src = L.OP_LINEAR, 1, int(op[2]), -1
+                o.lin[0] = self._add_linear(op[1])
+            else:
+                blk, lins = op[1], op[2]
+                if len(lins) > 2:
+                    raise L.PmtError("skip blocks deeper than 2 layers are not supported by the gfx950 kernels")
+                o.kind, o.n_layers, o.selu_after = L.OP_SKIP, len(lins), 0
+                o.alpha_src = self.space.offset_of(blk.alpha)
+                for t, lin in enumerate(lins):
+                    o.lin[t] = self._add_linear(lin)
+
+    # ---- phi ------------------------------------------------------------------------------------------------------
+    def materialize_phi(self, model) -> torch.Tensor:
+        """Evaluate every parametrization with torch (autograd-tracked) in the order of phi_layout."""
+        fc = model.feature_clustering
+        parts = [blk.sgu.reg_weight.reshape(1) for blk in model.ref_alt_reads_encoder.blocks]
+        parts += [model.pre_clustering_transform.rotation_ee.weight.reshape(-1),
+                  fc.nonartifact_stdev_e.reshape(-1), fc.artifact_directions_ke.reshape(-1),
+                  fc.artifact_stdev_k.reshape(-1), fc.log_cluster_weights_k.reshape(-1),
+                  fc.artifact_emg.sigma_k.reshape(-1), fc.artifact_emg.lambda_k.reshape(-1)]
+        phi = torch.cat(parts)
+        if phi.numel() < self.desc.phi_size:
+            phi = torch.cat([phi, phi.new_zeros(self.desc.phi_size - phi.numel())])
+        return phi

@@ -1,0 +1,135 @@
+"""Runtime glue between torch tensors (device memory + streams only) and the C ABI.
+
+`ReadSetEngine` owns the flat parameter space and the device descriptor of one ArtifactModel;
+`ReadSetFunction` is the single torch.autograd.Function through which the read-set encoder + clustering head run:
+forward = pmt_forward (one fused HIP launch), backward = pmt_backward (one fused HIP launch).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from permutect_amd.engine import lib as L
+from permutect_amd.engine.plan import EnginePlan, ParamSpace
+
+
+def _ptr(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class ReadSetEngine:
+    def __init__(self, model, device: torch.device):
+        if device.type != "cuda":
+            raise L.PmtError("permutect_amd computes on an MI355X (ROCm device 'cuda') only; there is no CPU fallback. "
+                             "Model construction, state_dict and save/load work on any device.")
+        self.lib = L.load()
+        self.device = device
+        self.space = ParamSpace(model, device)
+        self.plan = EnginePlan(model, self.space, device)
+        self._packed_key = None
+
+    # ---- parameters -------------------------------------------------------------------------------------------------
+    def pack(self, phi: Tensor):
+        d = self.plan
+        L.check(self.lib.pmt_pack_params(C.byref(d.desc), d.desc_dev.data_ptr(), self.space.theta.data_ptr(),
+                                         phi.data_ptr(), d.packed.data_ptr(), _stream()), "pmt_pack_params")
+
+    # ---- batch views --------------------------------------------------------------------------------------------------
+    def offsets(self, batch) -> Tuple[Tensor, Tensor]:
+        if getattr(batch, "_offsets", None) is None:
+            ref_c, alt_c, elem, stride = batch.device_counts()
+            b = batch.size()
+            ref_off = torch.empty(b + 1, dtype=torch.int32, device=self.device)
+            alt_off = torch.empty(b + 1, dtype=torch.int32, device=self.device)
+            L.check(self.lib.pmt_scan_counts(ref_c.data_ptr(), alt_c.data_ptr(), elem, stride, b, ref_off.data_ptr(),
+                                             alt_off.data_ptr(), _stream()), "pmt_scan_counts")
+            batch._offsets = (ref_off, alt_off)
+        return batch._offsets
+
+    def batch_view(self, batch, variant_embed: Tensor):
+        plan = batch.plan()
+        gs, gt = plan.on(self.device)
+        ref_off, alt_off = self.offsets(batch)
+        reads, fmt, row_bytes, index = batch.read_rows()
+        if reads.device != self.device:
+            raise L.PmtError("batch tensors must be on the model's device (call batch.copy_to(device, dtype))")
+        bv = L.PmtBatch()
+        bv.num_variants, bv.num_groups = batch.size(), plan.num_groups
+        bv.read_format, bv.read_row_bytes = fmt, row_bytes
+        bv.reads, bv.read_index = reads.data_ptr(), _ptr(index)
+        bv.ref_offsets, bv.alt_offsets = ref_off.data_ptr(), alt_off.data_ptr()
+        bv.variant_embed = variant_embed.data_ptr()
+        bv.group_start, bv.group_tile_base = gs.data_ptr(), gt.data_ptr()
+        bv.total_tiles = plan.total_tiles
+        keep = (gs, gt, ref_off, alt_off, reads, index, variant_embed)
+        return bv, keep, plan
+
+    # ---- passes -----------------------------------------------------------------------------------------------------
+    def forward(self, batch, phi: Tensor, variant_embed: Tensor, train: bool):
+        d = self.plan.desc
+        b, k, e = batch.size(), d.num_clusters, d.feature_dim
+        variant_embed = variant_embed.contiguous().float()
+        assert variant_embed.shape == (b, d.variant_embed_dim), (variant_embed.shape, d.variant_embed_dim)
+        phi = phi.contiguous()
+        self.pack(phi)
+        bv, keep, plan = self.batch_view(batch, variant_embed)
+        dev = self.device
+        logits_b = torch.empty(b, dtype=torch.float32, device=dev)
+        logits_bk = torch.empty(b, k + 2, dtype=torch.float32, device=dev)
+        feats = torch.empty(b, e, dtype=torch.float32, device=dev)
+        ref_feats = torch.empty(b, e, dtype=torch.float32, device=dev)
+        out = L.PmtOutputs(logits_b.data_ptr(), logits_bk.data_ptr(), feats.data_ptr(), ref_feats.data_ptr())
+        stash = None
+        if train:
+            nbytes = self.lib.pmt_stash_bytes(C.byref(d), plan.total_tiles, b)
+            stash = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+        L.check(self.lib.pmt_forward(C.byref(d), self.plan.desc_dev.data_ptr(), self.space.theta.data_ptr(),
+                                     phi.data_ptr(), self.plan.packed.data_ptr(), C.byref(bv), C.byref(out),
+                                     _ptr(stash), _stream()), "pmt_forward")
+        return (logits_b, logits_bk, feats, ref_feats), stash, variant_embed, phi
+
+    def backward(self, batch, phi: Tensor, variant_embed: Tensor, stash: Tensor, grads):
+        d = self.plan.desc
+        bv, keep, plan = self.batch_view(batch, variant_embed)
+        g = [None if t is None else t.contiguous().float() for t in grads]
+        dout = L.PmtOutputGrads(_ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]))
+        gphi = torch.zeros(d.phi_size, dtype=torch.float32, device=self.device)
+        gvar = torch.zeros_like(variant_embed)
+        L.check(self.lib.pmt_backward(C.byref(d), self.plan.desc_dev.data_ptr(), self.space.theta.data_ptr(),
+                                      phi.data_ptr(), self.plan.packed.data_ptr(), C.byref(bv), C.byref(dout),
+                                      stash.data_ptr(), self.space.gtheta.data_ptr(), gphi.data_ptr(),
+                                      gvar.data_ptr(), _stream()), "pmt_backward")
+        return gphi, gvar
+
+
+class ReadSetFunction(torch.autograd.Function):
+    """(phi, variant_embed) -> (logits_b, logits_bk, features_be, ref_features_be).
+
+    Gradients w.r.t. the direct (un-parametrized) leaves are accumulated by the backward kernel straight into the flat
+    gradient buffer that `param.grad` views alias; gradients w.r.t. phi and the per-variant embedding are returned to
+    autograd."""
+
+    @staticmethod
+    def forward(ctx, engine: ReadSetEngine, batch, phi: Tensor, variant_embed: Tensor):
+        train = bool(ctx.needs_input_grad[2] or ctx.needs_input_grad[3])  # False under no_grad / inference_mode
+        outs, stash, ve, ph = engine.forward(batch, phi.detach(), variant_embed.detach(), train)
+        ctx.engine, ctx.batch, ctx.train = engine, batch, train
+        if train:
+            ctx.save_for_backward(ph, ve, stash)
+        return outs
+
+    @staticmethod
+    def backward(ctx, d_logits_b, d_logits_bk, d_feats, d_ref_feats):
+        if not ctx.train:
+            return None, None, None, None
+        phi, ve, stash = ctx.saved_tensors
+        ctx.engine.space.bind_grads()
+        gphi, gvar = ctx.engine.backward(ctx.batch, phi, ve, stash, (d_logits_b, d_logits_bk, d_feats, d_ref_feats))
+        return None, None, gphi, gvar

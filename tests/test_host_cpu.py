@@ -1,0 +1,140 @@
+"""CPU: host-side logic -- state_dict contract, checkpoint format, C-ABI surface, group planner, batch collate."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from permutect_amd.architecture.artifact_model import ArtifactModel, load_model
+from permutect_amd.data.batch import Batch, DownsampledBatch, decode_packed_reads
+from permutect_amd.data.datum import Data, Datum
+from permutect_amd.engine import lib as L
+from permutect_amd.parameters import P0_DIMS, p0_params, t0_params
+from tests.helpers import GOLDEN, load_case
+
+CPU = torch.device("cpu")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name,params", [("t0_b8", t0_params), ("p0_b16", p0_params)])
+def test_state_dict_matches_reference_keys_and_shapes(name, params):
+    z, sd, _ = load_case(name)
+    model = ArtifactModel(params(), device=CPU, **P0_DIMS)
+    ours = model.state_dict()
+    assert list(ours.keys()) == list(sd.keys())  # same names in the same order
+    for k in sd:
+        assert tuple(ours[k].shape) == tuple(sd[k].shape), k
+    model.load_state_dict(sd)  # strict
+    assert sum(p.numel() for p in model.parameters()) == sum(v.numel() for k, v in sd.items() if not k.endswith(".base"))
+
+
+def test_p0_parameter_count():
+    model = ArtifactModel(p0_params(), device=CPU, **P0_DIMS)
+    assert sum(p.numel() for p in model.parameters()) == 59845
+
+
+def test_checkpoint_roundtrip_and_dict_keys(tmp_path):
+    z, sd, _ = load_case("t0_b8")
+    model = ArtifactModel(t0_params(), device=CPU, **P0_DIMS)
+    model.load_state_dict(sd)
+    path = tmp_path / "model.pt"
+    model.save_model(path, artifact_log_priors=torch.tensor([1.0, 2.0]))
+    saved = torch.load(path, weights_only=False)
+    assert set(saved.keys()) == {"model_state_dict", "hyperparams", "num_read_features", "num_info_features",
+                                 "ref_sequence_length", "artifact_log_priors", "artifact_spectra_state_dict"}
+    assert type(saved["hyperparams"]).__module__ == "permutect.parameters"
+    loaded, priors, spectra = load_model(path, device=CPU)
+    assert spectra is None and torch.equal(priors, torch.tensor([1.0, 2.0]))
+    for (k1, v1), (k2, v2) in zip(model.state_dict().items(), loaded.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2), k1
+
+
+def test_compute_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    z, sd, b = load_case("t0_b8")
+    model = ArtifactModel(t0_params(), device=CPU, **P0_DIMS)
+    batch = Batch.from_arrays(b["int_array"], b["float_array"], b["packed_reads"])
+    with pytest.raises(L.PmtError):
+        model.compute_batch_output(batch)
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "permutect_amd.h")).read()
+    declared = sorted(set(re.findall(r"\b(pmt_[a-z_]+)\s*\(", header)))
+    assert declared == sorted(L.EXPORTS)
+    lib = L.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.pmt_abi_version() == L.ABI_VERSION
+
+
+def test_ctypes_struct_sizes_match_the_compiled_library():
+    lib = L.load()  # load() itself raises on any mismatch; spot-check two here
+    assert lib.pmt_struct_bytes(0) == C.sizeof(L.PmtModel) and lib.pmt_struct_bytes(1) == C.sizeof(L.PmtBatch)
+    assert lib.pmt_struct_bytes(99) < 0
+
+
+def test_group_planner():
+    rng = np.random.default_rng(0)
+    ref = rng.integers(0, 11, size=5000).astype(np.int32)
+    alt = rng.integers(1, 16, size=5000).astype(np.int32)
+    from permutect_amd.data.batch import GroupPlan
+    plan = GroupPlan(ref, alt)
+    gs = plan.group_start
+    assert gs[0] == 0 and gs[-1] == 5000 and np.all(np.diff(gs) > 0)
+    tiles = 0
+    for g in range(plan.num_groups):
+        r, a = ref[gs[g]:gs[g + 1]].sum(), alt[gs[g]:gs[g + 1]].sum()
+        t = (r + 15) // 16 + (a + 15) // 16
+        assert t <= L.GROUP_TILES and gs[g + 1] - gs[g] <= L.GROUP_MAX_SETS
+        assert plan.group_tile_base[g] == tiles
+        tiles += t
+    assert plan.total_tiles == tiles
+    # a set that cannot fit one group is refused loudly, naming the variant
+    with pytest.raises(L.PmtError, match="variant 1"):
+        GroupPlan(np.array([1, 200], dtype=np.int32), np.array([1, 200], dtype=np.int32))
+    assert GroupPlan(np.zeros(0, np.int32), np.zeros(0, np.int32)).num_groups == 0
+
+
+def test_batch_collate_matches_reference_layout():
+    z, _, b = load_case("p0_b16")
+    ints, floats, packed = b["int_array"], b["float_array"], b["packed_reads"]
+    # per-datum construction (ref rows then alt rows per datum) collates to the reference's batch order
+    nref, nalt = ints[:, 0].astype(int), ints[:, 1].astype(int)
+    total_ref = nref.sum()
+    ro, ao = np.concatenate([[0], np.cumsum(nref)]), np.concatenate([[0], np.cumsum(nalt)]) + total_ref
+    data = [Datum(ints[i], floats[i], np.vstack([packed[ro[i]:ro[i + 1]], packed[ao[i]:ao[i + 1]]])) for i in range(len(ints))]
+    batch = Batch(data)
+    assert torch.equal(batch.packed_reads, torch.from_numpy(packed))
+    assert batch.int_tensor.dtype == torch.int64 and batch.float_tensor.dtype == torch.float32
+    np.testing.assert_array_equal(batch.get_reads_re().numpy(), z["reads_re_f16"])
+    assert batch.get_reads_re().dtype == torch.float16 and batch.num_read_features() == 61
+    oh = batch.get_one_hot_haplotypes_bcs()
+    assert oh.shape == (16, 10, 21)
+    hap = ints[:, 16:]
+    assert oh[3, 2 * hap[3, 5] + 0, 5] == 1 and oh[3, 2 * hap[3, 21 + 5] + 1, 5] == 1  # refX / altX interleave
+
+
+def test_decode_quirk_in_product_collate():
+    z = np.load(f"{GOLDEN}/quirk_decode.npz")
+    np.testing.assert_array_equal(decode_packed_reads(z["packed_reads"]), z["reads_re_f16"])
+
+
+def test_downsampled_batch_reproduces_reference_gather_quirk():
+    z = np.load(f"{GOLDEN}/quirk_downsample.npz")
+    ref, alt = z["ref_counts"], z["alt_counts"]
+    ints = np.zeros((3, 16 + 42), dtype=np.int16)
+    ints[:, 0], ints[:, 1] = ref, alt
+    floats = np.zeros((3, 6 + 71), dtype=np.float16)
+    reads = np.random.default_rng(1).integers(0, 256, size=(int(ref.sum() + alt.sum()), 12), dtype=np.uint8)
+    parent = Batch.from_arrays(ints, floats, reads)
+    db = DownsampledBatch(parent, torch.ones(3), torch.ones(3))
+    np.testing.assert_array_equal(db.read_indices.numpy(), z["read_indices_all_kept"])
+    np.testing.assert_array_equal(db.get(Data.REF_COUNT).numpy(), z["new_ref_counts_all_kept"])
+    np.testing.assert_array_equal(db.get(Data.ALT_COUNT).numpy(), z["new_alt_counts_all_kept"])
+    fixed = DownsampledBatch(parent, torch.ones(3), torch.ones(3), fix_alt_gather=True)
+    np.testing.assert_array_equal(fixed.read_indices.numpy(), np.arange(int(ref.sum() + alt.sum())))
+    assert db.plan() is parent.plan()
