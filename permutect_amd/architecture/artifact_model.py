@@ -78,6 +78,8 @@ class ArtifactModel(nn.Module):
         if device is None:
             device = gpu_if_available()
         self._device = torch.device(device)
+        if self._device.type == "cuda" and self._device.index is None:
+            self._device = torch.device("cuda", torch.cuda.current_device())
         self._dtype = torch.float32  # reference data/datum.py:37-38: fp32 on every device
         self._haplotypes_length = haplotypes_length
         self._params = params
