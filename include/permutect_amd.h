@@ -213,8 +213,8 @@ int pmt_forward(const PmtModel* model_host, const PmtModel* model_dev, const flo
  * phi; the caller zeroes them) and writes grad_variant_embed [B][E_v].  Replaces autograd over the same graph
  * (reference misc_utils.py:127). */
 int pmt_backward(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* phi,
-                 const float* packed, const PmtBatch* batch, const PmtOutputGrads* dout, const float* stash,
-                 float* grad_theta, float* grad_phi, float* grad_variant_embed, void* stream);
+                 const float* packed, const PmtBatch* batch, const PmtOutputs* out, const PmtOutputGrads* dout,
+                 const float* stash, float* grad_theta, float* grad_phi, float* grad_variant_embed, void* stream);
 
 /* Global-norm clip + AdamW over the flat parameter buffer, one launch sequence, no host sync.
  * Replaces nn.utils.clip_grad_norm_(max_norm=1.0) + torch.optim.AdamW.step (reference misc_utils.py:128-129).

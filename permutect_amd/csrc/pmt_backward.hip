@@ -1,8 +1,832 @@
-// Fused read-set backward for gfx950 (placeholder until the kernel lands: fails loudly, never falls back).
+// Fused read-set backward for gfx950.  Same group / tile / register layout as the forward (pmt_device.hpp).  The
+// kernel walks the network in reverse; inside each layer group it RECOMPUTES the forward from the stashed layer-group
+// input (pmt_forward<TRAIN> wrote those), so only ~0.7 K floats per read cross HBM between the two passes.
+//
+//   dgrad  dx = W^T dy      : MFMA with the transposed A fragments (wt_frag); dy is already the B operand.
+//   wgrad  dW += dy x^T     : contraction over READS.  Both operands are transposed through a per-wave LDS tile
+//                             (reads move from the lane axis to the MFMA k axis), multiplied with
+//                             v_mfma_f32_16x16x4_f32, summed across the 8 waves with LDS float atomics and flushed once
+//                             per workgroup with global float atomics into the flat gradient buffer.
+//   set-coupled terms       : per-set sums of d(gate) go through LDS exactly like the forward's z2 sums.
+//
+// Replaces autograd over reference artifact_model.py:239-297 (misc_utils.py:127 `loss.backward()`).
 #include "pmt_device.hpp"
 
+#define TR_STRIDE 20  // floats per row of the per-wave transpose tile (16 + 4 pad: conflict-free b32 writes, 16B-aligned b128 reads)
+#define WG_TILE (PMT_MAX_WIDTH * PMT_MAX_WIDTH)
+
+struct BwdShared {
+    int off[2][PMT_GROUP_MAX_SETS + 1];
+    float gsum[PMT_GROUP_MAX_SETS][2][16];                      // per-set sums of d(gate), current block
+    float dmean[PMT_GROUP_MAX_SETS][2][16];                     // d(m_ref), d(m_alt) already divided by (n + w)
+    float dl[PMT_GROUP_MAX_SETS][PMT_MAX_CLUSTERS + 2];         // d(loss)/d(Lambda[b][j]) incl. the logit path
+    float dfeat[PMT_GROUP_MAX_SETS][2][PMT_MAX_WIDTH];          // d(loss)/d(set mean) / (n + 1e-4), position order
+    float dv[PMT_GROUP_MAX_SETS][PMT_MAX_WIDTH];                // per-set sum of d(x_0) (variant-embedding part)
+    float wg[2][WG_TILE + PMT_MAX_WIDTH];                       // weight (+bias) gradient tiles, double buffered
+    float tr[PMT_GROUP_WAVES][16 * TR_STRIDE];                  // per-wave transpose scratch
+};
+
+DEV float read_lanes_sum(float v) {  // sum over the 16 reads of a tile (lanes with equal lane >> 4)
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+DEV float wave_sum(float v) { return group_sum(read_lanes_sum(v)); }
+
+// C-layout registers of one 16x16 (feature x read) tile -> "reads on k" operand: element ks = value of feature position
+// p = lane & 15 for read 4 * (lane >> 4) + ks.
+DEV f4 transpose_tile(float* __restrict__ tr, f4 v) {
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tr[(4 * g + j) * TR_STRIDE + r] = v[j];
+    __builtin_amdgcn_wave_barrier();
+    const f4 o = *reinterpret_cast<const f4*>(&tr[(lane & 15) * TR_STRIDE + 4 * (lane >> 4)]);
+    __builtin_amdgcn_wave_barrier();
+    return o;
+}
+
+// Accumulate this wave's contribution to dW (and db) of one linear into the shared tile buffer.
+//   dy: [out_v] gradient w.r.t. the linear's output, x: [in_v] its input; rows of padding reads carry dy = 0.
+template <int NTO, int NTI>
+DEV void wgrad_accumulate(float* __restrict__ wgbuf, float* __restrict__ tr, const f4 (&dy)[PMT_RT][NTO],
+                          const f4 (&x)[PMT_RT][NTI], int out_v, int in_v, unsigned tile_mask, bool with_bias) {
+    const int lane = threadIdx.x & 63, g = lane >> 4;
+    const int nmt = (out_v + 15) >> 4, nkt = (in_v + 15) >> 4;
+    f4 xT[PMT_RT][NTI];
+#pragma unroll
+    for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+        for (int it = 0; it < NTI; ++it)
+            if ((tile_mask & (1u << rt)) && it < nkt) xT[rt][it] = transpose_tile(tr, x[rt][it]);
+#pragma unroll
+    for (int ot = 0; ot < NTO; ++ot) {
+        if (ot < nmt && tile_mask) {
+            f4 acc[NTI];
+#pragma unroll
+            for (int it = 0; it < NTI; ++it) acc[it] = f4{0.f, 0.f, 0.f, 0.f};
+            f4 bsum = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt) {
+                if (tile_mask & (1u << rt)) {
+                    const f4 dT = transpose_tile(tr, dy[rt][ot]);
+                    bsum = bsum + dy[rt][ot];
+#pragma unroll
+                    for (int it = 0; it < NTI; ++it)
+                        if (it < nkt) {
+#pragma unroll
+                            for (int ks = 0; ks < 4; ++ks) acc[it] = mfma16(dT[ks], xT[rt][it][ks], acc[it]);
+                        }
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NTI; ++it)
+                if (it < nkt) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        atomicAdd(&wgbuf[(16 * ot + 4 * g + j) * PMT_MAX_WIDTH + 16 * it + (lane & 15)], acc[it][j]);
+                }
+            if (with_bias) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float s = read_lanes_sum(bsum[j]);
+                    if ((lane & 15) == 0) atomicAdd(&wgbuf[WG_TILE + 16 * ot + 4 * g + j], s);
+                }
+            }
+        }
+    }
+}
+
+DEV int pos_to_feat(int p) { return 16 * (p >> 4) + 4 * (p & 3) + ((p & 15) >> 2); }
+DEV int split_row_dev(int v, int h) {
+    if (h <= 0) return v;
+    if (v < 16) return v < h ? v : -1;
+    return (v - 16) < h ? h + (v - 16) : -1;
+}
+
+// After a workgroup barrier: add the shared tile into the flat gradient buffers with global float atomics and clear it.
+DEV void wgrad_flush(float* __restrict__ wgbuf, const PmtLinear& L, float scale, float* __restrict__ gtheta,
+                     float* __restrict__ gphi) {
+    const int h = L.out_split, out_dim = L.out_dim, in_dim = L.in_dim;
+    const int out_v = h > 0 ? 16 + h : out_dim;
+    const int nmt = (out_v + 15) >> 4, nkt = (in_dim + 15) >> 4;
+    float* gw = grad_ptr(L.w_src, gtheta, gphi);
+    for (int i = threadIdx.x; i < nmt * 16 * nkt * 16; i += PMT_THREADS) {
+        const int po = i / (nkt * 16), pi = i - po * (nkt * 16);
+        float* cell = &wgbuf[po * PMT_MAX_WIDTH + pi];
+        const float v = *cell;
+        *cell = 0.f;
+        const int o = split_row_dev(pos_to_feat(po), h), c = pos_to_feat(pi);
+        if (o >= 0 && o < out_dim && c < in_dim && pos_to_feat(po) < out_v) atomicAdd(&gw[(size_t)o * in_dim + c], scale * v);
+    }
+    if (L.b_src != -1) {
+        float* gb = grad_ptr(L.b_src, gtheta, gphi);
+        for (int p = threadIdx.x; p < nmt * 16; p += PMT_THREADS) {
+            float* cell = &wgbuf[WG_TILE + p];
+            const float v = *cell;
+            *cell = 0.f;
+            const int o = split_row_dev(pos_to_feat(p), h);
+            if (o >= 0 && o < out_dim && pos_to_feat(p) < out_v) atomicAdd(&gb[o], scale * v);
+        }
+    }
+}
+
+// per-feature parameter gradient (tile-position registers summed over this wave's reads) -> global atomics
+template <int NT>
+DEV void vec_grad_atomic(float* __restrict__ dst, const f4 (&v)[NT], int dim, int g) {
+    const int nt = (dim + 15) >> 4;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        if (t < nt) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float s = read_lanes_sum(v[t][j]);
+                const int f = feat_of(t, j, g);
+                if ((threadIdx.x & 15) == 0 && f < dim) atomicAdd(dst + f, s);
+            }
+        }
+}
+DEV void scalar_grad_atomic(float* __restrict__ dst, float v) {
+    const float s = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) atomicAdd(dst, s);
+}
+
+// LayerNorm backward for one read tile: given d(y) with y = xhat*w + b, returns d(x); accumulates dw, db partials.
+template <int NT>
+DEV void layernorm_bwd_tile(f4 (&dx)[NT], const f4 (&dyv)[NT], const f4 (&xhat)[NT], float rstd, int dim,
+                            const f4 (&w)[NT], f4 (&dw)[NT], f4 (&db)[NT], int g) {
+    const int nt = (dim + 15) >> 4;
+    float s1 = 0.f, s2 = 0.f;
+    f4 dxh[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        dxh[t] = f4{0.f, 0.f, 0.f, 0.f};
+        if (t < nt) {
+            dw[t] = dw[t] + dyv[t] * xhat[t];
+            db[t] = db[t] + dyv[t];
+            dxh[t] = dyv[t] * w[t];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (feat_of(t, j, g) < dim) {
+                    s1 += dxh[t][j];
+                    s2 += dxh[t][j] * xhat[t][j];
+                } else {
+                    dxh[t][j] = 0.f;
+                }
+        }
+    }
+    const float m1 = group_sum(s1) / (float)dim, m2 = group_sum(s2) / (float)dim;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            dx[t][j] = (t < nt && feat_of(t, j, g) < dim) ? rstd * (dxh[t][j] - m1 - xhat[t][j] * m2) : 0.f;
+}
+
+DEV f4 selu_bwd4(f4 d, f4 s) {
+    return f4{d[0] * selu_grad_from_out(s[0]), d[1] * selu_grad_from_out(s[1]), d[2] * selu_grad_from_out(s[2]),
+              d[3] * selu_grad_from_out(s[3])};
+}
+
+// d/dz of the reference's logerfc (exponentially_modified_gaussian.py:30-55)
+DEV float dlogerfc_dev(float z) {
+    if (z > 5.f) {
+        const float z2 = z * z, z3 = z2 * z, z4 = z2 * z2, z5 = z4 * z, z6 = z4 * z2, z7 = z6 * z;
+        const float q = -1.f / (2.f * z2) + 3.f / (4.f * z4) - 15.f / (8.f * z6);
+        const float dq = 1.f / z3 - 3.f / z5 + 45.f / (4.f * z7);
+        return -2.f * z - 1.f / z + dq / (1.f + q);
+    }
+    const float e = erfcf(z);
+    return e > 1.0e-12f ? -1.1283791670955126f * expf(-z * z) / e : 0.f;
+}
+
+struct BwdCtx {
+    const PmtModel* M;
+    const float* theta;
+    const float* phi;
+    const float* packed;
+    float* gtheta;
+    float* gphi;
+    BwdShared* sh;
+    float* tr;      // this wave's transpose tile
+    int g;
+    unsigned mask_all;
+    int wg_flip;    // which weight-gradient buffer the next linear uses
+};
+
+// One linear's weight/bias gradient: accumulate, workgroup barrier, flush.  Every wave of the group must call it.
+template <int NTO, int NTI>
+DEV void linear_wgrad(BwdCtx& c, const PmtLinear& L, const f4 (&dy)[PMT_RT][NTO], const f4 (&x)[PMT_RT][NTI], unsigned mask,
+                      float scale = 1.0f) {
+    float* buf = c.sh->wg[c.wg_flip];
+    const int h = uniform(L.out_split);
+    const int out_v = h > 0 ? 16 + h : uniform(L.out_dim);
+    wgrad_accumulate<NTO, NTI>(buf, c.tr, dy, x, out_v, uniform(L.in_dim), mask, uniform(L.b_src) != -1);
+    __syncthreads();
+    wgrad_flush(buf, L, scale, c.gtheta, c.gphi);
+    c.wg_flip ^= 1;
+}
+
+// backward of one MLP program.  dy (in/out): gradient w.r.t. the MLP output on entry, w.r.t. its input on exit
+// (not computed for op 0 when need_input_grad is false).  in_slot(op) gives the stash slot of op's input.
+template <typename LoadInput>
+DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][PMT_NT], bool need_input_grad, LoadInput load_input) {
+    const PmtModel* M = c.M;
+    const int n_ops = uniform(mlp.n_ops);
+    for (int op = n_ops - 1; op >= 0; --op) {
+        const PmtOp& o = mlp.ops[op];
+        f4 x[PMT_RT][PMT_NT];
+        load_input(op, x);
+        if (uniform(o.kind) == PMT_OP_LINEAR) {
+            const PmtLinear& L = M->lin[uniform(o.lin[0])];
+            const int in_dim = uniform(L.in_dim), out_dim = uniform(L.out_dim);
+            if (uniform(o.selu_after) != 0) {  // recompute s = selu(Wx + b); dy <- dy * selu'(s)
+                f4 y[PMT_RT][PMT_NT];
+                init_bias<PMT_NT>(y, uniform(L.b_pvec) >= 0 ? c.packed + uniform(L.b_pvec) : nullptr, out_dim, c.g);
+                linear_acc<PMT_NT, PMT_NT, false>(y, x, c.packed + uniform(L.w_frag), in_dim, out_dim, c.mask_all);
+#pragma unroll
+                for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                    for (int t = 0; t < PMT_NT; ++t) dy[rt][t] = selu_bwd4(dy[rt][t], selu4(y[rt][t]));
+            }
+            linear_wgrad<PMT_NT, PMT_NT>(c, L, dy, x, c.mask_all);
+            if (op > 0 || need_input_grad) {
+                f4 dx[PMT_RT][PMT_NT];
+                init_bias<PMT_NT>(dx, nullptr, in_dim, c.g);
+                linear_acc<PMT_NT, PMT_NT, false>(dx, dy, c.packed + uniform(L.wt_frag), out_dim, in_dim, c.mask_all);
+#pragma unroll
+                for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                    for (int t = 0; t < PMT_NT; ++t) dy[rt][t] = dx[rt][t];
+            }
+        } else {
+            // y = x + alpha * f(x); f = L2(selu(L1(selu(x))))  (n = 2)   or   f = L1(selu(x))  (n = 1)
+            const int nl = uniform(o.n_layers);
+            const PmtLinear& L1 = M->lin[uniform(o.lin[0])];
+            const PmtLinear& L2 = M->lin[uniform(o.lin[nl - 1])];
+            const int width = uniform(L1.in_dim);
+            const float alpha = uniform(c.theta[uniform(o.alpha_src)]);
+            f4 s0[PMT_RT][PMT_NT], s1[PMT_RT][PMT_NT];
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                for (int t = 0; t < PMT_NT; ++t) s0[rt][t] = selu4(x[rt][t]);
+            if (nl == 2) {
+                init_bias<PMT_NT>(s1, c.packed + uniform(L1.b_pvec), width, c.g);
+                linear_acc<PMT_NT, PMT_NT, false>(s1, s0, c.packed + uniform(L1.w_frag), width, width, c.mask_all);
+#pragma unroll
+                for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                    for (int t = 0; t < PMT_NT; ++t) s1[rt][t] = selu4(s1[rt][t]);
+            } else {
+#pragma unroll
+                for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                    for (int t = 0; t < PMT_NT; ++t) s1[rt][t] = s0[rt][t];
+            }
+            {   // d(alpha) = sum dy . f,  f = L2 s1 + b2
+                f4 f[PMT_RT][PMT_NT];
+                init_bias<PMT_NT>(f, c.packed + uniform(L2.b_pvec), width, c.g);
+                linear_acc<PMT_NT, PMT_NT, false>(f, s1, c.packed + uniform(L2.w_frag), width, width, c.mask_all);
+                float da = 0.f;
+#pragma unroll
+                for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                    for (int t = 0; t < PMT_NT; ++t) da += (dy[rt][t][0] * f[rt][t][0] + dy[rt][t][1] * f[rt][t][1]) + (dy[rt][t][2] * f[rt][t][2] + dy[rt][t][3] * f[rt][t][3]);
+                scalar_grad_atomic(c.gtheta + uniform(o.alpha_src), da);
+            }
+            // last layer: d(f) = alpha * dy
+            linear_wgrad<PMT_NT, PMT_NT>(c, L2, dy, s1, c.mask_all, alpha);
+            f4 d1[PMT_RT][PMT_NT];
+            init_bias<PMT_NT>(d1, nullptr, width, c.g);
+            linear_acc<PMT_NT, PMT_NT, false>(d1, dy, c.packed + uniform(L2.wt_frag), width, width, c.mask_all);
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                for (int t = 0; t < PMT_NT; ++t) d1[rt][t] = alpha * selu_bwd4(d1[rt][t], s1[rt][t]);  // d(h1) (n=2) or d(x) part (n=1)
+            if (nl == 2) {
+                linear_wgrad<PMT_NT, PMT_NT>(c, L1, d1, s0, c.mask_all);
+                f4 d0[PMT_RT][PMT_NT];
+                init_bias<PMT_NT>(d0, nullptr, width, c.g);
+                linear_acc<PMT_NT, PMT_NT, false>(d0, d1, c.packed + uniform(L1.wt_frag), width, width, c.mask_all);
+#pragma unroll
+                for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                    for (int t = 0; t < PMT_NT; ++t) dy[rt][t] = dy[rt][t] + selu_bwd4(d0[rt][t], s0[rt][t]);
+            } else {
+#pragma unroll
+                for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                    for (int t = 0; t < PMT_NT; ++t) dy[rt][t] = dy[rt][t] + d1[rt][t];
+            }
+        }
+    }
+}
+
+DEV float read_feature_b(const unsigned char* __restrict__ row, int fmt, int f, int F) {
+    if (f >= F) return 0.f;
+    if (fmt == PMT_READS_PACKED_U8) {
+        if (f < 56) return (float)((row[f >> 3] >> (7 - (f & 7))) & 1);
+        const unsigned u = row[7 + (f - 56)];
+        return (float)((u + 128u) & 0xFFu) * (1.0f / 32.0f);
+    } else if (fmt == PMT_READS_F16) {
+        return (float)reinterpret_cast<const _Float16*>(row)[f];
+    }
+    return reinterpret_cast<const float*>(row)[f];
+}
+
+__global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
+    const PmtModel* __restrict__ M, const float* __restrict__ theta, const float* __restrict__ phi,
+    const float* __restrict__ packed, PmtBatch bt, PmtOutputs out, PmtOutputGrads dout, const float* __restrict__ stash,
+    const float* __restrict__ zsum_stash, float* __restrict__ gtheta, float* __restrict__ gphi,
+    float* __restrict__ gvar) {
+    __shared__ __attribute__((aligned(16))) BwdShared sh;
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, wave = uniform((int)(tid >> 6));
+    const GroupGeom gg = group_geometry(bt, blockIdx.x);
+    const int D = uniform(M->d_model), E = uniform(M->feature_dim), K = uniform(M->num_clusters);
+    const int Er = uniform(M->read_embed_dim), Ev = uniform(M->variant_embed_dim);
+    const int h = uniform(M->d_ffn) >> 1, L = uniform(M->num_blocks), F = uniform(M->num_read_features);
+    const int nte = (E + 15) >> 4;
+
+    // ---- setup ------------------------------------------------------------------------------------------------------
+    for (int i = tid; i <= gg.nsets; i += PMT_THREADS) {
+        sh.off[0][i] = bt.ref_offsets[gg.v0 + i] - gg.ref_base;
+        sh.off[1][i] = bt.alt_offsets[gg.v0 + i] - gg.alt_base;
+    }
+    for (int i = tid; i < 2 * (WG_TILE + PMT_MAX_WIDTH); i += PMT_THREADS) (&sh.wg[0][0])[i] = 0.f;
+    for (int i = tid; i < PMT_GROUP_MAX_SETS * PMT_MAX_WIDTH; i += PMT_THREADS) (&sh.dv[0][0])[i] = 0.f;
+    for (int i = tid; i < PMT_GROUP_MAX_SETS * 32; i += PMT_THREADS) (&sh.gsum[0][0][0])[i] = 0.f;
+    __syncthreads();
+    // per-set upstream gradients (reference feature_clustering.py:121-135 differentiated)
+    for (int i = tid; i < gg.nsets; i += PMT_THREADS) {
+        const int b = gg.v0 + i;
+        const float* lk = out.logits_bk + (size_t)b * (K + 2);
+        const float dlogit = dout.d_logits_b ? dout.d_logits_b[b] : 0.f;
+        const float capped = out.logits_b[b];
+        const float th = capped / PMT_MAX_LOGIT_F;
+        const float draw = dlogit * (1.f - th * th);
+        float mx = -INFINITY;
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, lk[2 + k]);
+        float se = 0.f;
+        for (int k = 0; k < K; ++k) se += expf(lk[2 + k] - mx);
+        const float* dk = dout.d_logits_bk ? dout.d_logits_bk + (size_t)b * (K + 2) : nullptr;
+        sh.dl[i][0] = (dk ? dk[0] : 0.f) - draw;
+        sh.dl[i][1] = dk ? dk[1] : 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float v = (dk ? dk[2 + k] : 0.f) + draw * expf(lk[2 + k] - mx) / se;
+            sh.dl[i][2 + k] = v;
+            atomicAdd(&gphi[M->head.log_w_k_phi + k], v);
+        }
+    }
+    for (int i = tid; i < gg.nsets * 2 * PMT_MAX_WIDTH; i += PMT_THREADS) {
+        const int set = i / (2 * PMT_MAX_WIDTH), rem = i - set * 2 * PMT_MAX_WIDTH, s = rem / PMT_MAX_WIDTH, p = rem - s * PMT_MAX_WIDTH;
+        const int f = pos_to_feat(p);
+        const float* src = s == 1 ? dout.d_features_be : dout.d_ref_features_be;
+        const float n = (float)(sh.off[s][set + 1] - sh.off[s][set]);
+        sh.dfeat[set][s][p] = (src && f < E) ? src[(size_t)(gg.v0 + set) * E + f] / (n + 1e-4f) : 0.f;
+    }
+    __syncthreads();
+
+    TileMeta tm[PMT_RT];
+    unsigned mask_all = 0, mask_side[2] = {0, 0};
+    const float* stash_tile[PMT_RT];
+    const int nslots = stash_num_slots(M);
+#pragma unroll
+    for (int rt = 0; rt < PMT_RT; ++rt) {
+        tm[rt] = tile_meta(gg, rt, &sh.off[0][0]);
+        if (tm[rt].side >= 0) {
+            mask_all |= 1u << rt;
+            if (tm[rt].side == 0) mask_side[0] |= 1u << rt; else mask_side[1] |= 1u << rt;
+        }
+        stash_tile[rt] = stash + (size_t)(bt.group_tile_base[blockIdx.x] + gg.tile_begin + rt) * (size_t)(nslots * PMT_SLOT_FLOATS);
+    }
+    BwdCtx c{M, theta, phi, packed, gtheta, gphi, &sh, &sh.tr[wave][0], g, mask_all, 0};
+    const int n_read_ops = uniform(M->read_mlp.n_ops), n_red_ops = uniform(M->reducer.n_ops);
+    const int slot_x0 = n_read_ops - 1, slot_red = slot_x0 + L + 1;
+
+    auto load_slot = [&](int slot, f4 (&v)[PMT_RT][PMT_NT]) {
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt) {
+            if (mask_all & (1u << rt)) {
+                stash_load<PMT_NT>(stash_tile[rt] + slot * PMT_SLOT_FLOATS, v[rt]);
+            } else {
+#pragma unroll
+                for (int t = 0; t < PMT_NT; ++t) v[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+
+    // ---- recompute the tail of the forward: last reducer op, translation, rotation -> a ----------------------------
+    f4 dy[PMT_RT][PMT_NT];  // running gradient
+    {
+        f4 r[PMT_RT][PMT_NT];
+        load_slot(n_red_ops > 1 ? slot_red + (n_red_ops - 2) : slot_x0 + L, r);
+        {   // forward of the last reducer op only
+            const PmtOp& o = M->reducer.ops[n_red_ops - 1];
+            f4 y[PMT_RT][PMT_NT];
+            if (uniform(o.kind) == PMT_OP_LINEAR) {
+                const PmtLinear& Lr = M->lin[uniform(o.lin[0])];
+                init_bias<PMT_NT>(y, uniform(Lr.b_pvec) >= 0 ? packed + uniform(Lr.b_pvec) : nullptr, uniform(Lr.out_dim), g);
+                linear_acc<PMT_NT, PMT_NT, false>(y, r, packed + uniform(Lr.w_frag), uniform(Lr.in_dim), uniform(Lr.out_dim), mask_all);
+                const bool act = uniform(o.selu_after) != 0;
+#pragma unroll
+                for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                    for (int t = 0; t < PMT_NT; ++t) r[rt][t] = act ? selu4(y[rt][t]) : y[rt][t];
+            } else {
+                const int nl = uniform(o.n_layers);
+                const PmtLinear& L1 = M->lin[uniform(o.lin[0])];
+                const PmtLinear& L2 = M->lin[uniform(o.lin[nl - 1])];
+                const int width = uniform(L1.in_dim);
+                const float alpha = uniform(theta[uniform(o.alpha_src)]);
+                if (nl == 2) {
+                    init_bias<PMT_NT>(y, packed + uniform(L1.b_pvec), width, g);
+                    linear_acc<PMT_NT, PMT_NT, true>(y, r, packed + uniform(L1.w_frag), width, width, mask_all);
+                } else {
+#pragma unroll
+                    for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                        for (int t = 0; t < PMT_NT; ++t) y[rt][t] = r[rt][t];
+                }
+#pragma unroll
+                for (int t = 0; t < PMT_NT; ++t) {
+                    const f4 b = alpha * load_pvec(packed + uniform(L2.b_pvec), t, g);
+#pragma unroll
+                    for (int rt = 0; rt < PMT_RT; ++rt) r[rt][t] = r[rt][t] + b;
+                }
+                linear_acc<PMT_NT, PMT_NT, true>(r, y, packed + uniform(L2.w_frag), width, width, mask_all, alpha);
+            }
+        }
+        const PmtLinear& R = M->lin[uniform(M->rotation_lin)];
+        f4 a[PMT_RT][PMT_NT];
+#pragma unroll
+        for (int t = 0; t < PMT_NT; ++t) {
+            const f4 tr = load_pvec(packed + uniform(M->translation_pvec), t, g);
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt) {
+                r[rt][t] = r[rt][t] + tr;  // r + t, the rotation's input
+                a[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        linear_acc<PMT_NT, PMT_NT, false>(a, r, packed + uniform(R.w_frag), E, E, mask_all);
+
+        // ---- head backward (alt reads) + set-mean gradients -> d(a) in dy ------------------------------------------
+        f4 sig[PMT_NT], dsig[PMT_NT];
+#pragma unroll
+        for (int t = 0; t < PMT_NT; ++t) {
+            sig[t] = f4{1.f, 1.f, 1.f, 1.f};
+            dsig[t] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (t < nte && feat_of(t, j, g) < E) sig[t][j] = phi[uniform(M->head.stdev_e_phi) + feat_of(t, j, g)];
+        }
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt) {
+            const int set = tm[rt].set, s = tm[rt].side;
+#pragma unroll
+            for (int t = 0; t < PMT_NT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    dy[rt][t][j] = (tm[rt].valid && t < nte) ? sh.dfeat[set][s == 1 ? 1 : 0][16 * t + 4 * g + j] : 0.f;
+        }
+        for (int k = -1; k < K; ++k) {  // k = -1: the two diagonal Gaussians; k >= 0: artifact cluster k
+            f4 v[PMT_NT], dvk[PMT_NT];
+            float d_tau = 0.f, d_mu = 0.f, d_lam = 0.f, d_sg = 0.f;
+            float tau = 1.f, mu = 0.f, sg = 1.f, lam = 1.f;
+            if (k >= 0) {
+                tau = uniform(phi[uniform(M->head.art_stdev_k_phi) + k]);
+                mu = uniform(theta[uniform(M->head.mu_k_src) + k]);
+                sg = uniform(phi[uniform(M->head.sigma_k_phi) + k]);
+                lam = uniform(phi[uniform(M->head.lambda_k_phi) + k]);
+            }
+#pragma unroll
+            for (int t = 0; t < PMT_NT; ++t) {
+                v[t] = f4{0.f, 0.f, 0.f, 0.f};
+                dvk[t] = f4{0.f, 0.f, 0.f, 0.f};
+                if (k >= 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (t < nte && feat_of(t, j, g) < E) v[t][j] = phi[uniform(M->head.dirs_ke_phi) + k * E + feat_of(t, j, g)];
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt) {
+                if (!(mask_side[1] & (1u << rt))) continue;
+                const int set = tm[rt].set;
+                const bool ok = tm[rt].valid;
+                if (k < 0) {
+                    const float g0 = ok ? sh.dl[set][0] : 0.f, g1 = ok ? sh.dl[set][1] : 0.f;
+#pragma unroll
+                    for (int t = 0; t < PMT_NT; ++t)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (t < nte && feat_of(t, j, g) < E) {
+                                const float av = a[rt][t][j], sv = sig[t][j], inv2 = 1.f / (sv * sv);
+                                dy[rt][t][j] += -(g0 + 0.25f * g1) * av * inv2;
+                                dsig[t][j] += g0 * (-1.f / sv + av * av * inv2 / sv) + g1 * (-1.f / sv + 0.25f * av * av * inv2 / sv);
+                            }
+                    continue;
+                }
+                const float G = ok ? sh.dl[set][2 + k] : 0.f;
+                float p = 0.f;
+#pragma unroll
+                for (int t = 0; t < PMT_NT; ++t) p += (a[rt][t][0] * v[t][0] + a[rt][t][1] * v[t][1]) + (a[rt][t][2] * v[t][2] + a[rt][t][3] * v[t][3]);
+                p = group_sum(p);
+                float o2 = 0.f, eu = 0.f;
+#pragma unroll
+                for (int t = 0; t < PMT_NT; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float e = a[rt][t][j] - p * v[t][j];
+                        o2 += e * e;
+                        eu += e * v[t][j];
+                    }
+                o2 = group_sum(o2);
+                eu = group_sum(eu);
+                const float var = sg * sg;
+                const float zz = (mu + lam * var - p) / (1.4142135623730951f * sg);
+                const float Lp = dlogerfc_dev(zz);
+                const float demg_dp = -Lp / (1.4142135623730951f * sg) - lam;
+                const float c_o = -G / (2.f * tau * tau);  // d(loss)/d(o2)
+#pragma unroll
+                for (int t = 0; t < PMT_NT; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (t < nte && feat_of(t, j, g) < E) {
+                            const float e = a[rt][t][j] - p * v[t][j];
+                            dy[rt][t][j] += c_o * (2.f * e - 2.f * eu * v[t][j]) + G * demg_dp * v[t][j];
+                            dvk[t][j] += c_o * (-2.f * eu * a[rt][t][j] - 2.f * p * e) + G * demg_dp * a[rt][t][j];
+                        }
+                if (g == 0) {  // scalar parameter gradients: once per read
+                    d_tau += G * (-(float)(E - 1) / tau + o2 / (tau * tau * tau));
+                    d_mu += G * (Lp / (1.4142135623730951f * sg) + lam);
+                    d_lam += G * (1.f / lam + Lp * sg * 0.7071067811865476f + mu + lam * var - p);
+                    d_sg += G * (Lp * (-(mu - p) / (1.4142135623730951f * var) + lam * 0.7071067811865476f) + lam * lam * sg);
+                }
+            }
+            if (k >= 0 && mask_side[1]) {
+                vec_grad_atomic<PMT_NT>(gphi + uniform(M->head.dirs_ke_phi) + k * E, dvk, E, g);
+                scalar_grad_atomic(gphi + uniform(M->head.art_stdev_k_phi) + k, d_tau);
+                scalar_grad_atomic(gtheta + uniform(M->head.mu_k_src) + k, d_mu);
+                scalar_grad_atomic(gphi + uniform(M->head.lambda_k_phi) + k, d_lam);
+                scalar_grad_atomic(gphi + uniform(M->head.sigma_k_phi) + k, d_sg);
+            }
+        }
+        if (mask_side[1]) vec_grad_atomic<PMT_NT>(gphi + uniform(M->head.stdev_e_phi), dsig, E, g);
+
+        // ---- rotation + translation backward: a = Q (r + t) ------------------------------------------------------------
+        linear_wgrad<PMT_NT, PMT_NT>(c, R, dy, r, mask_all);
+        f4 dx[PMT_RT][PMT_NT];
+        init_bias<PMT_NT>(dx, nullptr, E, g);
+        linear_acc<PMT_NT, PMT_NT, false>(dx, dy, packed + uniform(R.wt_frag), E, E, mask_all);
+        f4 dt[PMT_NT];
+#pragma unroll
+        for (int t = 0; t < PMT_NT; ++t) {
+            dt[t] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt) {
+                dy[rt][t] = dx[rt][t];
+                dt[t] = dt[t] + dx[rt][t];
+            }
+        }
+        if (mask_all) vec_grad_atomic<PMT_NT>(gtheta + uniform(M->translation_src), dt, E, g);
+    }
+
+    // ---- reducer backward ---------------------------------------------------------------------------------------------
+    mlp_backward(c, M->reducer, dy, true, [&](int op, f4 (&x)[PMT_RT][PMT_NT]) { load_slot(op == 0 ? slot_x0 + L : slot_red + op - 1, x); });
+
+    // ---- gated blocks backward -----------------------------------------------------------------------------------------
+    for (int l = L - 1; l >= 0; --l) {
+        const PmtBlock& B = M->blocks[l];
+        f4 x[PMT_RT][PMT_NT];
+        load_slot(slot_x0 + l, x);
+        f4 lw[PMT_NT], lb[PMT_NT];
+#pragma unroll
+        for (int t = 0; t < PMT_NT; ++t) {
+            lw[t] = load_pvec(packed + uniform(B.norm_w_pvec), t, g);
+            lb[t] = load_pvec(packed + uniform(B.norm_b_pvec), t, g);
+        }
+        // recompute: n = LN(x) (kept as xhat + rstd), z = selu(W1 n + b1)
+        f4 xhat[PMT_RT][PMT_NT], z[PMT_RT][2];
+        float rstd[PMT_RT];
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt) z[rt][0] = z[rt][1] = f4{0.f, 0.f, 0.f, 0.f};  // absent tiles stay finite
+        {
+            f4 n[PMT_RT][PMT_NT];
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt) layernorm_tile<PMT_NT>(n[rt], xhat[rt], rstd[rt], x[rt], D, lw, lb, g);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                if (mask_side[s]) {
+                    const PmtLinear& P1 = M->lin[uniform(B.proj1[s])];
+                    const f4 b0 = load_pvec(packed + uniform(P1.b_pvec), 0, g), b1 = load_pvec(packed + uniform(P1.b_pvec), 1, g);
+#pragma unroll
+                    for (int rt = 0; rt < PMT_RT; ++rt)
+                        if (mask_side[s] & (1u << rt)) { z[rt][0] = b0; z[rt][1] = b1; }
+                    linear_acc<PMT_NT, 2, false>(z, n, packed + uniform(P1.w_frag), D, 16 + h, mask_side[s]);
+                }
+        }
+        const f4 sw = load_pvec(packed + uniform(B.sgu_norm_w_pvec), 0, g), sb = load_pvec(packed + uniform(B.sgu_norm_b_pvec), 0, g);
+        const float w = uniform(phi[uniform(B.reg_weight_phi)]) + 0.25f;
+        const f4 rho = load_pvec(packed + uniform(B.ref_reg_pvec), 0, g);
+        const float alpha_ref = uniform(theta[uniform(B.alpha_src[0])]), alpha_alt = uniform(theta[uniform(B.alpha_src[1])]);
+        const float beta_ref = uniform(theta[uniform(B.beta_src[0])]), beta_alt = uniform(theta[uniform(B.beta_src[1])]);
+        const float gamma = uniform(theta[uniform(B.gamma_src)]);
+        f4 z2hat[PMT_RT], z2[PMT_RT], gate[PMT_RT], dgate[PMT_RT], du[PMT_RT][1];
+        float rstd2[PMT_RT];
+        float d_alpha[2] = {0.f, 0.f}, d_beta[2] = {0.f, 0.f}, d_gamma = 0.f;
+        // d(u) = W2^T dy ; weight gradient of proj2 needs u = z1 * gate
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt) du[rt][0] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            if (mask_side[s]) linear_acc<PMT_NT, 1, false>(du, dy, packed + uniform(M->lin[uniform(B.proj2[s])].wt_frag), D, h, mask_side[s]);
+        f4 u[PMT_RT][1];
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt) {
+            z[rt][0] = selu4(z[rt][0]);
+            z[rt][1] = selu4(z[rt][1]);
+            f4 zin[1] = {z[rt][1]}, zo[1], zh[1], sw1[1] = {sw}, sb1[1] = {sb};
+            layernorm_tile<1>(zo, zh, rstd2[rt], zin, h, sw1, sb1, g);
+            z2[rt] = zo[0];
+            z2hat[rt] = zh[0];
+            const int set = tm[rt].set, s = tm[rt].side;
+            const float n_ref = (float)(sh.off[0][set + 1] - sh.off[0][set]);
+            const float n_alt = (float)(sh.off[1][set + 1] - sh.off[1][set]);
+            const float* zs = zsum_stash + ((size_t)(gg.v0 + set) * L + l) * 32;
+            const f4 m_ref = (*reinterpret_cast<const f4*>(zs + 4 * g) + w * rho) / (n_ref + w);
+            const f4 m_alt = *reinterpret_cast<const f4*>(zs + 16 + 4 * g) / (n_alt + 1e-4f);
+            f4 gt = z2[rt] * (s == 0 ? alpha_ref : alpha_alt) + 1.0f;
+            gt = s == 0 ? gt + beta_ref * m_ref : (gt + beta_alt * m_alt) + gamma * m_ref;
+            gate[rt] = gt;
+            u[rt][0] = z[rt][0] * gt;
+            const bool ok = tm[rt].valid;
+            dgate[rt] = ok ? du[rt][0] * z[rt][0] : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dg = (feat_of(0, j, g) < h) ? dgate[rt][j] : 0.f;
+                dgate[rt][j] = dg;
+                if (s == 0) {
+                    d_alpha[0] += dg * z2[rt][j];
+                    d_beta[0] += dg * m_ref[j];
+                } else if (s == 1) {
+                    d_alpha[1] += dg * z2[rt][j];
+                    d_beta[1] += dg * m_alt[j];
+                    d_gamma += dg * m_ref[j];
+                }
+                if (ok && feat_of(0, j, g) < h) atomicAdd(&sh.gsum[set][s][4 * g + j], dg);
+            }
+        }
+        // proj2 weight gradients (per side), then the barrier inside makes gsum complete as well
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const PmtLinear& P2 = M->lin[uniform(B.proj2[s])];
+            float* buf = sh.wg[c.wg_flip];
+            wgrad_accumulate<PMT_NT, 1>(buf, c.tr, dy, u, D, h, mask_side[s], true);
+            __syncthreads();
+            wgrad_flush(buf, P2, 1.0f, gtheta, gphi);
+            c.wg_flip ^= 1;
+        }
+        // per-set coupling: d(m_ref), d(m_alt), d(ref_regularizer), d(reg_weight)
+        for (int i = tid; i < gg.nsets * 16; i += PMT_THREADS) {
+            const int set = i >> 4, p = i & 15, f = pos_to_feat(p);
+            const float n_ref = (float)(sh.off[0][set + 1] - sh.off[0][set]);
+            const float n_alt = (float)(sh.off[1][set + 1] - sh.off[1][set]);
+            const float gr = sh.gsum[set][0][p], ga = sh.gsum[set][1][p];
+            const float dm_ref = beta_ref * gr + gamma * ga, dm_alt = beta_alt * ga;
+            sh.dmean[set][0][p] = dm_ref / (n_ref + w);
+            sh.dmean[set][1][p] = dm_alt / (n_alt + 1e-4f);
+            if (f < h) {
+                const float* zs = zsum_stash + ((size_t)(gg.v0 + set) * L + l) * 32;
+                const float rho_f = theta[B.ref_reg_src + f];
+                const float m_ref = (zs[p] + w * rho_f) / (n_ref + w);
+                atomicAdd(&gtheta[B.ref_reg_src + f], dm_ref * w / (n_ref + w));
+                atomicAdd(&gphi[B.reg_weight_phi], dm_ref * (rho_f - m_ref) / (n_ref + w));
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS) (&sh.gsum[0][0][0])[i] = 0.f;
+        // finish d(z2), LayerNorm(h) backward, SELU backward -> d(zpre) in dz (2 tiles)
+        f4 dz[PMT_RT][2];
+        f4 dsw[1] = {f4{0.f, 0.f, 0.f, 0.f}}, dsb[1] = {f4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt) {
+            const int set = tm[rt].set, s = tm[rt].side;
+            const bool ok = tm[rt].valid;
+            f4 dz2 = dgate[rt] * (s == 0 ? alpha_ref : alpha_alt);
+            const f4 dm = *reinterpret_cast<const f4*>(&sh.dmean[set][s == 1 ? 1 : 0][4 * g]);
+            if (ok) dz2 = dz2 + dm;
+            f4 dz2v[1] = {dz2}, zh[1] = {z2hat[rt]}, sw1[1] = {sw}, dxr[1];
+            layernorm_bwd_tile<1>(dxr, dz2v, zh, rstd2[rt], h, sw1, dsw, dsb, g);
+            const f4 dz1 = ok ? du[rt][0] * gate[rt] : f4{0.f, 0.f, 0.f, 0.f};
+            dz[rt][0] = selu_bwd4(dz1, z[rt][0]);
+            dz[rt][1] = selu_bwd4(dxr[0], z[rt][1]);
+        }
+        if (mask_all) {
+            vec_grad_atomic<1>(gtheta + uniform(B.sgu_norm_w_src), dsw, h, g);
+            vec_grad_atomic<1>(gtheta + uniform(B.sgu_norm_b_src), dsb, h, g);
+            scalar_grad_atomic(gtheta + uniform(B.alpha_src[0]), d_alpha[0]);
+            scalar_grad_atomic(gtheta + uniform(B.alpha_src[1]), d_alpha[1]);
+            scalar_grad_atomic(gtheta + uniform(B.beta_src[0]), d_beta[0]);
+            scalar_grad_atomic(gtheta + uniform(B.beta_src[1]), d_beta[1]);
+            scalar_grad_atomic(gtheta + uniform(B.gamma_src), d_gamma);
+        }
+        // proj1: weight gradients need n = xhat * lw + lb again; then d(n) = W1^T d(zpre)
+        f4 dn[PMT_RT][PMT_NT];
+        {
+            f4 n[PMT_RT][PMT_NT];
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                for (int t = 0; t < PMT_NT; ++t) n[rt][t] = xhat[rt][t] * lw[t] + lb[t];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const PmtLinear& P1 = M->lin[uniform(B.proj1[s])];
+                float* buf = sh.wg[c.wg_flip];
+                wgrad_accumulate<2, PMT_NT>(buf, c.tr, dz, n, 16 + h, D, mask_side[s], true);
+                __syncthreads();
+                wgrad_flush(buf, P1, 1.0f, gtheta, gphi);
+                c.wg_flip ^= 1;
+            }
+        }
+        init_bias<PMT_NT>(dn, nullptr, D, g);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            if (mask_side[s]) linear_acc<2, PMT_NT, false>(dn, dz, packed + uniform(M->lin[uniform(B.proj1[s])].wt_frag), 16 + h, D, mask_side[s]);
+        // LayerNorm(D) backward, add to the residual gradient
+        f4 dlw[PMT_NT], dlb[PMT_NT];
+#pragma unroll
+        for (int t = 0; t < PMT_NT; ++t) { dlw[t] = f4{0.f, 0.f, 0.f, 0.f}; dlb[t] = f4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt) {
+            f4 dxr[PMT_NT];
+            layernorm_bwd_tile<PMT_NT>(dxr, dn[rt], xhat[rt], rstd[rt], D, lw, dlw, dlb, g);
+#pragma unroll
+            for (int t = 0; t < PMT_NT; ++t) dy[rt][t] = dy[rt][t] + dxr[t];
+        }
+        if (mask_all) {
+            vec_grad_atomic<PMT_NT>(gtheta + uniform(B.norm_w_src), dlw, D, g);
+            vec_grad_atomic<PMT_NT>(gtheta + uniform(B.norm_b_src), dlb, D, g);
+        }
+    }
+
+    // ---- split d(x_0): variant-embedding part -> per-set sums; read-embedding part -> read MLP backward --------------
+#pragma unroll
+    for (int rt = 0; rt < PMT_RT; ++rt) {
+        const int set = tm[rt].set;
+#pragma unroll
+        for (int t = 0; t < PMT_NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int f = feat_of(t, j, g);
+                if (f >= Er) {
+                    if (tm[rt].valid && f < D) atomicAdd(&sh.dv[set][f - Er], dy[rt][t][j]);
+                    dy[rt][t][j] = 0.f;
+                }
+            }
+    }
+    const int fmt = bt.read_format;
+    mlp_backward(c, M->read_mlp, dy, false, [&](int op, f4 (&x)[PMT_RT][PMT_NT]) {
+        if (op > 0) {
+            load_slot(op - 1, x);
+            return;
+        }
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt) {
+            const unsigned char* rowp = nullptr;
+            if (tm[rt].valid) {
+                const long long src = bt.read_index ? bt.read_index[tm[rt].row] : (long long)tm[rt].row;
+                rowp = reinterpret_cast<const unsigned char*>(bt.reads) + (size_t)src * (size_t)bt.read_row_bytes;
+            }
+#pragma unroll
+            for (int t = 0; t < PMT_NT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[rt][t][j] = rowp ? read_feature_b(rowp, fmt, feat_of(t, j, g), F) : 0.f;
+        }
+    });
+    __syncthreads();
+    for (int i = tid; i < gg.nsets * Ev; i += PMT_THREADS) {
+        const int set = i / Ev, f = i - set * Ev;
+        gvar[(size_t)(gg.v0 + set) * Ev + f] = sh.dv[set][f];
+    }
+}
+
 extern "C" int pmt_backward(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* phi,
-                            const float* packed, const PmtBatch* batch, const PmtOutputGrads* dout, const float* stash,
-                            float* grad_theta, float* grad_phi, float* grad_variant_embed, void* stream) {
-    return PMT_E_UNSUPPORTED;
+                            const float* packed, const PmtBatch* batch, const PmtOutputs* out, const PmtOutputGrads* dout,
+                            const float* stash, float* grad_theta, float* grad_phi, float* grad_variant_embed,
+                            void* stream) {
+    if (!model_host || !model_dev || !batch || !out || !dout || !stash || !grad_theta || !grad_phi || !grad_variant_embed)
+        return PMT_E_INVALID;
+    const int rc = pmt_model_check(model_host);
+    if (rc != PMT_OK) return rc;
+    if (batch->num_groups <= 0) return batch->num_groups == 0 ? PMT_OK : PMT_E_INVALID;
+    if (!batch->reads || !batch->ref_offsets || !batch->alt_offsets || !batch->group_start || !batch->group_tile_base ||
+        batch->total_tiles <= 0 || !out->logits_b || !out->logits_bk)
+        return PMT_E_INVALID;
+    const float* zsum_stash = stash + (size_t)batch->total_tiles * (size_t)pmt_stash_slots(model_host) * PMT_SLOT_FLOATS;
+    hipLaunchKernelGGL(pmt_backward_kernel, dim3(batch->num_groups), dim3(PMT_THREADS), 0,
+                       reinterpret_cast<hipStream_t>(stream), model_dev, theta, phi, packed, *batch, *out, *dout, stash,
+                       zsum_stash, grad_theta, grad_phi, grad_variant_embed);
+    return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }

@@ -118,7 +118,7 @@ def load() -> C.CDLL:
     lib.pmt_pack_params.argtypes = [P(PmtModel), vp, vp, vp, vp, vp]
     lib.pmt_scan_counts.argtypes = [vp, vp, i32, i64, i32, vp, vp, vp]
     lib.pmt_forward.argtypes = [P(PmtModel), vp, vp, vp, vp, P(PmtBatch), P(PmtOutputs), vp, vp]
-    lib.pmt_backward.argtypes = [P(PmtModel), vp, vp, vp, vp, P(PmtBatch), P(PmtOutputGrads), vp, vp, vp, vp, vp]
+    lib.pmt_backward.argtypes = [P(PmtModel), vp, vp, vp, vp, P(PmtBatch), P(PmtOutputs), P(PmtOutputGrads), vp, vp, vp, vp, vp]
     lib.pmt_clip_adamw.argtypes = [vp, vp, vp, vp, i64, P(PmtAdamW), vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)

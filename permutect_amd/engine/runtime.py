@@ -95,16 +95,17 @@ class ReadSetEngine:
                                      _ptr(stash), _stream()), "pmt_forward")
         return (logits_b, logits_bk, feats, ref_feats), stash, variant_embed, phi
 
-    def backward(self, batch, phi: Tensor, variant_embed: Tensor, stash: Tensor, grads):
+    def backward(self, batch, phi: Tensor, variant_embed: Tensor, stash: Tensor, outs, grads):
         d = self.plan.desc
         bv, keep, plan = self.batch_view(batch, variant_embed)
         g = [None if t is None else t.contiguous().float() for t in grads]
         dout = L.PmtOutputGrads(_ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]))
+        out = L.PmtOutputs(*[t.data_ptr() for t in outs])
         gphi = torch.zeros(d.phi_size, dtype=torch.float32, device=self.device)
         gvar = torch.zeros_like(variant_embed)
         L.check(self.lib.pmt_backward(C.byref(d), self.plan.desc_dev.data_ptr(), self.space.theta.data_ptr(),
-                                      phi.data_ptr(), self.plan.packed.data_ptr(), C.byref(bv), C.byref(dout),
-                                      stash.data_ptr(), self.space.gtheta.data_ptr(), gphi.data_ptr(),
+                                      phi.data_ptr(), self.plan.packed.data_ptr(), C.byref(bv), C.byref(out),
+                                      C.byref(dout), stash.data_ptr(), self.space.gtheta.data_ptr(), gphi.data_ptr(),
                                       gvar.data_ptr(), _stream()), "pmt_backward")
         return gphi, gvar
 
@@ -122,14 +123,14 @@ class ReadSetFunction(torch.autograd.Function):
         outs, stash, ve, ph = engine.forward(batch, phi.detach(), variant_embed.detach(), train)
         ctx.engine, ctx.batch, ctx.train = engine, batch, train
         if train:
-            ctx.save_for_backward(ph, ve, stash)
+            ctx.save_for_backward(ph, ve, stash, *outs)
         return outs
 
     @staticmethod
     def backward(ctx, d_logits_b, d_logits_bk, d_feats, d_ref_feats):
         if not ctx.train:
             return None, None, None, None
-        phi, ve, stash = ctx.saved_tensors
+        phi, ve, stash, *outs = ctx.saved_tensors
         ctx.engine.space.bind_grads()
-        gphi, gvar = ctx.engine.backward(ctx.batch, phi, ve, stash, (d_logits_b, d_logits_bk, d_feats, d_ref_feats))
+        gphi, gvar = ctx.engine.backward(ctx.batch, phi, ve, stash, outs, (d_logits_b, d_logits_bk, d_feats, d_ref_feats))
         return None, None, gphi, gvar

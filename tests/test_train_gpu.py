@@ -1,0 +1,94 @@
+"""GPU parity of one training step: fused HIP forward + backward (through autograd) + fused clip/AdamW against the
+reference's gradients and post-step parameters (golden fixtures).  Tolerances: global gradient vector
+1e-4 relative in L2; each tensor 5e-4 of max(its own scale, 1e-3 of the global scale); parameters after the step 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from permutect_amd.data.batch import Batch
+from permutect_amd.training.optimizer import FusedClipAdamW, backpropagate
+from tests.helpers import CASES, load_case
+from tests.test_forward_gpu import build
+
+pytestmark = pytest.mark.gpu
+
+
+def run_step(name, fmt="packed"):
+    z, sd, b = load_case(name)
+    model, dev = build(name, sd)
+    model.train(True)
+    if "source_strength" in z.files:
+        model.source_predictor.set_adversarial_strength(float(z["source_strength"]))
+    batch = Batch.from_arrays(b["int_array"], b["float_array"], b["packed_reads"]).copy_to(dev)
+    out = model.compute_batch_output(batch)
+    losses = model.compute_batch_losses(out, batch)
+    return z, model, out, losses
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_losses_match_reference(name):
+    z, model, out, losses = run_step(name)
+    for k in ("supervised_losses_b", "unsupervised_losses_b", "alt_count_losses_b", "source_prediction_losses_b",
+              "total_losses_b"):
+        ref = z["loss/" + k]
+        np.testing.assert_allclose(getattr(losses, k).detach().cpu().numpy(), ref, rtol=1e-4, atol=1e-4 + 1e-5 * np.abs(ref).max(), err_msg=k)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_gradients_match_reference(name):
+    z, model, out, losses = run_step(name)
+    opt = FusedClipAdamW(model, lr=float(z["lr"]), weight_decay=float(z["weight_decay"]))
+    opt.zero_grad()
+    losses.total_loss.backward()
+    torch.cuda.synchronize()
+    names = [n for n, _ in model.named_parameters()]
+    assert set(names) == {k[5:] for k in z.files if k.startswith("grad/")}
+    gref = np.concatenate([z["grad/" + n].ravel() for n in names])
+    gour = np.concatenate([p.grad.detach().cpu().numpy().ravel() for _, p in model.named_parameters()])
+    assert np.all(np.isfinite(gour))
+    gscale = np.abs(gref).max()
+    bad = []
+    for n, p in model.named_parameters():
+        ref = z["grad/" + n]
+        err = np.abs(p.grad.detach().cpu().numpy() - ref).max()
+        tol = 5e-4 * max(np.abs(ref).max(), 1e-3 * gscale)
+        if err > tol:
+            bad.append((n, float(err), float(np.abs(ref).max())))
+    assert not bad, bad[:12]
+    assert np.linalg.norm(gour - gref) <= 1e-4 * np.linalg.norm(gref)
+
+
+@pytest.mark.parametrize("name", ["t0_b8", "p0_b16", "p0_deep"])
+def test_fused_clip_adamw_kernel_on_reference_gradients(name):
+    """The optimizer kernel alone: fed the reference's raw gradients it must reproduce the reference's parameters after
+    clip_grad_norm_(1.0) + AdamW.step to fp32 rounding."""
+    z, sd, b = load_case(name)
+    model, dev = build(name, sd)
+    opt = FusedClipAdamW(model, lr=float(z["lr"]), weight_decay=float(z["weight_decay"]))
+    opt.zero_grad()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            p.grad.copy_(torch.from_numpy(z["grad/" + n]))
+    opt.step()
+    torch.cuda.synchronize()
+    ref_norm = float(np.sqrt(sum((z["grad/" + n].astype(np.float64) ** 2).sum() for n, _ in model.named_parameters())))
+    assert abs(float(opt.grad_norm.item()) - ref_norm) <= 1e-5 * ref_norm
+    for n, p in model.named_parameters():
+        np.testing.assert_allclose(p.detach().cpu().numpy(), z["after/" + n], rtol=1e-5, atol=1e-6, err_msg=n)
+
+
+@pytest.mark.parametrize("name", ["t0_b8", "p0_b16", "p0_deep"])
+def test_full_train_step_matches_reference(name):
+    """forward + losses + backward + clip + AdamW end to end.  The first Adam step is lr * g / (|g| + eps): elements whose
+    gradient is within a few orders of eps = 1e-8 amplify fp32 gradient noise, so the bound is 2% of one step (lr)."""
+    z, model, out, losses = run_step(name)
+    lr = float(z["lr"])
+    opt = FusedClipAdamW(model, lr=lr, weight_decay=float(z["weight_decay"]))
+    backpropagate(opt, losses.total_loss, params_to_clip=model.parameters())
+    torch.cuda.synchronize()
+    ref_norm = float(np.sqrt(sum((z["grad/" + n].astype(np.float64) ** 2).sum() for n, _ in model.named_parameters())))
+    assert abs(float(opt.grad_norm.item()) - ref_norm) <= 1e-4 * ref_norm
+    worst = 0.0
+    for n, p in model.named_parameters():
+        worst = max(worst, float(np.abs(p.detach().cpu().numpy() - z["after/" + n]).max()))
+    assert worst <= 0.02 * lr, worst
