@@ -33,7 +33,20 @@ class ReadSetEngine:
         self.device = device
         self.space = ParamSpace(model, device)
         self.plan = EnginePlan(model, self.space, device)
-        self._packed_key = None
+        self.timers = None  # bench.py sets {'pmt_forward': [], 'pmt_backward': []} to collect (start, end) HIP events
+
+    def _event_start(self):
+        if self.timers is None:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()  # on torch's current stream, which is the stream the kernel is launched on (_stream())
+        return ev
+
+    def _event_stop(self, name: str, start):
+        if start is not None:
+            end = torch.cuda.Event(enable_timing=True)
+            end.record()
+            self.timers[name].append((start, end))
 
     # ---- parameters -------------------------------------------------------------------------------------------------
     def pack(self, phi: Tensor):
@@ -90,9 +103,11 @@ class ReadSetEngine:
         if train:
             nbytes = self.lib.pmt_stash_bytes(C.byref(d), plan.total_tiles, b)
             stash = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+        ev = self._event_start()
         L.check(self.lib.pmt_forward(C.byref(d), self.plan.desc_dev.data_ptr(), self.space.theta.data_ptr(),
                                      phi.data_ptr(), self.plan.packed.data_ptr(), C.byref(bv), C.byref(out),
                                      _ptr(stash), _stream()), "pmt_forward")
+        self._event_stop("pmt_forward", ev)
         return (logits_b, logits_bk, feats, ref_feats), stash, variant_embed, phi
 
     def backward(self, batch, phi: Tensor, variant_embed: Tensor, stash: Tensor, outs, grads):
@@ -103,10 +118,12 @@ class ReadSetEngine:
         out = L.PmtOutputs(*[t.data_ptr() for t in outs])
         gphi = torch.zeros(d.phi_size, dtype=torch.float32, device=self.device)
         gvar = torch.zeros_like(variant_embed)
+        ev = self._event_start()
         L.check(self.lib.pmt_backward(C.byref(d), self.plan.desc_dev.data_ptr(), self.space.theta.data_ptr(),
                                       phi.data_ptr(), self.plan.packed.data_ptr(), C.byref(bv), C.byref(out),
                                       C.byref(dout), stash.data_ptr(), self.space.gtheta.data_ptr(), gphi.data_ptr(),
                                       gvar.data_ptr(), _stream()), "pmt_backward")
+        self._event_stop("pmt_backward", ev)
         return gphi, gvar
 
 
