@@ -43,6 +43,8 @@ extern "C" {
 #define PMT_MAX_SKIP_LAYERS 4
 #define PMT_MAX_BLOCKS 16
 #define PMT_MAX_LINEAR 96
+#define PMT_MAX_SCHED 192       /* entries of a weight-staging schedule */
+#define PMT_STAGE_FLOATS 4608   /* floats per LDS weight-staging buffer: 4096 of fragments + 512 of vectors */
 #define PMT_GROUP_WAVES 8       /* waves per workgroup */
 #define PMT_GROUP_TILES 16      /* 16-read tiles per group (8 waves x 2 tiles) */
 #define PMT_GROUP_MAX_SETS 64   /* read sets (variants) per group */
@@ -61,9 +63,17 @@ typedef struct PmtLinear {
     int32_t b_pvec;      /* packed: bias in tile-position order, -1 = no bias                       */
     int32_t w_src;       /* natural-layout source of W: offset into theta (>=0) or phi (<= -2: -(off+2)) */
     int32_t b_src;       /* same for the bias, -1 = none                                            */
+    int32_t w_stage;     /* floats staged into LDS with the forward fragments: [w_frag, w_frag + w_stage) holds the
+                            fragments, then this linear's bias (and, for a block's first projection, the block's
+                            per-feature vectors); a multiple of 256, <= PMT_STAGE_FLOATS.  For a ref/alt pair the
+                            ref linear's range covers both sides and the alt linear's w_stage is 0.             */
     int32_t out_split;   /* 0, or h: the 2h output rows are laid out as two 16-row tiles (rows 0..h-1 -> tile 0,
                             rows h..2h-1 -> tile 1) so that z1 / z2 of the gating unit are tile aligned       */
 } PmtLinear;
+
+typedef struct PmtStage {
+    int32_t off, n;     /* range [off, off + n) of the packed buffer, n a multiple of 256 and <= PMT_STAGE_FLOATS */
+} PmtStage;
 
 #define PMT_OP_LINEAR 0         /* y = W x + b, optional SELU after   (reference mlp.py:55-61)          */
 #define PMT_OP_SKIP 1           /* y = x + alpha * f(x), f = (SELU, Linear) x n   (reference mlp.py:15-22) */
@@ -127,6 +137,12 @@ typedef struct PmtModel {
     PmtBlock blocks[PMT_MAX_BLOCKS];
     PmtHead head;
     PmtLinear lin[PMT_MAX_LINEAR];
+    /* Weight-staging schedules (filled by pmt_build_schedules): the ranges of the packed buffer in the order the
+     * forward / backward kernels consume them.  The kernels DMA entry i+1 into LDS while computing with entry i.
+     * A wrong schedule costs speed, never correctness (the kernel re-stages synchronously and raises a debug flag). */
+    int32_t n_fwd_sched, n_bwd_sched;
+    PmtStage fwd_sched[PMT_MAX_SCHED];
+    PmtStage bwd_sched[PMT_MAX_SCHED];
 } PmtModel;
 
 /* Inputs of one forward / backward pass.  Reads are ordered as the reference's Batch orders them: all ref reads
@@ -144,6 +160,7 @@ typedef struct PmtBatch {
     const int32_t* group_start;     /* device [G+1] first variant of each group (pmt_plan_groups) */
     const int32_t* group_tile_base; /* device [G+1] first stash tile of each group (pmt_plan_groups) */
     int64_t total_tiles;            /* host value of group_tile_base[G] (sizes the stash)             */
+    int32_t* debug_flags;           /* device, optional [4]: [0] counts weight-staging schedule misses  */
 } PmtBatch;
 
 typedef struct PmtOutputs {
@@ -177,6 +194,9 @@ int pmt_struct_bytes(int which);
 
 /* Validates a descriptor against the kernels' limits. */
 int pmt_model_check(const PmtModel* model);
+
+/* Fills model->fwd_sched / bwd_sched from the rest of the descriptor (host, in place). */
+int pmt_build_schedules(PmtModel* model);
 
 /* Partition variants into register-resident groups: greedy over consecutive variants so that each group has
  * <= PMT_GROUP_TILES tiles (ceil(ref/16) + ceil(alt/16)) and <= PMT_GROUP_MAX_SETS sets.  Counts are HOST arrays

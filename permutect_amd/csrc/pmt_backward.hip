@@ -10,6 +10,10 @@
 //   set-coupled terms       : per-set sums of d(gate) go through LDS exactly like the forward's z2 sums.
 //
 // Replaces autograd over reference artifact_model.py:239-297 (misc_utils.py:127 `loss.backward()`).
+// Wave shape of this kernel: 4 waves x 4 read tiles, one wave per SIMD with the full 512-register budget.  The same
+// 16-tile groups as the forward (8 waves x 2 tiles); the activation stash is indexed by tile, not by wave.
+#define PMT_WAVES 4
+#define PMT_RT 4
 #include "pmt_device.hpp"
 
 #define TR_STRIDE 20  // floats per row of the per-wave transpose tile (16 + 4 pad: conflict-free b32 writes, 16B-aligned b128 reads)
@@ -23,7 +27,7 @@ struct BwdShared {
     float dfeat[PMT_GROUP_MAX_SETS][2][PMT_MAX_WIDTH];          // d(loss)/d(set mean) / (n + 1e-4), position order
     float dv[PMT_GROUP_MAX_SETS][PMT_MAX_WIDTH];                // per-set sum of d(x_0) (variant-embedding part)
     float wg[2][WG_TILE + PMT_MAX_WIDTH];                       // weight (+bias) gradient tiles, double buffered
-    float tr[PMT_GROUP_WAVES][16 * TR_STRIDE];                  // per-wave transpose scratch
+    float tr[PMT_WAVES][16 * TR_STRIDE];                  // per-wave transpose scratch
 };
 
 DEV float read_lanes_sum(float v) {  // sum over the 16 reads of a tile (lanes with equal lane >> 4)
@@ -244,17 +248,17 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][PMT_NT], bo
             if (uniform(o.selu_after) != 0) {  // recompute s = selu(Wx + b); dy <- dy * selu'(s)
                 f4 y[PMT_RT][PMT_NT];
                 init_bias<PMT_NT>(y, uniform(L.b_pvec) >= 0 ? c.packed + uniform(L.b_pvec) : nullptr, out_dim, c.g);
-                linear_acc<PMT_NT, PMT_NT, false>(y, x, c.packed + uniform(L.w_frag), in_dim, out_dim, c.mask_all);
+                linear_acc<PMT_NT, PMT_NT, false>(y, x, c.packed + uniform(L.w_frag), in_dim, out_dim, PMT_FULL_MASK);
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
                     for (int t = 0; t < PMT_NT; ++t) dy[rt][t] = selu_bwd4(dy[rt][t], selu4(y[rt][t]));
             }
-            linear_wgrad<PMT_NT, PMT_NT>(c, L, dy, x, c.mask_all);
+            linear_wgrad<PMT_NT, PMT_NT>(c, L, dy, x, PMT_FULL_MASK);
             if (op > 0 || need_input_grad) {
                 f4 dx[PMT_RT][PMT_NT];
                 init_bias<PMT_NT>(dx, nullptr, in_dim, c.g);
-                linear_acc<PMT_NT, PMT_NT, false>(dx, dy, c.packed + uniform(L.wt_frag), out_dim, in_dim, c.mask_all);
+                linear_acc<PMT_NT, PMT_NT, false>(dx, dy, c.packed + uniform(L.wt_frag), out_dim, in_dim, PMT_FULL_MASK);
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
@@ -274,7 +278,7 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][PMT_NT], bo
                 for (int t = 0; t < PMT_NT; ++t) s0[rt][t] = selu4(x[rt][t]);
             if (nl == 2) {
                 init_bias<PMT_NT>(s1, c.packed + uniform(L1.b_pvec), width, c.g);
-                linear_acc<PMT_NT, PMT_NT, false>(s1, s0, c.packed + uniform(L1.w_frag), width, width, c.mask_all);
+                linear_acc<PMT_NT, PMT_NT, false>(s1, s0, c.packed + uniform(L1.w_frag), width, width, PMT_FULL_MASK);
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
@@ -288,7 +292,7 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][PMT_NT], bo
             {   // d(alpha) = sum dy . f,  f = L2 s1 + b2
                 f4 f[PMT_RT][PMT_NT];
                 init_bias<PMT_NT>(f, c.packed + uniform(L2.b_pvec), width, c.g);
-                linear_acc<PMT_NT, PMT_NT, false>(f, s1, c.packed + uniform(L2.w_frag), width, width, c.mask_all);
+                linear_acc<PMT_NT, PMT_NT, false>(f, s1, c.packed + uniform(L2.w_frag), width, width, PMT_FULL_MASK);
                 float da = 0.f;
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
@@ -300,16 +304,16 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][PMT_NT], bo
             linear_wgrad<PMT_NT, PMT_NT>(c, L2, dy, s1, c.mask_all, alpha);
             f4 d1[PMT_RT][PMT_NT];
             init_bias<PMT_NT>(d1, nullptr, width, c.g);
-            linear_acc<PMT_NT, PMT_NT, false>(d1, dy, c.packed + uniform(L2.wt_frag), width, width, c.mask_all);
+            linear_acc<PMT_NT, PMT_NT, false>(d1, dy, c.packed + uniform(L2.wt_frag), width, width, PMT_FULL_MASK);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
                 for (int t = 0; t < PMT_NT; ++t) d1[rt][t] = alpha * selu_bwd4(d1[rt][t], s1[rt][t]);  // d(h1) (n=2) or d(x) part (n=1)
             if (nl == 2) {
-                linear_wgrad<PMT_NT, PMT_NT>(c, L1, d1, s0, c.mask_all);
+                linear_wgrad<PMT_NT, PMT_NT>(c, L1, d1, s0, PMT_FULL_MASK);
                 f4 d0[PMT_RT][PMT_NT];
                 init_bias<PMT_NT>(d0, nullptr, width, c.g);
-                linear_acc<PMT_NT, PMT_NT, false>(d0, d1, c.packed + uniform(L1.wt_frag), width, width, c.mask_all);
+                linear_acc<PMT_NT, PMT_NT, false>(d0, d1, c.packed + uniform(L1.wt_frag), width, width, PMT_FULL_MASK);
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
@@ -336,7 +340,7 @@ DEV float read_feature_b(const unsigned char* __restrict__ row, int fmt, int f, 
     return reinterpret_cast<const float*>(row)[f];
 }
 
-__global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
+__global__ __launch_bounds__(PMT_THREADS, 1) void pmt_backward_kernel(
     const PmtModel* __restrict__ M, const float* __restrict__ theta, const float* __restrict__ phi,
     const float* __restrict__ packed, PmtBatch bt, PmtOutputs out, PmtOutputGrads dout, const float* __restrict__ stash,
     const float* __restrict__ zsum_stash, float* __restrict__ gtheta, float* __restrict__ gphi,
@@ -395,10 +399,8 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
 #pragma unroll
     for (int rt = 0; rt < PMT_RT; ++rt) {
         tm[rt] = tile_meta(gg, rt, &sh.off[0][0]);
-        if (tm[rt].side >= 0) {
-            mask_all |= 1u << rt;
-            if (tm[rt].side == 0) mask_side[0] |= 1u << rt; else mask_side[1] |= 1u << rt;
-        }
+        if (tm[rt].present) mask_all |= 1u << rt;
+        if (tm[rt].side == 0) mask_side[0] |= 1u << rt; else mask_side[1] |= 1u << rt;
         stash_tile[rt] = stash + (size_t)(bt.group_tile_base[blockIdx.x] + gg.tile_begin + rt) * (size_t)(nslots * PMT_SLOT_FLOATS);
     }
     BwdCtx c{M, theta, phi, packed, gtheta, gphi, &sh, &sh.tr[wave][0], g, mask_all, 0};
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             if (uniform(o.kind) == PMT_OP_LINEAR) {
                 const PmtLinear& Lr = M->lin[uniform(o.lin[0])];
                 init_bias<PMT_NT>(y, uniform(Lr.b_pvec) >= 0 ? packed + uniform(Lr.b_pvec) : nullptr, uniform(Lr.out_dim), g);
-                linear_acc<PMT_NT, PMT_NT, false>(y, r, packed + uniform(Lr.w_frag), uniform(Lr.in_dim), uniform(Lr.out_dim), mask_all);
+                linear_acc<PMT_NT, PMT_NT, false>(y, r, packed + uniform(Lr.w_frag), uniform(Lr.in_dim), uniform(Lr.out_dim), PMT_FULL_MASK);
                 const bool act = uniform(o.selu_after) != 0;
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
                 const float alpha = uniform(theta[uniform(o.alpha_src)]);
                 if (nl == 2) {
                     init_bias<PMT_NT>(y, packed + uniform(L1.b_pvec), width, g);
-                    linear_acc<PMT_NT, PMT_NT, true>(y, r, packed + uniform(L1.w_frag), width, width, mask_all);
+                    linear_acc<PMT_NT, PMT_NT, true>(y, r, packed + uniform(L1.w_frag), width, width, PMT_FULL_MASK);
                 } else {
 #pragma unroll
                     for (int rt = 0; rt < PMT_RT; ++rt)
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
 #pragma unroll
                     for (int rt = 0; rt < PMT_RT; ++rt) r[rt][t] = r[rt][t] + b;
                 }
-                linear_acc<PMT_NT, PMT_NT, true>(r, y, packed + uniform(L2.w_frag), width, width, mask_all, alpha);
+                linear_acc<PMT_NT, PMT_NT, true>(r, y, packed + uniform(L2.w_frag), width, width, PMT_FULL_MASK, alpha);
             }
         }
         const PmtLinear& R = M->lin[uniform(M->rotation_lin)];
@@ -469,7 +471,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
                 a[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        linear_acc<PMT_NT, PMT_NT, false>(a, r, packed + uniform(R.w_frag), E, E, mask_all);
+        linear_acc<PMT_NT, PMT_NT, false>(a, r, packed + uniform(R.w_frag), E, E, PMT_FULL_MASK);
 
         // ---- head backward (alt reads) + set-mean gradients -> d(a) in dy ------------------------------------------
         f4 sig[PMT_NT], dsig[PMT_NT];
@@ -579,7 +581,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         linear_wgrad<PMT_NT, PMT_NT>(c, R, dy, r, mask_all);
         f4 dx[PMT_RT][PMT_NT];
         init_bias<PMT_NT>(dx, nullptr, E, g);
-        linear_acc<PMT_NT, PMT_NT, false>(dx, dy, packed + uniform(R.wt_frag), E, E, mask_all);
+        linear_acc<PMT_NT, PMT_NT, false>(dx, dy, packed + uniform(R.wt_frag), E, E, PMT_FULL_MASK);
         f4 dt[PMT_NT];
 #pragma unroll
         for (int t = 0; t < PMT_NT; ++t) {
@@ -683,7 +685,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         for (int s = 0; s < 2; ++s) {
             const PmtLinear& P2 = M->lin[uniform(B.proj2[s])];
             float* buf = sh.wg[c.wg_flip];
-            wgrad_accumulate<PMT_NT, 1>(buf, c.tr, dy, u, D, h, mask_side[s], true);
+            wgrad_accumulate<PMT_NT, 1>(buf, c.tr, dy, u, D, h, mask_side[s] & mask_all, true);
             __syncthreads();
             wgrad_flush(buf, P2, 1.0f, gtheta, gphi);
             c.wg_flip ^= 1;
@@ -744,7 +746,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             for (int s = 0; s < 2; ++s) {
                 const PmtLinear& P1 = M->lin[uniform(B.proj1[s])];
                 float* buf = sh.wg[c.wg_flip];
-                wgrad_accumulate<2, PMT_NT>(buf, c.tr, dz, n, 16 + h, D, mask_side[s], true);
+                wgrad_accumulate<2, PMT_NT>(buf, c.tr, dz, n, 16 + h, D, mask_side[s] & mask_all, true);
                 __syncthreads();
                 wgrad_flush(buf, P1, 1.0f, gtheta, gphi);
                 c.wg_flip ^= 1;

@@ -21,8 +21,13 @@
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 #define PMT_NT 4                 // feature tiles per activation (PMT_MAX_WIDTH / 16)
-#define PMT_RT 2                 // read tiles per wave
-#define PMT_THREADS (PMT_GROUP_WAVES * 64)
+#ifndef PMT_RT
+#define PMT_RT 2                 // read tiles per wave (a translation unit may choose its own wave shape)
+#endif
+#ifndef PMT_WAVES
+#define PMT_WAVES PMT_GROUP_WAVES  // waves per workgroup; PMT_WAVES * PMT_RT must equal the planned group capacity
+#endif
+#define PMT_THREADS (PMT_WAVES * 64)
 
 #define PMT_SELU_ALPHA 1.6732632423543772848170429916717f
 #define PMT_SELU_SCALE 1.0507009873554804934193349852946f
@@ -30,7 +35,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #define PMT_LOG2PI 1.8378770664093453f
 #define PMT_MAX_LOGIT_F 20.0f
 
-static_assert(PMT_GROUP_TILES == PMT_GROUP_WAVES * PMT_RT, "group capacity");
+static_assert(PMT_GROUP_TILES == PMT_WAVES * PMT_RT, "group capacity");
 
 #define DEV __device__ __forceinline__
 
@@ -47,8 +52,10 @@ DEV float group_sum(float v) {
 DEV f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 DEV float selu1(float x) {
-    // scale * (x > 0 ? x : alpha * (exp(x) - 1)); torch evaluates the negative branch as expm1(x) * (alpha*scale)
-    float neg = (PMT_SELU_ALPHA * PMT_SELU_SCALE) * expm1f(x);
+    // scale * (x > 0 ? x : alpha * (exp(x) - 1)).  The negative branch uses the hardware exp2 (v_exp_f32, ~1 ulp):
+    // absolute error <= ~1.2e-7 on a value in (-1.76, 0], the same size as one fp32 rounding of an O(1) activation.
+    // (OCML expm1f costs ~35 VALU instructions per element and made the kernels VALU-bound.)
+    const float neg = (PMT_SELU_ALPHA * PMT_SELU_SCALE) * (__builtin_amdgcn_exp2f(x * 1.4426950408889634f) - 1.0f);
     return x > 0.f ? PMT_SELU_SCALE * x : neg;
 }
 DEV f4 selu4(f4 v) { return f4{selu1(v[0]), selu1(v[1]), selu1(v[2]), selu1(v[3])}; }
@@ -66,34 +73,49 @@ DEV f4 load_pvec(const float* __restrict__ p, int t, int g) { return *reinterpre
 // acc[rt][mt] += sum_k W[m][k] * in[rt][k]   for the tiles selected by tile_mask (wave-uniform).
 // `frag` = packed A fragments of W ([out_dim][in_dim]).  SELU_IN applies SELU to the input on the fly.
 // ---------------------------------------------------------------------------------------------------------------
-template <int NTI, int NTO, bool SELU_IN>
-DEV void linear_acc(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], const float* __restrict__ frag, int in_dim,
-                    int out_dim, unsigned tile_mask, float in_scale = 1.0f) {
+#define PMT_FULL_MASK ((1u << PMT_RT) - 1u)
+template <int NTI, int NTO, bool SELU_IN, bool MASKED>
+DEV void linear_acc_impl(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], const float* __restrict__ frag, int in_dim,
+                         int out_dim, unsigned tile_mask, float in_scale) {
+    // Fragments are stored kt-major ((kt * nmt + mt) * 256 floats), i.e. in exactly the order this loop nest consumes
+    // them, so the NEXT fragment is one fixed stride away and is fetched before the current fragment's MFMAs: the LDS
+    // (or L2) latency hides behind 4 * PMT_RT MFMAs.  All 4 k-steps of a tile always run: the fragment rows / columns
+    // beyond the layer's true dimensions are zero, and so are the activations there.
     const int nkt = (in_dim + 15) >> 4, nmt = (out_dim + 15) >> 4;
     const f4* __restrict__ fp = reinterpret_cast<const f4*>(frag) + (threadIdx.x & 63);
+    f4 a_next = fp[0];
 #pragma unroll
     for (int kt = 0; kt < NTI; ++kt) {
         if (kt < nkt) {
-            const int ksteps = min(4, (in_dim - 16 * kt + 3) >> 2);
             f4 b[PMT_RT];
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) b[rt] = SELU_IN ? selu4(in[rt][kt]) * in_scale : in[rt][kt];
 #pragma unroll
             for (int mt = 0; mt < NTO; ++mt) {
                 if (mt < nmt) {
-                    const f4 a = fp[(mt * nkt + kt) * 64];
+                    const f4 a = a_next;
+                    fp += 64;
+                    a_next = fp[0];  // one fragment past the end on the last step: still inside the padded region
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        if (j < ksteps) {
 #pragma unroll
-                            for (int rt = 0; rt < PMT_RT; ++rt)
-                                if (tile_mask & (1u << rt)) acc[rt][mt] = mfma16(a[j], b[rt][j], acc[rt][mt]);
-                        }
+                        for (int rt = 0; rt < PMT_RT; ++rt)
+                            if (!MASKED || (tile_mask & (1u << rt))) acc[rt][mt] = mfma16(a[j], b[rt][j], acc[rt][mt]);
                     }
                 }
             }
         }
     }
+}
+
+// tile_mask == all tiles (the common case: a wave's tiles are on one side) takes the branch-free body
+template <int NTI, int NTO, bool SELU_IN>
+DEV void linear_acc(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], const float* __restrict__ frag, int in_dim,
+                    int out_dim, unsigned tile_mask, float in_scale = 1.0f) {
+    if (tile_mask == PMT_FULL_MASK)
+        linear_acc_impl<NTI, NTO, SELU_IN, false>(acc, in, frag, in_dim, out_dim, tile_mask, in_scale);
+    else if (tile_mask != 0)
+        linear_acc_impl<NTI, NTO, SELU_IN, true>(acc, in, frag, in_dim, out_dim, tile_mask, in_scale);
 }
 
 // acc[rt][mt] = bias (tile-position order) for every tile; rows beyond out_dim are zero in the packed bias
@@ -187,7 +209,7 @@ DEV GroupGeom group_geometry(const PmtBatch& bt, int group) {
     gg.tiles_alt = (gg.nalt + 15) >> 4;
     gg.ntiles = gg.tiles_ref + gg.tiles_alt;
     const int wave = uniform((int)(threadIdx.x >> 6));
-    const int q = gg.ntiles / PMT_GROUP_WAVES, rem = gg.ntiles % PMT_GROUP_WAVES;
+    const int q = gg.ntiles / PMT_WAVES, rem = gg.ntiles % PMT_WAVES;
     gg.tile_begin = wave * q + min(wave, rem);
     gg.tile_count = q + (wave < rem ? 1 : 0);
     return gg;
@@ -195,18 +217,21 @@ DEV GroupGeom group_geometry(const PmtBatch& bt, int group) {
 
 // per-tile metadata for this lane
 struct TileMeta {
-    int side;       // 0 = ref, 1 = alt (wave-uniform), -1 = tile not present
+    int side;       // 0 = ref, 1 = alt (wave-uniform).  Tiles beyond the group's last tile count as (empty) alt tiles:
+                    // they are computed like any other tile (all lanes are padding) and never stored.
+    bool present;   // tile exists in this group (wave-uniform)
     int row;        // global row in the batch's read order (before the optional gather), -1 = padding lane
     int set;        // local set index within the group (0 if padding)
-    bool valid;
+    bool valid;     // this lane holds a real read
 };
 
 // s_off: LDS array [2][PMT_GROUP_MAX_SETS + 1] of group-local exclusive offsets per side
 DEV TileMeta tile_meta(const GroupGeom& gg, int rt, const int* s_off) {
     TileMeta tm;
     const int r = threadIdx.x & 15;
-    if (rt >= gg.tile_count) {
-        tm.side = -1; tm.row = -1; tm.set = 0; tm.valid = false;
+    tm.present = rt < gg.tile_count;
+    if (!tm.present) {
+        tm.side = 1; tm.row = -1; tm.set = 0; tm.valid = false;
         return tm;
     }
     const int tau = gg.tile_begin + rt;
@@ -227,3 +252,60 @@ DEV TileMeta tile_meta(const GroupGeom& gg, int rt, const int* s_off) {
 }
 
 extern "C" int pmt_stash_slots(const PmtModel* m);  // host helper (pmt_host.hip)
+
+// ---- LDS weight staging ------------------------------------------------------------------------------------------
+// Every linear's A fragments are consumed by all waves of the workgroup, so they are staged ONCE per workgroup into
+// LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPRs), double buffered: while the waves
+// run the MFMAs of schedule entry i out of one buffer, entry i+1 lands in the other.  One workgroup barrier per
+// entry.  The order of entries comes from the descriptor (pmt_build_schedules); each acquire names the range it
+// needs, and a mismatch is repaired by a synchronous re-stage (slower, still correct) and counted in debug_flags[0].
+struct WStage {
+    float* buf;               // LDS, 2 * PMT_STAGE_FLOATS floats, 16-byte aligned
+    const PmtStage* sched;    // device descriptor array
+    int n;                    // entries
+    int idx;                  // next entry to be acquired (its DMA is already in flight)
+    const float* packed;
+    int* debug_flags;
+};
+
+DEV void wstage_dma(const WStage& ws, int off, int nfloats, float* dst) {
+    const int lane = threadIdx.x & 63, wave = uniform((int)(threadIdx.x >> 6));
+    const int nchunks = nfloats >> 8;
+    for (int c = wave; c < nchunks; c += PMT_WAVES)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ws.packed + off + c * 256 + lane * 4),
+                                         (__attribute__((address_space(3))) void*)(dst + c * 256), 16, 0, 0);
+}
+
+template <bool STAGED>
+DEV void wstage_begin(WStage& ws) {  // kick off entry 0; call once, before the first acquire
+    ws.idx = 0;
+    if (STAGED && ws.n > 0) wstage_dma(ws, uniform(ws.sched[0].off), uniform(ws.sched[0].n), ws.buf);
+}
+
+// Returns the LDS address of the fragments at packed[off .. off + nfloats).  Must be called by ALL threads of the
+// workgroup in uniform control flow.
+template <bool STAGED>
+DEV const float* wstage_acquire(WStage& ws, int off, int nfloats) {
+    if (!STAGED) return ws.packed + off;  // direct path: fragments and vectors come straight from L2 / HBM
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
+    __syncthreads();                                   // everybody's have, and nobody still reads the other buffer
+    const int i = ws.idx;
+    if (i < ws.n && uniform(ws.sched[i].off) == off) {
+        if (i + 1 < ws.n) wstage_dma(ws, uniform(ws.sched[i + 1].off), uniform(ws.sched[i + 1].n), ws.buf + ((i + 1) & 1) * PMT_STAGE_FLOATS);
+        ws.idx = i + 1;
+        return ws.buf + (i & 1) * PMT_STAGE_FLOATS;
+    }
+    // schedule miss: stage synchronously into the buffer that is free (entry i, if any, stays parked in its buffer)
+    if (ws.debug_flags != nullptr && threadIdx.x == 0) atomicAdd(ws.debug_flags, 1);
+    float* dst = ws.buf + ((i + 1) & 1) * PMT_STAGE_FLOATS;
+    wstage_dma(ws, off, nfloats, dst);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    return dst;
+}
+
+DEV int frag_floats_dev(const PmtLinear& L) {
+    const int h = uniform(L.out_split);
+    const int out_v = h > 0 ? 16 + h : uniform(L.out_dim);
+    return ((out_v + 15) >> 4) * ((uniform(L.in_dim) + 15) >> 4) * 256;
+}

@@ -6,11 +6,17 @@
 // feature_clustering.py:82-135, exponentially_modified_gaussian.py:30-89, artifact_model.py:291-292.
 #include "pmt_device.hpp"
 
+// LDS weight staging in the forward: with 8 waves (2 per SIMD) the L2 latency of the fragment loads is already
+// covered by the partner wave and the one-fragment-ahead prefetch in linear_acc, and the per-linear workgroup barrier
+// of the staged path costs more than it saves (measured 2.46 ms staged vs 2.0 ms direct at B = 65536, P0).
+#define FWD_STAGED false
+
 struct FwdShared {
     int off[2][PMT_GROUP_MAX_SETS + 1];
     float zsum[3][PMT_GROUP_MAX_SETS][2][16];
     float fsum[PMT_GROUP_MAX_SETS][2][PMT_MAX_WIDTH];
     float hsum[PMT_GROUP_MAX_SETS][PMT_MAX_CLUSTERS + 2];
+    float wbuf[FWD_STAGED ? 2 * PMT_STAGE_FLOATS : 4];  // LDS weight staging, double buffered
 };
 
 // ---- input decode ------------------------------------------------------------------------------------------------
@@ -35,7 +41,7 @@ DEV float read_feature(const unsigned char* __restrict__ row, int fmt, int f, in
 template <bool TRAIN>
 DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_RT][PMT_NT],
                  const float* __restrict__ packed, const float* __restrict__ theta, int g, unsigned tile_mask,
-                 float* const (&stash_tile)[PMT_RT], int& slot, int first_stashed_op) {
+                 float* const (&stash_tile)[PMT_RT], int& slot, int first_stashed_op, WStage& ws) {
     const int n_ops = uniform(mlp.n_ops);
     for (int op = 0; op < n_ops; ++op) {
         const PmtOp& o = mlp.ops[op];
@@ -48,9 +54,10 @@ DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_
         f4 y[PMT_RT][PMT_NT];
         if (uniform(o.kind) == PMT_OP_LINEAR) {
             const PmtLinear& L = M->lin[uniform(o.lin[0])];
-            const int b_pvec = uniform(L.b_pvec);
-            init_bias<PMT_NT>(y, b_pvec >= 0 ? packed + b_pvec : nullptr, uniform(L.out_dim), g);
-            linear_acc<PMT_NT, PMT_NT, false>(y, x, packed + uniform(L.w_frag), uniform(L.in_dim), uniform(L.out_dim), tile_mask);
+            const int b_pvec = uniform(L.b_pvec), base = uniform(L.w_frag);
+            const float* st = wstage_acquire<FWD_STAGED>(ws, base, uniform(L.w_stage));  // [fragments | bias]
+            init_bias<PMT_NT>(y, b_pvec >= 0 ? st + (b_pvec - base) : nullptr, uniform(L.out_dim), g);
+            linear_acc<PMT_NT, PMT_NT, false>(y, x, st, uniform(L.in_dim), uniform(L.out_dim), PMT_FULL_MASK);
             const bool act = uniform(o.selu_after) != 0;
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
@@ -68,21 +75,23 @@ DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_
                     for (int t = 0; t < PMT_NT; ++t) y[rt][t] = x[rt][t];
             } else {
                 const PmtLinear& L1 = M->lin[uniform(o.lin[0])];
-                init_bias<PMT_NT>(y, packed + uniform(L1.b_pvec), width, g);
-                linear_acc<PMT_NT, PMT_NT, true>(y, x, packed + uniform(L1.w_frag), width, width, tile_mask);
+                const float* st1 = wstage_acquire<FWD_STAGED>(ws, uniform(L1.w_frag), uniform(L1.w_stage));
+                init_bias<PMT_NT>(y, st1 + (uniform(L1.b_pvec) - uniform(L1.w_frag)), width, g);
+                linear_acc<PMT_NT, PMT_NT, true>(y, x, st1, width, width, PMT_FULL_MASK);
             }
             const PmtLinear& L2 = M->lin[uniform(o.lin[nl - 1])];
             const float alpha = uniform(theta[uniform(o.alpha_src)]);
             const int nmt = (width + 15) >> 4;
+            const float* st2 = wstage_acquire<FWD_STAGED>(ws, uniform(L2.w_frag), uniform(L2.w_stage));
 #pragma unroll
             for (int t = 0; t < PMT_NT; ++t) {
                 if (t < nmt) {
-                    const f4 b = alpha * load_pvec(packed + uniform(L2.b_pvec), t, g);
+                    const f4 b = alpha * load_pvec(st2 + (uniform(L2.b_pvec) - uniform(L2.w_frag)), t, g);
 #pragma unroll
                     for (int rt = 0; rt < PMT_RT; ++rt) x[rt][t] = x[rt][t] + b;
                 }
             }
-            linear_acc<PMT_NT, PMT_NT, true>(x, y, packed + uniform(L2.w_frag), width, width, tile_mask, alpha);
+            linear_acc<PMT_NT, PMT_NT, true>(x, y, st2, width, width, PMT_FULL_MASK, alpha);
         }
     }
 }
@@ -127,10 +136,8 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_forward_kernel(const PmtMo
 #pragma unroll
     for (int rt = 0; rt < PMT_RT; ++rt) {
         tm[rt] = tile_meta(gg, rt, &sh.off[0][0]);
-        if (tm[rt].side >= 0) {
-            mask_all |= 1u << rt;
-            if (tm[rt].side == 0) mask_side[0] |= 1u << rt; else mask_side[1] |= 1u << rt;
-        }
+        if (tm[rt].present) mask_all |= 1u << rt;  // tiles that exist: gates memory traffic only
+        if (tm[rt].side == 0) mask_side[0] |= 1u << rt; else mask_side[1] |= 1u << rt;
         stash_tile[rt] = nullptr;
         if (TRAIN)
             stash_tile[rt] = stash + (size_t)(bt.group_tile_base[blockIdx.x] + gg.tile_begin + rt) * (size_t)(stash_num_slots(M) * PMT_SLOT_FLOATS);
@@ -154,8 +161,10 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_forward_kernel(const PmtMo
         }
     }
 
+    WStage ws{&sh.wbuf[0], M->fwd_sched, uniform(M->n_fwd_sched), 0, packed, bt.debug_flags};
+    wstage_begin<FWD_STAGED>(ws);
     int slot = 0;
-    run_mlp<TRAIN>(M, M->read_mlp, x, packed, theta, g, mask_all, stash_tile, slot, 1);
+    run_mlp<TRAIN>(M, M->read_mlp, x, packed, theta, g, mask_all, stash_tile, slot, 1, ws);
 
     // ---- broadcast-concat of the per-variant embedding (reference artifact_model.py:246-251) --------------------
 #pragma unroll
@@ -166,7 +175,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_forward_kernel(const PmtMo
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int f = feat_of(t, j, g);
-                if (tm[rt].side >= 0 && f >= Er && f < D) x[rt][t][j] = vrow[f - Er];
+                if (f >= Er && f < D) x[rt][t][j] = vrow[f - Er];
             }
     }
 
@@ -180,12 +189,21 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_forward_kernel(const PmtMo
             ++slot;
         }
         f4 z[PMT_RT][2];
+        // staging region A of this block: [W1_ref | W1_alt | b1_ref | b1_alt | LN(D) w,b | LN(h) w,b | rho] -- everything
+        // the first half of the block reads comes out of LDS; no vector-memory load sits behind the in-flight DMA.
+        const PmtLinear& P1r = M->lin[uniform(B.proj1[0])];
+        const int baseA = uniform(P1r.w_frag);
+        const float* stA = wstage_acquire<FWD_STAGED>(ws, baseA, uniform(P1r.w_stage));
+        const f4 rho = load_pvec(stA + (uniform(B.ref_reg_pvec) - baseA), 0, g);
+        f4 sw[1], sb[1];
+        sw[0] = load_pvec(stA + (uniform(B.sgu_norm_w_pvec) - baseA), 0, g);
+        sb[0] = load_pvec(stA + (uniform(B.sgu_norm_b_pvec) - baseA), 0, g);
         {
             f4 lw[PMT_NT], lb[PMT_NT];
 #pragma unroll
             for (int t = 0; t < PMT_NT; ++t) {
-                lw[t] = load_pvec(packed + uniform(B.norm_w_pvec), t, g);
-                lb[t] = load_pvec(packed + uniform(B.norm_b_pvec), t, g);
+                lw[t] = load_pvec(stA + (uniform(B.norm_w_pvec) - baseA), t, g);
+                lb[t] = load_pvec(stA + (uniform(B.norm_b_pvec) - baseA), t, g);
             }
             f4 n[PMT_RT][PMT_NT];
 #pragma unroll
@@ -194,24 +212,22 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_forward_kernel(const PmtMo
                 float rstd;
                 layernorm_tile<PMT_NT>(n[rt], xhat, rstd, x[rt], D, lw, lb, g);
             }
+            const int p1_floats = frag_floats_dev(P1r);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 if (mask_side[s]) {
-                    const PmtLinear& P1 = M->lin[uniform(B.proj1[s])];
-                    const f4 b0 = load_pvec(packed + uniform(P1.b_pvec), 0, g), b1 = load_pvec(packed + uniform(P1.b_pvec), 1, g);
+                    const float* bp = stA + (uniform(M->lin[uniform(B.proj1[s])].b_pvec) - baseA);
+                    const f4 b0 = load_pvec(bp, 0, g), b1 = load_pvec(bp, 1, g);
 #pragma unroll
                     for (int rt = 0; rt < PMT_RT; ++rt)
                         if (mask_side[s] & (1u << rt)) { z[rt][0] = b0; z[rt][1] = b1; }
-                    linear_acc<PMT_NT, 2, false>(z, n, packed + uniform(P1.w_frag), D, 16 + h, mask_side[s]);
+                    linear_acc<PMT_NT, 2, false>(z, n, stA + s * p1_floats, D, 16 + h, mask_side[s]);
                 }
             }
         }
         // SELU, LayerNorm(h) on z2, per-set sums (reference gated_mlp.py:228-239)
         const int buf = l % 3;
         {
-            f4 sw[1], sb[1];
-            sw[0] = load_pvec(packed + uniform(B.sgu_norm_w_pvec), 0, g);
-            sb[0] = load_pvec(packed + uniform(B.sgu_norm_b_pvec), 0, g);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) {
                 if (mask_all & (1u << rt)) {
@@ -241,7 +257,6 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_forward_kernel(const PmtMo
         // gate and second projection with the residual as the accumulator input
         {
             const float w = uniform(phi[uniform(B.reg_weight_phi)]) + 0.25f;
-            const f4 rho = load_pvec(packed + uniform(B.ref_reg_pvec), 0, g);
             const float alpha_ref = uniform(theta[uniform(B.alpha_src[0])]), alpha_alt = uniform(theta[uniform(B.alpha_src[1])]);
             const float beta_ref = uniform(theta[uniform(B.beta_src[0])]), beta_alt = uniform(theta[uniform(B.beta_src[1])]);
             const float gamma = uniform(theta[uniform(B.gamma_src)]);
@@ -266,18 +281,21 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_forward_kernel(const PmtMo
                     u[rt][0] = z[rt][0] * gate;
                 }
             }
+            const PmtLinear& P2r = M->lin[uniform(B.proj2[0])];
+            const int p2_floats = frag_floats_dev(P2r), baseB = uniform(P2r.w_frag);
+            const float* p2_frags = wstage_acquire<FWD_STAGED>(ws, baseB, uniform(P2r.w_stage));  // [W2_ref | W2_alt | b2_ref | b2_alt]
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 if (mask_side[s]) {
                     const PmtLinear& P2 = M->lin[uniform(B.proj2[s])];
 #pragma unroll
                     for (int t = 0; t < PMT_NT; ++t) {
-                        const f4 b = load_pvec(packed + uniform(P2.b_pvec), t, g);
+                        const f4 b = load_pvec(p2_frags + (uniform(P2.b_pvec) - baseB), t, g);
 #pragma unroll
                         for (int rt = 0; rt < PMT_RT; ++rt)
                             if (mask_side[s] & (1u << rt)) x[rt][t] = x[rt][t] + b;
                     }
-                    linear_acc<1, PMT_NT, false>(x, u, packed + uniform(P2.w_frag), h, D, mask_side[s]);
+                    linear_acc<1, PMT_NT, false>(x, u, p2_frags + s * p2_floats, h, D, mask_side[s]);
                 }
             }
         }
@@ -290,20 +308,21 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_forward_kernel(const PmtMo
     }
 
     // ---- reducer MLP, then translation + rotation ----------------------------------------------------------------
-    run_mlp<TRAIN>(M, M->reducer, x, packed, theta, g, mask_all, stash_tile, slot, 1);
+    run_mlp<TRAIN>(M, M->reducer, x, packed, theta, g, mask_all, stash_tile, slot, 1, ws);
     f4 a[PMT_RT][PMT_NT];
     {
         const PmtLinear& R = M->lin[uniform(M->rotation_lin)];
+        const float* stR = wstage_acquire<FWD_STAGED>(ws, uniform(R.w_frag), uniform(R.w_stage));  // [Q fragments | translation]
 #pragma unroll
         for (int t = 0; t < PMT_NT; ++t) {
-            const f4 tr = load_pvec(packed + uniform(M->translation_pvec), t, g);
+            const f4 tr = load_pvec(stR + (uniform(M->translation_pvec) - uniform(R.w_frag)), t, g);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) {
                 x[rt][t] = x[rt][t] + tr;
                 a[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        linear_acc<PMT_NT, PMT_NT, false>(a, x, packed + uniform(R.w_frag), E, E, mask_all);
+        linear_acc<PMT_NT, PMT_NT, false>(a, x, stR, E, E, PMT_FULL_MASK);
     }
 
     // ---- per-set feature sums (both sides) and the clustering head (alt reads) -------------------------------------

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libpermutect_amd.so")
 ABI_VERSION = 1
 MAX_WIDTH, MAX_HALF_FFN, MAX_CLUSTERS = 64, 16, 16
 MAX_OPS, MAX_SKIP_LAYERS, MAX_BLOCKS, MAX_LINEAR = 8, 4, 16, 96
+MAX_SCHED, STAGE_FLOATS = 192, 4608
 GROUP_WAVES, GROUP_TILES, GROUP_MAX_SETS, TILE = 8, 16, 64, 16
 READS_PACKED_U8, READS_F16, READS_F32 = 0, 1, 2
 OP_LINEAR, OP_SKIP = 0, 1
@@ -30,7 +31,11 @@ i32, i64, vp = C.c_int32, C.c_int64, C.c_void_p
 
 class PmtLinear(C.Structure):
     _fields_ = [("in_dim", i32), ("out_dim", i32), ("w_frag", i32), ("wt_frag", i32), ("b_pvec", i32),
-                ("w_src", i32), ("b_src", i32), ("out_split", i32)]
+                ("w_src", i32), ("b_src", i32), ("w_stage", i32), ("out_split", i32)]
+
+
+class PmtStage(C.Structure):
+    _fields_ = [("off", i32), ("n", i32)]
 
 
 class PmtOp(C.Structure):
@@ -62,13 +67,14 @@ class PmtModel(C.Structure):
                 ("theta_size", i32), ("phi_size", i32), ("packed_size", i32),
                 ("translation_src", i32), ("translation_pvec", i32), ("rotation_lin", i32),
                 ("read_mlp", PmtMlp), ("reducer", PmtMlp), ("blocks", PmtBlock * MAX_BLOCKS), ("head", PmtHead),
-                ("lin", PmtLinear * MAX_LINEAR)]
+                ("lin", PmtLinear * MAX_LINEAR), ("n_fwd_sched", i32), ("n_bwd_sched", i32),
+                ("fwd_sched", PmtStage * MAX_SCHED), ("bwd_sched", PmtStage * MAX_SCHED)]
 
 
 class PmtBatch(C.Structure):
     _fields_ = [("num_variants", i32), ("num_groups", i32), ("read_format", i32), ("read_row_bytes", i32),
                 ("reads", vp), ("read_index", vp), ("ref_offsets", vp), ("alt_offsets", vp), ("variant_embed", vp),
-                ("group_start", vp), ("group_tile_base", vp), ("total_tiles", i64)]
+                ("group_start", vp), ("group_tile_base", vp), ("total_tiles", i64), ("debug_flags", vp)]
 
 
 class PmtOutputs(C.Structure):
@@ -84,7 +90,7 @@ class PmtAdamW(C.Structure):
                 ("weight_decay", C.c_float), ("max_grad_norm", C.c_float), ("step", i32), ("reserved", i32)]
 
 
-EXPORTS = ["pmt_abi_version", "pmt_struct_bytes", "pmt_model_check", "pmt_plan_groups", "pmt_stash_bytes", "pmt_pack_params",
+EXPORTS = ["pmt_abi_version", "pmt_struct_bytes", "pmt_model_check", "pmt_build_schedules", "pmt_plan_groups", "pmt_stash_bytes", "pmt_pack_params",
            "pmt_scan_counts", "pmt_forward", "pmt_backward", "pmt_clip_adamw"]
 
 _lib = None
@@ -112,6 +118,7 @@ def load() -> C.CDLL:
     P = C.POINTER
     lib.pmt_abi_version.restype = i32
     lib.pmt_model_check.argtypes = [P(PmtModel)]
+    lib.pmt_build_schedules.argtypes = [P(PmtModel)]
     lib.pmt_plan_groups.argtypes = [vp, vp, i32, vp, vp, P(i32)]
     lib.pmt_stash_bytes.argtypes = [P(PmtModel), i64, i32]
     lib.pmt_stash_bytes.restype = C.c_size_t

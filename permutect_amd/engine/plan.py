@@ -92,27 +92,33 @@ class EnginePlan:
         self._lower_mlp(d.read_mlp, read_mlp)
         for i, blk in enumerate(enc.blocks):
             b = d.blocks[i]
-            b.norm_w_src, b.norm_b_src = space.offset_of(blk.norm.weight), space.offset_of(blk.norm.bias)
-            b.norm_w_pvec, b.norm_b_pvec = self._alloc_packed(_ceil16(d.d_model)), self._alloc_packed(_ceil16(d.d_model))
-            b.proj1[0] = self._add_linear(blk.proj1_ref, out_split=h)
-            b.proj1[1] = self._add_linear(blk.proj1_alt, out_split=h)
-            b.proj2[0] = self._add_linear(blk.proj2_ref)
-            b.proj2[1] = self._add_linear(blk.proj2_alt)
             s = blk.sgu
+            b.norm_w_src, b.norm_b_src = space.offset_of(blk.norm.weight), space.offset_of(blk.norm.bias)
             b.sgu_norm_w_src, b.sgu_norm_b_src = space.offset_of(s.norm.weight), space.offset_of(s.norm.bias)
-            b.sgu_norm_w_pvec, b.sgu_norm_b_pvec = self._alloc_packed(_ceil16(h)), self._alloc_packed(_ceil16(h))
+            b.ref_reg_src = space.offset_of(s.ref_regularizer)
+            # One LDS staging region per projection pair: [W_ref | W_alt | vectors used with them | pad to 256].
+            # The first region also carries the block's LayerNorm / gating vectors.
+            vecs = {}
+            b.proj1[0], b.proj1[1] = self._add_linear_pair(
+                blk.proj1_ref, blk.proj1_alt, out_split=h,
+                extra_vectors=[("norm_w", _ceil16(d.d_model)), ("norm_b", _ceil16(d.d_model)), ("sgu_w", _ceil16(h)),
+                               ("sgu_b", _ceil16(h)), ("rho", _ceil16(h))], out=vecs)
+            b.norm_w_pvec, b.norm_b_pvec = vecs["norm_w"], vecs["norm_b"]
+            b.sgu_norm_w_pvec, b.sgu_norm_b_pvec, b.ref_reg_pvec = vecs["sgu_w"], vecs["sgu_b"], vecs["rho"]
+            b.proj2[0], b.proj2[1] = self._add_linear_pair(blk.proj2_ref, blk.proj2_alt)
             b.alpha_src[0], b.alpha_src[1] = space.offset_of(s.alpha_ref), space.offset_of(s.alpha_alt)
             b.beta_src[0], b.beta_src[1] = space.offset_of(s.beta_ref), space.offset_of(s.beta_alt)
             b.gamma_src = space.offset_of(s.gamma)
-            b.ref_reg_src, b.ref_reg_pvec = space.offset_of(s.ref_regularizer), self._alloc_packed(_ceil16(h))
             b.reg_weight_phi = self._alloc_phi(f"reg_weight.{i}", 1)
         self._lower_mlp(d.reducer, reducer)
 
         tr = model.pre_clustering_transform
         d.translation_src = space.offset_of(tr.translation_e)
-        d.translation_pvec = self._alloc_packed(_ceil16(e))
         q_phi = self._alloc_phi("rotation", e * e)
-        d.rotation_lin = self._add_raw_linear(e, e, w_src=-(q_phi + 2), b_src=-1, has_bias=False)
+        vecs = {}
+        d.rotation_lin = self._add_raw_linear(e, e, w_src=-(q_phi + 2), b_src=-1, has_bias=False,
+                                              extra_vectors=[("translation", _ceil16(e))], out=vecs)
+        d.translation_pvec = vecs["translation"]
 
         hd = d.head
         hd.stdev_e_phi = self._alloc_phi("stdev_e", e)
@@ -124,14 +130,16 @@ class EnginePlan:
         hd.mu_k_src = space.offset_of(fc.artifact_emg.mu_k)
 
         d.n_linear = self._n_lin
-        d.theta_size, d.phi_size, d.packed_size = space.size, max(self._phi_off, 4), max(self._packed_off, 4)
+        d.theta_size, d.phi_size, d.packed_size = space.size, max(self._phi_off, 4), self._packed_off + 256
 
         lib = L.load()
         L.check(lib.pmt_model_check(C.byref(d)), "pmt_model_check")
+        L.check(lib.pmt_build_schedules(C.byref(d)), "pmt_build_schedules")
         self.packed = torch.zeros(d.packed_size, dtype=torch.float32, device=device)
         self.gphi_size = d.phi_size
         raw = bytes(d)
         self.desc_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        self.debug_flags = torch.zeros(4, dtype=torch.int32, device=device)  # [0]: weight-staging schedule misses
         self.stash_slots = (d.read_mlp.n_ops - 1) + (d.num_blocks + 1) + (d.reducer.n_ops - 1)
 
     # ---- allocation helpers --------------------------------------------------------------------------------------
@@ -146,7 +154,17 @@ class EnginePlan:
         self._phi_off += n
         return off
 
-    def _add_raw_linear(self, in_dim: int, out_dim: int, w_src: int, b_src: int, has_bias: bool, out_split: int = 0) -> int:
+    def _close_region(self, start: int) -> int:
+        """Pad the packed cursor to a multiple of 256 floats past `start` (LDS-DMA moves 1 KiB pieces); returns the
+        region length."""
+        n = (self._packed_off - start + 255) // 256 * 256
+        if n > L.STAGE_FLOATS:
+            raise L.PmtError("a weight-staging region exceeds the LDS staging buffer")
+        self._packed_off = start + n
+        return n
+
+    def _add_raw_linear(self, in_dim: int, out_dim: int, w_src: int, b_src: int, has_bias: bool, out_split: int = 0,
+                        alloc: bool = True, extra_vectors=(), out=None) -> int:
         if self._n_lin >= L.MAX_LINEAR:
             raise L.PmtError("too many linear layers for the kernel descriptor")
         if in_dim > L.MAX_WIDTH or out_dim > L.MAX_WIDTH:
@@ -155,12 +173,36 @@ class EnginePlan:
         out_v = 16 + out_split if out_split else out_dim
         nmt, nkt = (out_v + 15) // 16, (in_dim + 15) // 16
         lin.in_dim, lin.out_dim, lin.out_split = in_dim, out_dim, out_split
-        lin.w_frag = self._alloc_packed(nmt * nkt * 256)
-        lin.wt_frag = self._alloc_packed(nmt * nkt * 256)
-        lin.b_pvec = self._alloc_packed(nmt * 16) if has_bias else -1
+        if alloc:
+            # staging region: [forward fragments | bias | extra vectors | pad]; the transposed fragments follow
+            self._packed_off = (self._packed_off + 255) // 256 * 256
+            lin.w_frag = self._alloc_packed(nmt * nkt * 256)
+            lin.b_pvec = self._alloc_packed(nmt * 16) if has_bias else -1
+            for name, n in extra_vectors:
+                out[name] = self._alloc_packed(n)
+            lin.w_stage = self._close_region(lin.w_frag)
+            lin.wt_frag = self._alloc_packed(nmt * nkt * 256)
         lin.w_src, lin.b_src = w_src, b_src
         self._n_lin += 1
         return self._n_lin - 1
+
+    def _add_linear_pair(self, ref: nn.Linear, alt: nn.Linear, out_split: int = 0, extra_vectors=(), out=None):
+        ids = []
+        for layer in (ref, alt):
+            ids.append(self._add_raw_linear(layer.in_features, layer.out_features, self.space.offset_of(layer.weight),
+                                            self.space.offset_of(layer.bias), True, out_split, alloc=False))
+        lr, la = self.desc.lin[ids[0]], self.desc.lin[ids[1]]
+        out_v = 16 + out_split if out_split else lr.out_dim
+        nfl = ((out_v + 15) // 16) * ((lr.in_dim + 15) // 16) * 256
+        nb = ((out_v + 15) // 16) * 16
+        self._packed_off = (self._packed_off + 255) // 256 * 256
+        lr.w_frag = self._alloc_packed(nfl); la.w_frag = self._alloc_packed(nfl)
+        lr.b_pvec = self._alloc_packed(nb); la.b_pvec = self._alloc_packed(nb)
+        for name, n in extra_vectors:
+            out[name] = self._alloc_packed(n)
+        lr.w_stage, la.w_stage = self._close_region(lr.w_frag), 0
+        lr.wt_frag = self._alloc_packed(nfl); la.wt_frag = self._alloc_packed(nfl)
+        return ids[0], ids[1]
 
     def _add_linear(self, layer: nn.Linear, out_split: int = 0) -> int:
         b_src = self.space.offset_of(layer.bias) if layer.bias is not None else -1

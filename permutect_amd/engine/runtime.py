@@ -81,6 +81,7 @@ class ReadSetEngine:
         bv.variant_embed = variant_embed.data_ptr()
         bv.group_start, bv.group_tile_base = gs.data_ptr(), gt.data_ptr()
         bv.total_tiles = plan.total_tiles
+        bv.debug_flags = self.plan.debug_flags.data_ptr()
         keep = (gs, gt, ref_off, alt_off, reads, index, variant_embed)
         return bv, keep, plan
 

@@ -92,3 +92,12 @@ def test_full_train_step_matches_reference(name):
     for n, p in model.named_parameters():
         worst = max(worst, float(np.abs(p.detach().cpu().numpy() - z["after/" + n]).max()))
     assert worst <= 0.02 * lr, worst
+
+
+def test_weight_staging_schedule_is_in_sync():
+    """The LDS weight-staging schedules must match the kernels' consumption order exactly (a miss only costs speed, so it
+    needs its own check): zero misses after a forward + backward."""
+    z, model, out, losses = run_step("p0_b16")
+    losses.total_loss.backward()
+    torch.cuda.synchronize()
+    assert int(model.engine().plan.debug_flags[0].item()) == 0
