@@ -10,10 +10,10 @@
 //   set-coupled terms       : per-set sums of d(gate) go through LDS exactly like the forward's z2 sums.
 //
 // Replaces autograd over reference artifact_model.py:239-297 (misc_utils.py:127 `loss.backward()`).
-// Wave shape of this kernel: 4 waves x 4 read tiles, one wave per SIMD with the full 512-register budget.  The same
-// 16-tile groups as the forward (8 waves x 2 tiles); the activation stash is indexed by tile, not by wave.
-#define PMT_WAVES 4
-#define PMT_RT 4
+// Wave shape: 8 waves x 2 read tiles (2 waves per SIMD, 256 VGPRs each).  VALU instructions only address the 256
+// architectural VGPRs, so a 512-register "fat wave" (4 x 4) just shuffles values through AGPRs: measured slower.
+#define PMT_WAVES 8
+#define PMT_RT 2
 #include "pmt_device.hpp"
 
 #define TR_STRIDE 20  // floats per row of the per-wave transpose tile (16 + 4 pad: conflict-free b32 writes, 16B-aligned b128 reads)
@@ -188,6 +188,56 @@ DEV void layernorm_bwd_tile(f4 (&dx)[NT], const f4 (&dyv)[NT], const f4 (&xhat)[
             dx[t][j] = (t < nt && feat_of(t, j, g) < dim) ? rstd * (dxh[t][j] - m1 - xhat[t][j] * m2) : 0.f;
 }
 
+// xhat = (x - mean) * rstd without the affine part
+template <int NT>
+DEV void layernorm_stats_tile(f4 (&xhat)[NT], float& rstd, const f4 (&x)[NT], int dim, int g) {
+    const int nt = (dim + 15) >> 4;
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        if (t < nt) s += (x[t][0] + x[t][1]) + (x[t][2] + x[t][3]);
+    const float mean = group_sum(s) / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = (t < nt && feat_of(t, j, g) < dim) ? x[t][j] - mean : 0.f;
+            xhat[t][j] = d;
+            q += d * d;
+        }
+    rstd = rsqrtf(group_sum(q) / (float)dim + PMT_LN_EPS);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) xhat[t] = xhat[t] * rstd;
+}
+
+// acc += LayerNorm backward of d(y) (y = xhat * w + b); also accumulates dw, db.  No temporaries of width D besides xhat.
+template <int NT>
+DEV void layernorm_bwd_inplace_tile(f4 (&acc)[NT], const f4 (&dyv)[NT], const f4 (&xhat)[NT], float rstd, int dim,
+                                    const f4 (&w)[NT], f4 (&dw)[NT], f4 (&db)[NT], int g) {
+    const int nt = (dim + 15) >> 4;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        if (t < nt) {
+            dw[t] = dw[t] + dyv[t] * xhat[t];
+            db[t] = db[t] + dyv[t];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (feat_of(t, j, g) < dim) {
+                    const float d = dyv[t][j] * w[t][j];
+                    s1 += d;
+                    s2 += d * xhat[t][j];
+                }
+        }
+    const float m1 = group_sum(s1) / (float)dim, m2 = group_sum(s2) / (float)dim;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (t < nt && feat_of(t, j, g) < dim) acc[t][j] += rstd * (dyv[t][j] * w[t][j] - m1 - xhat[t][j] * m2);
+}
+
 DEV f4 selu_bwd4(f4 d, f4 s) {
     return f4{d[0] * selu_grad_from_out(s[0]), d[1] * selu_grad_from_out(s[1]), d[2] * selu_grad_from_out(s[2]),
               d[3] * selu_grad_from_out(s[3])};
@@ -340,7 +390,7 @@ DEV float read_feature_b(const unsigned char* __restrict__ row, int fmt, int f, 
     return reinterpret_cast<const float*>(row)[f];
 }
 
-__global__ __launch_bounds__(PMT_THREADS, 1) void pmt_backward_kernel(
+__global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
     const PmtModel* __restrict__ M, const float* __restrict__ theta, const float* __restrict__ phi,
     const float* __restrict__ packed, PmtBatch bt, PmtOutputs out, PmtOutputGrads dout, const float* __restrict__ stash,
     const float* __restrict__ zsum_stash, float* __restrict__ gtheta, float* __restrict__ gphi,
@@ -600,24 +650,37 @@ __global__ __launch_bounds__(PMT_THREADS, 1) void pmt_backward_kernel(
 
     // ---- gated blocks backward -----------------------------------------------------------------------------------------
     for (int l = L - 1; l >= 0; --l) {
+        // Register discipline (this loop body used to spill thousands of VGPRs): nothing of width D except the running
+        // gradient dy stays live across phases.  x_l is re-read from the stash (L2/HBM, 4 KB per tile) and its LayerNorm
+        // recomputed each of the three times it is needed; z2 / gate are recomputed from z2hat.
         const PmtBlock& B = M->blocks[l];
-        f4 x[PMT_RT][PMT_NT];
-        load_slot(slot_x0 + l, x);
-        f4 lw[PMT_NT], lb[PMT_NT];
+        const float* lw_p = packed + uniform(B.norm_w_pvec);
+        const float* lb_p = packed + uniform(B.norm_b_pvec);
+        const float* xs[PMT_RT];
 #pragma unroll
-        for (int t = 0; t < PMT_NT; ++t) {
-            lw[t] = load_pvec(packed + uniform(B.norm_w_pvec), t, g);
-            lb[t] = load_pvec(packed + uniform(B.norm_b_pvec), t, g);
-        }
-        // recompute: n = LN(x) (kept as xhat + rstd), z = selu(W1 n + b1)
-        f4 xhat[PMT_RT][PMT_NT], z[PMT_RT][2];
-        float rstd[PMT_RT];
+        for (int rt = 0; rt < PMT_RT; ++rt) xs[rt] = stash_tile[rt] + (slot_x0 + l) * PMT_SLOT_FLOATS;
+        // n[rt] = LayerNorm_D(x_l[rt]) for every tile of this wave (absent tiles: zeros in, finite out)
+        auto recompute_n = [&](f4 (&n)[PMT_RT][PMT_NT]) {
+            f4 lw[PMT_NT], lb[PMT_NT];
 #pragma unroll
-        for (int rt = 0; rt < PMT_RT; ++rt) z[rt][0] = z[rt][1] = f4{0.f, 0.f, 0.f, 0.f};  // absent tiles stay finite
+            for (int t = 0; t < PMT_NT; ++t) { lw[t] = load_pvec(lw_p, t, g); lb[t] = load_pvec(lb_p, t, g); }
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt) {
+                f4 xr[PMT_NT], xh[PMT_NT];
+                float rs;
+#pragma unroll
+                for (int t = 0; t < PMT_NT; ++t) xr[t] = f4{0.f, 0.f, 0.f, 0.f};
+                if (mask_all & (1u << rt)) stash_load<PMT_NT>(xs[rt], xr);
+                layernorm_tile<PMT_NT>(n[rt], xh, rs, xr, D, lw, lb, g);
+            }
+        };
+        // ---- phase 1: z = selu(W1 n + b1) ---------------------------------------------------------------------------
+        f4 z[PMT_RT][2];
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt) z[rt][0] = z[rt][1] = f4{0.f, 0.f, 0.f, 0.f};
         {
             f4 n[PMT_RT][PMT_NT];
-#pragma unroll
-            for (int rt = 0; rt < PMT_RT; ++rt) layernorm_tile<PMT_NT>(n[rt], xhat[rt], rstd[rt], x[rt], D, lw, lb, g);
+            recompute_n(n);
 #pragma unroll
             for (int s = 0; s < 2; ++s)
                 if (mask_side[s]) {
@@ -635,60 +698,66 @@ __global__ __launch_bounds__(PMT_THREADS, 1) void pmt_backward_kernel(
         const float alpha_ref = uniform(theta[uniform(B.alpha_src[0])]), alpha_alt = uniform(theta[uniform(B.alpha_src[1])]);
         const float beta_ref = uniform(theta[uniform(B.beta_src[0])]), beta_alt = uniform(theta[uniform(B.beta_src[1])]);
         const float gamma = uniform(theta[uniform(B.gamma_src)]);
-        f4 z2hat[PMT_RT], z2[PMT_RT], gate[PMT_RT], dgate[PMT_RT], du[PMT_RT][1];
+        // gate of one tile from z2hat (recomputed wherever it is needed)
+        auto gate_of = [&](int rt, f4 z2hat_rt, f4& z2_out, f4& m_ref, f4& m_alt) -> f4 {
+            const int set = tm[rt].set, s = tm[rt].side;
+            const float n_ref = (float)(sh.off[0][set + 1] - sh.off[0][set]);
+            const float n_alt = (float)(sh.off[1][set + 1] - sh.off[1][set]);
+            const float* zs = zsum_stash + ((size_t)(gg.v0 + set) * L + l) * 32;
+            m_ref = (*reinterpret_cast<const f4*>(zs + 4 * g) + w * rho) / (n_ref + w);
+            m_alt = *reinterpret_cast<const f4*>(zs + 16 + 4 * g) / (n_alt + 1e-4f);
+            z2_out = z2hat_rt * sw + sb;
+            f4 gt = z2_out * (s == 0 ? alpha_ref : alpha_alt) + 1.0f;
+            return s == 0 ? gt + beta_ref * m_ref : (gt + beta_alt * m_alt) + gamma * m_ref;
+        };
+        // ---- phase 2: d(u) = W2^T dy, d(gate), per-set sums of d(gate), proj2 weight gradient ------------------------------
+        f4 z2hat[PMT_RT], dgate[PMT_RT], du[PMT_RT][1];
         float rstd2[PMT_RT];
-        float d_alpha[2] = {0.f, 0.f}, d_beta[2] = {0.f, 0.f}, d_gamma = 0.f;
-        // d(u) = W2^T dy ; weight gradient of proj2 needs u = z1 * gate
+        float d_alpha_ref = 0.f, d_alpha_alt = 0.f, d_beta_ref = 0.f, d_beta_alt = 0.f, d_gamma = 0.f;
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt) du[rt][0] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 2; ++s)
             if (mask_side[s]) linear_acc<PMT_NT, 1, false>(du, dy, packed + uniform(M->lin[uniform(B.proj2[s])].wt_frag), D, h, mask_side[s]);
-        f4 u[PMT_RT][1];
+        {
+            f4 u[PMT_RT][1];
 #pragma unroll
-        for (int rt = 0; rt < PMT_RT; ++rt) {
-            z[rt][0] = selu4(z[rt][0]);
-            z[rt][1] = selu4(z[rt][1]);
-            f4 zin[1] = {z[rt][1]}, zo[1], zh[1], sw1[1] = {sw}, sb1[1] = {sb};
-            layernorm_tile<1>(zo, zh, rstd2[rt], zin, h, sw1, sb1, g);
-            z2[rt] = zo[0];
-            z2hat[rt] = zh[0];
-            const int set = tm[rt].set, s = tm[rt].side;
-            const float n_ref = (float)(sh.off[0][set + 1] - sh.off[0][set]);
-            const float n_alt = (float)(sh.off[1][set + 1] - sh.off[1][set]);
-            const float* zs = zsum_stash + ((size_t)(gg.v0 + set) * L + l) * 32;
-            const f4 m_ref = (*reinterpret_cast<const f4*>(zs + 4 * g) + w * rho) / (n_ref + w);
-            const f4 m_alt = *reinterpret_cast<const f4*>(zs + 16 + 4 * g) / (n_alt + 1e-4f);
-            f4 gt = z2[rt] * (s == 0 ? alpha_ref : alpha_alt) + 1.0f;
-            gt = s == 0 ? gt + beta_ref * m_ref : (gt + beta_alt * m_alt) + gamma * m_ref;
-            gate[rt] = gt;
-            u[rt][0] = z[rt][0] * gt;
-            const bool ok = tm[rt].valid;
-            dgate[rt] = ok ? du[rt][0] * z[rt][0] : f4{0.f, 0.f, 0.f, 0.f};
+            for (int rt = 0; rt < PMT_RT; ++rt) {
+                z[rt][0] = selu4(z[rt][0]);
+                z[rt][1] = selu4(z[rt][1]);
+                f4 zin[1] = {z[rt][1]}, zo[1], zh[1], sw1[1] = {sw}, sb1[1] = {sb};
+                layernorm_tile<1>(zo, zh, rstd2[rt], zin, h, sw1, sb1, g);
+                z2hat[rt] = zh[0];
+                f4 z2v, m_ref, m_alt;
+                const f4 gt = gate_of(rt, z2hat[rt], z2v, m_ref, m_alt);
+                u[rt][0] = z[rt][0] * gt;
+                const int set = tm[rt].set, s = tm[rt].side;
+                const bool ok = tm[rt].valid;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float dg = (feat_of(0, j, g) < h) ? dgate[rt][j] : 0.f;
-                dgate[rt][j] = dg;
-                if (s == 0) {
-                    d_alpha[0] += dg * z2[rt][j];
-                    d_beta[0] += dg * m_ref[j];
-                } else if (s == 1) {
-                    d_alpha[1] += dg * z2[rt][j];
-                    d_beta[1] += dg * m_alt[j];
-                    d_gamma += dg * m_ref[j];
+                for (int j = 0; j < 4; ++j) {
+                    const float dg = (ok && feat_of(0, j, g) < h) ? du[rt][0][j] * z[rt][0][j] : 0.f;
+                    dgate[rt][j] = dg;
+                    if (s == 0) {
+                        d_alpha_ref += dg * z2v[j];
+                        d_beta_ref += dg * m_ref[j];
+                    } else {
+                        d_alpha_alt += dg * z2v[j];
+                        d_beta_alt += dg * m_alt[j];
+                        d_gamma += dg * m_ref[j];
+                    }
+                    if (ok && feat_of(0, j, g) < h) atomicAdd(&sh.gsum[set][s][4 * g + j], dg);
                 }
-                if (ok && feat_of(0, j, g) < h) atomicAdd(&sh.gsum[set][s][4 * g + j], dg);
             }
-        }
-        // proj2 weight gradients (per side), then the barrier inside makes gsum complete as well
+            // proj2 weight gradients (per side); the barrier inside also completes gsum
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const PmtLinear& P2 = M->lin[uniform(B.proj2[s])];
-            float* buf = sh.wg[c.wg_flip];
-            wgrad_accumulate<PMT_NT, 1>(buf, c.tr, dy, u, D, h, mask_side[s] & mask_all, true);
-            __syncthreads();
-            wgrad_flush(buf, P2, 1.0f, gtheta, gphi);
-            c.wg_flip ^= 1;
+            for (int s = 0; s < 2; ++s) {
+                const PmtLinear& P2 = M->lin[uniform(B.proj2[s])];
+                float* buf = sh.wg[c.wg_flip];
+                wgrad_accumulate<PMT_NT, 1>(buf, c.tr, dy, u, D, h, mask_side[s] & mask_all, true);
+                __syncthreads();
+                wgrad_flush(buf, P2, 1.0f, gtheta, gphi);
+                c.wg_flip ^= 1;
+            }
         }
         // per-set coupling: d(m_ref), d(m_alt), d(ref_regularizer), d(reg_weight)
         for (int i = tid; i < gg.nsets * 16; i += PMT_THREADS) {
@@ -709,39 +778,39 @@ __global__ __launch_bounds__(PMT_THREADS, 1) void pmt_backward_kernel(
         }
         __syncthreads();
         for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS) (&sh.gsum[0][0][0])[i] = 0.f;
-        // finish d(z2), LayerNorm(h) backward, SELU backward -> d(zpre) in dz (2 tiles)
+        // ---- phase 3: finish d(z2), LayerNorm(h) backward, SELU backward -> d(zpre) ---------------------------------------
         f4 dz[PMT_RT][2];
-        f4 dsw[1] = {f4{0.f, 0.f, 0.f, 0.f}}, dsb[1] = {f4{0.f, 0.f, 0.f, 0.f}};
+        {
+            f4 dsw[1] = {f4{0.f, 0.f, 0.f, 0.f}}, dsb[1] = {f4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int rt = 0; rt < PMT_RT; ++rt) {
-            const int set = tm[rt].set, s = tm[rt].side;
-            const bool ok = tm[rt].valid;
-            f4 dz2 = dgate[rt] * (s == 0 ? alpha_ref : alpha_alt);
-            const f4 dm = *reinterpret_cast<const f4*>(&sh.dmean[set][s == 1 ? 1 : 0][4 * g]);
-            if (ok) dz2 = dz2 + dm;
-            f4 dz2v[1] = {dz2}, zh[1] = {z2hat[rt]}, sw1[1] = {sw}, dxr[1];
-            layernorm_bwd_tile<1>(dxr, dz2v, zh, rstd2[rt], h, sw1, dsw, dsb, g);
-            const f4 dz1 = ok ? du[rt][0] * gate[rt] : f4{0.f, 0.f, 0.f, 0.f};
-            dz[rt][0] = selu_bwd4(dz1, z[rt][0]);
-            dz[rt][1] = selu_bwd4(dxr[0], z[rt][1]);
+            for (int rt = 0; rt < PMT_RT; ++rt) {
+                const int set = tm[rt].set, s = tm[rt].side;
+                const bool ok = tm[rt].valid;
+                f4 z2v, m_ref, m_alt;
+                const f4 gt = gate_of(rt, z2hat[rt], z2v, m_ref, m_alt);
+                f4 dz2 = dgate[rt] * (s == 0 ? alpha_ref : alpha_alt);
+                const f4 dm = *reinterpret_cast<const f4*>(&sh.dmean[set][s][4 * g]);
+                if (ok) dz2 = dz2 + dm;
+                f4 dz2v[1] = {dz2}, zh[1] = {z2hat[rt]}, sw1[1] = {sw}, dxr[1];
+                layernorm_bwd_tile<1>(dxr, dz2v, zh, rstd2[rt], h, sw1, dsw, dsb, g);
+                const f4 dz1 = ok ? du[rt][0] * gt : f4{0.f, 0.f, 0.f, 0.f};
+                dz[rt][0] = selu_bwd4(dz1, z[rt][0]);
+                dz[rt][1] = selu_bwd4(dxr[0], z[rt][1]);
+            }
+            if (mask_all) {
+                vec_grad_atomic<1>(gtheta + uniform(B.sgu_norm_w_src), dsw, h, g);
+                vec_grad_atomic<1>(gtheta + uniform(B.sgu_norm_b_src), dsb, h, g);
+                scalar_grad_atomic(gtheta + uniform(B.alpha_src[0]), d_alpha_ref);
+                scalar_grad_atomic(gtheta + uniform(B.alpha_src[1]), d_alpha_alt);
+                scalar_grad_atomic(gtheta + uniform(B.beta_src[0]), d_beta_ref);
+                scalar_grad_atomic(gtheta + uniform(B.beta_src[1]), d_beta_alt);
+                scalar_grad_atomic(gtheta + uniform(B.gamma_src), d_gamma);
+            }
         }
-        if (mask_all) {
-            vec_grad_atomic<1>(gtheta + uniform(B.sgu_norm_w_src), dsw, h, g);
-            vec_grad_atomic<1>(gtheta + uniform(B.sgu_norm_b_src), dsb, h, g);
-            scalar_grad_atomic(gtheta + uniform(B.alpha_src[0]), d_alpha[0]);
-            scalar_grad_atomic(gtheta + uniform(B.alpha_src[1]), d_alpha[1]);
-            scalar_grad_atomic(gtheta + uniform(B.beta_src[0]), d_beta[0]);
-            scalar_grad_atomic(gtheta + uniform(B.beta_src[1]), d_beta[1]);
-            scalar_grad_atomic(gtheta + uniform(B.gamma_src), d_gamma);
-        }
-        // proj1: weight gradients need n = xhat * lw + lb again; then d(n) = W1^T d(zpre)
-        f4 dn[PMT_RT][PMT_NT];
+        // ---- phase 4: proj1 weight gradient (needs n again), d(n) = W1^T d(zpre), LayerNorm(D) backward ---------------------
         {
             f4 n[PMT_RT][PMT_NT];
-#pragma unroll
-            for (int rt = 0; rt < PMT_RT; ++rt)
-#pragma unroll
-                for (int t = 0; t < PMT_NT; ++t) n[rt][t] = xhat[rt][t] * lw[t] + lb[t];
+            recompute_n(n);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const PmtLinear& P1 = M->lin[uniform(B.proj1[s])];
@@ -752,24 +821,39 @@ __global__ __launch_bounds__(PMT_THREADS, 1) void pmt_backward_kernel(
                 c.wg_flip ^= 1;
             }
         }
-        init_bias<PMT_NT>(dn, nullptr, D, g);
+        {
+            f4 dn[PMT_RT][PMT_NT];
+            init_bias<PMT_NT>(dn, nullptr, D, g);
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
-            if (mask_side[s]) linear_acc<2, PMT_NT, false>(dn, dz, packed + uniform(M->lin[uniform(B.proj1[s])].wt_frag), 16 + h, D, mask_side[s]);
-        // LayerNorm(D) backward, add to the residual gradient
-        f4 dlw[PMT_NT], dlb[PMT_NT];
+            for (int s = 0; s < 2; ++s)
+                if (mask_side[s]) linear_acc<2, PMT_NT, false>(dn, dz, packed + uniform(M->lin[uniform(B.proj1[s])].wt_frag), 16 + h, D, mask_side[s]);
+            f4 lw[PMT_NT], dlw[PMT_NT], dlb[PMT_NT];
 #pragma unroll
-        for (int t = 0; t < PMT_NT; ++t) { dlw[t] = f4{0.f, 0.f, 0.f, 0.f}; dlb[t] = f4{0.f, 0.f, 0.f, 0.f}; }
+            for (int t = 0; t < PMT_NT; ++t) {
+                lw[t] = load_pvec(lw_p, t, g);
+                dlw[t] = f4{0.f, 0.f, 0.f, 0.f};
+                dlb[t] = f4{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
-        for (int rt = 0; rt < PMT_RT; ++rt) {
-            f4 dxr[PMT_NT];
-            layernorm_bwd_tile<PMT_NT>(dxr, dn[rt], xhat[rt], rstd[rt], D, lw, dlw, dlb, g);
+            for (int rt = 0; rt < PMT_RT; ++rt) {
+                // one tile at a time (the scheduling barrier keeps the compiler from interleaving the tiles' temporaries)
+                __builtin_amdgcn_sched_barrier(0);
+                f4 xh[PMT_NT];
+                float rs;
+                {
+                    f4 xr[PMT_NT];
 #pragma unroll
-            for (int t = 0; t < PMT_NT; ++t) dy[rt][t] = dy[rt][t] + dxr[t];
-        }
-        if (mask_all) {
-            vec_grad_atomic<PMT_NT>(gtheta + uniform(B.norm_w_src), dlw, D, g);
-            vec_grad_atomic<PMT_NT>(gtheta + uniform(B.norm_b_src), dlb, D, g);
+                    for (int t = 0; t < PMT_NT; ++t) xr[t] = f4{0.f, 0.f, 0.f, 0.f};
+                    if (mask_all & (1u << rt)) stash_load<PMT_NT>(xs[rt], xr);
+                    layernorm_stats_tile<PMT_NT>(xh, rs, xr, D, g);
+                }
+                layernorm_bwd_inplace_tile<PMT_NT>(dy[rt], dn[rt], xh, rs, D, lw, dlw, dlb, g);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (mask_all) {
+                vec_grad_atomic<PMT_NT>(gtheta + uniform(B.norm_w_src), dlw, D, g);
+                vec_grad_atomic<PMT_NT>(gtheta + uniform(B.norm_b_src), dlb, D, g);
+            }
         }
     }
 

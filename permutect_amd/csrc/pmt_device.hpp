@@ -74,7 +74,7 @@ DEV f4 load_pvec(const float* __restrict__ p, int t, int g) { return *reinterpre
 // `frag` = packed A fragments of W ([out_dim][in_dim]).  SELU_IN applies SELU to the input on the fly.
 // ---------------------------------------------------------------------------------------------------------------
 #define PMT_FULL_MASK ((1u << PMT_RT) - 1u)
-template <int NTI, int NTO, bool SELU_IN, bool MASKED>
+template <int NTI, int NTO, bool SELU_IN, bool MASKED, bool EXACT>
 DEV void linear_acc_impl(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], const float* __restrict__ frag, int in_dim,
                          int out_dim, unsigned tile_mask, float in_scale) {
     // Fragments are stored kt-major ((kt * nmt + mt) * 256 floats), i.e. in exactly the order this loop nest consumes
@@ -86,13 +86,19 @@ DEV void linear_acc_impl(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], co
     f4 a_next = fp[0];
 #pragma unroll
     for (int kt = 0; kt < NTI; ++kt) {
-        if (kt < nkt) {
+        if (EXACT || kt < nkt) {
             f4 b[PMT_RT];
 #pragma unroll
-            for (int rt = 0; rt < PMT_RT; ++rt) b[rt] = SELU_IN ? selu4(in[rt][kt]) * in_scale : in[rt][kt];
+            for (int rt = 0; rt < PMT_RT; ++rt) {
+                b[rt] = SELU_IN ? selu4(in[rt][kt]) * in_scale : in[rt][kt];
+                // MASKED (a wave whose tiles sit on both sides of the ref/alt boundary): tiles outside the mask get a
+                // zero B operand instead of a branch per MFMA.  (Per-MFMA guards made the compiler keep dozens of lane
+                // masks alive, spill them through VGPR lanes and then spill thousands of VGPRs.)
+                if (MASKED && !(tile_mask & (1u << rt))) b[rt] = f4{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
             for (int mt = 0; mt < NTO; ++mt) {
-                if (mt < nmt) {
+                if (EXACT || mt < nmt) {
                     const f4 a = a_next;
                     fp += 64;
                     a_next = fp[0];  // one fragment past the end on the last step: still inside the padded region
@@ -100,7 +106,7 @@ DEV void linear_acc_impl(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], co
                     for (int j = 0; j < 4; ++j) {
 #pragma unroll
                         for (int rt = 0; rt < PMT_RT; ++rt)
-                            if (!MASKED || (tile_mask & (1u << rt))) acc[rt][mt] = mfma16(a[j], b[rt][j], acc[rt][mt]);
+                            acc[rt][mt] = mfma16(a[j], b[rt][j], acc[rt][mt]);
                     }
                 }
             }
@@ -112,10 +118,17 @@ DEV void linear_acc_impl(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], co
 template <int NTI, int NTO, bool SELU_IN>
 DEV void linear_acc(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], const float* __restrict__ frag, int in_dim,
                     int out_dim, unsigned tile_mask, float in_scale = 1.0f) {
-    if (tile_mask == PMT_FULL_MASK)
-        linear_acc_impl<NTI, NTO, SELU_IN, false>(acc, in, frag, in_dim, out_dim, tile_mask, in_scale);
-    else if (tile_mask != 0)
-        linear_acc_impl<NTI, NTO, SELU_IN, true>(acc, in, frag, in_dim, out_dim, tile_mask, in_scale);
+    // EXACT: the layer fills every tile of both register arrays -> one straight-line MFMA chain with no per-tile guards
+    // (guards turn every accumulator into a web of PHI copies; they were the source of thousands of VGPR spills).
+    const bool exact = ((in_dim + 15) >> 4) == NTI && ((out_dim + 15) >> 4) == NTO;
+    if (tile_mask == PMT_FULL_MASK) {
+        if (exact)
+            linear_acc_impl<NTI, NTO, SELU_IN, false, true>(acc, in, frag, in_dim, out_dim, tile_mask, in_scale);
+        else
+            linear_acc_impl<NTI, NTO, SELU_IN, false, false>(acc, in, frag, in_dim, out_dim, tile_mask, in_scale);
+    } else if (tile_mask != 0) {
+        linear_acc_impl<NTI, NTO, SELU_IN, true, false>(acc, in, frag, in_dim, out_dim, tile_mask, in_scale);
+    }
 }
 
 // acc[rt][mt] = bias (tile-position order) for every tile; rows beyond out_dim are zero in the packed bias
