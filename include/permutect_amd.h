@@ -40,6 +40,10 @@ extern "C" {
 #define PMT_MAX_HALF_FFN 16     /* d_ffn / 2 */
 #define PMT_MAX_CLUSTERS 16
 #define PMT_MAX_OPS 8           /* top-level ops per MLP program */
+#define PMT_MAX_ROW_INPUT 128    /* widest input of a per-variant row MLP (info vector) */
+#define PMT_ROWS_INFO 0
+#define PMT_ROWS_ALT_COUNT 1
+#define PMT_ROWS_SOURCE 2
 #define PMT_MAX_SKIP_LAYERS 4
 #define PMT_MAX_BLOCKS 16
 #define PMT_MAX_LINEAR 96
@@ -134,6 +138,9 @@ typedef struct PmtModel {
     int32_t rotation_lin;       /* linear id, weight source = phi (materialised Q), no bias */
     PmtMlp read_mlp;            /* read_embedding  */
     PmtMlp reducer;             /* reducer         */
+    PmtMlp row_mlp[3];          /* per-variant row MLPs (pmt_rows_*): [0] info_embedding, [1] alt_count_predictor,
+                                   [2] source_predictor (n_ops = 0 when there is a single source).  Their first
+                                   linear may read up to PMT_MAX_ROW_INPUT features                               */
     PmtBlock blocks[PMT_MAX_BLOCKS];
     PmtHead head;
     PmtLinear lin[PMT_MAX_LINEAR];
@@ -235,6 +242,23 @@ int pmt_forward(const PmtModel* model_host, const PmtModel* model_dev, const flo
 int pmt_backward(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* phi,
                  const float* packed, const PmtBatch* batch, const PmtOutputs* out, const PmtOutputGrads* dout,
                  const float* stash, float* grad_theta, float* grad_phi, float* grad_variant_embed, void* stream);
+
+/* Row-wise MLP over N independent rows -- the per-variant branches: `which` = PMT_ROWS_INFO (info_embedding,
+ * reference artifact_model.py:244), PMT_ROWS_ALT_COUNT (alt_count_predictor, :180-183, :276-279) or PMT_ROWS_SOURCE
+ * (source_predictor, :267-274).  in: [n_rows] rows of in_dim floats with the given row stride (floats); out likewise, so a
+ * result can be written straight into a column block of a wider matrix.  stash = NULL for inference, else
+ * pmt_rows_stash_bytes() bytes that the backward pass re-reads. */
+size_t pmt_rows_stash_bytes(const PmtModel* model, int which, int32_t n_rows);
+int pmt_rows_forward(const PmtModel* model_host, const PmtModel* model_dev, int which, const float* theta,
+                     const float* packed, const float* in, int64_t in_stride, int32_t n_rows, float* out,
+                     int64_t out_stride, float* stash, void* stream);
+/* Backward of pmt_rows_forward: accumulates parameter gradients into grad_theta (atomics) and, if d_in != NULL, writes
+ * d_in = d_in_scale * dL/d(in)  (d_in_scale = -alpha implements the reference's gradient reversal,
+ * gradient_reversal/functional.py:18-22). */
+int pmt_rows_backward(const PmtModel* model_host, const PmtModel* model_dev, int which, const float* theta,
+                      const float* packed, const float* in, int64_t in_stride, int32_t n_rows, const float* d_out,
+                      int64_t d_out_stride, const float* stash, float* grad_theta, float* d_in, int64_t d_in_stride,
+                      float d_in_scale, void* stream);
 
 /* Global-norm clip + AdamW over the flat parameter buffer, one launch sequence, no host sync.
  * Replaces nn.utils.clip_grad_norm_(max_norm=1.0) + torch.optim.AdamW.step (reference misc_utils.py:128-129).

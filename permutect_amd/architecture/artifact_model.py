@@ -18,7 +18,8 @@ from permutect_amd import constants
 from permutect_amd.architecture import modules as M
 from permutect_amd.data.batch import Batch
 from permutect_amd.data.datum import Data
-from permutect_amd.engine.runtime import ReadSetEngine, ReadSetFunction
+from permutect_amd.engine import lib as L
+from permutect_amd.engine.runtime import ReadSetEngine, ReadSetFunction, RowsMlpFunction
 from permutect_amd.enums import Epoch
 from permutect_amd.parameters import ModelParameters, install_pickle_alias
 
@@ -143,15 +144,18 @@ class ArtifactModel(nn.Module):
 
     # ---- forward ------------------------------------------------------------------------------------------------------
     def variant_embedding(self, batch: Batch) -> Tensor:
-        """[B, E_info + E_hap]: the per-variant part of every read's input (reference artifact_model.py:244-246)."""
-        info = self.info_embedding(batch.get_info_be().to(dtype=self._dtype))
+        """[B, E_info + E_hap]: the per-variant part of every read's input (reference artifact_model.py:244-246).
+        The info MLP is a HIP row kernel (pmt_rows_forward); requires packed weights to be current (see _encode)."""
+        eng = self.engine()
+        info = RowsMlpFunction.apply(eng, L.ROWS_INFO, batch.get_info_be(), eng.trigger, 0.0)
         hap = self.haplotypes_cnn(batch.get_one_hot_haplotypes_bcs().to(dtype=self._dtype))
         return torch.hstack((info, hap))
 
     def _encode(self, batch: Batch):
         eng = self.engine()
-        variant_embed = self.variant_embedding(batch)
         phi = eng.plan.materialize_phi(self)
+        eng.pack(phi.detach().contiguous())  # weights -> MFMA fragment order, once per forward, before any kernel uses them
+        variant_embed = self.variant_embedding(batch)
         outs = ReadSetFunction.apply(eng, batch, phi, variant_embed)
         return outs, variant_embed
 
@@ -174,14 +178,19 @@ class ArtifactModel(nn.Module):
     # ---- losses (reference artifact_model.py:267-325) --------------------------------------------------------------------
     def compute_source_prediction_losses(self, features_be: Tensor, batch: Batch) -> Tensor:
         if self.num_sources > 1:
-            logits = self.source_predictor.adversarial_forward(features_be)
+            eng = self.engine()
+            logits = RowsMlpFunction.apply(eng, L.ROWS_SOURCE, features_be, eng.trigger,
+                                           float(self.source_predictor.gradient_reversal.alpha))
             probs = torch.softmax(logits, dim=-1)
             targets = torch.nn.functional.one_hot(batch.get(Data.SOURCE).long(), self.num_sources)
             return torch.sum(torch.square(probs - targets), dim=-1)
         return torch.zeros(batch.size(), device=self._device, dtype=self._dtype)
 
     def compute_alt_count_losses(self, features_be: Tensor, batch: Batch) -> Tensor:
-        pred = torch.sigmoid(self.alt_count_predictor.adversarial_forward(features_be).view(-1))
+        eng = self.engine()
+        raw = RowsMlpFunction.apply(eng, L.ROWS_ALT_COUNT, features_be, eng.trigger,
+                                    float(self.alt_count_predictor.gradient_reversal.alpha))
+        pred = torch.sigmoid(raw.view(-1))
         target = batch.get(Data.ALT_COUNT).to(dtype=pred.dtype) / constants.MAX_ALT_COUNT
         return self.alt_count_loss_func(pred, target)
 

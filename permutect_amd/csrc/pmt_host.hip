@@ -29,26 +29,27 @@ extern "C" int pmt_stash_slots(const PmtModel* m) { return (m->read_mlp.n_ops - 
 // ---------------------------------------------------------------------------------------------------------------------
 // descriptor validation
 // ---------------------------------------------------------------------------------------------------------------------
-static int check_linear(const PmtModel* m, int id, int in_dim, int out_dim) {
+static int check_linear(const PmtModel* m, int id, int in_dim, int out_dim, int max_in = PMT_MAX_WIDTH) {
     if (id < 0 || id >= m->n_linear) return PMT_E_INVALID;
     const PmtLinear* l = &m->lin[id];
     if (l->in_dim != in_dim || l->out_dim != out_dim) return PMT_E_INVALID;
-    if (in_dim < 1 || out_dim < 1 || in_dim > PMT_MAX_WIDTH || out_dim > PMT_MAX_WIDTH) return PMT_E_UNSUPPORTED;
+    if (in_dim < 1 || out_dim < 1 || in_dim > max_in || out_dim > PMT_MAX_WIDTH) return PMT_E_UNSUPPORTED;
     if (l->w_frag < 0 || l->wt_frag < 0 || (l->w_frag & 3) || (l->wt_frag & 3)) return PMT_E_INVALID;
     if (l->b_pvec >= 0 && (l->b_pvec & 3)) return PMT_E_INVALID;
     if (l->b_pvec >= 0 && l->w_stage > 0 && (l->b_pvec < l->w_frag || l->b_pvec >= l->w_frag + l->w_stage)) return PMT_E_INVALID;
     return PMT_OK;
 }
 
-static int check_mlp(const PmtModel* m, const PmtMlp* mlp) {
+static int check_mlp(const PmtModel* m, const PmtMlp* mlp, int max_in = PMT_MAX_WIDTH) {
     if (mlp->n_ops < 1 || mlp->n_ops > PMT_MAX_OPS) return PMT_E_UNSUPPORTED;
     int width = mlp->in_dim;
+    if (width > PMT_MAX_WIDTH && mlp->ops[0].kind != PMT_OP_LINEAR) return PMT_E_UNSUPPORTED;
     for (int i = 0; i < mlp->n_ops; ++i) {
         const PmtOp* o = &mlp->ops[i];
         if (o->kind == PMT_OP_LINEAR) {
             if (o->lin[0] < 0 || o->lin[0] >= m->n_linear) return PMT_E_INVALID;
             const int out = m->lin[o->lin[0]].out_dim;
-            const int rc = check_linear(m, o->lin[0], width, out);
+            const int rc = check_linear(m, o->lin[0], width, out, i == 0 ? max_in : PMT_MAX_WIDTH);
             if (rc) return rc;
             width = out;
         } else if (o->kind == PMT_OP_SKIP) {
@@ -81,6 +82,10 @@ extern "C" int pmt_model_check(const PmtModel* m) {
     if (rc) return rc;
     rc = check_mlp(m, &m->reducer);
     if (rc) return rc;
+    for (int k = 0; k < 3; ++k) {
+        if (m->row_mlp[k].n_ops == 0 && k == PMT_ROWS_SOURCE) continue;
+        if ((rc = check_mlp(m, &m->row_mlp[k], PMT_MAX_ROW_INPUT))) return rc;
+    }
     const int h = m->d_ffn / 2;
     for (int l = 0; l < m->num_blocks; ++l) {
         const PmtBlock* b = &m->blocks[l];

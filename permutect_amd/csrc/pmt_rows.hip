@@ -1,0 +1,225 @@
+// Row-wise MLPs over independent rows: the per-variant branches of the artifact model (info embedding,
+// alt-count adversary, source adversary; reference artifact_model.py:244, :180-183/:276-279, :267-274, mlp.py:8-76).
+// Same register layout, MFMA linear, layer-program interpreter and weight-gradient machinery as the read-set kernels
+// (pmt_device.hpp); a "tile" is 16 rows, there are no sets.  The first linear may read up to 128 input features (the
+// info vector has 71), held in an 8-tile input array.
+#define PMT_WG_COLS PMT_MAX_ROW_INPUT
+#include "pmt_device.hpp"
+#include "pmt_mlp_device.hpp"
+#include "pmt_bwd_device.hpp"
+
+#define ROWS_NTIN (PMT_MAX_ROW_INPUT / 16)
+#define ROWS_PER_BLOCK (PMT_WAVES * PMT_RT * 16)
+
+extern "C" int pmt_stash_slots(const PmtModel* m);
+
+// rows -> input registers (tile-position layout), zero beyond in_dim / n_rows
+template <int NTIN>
+DEV void load_rows(f4 (&x)[PMT_RT][NTIN], const float* __restrict__ in, long long stride, int n_rows, int in_dim, int tile0,
+                   int g) {
+    const int r = threadIdx.x & 15;
+#pragma unroll
+    for (int rt = 0; rt < PMT_RT; ++rt) {
+        const int row = (tile0 + rt) * 16 + r;
+        const float* p = in + (size_t)row * stride;
+#pragma unroll
+        for (int t = 0; t < NTIN; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int f = feat_of(t, j, g);
+                x[rt][t][j] = (row < n_rows && f < in_dim) ? p[f] : 0.f;
+            }
+    }
+}
+
+template <bool TRAIN>
+__global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_forward_kernel(const PmtModel* __restrict__ M, int which,
+                                                                           const float* __restrict__ theta,
+                                                                           const float* __restrict__ packed,
+                                                                           const float* __restrict__ in, long long in_stride,
+                                                                           int n_rows, float* __restrict__ out,
+                                                                           long long out_stride, float* __restrict__ stash) {
+    const PmtMlp& mlp = M->row_mlp[which];
+    const int lane = threadIdx.x & 63, g = lane >> 4, wave = uniform((int)(threadIdx.x >> 6));
+    const int tile0 = (blockIdx.x * PMT_WAVES + wave) * PMT_RT;
+    const int in_dim = uniform(mlp.in_dim), out_dim = uniform(mlp.out_dim), n_ops = uniform(mlp.n_ops);
+    float* stash_tile[PMT_RT];
+    unsigned present = 0;
+#pragma unroll
+    for (int rt = 0; rt < PMT_RT; ++rt) {
+        if ((tile0 + rt) * 16 < n_rows) present |= 1u << rt;
+        stash_tile[rt] = TRAIN ? stash + (size_t)(tile0 + rt) * (size_t)((n_ops - 1) * PMT_SLOT_FLOATS) : nullptr;
+    }
+    WStage ws{nullptr, nullptr, 0, 0, packed, nullptr};
+    f4 x[PMT_RT][PMT_NT];
+    int slot = 0, op_begin = 0;
+    if (in_dim > PMT_MAX_WIDTH) {  // wide first linear (checked on the host: op 0 is LINEAR)
+        f4 xin[PMT_RT][ROWS_NTIN];
+        load_rows<ROWS_NTIN>(xin, in, in_stride, n_rows, in_dim, tile0, g);
+        const PmtOp& o = mlp.ops[0];
+        const PmtLinear& L = M->lin[uniform(o.lin[0])];
+        const int b_pvec = uniform(L.b_pvec);
+        init_bias<PMT_NT>(x, b_pvec >= 0 ? packed + b_pvec : nullptr, uniform(L.out_dim), g);
+        linear_acc<ROWS_NTIN, PMT_NT, false>(x, xin, packed + uniform(L.w_frag), in_dim, uniform(L.out_dim), PMT_FULL_MASK);
+        if (uniform(o.selu_after) != 0) {
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                for (int t = 0; t < PMT_NT; ++t) x[rt][t] = selu4(x[rt][t]);
+        }
+        op_begin = 1;
+    } else {
+        load_rows<PMT_NT>(x, in, in_stride, n_rows, in_dim, tile0, g);
+    }
+    run_mlp<TRAIN, false>(M, mlp, x, packed, theta, g, present, stash_tile, slot, 1, ws, op_begin);
+    const int r = lane & 15;
+#pragma unroll
+    for (int rt = 0; rt < PMT_RT; ++rt) {
+        const int row = (tile0 + rt) * 16 + r;
+        if (row < n_rows) {
+            float* p = out + (size_t)row * out_stride;
+#pragma unroll
+            for (int t = 0; t < PMT_NT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (feat_of(t, j, g) < out_dim) p[feat_of(t, j, g)] = x[rt][t][j];
+        }
+    }
+}
+
+struct RowsBwdShared {
+    float wg[2][WG_TILE + PMT_MAX_WIDTH];
+    float tr[PMT_WAVES][16 * TR_STRIDE];
+};
+
+__global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_backward_kernel(
+    const PmtModel* __restrict__ M, int which, const float* __restrict__ theta, const float* __restrict__ packed,
+    const float* __restrict__ in, long long in_stride, int n_rows, const float* __restrict__ d_out, long long d_out_stride,
+    const float* __restrict__ stash, float* __restrict__ gtheta, float* __restrict__ d_in, long long d_in_stride,
+    float d_in_scale) {
+    __shared__ __attribute__((aligned(16))) RowsBwdShared sh;
+    const PmtMlp& mlp = M->row_mlp[which];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, r = lane & 15, wave = uniform((int)(tid >> 6));
+    const int tile0 = (blockIdx.x * PMT_WAVES + wave) * PMT_RT;
+    const int in_dim = uniform(mlp.in_dim), out_dim = uniform(mlp.out_dim), n_ops = uniform(mlp.n_ops);
+    for (int i = tid; i < 2 * (WG_TILE + PMT_MAX_WIDTH); i += PMT_THREADS) (&sh.wg[0][0])[i] = 0.f;
+    __syncthreads();
+    unsigned present = 0;
+    const float* stash_tile[PMT_RT];
+#pragma unroll
+    for (int rt = 0; rt < PMT_RT; ++rt) {
+        if ((tile0 + rt) * 16 < n_rows) present |= 1u << rt;
+        stash_tile[rt] = stash + (size_t)(tile0 + rt) * (size_t)((n_ops - 1) * PMT_SLOT_FLOATS);
+    }
+    // (phi / gphi are never dereferenced for row MLPs -- all their leaves are direct -- but passing nullptr constants here
+    //  makes hipcc 7.2's SimplifyCFG crash while folding grad_ptr(), so theta / gtheta stand in)
+    BwdCtx c{M, theta, theta, packed, gtheta, gtheta, {&sh.wg[0][0], &sh.wg[1][0]}, &sh.tr[wave][0], g, present, 0};
+    // d(out) -> registers (zero for padding rows: they then contribute nothing to any weight gradient)
+    f4 dy[PMT_RT][PMT_NT];
+#pragma unroll
+    for (int rt = 0; rt < PMT_RT; ++rt) {
+        const int row = (tile0 + rt) * 16 + r;
+        const float* p = d_out + (size_t)row * d_out_stride;
+#pragma unroll
+        for (int t = 0; t < PMT_NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int f = feat_of(t, j, g);
+                dy[rt][t][j] = (row < n_rows && f < out_dim) ? p[f] : 0.f;
+            }
+    }
+    auto load_input = [&](int op, f4 (&x)[PMT_RT][PMT_NT]) {
+        if (op == 0) {
+            load_rows<PMT_NT>(x, in, in_stride, n_rows, in_dim, tile0, g);
+        } else {
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt) {
+#pragma unroll
+                for (int t = 0; t < PMT_NT; ++t) x[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
+                if (present & (1u << rt)) stash_load<PMT_NT>(stash_tile[rt] + (op - 1) * PMT_SLOT_FLOATS, x[rt]);
+            }
+        }
+    };
+    const bool wide = in_dim > PMT_MAX_WIDTH;
+    const bool want_d_in = d_in != nullptr;
+    const int first_op = wide ? 1 : 0;
+    mlp_backward(c, mlp, dy, want_d_in, load_input, first_op);
+    if (wide) {  // op 0 is a LINEAR with up to 128 inputs: weight gradient only (its input needs no gradient)
+        const PmtOp& o = mlp.ops[0];
+        const PmtLinear& L = M->lin[uniform(o.lin[0])];
+        f4 xin[PMT_RT][ROWS_NTIN];
+        load_rows<ROWS_NTIN>(xin, in, in_stride, n_rows, in_dim, tile0, g);
+        if (uniform(o.selu_after) != 0) {
+            f4 y[PMT_RT][PMT_NT];
+            const int b_pvec = uniform(L.b_pvec);
+            init_bias<PMT_NT>(y, b_pvec >= 0 ? packed + b_pvec : nullptr, uniform(L.out_dim), g);
+            linear_acc<ROWS_NTIN, PMT_NT, false>(y, xin, packed + uniform(L.w_frag), in_dim, uniform(L.out_dim), PMT_FULL_MASK);
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                for (int t = 0; t < PMT_NT; ++t) dy[rt][t] = selu_bwd4(dy[rt][t], selu4(y[rt][t]));
+        }
+        linear_wgrad<PMT_NT, ROWS_NTIN>(c, L, dy, xin, present);
+    }
+    if (!wide && want_d_in) {
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt) {
+            const int row = (tile0 + rt) * 16 + r;
+            if (row < n_rows) {
+                float* p = d_in + (size_t)row * d_in_stride;
+#pragma unroll
+                for (int t = 0; t < PMT_NT; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (feat_of(t, j, g) < in_dim) p[feat_of(t, j, g)] = d_in_scale * dy[rt][t][j];
+            }
+        }
+    }
+}
+
+static int rows_check(const PmtModel* m, int which, int n_rows) {
+    if (!m || which < 0 || which > 2 || n_rows < 0) return PMT_E_INVALID;
+    if (m->row_mlp[which].n_ops < 1) return PMT_E_INVALID;
+    return pmt_model_check(m);
+}
+
+extern "C" size_t pmt_rows_stash_bytes(const PmtModel* m, int which, int32_t n_rows) {
+    if (!m || which < 0 || which > 2) return 0;
+    const size_t tiles = ((size_t)n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK * (PMT_WAVES * PMT_RT);
+    const int slots = m->row_mlp[which].n_ops > 1 ? m->row_mlp[which].n_ops - 1 : 1;
+    return tiles * slots * PMT_SLOT_FLOATS * sizeof(float);
+}
+
+extern "C" int pmt_rows_forward(const PmtModel* model_host, const PmtModel* model_dev, int which, const float* theta,
+                                const float* packed, const float* in, int64_t in_stride, int32_t n_rows, float* out,
+                                int64_t out_stride, float* stash, void* stream) {
+    const int rc = rows_check(model_host, which, n_rows);
+    if (rc) return rc;
+    if (!model_dev || !theta || !packed || !in || !out) return PMT_E_INVALID;
+    if (n_rows == 0) return PMT_OK;
+    const int grid = (n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (stash)
+        hipLaunchKernelGGL(pmt_rows_forward_kernel<true>, dim3(grid), dim3(PMT_THREADS), 0, s, model_dev, which, theta, packed, in,
+                           (long long)in_stride, n_rows, out, (long long)out_stride, stash);
+    else
+        hipLaunchKernelGGL(pmt_rows_forward_kernel<false>, dim3(grid), dim3(PMT_THREADS), 0, s, model_dev, which, theta, packed,
+                           in, (long long)in_stride, n_rows, out, (long long)out_stride, (float*)nullptr);
+    return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
+}
+
+extern "C" int pmt_rows_backward(const PmtModel* model_host, const PmtModel* model_dev, int which, const float* theta,
+                                 const float* packed, const float* in, int64_t in_stride, int32_t n_rows, const float* d_out,
+                                 int64_t d_out_stride, const float* stash, float* grad_theta, float* d_in,
+                                 int64_t d_in_stride, float d_in_scale, void* stream) {
+    const int rc = rows_check(model_host, which, n_rows);
+    if (rc) return rc;
+    if (!model_dev || !theta || !packed || !in || !d_out || !stash || !grad_theta) return PMT_E_INVALID;
+    if (model_host->row_mlp[which].in_dim > PMT_MAX_WIDTH && d_in) return PMT_E_UNSUPPORTED;
+    if (n_rows == 0) return PMT_OK;
+    const int grid = (n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    hipLaunchKernelGGL(pmt_rows_backward_kernel, dim3(grid), dim3(PMT_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
+                       model_dev, which, theta, packed, in, (long long)in_stride, n_rows, d_out, (long long)d_out_stride, stash,
+                       grad_theta, d_in, (long long)d_in_stride, d_in_scale);
+    return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
+}

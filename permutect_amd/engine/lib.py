@@ -14,6 +14,8 @@ LIB_PATH = os.path.join(_HERE, "libpermutect_amd.so")
 # ---- limits (must match the header) -------------------------------------------------------------------------------
 ABI_VERSION = 1
 MAX_WIDTH, MAX_HALF_FFN, MAX_CLUSTERS = 64, 16, 16
+MAX_ROW_INPUT = 128
+ROWS_INFO, ROWS_ALT_COUNT, ROWS_SOURCE = 0, 1, 2
 MAX_OPS, MAX_SKIP_LAYERS, MAX_BLOCKS, MAX_LINEAR = 8, 4, 16, 96
 MAX_SCHED, STAGE_FLOATS = 192, 4608
 GROUP_WAVES, GROUP_TILES, GROUP_MAX_SETS, TILE = 8, 16, 64, 16
@@ -66,7 +68,7 @@ class PmtModel(C.Structure):
                 ("feature_dim", i32), ("num_clusters", i32), ("n_linear", i32),
                 ("theta_size", i32), ("phi_size", i32), ("packed_size", i32),
                 ("translation_src", i32), ("translation_pvec", i32), ("rotation_lin", i32),
-                ("read_mlp", PmtMlp), ("reducer", PmtMlp), ("blocks", PmtBlock * MAX_BLOCKS), ("head", PmtHead),
+                ("read_mlp", PmtMlp), ("reducer", PmtMlp), ("row_mlp", PmtMlp * 3), ("blocks", PmtBlock * MAX_BLOCKS), ("head", PmtHead),
                 ("lin", PmtLinear * MAX_LINEAR), ("n_fwd_sched", i32), ("n_bwd_sched", i32),
                 ("fwd_sched", PmtStage * MAX_SCHED), ("bwd_sched", PmtStage * MAX_SCHED)]
 
@@ -91,7 +93,8 @@ class PmtAdamW(C.Structure):
 
 
 EXPORTS = ["pmt_abi_version", "pmt_struct_bytes", "pmt_model_check", "pmt_build_schedules", "pmt_plan_groups", "pmt_stash_bytes", "pmt_pack_params",
-           "pmt_scan_counts", "pmt_forward", "pmt_backward", "pmt_clip_adamw"]
+           "pmt_scan_counts", "pmt_forward", "pmt_backward", "pmt_clip_adamw",
+           "pmt_rows_stash_bytes", "pmt_rows_forward", "pmt_rows_backward"]
 
 _lib = None
 
@@ -127,9 +130,13 @@ def load() -> C.CDLL:
     lib.pmt_forward.argtypes = [P(PmtModel), vp, vp, vp, vp, P(PmtBatch), P(PmtOutputs), vp, vp]
     lib.pmt_backward.argtypes = [P(PmtModel), vp, vp, vp, vp, P(PmtBatch), P(PmtOutputs), P(PmtOutputGrads), vp, vp, vp, vp, vp]
     lib.pmt_clip_adamw.argtypes = [vp, vp, vp, vp, i64, P(PmtAdamW), vp, vp, vp]
+    lib.pmt_rows_stash_bytes.argtypes = [P(PmtModel), i32, i32]
+    lib.pmt_rows_stash_bytes.restype = C.c_size_t
+    lib.pmt_rows_forward.argtypes = [P(PmtModel), vp, i32, vp, vp, vp, i64, i32, vp, i64, vp, vp]
+    lib.pmt_rows_backward.argtypes = [P(PmtModel), vp, i32, vp, vp, vp, i64, i32, vp, i64, vp, vp, vp, i64, C.c_float, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("pmt_abi_version", "pmt_stash_bytes"):
+        if name not in ("pmt_abi_version", "pmt_stash_bytes", "pmt_rows_stash_bytes"):
             fn.restype = i32
     lib.pmt_struct_bytes.argtypes = [i32]
     if lib.pmt_abi_version() != ABI_VERSION:

@@ -111,6 +111,11 @@ class EnginePlan:
             b.gamma_src = space.offset_of(s.gamma)
             b.reg_weight_phi = self._alloc_phi(f"reg_weight.{i}", 1)
         self._lower_mlp(d.reducer, reducer)
+        # per-variant row MLPs (pmt_rows_*)
+        self._lower_mlp(d.row_mlp[L.ROWS_INFO], model.info_embedding, max_in=L.MAX_ROW_INPUT)
+        self._lower_mlp(d.row_mlp[L.ROWS_ALT_COUNT], model.alt_count_predictor.wrapped_module)
+        if model.num_sources > 1:
+            self._lower_mlp(d.row_mlp[L.ROWS_SOURCE], model.source_predictor.wrapped_module)
 
         tr = model.pre_clustering_transform
         d.translation_src = space.offset_of(tr.translation_e)
@@ -164,10 +169,10 @@ class EnginePlan:
         return n
 
     def _add_raw_linear(self, in_dim: int, out_dim: int, w_src: int, b_src: int, has_bias: bool, out_split: int = 0,
-                        alloc: bool = True, extra_vectors=(), out=None) -> int:
+                        alloc: bool = True, extra_vectors=(), out=None, max_in: int = L.MAX_WIDTH) -> int:
         if self._n_lin >= L.MAX_LINEAR:
             raise L.PmtError("too many linear layers for the kernel descriptor")
-        if in_dim > L.MAX_WIDTH or out_dim > L.MAX_WIDTH:
+        if in_dim > max_in or out_dim > L.MAX_WIDTH:
             raise L.PmtError(f"layer width {in_dim}->{out_dim} exceeds the register-resident limit {L.MAX_WIDTH}")
         lin = self.desc.lin[self._n_lin]
         out_v = 16 + out_split if out_split else out_dim
@@ -204,12 +209,12 @@ class EnginePlan:
         lr.wt_frag = self._alloc_packed(nfl); la.wt_frag = self._alloc_packed(nfl)
         return ids[0], ids[1]
 
-    def _add_linear(self, layer: nn.Linear, out_split: int = 0) -> int:
+    def _add_linear(self, layer: nn.Linear, out_split: int = 0, max_in: int = L.MAX_WIDTH) -> int:
         b_src = self.space.offset_of(layer.bias) if layer.bias is not None else -1
         return self._add_raw_linear(layer.in_features, layer.out_features, self.space.offset_of(layer.weight), b_src,
-                                    layer.bias is not None, out_split)
+                                    layer.bias is not None, out_split, max_in=max_in)
 
-    def _lower_mlp(self, dst: L.PmtMlp, mlp: M.MLP):
+    def _lower_mlp(self, dst: L.PmtMlp, mlp: M.MLP, max_in: int = L.MAX_WIDTH):
         children = list(mlp._model.children())
         ops = []
         i = 0
@@ -234,7 +239,7 @@ class EnginePlan:
             o = dst.ops[j]
             if op[0] == "lin":
                 o.kind, o.n_layers, o.selu_after, o.alpha_src = L.OP_LINEAR, 1, int(op[2]), -1
-                o.lin[0] = self._add_linear(op[1])
+                o.lin[0] = self._add_linear(op[1], max_in=max_in if j == 0 else L.MAX_WIDTH)
             else:
                 blk, lins = op[1], op[2]
                 if len(lins) > 2:

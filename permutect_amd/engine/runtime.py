@@ -33,6 +33,7 @@ class ReadSetEngine:
         self.device = device
         self.space = ParamSpace(model, device)
         self.plan = EnginePlan(model, self.space, device)
+        self.trigger = torch.zeros(1, dtype=torch.float32, device=device, requires_grad=True)  # see RowsMlpFunction
         self.timers = None  # bench.py sets {'pmt_forward': [], 'pmt_backward': []} to collect (start, end) HIP events
 
     def _event_start(self):
@@ -92,7 +93,6 @@ class ReadSetEngine:
         variant_embed = variant_embed.contiguous().float()
         assert variant_embed.shape == (b, d.variant_embed_dim), (variant_embed.shape, d.variant_embed_dim)
         phi = phi.contiguous()
-        self.pack(phi)
         bv, keep, plan = self.batch_view(batch, variant_embed)
         dev = self.device
         logits_b = torch.empty(b, dtype=torch.float32, device=dev)
@@ -152,3 +152,52 @@ class ReadSetFunction(torch.autograd.Function):
         ctx.engine.space.bind_grads()
         gphi, gvar = ctx.engine.backward(ctx.batch, phi, ve, stash, outs, (d_logits_b, d_logits_bk, d_feats, d_ref_feats))
         return None, None, gphi, gvar
+
+
+class RowsMlpFunction(torch.autograd.Function):
+    """One of the per-variant row MLPs (pmt_rows_forward / pmt_rows_backward): info embedding, alt-count adversary,
+    source adversary.  `x` is [N, in_dim] fp32 (any row stride); the result is [N, out_dim].  `trigger` is the engine's
+    1-element leaf that makes autograd call backward even when x itself needs no gradient (the MLP's own parameters
+    live in the flat buffer and receive their gradients by atomics inside the kernel).  `reverse_alpha` > 0 applies the
+    reference's gradient reversal to d(x) (architecture/adversarial.py:23-27)."""
+
+    @staticmethod
+    def forward(ctx, engine: ReadSetEngine, which: int, x: Tensor, trigger: Tensor, reverse_alpha: float):
+        lib, d = engine.lib, engine.plan.desc
+        mlp = d.row_mlp[which]
+        n = x.shape[0]
+        x = x.detach()
+        if x.dtype != torch.float32 or x.stride(-1) != 1:
+            x = x.float().contiguous()
+        assert x.shape[1] == mlp.in_dim
+        out = torch.empty(n, mlp.out_dim, dtype=torch.float32, device=engine.device)
+        train = bool(ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
+        stash = None
+        if train:
+            stash = torch.empty(lib.pmt_rows_stash_bytes(C.byref(d), which, n) // 4, dtype=torch.float32, device=engine.device)
+        L.check(lib.pmt_rows_forward(C.byref(d), engine.plan.desc_dev.data_ptr(), which, engine.space.theta.data_ptr(),
+                                     engine.plan.packed.data_ptr(), x.data_ptr(), x.stride(0), n, out.data_ptr(),
+                                     out.stride(0), _ptr(stash), _stream()), "pmt_rows_forward")
+        ctx.engine, ctx.which, ctx.train, ctx.alpha = engine, which, train, reverse_alpha
+        ctx.x_needs_grad = bool(ctx.needs_input_grad[2])
+        if train:
+            ctx.save_for_backward(x, stash)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        if not ctx.train:
+            return None, None, None, None, None
+        x, stash = ctx.saved_tensors
+        eng, d = ctx.engine, ctx.engine.plan.desc
+        eng.space.bind_grads()
+        if d_out.dtype != torch.float32 or d_out.stride(-1) != 1:
+            d_out = d_out.float().contiguous()
+        n = x.shape[0]
+        d_in = torch.empty_like(x) if ctx.x_needs_grad else None
+        scale = -ctx.alpha if ctx.alpha else 1.0
+        L.check(eng.lib.pmt_rows_backward(C.byref(d), eng.plan.desc_dev.data_ptr(), ctx.which, eng.space.theta.data_ptr(),
+                                          eng.plan.packed.data_ptr(), x.data_ptr(), x.stride(0), n, d_out.data_ptr(),
+                                          d_out.stride(0), stash.data_ptr(), eng.space.gtheta.data_ptr(), _ptr(d_in),
+                                          d_in.stride(0) if d_in is not None else 0, scale, _stream()), "pmt_rows_backward")
+        return None, None, d_in, torch.zeros(1, device=eng.device), None
