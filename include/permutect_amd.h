@@ -121,6 +121,36 @@ typedef struct PmtHead {
     int32_t reserved;
 } PmtHead;
 
+/* Haplotype CNN (reference architecture/dna_sequence_convolution.py:31-111): a short list of 1-D layers applied to the
+ * [10][S] one-hot of the ref/alt haplotypes; evaluated per variant entirely in LDS by pmt_cnn_forward / _backward. */
+#define PMT_MAX_CNN_LAYERS 12
+#define PMT_CNN_CONV 0
+#define PMT_CNN_POOL 1
+#define PMT_CNN_LEAKY_RELU 2
+#define PMT_CNN_SELU 3
+#define PMT_CNN_FLATTEN 4
+#define PMT_CNN_LINEAR 5
+typedef struct PmtCnnLayer {
+    int32_t kind;
+    int32_t in_ch, in_len, out_ch, out_len;     /* LINEAR (after FLATTEN): in_ch = features, in_len = out_len = 1 */
+    int32_t kernel, stride, padding, dilation;  /* CONV / POOL */
+    int32_t w_src, b_src;                       /* theta offsets of weight ([out][in][k] or [out][in]) and bias */
+    int32_t in_off, out_off;                    /* per-variant offsets of this layer's input / output in the backward's
+                                                   activation region (the one-hot input sits at offset 0)         */
+    int32_t lin;                                /* CONV: PmtLinear id of the weight viewed as [out_ch][in_ch * kernel]
+                                                   (packed fragments for the implicit-GEMM kernels), else -1      */
+    int32_t reserved[2];
+} PmtCnnLayer;
+typedef struct PmtCnn {
+    int32_t n_layers;
+    int32_t seq_len;    /* S = haplotypes_length / 2 */
+    int32_t out_dim;    /* width of the haplotype embedding */
+    int32_t max_act;    /* max floats of any single activation (including the 10*S input) */
+    int32_t sum_act;    /* floats of input + every layer output (backward keeps them all in LDS) */
+    int32_t reserved[3];
+    PmtCnnLayer layers[PMT_MAX_CNN_LAYERS];
+} PmtCnn;
+
 typedef struct PmtModel {
     int32_t abi_version;
     int32_t num_read_features;  /* F */
@@ -143,6 +173,7 @@ typedef struct PmtModel {
                                    linear may read up to PMT_MAX_ROW_INPUT features                               */
     PmtBlock blocks[PMT_MAX_BLOCKS];
     PmtHead head;
+    PmtCnn cnn;                 /* haplotypes_cnn */
     PmtLinear lin[PMT_MAX_LINEAR];
     /* Weight-staging schedules (filled by pmt_build_schedules): the ranges of the packed buffer in the order the
      * forward / backward kernels consume them.  The kernels DMA entry i+1 into LDS while computing with entry i.
@@ -259,6 +290,16 @@ int pmt_rows_backward(const PmtModel* model_host, const PmtModel* model_dev, int
                       const float* packed, const float* in, int64_t in_stride, int32_t n_rows, const float* d_out,
                       int64_t d_out_stride, const float* stash, float* grad_theta, float* d_in, int64_t d_in_stride,
                       float d_in_scale, void* stream);
+
+/* Haplotype CNN: haplotypes = device int64 [n][H] rows (values 0..4: A, C, G, T, indel; ref half then alt half,
+ * reference data/batch.py:110-130) with the given row stride in elements; out = [n][cnn.out_dim] with row stride.
+ * Replaces Batch.get_one_hot_haplotypes_bcs + DNASequenceConvolution.forward (artifact_model.py:245). */
+int pmt_cnn_forward(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* packed,
+                    const int64_t* haplotypes, int64_t hap_stride, int32_t n, float* out, int64_t out_stride, void* stream);
+/* Backward: recomputes the forward in LDS and accumulates parameter gradients into grad_theta (atomics). */
+int pmt_cnn_backward(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* packed,
+                     const int64_t* haplotypes, int64_t hap_stride, int32_t n, const float* d_out, int64_t d_out_stride,
+                     float* grad_theta, void* stream);
 
 /* Global-norm clip + AdamW over the flat parameter buffer, one launch sequence, no host sync.
  * Replaces nn.utils.clip_grad_norm_(max_norm=1.0) + torch.optim.AdamW.step (reference misc_utils.py:128-129).

@@ -19,7 +19,7 @@ from permutect_amd.architecture import modules as M
 from permutect_amd.data.batch import Batch
 from permutect_amd.data.datum import Data
 from permutect_amd.engine import lib as L
-from permutect_amd.engine.runtime import ReadSetEngine, ReadSetFunction, RowsMlpFunction
+from permutect_amd.engine.runtime import HaplotypeCnnFunction, ReadSetEngine, ReadSetFunction, RowsMlpFunction
 from permutect_amd.enums import Epoch
 from permutect_amd.parameters import ModelParameters, install_pickle_alias
 
@@ -148,7 +148,7 @@ class ArtifactModel(nn.Module):
         The info MLP is a HIP row kernel (pmt_rows_forward); requires packed weights to be current (see _encode)."""
         eng = self.engine()
         info = RowsMlpFunction.apply(eng, L.ROWS_INFO, batch.get_info_be(), eng.trigger, 0.0)
-        hap = self.haplotypes_cnn(batch.get_one_hot_haplotypes_bcs().to(dtype=self._dtype))
+        hap = HaplotypeCnnFunction.apply(eng, batch.get_haplotypes_bs(), eng.trigger)
         return torch.hstack((info, hap))
 
     def _encode(self, batch: Batch):

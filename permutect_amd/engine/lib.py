@@ -62,13 +62,28 @@ class PmtHead(C.Structure):
                 ("mu_k_src", i32), ("sigma_k_phi", i32), ("lambda_k_phi", i32), ("reserved", i32)]
 
 
+MAX_CNN_LAYERS = 12
+CNN_CONV, CNN_POOL, CNN_LEAKY_RELU, CNN_SELU, CNN_FLATTEN, CNN_LINEAR = range(6)
+
+
+class PmtCnnLayer(C.Structure):
+    _fields_ = [("kind", i32), ("in_ch", i32), ("in_len", i32), ("out_ch", i32), ("out_len", i32),
+                ("kernel", i32), ("stride", i32), ("padding", i32), ("dilation", i32), ("w_src", i32), ("b_src", i32),
+                ("in_off", i32), ("out_off", i32), ("lin", i32), ("reserved", i32 * 2)]
+
+
+class PmtCnn(C.Structure):
+    _fields_ = [("n_layers", i32), ("seq_len", i32), ("out_dim", i32), ("max_act", i32), ("sum_act", i32),
+                ("reserved", i32 * 3), ("layers", PmtCnnLayer * MAX_CNN_LAYERS)]
+
+
 class PmtModel(C.Structure):
     _fields_ = [("abi_version", i32), ("num_read_features", i32), ("read_embed_dim", i32),
                 ("variant_embed_dim", i32), ("d_model", i32), ("d_ffn", i32), ("num_blocks", i32),
                 ("feature_dim", i32), ("num_clusters", i32), ("n_linear", i32),
                 ("theta_size", i32), ("phi_size", i32), ("packed_size", i32),
                 ("translation_src", i32), ("translation_pvec", i32), ("rotation_lin", i32),
-                ("read_mlp", PmtMlp), ("reducer", PmtMlp), ("row_mlp", PmtMlp * 3), ("blocks", PmtBlock * MAX_BLOCKS), ("head", PmtHead),
+                ("read_mlp", PmtMlp), ("reducer", PmtMlp), ("row_mlp", PmtMlp * 3), ("blocks", PmtBlock * MAX_BLOCKS), ("head", PmtHead), ("cnn", PmtCnn),
                 ("lin", PmtLinear * MAX_LINEAR), ("n_fwd_sched", i32), ("n_bwd_sched", i32),
                 ("fwd_sched", PmtStage * MAX_SCHED), ("bwd_sched", PmtStage * MAX_SCHED)]
 
@@ -94,7 +109,7 @@ class PmtAdamW(C.Structure):
 
 EXPORTS = ["pmt_abi_version", "pmt_struct_bytes", "pmt_model_check", "pmt_build_schedules", "pmt_plan_groups", "pmt_stash_bytes", "pmt_pack_params",
            "pmt_scan_counts", "pmt_forward", "pmt_backward", "pmt_clip_adamw",
-           "pmt_rows_stash_bytes", "pmt_rows_forward", "pmt_rows_backward"]
+           "pmt_rows_stash_bytes", "pmt_rows_forward", "pmt_rows_backward", "pmt_cnn_forward", "pmt_cnn_backward"]
 
 _lib = None
 
@@ -130,6 +145,8 @@ def load() -> C.CDLL:
     lib.pmt_forward.argtypes = [P(PmtModel), vp, vp, vp, vp, P(PmtBatch), P(PmtOutputs), vp, vp]
     lib.pmt_backward.argtypes = [P(PmtModel), vp, vp, vp, vp, P(PmtBatch), P(PmtOutputs), P(PmtOutputGrads), vp, vp, vp, vp, vp]
     lib.pmt_clip_adamw.argtypes = [vp, vp, vp, vp, i64, P(PmtAdamW), vp, vp, vp]
+    lib.pmt_cnn_forward.argtypes = [P(PmtModel), vp, vp, vp, vp, i64, i32, vp, i64, vp]
+    lib.pmt_cnn_backward.argtypes = [P(PmtModel), vp, vp, vp, vp, i64, i32, vp, i64, vp, vp]
     lib.pmt_rows_stash_bytes.argtypes = [P(PmtModel), i32, i32]
     lib.pmt_rows_stash_bytes.restype = C.c_size_t
     lib.pmt_rows_forward.argtypes = [P(PmtModel), vp, i32, vp, vp, vp, i64, i32, vp, i64, vp, vp]

@@ -134,6 +134,7 @@ class EnginePlan:
         hd.lambda_k_phi = self._alloc_phi("lambda_k", k)
         hd.mu_k_src = space.offset_of(fc.artifact_emg.mu_k)
 
+        self._lower_cnn(d.cnn, model.haplotypes_cnn, model.haplotypes_length() // 2)
         d.n_linear = self._n_lin
         d.theta_size, d.phi_size, d.packed_size = space.size, max(self._phi_off, 4), self._packed_off + 256
 
@@ -248,6 +249,56 @@ class EnginePlan:
                 o.alpha_src = self.space.offset_of(blk.alpha)
                 for t, lin in enumerate(lins):
                     o.lin[t] = self._add_linear(lin)
+
+    def _lower_cnn(self, dst: L.PmtCnn, cnn: M.DNASequenceConvolution, seq_len: int):
+        layers = list(cnn._model.children())
+        if len(layers) > L.MAX_CNN_LAYERS:
+            raise L.PmtError(f"haplotype CNN with {len(layers)} layers exceeds the kernel limit {L.MAX_CNN_LAYERS}")
+        ch, length = M.INITIAL_NUM_CHANNELS, seq_len
+        off = ch * length  # the one-hot input occupies [0, 10*S)
+        in_off, max_act = 0, ch * length
+        for i, layer in enumerate(layers):
+            c = dst.layers[i]
+            c.in_ch, c.in_len, c.in_off = ch, length, in_off
+            c.kernel, c.stride, c.padding, c.dilation = 1, 1, 0, 1
+            c.w_src = c.b_src = c.lin = -1
+            if isinstance(layer, nn.Conv1d):
+                if layer.groups != 1 or layer.padding_mode != "zeros" or isinstance(layer.padding, str):
+                    raise L.PmtError("unsupported Conv1d options in the haplotype CNN")
+                c.kind = L.CNN_CONV
+                c.kernel, c.stride, c.padding, c.dilation = layer.kernel_size[0], layer.stride[0], layer.padding[0], layer.dilation[0]
+                c.w_src, c.b_src = self.space.offset_of(layer.weight), self.space.offset_of(layer.bias)
+                # the weight [out][in][k] is contiguous = an [out][in*k] matrix: packed like any linear (implicit GEMM)
+                c.lin = self._add_raw_linear(ch * c.kernel, layer.out_channels, c.w_src, c.b_src, True, max_in=L.MAX_ROW_INPUT)
+                ch, length = layer.out_channels, M._conv_len(length, kernel_size=c.kernel, stride=c.stride, padding=c.padding, dilation=c.dilation)
+            elif isinstance(layer, nn.MaxPool1d):
+                if layer.padding != 0 or layer.dilation != 1 or layer.ceil_mode:
+                    raise L.PmtError("unsupported MaxPool1d options in the haplotype CNN")
+                c.kind = L.CNN_POOL
+                c.kernel = layer.kernel_size
+                c.stride = layer.stride if layer.stride is not None else layer.kernel_size
+                length = M._pool_len(length, kernel_size=c.kernel, stride=c.stride)
+            elif isinstance(layer, nn.LeakyReLU):
+                c.kind = L.CNN_LEAKY_RELU
+            elif isinstance(layer, nn.SELU):
+                c.kind = L.CNN_SELU
+            elif isinstance(layer, nn.Flatten):
+                c.kind = L.CNN_FLATTEN
+                ch, length = ch * length, 1
+                c.out_ch, c.out_len, c.out_off = ch, length, in_off
+                continue
+            elif isinstance(layer, nn.Linear):
+                c.kind = L.CNN_LINEAR
+                c.w_src, c.b_src = self.space.offset_of(layer.weight), self.space.offset_of(layer.bias)
+                ch, length = layer.out_features, 1
+            else:
+                raise L.PmtError(f"unsupported layer in the haplotype CNN: {type(layer).__name__}")
+            c.out_ch, c.out_len, c.out_off = ch, length, off
+            in_off = off
+            off += ch * length
+            max_act = max(max_act, ch * length)
+        dst.n_layers, dst.seq_len, dst.out_dim = len(layers), seq_len, ch * length
+        dst.max_act, dst.sum_act = max_act, off
 
     # ---- phi ------------------------------------------------------------------------------------------------------
     def materialize_phi(self, model) -> torch.Tensor:

@@ -154,6 +154,39 @@ class ReadSetFunction(torch.autograd.Function):
         return None, None, gphi, gvar
 
 
+class HaplotypeCnnFunction(torch.autograd.Function):
+    """haplotypes int64 [B, H] -> haplotype embedding [B, E_h] (pmt_cnn_forward / pmt_cnn_backward).  Replaces
+    Batch.get_one_hot_haplotypes_bcs + DNASequenceConvolution.forward (reference artifact_model.py:245).  The CNN's
+    parameters get their gradients by atomics into the flat buffer; `trigger` makes autograd call backward."""
+
+    @staticmethod
+    def forward(ctx, engine: ReadSetEngine, haplotypes: Tensor, trigger: Tensor):
+        d = engine.plan.desc
+        hap = haplotypes if haplotypes.dtype == torch.int64 else haplotypes.long()
+        assert hap.stride(-1) == 1 and hap.shape[1] == 2 * d.cnn.seq_len
+        n = hap.shape[0]
+        out = torch.empty(n, d.cnn.out_dim, dtype=torch.float32, device=engine.device)
+        L.check(engine.lib.pmt_cnn_forward(C.byref(d), engine.plan.desc_dev.data_ptr(), engine.space.theta.data_ptr(),
+                                           engine.plan.packed.data_ptr(), hap.data_ptr(), hap.stride(0), n, out.data_ptr(), out.stride(0), _stream()),
+                "pmt_cnn_forward")
+        ctx.engine, ctx.train = engine, bool(ctx.needs_input_grad[2])
+        ctx.hap = hap  # integer tensor: kept on ctx (save_for_backward is for differentiable tensors' bookkeeping)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        if not ctx.train:
+            return None, None, None
+        eng, d, hap = ctx.engine, ctx.engine.plan.desc, ctx.hap
+        eng.space.bind_grads()
+        if d_out.dtype != torch.float32 or d_out.stride(-1) != 1:
+            d_out = d_out.float().contiguous()
+        L.check(eng.lib.pmt_cnn_backward(C.byref(d), eng.plan.desc_dev.data_ptr(), eng.space.theta.data_ptr(),
+                                         eng.plan.packed.data_ptr(), hap.data_ptr(), hap.stride(0), hap.shape[0], d_out.data_ptr(), d_out.stride(0),
+                                         eng.space.gtheta.data_ptr(), _stream()), "pmt_cnn_backward")
+        return None, None, torch.zeros(1, device=eng.device)
+
+
 class RowsMlpFunction(torch.autograd.Function):
     """One of the per-variant row MLPs (pmt_rows_forward / pmt_rows_backward): info embedding, alt-count adversary,
     source adversary.  `x` is [N, in_dim] fp32 (any row stride); the result is [N, out_dim].  `trigger` is the engine's

