@@ -198,7 +198,8 @@ typedef struct PmtBatch {
     const int32_t* group_start;     /* device [G+1] first variant of each group (pmt_plan_groups) */
     const int32_t* group_tile_base; /* device [G+1] first stash tile of each group (pmt_plan_groups) */
     int64_t total_tiles;            /* host value of group_tile_base[G] (sizes the stash)             */
-    int32_t* debug_flags;           /* device, optional [4]: [0] counts weight-staging schedule misses  */
+    int32_t* debug_flags;           /* device, optional [64]: [0] counts weight-staging schedule misses, [1] development
+                                       switches of the backward kernel (0 in production), [8:56] 24 x u64 cycle counters */
 } PmtBatch;
 
 typedef struct PmtOutputs {

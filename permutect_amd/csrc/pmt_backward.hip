@@ -103,7 +103,10 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         if (tm[rt].side == 0) mask_side[0] |= 1u << rt; else mask_side[1] |= 1u << rt;
         stash_tile[rt] = stash + (size_t)(bt.group_tile_base[blockIdx.x] + gg.tile_begin + rt) * (size_t)(nslots * PMT_SLOT_FLOATS);
     }
-    BwdCtx c{M, theta, phi, packed, gtheta, gphi, {&sh.wg[0][0], &sh.wg[1][0]}, &sh.tr[wave][0], g, mask_all, 0};
+    BwdCtx c{M, theta, phi, packed, gtheta, gphi, &sh.wg[0][0], &sh.tr[wave][0], g, mask_all, 0,
+             bt.debug_flags ? uniform(bt.debug_flags[1]) : 0,
+             bt.debug_flags ? reinterpret_cast<unsigned long long*>(bt.debug_flags + 8) : nullptr};
+    const unsigned long long t_kernel0 = prof_now();
     const int n_read_ops = uniform(M->read_mlp.n_ops), n_red_ops = uniform(M->reducer.n_ops);
     const int slot_x0 = n_read_ops - 1, slot_red = slot_x0 + L + 1;
 
@@ -277,6 +280,8 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         }
         if (mask_side[1]) vec_grad_atomic<PMT_NT>(gphi + uniform(M->head.stdev_e_phi), dsig, E, g);
 
+        prof_add(c, 4, t_kernel0);
+        unsigned long long t_rot = prof_now();
         // ---- rotation + translation backward: a = Q (r + t) ------------------------------------------------------------
         linear_wgrad<PMT_NT, PMT_NT>(c, R, dy, r, mask_all);
         f4 dx[PMT_RT][PMT_NT];
@@ -293,13 +298,16 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             }
         }
         if (mask_all) vec_grad_atomic<PMT_NT>(gtheta + uniform(M->translation_src), dt, E, g);
+        prof_add(c, 5, t_rot);
     }
+    unsigned long long t_ph = prof_now();
 
     // ---- reducer backward ---------------------------------------------------------------------------------------------
     mlp_backward(c, M->reducer, dy, true, [&](int op, f4 (&x)[PMT_RT][PMT_NT]) { load_slot(op == 0 ? slot_x0 + L : slot_red + op - 1, x); });
 
+    prof_add(c, 6, t_ph);
     // ---- gated blocks backward -----------------------------------------------------------------------------------------
-    for (int l = L - 1; l >= 0; --l) {
+    for (int l = (c.dbg & 4) ? -1 : L - 1; l >= 0; --l) {
         // Register discipline (this loop body used to spill thousands of VGPRs): nothing of width D except the running
         // gradient dy stays live across phases.  x_l is re-read from the stash (L2/HBM, 4 KB per tile) and its LayerNorm
         // recomputed each of the three times it is needed; z2 / gate are recomputed from z2hat.
@@ -324,6 +332,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
                 layernorm_tile<PMT_NT>(n[rt], xh, rs, xr, D, lw, lb, g);
             }
         };
+        t_ph = prof_now();
         // ---- phase 1: z = selu(W1 n + b1) ---------------------------------------------------------------------------
         f4 z[PMT_RT][2];
 #pragma unroll
@@ -360,6 +369,8 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             f4 gt = z2_out * (s == 0 ? alpha_ref : alpha_alt) + 1.0f;
             return s == 0 ? gt + beta_ref * m_ref : (gt + beta_alt * m_alt) + gamma * m_ref;
         };
+        prof_add(c, 8, t_ph);
+        t_ph = prof_now();
         // ---- phase 2: d(u) = W2^T dy, d(gate), per-set sums of d(gate), proj2 weight gradient ------------------------------
         f4 z2hat[PMT_RT], dgate[PMT_RT], du[PMT_RT][1];
         float rstd2[PMT_RT];
@@ -398,17 +409,21 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
                     if (ok && feat_of(0, j, g) < h) atomicAdd(&sh.gsum[set][s][4 * g + j], dg);
                 }
             }
+            prof_add(c, 9, t_ph);
+            t_ph = prof_now();
             // proj2 weight gradients (per side); the barrier inside also completes gsum
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const PmtLinear& P2 = M->lin[uniform(B.proj2[s])];
                 float* buf = sh.wg[c.wg_flip];
-                wgrad_accumulate<PMT_NT, 1>(buf, c.tr, dy, u, D, h, mask_side[s] & mask_all, true);
+                if (!(c.dbg & 1)) wgrad_accumulate<PMT_NT, 1>(buf, c.tr, dy, u, D, h, mask_side[s] & mask_all, true);
                 __syncthreads();
-                wgrad_flush(buf, P2, 1.0f, gtheta, gphi);
+                if (!(c.dbg & 3)) wgrad_flush(buf, P2, 1.0f, gtheta, gphi);
                 c.wg_flip ^= 1;
             }
         }
+        prof_add(c, 10, t_ph);
+        t_ph = prof_now();
         // per-set coupling: d(m_ref), d(m_alt), d(ref_regularizer), d(reg_weight)
         for (int i = tid; i < gg.nsets * 16; i += PMT_THREADS) {
             const int set = i >> 4, p = i & 15, f = pos_to_feat(p);
@@ -428,6 +443,8 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         }
         __syncthreads();
         for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS) (&sh.gsum[0][0][0])[i] = 0.f;
+        prof_add(c, 11, t_ph);
+        t_ph = prof_now();
         // ---- phase 3: finish d(z2), LayerNorm(h) backward, SELU backward -> d(zpre) ---------------------------------------
         f4 dz[PMT_RT][2];
         {
@@ -457,6 +474,8 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
                 scalar_grad_atomic(gtheta + uniform(B.gamma_src), d_gamma);
             }
         }
+        prof_add(c, 12, t_ph);
+        t_ph = prof_now();
         // ---- phase 4: proj1 weight gradient (needs n again), d(n) = W1^T d(zpre), LayerNorm(D) backward ---------------------
         {
             f4 n[PMT_RT][PMT_NT];
@@ -465,12 +484,14 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             for (int s = 0; s < 2; ++s) {
                 const PmtLinear& P1 = M->lin[uniform(B.proj1[s])];
                 float* buf = sh.wg[c.wg_flip];
-                wgrad_accumulate<2, PMT_NT>(buf, c.tr, dz, n, 16 + h, D, mask_side[s] & mask_all, true);
+                if (!(c.dbg & 1)) wgrad_accumulate<2, PMT_NT>(buf, c.tr, dz, n, 16 + h, D, mask_side[s] & mask_all, true);
                 __syncthreads();
-                wgrad_flush(buf, P1, 1.0f, gtheta, gphi);
+                if (!(c.dbg & 3)) wgrad_flush(buf, P1, 1.0f, gtheta, gphi);
                 c.wg_flip ^= 1;
             }
         }
+        prof_add(c, 13, t_ph);
+        t_ph = prof_now();
         {
             f4 dn[PMT_RT][PMT_NT];
             init_bias<PMT_NT>(dn, nullptr, D, g);
@@ -505,7 +526,9 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
                 vec_grad_atomic<PMT_NT>(gtheta + uniform(B.norm_b_src), dlb, D, g);
             }
         }
+        prof_add(c, 14, t_ph);
     }
+    t_ph = prof_now();
 
     // ---- split d(x_0): variant-embedding part -> per-set sums; read-embedding part -> read MLP backward --------------
 #pragma unroll
@@ -541,11 +564,13 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
                 for (int j = 0; j < 4; ++j) x[rt][t][j] = rowp ? read_feature_b(rowp, fmt, feat_of(t, j, g), F) : 0.f;
         }
     });
+    prof_add(c, 16, t_ph);
     __syncthreads();
     for (int i = tid; i < gg.nsets * Ev; i += PMT_THREADS) {
         const int set = i / Ev, f = i - set * Ev;
         gvar[(size_t)(gg.v0 + set) * Ev + f] = sh.dv[set][f];
     }
+    prof_add(c, 7, t_kernel0);  // whole kernel, per wave
 }
 
 extern "C" int pmt_backward(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* phi,

@@ -20,13 +20,16 @@ DEV float wave_sum(float v) { return group_sum(read_lanes_sum(v)); }
 
 // C-layout registers of one 16x16 (feature x read) tile -> "reads on k" operand: element ks = value of feature position
 // p = lane & 15 for read 4 * (lane >> 4) + ks.
-DEV f4 transpose_tile(float* __restrict__ tr, f4 v) {
-    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+//
+// Done on the matrix core, with no LDS round trip: a C-layout register is also a valid A operand (m = read = lane & 15,
+// k = lane >> 4 <-> position 4*(lane>>4) + j at k-step j), so  D = X^T * I  with the 16x16 identity as B lands the tile
+// transposed in C layout (row 4G+J = read, column = position).  Multiplying by exact 0 / 1 makes it bit-exact.  Four
+// MFMAs per tile on a pipe that is mostly idle in this kernel, instead of 4 ds_write + 1 ds_read and two LDS latencies.
+DEV f4 transpose_tile(float* __restrict__ /*unused LDS scratch*/, f4 v) {
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    f4 o = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) tr[(4 * g + j) * TR_STRIDE + r] = v[j];
-    __builtin_amdgcn_wave_barrier();
-    const f4 o = *reinterpret_cast<const f4*>(&tr[(lane & 15) * TR_STRIDE + 4 * (lane >> 4)]);
-    __builtin_amdgcn_wave_barrier();
+    for (int j = 0; j < 4; ++j) o = mfma16(v[j], (n == 4 * g + j) ? 1.0f : 0.0f, o);
     return o;
 }
 
@@ -241,119 +244,137 @@ struct BwdCtx {
     const float* packed;
     float* gtheta;
     float* gphi;
-    float* wg[2];   // LDS: two weight(+bias)-gradient tile buffers of WG_TILE + PMT_MAX_WIDTH floats
+    float* wg;      // LDS: two CONTIGUOUS weight(+bias)-gradient tile buffers of WG_TILE + PMT_MAX_WIDTH floats each.
+                    // One base pointer + offset (not an array of pointers): a runtime-indexed pointer array defeats
+                    // address-space inference and turns every LDS atomic into a slow flat_atomic_add_f32.
     float* tr;      // this wave's transpose tile
     int g;
     unsigned mask_all;
     int wg_flip;    // which weight-gradient buffer the next linear uses
+    int dbg;        // profiling aid (PmtBatch.debug_flags[1]): bit 0 skip weight gradients, bit 1 skip their flush only,
+                    // bit 3 accumulate per-section cycle counts into prof[]
+    unsigned long long* prof;  // device, 8 counters (see scripts/bwd_ablate.py); only touched when dbg bit 3 is set
 };
+DEV unsigned long long prof_now() { return __builtin_readcyclecounter(); }
+DEV void prof_add(const BwdCtx& c, int slot, unsigned long long t0) {
+    if ((c.dbg & 8) && c.prof != nullptr && (threadIdx.x & 63) == 0) atomicAdd(c.prof + slot, prof_now() - t0);
+}
 
 // One linear's weight/bias gradient: accumulate, workgroup barrier, flush.  Every wave of the group must call it.
 template <int NTO, int NTI>
 DEV void linear_wgrad(BwdCtx& c, const PmtLinear& L, const f4 (&dy)[PMT_RT][NTO], const f4 (&x)[PMT_RT][NTI], unsigned mask,
                       float scale = 1.0f) {
-    float* buf = c.wg[c.wg_flip];
+    if (c.dbg & 1) return;
+    float* buf = c.wg + c.wg_flip * (WG_TILE + PMT_MAX_WIDTH);
     const int h = uniform(L.out_split);
     const int out_v = h > 0 ? 16 + h : uniform(L.out_dim);
+    unsigned long long t0 = prof_now();
     wgrad_accumulate<NTO, NTI>(buf, c.tr, dy, x, out_v, uniform(L.in_dim), mask, uniform(L.b_src) != -1);
+    prof_add(c, 0, t0);
+    t0 = prof_now();
     __syncthreads();
-    wgrad_flush(buf, L, scale, c.gtheta, c.gphi);
+    prof_add(c, 1, t0);
+    t0 = prof_now();
+    if (!(c.dbg & 2)) wgrad_flush(buf, L, scale, c.gtheta, c.gphi);
+    prof_add(c, 2, t0);
     c.wg_flip ^= 1;
 }
 
 // backward of one MLP program.  dy (in/out): gradient w.r.t. the MLP output on entry, w.r.t. its input on exit
 // (not computed for op 0 when need_input_grad is false).  in_slot(op) gives the stash slot of op's input.
-template <typename LoadInput>
-DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][PMT_NT], bool need_input_grad, LoadInput load_input,
+template <int NT = PMT_NT, typename LoadInput>
+DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool need_input_grad, LoadInput load_input,
                       int op_begin = 0) {
     const PmtModel* M = c.M;
     const int n_ops = uniform(mlp.n_ops);
     for (int op = n_ops - 1; op >= op_begin; --op) {
         const PmtOp& o = mlp.ops[op];
-        f4 x[PMT_RT][PMT_NT];
+        f4 x[PMT_RT][NT];
         load_input(op, x);
         if (uniform(o.kind) == PMT_OP_LINEAR) {
             const PmtLinear& L = M->lin[uniform(o.lin[0])];
             const int in_dim = uniform(L.in_dim), out_dim = uniform(L.out_dim);
             if (uniform(o.selu_after) != 0) {  // recompute s = selu(Wx + b); dy <- dy * selu'(s)
-                f4 y[PMT_RT][PMT_NT];
-                init_bias<PMT_NT>(y, uniform(L.b_pvec) >= 0 ? c.packed + uniform(L.b_pvec) : nullptr, out_dim, c.g);
-                linear_acc<PMT_NT, PMT_NT, false>(y, x, c.packed + uniform(L.w_frag), in_dim, out_dim, PMT_FULL_MASK);
+                f4 y[PMT_RT][NT];
+                init_bias<NT>(y, uniform(L.b_pvec) >= 0 ? c.packed + uniform(L.b_pvec) : nullptr, out_dim, c.g);
+                linear_acc<NT, NT, false>(y, x, c.packed + uniform(L.w_frag), in_dim, out_dim, PMT_FULL_MASK);
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
-                    for (int t = 0; t < PMT_NT; ++t) dy[rt][t] = selu_bwd4(dy[rt][t], selu4(y[rt][t]));
+                    for (int t = 0; t < NT; ++t) dy[rt][t] = selu_bwd4(dy[rt][t], selu4(y[rt][t]));
             }
-            linear_wgrad<PMT_NT, PMT_NT>(c, L, dy, x, PMT_FULL_MASK);
+            linear_wgrad<NT, NT>(c, L, dy, x, c.mask_all);
             if (op > 0 || need_input_grad) {
-                f4 dx[PMT_RT][PMT_NT];
-                init_bias<PMT_NT>(dx, nullptr, in_dim, c.g);
-                linear_acc<PMT_NT, PMT_NT, false>(dx, dy, c.packed + uniform(L.wt_frag), out_dim, in_dim, PMT_FULL_MASK);
+                f4 dx[PMT_RT][NT];
+                init_bias<NT>(dx, nullptr, in_dim, c.g);
+                linear_acc<NT, NT, false>(dx, dy, c.packed + uniform(L.wt_frag), out_dim, in_dim, PMT_FULL_MASK);
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
-                    for (int t = 0; t < PMT_NT; ++t) dy[rt][t] = dx[rt][t];
+                    for (int t = 0; t < NT; ++t) dy[rt][t] = dx[rt][t];
             }
         } else {
             // y = x + alpha * f(x); f = L2(selu(L1(selu(x))))  (n = 2)   or   f = L1(selu(x))  (n = 1)
+            // Register discipline: at most three width-sized arrays are live at once (dy + two); s0 = selu(x) is
+            // recomputed from a second read of the stashed x instead of being kept across the L2 phase.
             const int nl = uniform(o.n_layers);
             const PmtLinear& L1 = M->lin[uniform(o.lin[0])];
             const PmtLinear& L2 = M->lin[uniform(o.lin[nl - 1])];
             const int width = uniform(L1.in_dim);
             const float alpha = uniform(c.theta[uniform(o.alpha_src)]);
-            f4 s0[PMT_RT][PMT_NT], s1[PMT_RT][PMT_NT];
+            f4 s1[PMT_RT][NT];
+            if (nl == 2) {  // s1 = selu(L1 selu(x) + b1)
+                init_bias<NT>(s1, c.packed + uniform(L1.b_pvec), width, c.g);
+                linear_acc<NT, NT, true>(s1, x, c.packed + uniform(L1.w_frag), width, width, PMT_FULL_MASK);
+            }
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
-                for (int t = 0; t < PMT_NT; ++t) s0[rt][t] = selu4(x[rt][t]);
-            if (nl == 2) {
-                init_bias<PMT_NT>(s1, c.packed + uniform(L1.b_pvec), width, c.g);
-                linear_acc<PMT_NT, PMT_NT, false>(s1, s0, c.packed + uniform(L1.w_frag), width, width, PMT_FULL_MASK);
-#pragma unroll
-                for (int rt = 0; rt < PMT_RT; ++rt)
-#pragma unroll
-                    for (int t = 0; t < PMT_NT; ++t) s1[rt][t] = selu4(s1[rt][t]);
-            } else {
-#pragma unroll
-                for (int rt = 0; rt < PMT_RT; ++rt)
-#pragma unroll
-                    for (int t = 0; t < PMT_NT; ++t) s1[rt][t] = s0[rt][t];
-            }
-            {   // d(alpha) = sum dy . f,  f = L2 s1 + b2
-                f4 f[PMT_RT][PMT_NT];
-                init_bias<PMT_NT>(f, c.packed + uniform(L2.b_pvec), width, c.g);
-                linear_acc<PMT_NT, PMT_NT, false>(f, s1, c.packed + uniform(L2.w_frag), width, width, PMT_FULL_MASK);
+                for (int t = 0; t < NT; ++t) s1[rt][t] = selu4(nl == 2 ? s1[rt][t] : x[rt][t]);
+            {   // d(alpha) = sum dy . f,  f = L2 s1 + b2   (x's registers are free from here on)
+                f4 f[PMT_RT][NT];
+                init_bias<NT>(f, c.packed + uniform(L2.b_pvec), width, c.g);
+                linear_acc<NT, NT, false>(f, s1, c.packed + uniform(L2.w_frag), width, width, PMT_FULL_MASK);
                 float da = 0.f;
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
-                    for (int t = 0; t < PMT_NT; ++t) da += (dy[rt][t][0] * f[rt][t][0] + dy[rt][t][1] * f[rt][t][1]) + (dy[rt][t][2] * f[rt][t][2] + dy[rt][t][3] * f[rt][t][3]);
+                    for (int t = 0; t < NT; ++t) da += (dy[rt][t][0] * f[rt][t][0] + dy[rt][t][1] * f[rt][t][1]) + (dy[rt][t][2] * f[rt][t][2] + dy[rt][t][3] * f[rt][t][3]);
                 scalar_grad_atomic(c.gtheta + uniform(o.alpha_src), da);
             }
+            __builtin_amdgcn_sched_barrier(0);
             // last layer: d(f) = alpha * dy
-            linear_wgrad<PMT_NT, PMT_NT>(c, L2, dy, s1, c.mask_all, alpha);
-            f4 d1[PMT_RT][PMT_NT];
-            init_bias<PMT_NT>(d1, nullptr, width, c.g);
-            linear_acc<PMT_NT, PMT_NT, false>(d1, dy, c.packed + uniform(L2.wt_frag), width, width, PMT_FULL_MASK);
+            linear_wgrad<NT, NT>(c, L2, dy, s1, c.mask_all, alpha);
+            f4 d1[PMT_RT][NT];
+            init_bias<NT>(d1, nullptr, width, c.g);
+            linear_acc<NT, NT, false>(d1, dy, c.packed + uniform(L2.wt_frag), width, width, PMT_FULL_MASK);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
-                for (int t = 0; t < PMT_NT; ++t) d1[rt][t] = alpha * selu_bwd4(d1[rt][t], s1[rt][t]);  // d(h1) (n=2) or d(x) part (n=1)
+                for (int t = 0; t < NT; ++t) d1[rt][t] = alpha * selu_bwd4(d1[rt][t], s1[rt][t]);  // d(h1) (n=2) or d(x) part (n=1)
+            __builtin_amdgcn_sched_barrier(0);
             if (nl == 2) {
-                linear_wgrad<PMT_NT, PMT_NT>(c, L1, d1, s0, PMT_FULL_MASK);
-                f4 d0[PMT_RT][PMT_NT];
-                init_bias<PMT_NT>(d0, nullptr, width, c.g);
-                linear_acc<PMT_NT, PMT_NT, false>(d0, d1, c.packed + uniform(L1.wt_frag), width, width, PMT_FULL_MASK);
+                f4 s0[PMT_RT][NT];  // second read of x (s1's registers are free now)
+                load_input(op, s0);
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
-                    for (int t = 0; t < PMT_NT; ++t) dy[rt][t] = dy[rt][t] + selu_bwd4(d0[rt][t], s0[rt][t]);
+                    for (int t = 0; t < NT; ++t) s0[rt][t] = selu4(s0[rt][t]);
+                linear_wgrad<NT, NT>(c, L1, d1, s0, c.mask_all);
+                f4 d0[PMT_RT][NT];
+                init_bias<NT>(d0, nullptr, width, c.g);
+                linear_acc<NT, NT, false>(d0, d1, c.packed + uniform(L1.wt_frag), width, width, PMT_FULL_MASK);
+#pragma unroll
+                for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) dy[rt][t] = dy[rt][t] + selu_bwd4(d0[rt][t], s0[rt][t]);
             } else {
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
-                    for (int t = 0; t < PMT_NT; ++t) dy[rt][t] = dy[rt][t] + d1[rt][t];
+                    for (int t = 0; t < NT; ++t) dy[rt][t] = dy[rt][t] + d1[rt][t];
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }

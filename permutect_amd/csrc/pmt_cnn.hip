@@ -248,7 +248,7 @@ extern "C" __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn_backward_ke
         g0[v * ma + o] = d_out[(size_t)(v0 + v) * d_out_stride + o];
     }
     __syncthreads();
-    BwdCtx c{M, theta, theta, packed, gtheta, gtheta, {&sh.wg[0][0], &sh.wg[1][0]}, &sh.tr[wave][0], g, 0u, 0};
+    BwdCtx c{M, theta, theta, packed, gtheta, gtheta, &sh.wg[0][0], &sh.tr[wave][0], g, 0u, 0};
     float* gout = g0;
     float* gin = g1;
     for (int l = nl - 1; l >= 0; --l) {

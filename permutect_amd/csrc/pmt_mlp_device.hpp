@@ -5,8 +5,8 @@
 // ---- MLP program interpreter (reference architecture/mlp.py) ------------------------------------------------------
 // x (in place): in_dim -> out_dim.  When stash != nullptr the INPUT of every op with index >= first_stashed_op is
 // written to consecutive slots starting at *slot.
-template <bool TRAIN, bool STAGED>
-DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_RT][PMT_NT],
+template <bool TRAIN, bool STAGED, int NT = PMT_NT>
+DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_RT][NT],
                  const float* __restrict__ packed, const float* __restrict__ theta, int g, unsigned tile_mask,
                  float* const (&stash_tile)[PMT_RT], int& slot, int first_stashed_op, WStage& ws, int op_begin = 0) {
     const int n_ops = uniform(mlp.n_ops);
@@ -15,21 +15,21 @@ DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_
         if (TRAIN && op >= first_stashed_op) {
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
-                if (tile_mask & (1u << rt)) stash_store<PMT_NT>(stash_tile[rt] + slot * PMT_SLOT_FLOATS, x[rt]);
+                if (tile_mask & (1u << rt)) stash_store<NT>(stash_tile[rt] + slot * PMT_SLOT_FLOATS, x[rt]);
             ++slot;
         }
-        f4 y[PMT_RT][PMT_NT];
+        f4 y[PMT_RT][NT];
         if (uniform(o.kind) == PMT_OP_LINEAR) {
             const PmtLinear& L = M->lin[uniform(o.lin[0])];
             const int b_pvec = uniform(L.b_pvec), base = uniform(L.w_frag);
             const float* st = wstage_acquire<STAGED>(ws, base, uniform(L.w_stage));  // [fragments | bias]
-            init_bias<PMT_NT>(y, b_pvec >= 0 ? st + (b_pvec - base) : nullptr, uniform(L.out_dim), g);
-            linear_acc<PMT_NT, PMT_NT, false>(y, x, st, uniform(L.in_dim), uniform(L.out_dim), PMT_FULL_MASK);
+            init_bias<NT>(y, b_pvec >= 0 ? st + (b_pvec - base) : nullptr, uniform(L.out_dim), g);
+            linear_acc<NT, NT, false>(y, x, st, uniform(L.in_dim), uniform(L.out_dim), PMT_FULL_MASK);
             const bool act = uniform(o.selu_after) != 0;
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
-                for (int t = 0; t < PMT_NT; ++t) x[rt][t] = act ? selu4(y[rt][t]) : y[rt][t];
+                for (int t = 0; t < NT; ++t) x[rt][t] = act ? selu4(y[rt][t]) : y[rt][t];
         } else {
             // x + alpha * f(x) with one or two (SELU, Linear) layers.  Only two register arrays are live: the last
             // layer accumulates straight into x, with alpha folded into its B operand and bias.
@@ -39,26 +39,26 @@ DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
-                    for (int t = 0; t < PMT_NT; ++t) y[rt][t] = x[rt][t];
+                    for (int t = 0; t < NT; ++t) y[rt][t] = x[rt][t];
             } else {
                 const PmtLinear& L1 = M->lin[uniform(o.lin[0])];
                 const float* st1 = wstage_acquire<STAGED>(ws, uniform(L1.w_frag), uniform(L1.w_stage));
-                init_bias<PMT_NT>(y, st1 + (uniform(L1.b_pvec) - uniform(L1.w_frag)), width, g);
-                linear_acc<PMT_NT, PMT_NT, true>(y, x, st1, width, width, PMT_FULL_MASK);
+                init_bias<NT>(y, st1 + (uniform(L1.b_pvec) - uniform(L1.w_frag)), width, g);
+                linear_acc<NT, NT, true>(y, x, st1, width, width, PMT_FULL_MASK);
             }
             const PmtLinear& L2 = M->lin[uniform(o.lin[nl - 1])];
             const float alpha = uniform(theta[uniform(o.alpha_src)]);
             const int nmt = (width + 15) >> 4;
             const float* st2 = wstage_acquire<STAGED>(ws, uniform(L2.w_frag), uniform(L2.w_stage));
 #pragma unroll
-            for (int t = 0; t < PMT_NT; ++t) {
+            for (int t = 0; t < NT; ++t) {
                 if (t < nmt) {
                     const f4 b = alpha * load_pvec(st2 + (uniform(L2.b_pvec) - uniform(L2.w_frag)), t, g);
 #pragma unroll
                     for (int rt = 0; rt < PMT_RT; ++rt) x[rt][t] = x[rt][t] + b;
                 }
             }
-            linear_acc<PMT_NT, PMT_NT, true>(x, y, st2, width, width, PMT_FULL_MASK, alpha);
+            linear_acc<NT, NT, true>(x, y, st2, width, width, PMT_FULL_MASK, alpha);
         }
     }
 }

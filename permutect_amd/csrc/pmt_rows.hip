@@ -113,7 +113,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_backward_kernel(
     }
     // (phi / gphi are never dereferenced for row MLPs -- all their leaves are direct -- but passing nullptr constants here
     //  makes hipcc 7.2's SimplifyCFG crash while folding grad_ptr(), so theta / gtheta stand in)
-    BwdCtx c{M, theta, theta, packed, gtheta, gtheta, {&sh.wg[0][0], &sh.wg[1][0]}, &sh.tr[wave][0], g, present, 0};
+    BwdCtx c{M, theta, theta, packed, gtheta, gtheta, &sh.wg[0][0], &sh.tr[wave][0], g, present, 0};
     // d(out) -> registers (zero for padding rows: they then contribute nothing to any weight gradient)
     f4 dy[PMT_RT][PMT_NT];
 #pragma unroll

@@ -145,7 +145,7 @@ class EnginePlan:
         self.gphi_size = d.phi_size
         raw = bytes(d)
         self.desc_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
-        self.debug_flags = torch.zeros(4, dtype=torch.int32, device=device)  # [0]: weight-staging schedule misses
+        self.debug_flags = torch.zeros(64, dtype=torch.int32, device=device)  # [0] staging misses, [1] debug switches, [8:56] 24 x u64 cycle counters
         self.stash_slots = (d.read_mlp.n_ops - 1) + (d.num_blocks + 1) + (d.reducer.n_ops - 1)
 
     # ---- allocation helpers --------------------------------------------------------------------------------------
