@@ -3,10 +3,11 @@
 // input (pmt_forward<TRAIN> wrote those), so only ~0.7 K floats per read cross HBM between the two passes.
 //
 //   dgrad  dx = W^T dy      : MFMA with the transposed A fragments (wt_frag); dy is already the B operand.
-//   wgrad  dW += dy x^T     : contraction over READS.  Both operands are transposed through a per-wave LDS tile
-//                             (reads move from the lane axis to the MFMA k axis), multiplied with
-//                             v_mfma_f32_16x16x4_f32, summed across the 8 waves with LDS float atomics and flushed once
-//                             per workgroup with global float atomics into the flat gradient buffer.
+//   wgrad  dW += dy x^T     : contraction over READS.  Both operands are transposed on the matrix core (reads move
+//                             from the lane axis to the MFMA k axis) and exchanged through LDS; each wave then owns
+//                             distinct 16x16 blocks of dW, contracts them over all reads of the workgroup with
+//                             v_mfma_f32_16x16x4_f32 and adds them with global float atomics into the flat gradient
+//                             buffer (pmt_bwd_device.hpp: wgrad_exchange).  No LDS atomics.
 //   set-coupled terms       : per-set sums of d(gate) go through LDS exactly like the forward's z2 sums.
 //
 // Replaces autograd over reference artifact_model.py:239-297 (misc_utils.py:127 `loss.backward()`).
@@ -22,11 +23,15 @@ struct BwdShared {
     float gsum[PMT_GROUP_MAX_SETS][2][16];                      // per-set sums of d(gate), current block
     float dmean[PMT_GROUP_MAX_SETS][2][16];                     // d(m_ref), d(m_alt) already divided by (n + w)
     float dl[PMT_GROUP_MAX_SETS][PMT_MAX_CLUSTERS + 2];         // d(loss)/d(Lambda[b][j]) incl. the logit path
-    float dfeat[PMT_GROUP_MAX_SETS][2][PMT_MAX_WIDTH];          // d(loss)/d(set mean) / (n + 1e-4), position order
-    float dv[PMT_GROUP_MAX_SETS][PMT_MAX_WIDTH];                // per-set sum of d(x_0) (variant-embedding part)
-    float wg[2][WG_TILE + PMT_MAX_WIDTH];                       // weight (+bias) gradient tiles, double buffered
-    float tr[PMT_WAVES][16 * TR_STRIDE];                  // per-wave transpose scratch
+    union {                                                     // the two never overlap in time (head / input split)
+        float dfeat[PMT_GROUP_MAX_SETS][2][PMT_MAX_WIDTH];      // d(loss)/d(set mean) / (n + 1e-4), position order
+        float dv[PMT_GROUP_MAX_SETS][PMT_MAX_WIDTH];            // per-set sum of d(x_0) (variant-embedding part)
+    };
+    float aux[PMT_WAVES][PMT_AUX_CAP];                          // small-parameter gradient slabs (BwdCtx.aux)
+    int aux_dst[PMT_AUX_CAP];
+    f4 stage[PMT_STAGE_PLANES * 64];                            // weight-gradient operand exchange (BwdCtx.stage)
 };
+static_assert(sizeof(BwdShared) <= 160 * 1024, "LDS budget");
 
 DEV float read_feature_b(const unsigned char* __restrict__ row, int fmt, int f, int F) {
     if (f >= F) return 0.f;
@@ -58,8 +63,6 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         sh.off[0][i] = bt.ref_offsets[gg.v0 + i] - gg.ref_base;
         sh.off[1][i] = bt.alt_offsets[gg.v0 + i] - gg.alt_base;
     }
-    for (int i = tid; i < 2 * (WG_TILE + PMT_MAX_WIDTH); i += PMT_THREADS) (&sh.wg[0][0])[i] = 0.f;
-    for (int i = tid; i < PMT_GROUP_MAX_SETS * PMT_MAX_WIDTH; i += PMT_THREADS) (&sh.dv[0][0])[i] = 0.f;
     for (int i = tid; i < PMT_GROUP_MAX_SETS * 32; i += PMT_THREADS) (&sh.gsum[0][0][0])[i] = 0.f;
     __syncthreads();
     // per-set upstream gradients (reference feature_clustering.py:121-135 differentiated)
@@ -80,7 +83,6 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         for (int k = 0; k < K; ++k) {
             const float v = (dk ? dk[2 + k] : 0.f) + draw * expf(lk[2 + k] - mx) / se;
             sh.dl[i][2 + k] = v;
-            atomicAdd(&gphi[M->head.log_w_k_phi + k], v);
         }
     }
     for (int i = tid; i < gg.nsets * 2 * PMT_MAX_WIDTH; i += PMT_THREADS) {
@@ -103,10 +105,19 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         if (tm[rt].side == 0) mask_side[0] |= 1u << rt; else mask_side[1] |= 1u << rt;
         stash_tile[rt] = stash + (size_t)(bt.group_tile_base[blockIdx.x] + gg.tile_begin + rt) * (size_t)(nslots * PMT_SLOT_FLOATS);
     }
-    BwdCtx c{M, theta, phi, packed, gtheta, gphi, &sh.wg[0][0], &sh.tr[wave][0], g, mask_all, 0,
+    BwdCtx c{M, theta, phi, packed, gtheta, gphi, &sh.stage[0], &sh.aux[0][0], &sh.aux_dst[0], g, mask_all,
+             gg.tile_begin, gg.ntiles, gg.tiles_ref, 0,
              bt.debug_flags ? uniform(bt.debug_flags[1]) : 0,
              bt.debug_flags ? reinterpret_cast<unsigned long long*>(bt.debug_flags + 8) : nullptr};
     const unsigned long long t_kernel0 = prof_now();
+    if (wave == 0 && !(c.dbg & 16)) {  // d(log cluster weights): summed over the sets of the group, one atomic per cluster
+        const int k = lane & 15;
+        float a = 0.f;
+        if (k < K)
+            for (int set = g; set < gg.nsets; set += 4) a += sh.dl[set][2 + k];
+        a = group_sum(a);
+        if (g == 0 && k < K) atomicAdd(&gphi[M->head.log_w_k_phi + k], a);
+    }
     const int n_read_ops = uniform(M->read_mlp.n_ops), n_red_ops = uniform(M->reducer.n_ops);
     const int slot_x0 = n_read_ops - 1, slot_red = slot_x0 + L + 1;
 
@@ -270,20 +281,20 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
                     d_sg += G * (Lp * (-(mu - p) / (1.4142135623730951f * var) + lam * 0.7071067811865476f) + lam * lam * sg);
                 }
             }
-            if (k >= 0 && mask_side[1]) {
-                vec_grad_atomic<PMT_NT>(gphi + uniform(M->head.dirs_ke_phi) + k * E, dvk, E, g);
-                scalar_grad_atomic(gphi + uniform(M->head.art_stdev_k_phi) + k, d_tau);
-                scalar_grad_atomic(gtheta + uniform(M->head.mu_k_src) + k, d_mu);
-                scalar_grad_atomic(gphi + uniform(M->head.lambda_k_phi) + k, d_lam);
-                scalar_grad_atomic(gphi + uniform(M->head.sigma_k_phi) + k, d_sg);
+            if (k >= 0) {  // every wave pushes (zeros if it has no alt tile): the slab layout is workgroup-uniform
+                aux_push_vec<PMT_NT>(c, enc_phi(uniform(M->head.dirs_ke_phi) + k * E), dvk, E);
+                aux_push_scalar(c, enc_phi(uniform(M->head.art_stdev_k_phi) + k), d_tau);
+                aux_push_scalar(c, uniform(M->head.mu_k_src) + k, d_mu);
+                aux_push_scalar(c, enc_phi(uniform(M->head.lambda_k_phi) + k), d_lam);
+                aux_push_scalar(c, enc_phi(uniform(M->head.sigma_k_phi) + k), d_sg);
             }
         }
-        if (mask_side[1]) vec_grad_atomic<PMT_NT>(gphi + uniform(M->head.stdev_e_phi), dsig, E, g);
+        aux_push_vec<PMT_NT>(c, enc_phi(uniform(M->head.stdev_e_phi)), dsig, E);
 
         prof_add(c, 4, t_kernel0);
         unsigned long long t_rot = prof_now();
         // ---- rotation + translation backward: a = Q (r + t) ------------------------------------------------------------
-        linear_wgrad<PMT_NT, PMT_NT>(c, R, dy, r, mask_all);
+        linear_wgrad<PMT_NT, PMT_NT>(c, R, dy, r);
         f4 dx[PMT_RT][PMT_NT];
         init_bias<PMT_NT>(dx, nullptr, E, g);
         linear_acc<PMT_NT, PMT_NT, false>(dx, dy, packed + uniform(R.wt_frag), E, E, PMT_FULL_MASK);
@@ -297,7 +308,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
                 dt[t] = dt[t] + dx[rt][t];
             }
         }
-        if (mask_all) vec_grad_atomic<PMT_NT>(gtheta + uniform(M->translation_src), dt, E, g);
+        aux_push_vec<PMT_NT>(c, uniform(M->translation_src), dt, E);
         prof_add(c, 5, t_rot);
     }
     unsigned long long t_ph = prof_now();
@@ -411,35 +422,40 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             }
             prof_add(c, 9, t_ph);
             t_ph = prof_now();
-            // proj2 weight gradients (per side); the barrier inside also completes gsum
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const PmtLinear& P2 = M->lin[uniform(B.proj2[s])];
-                float* buf = sh.wg[c.wg_flip];
-                if (!(c.dbg & 1)) wgrad_accumulate<PMT_NT, 1>(buf, c.tr, dy, u, D, h, mask_side[s] & mask_all, true);
-                __syncthreads();
-                if (!(c.dbg & 3)) wgrad_flush(buf, P2, 1.0f, gtheta, gphi);
-                c.wg_flip ^= 1;
-            }
+            // proj2 weight gradients of both sides in one exchange round
+            wgrad_exchange<PMT_NT, 1, 2>(c, M->lin[uniform(B.proj2[0])], M->lin[uniform(B.proj2[1])], dy, u, 1.0f);
         }
+        __syncthreads();  // gsum complete
         prof_add(c, 10, t_ph);
         t_ph = prof_now();
         // per-set coupling: d(m_ref), d(m_alt), d(ref_regularizer), d(reg_weight)
         for (int i = tid; i < gg.nsets * 16; i += PMT_THREADS) {
-            const int set = i >> 4, p = i & 15, f = pos_to_feat(p);
+            const int set = i >> 4, p = i & 15;
             const float n_ref = (float)(sh.off[0][set + 1] - sh.off[0][set]);
             const float n_alt = (float)(sh.off[1][set + 1] - sh.off[1][set]);
             const float gr = sh.gsum[set][0][p], ga = sh.gsum[set][1][p];
             const float dm_ref = beta_ref * gr + gamma * ga, dm_alt = beta_alt * ga;
             sh.dmean[set][0][p] = dm_ref / (n_ref + w);
             sh.dmean[set][1][p] = dm_alt / (n_alt + 1e-4f);
-            if (f < h) {
-                const float* zs = zsum_stash + ((size_t)(gg.v0 + set) * L + l) * 32;
+        }
+        if (wave == 0) {  // d(ref_regularizer), d(reg_weight): summed over the sets of the group, one atomic per element
+            const int p = lane & 15, f = pos_to_feat(p);
+            float a_rho = 0.f, a_w = 0.f;
+            if (f < h && !(c.dbg & 16)) {
                 const float rho_f = theta[B.ref_reg_src + f];
-                const float m_ref = (zs[p] + w * rho_f) / (n_ref + w);
-                atomicAdd(&gtheta[B.ref_reg_src + f], dm_ref * w / (n_ref + w));
-                atomicAdd(&gphi[B.reg_weight_phi], dm_ref * (rho_f - m_ref) / (n_ref + w));
+                for (int set = g; set < gg.nsets; set += 4) {
+                    const float n_ref = (float)(sh.off[0][set + 1] - sh.off[0][set]);
+                    const float dm_ref = beta_ref * sh.gsum[set][0][p] + gamma * sh.gsum[set][1][p];
+                    const float* zs = zsum_stash + ((size_t)(gg.v0 + set) * L + l) * 32;
+                    const float m_ref = (zs[p] + w * rho_f) / (n_ref + w);
+                    a_rho += dm_ref * w / (n_ref + w);
+                    a_w += dm_ref * (rho_f - m_ref) / (n_ref + w);
+                }
             }
+            a_rho = group_sum(a_rho);
+            a_w = wave_sum(a_w);
+            if (g == 0 && f < h) atomicAdd(&gtheta[B.ref_reg_src + f], a_rho);
+            if (lane == 0) atomicAdd(&gphi[B.reg_weight_phi], a_w);
         }
         __syncthreads();
         for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS) (&sh.gsum[0][0][0])[i] = 0.f;
@@ -464,15 +480,13 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
                 dz[rt][0] = selu_bwd4(dz1, z[rt][0]);
                 dz[rt][1] = selu_bwd4(dxr[0], z[rt][1]);
             }
-            if (mask_all) {
-                vec_grad_atomic<1>(gtheta + uniform(B.sgu_norm_w_src), dsw, h, g);
-                vec_grad_atomic<1>(gtheta + uniform(B.sgu_norm_b_src), dsb, h, g);
-                scalar_grad_atomic(gtheta + uniform(B.alpha_src[0]), d_alpha_ref);
-                scalar_grad_atomic(gtheta + uniform(B.alpha_src[1]), d_alpha_alt);
-                scalar_grad_atomic(gtheta + uniform(B.beta_src[0]), d_beta_ref);
-                scalar_grad_atomic(gtheta + uniform(B.beta_src[1]), d_beta_alt);
-                scalar_grad_atomic(gtheta + uniform(B.gamma_src), d_gamma);
-            }
+            aux_push_vec<1>(c, uniform(B.sgu_norm_w_src), dsw, h);
+            aux_push_vec<1>(c, uniform(B.sgu_norm_b_src), dsb, h);
+            aux_push_scalar(c, uniform(B.alpha_src[0]), d_alpha_ref);
+            aux_push_scalar(c, uniform(B.alpha_src[1]), d_alpha_alt);
+            aux_push_scalar(c, uniform(B.beta_src[0]), d_beta_ref);
+            aux_push_scalar(c, uniform(B.beta_src[1]), d_beta_alt);
+            aux_push_scalar(c, uniform(B.gamma_src), d_gamma);
         }
         prof_add(c, 12, t_ph);
         t_ph = prof_now();
@@ -480,15 +494,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         {
             f4 n[PMT_RT][PMT_NT];
             recompute_n(n);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const PmtLinear& P1 = M->lin[uniform(B.proj1[s])];
-                float* buf = sh.wg[c.wg_flip];
-                if (!(c.dbg & 1)) wgrad_accumulate<2, PMT_NT>(buf, c.tr, dz, n, 16 + h, D, mask_side[s] & mask_all, true);
-                __syncthreads();
-                if (!(c.dbg & 3)) wgrad_flush(buf, P1, 1.0f, gtheta, gphi);
-                c.wg_flip ^= 1;
-            }
+            wgrad_exchange<2, PMT_NT, 2>(c, M->lin[uniform(B.proj1[0])], M->lin[uniform(B.proj1[1])], dz, n, 1.0f);
         }
         prof_add(c, 13, t_ph);
         t_ph = prof_now();
@@ -521,16 +527,17 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
                 layernorm_bwd_inplace_tile<PMT_NT>(dy[rt], dn[rt], xh, rs, D, lw, dlw, dlb, g);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (mask_all) {
-                vec_grad_atomic<PMT_NT>(gtheta + uniform(B.norm_w_src), dlw, D, g);
-                vec_grad_atomic<PMT_NT>(gtheta + uniform(B.norm_b_src), dlb, D, g);
-            }
+            aux_push_vec<PMT_NT>(c, uniform(B.norm_w_src), dlw, D);
+            aux_push_vec<PMT_NT>(c, uniform(B.norm_b_src), dlb, D);
         }
         prof_add(c, 14, t_ph);
     }
     t_ph = prof_now();
 
     // ---- split d(x_0): variant-embedding part -> per-set sums; read-embedding part -> read MLP backward --------------
+    __syncthreads();  // dfeat (head) is dead in every wave: its LDS becomes dv
+    for (int i = tid; i < PMT_GROUP_MAX_SETS * PMT_MAX_WIDTH; i += PMT_THREADS) (&sh.dv[0][0])[i] = 0.f;
+    __syncthreads();
 #pragma unroll
     for (int rt = 0; rt < PMT_RT; ++rt) {
         const int set = tm[rt].set;
@@ -565,7 +572,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         }
     });
     prof_add(c, 16, t_ph);
-    __syncthreads();
+    aux_flush(c);  // ends with a workgroup barrier
     for (int i = tid; i < gg.nsets * Ev; i += PMT_THREADS) {
         const int set = i / Ev, f = i - set * Ev;
         gvar[(size_t)(gg.v0 + set) * Ev + f] = sh.dv[set][f];

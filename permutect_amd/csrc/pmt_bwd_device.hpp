@@ -3,11 +3,10 @@
 #pragma once
 #include "pmt_device.hpp"
 
-#define TR_STRIDE 20  // floats per row of the per-wave transpose tile (16 + 4 pad: conflict-free b32 writes, 16B-aligned b128 reads)
-#ifndef PMT_WG_COLS
-#define PMT_WG_COLS PMT_MAX_WIDTH  // columns (input features) of the LDS weight-gradient tile; a TU may widen it
+#ifndef PMT_STAGE_PLANES
+#define PMT_STAGE_PLANES 96  // LDS operand-exchange capacity in planes of 64 x float4 (1 KiB each); a TU may shrink it
 #endif
-#define WG_TILE (PMT_MAX_WIDTH * PMT_WG_COLS)
+#define PMT_AUX_CAP 256      // floats per wave of the small-parameter gradient slab
 
 DEV float read_lanes_sum(float v) {  // sum over the 16 reads of a tile (lanes with equal lane >> 4)
     v += __shfl_xor(v, 1);
@@ -25,7 +24,7 @@ DEV float wave_sum(float v) { return group_sum(read_lanes_sum(v)); }
 // k = lane >> 4 <-> position 4*(lane>>4) + j at k-step j), so  D = X^T * I  with the 16x16 identity as B lands the tile
 // transposed in C layout (row 4G+J = read, column = position).  Multiplying by exact 0 / 1 makes it bit-exact.  Four
 // MFMAs per tile on a pipe that is mostly idle in this kernel, instead of 4 ds_write + 1 ds_read and two LDS latencies.
-DEV f4 transpose_tile(float* __restrict__ /*unused LDS scratch*/, f4 v) {
+DEV f4 transpose_tile(f4 v) {
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
     f4 o = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -33,109 +32,11 @@ DEV f4 transpose_tile(float* __restrict__ /*unused LDS scratch*/, f4 v) {
     return o;
 }
 
-// Accumulate this wave's contribution to dW (and db) of one linear into the shared tile buffer.
-//   dy: [out_v] gradient w.r.t. the linear's output, x: [in_v] its input; rows of padding reads carry dy = 0.
-template <int NTO, int NTI>
-DEV void wgrad_accumulate(float* __restrict__ wgbuf, float* __restrict__ tr, const f4 (&dy)[PMT_RT][NTO],
-                          const f4 (&x)[PMT_RT][NTI], int out_v, int in_v, unsigned tile_mask, bool with_bias) {
-    const int lane = threadIdx.x & 63, g = lane >> 4;
-    const int nmt = (out_v + 15) >> 4, nkt = (in_v + 15) >> 4;
-    f4 xT[PMT_RT][NTI];
-#pragma unroll
-    for (int rt = 0; rt < PMT_RT; ++rt)
-#pragma unroll
-        for (int it = 0; it < NTI; ++it)
-            if ((tile_mask & (1u << rt)) && it < nkt) xT[rt][it] = transpose_tile(tr, x[rt][it]);
-#pragma unroll
-    for (int ot = 0; ot < NTO; ++ot) {
-        if (ot < nmt && tile_mask) {
-            f4 acc[NTI];
-#pragma unroll
-            for (int it = 0; it < NTI; ++it) acc[it] = f4{0.f, 0.f, 0.f, 0.f};
-            f4 bsum = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int rt = 0; rt < PMT_RT; ++rt) {
-                if (tile_mask & (1u << rt)) {
-                    const f4 dT = transpose_tile(tr, dy[rt][ot]);
-                    bsum = bsum + dy[rt][ot];
-#pragma unroll
-                    for (int it = 0; it < NTI; ++it)
-                        if (it < nkt) {
-#pragma unroll
-                            for (int ks = 0; ks < 4; ++ks) acc[it] = mfma16(dT[ks], xT[rt][it][ks], acc[it]);
-                        }
-                }
-            }
-#pragma unroll
-            for (int it = 0; it < NTI; ++it)
-                if (it < nkt) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        atomicAdd(&wgbuf[(16 * ot + 4 * g + j) * PMT_WG_COLS + 16 * it + (lane & 15)], acc[it][j]);
-                }
-            if (with_bias) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float s = read_lanes_sum(bsum[j]);
-                    if ((lane & 15) == 0) atomicAdd(&wgbuf[WG_TILE + 16 * ot + 4 * g + j], s);
-                }
-            }
-        }
-    }
-}
-
 DEV int pos_to_feat(int p) { return 16 * (p >> 4) + 4 * (p & 3) + ((p & 15) >> 2); }
 DEV int split_row_dev(int v, int h) {
     if (h <= 0) return v;
     if (v < 16) return v < h ? v : -1;
     return (v - 16) < h ? h + (v - 16) : -1;
-}
-
-// After a workgroup barrier: add the shared tile into the flat gradient buffers with global float atomics and clear it.
-DEV void wgrad_flush(float* __restrict__ wgbuf, const PmtLinear& L, float scale, float* __restrict__ gtheta,
-                     float* __restrict__ gphi) {
-    const int h = L.out_split, out_dim = L.out_dim, in_dim = L.in_dim;
-    const int out_v = h > 0 ? 16 + h : out_dim;
-    const int nmt = (out_v + 15) >> 4, nkt = (in_dim + 15) >> 4;
-    float* gw = grad_ptr(L.w_src, gtheta, gphi);
-    for (int i = threadIdx.x; i < nmt * 16 * nkt * 16; i += PMT_THREADS) {
-        const int po = i / (nkt * 16), pi = i - po * (nkt * 16);
-        float* cell = &wgbuf[po * PMT_WG_COLS + pi];
-        const float v = *cell;
-        *cell = 0.f;
-        const int o = split_row_dev(pos_to_feat(po), h), c = pos_to_feat(pi);
-        if (o >= 0 && o < out_dim && c < in_dim && pos_to_feat(po) < out_v) atomicAdd(&gw[(size_t)o * in_dim + c], scale * v);
-    }
-    if (L.b_src != -1) {
-        float* gb = grad_ptr(L.b_src, gtheta, gphi);
-        for (int p = threadIdx.x; p < nmt * 16; p += PMT_THREADS) {
-            float* cell = &wgbuf[WG_TILE + p];
-            const float v = *cell;
-            *cell = 0.f;
-            const int o = split_row_dev(pos_to_feat(p), h);
-            if (o >= 0 && o < out_dim && pos_to_feat(p) < out_v) atomicAdd(&gb[o], scale * v);
-        }
-    }
-}
-
-// per-feature parameter gradient (tile-position registers summed over this wave's reads) -> global atomics
-template <int NT>
-DEV void vec_grad_atomic(float* __restrict__ dst, const f4 (&v)[NT], int dim, int g) {
-    const int nt = (dim + 15) >> 4;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-        if (t < nt) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float s = read_lanes_sum(v[t][j]);
-                const int f = feat_of(t, j, g);
-                if ((threadIdx.x & 15) == 0 && f < dim) atomicAdd(dst + f, s);
-            }
-        }
-}
-DEV void scalar_grad_atomic(float* __restrict__ dst, float v) {
-    const float s = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) atomicAdd(dst, s);
 }
 
 // LayerNorm backward for one read tile: given d(y) with y = xhat*w + b, returns d(x); accumulates dw, db partials.
@@ -237,6 +138,12 @@ DEV float dlogerfc_dev(float z) {
     return e > 1.0e-12f ? -1.1283791670955126f * expf(-z * z) / e : 0.f;
 }
 
+// Weight gradients contract over READS, and the reads of a workgroup are spread over its waves.  Summing per-wave
+// partial dW tiles with LDS float atomics measured ~100 cycles per ds_add_f32 instruction (4.4 ms of a 16 ms kernel), so
+// the waves exchange OPERANDS instead ("owner computes"): every wave writes the transposed tiles of dy and x of its
+// reads into the LDS stage (plain 16-byte stores), and after one barrier each wave owns distinct 16x16 blocks of dW,
+// which it contracts over ALL reads of the workgroup on the matrix core and adds straight from registers into the flat
+// gradient buffer: no LDS atomics, no dW tile in LDS, no flush pass.
 struct BwdCtx {
     const PmtModel* M;
     const float* theta;
@@ -244,40 +151,176 @@ struct BwdCtx {
     const float* packed;
     float* gtheta;
     float* gphi;
-    float* wg;      // LDS: two CONTIGUOUS weight(+bias)-gradient tile buffers of WG_TILE + PMT_MAX_WIDTH floats each.
-                    // One base pointer + offset (not an array of pointers): a runtime-indexed pointer array defeats
-                    // address-space inference and turns every LDS atomic into a slow flat_atomic_add_f32.
-    float* tr;      // this wave's transpose tile
+    f4* stage;      // LDS [PMT_STAGE_PLANES][64] operand exchange
+    float* aux;     // LDS [PMT_WAVES][PMT_AUX_CAP]: per-wave sums of small-parameter gradients, reduced over the waves and
+                    // added to global memory once per workgroup inside the next exchange round (or by aux_flush)
+    int* aux_dst;   // LDS [PMT_AUX_CAP] destination of every slab entry (encoded like PmtLinear.w_src; -1 = none)
     int g;
-    unsigned mask_all;
-    int wg_flip;    // which weight-gradient buffer the next linear uses
-    int dbg;        // profiling aid (PmtBatch.debug_flags[1]): bit 0 skip weight gradients, bit 1 skip their flush only,
-                    // bit 3 accumulate per-section cycle counts into prof[]
-    unsigned long long* prof;  // device, 8 counters (see scripts/bwd_ablate.py); only touched when dbg bit 3 is set
+    unsigned mask_all;  // which of this wave's tiles exist
+    int slot0;      // tile slot (0 .. PMT_GROUP_TILES-1) of this wave's tile 0; the existing tiles of the workgroup are
+    int ntiles;     //   exactly the slots [0, ntiles)
+    int tiles_ref;  // slots below this belong to side 0 (ref) of a two-sided linear pair
+    int aux_n;      // slab entries in use (wave-uniform, identical in every wave)
+    int dbg;        // development switches (PmtBatch.debug_flags[1]): bit 0 skip weight gradients, bit 1 skip only their
+                    // global atomics, bit 2 skip the gated blocks, bit 3 collect cycle counters, bit 4 drop small-parameter
+                    // gradients.  0 in production.
+    unsigned long long* prof;  // device, 24 counters (see scripts/bwd_ablate.py); only touched when dbg bit 3 is set
 };
 DEV unsigned long long prof_now() { return __builtin_readcyclecounter(); }
 DEV void prof_add(const BwdCtx& c, int slot, unsigned long long t0) {
     if ((c.dbg & 8) && c.prof != nullptr && (threadIdx.x & 63) == 0) atomicAdd(c.prof + slot, prof_now() - t0);
 }
 
-// One linear's weight/bias gradient: accumulate, workgroup barrier, flush.  Every wave of the group must call it.
-template <int NTO, int NTI>
-DEV void linear_wgrad(BwdCtx& c, const PmtLinear& L, const f4 (&dy)[PMT_RT][NTO], const f4 (&x)[PMT_RT][NTI], unsigned mask,
-                      float scale = 1.0f) {
-    if (c.dbg & 1) return;
-    float* buf = c.wg + c.wg_flip * (WG_TILE + PMT_MAX_WIDTH);
-    const int h = uniform(L.out_split);
-    const int out_v = h > 0 ? 16 + h : uniform(L.out_dim);
-    unsigned long long t0 = prof_now();
-    wgrad_accumulate<NTO, NTI>(buf, c.tr, dy, x, out_v, uniform(L.in_dim), mask, uniform(L.b_src) != -1);
-    prof_add(c, 0, t0);
-    t0 = prof_now();
+// ---- small-parameter gradients ---------------------------------------------------------------------------------------
+DEV int enc_phi(int off) { return -(off + 2); }
+DEV int enc_at(int enc, int f) { return enc >= 0 ? enc + f : enc - f; }
+
+// sum the slabs over the waves and add to global memory; callers bracket it with workgroup barriers
+DEV void aux_reduce(BwdCtx& c) {
+    for (int i = threadIdx.x; i < c.aux_n; i += PMT_THREADS) {
+        const int d = c.aux_dst[i];
+        if (d != -1) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < PMT_WAVES; ++w) s += c.aux[w * PMT_AUX_CAP + i];
+            atomicAdd(grad_ptr(d, c.gtheta, c.gphi), s);
+        }
+    }
+    c.aux_n = 0;
+}
+DEV void aux_flush(BwdCtx& c) {
     __syncthreads();
-    prof_add(c, 1, t0);
-    t0 = prof_now();
-    if (!(c.dbg & 2)) wgrad_flush(buf, L, scale, c.gtheta, c.gphi);
-    prof_add(c, 2, t0);
-    c.wg_flip ^= 1;
+    aux_reduce(c);
+    __syncthreads();
+}
+// per-feature parameter gradient (tile-position registers, summed here over this wave's reads)
+template <int NT>
+DEV void aux_push_vec(BwdCtx& c, int enc, const f4 (&v)[NT], int dim) {
+    const int nt = (dim + 15) >> 4, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (c.aux_n + 16 * nt > PMT_AUX_CAP) aux_flush(c);
+    if (c.dbg & 16) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        if (t < nt) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float s = read_lanes_sum(v[t][j]);
+                if ((lane & 15) == 0) {
+                    const int p = c.aux_n + 16 * t + 4 * c.g + j, f = feat_of(t, j, c.g);
+                    c.aux[wave * PMT_AUX_CAP + p] = s;
+                    if (wave == 0) c.aux_dst[p] = f < dim ? enc_at(enc, f) : -1;
+                }
+            }
+        }
+    c.aux_n += 16 * nt;
+}
+DEV void aux_push_scalar(BwdCtx& c, int enc, float v) {
+    if (c.aux_n + 1 > PMT_AUX_CAP) aux_flush(c);
+    if (c.dbg & 16) return;
+    const float s = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) {
+        c.aux[(threadIdx.x >> 6) * PMT_AUX_CAP + c.aux_n] = s;
+        if (threadIdx.x == 0) c.aux_dst[c.aux_n] = enc;
+    }
+    c.aux_n += 1;
+}
+
+// ---- weight gradients ------------------------------------------------------------------------------------------------
+// dW (+ db) of one linear (SIDES = 1) or of a ref / alt pair applied to the two sides of the group (SIDES = 2).
+// dy: gradient w.r.t. the linear's output (rows of padding reads are zero), x: its input.  Every wave of the workgroup
+// must call it (two barriers per pass; one pass unless (NTO + NTI) * ntiles planes exceed the stage).
+template <int NTO, int NTI, int SIDES>
+DEV void wgrad_exchange(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, const f4 (&dy)[PMT_RT][NTO],
+                        const f4 (&x)[PMT_RT][NTI], float scale) {
+    if (c.dbg & 1) return;
+    constexpr int P = NTO + NTI;
+    constexpr int TP = (PMT_STAGE_PLANES / P) < PMT_GROUP_TILES ? (PMT_STAGE_PLANES / P) : PMT_GROUP_TILES;
+    constexpr int TPW = (SIDES * NTO * NTI + PMT_WAVES - 1) / PMT_WAVES;
+    static_assert(TP >= 1, "stage too small");
+    const int lane = threadIdx.x & 63, wave = uniform((int)(threadIdx.x >> 6)), g = lane >> 4;
+    const int h = uniform(L0.out_split), out_dim = uniform(L0.out_dim), in_dim = uniform(L0.in_dim);
+    const int out_v = h > 0 ? 16 + h : out_dim;
+    const int nmt = (out_v + 15) >> 4, nkt = (in_dim + 15) >> 4;
+    const int per_side = nmt * nkt, ntask = SIDES * per_side;
+    f4 acc[TPW];
+    float bs[TPW];
+    int t_side[TPW], t_ot[TPW], t_it[TPW];
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+        acc[k] = f4{0.f, 0.f, 0.f, 0.f};
+        bs[k] = 0.f;
+        const int q = wave + PMT_WAVES * k;
+        t_side[k] = (SIDES == 2 && q >= per_side) ? 1 : 0;
+        const int rem = q - t_side[k] * per_side;
+        t_ot[k] = rem / nkt;
+        t_it[k] = rem - t_ot[k] * nkt;
+        if (q >= ntask) t_side[k] = -1;
+    }
+    unsigned long long t0c = prof_now();
+    for (int t0 = 0; t0 < c.ntiles; t0 += TP) {
+        __syncthreads();  // the stage (and the slabs) of the previous round have been consumed
+        if (t0 == 0) aux_reduce(c);
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt) {
+            const int tau = c.slot0 + rt - t0;
+            if (((c.mask_all >> rt) & 1u) && tau >= 0 && tau < TP) {
+                f4* pl = c.stage + (size_t)(tau * P) * 64 + lane;
+#pragma unroll
+                for (int ot = 0; ot < NTO; ++ot)
+                    if (ot < nmt) pl[ot * 64] = transpose_tile(dy[rt][ot]);
+#pragma unroll
+                for (int it = 0; it < NTI; ++it)
+                    if (it < nkt) pl[(NTO + it) * 64] = transpose_tile(x[rt][it]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < TPW; ++k) {
+            if (t_side[k] < 0) continue;
+            int lo = (SIDES == 2 && t_side[k] == 1) ? c.tiles_ref : 0;
+            int hi = (SIDES == 2 && t_side[k] == 0) ? c.tiles_ref : c.ntiles;
+            lo = max(lo, t0) - t0;
+            hi = min(hi, t0 + TP) - t0;
+            const f4* pa = c.stage + (size_t)t_ot[k] * 64 + lane;
+            const f4* pb = c.stage + (size_t)(NTO + t_it[k]) * 64 + lane;
+            const bool with_bias = t_it[k] == 0;
+            for (int tau = lo; tau < hi; ++tau) {
+                const f4 a = pa[tau * P * 64], b = pb[tau * P * 64];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) acc[k] = mfma16(a[ks], b[ks], acc[k]);
+                if (with_bias) bs[k] += (a[0] + a[1]) + (a[2] + a[3]);
+            }
+        }
+    }
+    prof_add(c, 0, t0c);
+    if (c.dbg & 2) return;
+    t0c = prof_now();
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+        if (t_side[k] < 0) continue;
+        const bool side1 = SIDES == 2 && t_side[k] == 1;
+        if ((side1 ? c.ntiles - c.tiles_ref : (SIDES == 2 ? c.tiles_ref : c.ntiles)) <= 0) continue;
+        const PmtLinear& L = side1 ? L1 : L0;
+        float* gw = grad_ptr(uniform(L.w_src), c.gtheta, c.gphi);
+        const int col = pos_to_feat(16 * t_it[k] + (lane & 15));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pf = feat_of(t_ot[k], j, g), o = split_row_dev(pf, h);
+            if (o >= 0 && o < out_dim && pf < out_v && col < in_dim) atomicAdd(&gw[(size_t)o * in_dim + col], scale * acc[k][j]);
+        }
+        if (t_it[k] == 0 && uniform(L.b_src) != -1) {
+            const float tot = group_sum(bs[k]);  // lanes (m, *) now hold the sum over all reads for output position m
+            const int pf = pos_to_feat(16 * t_ot[k] + (lane & 15)), o = split_row_dev(pf, h);
+            if (g == 0 && o >= 0 && o < out_dim && pf < out_v) atomicAdd(&grad_ptr(uniform(L.b_src), c.gtheta, c.gphi)[o], scale * tot);
+        }
+    }
+    prof_add(c, 2, t0c);
+}
+
+template <int NTO, int NTI>
+DEV void linear_wgrad(BwdCtx& c, const PmtLinear& L, const f4 (&dy)[PMT_RT][NTO], const f4 (&x)[PMT_RT][NTI],
+                      float scale = 1.0f) {
+    wgrad_exchange<NTO, NTI, 1>(c, L, L, dy, x, scale);
 }
 
 // backward of one MLP program.  dy (in/out): gradient w.r.t. the MLP output on entry, w.r.t. its input on exit
@@ -303,7 +346,7 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
 #pragma unroll
                     for (int t = 0; t < NT; ++t) dy[rt][t] = selu_bwd4(dy[rt][t], selu4(y[rt][t]));
             }
-            linear_wgrad<NT, NT>(c, L, dy, x, c.mask_all);
+            linear_wgrad<NT, NT>(c, L, dy, x);
             if (op > 0 || need_input_grad) {
                 f4 dx[PMT_RT][NT];
                 init_bias<NT>(dx, nullptr, in_dim, c.g);
@@ -340,11 +383,11 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
                 for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
                     for (int t = 0; t < NT; ++t) da += (dy[rt][t][0] * f[rt][t][0] + dy[rt][t][1] * f[rt][t][1]) + (dy[rt][t][2] * f[rt][t][2] + dy[rt][t][3] * f[rt][t][3]);
-                scalar_grad_atomic(c.gtheta + uniform(o.alpha_src), da);
+                aux_push_scalar(c, uniform(o.alpha_src), da);
             }
             __builtin_amdgcn_sched_barrier(0);
             // last layer: d(f) = alpha * dy
-            linear_wgrad<NT, NT>(c, L2, dy, s1, c.mask_all, alpha);
+            linear_wgrad<NT, NT>(c, L2, dy, s1, alpha);
             f4 d1[PMT_RT][NT];
             init_bias<NT>(d1, nullptr, width, c.g);
             linear_acc<NT, NT, false>(d1, dy, c.packed + uniform(L2.wt_frag), width, width, PMT_FULL_MASK);
@@ -360,7 +403,7 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
                 for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
                     for (int t = 0; t < NT; ++t) s0[rt][t] = selu4(s0[rt][t]);
-                linear_wgrad<NT, NT>(c, L1, d1, s0, c.mask_all);
+                linear_wgrad<NT, NT>(c, L1, d1, s0);
                 f4 d0[PMT_RT][NT];
                 init_bias<NT>(d0, nullptr, width, c.g);
                 linear_acc<NT, NT, false>(d0, d1, c.packed + uniform(L1.wt_frag), width, width, PMT_FULL_MASK);

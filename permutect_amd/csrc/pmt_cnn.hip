@@ -5,11 +5,11 @@
 // list with every activation resident in LDS.  Convolutions run on the matrix cores as implicit GEMMs: a column is one
 // (variant, output position) pair, its im2col vector (in_ch * kernel taps, <= 128) is gathered from LDS directly into
 // the B-operand register layout of pmt_device.hpp, and the convolution weight [out_ch][in_ch * kernel] is an ordinary
-// packed PmtLinear -- so the forward is linear_acc, the weight gradient is wgrad_accumulate and the input gradient is
+// packed PmtLinear -- so the forward is linear_acc, the weight gradient is wgrad_exchange and the input gradient is
 // linear_acc with the transposed fragments followed by a col2im scatter-add in LDS.  Pooling, activations and the final
 // (wide) linear layer are small and stay on the vector ALU.  The backward kernel recomputes the forward keeping every layer
 // output in LDS.
-#define PMT_WG_COLS PMT_MAX_ROW_INPUT
+#define PMT_STAGE_PLANES 48  // 12 planes per tile (4 of dy + 8 of im2col): 4 tiles per exchange pass; leaves LDS for the activations
 #include "pmt_device.hpp"
 #include "pmt_bwd_device.hpp"
 
@@ -204,8 +204,9 @@ extern "C" __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn_forward_ker
 
 struct CnnBwdShared {
     int tap[PMT_MAX_ROW_INPUT];
-    float wg[2][WG_TILE + PMT_MAX_WIDTH];
-    float tr[PMT_WAVES][16 * TR_STRIDE];
+    float aux[PMT_WAVES][PMT_AUX_CAP];
+    int aux_dst[PMT_AUX_CAP];
+    f4 stage[PMT_STAGE_PLANES * 64];
 };
 
 // Backward: dynamic LDS holds, per variant, the one-hot input and the output of every layer (stride sum_act) plus two
@@ -224,7 +225,6 @@ extern "C" __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn_backward_ke
     float* acts = lds;
     float* g0 = lds + (size_t)vpb * sa;
     float* g1 = g0 + (size_t)vpb * ma;
-    for (int i = tid; i < 2 * (WG_TILE + PMT_MAX_WIDTH); i += PMT_THREADS) (&sh.wg[0][0])[i] = 0.f;
     // ---- recompute the forward, keeping everything ----
     build_one_hot(acts, sa, hap, uniform(C.seq_len), nv, hap_stride, v0);
     __syncthreads();
@@ -248,7 +248,8 @@ extern "C" __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn_backward_ke
         g0[v * ma + o] = d_out[(size_t)(v0 + v) * d_out_stride + o];
     }
     __syncthreads();
-    BwdCtx c{M, theta, theta, packed, gtheta, gtheta, &sh.wg[0][0], &sh.tr[wave][0], g, 0u, 0};
+    BwdCtx c{M, theta, theta, packed, gtheta, gtheta, &sh.stage[0], &sh.aux[0][0], &sh.aux_dst[0], g, 0u,
+             wave * PMT_RT, 0, 0, 0, 0, nullptr};
     float* gout = g0;
     float* gin = g1;
     for (int l = nl - 1; l >= 0; --l) {
@@ -327,7 +328,9 @@ extern "C" __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn_backward_ke
                             const int co = feat_of(t, j, g);
                             dy[rt][t][j] = (cm[rt].valid && co < OC) ? gout[cm[rt].v * ma + co * out_len + cm[rt].so] : 0.f;
                         }
-                linear_wgrad<PMT_NT, CNN_NTIN>(c, Wl, dy, x, present);  // workgroup barrier + flush inside
+                c.mask_all = present;
+                c.ntiles = c.tiles_ref = min(PMT_GROUP_TILES, ntiles - tile0);
+                linear_wgrad<PMT_NT, CNN_NTIN>(c, Wl, dy, x);  // workgroup barriers inside
                 if (need_din) {
                     f4 dx[PMT_RT][CNN_NTIN];
                     init_bias<CNN_NTIN>(dx, nullptr, K, g);

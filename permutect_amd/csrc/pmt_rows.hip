@@ -3,7 +3,6 @@
 // Same register layout, MFMA linear, layer-program interpreter and weight-gradient machinery as the read-set kernels
 // (pmt_device.hpp); a "tile" is 16 rows, there are no sets.  The first linear may read up to 128 input features (the
 // info vector has 71), held in an 8-tile input array.
-#define PMT_WG_COLS PMT_MAX_ROW_INPUT
 #include "pmt_device.hpp"
 #include "pmt_mlp_device.hpp"
 #include "pmt_bwd_device.hpp"
@@ -88,8 +87,9 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_forward_kernel(const 
 }
 
 struct RowsBwdShared {
-    float wg[2][WG_TILE + PMT_MAX_WIDTH];
-    float tr[PMT_WAVES][16 * TR_STRIDE];
+    float aux[PMT_WAVES][PMT_AUX_CAP];
+    int aux_dst[PMT_AUX_CAP];
+    f4 stage[PMT_STAGE_PLANES * 64];
 };
 
 __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_backward_kernel(
@@ -102,8 +102,6 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_backward_kernel(
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, r = lane & 15, wave = uniform((int)(tid >> 6));
     const int tile0 = (blockIdx.x * PMT_WAVES + wave) * PMT_RT;
     const int in_dim = uniform(mlp.in_dim), out_dim = uniform(mlp.out_dim), n_ops = uniform(mlp.n_ops);
-    for (int i = tid; i < 2 * (WG_TILE + PMT_MAX_WIDTH); i += PMT_THREADS) (&sh.wg[0][0])[i] = 0.f;
-    __syncthreads();
     unsigned present = 0;
     const float* stash_tile[PMT_RT];
 #pragma unroll
@@ -113,7 +111,9 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_backward_kernel(
     }
     // (phi / gphi are never dereferenced for row MLPs -- all their leaves are direct -- but passing nullptr constants here
     //  makes hipcc 7.2's SimplifyCFG crash while folding grad_ptr(), so theta / gtheta stand in)
-    BwdCtx c{M, theta, theta, packed, gtheta, gtheta, &sh.wg[0][0], &sh.tr[wave][0], g, present, 0};
+    const int wg_tiles = min(PMT_GROUP_TILES, ((n_rows + 15) >> 4) - (int)blockIdx.x * PMT_GROUP_TILES);
+    BwdCtx c{M, theta, theta, packed, gtheta, gtheta, &sh.stage[0], &sh.aux[0][0], &sh.aux_dst[0], g, present,
+             wave * PMT_RT, wg_tiles, wg_tiles, 0, 0, nullptr};
     // d(out) -> registers (zero for padding rows: they then contribute nothing to any weight gradient)
     f4 dy[PMT_RT][PMT_NT];
 #pragma unroll
@@ -159,8 +159,9 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_backward_kernel(
 #pragma unroll
                 for (int t = 0; t < PMT_NT; ++t) dy[rt][t] = selu_bwd4(dy[rt][t], selu4(y[rt][t]));
         }
-        linear_wgrad<PMT_NT, ROWS_NTIN>(c, L, dy, xin, present);
+        linear_wgrad<PMT_NT, ROWS_NTIN>(c, L, dy, xin);
     }
+    aux_flush(c);  // skip-block alphas
     if (!wide && want_d_in) {
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt) {

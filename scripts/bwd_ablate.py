@@ -16,7 +16,7 @@ model.train(True)
 ints, floats, packed = synth_arrays(np.random.default_rng(0), B, "wgs")
 batch = Batch.from_arrays(ints, floats, packed).copy_to(dev)
 eng = model.engine()
-for mask, name in [(0, "full"), (2, "no flush"), (1, "no wgrad"), (4, "no blocks"), (5, "no blocks, no wgrad")]:
+for mask, name in [(0, "full"), (2, "no flush"), (1, "no wgrad"), (4, "no blocks"), (5, "no blocks, no wgrad"), (16, "no small-param atomics"), (32, "plain LDS stores in wgrad"), (48, "both")]:
     eng.plan.debug_flags[1] = mask
     ts = []
     for i in range(6):
