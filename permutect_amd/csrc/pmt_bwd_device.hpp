@@ -9,10 +9,10 @@
 #define PMT_AUX_CAP 256      // floats per wave of the small-parameter gradient slab
 
 DEV float read_lanes_sum(float v) {  // sum over the 16 reads of a tile (lanes with equal lane >> 4)
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
+    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x124>(v);  // row_ror 4
+    v += dpp_mov<0x128>(v);  // row_ror 8
     return v;
 }
 DEV float wave_sum(float v) { return group_sum(read_lanes_sum(v)); }

@@ -42,11 +42,22 @@ static_assert(PMT_GROUP_TILES == PMT_WAVES * PMT_RT, "group capacity");
 DEV float uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Cross-lane sums without the LDS pipe (__shfl_xor lowers to ds_bpermute_b32): DPP-modified adds inside a row of 16
+// lanes, and the gfx950 row-swap instructions across rows.
+template <int CTRL>
+DEV float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
 // sum over the 4 lane groups (lanes r, r+16, r+32, r+48): completes a per-read reduction over features
 DEV float group_sum(float v) {
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+    // Inline asm, not __builtin_amdgcn_permlane{16,32}_swap: hipcc 7.2 folds the builtin's two results into one register
+    // when they are added (it emits r[0] + r[0]).  s_nop 1 = the two wait states between a VALU write and the swap.
+    float a = v, b = v;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));  // a = rows {0,0,2,2}, b = rows {1,1,3,3}
+    a += b;
+    b = a;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));  // a = lower half twice, b = upper half twice
+    return a + b;
 }
 
 DEV f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
