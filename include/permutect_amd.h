@@ -238,7 +238,8 @@ int pmt_model_check(const PmtModel* model);
 int pmt_build_schedules(PmtModel* model);
 
 /* Partition variants into register-resident groups: greedy over consecutive variants so that each group has
- * <= PMT_GROUP_TILES tiles (ceil(ref/16) + ceil(alt/16)) and <= PMT_GROUP_MAX_SETS sets.  Counts are HOST arrays
+ * <= PMT_GROUP_MAX_SETS sets and its tiles fit the workgroup: ref tiles and alt tiles go to disjoint waves, two per wave,
+ * i.e. ceil(ceil(ref/16) / 2) + ceil(ceil(alt/16) / 2) <= PMT_GROUP_WAVES (so never more than PMT_GROUP_TILES tiles).  Counts are HOST arrays
  * (upper bounds are fine: a DownsampledBatch reuses its parent's plan).  group_start / group_tile_base must hold
  * num_variants + 1 ints.  Returns the number of groups, or PMT_E_CAPACITY if one variant alone exceeds a group
  * (*bad_variant receives its index). */

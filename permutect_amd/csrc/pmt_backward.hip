@@ -45,14 +45,29 @@ DEV float read_feature_b(const unsigned char* __restrict__ row, int fmt, int f, 
     return reinterpret_cast<const float*>(row)[f];
 }
 
+template <int NT>
+DEV void load_slot_tiles(const float* const (&stash_tile)[PMT_RT], unsigned mask, int slot, f4 (&v)[PMT_RT][NT]) {
+#pragma unroll
+    for (int rt = 0; rt < PMT_RT; ++rt) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) v[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
+        if (mask & (1u << rt)) stash_load<NT>(stash_tile[rt] + slot * PMT_SLOT_FLOATS, v[rt]);
+    }
+}
+
+template <typename S>
 __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
     const PmtModel* __restrict__ M, const float* __restrict__ theta, const float* __restrict__ phi,
     const float* __restrict__ packed, PmtBatch bt, PmtOutputs out, PmtOutputGrads dout, const float* __restrict__ stash,
     const float* __restrict__ zsum_stash, float* __restrict__ gtheta, float* __restrict__ gphi,
     float* __restrict__ gvar) {
+    constexpr int NTF = S::NTF, NTR = S::NTR, NTD = S::NTD, NTE = S::NTE;
+    constexpr bool EX = S::EXACT;
+    static_assert(EX || (NTF == NTD && NTR == NTD && NTE == NTD), "the generic shape keeps one array width");
     __shared__ __attribute__((aligned(16))) BwdShared sh;
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, wave = uniform((int)(tid >> 6));
     const GroupGeom gg = group_geometry(bt, blockIdx.x);
+    const int side = gg.side;
     const int D = uniform(M->d_model), E = uniform(M->feature_dim), K = uniform(M->num_clusters);
     const int Er = uniform(M->read_embed_dim), Ev = uniform(M->variant_embed_dim);
     const int h = uniform(M->d_ffn) >> 1, L = uniform(M->num_blocks), F = uniform(M->num_read_features);
@@ -80,10 +95,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         const float* dk = dout.d_logits_bk ? dout.d_logits_bk + (size_t)b * (K + 2) : nullptr;
         sh.dl[i][0] = (dk ? dk[0] : 0.f) - draw;
         sh.dl[i][1] = dk ? dk[1] : 0.f;
-        for (int k = 0; k < K; ++k) {
-            const float v = (dk ? dk[2 + k] : 0.f) + draw * expf(lk[2 + k] - mx) / se;
-            sh.dl[i][2 + k] = v;
-        }
+        for (int k = 0; k < K; ++k) sh.dl[i][2 + k] = (dk ? dk[2 + k] : 0.f) + draw * expf(lk[2 + k] - mx) / se;
     }
     for (int i = tid; i < gg.nsets * 2 * PMT_MAX_WIDTH; i += PMT_THREADS) {
         const int set = i / (2 * PMT_MAX_WIDTH), rem = i - set * 2 * PMT_MAX_WIDTH, s = rem / PMT_MAX_WIDTH, p = rem - s * PMT_MAX_WIDTH;
@@ -95,14 +107,13 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
     __syncthreads();
 
     TileMeta tm[PMT_RT];
-    unsigned mask_all = 0, mask_side[2] = {0, 0};
+    unsigned mask_all = 0;
     const float* stash_tile[PMT_RT];
     const int nslots = stash_num_slots(M);
 #pragma unroll
     for (int rt = 0; rt < PMT_RT; ++rt) {
         tm[rt] = tile_meta(gg, rt, &sh.off[0][0]);
         if (tm[rt].present) mask_all |= 1u << rt;
-        if (tm[rt].side == 0) mask_side[0] |= 1u << rt; else mask_side[1] |= 1u << rt;
         stash_tile[rt] = stash + (size_t)(bt.group_tile_base[blockIdx.x] + gg.tile_begin + rt) * (size_t)(nslots * PMT_SLOT_FLOATS);
     }
     BwdCtx c{M, theta, phi, packed, gtheta, gphi, &sh.stage[0], &sh.aux[0][0], &sh.aux_dst[0], g, mask_all,
@@ -120,77 +131,84 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
     }
     const int n_read_ops = uniform(M->read_mlp.n_ops), n_red_ops = uniform(M->reducer.n_ops);
     const int slot_x0 = n_read_ops - 1, slot_red = slot_x0 + L + 1;
-
-    auto load_slot = [&](int slot, f4 (&v)[PMT_RT][PMT_NT]) {
-#pragma unroll
-        for (int rt = 0; rt < PMT_RT; ++rt) {
-            if (mask_all & (1u << rt)) {
-                stash_load<PMT_NT>(stash_tile[rt] + slot * PMT_SLOT_FLOATS, v[rt]);
-            } else {
-#pragma unroll
-                for (int t = 0; t < PMT_NT; ++t) v[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
-            }
-        }
-    };
+    const int slot_last_in = n_red_ops > 1 ? slot_red + (n_red_ops - 2) : slot_x0 + L;  // input of the last reducer op
+    const PmtOp& red_last = M->reducer.ops[n_red_ops - 1];
 
     // ---- recompute the tail of the forward: last reducer op, translation, rotation -> a ----------------------------
-    f4 dy[PMT_RT][PMT_NT];  // running gradient
+    f4 dy[PMT_RT][NTD];  // running gradient (d_model wide)
     {
-        f4 r[PMT_RT][PMT_NT];
-        load_slot(n_red_ops > 1 ? slot_red + (n_red_ops - 2) : slot_x0 + L, r);
-        {   // forward of the last reducer op only
-            const PmtOp& o = M->reducer.ops[n_red_ops - 1];
-            f4 y[PMT_RT][PMT_NT];
-            if (uniform(o.kind) == PMT_OP_LINEAR) {
-                const PmtLinear& Lr = M->lin[uniform(o.lin[0])];
-                init_bias<PMT_NT>(y, uniform(Lr.b_pvec) >= 0 ? packed + uniform(Lr.b_pvec) : nullptr, uniform(Lr.out_dim), g);
-                linear_acc<PMT_NT, PMT_NT, false>(y, r, packed + uniform(Lr.w_frag), uniform(Lr.in_dim), uniform(Lr.out_dim), PMT_FULL_MASK);
-                const bool act = uniform(o.selu_after) != 0;
-#pragma unroll
-                for (int rt = 0; rt < PMT_RT; ++rt)
-#pragma unroll
-                    for (int t = 0; t < PMT_NT; ++t) r[rt][t] = act ? selu4(y[rt][t]) : y[rt][t];
-            } else {
-                const int nl = uniform(o.n_layers);
-                const PmtLinear& L1 = M->lin[uniform(o.lin[0])];
-                const PmtLinear& L2 = M->lin[uniform(o.lin[nl - 1])];
-                const int width = uniform(L1.in_dim);
-                const float alpha = uniform(theta[uniform(o.alpha_src)]);
-                if (nl == 2) {
-                    init_bias<PMT_NT>(y, packed + uniform(L1.b_pvec), width, g);
-                    linear_acc<PMT_NT, PMT_NT, true>(y, r, packed + uniform(L1.w_frag), width, width, PMT_FULL_MASK);
-                } else {
+        f4 e[PMT_RT][NTE];  // reducer output, then + translation (the rotation's input)
+        {
+            f4 r[PMT_RT][NTD];
+            load_slot_tiles<NTD>(stash_tile, mask_all, slot_last_in, r);
+            if constexpr (EX) {
+                const PmtLinear& Lr = M->lin[uniform(red_last.lin[0])];
+                init_bias<NTE>(e, uniform(Lr.b_pvec) >= 0 ? packed + uniform(Lr.b_pvec) : nullptr, uniform(Lr.out_dim), g);
+                linear_acc<NTD, NTE, false, true>(e, r, packed + uniform(Lr.w_frag), uniform(Lr.in_dim), uniform(Lr.out_dim));
+                if (uniform(red_last.selu_after) != 0) {
 #pragma unroll
                     for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
-                        for (int t = 0; t < PMT_NT; ++t) y[rt][t] = r[rt][t];
+                        for (int t = 0; t < NTE; ++t) e[rt][t] = selu4(e[rt][t]);
+                }
+            } else {  // forward of the last reducer op only, whatever its kind
+                f4 y[PMT_RT][NTD];
+                if (uniform(red_last.kind) == PMT_OP_LINEAR) {
+                    const PmtLinear& Lr = M->lin[uniform(red_last.lin[0])];
+                    init_bias<NTD>(y, uniform(Lr.b_pvec) >= 0 ? packed + uniform(Lr.b_pvec) : nullptr, uniform(Lr.out_dim), g);
+                    linear_acc<NTD, NTD, false>(y, r, packed + uniform(Lr.w_frag), uniform(Lr.in_dim), uniform(Lr.out_dim));
+                    const bool act = uniform(red_last.selu_after) != 0;
+#pragma unroll
+                    for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                        for (int t = 0; t < NTD; ++t) r[rt][t] = act ? selu4(y[rt][t]) : y[rt][t];
+                } else {
+                    const int nl = uniform(red_last.n_layers);
+                    const PmtLinear& L1 = M->lin[uniform(red_last.lin[0])];
+                    const PmtLinear& L2 = M->lin[uniform(red_last.lin[nl - 1])];
+                    const int width = uniform(L1.in_dim);
+                    const float alpha = uniform(theta[uniform(red_last.alpha_src)]);
+                    if (nl == 2) {
+                        init_bias<NTD>(y, packed + uniform(L1.b_pvec), width, g);
+                        linear_acc<NTD, NTD, true>(y, r, packed + uniform(L1.w_frag), width, width);
+                    } else {
+#pragma unroll
+                        for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                            for (int t = 0; t < NTD; ++t) y[rt][t] = r[rt][t];
+                    }
+#pragma unroll
+                    for (int t = 0; t < NTD; ++t) {
+                        const f4 b = alpha * load_pvec(packed + uniform(L2.b_pvec), t, g);
+#pragma unroll
+                        for (int rt = 0; rt < PMT_RT; ++rt) r[rt][t] = r[rt][t] + b;
+                    }
+                    linear_acc<NTD, NTD, true>(r, y, packed + uniform(L2.w_frag), width, width, alpha);
                 }
 #pragma unroll
-                for (int t = 0; t < PMT_NT; ++t) {
-                    const f4 b = alpha * load_pvec(packed + uniform(L2.b_pvec), t, g);
+                for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
-                    for (int rt = 0; rt < PMT_RT; ++rt) r[rt][t] = r[rt][t] + b;
-                }
-                linear_acc<PMT_NT, PMT_NT, true>(r, y, packed + uniform(L2.w_frag), width, width, PMT_FULL_MASK, alpha);
+                    for (int t = 0; t < NTE; ++t) e[rt][t] = r[rt][t < NTD ? t : 0];
             }
         }
         const PmtLinear& R = M->lin[uniform(M->rotation_lin)];
-        f4 a[PMT_RT][PMT_NT];
+        f4 a[PMT_RT][NTE];
 #pragma unroll
-        for (int t = 0; t < PMT_NT; ++t) {
+        for (int t = 0; t < NTE; ++t) {
             const f4 tr = load_pvec(packed + uniform(M->translation_pvec), t, g);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) {
-                r[rt][t] = r[rt][t] + tr;  // r + t, the rotation's input
+                e[rt][t] = e[rt][t] + tr;  // e + t, the rotation's input
                 a[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        linear_acc<PMT_NT, PMT_NT, false>(a, r, packed + uniform(R.w_frag), E, E, PMT_FULL_MASK);
+        linear_acc<NTE, NTE, false, EX>(a, e, packed + uniform(R.w_frag), E, E);
 
-        // ---- head backward (alt reads) + set-mean gradients -> d(a) in dy ------------------------------------------
-        f4 sig[PMT_NT], dsig[PMT_NT];
+        // ---- head backward (alt reads) + set-mean gradients -> d(a) in da ------------------------------------------
+        f4 da[PMT_RT][NTE];
+        f4 sig[NTE], dsig[NTE];
 #pragma unroll
-        for (int t = 0; t < PMT_NT; ++t) {
+        for (int t = 0; t < NTE; ++t) {
             sig[t] = f4{1.f, 1.f, 1.f, 1.f};
             dsig[t] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -199,15 +217,15 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         }
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt) {
-            const int set = tm[rt].set, s = tm[rt].side;
+            const int set = tm[rt].set;
 #pragma unroll
-            for (int t = 0; t < PMT_NT; ++t)
+            for (int t = 0; t < NTE; ++t)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    dy[rt][t][j] = (tm[rt].valid && t < nte) ? sh.dfeat[set][s == 1 ? 1 : 0][16 * t + 4 * g + j] : 0.f;
+                    da[rt][t][j] = (tm[rt].valid && t < nte) ? sh.dfeat[set][side][16 * t + 4 * g + j] : 0.f;
         }
         for (int k = -1; k < K; ++k) {  // k = -1: the two diagonal Gaussians; k >= 0: artifact cluster k
-            f4 v[PMT_NT], dvk[PMT_NT];
+            f4 v[NTE], dvk[NTE];
             float d_tau = 0.f, d_mu = 0.f, d_lam = 0.f, d_sg = 0.f;
             float tau = 1.f, mu = 0.f, sg = 1.f, lam = 1.f;
             if (k >= 0) {
@@ -217,7 +235,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
                 lam = uniform(phi[uniform(M->head.lambda_k_phi) + k]);
             }
 #pragma unroll
-            for (int t = 0; t < PMT_NT; ++t) {
+            for (int t = 0; t < NTE; ++t) {
                 v[t] = f4{0.f, 0.f, 0.f, 0.f};
                 dvk[t] = f4{0.f, 0.f, 0.f, 0.f};
                 if (k >= 0) {
@@ -226,95 +244,105 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
                         if (t < nte && feat_of(t, j, g) < E) v[t][j] = phi[uniform(M->head.dirs_ke_phi) + k * E + feat_of(t, j, g)];
                 }
             }
+            if (side == 1) {
 #pragma unroll
-            for (int rt = 0; rt < PMT_RT; ++rt) {
-                if (!(mask_side[1] & (1u << rt))) continue;
-                const int set = tm[rt].set;
-                const bool ok = tm[rt].valid;
-                if (k < 0) {
-                    const float g0 = ok ? sh.dl[set][0] : 0.f, g1 = ok ? sh.dl[set][1] : 0.f;
+                for (int rt = 0; rt < PMT_RT; ++rt) {
+                    const int set = tm[rt].set;
+                    const bool ok = tm[rt].valid;
+                    if (k < 0) {
+                        const float g0 = ok ? sh.dl[set][0] : 0.f, g1 = ok ? sh.dl[set][1] : 0.f;
 #pragma unroll
-                    for (int t = 0; t < PMT_NT; ++t)
+                        for (int t = 0; t < NTE; ++t)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (t < nte && feat_of(t, j, g) < E) {
+                                    const float av = a[rt][t][j], sv = sig[t][j], inv2 = 1.f / (sv * sv);
+                                    da[rt][t][j] += -(g0 + 0.25f * g1) * av * inv2;
+                                    dsig[t][j] += g0 * (-1.f / sv + av * av * inv2 / sv) + g1 * (-1.f / sv + 0.25f * av * av * inv2 / sv);
+                                }
+                        continue;
+                    }
+                    const float G = ok ? sh.dl[set][2 + k] : 0.f;
+                    float p = 0.f;
+#pragma unroll
+                    for (int t = 0; t < NTE; ++t) p += (a[rt][t][0] * v[t][0] + a[rt][t][1] * v[t][1]) + (a[rt][t][2] * v[t][2] + a[rt][t][3] * v[t][3]);
+                    p = group_sum(p);
+                    float o2 = 0.f, eu = 0.f;
+#pragma unroll
+                    for (int t = 0; t < NTE; ++t)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float ee = a[rt][t][j] - p * v[t][j];
+                            o2 += ee * ee;
+                            eu += ee * v[t][j];
+                        }
+                    o2 = group_sum(o2);
+                    eu = group_sum(eu);
+                    const float var = sg * sg;
+                    const float zz = (mu + lam * var - p) / (1.4142135623730951f * sg);
+                    const float Lp = dlogerfc_dev(zz);
+                    const float demg_dp = -Lp / (1.4142135623730951f * sg) - lam;
+                    const float c_o = -G / (2.f * tau * tau);  // d(loss)/d(o2)
+#pragma unroll
+                    for (int t = 0; t < NTE; ++t)
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             if (t < nte && feat_of(t, j, g) < E) {
-                                const float av = a[rt][t][j], sv = sig[t][j], inv2 = 1.f / (sv * sv);
-                                dy[rt][t][j] += -(g0 + 0.25f * g1) * av * inv2;
-                                dsig[t][j] += g0 * (-1.f / sv + av * av * inv2 / sv) + g1 * (-1.f / sv + 0.25f * av * av * inv2 / sv);
+                                const float ee = a[rt][t][j] - p * v[t][j];
+                                da[rt][t][j] += c_o * (2.f * ee - 2.f * eu * v[t][j]) + G * demg_dp * v[t][j];
+                                dvk[t][j] += c_o * (-2.f * eu * a[rt][t][j] - 2.f * p * ee) + G * demg_dp * a[rt][t][j];
                             }
-                    continue;
-                }
-                const float G = ok ? sh.dl[set][2 + k] : 0.f;
-                float p = 0.f;
-#pragma unroll
-                for (int t = 0; t < PMT_NT; ++t) p += (a[rt][t][0] * v[t][0] + a[rt][t][1] * v[t][1]) + (a[rt][t][2] * v[t][2] + a[rt][t][3] * v[t][3]);
-                p = group_sum(p);
-                float o2 = 0.f, eu = 0.f;
-#pragma unroll
-                for (int t = 0; t < PMT_NT; ++t)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float e = a[rt][t][j] - p * v[t][j];
-                        o2 += e * e;
-                        eu += e * v[t][j];
+                    if (g == 0) {  // scalar parameter gradients: once per read
+                        d_tau += G * (-(float)(E - 1) / tau + o2 / (tau * tau * tau));
+                        d_mu += G * (Lp / (1.4142135623730951f * sg) + lam);
+                        d_lam += G * (1.f / lam + Lp * sg * 0.7071067811865476f + mu + lam * var - p);
+                        d_sg += G * (Lp * (-(mu - p) / (1.4142135623730951f * var) + lam * 0.7071067811865476f) + lam * lam * sg);
                     }
-                o2 = group_sum(o2);
-                eu = group_sum(eu);
-                const float var = sg * sg;
-                const float zz = (mu + lam * var - p) / (1.4142135623730951f * sg);
-                const float Lp = dlogerfc_dev(zz);
-                const float demg_dp = -Lp / (1.4142135623730951f * sg) - lam;
-                const float c_o = -G / (2.f * tau * tau);  // d(loss)/d(o2)
-#pragma unroll
-                for (int t = 0; t < PMT_NT; ++t)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (t < nte && feat_of(t, j, g) < E) {
-                            const float e = a[rt][t][j] - p * v[t][j];
-                            dy[rt][t][j] += c_o * (2.f * e - 2.f * eu * v[t][j]) + G * demg_dp * v[t][j];
-                            dvk[t][j] += c_o * (-2.f * eu * a[rt][t][j] - 2.f * p * e) + G * demg_dp * a[rt][t][j];
-                        }
-                if (g == 0) {  // scalar parameter gradients: once per read
-                    d_tau += G * (-(float)(E - 1) / tau + o2 / (tau * tau * tau));
-                    d_mu += G * (Lp / (1.4142135623730951f * sg) + lam);
-                    d_lam += G * (1.f / lam + Lp * sg * 0.7071067811865476f + mu + lam * var - p);
-                    d_sg += G * (Lp * (-(mu - p) / (1.4142135623730951f * var) + lam * 0.7071067811865476f) + lam * lam * sg);
                 }
             }
-            if (k >= 0) {  // every wave pushes (zeros if it has no alt tile): the slab layout is workgroup-uniform
-                aux_push_vec<PMT_NT>(c, enc_phi(uniform(M->head.dirs_ke_phi) + k * E), dvk, E);
+            if (k >= 0) {  // every wave pushes (zeros from a ref wave): the slab layout is workgroup-uniform
+                aux_push_vec<NTE>(c, enc_phi(uniform(M->head.dirs_ke_phi) + k * E), dvk, E);
                 aux_push_scalar(c, enc_phi(uniform(M->head.art_stdev_k_phi) + k), d_tau);
                 aux_push_scalar(c, uniform(M->head.mu_k_src) + k, d_mu);
                 aux_push_scalar(c, enc_phi(uniform(M->head.lambda_k_phi) + k), d_lam);
                 aux_push_scalar(c, enc_phi(uniform(M->head.sigma_k_phi) + k), d_sg);
             }
         }
-        aux_push_vec<PMT_NT>(c, enc_phi(uniform(M->head.stdev_e_phi)), dsig, E);
-
+        aux_push_vec<NTE>(c, enc_phi(uniform(M->head.stdev_e_phi)), dsig, E);
         prof_add(c, 4, t_kernel0);
         unsigned long long t_rot = prof_now();
-        // ---- rotation + translation backward: a = Q (r + t) ------------------------------------------------------------
-        linear_wgrad<PMT_NT, PMT_NT>(c, R, dy, r);
-        f4 dx[PMT_RT][PMT_NT];
-        init_bias<PMT_NT>(dx, nullptr, E, g);
-        linear_acc<PMT_NT, PMT_NT, false>(dx, dy, packed + uniform(R.wt_frag), E, E, PMT_FULL_MASK);
-        f4 dt[PMT_NT];
+        // ---- rotation + translation backward: a = Q (e + t) ------------------------------------------------------------
+        linear_wgrad<NTE, NTE>(c, R, da, e);
+        f4 de[PMT_RT][NTE];
+        init_bias<NTE>(de, nullptr, E, g);
+        linear_acc<NTE, NTE, false, EX>(de, da, packed + uniform(R.wt_frag), E, E);
+        f4 dt[NTE];
 #pragma unroll
-        for (int t = 0; t < PMT_NT; ++t) {
+        for (int t = 0; t < NTE; ++t) {
             dt[t] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int rt = 0; rt < PMT_RT; ++rt) {
-                dy[rt][t] = dx[rt][t];
-                dt[t] = dt[t] + dx[rt][t];
-            }
+            for (int rt = 0; rt < PMT_RT; ++rt) dt[t] = dt[t] + de[rt][t];
         }
-        aux_push_vec<PMT_NT>(c, uniform(M->translation_src), dt, E);
+        aux_push_vec<NTE>(c, uniform(M->translation_src), dt, E);
         prof_add(c, 5, t_rot);
+        // ---- last reducer op ------------------------------------------------------------------------------------------
+        if constexpr (EX) {
+            f4 r[PMT_RT][NTD];
+            load_slot_tiles<NTD>(stash_tile, mask_all, slot_last_in, r);
+            linear_op_backward<NTD, NTE, true>(c, red_last, de, r, dy, true);
+        } else {
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                for (int t = 0; t < NTD; ++t) dy[rt][t] = de[rt][t < NTE ? t : 0];
+        }
     }
     unsigned long long t_ph = prof_now();
 
     // ---- reducer backward ---------------------------------------------------------------------------------------------
-    mlp_backward(c, M->reducer, dy, true, [&](int op, f4 (&x)[PMT_RT][PMT_NT]) { load_slot(op == 0 ? slot_x0 + L : slot_red + op - 1, x); });
+    mlp_backward<NTD, EX>(c, M->reducer, dy, true,
+                          [&](int op, f4 (&x)[PMT_RT][NTD]) { load_slot_tiles<NTD>(stash_tile, mask_all, op == 0 ? slot_x0 + L : slot_red + op - 1, x); },
+                          0, EX ? n_red_ops - 1 : n_red_ops);
 
     prof_add(c, 6, t_ph);
     // ---- gated blocks backward -----------------------------------------------------------------------------------------
@@ -323,74 +351,66 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         // gradient dy stays live across phases.  x_l is re-read from the stash (L2/HBM, 4 KB per tile) and its LayerNorm
         // recomputed each of the three times it is needed; z2 / gate are recomputed from z2hat.
         const PmtBlock& B = M->blocks[l];
+        const PmtLinear& P1 = M->lin[uniform(B.proj1[side])];
+        const PmtLinear& P2 = M->lin[uniform(B.proj2[side])];
         const float* lw_p = packed + uniform(B.norm_w_pvec);
         const float* lb_p = packed + uniform(B.norm_b_pvec);
         const float* xs[PMT_RT];
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt) xs[rt] = stash_tile[rt] + (slot_x0 + l) * PMT_SLOT_FLOATS;
         // n[rt] = LayerNorm_D(x_l[rt]) for every tile of this wave (absent tiles: zeros in, finite out)
-        auto recompute_n = [&](f4 (&n)[PMT_RT][PMT_NT]) {
-            f4 lw[PMT_NT], lb[PMT_NT];
+        auto recompute_n = [&](f4 (&n)[PMT_RT][NTD]) {
+            f4 lw[NTD], lb[NTD];
 #pragma unroll
-            for (int t = 0; t < PMT_NT; ++t) { lw[t] = load_pvec(lw_p, t, g); lb[t] = load_pvec(lb_p, t, g); }
+            for (int t = 0; t < NTD; ++t) { lw[t] = load_pvec(lw_p, t, g); lb[t] = load_pvec(lb_p, t, g); }
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) {
-                f4 xr[PMT_NT], xh[PMT_NT];
+                f4 xr[NTD], xh[NTD];
                 float rs;
 #pragma unroll
-                for (int t = 0; t < PMT_NT; ++t) xr[t] = f4{0.f, 0.f, 0.f, 0.f};
-                if (mask_all & (1u << rt)) stash_load<PMT_NT>(xs[rt], xr);
-                layernorm_tile<PMT_NT>(n[rt], xh, rs, xr, D, lw, lb, g);
+                for (int t = 0; t < NTD; ++t) xr[t] = f4{0.f, 0.f, 0.f, 0.f};
+                if (mask_all & (1u << rt)) stash_load<NTD>(xs[rt], xr);
+                layernorm_tile<NTD>(n[rt], xh, rs, xr, D, lw, lb, g);
             }
         };
         t_ph = prof_now();
         // ---- phase 1: z = selu(W1 n + b1) ---------------------------------------------------------------------------
         f4 z[PMT_RT][2];
-#pragma unroll
-        for (int rt = 0; rt < PMT_RT; ++rt) z[rt][0] = z[rt][1] = f4{0.f, 0.f, 0.f, 0.f};
         {
-            f4 n[PMT_RT][PMT_NT];
+            f4 n[PMT_RT][NTD];
             recompute_n(n);
+            const f4 b0 = load_pvec(packed + uniform(P1.b_pvec), 0, g), b1 = load_pvec(packed + uniform(P1.b_pvec), 1, g);
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-                if (mask_side[s]) {
-                    const PmtLinear& P1 = M->lin[uniform(B.proj1[s])];
-                    const f4 b0 = load_pvec(packed + uniform(P1.b_pvec), 0, g), b1 = load_pvec(packed + uniform(P1.b_pvec), 1, g);
-#pragma unroll
-                    for (int rt = 0; rt < PMT_RT; ++rt)
-                        if (mask_side[s] & (1u << rt)) { z[rt][0] = b0; z[rt][1] = b1; }
-                    linear_acc<PMT_NT, 2, false>(z, n, packed + uniform(P1.w_frag), D, 16 + h, mask_side[s]);
-                }
+            for (int rt = 0; rt < PMT_RT; ++rt) { z[rt][0] = b0; z[rt][1] = b1; }
+            linear_acc<NTD, 2, false, EX>(z, n, packed + uniform(P1.w_frag), D, 16 + h);
         }
         const f4 sw = load_pvec(packed + uniform(B.sgu_norm_w_pvec), 0, g), sb = load_pvec(packed + uniform(B.sgu_norm_b_pvec), 0, g);
         const float w = uniform(phi[uniform(B.reg_weight_phi)]) + 0.25f;
         const f4 rho = load_pvec(packed + uniform(B.ref_reg_pvec), 0, g);
-        const float alpha_ref = uniform(theta[uniform(B.alpha_src[0])]), alpha_alt = uniform(theta[uniform(B.alpha_src[1])]);
+        const float alpha = uniform(theta[uniform(B.alpha_src[side])]), beta = uniform(theta[uniform(B.beta_src[side])]);
         const float beta_ref = uniform(theta[uniform(B.beta_src[0])]), beta_alt = uniform(theta[uniform(B.beta_src[1])]);
         const float gamma = uniform(theta[uniform(B.gamma_src)]);
         // gate of one tile from z2hat (recomputed wherever it is needed)
         auto gate_of = [&](int rt, f4 z2hat_rt, f4& z2_out, f4& m_ref, f4& m_alt) -> f4 {
-            const int set = tm[rt].set, s = tm[rt].side;
+            const int set = tm[rt].set;
             const float n_ref = (float)(sh.off[0][set + 1] - sh.off[0][set]);
             const float n_alt = (float)(sh.off[1][set + 1] - sh.off[1][set]);
             const float* zs = zsum_stash + ((size_t)(gg.v0 + set) * L + l) * 32;
             m_ref = (*reinterpret_cast<const f4*>(zs + 4 * g) + w * rho) / (n_ref + w);
             m_alt = *reinterpret_cast<const f4*>(zs + 16 + 4 * g) / (n_alt + 1e-4f);
             z2_out = z2hat_rt * sw + sb;
-            f4 gt = z2_out * (s == 0 ? alpha_ref : alpha_alt) + 1.0f;
-            return s == 0 ? gt + beta_ref * m_ref : (gt + beta_alt * m_alt) + gamma * m_ref;
+            const f4 gt = z2_out * alpha + 1.0f;
+            return side == 0 ? gt + beta * m_ref : (gt + beta * m_alt) + gamma * m_ref;
         };
         prof_add(c, 8, t_ph);
         t_ph = prof_now();
         // ---- phase 2: d(u) = W2^T dy, d(gate), per-set sums of d(gate), proj2 weight gradient ------------------------------
         f4 z2hat[PMT_RT], dgate[PMT_RT], du[PMT_RT][1];
         float rstd2[PMT_RT];
-        float d_alpha_ref = 0.f, d_alpha_alt = 0.f, d_beta_ref = 0.f, d_beta_alt = 0.f, d_gamma = 0.f;
+        float d_alpha = 0.f, d_beta = 0.f, d_gamma = 0.f;
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt) du[rt][0] = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-            if (mask_side[s]) linear_acc<PMT_NT, 1, false>(du, dy, packed + uniform(M->lin[uniform(B.proj2[s])].wt_frag), D, h, mask_side[s]);
+        linear_acc<NTD, 1, false, EX>(du, dy, packed + uniform(P2.wt_frag), D, h);
         {
             f4 u[PMT_RT][1];
 #pragma unroll
@@ -403,27 +423,22 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
                 f4 z2v, m_ref, m_alt;
                 const f4 gt = gate_of(rt, z2hat[rt], z2v, m_ref, m_alt);
                 u[rt][0] = z[rt][0] * gt;
-                const int set = tm[rt].set, s = tm[rt].side;
+                const int set = tm[rt].set;
                 const bool ok = tm[rt].valid;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float dg = (ok && feat_of(0, j, g) < h) ? du[rt][0][j] * z[rt][0][j] : 0.f;
                     dgate[rt][j] = dg;
-                    if (s == 0) {
-                        d_alpha_ref += dg * z2v[j];
-                        d_beta_ref += dg * m_ref[j];
-                    } else {
-                        d_alpha_alt += dg * z2v[j];
-                        d_beta_alt += dg * m_alt[j];
-                        d_gamma += dg * m_ref[j];
-                    }
-                    if (ok && feat_of(0, j, g) < h) atomicAdd(&sh.gsum[set][s][4 * g + j], dg);
+                    d_alpha += dg * z2v[j];
+                    d_beta += dg * (side == 0 ? m_ref[j] : m_alt[j]);
+                    if (side == 1) d_gamma += dg * m_ref[j];
+                    if (ok && feat_of(0, j, g) < h) atomicAdd(&sh.gsum[set][side][4 * g + j], dg);
                 }
             }
             prof_add(c, 9, t_ph);
             t_ph = prof_now();
             // proj2 weight gradients of both sides in one exchange round
-            wgrad_exchange<PMT_NT, 1, 2>(c, M->lin[uniform(B.proj2[0])], M->lin[uniform(B.proj2[1])], dy, u, 1.0f);
+            wgrad_exchange<NTD, 1, 2>(c, M->lin[uniform(B.proj2[0])], M->lin[uniform(B.proj2[1])], dy, u, 1.0f);
         }
         __syncthreads();  // gsum complete
         prof_add(c, 10, t_ph);
@@ -467,12 +482,12 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             f4 dsw[1] = {f4{0.f, 0.f, 0.f, 0.f}}, dsb[1] = {f4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) {
-                const int set = tm[rt].set, s = tm[rt].side;
+                const int set = tm[rt].set;
                 const bool ok = tm[rt].valid;
                 f4 z2v, m_ref, m_alt;
                 const f4 gt = gate_of(rt, z2hat[rt], z2v, m_ref, m_alt);
-                f4 dz2 = dgate[rt] * (s == 0 ? alpha_ref : alpha_alt);
-                const f4 dm = *reinterpret_cast<const f4*>(&sh.dmean[set][s][4 * g]);
+                f4 dz2 = dgate[rt] * alpha;
+                const f4 dm = *reinterpret_cast<const f4*>(&sh.dmean[set][side][4 * g]);
                 if (ok) dz2 = dz2 + dm;
                 f4 dz2v[1] = {dz2}, zh[1] = {z2hat[rt]}, sw1[1] = {sw}, dxr[1];
                 layernorm_bwd_tile<1>(dxr, dz2v, zh, rstd2[rt], h, sw1, dsw, dsb, g);
@@ -482,31 +497,29 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             }
             aux_push_vec<1>(c, uniform(B.sgu_norm_w_src), dsw, h);
             aux_push_vec<1>(c, uniform(B.sgu_norm_b_src), dsb, h);
-            aux_push_scalar(c, uniform(B.alpha_src[0]), d_alpha_ref);
-            aux_push_scalar(c, uniform(B.alpha_src[1]), d_alpha_alt);
-            aux_push_scalar(c, uniform(B.beta_src[0]), d_beta_ref);
-            aux_push_scalar(c, uniform(B.beta_src[1]), d_beta_alt);
+            aux_push_scalar(c, uniform(B.alpha_src[0]), side == 0 ? d_alpha : 0.f);
+            aux_push_scalar(c, uniform(B.alpha_src[1]), side == 1 ? d_alpha : 0.f);
+            aux_push_scalar(c, uniform(B.beta_src[0]), side == 0 ? d_beta : 0.f);
+            aux_push_scalar(c, uniform(B.beta_src[1]), side == 1 ? d_beta : 0.f);
             aux_push_scalar(c, uniform(B.gamma_src), d_gamma);
         }
         prof_add(c, 12, t_ph);
         t_ph = prof_now();
         // ---- phase 4: proj1 weight gradient (needs n again), d(n) = W1^T d(zpre), LayerNorm(D) backward ---------------------
         {
-            f4 n[PMT_RT][PMT_NT];
+            f4 n[PMT_RT][NTD];
             recompute_n(n);
-            wgrad_exchange<2, PMT_NT, 2>(c, M->lin[uniform(B.proj1[0])], M->lin[uniform(B.proj1[1])], dz, n, 1.0f);
+            wgrad_exchange<2, NTD, 2>(c, M->lin[uniform(B.proj1[0])], M->lin[uniform(B.proj1[1])], dz, n, 1.0f);
         }
         prof_add(c, 13, t_ph);
         t_ph = prof_now();
         {
-            f4 dn[PMT_RT][PMT_NT];
-            init_bias<PMT_NT>(dn, nullptr, D, g);
+            f4 dn[PMT_RT][NTD];
+            init_bias<NTD>(dn, nullptr, D, g);
+            linear_acc<2, NTD, false, EX>(dn, dz, packed + uniform(P1.wt_frag), 16 + h, D);
+            f4 lw[NTD], dlw[NTD], dlb[NTD];
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-                if (mask_side[s]) linear_acc<2, PMT_NT, false>(dn, dz, packed + uniform(M->lin[uniform(B.proj1[s])].wt_frag), 16 + h, D, mask_side[s]);
-            f4 lw[PMT_NT], dlw[PMT_NT], dlb[PMT_NT];
-#pragma unroll
-            for (int t = 0; t < PMT_NT; ++t) {
+            for (int t = 0; t < NTD; ++t) {
                 lw[t] = load_pvec(lw_p, t, g);
                 dlw[t] = f4{0.f, 0.f, 0.f, 0.f};
                 dlb[t] = f4{0.f, 0.f, 0.f, 0.f};
@@ -515,20 +528,20 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             for (int rt = 0; rt < PMT_RT; ++rt) {
                 // one tile at a time (the scheduling barrier keeps the compiler from interleaving the tiles' temporaries)
                 __builtin_amdgcn_sched_barrier(0);
-                f4 xh[PMT_NT];
+                f4 xh[NTD];
                 float rs;
                 {
-                    f4 xr[PMT_NT];
+                    f4 xr[NTD];
 #pragma unroll
-                    for (int t = 0; t < PMT_NT; ++t) xr[t] = f4{0.f, 0.f, 0.f, 0.f};
-                    if (mask_all & (1u << rt)) stash_load<PMT_NT>(xs[rt], xr);
-                    layernorm_stats_tile<PMT_NT>(xh, rs, xr, D, g);
+                    for (int t = 0; t < NTD; ++t) xr[t] = f4{0.f, 0.f, 0.f, 0.f};
+                    if (mask_all & (1u << rt)) stash_load<NTD>(xs[rt], xr);
+                    layernorm_stats_tile<NTD>(xh, rs, xr, D, g);
                 }
-                layernorm_bwd_inplace_tile<PMT_NT>(dy[rt], dn[rt], xh, rs, D, lw, dlw, dlb, g);
+                layernorm_bwd_inplace_tile<NTD>(dy[rt], dn[rt], xh, rs, D, lw, dlw, dlb, g);
             }
             __builtin_amdgcn_sched_barrier(0);
-            aux_push_vec<PMT_NT>(c, uniform(B.norm_w_src), dlw, D);
-            aux_push_vec<PMT_NT>(c, uniform(B.norm_b_src), dlb, D);
+            aux_push_vec<NTD>(c, uniform(B.norm_w_src), dlw, D);
+            aux_push_vec<NTD>(c, uniform(B.norm_b_src), dlb, D);
         }
         prof_add(c, 14, t_ph);
     }
@@ -542,7 +555,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
     for (int rt = 0; rt < PMT_RT; ++rt) {
         const int set = tm[rt].set;
 #pragma unroll
-        for (int t = 0; t < PMT_NT; ++t)
+        for (int t = 0; t < NTD; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int f = feat_of(t, j, g);
@@ -553,11 +566,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             }
     }
     const int fmt = bt.read_format;
-    mlp_backward(c, M->read_mlp, dy, false, [&](int op, f4 (&x)[PMT_RT][PMT_NT]) {
-        if (op > 0) {
-            load_slot(op - 1, x);
-            return;
-        }
+    auto decode_reads = [&](f4 (&x)[PMT_RT][NTF]) {
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt) {
             const unsigned char* rowp = nullptr;
@@ -566,11 +575,28 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
                 rowp = reinterpret_cast<const unsigned char*>(bt.reads) + (size_t)src * (size_t)bt.read_row_bytes;
             }
 #pragma unroll
-            for (int t = 0; t < PMT_NT; ++t)
+            for (int t = 0; t < NTF; ++t)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) x[rt][t][j] = rowp ? read_feature_b(rowp, fmt, feat_of(t, j, g), F) : 0.f;
         }
-    });
+    };
+    if constexpr (EX) {
+        f4 dr[PMT_RT][NTR];
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < NTR; ++t) dr[rt][t] = dy[rt][t < NTD ? t : 0];
+        mlp_backward<NTR, true>(c, M->read_mlp, dr, true,
+                                [&](int op, f4 (&x)[PMT_RT][NTR]) { load_slot_tiles<NTR>(stash_tile, mask_all, op - 1, x); }, 1, n_read_ops);
+        f4 xf[PMT_RT][NTF], dxf[PMT_RT][NTF];
+        decode_reads(xf);
+        linear_op_backward<NTF, NTR, true>(c, M->read_mlp.ops[0], dr, xf, dxf, false);
+    } else {
+        mlp_backward<NTD, false>(c, M->read_mlp, dy, false,
+                                 [&](int op, f4 (&x)[PMT_RT][NTD]) {
+                                     if (op > 0) load_slot_tiles<NTD>(stash_tile, mask_all, op - 1, x); else decode_reads(x);
+                                 }, 0, n_read_ops);
+    }
     prof_add(c, 16, t_ph);
     aux_flush(c);  // ends with a workgroup barrier
     for (int i = tid; i < gg.nsets * Ev; i += PMT_THREADS) {
@@ -593,8 +619,8 @@ extern "C" int pmt_backward(const PmtModel* model_host, const PmtModel* model_de
         batch->total_tiles <= 0 || !out->logits_b || !out->logits_bk)
         return PMT_E_INVALID;
     const float* zsum_stash = stash + (size_t)batch->total_tiles * (size_t)pmt_stash_slots(model_host) * PMT_SLOT_FLOATS;
-    hipLaunchKernelGGL(pmt_backward_kernel, dim3(batch->num_groups), dim3(PMT_THREADS), 0,
-                       reinterpret_cast<hipStream_t>(stream), model_dev, theta, phi, packed, *batch, *out, *dout, stash,
-                       zsum_stash, grad_theta, grad_phi, grad_variant_embed);
+    auto kernel = pmt_shape_id(model_host) == 1 ? pmt_backward_kernel<ShapeP0> : pmt_backward_kernel<ShapeAny>;
+    hipLaunchKernelGGL(kernel, dim3(batch->num_groups), dim3(PMT_THREADS), 0, reinterpret_cast<hipStream_t>(stream), model_dev,
+                       theta, phi, packed, *batch, *out, *dout, stash, zsum_stash, grad_theta, grad_phi, grad_variant_embed);
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }

@@ -323,14 +323,36 @@ DEV void linear_wgrad(BwdCtx& c, const PmtLinear& L, const f4 (&dy)[PMT_RT][NTO]
     wgrad_exchange<NTO, NTI, 1>(c, L, L, dy, x, scale);
 }
 
+// Backward of one LINEAR op between register arrays of different tile counts (see run_linear_op): dy is the gradient
+// w.r.t. the op's output (modified: multiplied by the activation derivative), x its input; dx (if wanted) = W^T dy.
+template <int NTI, int NTO, bool EXACT>
+DEV void linear_op_backward(BwdCtx& c, const PmtOp& o, f4 (&dy)[PMT_RT][NTO], const f4 (&x)[PMT_RT][NTI],
+                            f4 (&dx)[PMT_RT][NTI], bool want_dx) {
+    const PmtLinear& L = c.M->lin[uniform(o.lin[0])];
+    const int in_dim = uniform(L.in_dim), out_dim = uniform(L.out_dim);
+    if (uniform(o.selu_after) != 0) {  // recompute s = selu(Wx + b); dy <- dy * selu'(s)
+        f4 y[PMT_RT][NTO];
+        init_bias<NTO>(y, uniform(L.b_pvec) >= 0 ? c.packed + uniform(L.b_pvec) : nullptr, out_dim, c.g);
+        linear_acc<NTI, NTO, false, EXACT>(y, x, c.packed + uniform(L.w_frag), in_dim, out_dim);
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < NTO; ++t) dy[rt][t] = selu_bwd4(dy[rt][t], selu4(y[rt][t]));
+    }
+    linear_wgrad<NTO, NTI>(c, L, dy, x);
+    if (want_dx) {
+        init_bias<NTI>(dx, nullptr, in_dim, c.g);
+        linear_acc<NTO, NTI, false, EXACT>(dx, dy, c.packed + uniform(L.wt_frag), out_dim, in_dim);
+    }
+}
+
 // backward of one MLP program.  dy (in/out): gradient w.r.t. the MLP output on entry, w.r.t. its input on exit
 // (not computed for op 0 when need_input_grad is false).  in_slot(op) gives the stash slot of op's input.
-template <int NT = PMT_NT, typename LoadInput>
+template <int NT, bool EXACT, typename LoadInput>
 DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool need_input_grad, LoadInput load_input,
-                      int op_begin = 0) {
+                      int op_begin, int op_end) {
     const PmtModel* M = c.M;
-    const int n_ops = uniform(mlp.n_ops);
-    for (int op = n_ops - 1; op >= op_begin; --op) {
+    for (int op = op_end - 1; op >= op_begin; --op) {
         const PmtOp& o = mlp.ops[op];
         f4 x[PMT_RT][NT];
         load_input(op, x);
@@ -340,17 +362,17 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
             if (uniform(o.selu_after) != 0) {  // recompute s = selu(Wx + b); dy <- dy * selu'(s)
                 f4 y[PMT_RT][NT];
                 init_bias<NT>(y, uniform(L.b_pvec) >= 0 ? c.packed + uniform(L.b_pvec) : nullptr, out_dim, c.g);
-                linear_acc<NT, NT, false>(y, x, c.packed + uniform(L.w_frag), in_dim, out_dim, PMT_FULL_MASK);
+                linear_acc<NT, NT, false, EXACT>(y, x, c.packed + uniform(L.w_frag), in_dim, out_dim);
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
                     for (int t = 0; t < NT; ++t) dy[rt][t] = selu_bwd4(dy[rt][t], selu4(y[rt][t]));
             }
             linear_wgrad<NT, NT>(c, L, dy, x);
-            if (op > 0 || need_input_grad) {
+            if (op > op_begin || need_input_grad) {
                 f4 dx[PMT_RT][NT];
                 init_bias<NT>(dx, nullptr, in_dim, c.g);
-                linear_acc<NT, NT, false>(dx, dy, c.packed + uniform(L.wt_frag), out_dim, in_dim, PMT_FULL_MASK);
+                linear_acc<NT, NT, false, EXACT>(dx, dy, c.packed + uniform(L.wt_frag), out_dim, in_dim);
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
@@ -368,7 +390,7 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
             f4 s1[PMT_RT][NT];
             if (nl == 2) {  // s1 = selu(L1 selu(x) + b1)
                 init_bias<NT>(s1, c.packed + uniform(L1.b_pvec), width, c.g);
-                linear_acc<NT, NT, true>(s1, x, c.packed + uniform(L1.w_frag), width, width, PMT_FULL_MASK);
+                linear_acc<NT, NT, true, EXACT>(s1, x, c.packed + uniform(L1.w_frag), width, width);
             }
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
@@ -377,7 +399,7 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
             {   // d(alpha) = sum dy . f,  f = L2 s1 + b2   (x's registers are free from here on)
                 f4 f[PMT_RT][NT];
                 init_bias<NT>(f, c.packed + uniform(L2.b_pvec), width, c.g);
-                linear_acc<NT, NT, false>(f, s1, c.packed + uniform(L2.w_frag), width, width, PMT_FULL_MASK);
+                linear_acc<NT, NT, false, EXACT>(f, s1, c.packed + uniform(L2.w_frag), width, width);
                 float da = 0.f;
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
@@ -390,7 +412,7 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
             linear_wgrad<NT, NT>(c, L2, dy, s1, alpha);
             f4 d1[PMT_RT][NT];
             init_bias<NT>(d1, nullptr, width, c.g);
-            linear_acc<NT, NT, false>(d1, dy, c.packed + uniform(L2.wt_frag), width, width, PMT_FULL_MASK);
+            linear_acc<NT, NT, false, EXACT>(d1, dy, c.packed + uniform(L2.wt_frag), width, width);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
@@ -406,7 +428,7 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
                 linear_wgrad<NT, NT>(c, L1, d1, s0);
                 f4 d0[PMT_RT][NT];
                 init_bias<NT>(d0, nullptr, width, c.g);
-                linear_acc<NT, NT, false>(d0, d1, c.packed + uniform(L1.wt_frag), width, width, PMT_FULL_MASK);
+                linear_acc<NT, NT, false, EXACT>(d0, d1, c.packed + uniform(L1.wt_frag), width, width);
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll

@@ -103,7 +103,7 @@ DEV void conv_forward(const PmtModel* __restrict__ M, const PmtCnnLayer& L, cons
             f4 x[PMT_RT][CNN_NTIN], y[PMT_RT][PMT_NT];
             gather_im2col(x, in, in_stride, tap, L, cm, g);
             init_bias<PMT_NT>(y, packed + uniform(W.b_pvec), OC, g);
-            linear_acc<CNN_NTIN, PMT_NT, false>(y, x, packed + uniform(W.w_frag), K, OC, PMT_FULL_MASK);
+            linear_acc<CNN_NTIN, PMT_NT, false>(y, x, packed + uniform(W.w_frag), K, OC);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
                 if (cm[rt].valid) {
@@ -334,7 +334,7 @@ extern "C" __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn_backward_ke
                 if (need_din) {
                     f4 dx[PMT_RT][CNN_NTIN];
                     init_bias<CNN_NTIN>(dx, nullptr, K, g);
-                    linear_acc<PMT_NT, CNN_NTIN, false>(dx, dy, packed + uniform(Wl.wt_frag), OC, K, PMT_FULL_MASK);
+                    linear_acc<PMT_NT, CNN_NTIN, false>(dx, dy, packed + uniform(Wl.wt_frag), OC, K);
                     const int nkt = (K + 15) >> 4;
 #pragma unroll
                     for (int t = 0; t < CNN_NTIN; ++t)

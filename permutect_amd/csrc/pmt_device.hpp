@@ -39,6 +39,17 @@ static_assert(PMT_GROUP_TILES == PMT_WAVES * PMT_RT, "group capacity");
 
 #define DEV __device__ __forceinline__
 
+// Register-array shapes of the read-set kernels, in 16-feature tiles: F read features, R read-MLP widths (after its first
+// linear), D d_model and reducer widths, E feature_dim.  EXACT: every layer fills its arrays completely, the read MLP
+// starts and the reducer ends with a LINEAR op (the two ops that change the tile count); the host picks the instance.
+template <int F, int R, int D, int E, bool EXACT_>
+struct Shape {
+    static constexpr int NTF = F, NTR = R, NTD = D, NTE = E;
+    static constexpr bool EXACT = EXACT_;
+};
+using ShapeAny = Shape<4, 4, 4, 4, false>;   // any supported model
+using ShapeP0 = Shape<4, 2, 4, 1, true>;     // F in 49..64, read widths 17..32, d_model / reducer widths 49..64, E <= 16
+
 DEV float uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -81,13 +92,12 @@ DEV int feat_of(int t, int j, int g) { return 16 * t + 4 * j + g; }
 DEV f4 load_pvec(const float* __restrict__ p, int t, int g) { return *reinterpret_cast<const f4*>(p + 16 * t + 4 * g); }
 
 // ---------------------------------------------------------------------------------------------------------------
-// acc[rt][mt] += sum_k W[m][k] * in[rt][k]   for the tiles selected by tile_mask (wave-uniform).
+// acc[rt][mt] += sum_k W[m][k] * in[rt][k]   for every tile of the wave.
 // `frag` = packed A fragments of W ([out_dim][in_dim]).  SELU_IN applies SELU to the input on the fly.
 // ---------------------------------------------------------------------------------------------------------------
-#define PMT_FULL_MASK ((1u << PMT_RT) - 1u)
-template <int NTI, int NTO, bool SELU_IN, bool MASKED, bool EXACT>
+template <int NTI, int NTO, bool SELU_IN, bool EXACT>
 DEV void linear_acc_impl(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], const float* __restrict__ frag, int in_dim,
-                         int out_dim, unsigned tile_mask, float in_scale) {
+                         int out_dim, float in_scale) {
     // Fragments are stored kt-major ((kt * nmt + mt) * 256 floats), i.e. in exactly the order this loop nest consumes
     // them, so the NEXT fragment is one fixed stride away and is fetched before the current fragment's MFMAs: the LDS
     // (or L2) latency hides behind 4 * PMT_RT MFMAs.  All 4 k-steps of a tile always run: the fragment rows / columns
@@ -100,13 +110,7 @@ DEV void linear_acc_impl(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], co
         if (EXACT || kt < nkt) {
             f4 b[PMT_RT];
 #pragma unroll
-            for (int rt = 0; rt < PMT_RT; ++rt) {
-                b[rt] = SELU_IN ? selu4(in[rt][kt]) * in_scale : in[rt][kt];
-                // MASKED (a wave whose tiles sit on both sides of the ref/alt boundary): tiles outside the mask get a
-                // zero B operand instead of a branch per MFMA.  (Per-MFMA guards made the compiler keep dozens of lane
-                // masks alive, spill them through VGPR lanes and then spill thousands of VGPRs.)
-                if (MASKED && !(tile_mask & (1u << rt))) b[rt] = f4{0.f, 0.f, 0.f, 0.f};
-            }
+            for (int rt = 0; rt < PMT_RT; ++rt) b[rt] = SELU_IN ? selu4(in[rt][kt]) * in_scale : in[rt][kt];
 #pragma unroll
             for (int mt = 0; mt < NTO; ++mt) {
                 if (EXACT || mt < nmt) {
@@ -125,21 +129,17 @@ DEV void linear_acc_impl(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], co
     }
 }
 
-// tile_mask == all tiles (the common case: a wave's tiles are on one side) takes the branch-free body
-template <int NTI, int NTO, bool SELU_IN>
+// A wave's tiles are all on one side of the ref / alt boundary (group_geometry), so no per-tile masks exist.
+// EXACT (compile time): the caller's Shape guarantees that the layer fills every tile of both register arrays -> one
+// straight-line MFMA chain with no per-tile guards (guards turn every accumulator into a web of PHI copies; they were
+// the source of thousands of VGPR spills).  Otherwise the same test is made at run time.
+template <int NTI, int NTO, bool SELU_IN, bool EXACT = false>
 DEV void linear_acc(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], const float* __restrict__ frag, int in_dim,
-                    int out_dim, unsigned tile_mask, float in_scale = 1.0f) {
-    // EXACT: the layer fills every tile of both register arrays -> one straight-line MFMA chain with no per-tile guards
-    // (guards turn every accumulator into a web of PHI copies; they were the source of thousands of VGPR spills).
-    const bool exact = ((in_dim + 15) >> 4) == NTI && ((out_dim + 15) >> 4) == NTO;
-    if (tile_mask == PMT_FULL_MASK) {
-        if (exact)
-            linear_acc_impl<NTI, NTO, SELU_IN, false, true>(acc, in, frag, in_dim, out_dim, tile_mask, in_scale);
-        else
-            linear_acc_impl<NTI, NTO, SELU_IN, false, false>(acc, in, frag, in_dim, out_dim, tile_mask, in_scale);
-    } else if (tile_mask != 0) {
-        linear_acc_impl<NTI, NTO, SELU_IN, true, false>(acc, in, frag, in_dim, out_dim, tile_mask, in_scale);
-    }
+                    int out_dim, float in_scale = 1.0f) {
+    if (EXACT || (((in_dim + 15) >> 4) == NTI && ((out_dim + 15) >> 4) == NTO))
+        linear_acc_impl<NTI, NTO, SELU_IN, true>(acc, in, frag, in_dim, out_dim, in_scale);
+    else
+        linear_acc_impl<NTI, NTO, SELU_IN, false>(acc, in, frag, in_dim, out_dim, in_scale);
 }
 
 // acc[rt][mt] = bias (tile-position order) for every tile; rows beyond out_dim are zero in the packed bias
@@ -217,7 +217,14 @@ struct GroupGeom {
     int total_ref;
     int tiles_ref, tiles_alt, ntiles;
     int tile_begin, tile_count;  // this wave's contiguous tile range
+    int side;                    // the side (0 ref / 1 alt) of ALL of this wave's tiles
 };
+
+// A group fits a workgroup when its ref tiles and its alt tiles can be dealt to disjoint sets of waves, PMT_RT per wave
+// (the planner, pmt_plan_groups, packs with the same rule).
+DEV bool group_fits(int tiles_ref, int tiles_alt) {
+    return (tiles_ref + PMT_RT - 1) / PMT_RT + (tiles_alt + PMT_RT - 1) / PMT_RT <= PMT_WAVES;
+}
 
 DEV GroupGeom group_geometry(const PmtBatch& bt, int group) {
     GroupGeom gg;
@@ -232,17 +239,25 @@ DEV GroupGeom group_geometry(const PmtBatch& bt, int group) {
     gg.tiles_ref = (gg.nref + 15) >> 4;
     gg.tiles_alt = (gg.nalt + 15) >> 4;
     gg.ntiles = gg.tiles_ref + gg.tiles_alt;
+    // Waves are side-homogeneous: the first wr waves share the ref tiles, the others the alt tiles, each side dealt
+    // contiguously and evenly; wr is the proportional share clamped so that no wave gets more than PMT_RT tiles.
     const int wave = uniform((int)(threadIdx.x >> 6));
-    const int q = gg.ntiles / PMT_WAVES, rem = gg.ntiles % PMT_WAVES;
-    gg.tile_begin = wave * q + min(wave, rem);
-    gg.tile_count = q + (wave < rem ? 1 : 0);
+    const int need_r = (gg.tiles_ref + PMT_RT - 1) / PMT_RT, need_a = (gg.tiles_alt + PMT_RT - 1) / PMT_RT;
+    int wr = gg.ntiles > 0 ? (PMT_WAVES * gg.tiles_ref + gg.ntiles / 2) / gg.ntiles : 0;
+    wr = min(max(wr, need_r), PMT_WAVES - need_a);
+    gg.side = wave < wr ? 0 : 1;
+    const int nw = gg.side == 0 ? wr : PMT_WAVES - wr, i = gg.side == 0 ? wave : wave - wr;
+    const int nt = gg.side == 0 ? gg.tiles_ref : gg.tiles_alt;
+    const int q = nw > 0 ? nt / nw : 0, rem = nw > 0 ? nt % nw : 0;
+    gg.tile_begin = (gg.side == 0 ? 0 : gg.tiles_ref) + i * q + min(i, rem);
+    gg.tile_count = q + (i < rem ? 1 : 0);
     return gg;
 }
 
 // per-tile metadata for this lane
 struct TileMeta {
-    int side;       // 0 = ref, 1 = alt (wave-uniform).  Tiles beyond the group's last tile count as (empty) alt tiles:
-                    // they are computed like any other tile (all lanes are padding) and never stored.
+    int side;       // 0 = ref, 1 = alt: the wave's side (GroupGeom.side).  Tiles the wave does not have are computed like
+                    // any other tile (all lanes are padding) and never stored.
     bool present;   // tile exists in this group (wave-uniform)
     int row;        // global row in the batch's read order (before the optional gather), -1 = padding lane
     int set;        // local set index within the group (0 if padding)
@@ -254,12 +269,12 @@ DEV TileMeta tile_meta(const GroupGeom& gg, int rt, const int* s_off) {
     TileMeta tm;
     const int r = threadIdx.x & 15;
     tm.present = rt < gg.tile_count;
+    tm.side = gg.side;
     if (!tm.present) {
-        tm.side = 1; tm.row = -1; tm.set = 0; tm.valid = false;
+        tm.row = -1; tm.set = 0; tm.valid = false;
         return tm;
     }
     const int tau = gg.tile_begin + rt;
-    tm.side = tau < gg.tiles_ref ? 0 : 1;
     const int local = (tm.side == 0 ? tau : tau - gg.tiles_ref) * 16 + r;
     const int n_side = tm.side == 0 ? gg.nref : gg.nalt;
     tm.valid = local < n_side;
@@ -276,6 +291,7 @@ DEV TileMeta tile_meta(const GroupGeom& gg, int rt, const int* s_off) {
 }
 
 extern "C" int pmt_stash_slots(const PmtModel* m);  // host helper (pmt_host.hip)
+extern "C" int pmt_shape_id(const PmtModel* m);     // host: 1 = the model fits ShapeP0 exactly, 0 = ShapeAny
 
 // ---- LDS weight staging ------------------------------------------------------------------------------------------
 // Every linear's A fragments are consumed by all waves of the workgroup, so they are staged ONCE per workgroup into

@@ -45,20 +45,25 @@ DEV float logerfc_dev(float z) {
     return z > 5.f ? asym : builtin;
 }
 
-template <bool TRAIN>
+template <bool TRAIN, typename S>
 __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_forward_kernel(const PmtModel* __restrict__ M,
                                                                       const float* __restrict__ theta,
                                                                       const float* __restrict__ phi,
                                                                       const float* __restrict__ packed, PmtBatch bt,
                                                                       PmtOutputs out, float* __restrict__ stash,
                                                                       float* __restrict__ zsum_stash) {
+    constexpr int NTF = S::NTF, NTR = S::NTR, NTD = S::NTD, NTE = S::NTE;
+    constexpr bool EX = S::EXACT;
+    static_assert(EX || (NTF == NTD && NTR == NTD && NTE == NTD), "the generic shape keeps one array width");
     __shared__ __attribute__((aligned(16))) FwdShared sh;
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
     const GroupGeom gg = group_geometry(bt, blockIdx.x);
+    const int side = gg.side;
 
     const int D = uniform(M->d_model), E = uniform(M->feature_dim), K = uniform(M->num_clusters);
     const int Er = uniform(M->read_embed_dim), Ev = uniform(M->variant_embed_dim);
     const int h = uniform(M->d_ffn) >> 1, L = uniform(M->num_blocks), F = uniform(M->num_read_features);
+    const int dbg = bt.debug_flags ? uniform(bt.debug_flags[1]) : 0;  // development switches, 0 in production
 
     // ---- group setup: local offsets, zero the per-set accumulators -------------------------------------------
     for (int i = tid; i <= gg.nsets; i += PMT_THREADS) {
@@ -71,21 +76,26 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_forward_kernel(const PmtMo
     __syncthreads();
 
     TileMeta tm[PMT_RT];
-    unsigned mask_all = 0, mask_side[2] = {0, 0};
+    unsigned mask_all = 0;  // tiles that exist: gates memory traffic only
     float* stash_tile[PMT_RT];
 #pragma unroll
     for (int rt = 0; rt < PMT_RT; ++rt) {
         tm[rt] = tile_meta(gg, rt, &sh.off[0][0]);
-        if (tm[rt].present) mask_all |= 1u << rt;  // tiles that exist: gates memory traffic only
-        if (tm[rt].side == 0) mask_side[0] |= 1u << rt; else mask_side[1] |= 1u << rt;
+        if (tm[rt].present) mask_all |= 1u << rt;
         stash_tile[rt] = nullptr;
         if (TRAIN)
             stash_tile[rt] = stash + (size_t)(bt.group_tile_base[blockIdx.x] + gg.tile_begin + rt) * (size_t)(stash_num_slots(M) * PMT_SLOT_FLOATS);
     }
 
-    // ---- decode the packed read rows straight into the B-operand layout -----------------------------------------
-    f4 x[PMT_RT][PMT_NT];
+    WStage ws{&sh.wbuf[0], M->fwd_sched, uniform(M->n_fwd_sched), 0, packed, bt.debug_flags};
+    wstage_begin<FWD_STAGED>(ws);
+    int slot = 0;
+    const int n_read_ops = uniform(M->read_mlp.n_ops), n_red_ops = uniform(M->reducer.n_ops);
+
+    // ---- decode the packed read rows straight into the B-operand layout, then the read MLP -------------------------
+    f4 x[PMT_RT][NTD];
     {
+        f4 xf[PMT_RT][NTF];
         const int fmt = bt.read_format;
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt) {
@@ -95,23 +105,33 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_forward_kernel(const PmtMo
                 rowp = reinterpret_cast<const unsigned char*>(bt.reads) + (size_t)src * (size_t)bt.read_row_bytes;
             }
 #pragma unroll
-            for (int t = 0; t < PMT_NT; ++t)
+            for (int t = 0; t < NTF; ++t)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) x[rt][t][j] = rowp ? read_feature(rowp, fmt, feat_of(t, j, g), F) : 0.f;
+                for (int j = 0; j < 4; ++j) xf[rt][t][j] = rowp ? read_feature(rowp, fmt, feat_of(t, j, g), F) : 0.f;
+        }
+        if constexpr (EX) {
+            f4 xr[PMT_RT][NTR];
+            run_linear_op<FWD_STAGED, NTF, NTR, true>(M, M->read_mlp.ops[0], xr, xf, g, ws);
+            run_mlp<TRAIN, FWD_STAGED, NTR, true>(M, M->read_mlp, xr, theta, g, mask_all, stash_tile, slot, 1, ws, 1, n_read_ops);
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                for (int t = 0; t < NTD; ++t) x[rt][t] = t < NTR ? xr[rt][t < NTR ? t : 0] : f4{0.f, 0.f, 0.f, 0.f};
+        } else {
+            run_mlp<TRAIN, FWD_STAGED, NTD, false>(M, M->read_mlp, xf, theta, g, mask_all, stash_tile, slot, 1, ws, 0, n_read_ops);
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                for (int t = 0; t < NTD; ++t) x[rt][t] = xf[rt][t < NTF ? t : 0];
         }
     }
-
-    WStage ws{&sh.wbuf[0], M->fwd_sched, uniform(M->n_fwd_sched), 0, packed, bt.debug_flags};
-    wstage_begin<FWD_STAGED>(ws);
-    int slot = 0;
-    run_mlp<TRAIN, FWD_STAGED>(M, M->read_mlp, x, packed, theta, g, mask_all, stash_tile, slot, 1, ws);
 
     // ---- broadcast-concat of the per-variant embedding (reference artifact_model.py:246-251) --------------------
 #pragma unroll
     for (int rt = 0; rt < PMT_RT; ++rt) {
         const float* vrow = bt.variant_embed + (size_t)(gg.v0 + tm[rt].set) * (size_t)Ev;
 #pragma unroll
-        for (int t = 0; t < PMT_NT; ++t)
+        for (int t = 0; t < NTD; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int f = feat_of(t, j, g);
@@ -119,13 +139,13 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_forward_kernel(const PmtMo
             }
     }
 
-    // ---- L gated ref/alt blocks ---------------------------------------------------------------------------------
+    // ---- L gated ref/alt blocks; this wave's tiles all use the weights of its side ------------------------------
     for (int l = 0; l < L; ++l) {
         const PmtBlock& B = M->blocks[l];
         if (TRAIN) {
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
-                if (mask_all & (1u << rt)) stash_store<PMT_NT>(stash_tile[rt] + slot * PMT_SLOT_FLOATS, x[rt]);
+                if (mask_all & (1u << rt)) stash_store<NTD>(stash_tile[rt] + slot * PMT_SLOT_FLOATS, x[rt]);
             ++slot;
         }
         f4 z[PMT_RT][2];
@@ -139,50 +159,41 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_forward_kernel(const PmtMo
         sw[0] = load_pvec(stA + (uniform(B.sgu_norm_w_pvec) - baseA), 0, g);
         sb[0] = load_pvec(stA + (uniform(B.sgu_norm_b_pvec) - baseA), 0, g);
         {
-            f4 lw[PMT_NT], lb[PMT_NT];
+            f4 lw[NTD], lb[NTD];
 #pragma unroll
-            for (int t = 0; t < PMT_NT; ++t) {
+            for (int t = 0; t < NTD; ++t) {
                 lw[t] = load_pvec(stA + (uniform(B.norm_w_pvec) - baseA), t, g);
                 lb[t] = load_pvec(stA + (uniform(B.norm_b_pvec) - baseA), t, g);
             }
-            f4 n[PMT_RT][PMT_NT];
+            f4 n[PMT_RT][NTD];
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) {
-                f4 xhat[PMT_NT];
+                f4 xhat[NTD];
                 float rstd;
-                layernorm_tile<PMT_NT>(n[rt], xhat, rstd, x[rt], D, lw, lb, g);
+                layernorm_tile<NTD>(n[rt], xhat, rstd, x[rt], D, lw, lb, g);
             }
-            const int p1_floats = frag_floats_dev(P1r);
+            const float* bp = stA + (uniform(M->lin[uniform(B.proj1[side])].b_pvec) - baseA);
+            const f4 b0 = load_pvec(bp, 0, g), b1 = load_pvec(bp, 1, g);
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                if (mask_side[s]) {
-                    const float* bp = stA + (uniform(M->lin[uniform(B.proj1[s])].b_pvec) - baseA);
-                    const f4 b0 = load_pvec(bp, 0, g), b1 = load_pvec(bp, 1, g);
-#pragma unroll
-                    for (int rt = 0; rt < PMT_RT; ++rt)
-                        if (mask_side[s] & (1u << rt)) { z[rt][0] = b0; z[rt][1] = b1; }
-                    linear_acc<PMT_NT, 2, false>(z, n, stA + s * p1_floats, D, 16 + h, mask_side[s]);
-                }
-            }
+            for (int rt = 0; rt < PMT_RT; ++rt) { z[rt][0] = b0; z[rt][1] = b1; }
+            linear_acc<NTD, 2, false, EX>(z, n, stA + side * frag_floats_dev(P1r), D, 16 + h);
         }
         // SELU, LayerNorm(h) on z2, per-set sums (reference gated_mlp.py:228-239)
         const int buf = l % 3;
-        {
 #pragma unroll
-            for (int rt = 0; rt < PMT_RT; ++rt) {
-                if (mask_all & (1u << rt)) {
-                    z[rt][0] = selu4(z[rt][0]);
-                    f4 zin[1] = {selu4(z[rt][1])}, zo[1], zh[1];
-                    float rstd;
-                    layernorm_tile<1>(zo, zh, rstd, zin, h, sw, sb, g);
-                    z[rt][1] = zo[0];
-                    if (tm[rt].valid) {
-                        float* dst = &sh.zsum[buf][tm[rt].set][tm[rt].side][4 * g];
+        for (int rt = 0; rt < PMT_RT; ++rt) {
+            z[rt][0] = selu4(z[rt][0]);
+            f4 zin[1] = {selu4(z[rt][1])}, zo[1], zh[1];
+            float rstd;
+            layernorm_tile<1>(zo, zh, rstd, zin, h, sw, sb, g);
+            z[rt][1] = zo[0];
+            if (tm[rt].valid) {
+                float* dst = &sh.zsum[buf][tm[rt].set][side][4 * g];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (feat_of(0, j, g) < h) atomicAdd(dst + j, z[rt][1][j]);
+                for (int j = 0; j < 4; ++j)
+                    if (feat_of(0, j, g) < h) {
+                        if (dbg & 64) dst[j] = z[rt][1][j]; else atomicAdd(dst + j, z[rt][1][j]);
                     }
-                }
             }
         }
         __syncthreads();
@@ -197,82 +208,88 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_forward_kernel(const PmtMo
         // gate and second projection with the residual as the accumulator input
         {
             const float w = uniform(phi[uniform(B.reg_weight_phi)]) + 0.25f;
-            const float alpha_ref = uniform(theta[uniform(B.alpha_src[0])]), alpha_alt = uniform(theta[uniform(B.alpha_src[1])]);
-            const float beta_ref = uniform(theta[uniform(B.beta_src[0])]), beta_alt = uniform(theta[uniform(B.beta_src[1])]);
+            const float alpha = uniform(theta[uniform(B.alpha_src[side])]), beta = uniform(theta[uniform(B.beta_src[side])]);
             const float gamma = uniform(theta[uniform(B.gamma_src)]);
             f4 u[PMT_RT][1];
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) {
-                u[rt][0] = f4{0.f, 0.f, 0.f, 0.f};
-                if (mask_all & (1u << rt)) {
-                    const int set = tm[rt].set, s = tm[rt].side;
-                    const float n_ref = (float)(sh.off[0][set + 1] - sh.off[0][set]);
-                    const float n_alt = (float)(sh.off[1][set + 1] - sh.off[1][set]);
-                    const f4 s_ref = *reinterpret_cast<const f4*>(&sh.zsum[buf][set][0][4 * g]);
-                    const f4 m_ref = (s_ref + w * rho) / (n_ref + w);
-                    f4 gate = z[rt][1] * (s == 0 ? alpha_ref : alpha_alt) + 1.0f;
-                    if (s == 0) {
-                        gate = gate + beta_ref * m_ref;
-                    } else {
-                        const f4 s_alt = *reinterpret_cast<const f4*>(&sh.zsum[buf][set][1][4 * g]);
-                        const f4 m_alt = s_alt / (n_alt + 1e-4f);
-                        gate = (gate + beta_alt * m_alt) + gamma * m_ref;
-                    }
-                    u[rt][0] = z[rt][0] * gate;
+                const int set = tm[rt].set;
+                const float n_ref = (float)(sh.off[0][set + 1] - sh.off[0][set]);
+                const float n_alt = (float)(sh.off[1][set + 1] - sh.off[1][set]);
+                const f4 s_ref = *reinterpret_cast<const f4*>(&sh.zsum[buf][set][0][4 * g]);
+                const f4 m_ref = (s_ref + w * rho) / (n_ref + w);
+                f4 gate = z[rt][1] * alpha + 1.0f;
+                if (side == 0) {
+                    gate = gate + beta * m_ref;
+                } else {
+                    const f4 s_alt = *reinterpret_cast<const f4*>(&sh.zsum[buf][set][1][4 * g]);
+                    const f4 m_alt = s_alt / (n_alt + 1e-4f);
+                    gate = (gate + beta * m_alt) + gamma * m_ref;
                 }
+                u[rt][0] = z[rt][0] * gate;
             }
             const PmtLinear& P2r = M->lin[uniform(B.proj2[0])];
-            const int p2_floats = frag_floats_dev(P2r), baseB = uniform(P2r.w_frag);
+            const int baseB = uniform(P2r.w_frag);
             const float* p2_frags = wstage_acquire<FWD_STAGED>(ws, baseB, uniform(P2r.w_stage));  // [W2_ref | W2_alt | b2_ref | b2_alt]
+            const float* bp = p2_frags + (uniform(M->lin[uniform(B.proj2[side])].b_pvec) - baseB);
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                if (mask_side[s]) {
-                    const PmtLinear& P2 = M->lin[uniform(B.proj2[s])];
+            for (int t = 0; t < NTD; ++t) {
+                const f4 b = load_pvec(bp, t, g);
 #pragma unroll
-                    for (int t = 0; t < PMT_NT; ++t) {
-                        const f4 b = load_pvec(p2_frags + (uniform(P2.b_pvec) - baseB), t, g);
-#pragma unroll
-                        for (int rt = 0; rt < PMT_RT; ++rt)
-                            if (mask_side[s] & (1u << rt)) x[rt][t] = x[rt][t] + b;
-                    }
-                    linear_acc<1, PMT_NT, false>(x, u, p2_frags + s * p2_floats, h, D, mask_side[s]);
-                }
+                for (int rt = 0; rt < PMT_RT; ++rt) x[rt][t] = x[rt][t] + b;
             }
+            linear_acc<1, NTD, false, EX>(x, u, p2_frags + side * frag_floats_dev(P2r), h, D);
         }
     }
     if (TRAIN) {  // x_L, the reducer's input
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt)
-            if (mask_all & (1u << rt)) stash_store<PMT_NT>(stash_tile[rt] + slot * PMT_SLOT_FLOATS, x[rt]);
+            if (mask_all & (1u << rt)) stash_store<NTD>(stash_tile[rt] + slot * PMT_SLOT_FLOATS, x[rt]);
         ++slot;
     }
 
     // ---- reducer MLP, then translation + rotation ----------------------------------------------------------------
-    run_mlp<TRAIN, FWD_STAGED>(M, M->reducer, x, packed, theta, g, mask_all, stash_tile, slot, 1, ws);
-    f4 a[PMT_RT][PMT_NT];
+    f4 e[PMT_RT][NTE];
+    if constexpr (EX) {
+        run_mlp<TRAIN, FWD_STAGED, NTD, true>(M, M->reducer, x, theta, g, mask_all, stash_tile, slot, 1, ws, 0, n_red_ops - 1);
+        if (TRAIN && n_red_ops > 1) {
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt)
+                if (mask_all & (1u << rt)) stash_store<NTD>(stash_tile[rt] + slot * PMT_SLOT_FLOATS, x[rt]);
+            ++slot;
+        }
+        run_linear_op<FWD_STAGED, NTD, NTE, true>(M, M->reducer.ops[n_red_ops - 1], e, x, g, ws);
+    } else {
+        run_mlp<TRAIN, FWD_STAGED, NTD, false>(M, M->reducer, x, theta, g, mask_all, stash_tile, slot, 1, ws, 0, n_red_ops);
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < NTE; ++t) e[rt][t] = x[rt][t < NTD ? t : 0];
+    }
+    f4 a[PMT_RT][NTE];
     {
         const PmtLinear& R = M->lin[uniform(M->rotation_lin)];
         const float* stR = wstage_acquire<FWD_STAGED>(ws, uniform(R.w_frag), uniform(R.w_stage));  // [Q fragments | translation]
 #pragma unroll
-        for (int t = 0; t < PMT_NT; ++t) {
+        for (int t = 0; t < NTE; ++t) {
             const f4 tr = load_pvec(stR + (uniform(M->translation_pvec) - uniform(R.w_frag)), t, g);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) {
-                x[rt][t] = x[rt][t] + tr;
+                e[rt][t] = e[rt][t] + tr;
                 a[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        linear_acc<PMT_NT, PMT_NT, false>(a, x, stR, E, E, PMT_FULL_MASK);
+        linear_acc<NTE, NTE, false, EX>(a, e, stR, E, E);
     }
 
     // ---- per-set feature sums (both sides) and the clustering head (alt reads) -------------------------------------
     const int nte = (E + 15) >> 4;
     {
         const float* hp = phi;  // head parameters live in phi (materialised parametrizations), mu in theta
-        f4 sig[PMT_NT];
+        f4 sig[NTE];
         float sum_log_sig = 0.f, sum_log_2sig = 0.f;
 #pragma unroll
-        for (int t = 0; t < PMT_NT; ++t) {
+        for (int t = 0; t < NTE; ++t) {
             sig[t] = f4{1.f, 1.f, 1.f, 1.f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -292,19 +309,19 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_forward_kernel(const PmtMo
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt) {
             if (!(mask_all & (1u << rt))) continue;
-            const int set = tm[rt].set, s = tm[rt].side;
+            const int set = tm[rt].set;
             if (tm[rt].valid) {
 #pragma unroll
-                for (int t = 0; t < PMT_NT; ++t)
+                for (int t = 0; t < NTE; ++t)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (t < nte && feat_of(t, j, g) < E) atomicAdd(&sh.fsum[set][s][16 * t + 4 * g + j], a[rt][t][j]);
+                        if (t < nte && feat_of(t, j, g) < E) atomicAdd(&sh.fsum[set][side][16 * t + 4 * g + j], a[rt][t][j]);
             }
-            if (s != 1) continue;
+            if (side != 1) continue;
             // nonartifact / outlier diagonal Gaussians
             float q0 = 0.f, q1 = 0.f;
 #pragma unroll
-            for (int t = 0; t < PMT_NT; ++t)
+            for (int t = 0; t < NTE; ++t)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (t < nte && feat_of(t, j, g) < E) {
@@ -321,10 +338,10 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_forward_kernel(const PmtMo
             // artifact clusters: projection on the unit direction, orthogonal distance, EMG along the direction
             for (int k = 0; k < K; ++k) {
                 const float* vk = hp + uniform(M->head.dirs_ke_phi) + k * E;
-                f4 v[PMT_NT];
+                f4 v[NTE];
                 float p = 0.f;
 #pragma unroll
-                for (int t = 0; t < PMT_NT; ++t) {
+                for (int t = 0; t < NTE; ++t) {
                     v[t] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -338,7 +355,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_forward_kernel(const PmtMo
                 p = group_sum(p);
                 float o2 = 0.f;
 #pragma unroll
-                for (int t = 0; t < PMT_NT; ++t)
+                for (int t = 0; t < NTE; ++t)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         if (t < nte && feat_of(t, j, g) < E) {
@@ -402,15 +419,16 @@ extern "C" int pmt_forward(const PmtModel* model_host, const PmtModel* model_dev
         !out->logits_b || !out->logits_bk || !out->features_be || !out->ref_features_be)
         return PMT_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool p0 = pmt_shape_id(model_host) == 1;  // tile-exact instance (pmt_device.hpp: ShapeP0) or the generic one
+    float* zsum_stash = nullptr;
     if (stash) {
         if (!batch->group_tile_base || batch->total_tiles <= 0) return PMT_E_INVALID;
         // per-set z2 sums follow the per-tile activation slots (layout: pmt_stash_bytes)
-        float* zsum_stash = stash + (size_t)batch->total_tiles * (size_t)pmt_stash_slots(model_host) * PMT_SLOT_FLOATS;
-        hipLaunchKernelGGL(pmt_forward_kernel<true>, dim3(batch->num_groups), dim3(PMT_THREADS), 0, s, model_dev, theta,
-                           phi, packed, *batch, *out, stash, zsum_stash);
-        return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
+        zsum_stash = stash + (size_t)batch->total_tiles * (size_t)pmt_stash_slots(model_host) * PMT_SLOT_FLOATS;
     }
-    hipLaunchKernelGGL(pmt_forward_kernel<false>, dim3(batch->num_groups), dim3(PMT_THREADS), 0, s, model_dev, theta, phi,
-                       packed, *batch, *out, (float*)nullptr, (float*)nullptr);
+    auto kernel = stash ? (p0 ? pmt_forward_kernel<true, ShapeP0> : pmt_forward_kernel<true, ShapeAny>)
+                        : (p0 ? pmt_forward_kernel<false, ShapeP0> : pmt_forward_kernel<false, ShapeAny>);
+    hipLaunchKernelGGL(kernel, dim3(batch->num_groups), dim3(PMT_THREADS), 0, s, model_dev, theta, phi, packed, *batch, *out,
+                       stash, zsum_stash);
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }

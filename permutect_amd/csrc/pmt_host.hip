@@ -26,6 +26,40 @@ extern "C" int pmt_struct_bytes(int which) {
 
 extern "C" int pmt_stash_slots(const PmtModel* m) { return (m->read_mlp.n_ops - 1) + (m->num_blocks + 1) + (m->reducer.n_ops - 1); }
 
+// Which register-array shape the read-set kernels run with (pmt_device.hpp: Shape).  1 = ShapeP0, every layer fills
+// its tile arrays exactly: F and the first read linear 4 -> 2 tiles, the rest of the read MLP 2 tiles wide, d_model
+// and the reducer 4 tiles wide up to a last LINEAR 4 -> 1, feature_dim 1 tile.  Anything else runs the generic shape.
+// PMT_SHAPE=any in the environment forces the generic instance (used by the parity tests to cover both).
+static int tiles_of(int dim) { return (dim + 15) / 16; }
+static bool mlp_ops_have_tiles(const PmtModel* m, const PmtMlp* mlp, int first, int last, int nt) {
+    for (int i = first; i < last; ++i) {
+        const PmtOp* o = &mlp->ops[i];
+        const int nl = o->kind == PMT_OP_SKIP ? o->n_layers : 1;
+        for (int k = 0; k < nl; ++k) {
+            const PmtLinear* L = &m->lin[o->lin[k]];
+            if (tiles_of(L->in_dim) != nt || tiles_of(L->out_dim) != nt) return false;
+        }
+    }
+    return true;
+}
+extern "C" int pmt_shape_id(const PmtModel* m) {
+    const char* force = getenv("PMT_SHAPE");
+    if (force && strcmp(force, "any") == 0) return 0;
+    const PmtMlp* rm = &m->read_mlp;
+    const PmtMlp* red = &m->reducer;
+    if (rm->n_ops < 1 || red->n_ops < 1 || m->num_blocks < 0) return 0;
+    const PmtOp* first = &rm->ops[0];
+    const PmtOp* last = &red->ops[red->n_ops - 1];
+    if (first->kind != PMT_OP_LINEAR || last->kind != PMT_OP_LINEAR) return 0;
+    const PmtLinear* Lf = &m->lin[first->lin[0]];
+    const PmtLinear* Ll = &m->lin[last->lin[0]];
+    const bool ok = tiles_of(m->num_read_features) == 4 && tiles_of(Lf->in_dim) == 4 && tiles_of(Lf->out_dim) == 2 &&
+                    mlp_ops_have_tiles(m, rm, 1, rm->n_ops, 2) && tiles_of(m->read_embed_dim) == 2 &&
+                    tiles_of(m->d_model) == 4 && m->d_ffn >= 2 && mlp_ops_have_tiles(m, red, 0, red->n_ops - 1, 4) &&
+                    tiles_of(Ll->in_dim) == 4 && tiles_of(Ll->out_dim) == 1 && tiles_of(m->feature_dim) == 1;
+    return ok ? 1 : 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // descriptor validation
 // ---------------------------------------------------------------------------------------------------------------------
@@ -203,6 +237,13 @@ extern "C" int pmt_build_schedules(PmtModel* m) {
 // ---------------------------------------------------------------------------------------------------------------------
 // group planning (host)
 // ---------------------------------------------------------------------------------------------------------------------
+// ref tiles and alt tiles go to disjoint waves, PMT_GROUP_TILES / PMT_GROUP_WAVES tiles per wave (group_geometry)
+static bool group_fits(long long ref_reads, long long alt_reads) {
+    const long long per = PMT_GROUP_TILES / PMT_GROUP_WAVES;
+    const long long tr = (ref_reads + 15) / 16, ta = (alt_reads + 15) / 16;
+    return (tr + per - 1) / per + (ta + per - 1) / per <= PMT_GROUP_WAVES;
+}
+
 extern "C" int pmt_plan_groups(const int32_t* ref_counts, const int32_t* alt_counts, int32_t num_variants,
                                int32_t* group_start, int32_t* group_tile_base, int32_t* bad_variant) {
     if (!ref_counts || !alt_counts || !group_start || !group_tile_base || num_variants < 0) return PMT_E_INVALID;
@@ -215,12 +256,11 @@ extern "C" int pmt_plan_groups(const int32_t* ref_counts, const int32_t* alt_cou
     for (int b = 0; b < num_variants; ++b) {
         const long long r = ref_counts[b], a = alt_counts[b];
         if (r < 0 || a < 0) return PMT_E_INVALID;
-        if ((r + 15) / 16 + (a + 15) / 16 > PMT_GROUP_TILES) {
+        if (!group_fits(r, a)) {
             if (bad_variant) *bad_variant = b;
             return PMT_E_CAPACITY;
         }
-        const long long tiles_if_added = (ref + r + 15) / 16 + (alt + a + 15) / 16;
-        if (sets > 0 && (tiles_if_added > PMT_GROUP_TILES || sets + 1 > PMT_GROUP_MAX_SETS)) {
+        if (sets > 0 && (!group_fits(ref + r, alt + a) || sets + 1 > PMT_GROUP_MAX_SETS)) {
             tile_base += (ref + 15) / 16 + (alt + 15) / 16;
             ++groups;
             group_start[groups] = b;

@@ -2,34 +2,47 @@
 #pragma once
 #include "pmt_device.hpp"
 
+// One LINEAR op between register arrays of different tile counts (the first op of the read MLP, the last op of the
+// reducer, the wide first op of a row MLP): y = act(W x + b).
+template <bool STAGED, int NTI, int NTO, bool EXACT>
+DEV void run_linear_op(const PmtModel* __restrict__ M, const PmtOp& o, f4 (&y)[PMT_RT][NTO], const f4 (&x)[PMT_RT][NTI],
+                       int g, WStage& ws) {
+    const PmtLinear& L = M->lin[uniform(o.lin[0])];
+    const int b_pvec = uniform(L.b_pvec), base = uniform(L.w_frag);
+    const float* st = wstage_acquire<STAGED>(ws, base, uniform(L.w_stage));  // [fragments | bias]
+    init_bias<NTO>(y, b_pvec >= 0 ? st + (b_pvec - base) : nullptr, uniform(L.out_dim), g);
+    linear_acc<NTI, NTO, false, EXACT>(y, x, st, uniform(L.in_dim), uniform(L.out_dim));
+    if (uniform(o.selu_after) != 0) {
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < NTO; ++t) y[rt][t] = selu4(y[rt][t]);
+    }
+}
+
 // ---- MLP program interpreter (reference architecture/mlp.py) ------------------------------------------------------
-// x (in place): in_dim -> out_dim.  When stash != nullptr the INPUT of every op with index >= first_stashed_op is
-// written to consecutive slots starting at *slot.
-template <bool TRAIN, bool STAGED, int NT = PMT_NT>
-DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_RT][NT],
-                 const float* __restrict__ packed, const float* __restrict__ theta, int g, unsigned tile_mask,
-                 float* const (&stash_tile)[PMT_RT], int& slot, int first_stashed_op, WStage& ws, int op_begin = 0) {
-    const int n_ops = uniform(mlp.n_ops);
-    for (int op = op_begin; op < n_ops; ++op) {
+// Runs ops [op_begin, op_end) on x in place; every op in the range maps NT tiles to NT tiles.  With TRAIN the INPUT of
+// every op with index >= first_stashed_op is written to consecutive stash slots starting at `slot` (tiles in
+// store_mask only).
+template <bool TRAIN, bool STAGED, int NT, bool EXACT>
+DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_RT][NT], const float* __restrict__ theta,
+                 int g, unsigned store_mask, float* const (&stash_tile)[PMT_RT], int& slot, int first_stashed_op,
+                 WStage& ws, int op_begin, int op_end) {
+    for (int op = op_begin; op < op_end; ++op) {
         const PmtOp& o = mlp.ops[op];
         if (TRAIN && op >= first_stashed_op) {
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
-                if (tile_mask & (1u << rt)) stash_store<NT>(stash_tile[rt] + slot * PMT_SLOT_FLOATS, x[rt]);
+                if (store_mask & (1u << rt)) stash_store<NT>(stash_tile[rt] + slot * PMT_SLOT_FLOATS, x[rt]);
             ++slot;
         }
         f4 y[PMT_RT][NT];
         if (uniform(o.kind) == PMT_OP_LINEAR) {
-            const PmtLinear& L = M->lin[uniform(o.lin[0])];
-            const int b_pvec = uniform(L.b_pvec), base = uniform(L.w_frag);
-            const float* st = wstage_acquire<STAGED>(ws, base, uniform(L.w_stage));  // [fragments | bias]
-            init_bias<NT>(y, b_pvec >= 0 ? st + (b_pvec - base) : nullptr, uniform(L.out_dim), g);
-            linear_acc<NT, NT, false>(y, x, st, uniform(L.in_dim), uniform(L.out_dim), PMT_FULL_MASK);
-            const bool act = uniform(o.selu_after) != 0;
+            run_linear_op<STAGED, NT, NT, EXACT>(M, o, y, x, g, ws);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) x[rt][t] = act ? selu4(y[rt][t]) : y[rt][t];
+                for (int t = 0; t < NT; ++t) x[rt][t] = y[rt][t];
         } else {
             // x + alpha * f(x) with one or two (SELU, Linear) layers.  Only two register arrays are live: the last
             // layer accumulates straight into x, with alpha folded into its B operand and bias.
@@ -44,7 +57,7 @@ DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_
                 const PmtLinear& L1 = M->lin[uniform(o.lin[0])];
                 const float* st1 = wstage_acquire<STAGED>(ws, uniform(L1.w_frag), uniform(L1.w_stage));
                 init_bias<NT>(y, st1 + (uniform(L1.b_pvec) - uniform(L1.w_frag)), width, g);
-                linear_acc<NT, NT, true>(y, x, st1, width, width, PMT_FULL_MASK);
+                linear_acc<NT, NT, true, EXACT>(y, x, st1, width, width);
             }
             const PmtLinear& L2 = M->lin[uniform(o.lin[nl - 1])];
             const float alpha = uniform(theta[uniform(o.alpha_src)]);
@@ -52,14 +65,13 @@ DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_
             const float* st2 = wstage_acquire<STAGED>(ws, uniform(L2.w_frag), uniform(L2.w_stage));
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                if (t < nmt) {
+                if (EXACT || t < nmt) {
                     const f4 b = alpha * load_pvec(st2 + (uniform(L2.b_pvec) - uniform(L2.w_frag)), t, g);
 #pragma unroll
                     for (int rt = 0; rt < PMT_RT; ++rt) x[rt][t] = x[rt][t] + b;
                 }
             }
-            linear_acc<NT, NT, true>(x, y, st2, width, width, PMT_FULL_MASK, alpha);
+            linear_acc<NT, NT, true, EXACT>(x, y, st2, width, width, alpha);
         }
     }
 }
-

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_forward_kernel(const 
         const PmtLinear& L = M->lin[uniform(o.lin[0])];
         const int b_pvec = uniform(L.b_pvec);
         init_bias<PMT_NT>(x, b_pvec >= 0 ? packed + b_pvec : nullptr, uniform(L.out_dim), g);
-        linear_acc<ROWS_NTIN, PMT_NT, false>(x, xin, packed + uniform(L.w_frag), in_dim, uniform(L.out_dim), PMT_FULL_MASK);
+        linear_acc<ROWS_NTIN, PMT_NT, false>(x, xin, packed + uniform(L.w_frag), in_dim, uniform(L.out_dim));
         if (uniform(o.selu_after) != 0) {
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_forward_kernel(const 
     } else {
         load_rows<PMT_NT>(x, in, in_stride, n_rows, in_dim, tile0, g);
     }
-    run_mlp<TRAIN, false>(M, mlp, x, packed, theta, g, present, stash_tile, slot, 1, ws, op_begin);
+    run_mlp<TRAIN, false, PMT_NT, false>(M, mlp, x, theta, g, present, stash_tile, slot, 1, ws, op_begin, uniform(mlp.n_ops));
     const int r = lane & 15;
 #pragma unroll
     for (int rt = 0; rt < PMT_RT; ++rt) {
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_backward_kernel(
     const bool wide = in_dim > PMT_MAX_WIDTH;
     const bool want_d_in = d_in != nullptr;
     const int first_op = wide ? 1 : 0;
-    mlp_backward(c, mlp, dy, want_d_in, load_input, first_op);
+    mlp_backward<PMT_NT, false>(c, mlp, dy, want_d_in || wide, load_input, first_op, n_ops);
     if (wide) {  // op 0 is a LINEAR with up to 128 inputs: weight gradient only (its input needs no gradient)
         const PmtOp& o = mlp.ops[0];
         const PmtLinear& L = M->lin[uniform(o.lin[0])];
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_backward_kernel(
             f4 y[PMT_RT][PMT_NT];
             const int b_pvec = uniform(L.b_pvec);
             init_bias<PMT_NT>(y, b_pvec >= 0 ? packed + b_pvec : nullptr, uniform(L.out_dim), g);
-            linear_acc<ROWS_NTIN, PMT_NT, false>(y, xin, packed + uniform(L.w_frag), in_dim, uniform(L.out_dim), PMT_FULL_MASK);
+            linear_acc<ROWS_NTIN, PMT_NT, false>(y, xin, packed + uniform(L.w_frag), in_dim, uniform(L.out_dim));
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll

@@ -14,6 +14,14 @@ from tests.helpers import CASES, config_for, load_case
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["auto", "any"], autouse=True)
+def kernel_shape(request, monkeypatch):
+    """Every case runs twice: with the tile-exact kernel instance the library picks for the model (ShapeP0 for the P0
+    fixtures) and with the generic instance forced through PMT_SHAPE=any (read by the library at every launch)."""
+    if request.param == "any":
+        monkeypatch.setenv("PMT_SHAPE", "any")
+
+
 def build(name, sd):
     dev = torch.device("cuda")
     params = t0_params() if name.startswith("t0") else p0_params()

@@ -88,8 +88,10 @@ def test_group_planner():
     tiles = 0
     for g in range(plan.num_groups):
         r, a = ref[gs[g]:gs[g + 1]].sum(), alt[gs[g]:gs[g + 1]].sum()
-        t = (r + 15) // 16 + (a + 15) // 16
-        assert t <= L.GROUP_TILES and gs[g + 1] - gs[g] <= L.GROUP_MAX_SETS
+        tr, ta = (r + 15) // 16, (a + 15) // 16
+        t = tr + ta
+        # ref and alt tiles are dealt to disjoint waves, two tiles per wave
+        assert (tr + 1) // 2 + (ta + 1) // 2 <= L.GROUP_WAVES and gs[g + 1] - gs[g] <= L.GROUP_MAX_SETS
         assert plan.group_tile_base[g] == tiles
         tiles += t
     assert plan.total_tiles == tiles
