@@ -227,36 +227,49 @@ DEV void aux_push_scalar(BwdCtx& c, int enc, float v) {
 
 // ---- weight gradients ------------------------------------------------------------------------------------------------
 // dW (+ db) of one linear (SIDES = 1) or of a ref / alt pair applied to the two sides of the group (SIDES = 2).
-// dy: gradient w.r.t. the linear's output (rows of padding reads are zero), x: its input.  Every wave of the workgroup
-// must call it (two barriers per pass; one pass unless (NTO + NTI) * ntiles planes exceed the stage).
+// A WgradAcc holds this wave's blocks of dW in registers: init once, accumulate any number of exchange rounds (a
+// persistent kernel keeps it across workgroup iterations), emit once with global float atomics.
 template <int NTO, int NTI, int SIDES>
-DEV void wgrad_exchange(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, const f4 (&dy)[PMT_RT][NTO],
-                        const f4 (&x)[PMT_RT][NTI], float scale) {
-    if (c.dbg & 1) return;
+struct WgradAcc {
+    static constexpr int TPW = (SIDES * NTO * NTI + PMT_WAVES - 1) / PMT_WAVES;  // blocks per wave
+    f4 acc[TPW];
+    float bs[TPW];                              // bias partials (blocks with it == 0)
+    int t_side[TPW], t_ot[TPW], t_it[TPW];      // wave-uniform block coordinates; t_side < 0: no block
+    int h, out_dim, in_dim, out_v, nmt, nkt;
+    bool any[2];                                // a round with tiles on that side has been accumulated
+};
+
+template <int NTO, int NTI, int SIDES>
+DEV void wgrad_init(WgradAcc<NTO, NTI, SIDES>& a, const PmtLinear& L0) {
+    const int wave = uniform((int)(threadIdx.x >> 6));
+    a.h = uniform(L0.out_split); a.out_dim = uniform(L0.out_dim); a.in_dim = uniform(L0.in_dim);
+    a.out_v = a.h > 0 ? 16 + a.h : a.out_dim;
+    a.nmt = (a.out_v + 15) >> 4; a.nkt = (a.in_dim + 15) >> 4;
+    const int per_side = a.nmt * a.nkt, ntask = SIDES * per_side;
+    a.any[0] = a.any[1] = false;
+#pragma unroll
+    for (int k = 0; k < a.TPW; ++k) {
+        a.acc[k] = f4{0.f, 0.f, 0.f, 0.f};
+        a.bs[k] = 0.f;
+        const int q = wave + PMT_WAVES * k;
+        a.t_side[k] = (SIDES == 2 && q >= per_side) ? 1 : 0;
+        const int rem = q - a.t_side[k] * per_side;
+        a.t_ot[k] = rem / a.nkt;
+        a.t_it[k] = rem - a.t_ot[k] * a.nkt;
+        if (q >= ntask) a.t_side[k] = -1;
+    }
+}
+
+// One exchange: dy = gradient w.r.t. the linear's output (rows of padding reads are zero), x = its input, for the
+// tiles of this wave.  Every wave of the workgroup must call it (two barriers per pass; one pass unless
+// (NTO + NTI) * c.ntiles planes exceed the stage).
+template <int NTO, int NTI, int SIDES>
+DEV void wgrad_accumulate(WgradAcc<NTO, NTI, SIDES>& a, BwdCtx& c, const f4 (&dy)[PMT_RT][NTO], const f4 (&x)[PMT_RT][NTI]) {
     constexpr int P = NTO + NTI;
     constexpr int TP = (PMT_STAGE_PLANES / P) < PMT_GROUP_TILES ? (PMT_STAGE_PLANES / P) : PMT_GROUP_TILES;
-    constexpr int TPW = (SIDES * NTO * NTI + PMT_WAVES - 1) / PMT_WAVES;
     static_assert(TP >= 1, "stage too small");
-    const int lane = threadIdx.x & 63, wave = uniform((int)(threadIdx.x >> 6)), g = lane >> 4;
-    const int h = uniform(L0.out_split), out_dim = uniform(L0.out_dim), in_dim = uniform(L0.in_dim);
-    const int out_v = h > 0 ? 16 + h : out_dim;
-    const int nmt = (out_v + 15) >> 4, nkt = (in_dim + 15) >> 4;
-    const int per_side = nmt * nkt, ntask = SIDES * per_side;
-    f4 acc[TPW];
-    float bs[TPW];
-    int t_side[TPW], t_ot[TPW], t_it[TPW];
-#pragma unroll
-    for (int k = 0; k < TPW; ++k) {
-        acc[k] = f4{0.f, 0.f, 0.f, 0.f};
-        bs[k] = 0.f;
-        const int q = wave + PMT_WAVES * k;
-        t_side[k] = (SIDES == 2 && q >= per_side) ? 1 : 0;
-        const int rem = q - t_side[k] * per_side;
-        t_ot[k] = rem / nkt;
-        t_it[k] = rem - t_ot[k] * nkt;
-        if (q >= ntask) t_side[k] = -1;
-    }
-    unsigned long long t0c = prof_now();
+    const int lane = threadIdx.x & 63;
+    if (SIDES == 2) { a.any[0] |= c.tiles_ref > 0; a.any[1] |= c.ntiles > c.tiles_ref; } else { a.any[0] |= c.ntiles > 0; }
     for (int t0 = 0; t0 < c.ntiles; t0 += TP) {
         __syncthreads();  // the stage (and the slabs) of the previous round have been consumed
         if (t0 == 0) aux_reduce(c);
@@ -267,53 +280,69 @@ DEV void wgrad_exchange(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, con
                 f4* pl = c.stage + (size_t)(tau * P) * 64 + lane;
 #pragma unroll
                 for (int ot = 0; ot < NTO; ++ot)
-                    if (ot < nmt) pl[ot * 64] = transpose_tile(dy[rt][ot]);
+                    if (ot < a.nmt) pl[ot * 64] = transpose_tile(dy[rt][ot]);
 #pragma unroll
                 for (int it = 0; it < NTI; ++it)
-                    if (it < nkt) pl[(NTO + it) * 64] = transpose_tile(x[rt][it]);
+                    if (it < a.nkt) pl[(NTO + it) * 64] = transpose_tile(x[rt][it]);
             }
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < TPW; ++k) {
-            if (t_side[k] < 0) continue;
-            int lo = (SIDES == 2 && t_side[k] == 1) ? c.tiles_ref : 0;
-            int hi = (SIDES == 2 && t_side[k] == 0) ? c.tiles_ref : c.ntiles;
+        for (int k = 0; k < a.TPW; ++k) {
+            if (a.t_side[k] < 0) continue;
+            int lo = (SIDES == 2 && a.t_side[k] == 1) ? c.tiles_ref : 0;
+            int hi = (SIDES == 2 && a.t_side[k] == 0) ? c.tiles_ref : c.ntiles;
             lo = max(lo, t0) - t0;
             hi = min(hi, t0 + TP) - t0;
-            const f4* pa = c.stage + (size_t)t_ot[k] * 64 + lane;
-            const f4* pb = c.stage + (size_t)(NTO + t_it[k]) * 64 + lane;
-            const bool with_bias = t_it[k] == 0;
+            const f4* pa = c.stage + (size_t)a.t_ot[k] * 64 + lane;
+            const f4* pb = c.stage + (size_t)(NTO + a.t_it[k]) * 64 + lane;
+            const bool with_bias = a.t_it[k] == 0;
             for (int tau = lo; tau < hi; ++tau) {
-                const f4 a = pa[tau * P * 64], b = pb[tau * P * 64];
+                const f4 va = pa[tau * P * 64], vb = pb[tau * P * 64];
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) acc[k] = mfma16(a[ks], b[ks], acc[k]);
-                if (with_bias) bs[k] += (a[0] + a[1]) + (a[2] + a[3]);
+                for (int ks = 0; ks < 4; ++ks) a.acc[k] = mfma16(va[ks], vb[ks], a.acc[k]);
+                if (with_bias) a.bs[k] += (va[0] + va[1]) + (va[2] + va[3]);
             }
         }
     }
+}
+
+template <int NTO, int NTI, int SIDES>
+DEV void wgrad_emit(WgradAcc<NTO, NTI, SIDES>& a, BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, float scale) {
+    const int lane = threadIdx.x & 63, g = lane >> 4;
+#pragma unroll
+    for (int k = 0; k < a.TPW; ++k) {
+        if (a.t_side[k] < 0) continue;
+        const bool side1 = SIDES == 2 && a.t_side[k] == 1;
+        if (!a.any[side1 ? 1 : 0]) continue;
+        const PmtLinear& L = side1 ? L1 : L0;
+        float* gw = grad_ptr(uniform(L.w_src), c.gtheta, c.gphi);
+        const int col = pos_to_feat(16 * a.t_it[k] + (lane & 15));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pf = feat_of(a.t_ot[k], j, g), o = split_row_dev(pf, a.h);
+            if (o >= 0 && o < a.out_dim && pf < a.out_v && col < a.in_dim) atomicAdd(&gw[(size_t)o * a.in_dim + col], scale * a.acc[k][j]);
+        }
+        if (a.t_it[k] == 0 && uniform(L.b_src) != -1) {
+            const float tot = group_sum(a.bs[k]);  // lanes (m, *) now hold the sum over all reads for output position m
+            const int pf = pos_to_feat(16 * a.t_ot[k] + (lane & 15)), o = split_row_dev(pf, a.h);
+            if (g == 0 && o >= 0 && o < a.out_dim && pf < a.out_v) atomicAdd(&grad_ptr(uniform(L.b_src), c.gtheta, c.gphi)[o], scale * tot);
+        }
+    }
+}
+
+template <int NTO, int NTI, int SIDES>
+DEV void wgrad_exchange(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, const f4 (&dy)[PMT_RT][NTO],
+                        const f4 (&x)[PMT_RT][NTI], float scale) {
+    if (c.dbg & 1) return;
+    WgradAcc<NTO, NTI, SIDES> a;
+    wgrad_init(a, L0);
+    unsigned long long t0c = prof_now();
+    wgrad_accumulate(a, c, dy, x);
     prof_add(c, 0, t0c);
     if (c.dbg & 2) return;
     t0c = prof_now();
-#pragma unroll
-    for (int k = 0; k < TPW; ++k) {
-        if (t_side[k] < 0) continue;
-        const bool side1 = SIDES == 2 && t_side[k] == 1;
-        if ((side1 ? c.ntiles - c.tiles_ref : (SIDES == 2 ? c.tiles_ref : c.ntiles)) <= 0) continue;
-        const PmtLinear& L = side1 ? L1 : L0;
-        float* gw = grad_ptr(uniform(L.w_src), c.gtheta, c.gphi);
-        const int col = pos_to_feat(16 * t_it[k] + (lane & 15));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int pf = feat_of(t_ot[k], j, g), o = split_row_dev(pf, h);
-            if (o >= 0 && o < out_dim && pf < out_v && col < in_dim) atomicAdd(&gw[(size_t)o * in_dim + col], scale * acc[k][j]);
-        }
-        if (t_it[k] == 0 && uniform(L.b_src) != -1) {
-            const float tot = group_sum(bs[k]);  // lanes (m, *) now hold the sum over all reads for output position m
-            const int pf = pos_to_feat(16 * t_ot[k] + (lane & 15)), o = split_row_dev(pf, h);
-            if (g == 0 && o >= 0 && o < out_dim && pf < out_v) atomicAdd(&grad_ptr(uniform(L.b_src), c.gtheta, c.gphi)[o], scale * tot);
-        }
-    }
+    wgrad_emit(a, c, L0, L1, scale);
     prof_add(c, 2, t0c);
 }
 

@@ -279,7 +279,9 @@ extern "C" __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn_backward_ke
                         if (val > m) { m = val; arg = s; }
                     }
                 }
-                atomicAdd(&gin[v * ma + ch * L.in_len + arg], gout[v * ma + rem]);
+                float* dst = &gin[v * ma + ch * L.in_len + arg];
+                if (L.stride >= L.kernel) *dst = gout[v * ma + rem];  // disjoint windows: one writer per input element
+                else atomicAdd(dst, gout[v * ma + rem]);
             }
         } else if (kind == PMT_CNN_LINEAR) {
             const float* W = theta + L.w_src;
