@@ -396,8 +396,8 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             const float n_ref = (float)(sh.off[0][set + 1] - sh.off[0][set]);
             const float n_alt = (float)(sh.off[1][set + 1] - sh.off[1][set]);
             const float* zs = zsum_stash + ((size_t)(gg.v0 + set) * L + l) * 32;
-            m_ref = (*reinterpret_cast<const f4*>(zs + 4 * g) + w * rho) / (n_ref + w);
-            m_alt = *reinterpret_cast<const f4*>(zs + 16 + 4 * g) / (n_alt + 1e-4f);
+            m_ref = (*reinterpret_cast<const f4*>(zs + 4 * g) + w * rho) * fast_rcp(n_ref + w);
+            m_alt = *reinterpret_cast<const f4*>(zs + 16 + 4 * g) * fast_rcp(n_alt + 1e-4f);
             z2_out = z2hat_rt * sw + sb;
             const f4 gt = z2_out * alpha + 1.0f;
             return side == 0 ? gt + beta * m_ref : (gt + beta * m_alt) + gamma * m_ref;

@@ -63,7 +63,8 @@ DEV void layernorm_bwd_tile(f4 (&dx)[NT], const f4 (&dyv)[NT], const f4 (&xhat)[
                 }
         }
     }
-    const float m1 = group_sum(s1) / (float)dim, m2 = group_sum(s2) / (float)dim;
+    const float inv_dim = fast_rcp((float)dim);
+    const float m1 = group_sum(s1) * inv_dim, m2 = group_sum(s2) * inv_dim;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -79,7 +80,8 @@ DEV void layernorm_stats_tile(f4 (&xhat)[NT], float& rstd, const f4 (&x)[NT], in
 #pragma unroll
     for (int t = 0; t < NT; ++t)
         if (t < nt) s += (x[t][0] + x[t][1]) + (x[t][2] + x[t][3]);
-    const float mean = group_sum(s) / (float)dim;
+    const float inv_dim = fast_rcp((float)dim);
+    const float mean = group_sum(s) * inv_dim;
     float q = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -89,7 +91,7 @@ DEV void layernorm_stats_tile(f4 (&xhat)[NT], float& rstd, const f4 (&x)[NT], in
             xhat[t][j] = d;
             q += d * d;
         }
-    rstd = rsqrtf(group_sum(q) / (float)dim + PMT_LN_EPS);
+    rstd = __builtin_amdgcn_rsqf(group_sum(q) * inv_dim + PMT_LN_EPS);
 #pragma unroll
     for (int t = 0; t < NT; ++t) xhat[t] = xhat[t] * rstd;
 }
@@ -113,7 +115,8 @@ DEV void layernorm_bwd_inplace_tile(f4 (&acc)[NT], const f4 (&dyv)[NT], const f4
                     s2 += d * xhat[t][j];
                 }
         }
-    const float m1 = group_sum(s1) / (float)dim, m2 = group_sum(s2) / (float)dim;
+    const float inv_dim = fast_rcp((float)dim);
+    const float m1 = group_sum(s1) * inv_dim, m2 = group_sum(s2) * inv_dim;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll

@@ -217,13 +217,13 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_forward_kernel(const PmtMo
                 const float n_ref = (float)(sh.off[0][set + 1] - sh.off[0][set]);
                 const float n_alt = (float)(sh.off[1][set + 1] - sh.off[1][set]);
                 const f4 s_ref = *reinterpret_cast<const f4*>(&sh.zsum[buf][set][0][4 * g]);
-                const f4 m_ref = (s_ref + w * rho) / (n_ref + w);
+                const f4 m_ref = (s_ref + w * rho) * fast_rcp(n_ref + w);
                 f4 gate = z[rt][1] * alpha + 1.0f;
                 if (side == 0) {
                     gate = gate + beta * m_ref;
                 } else {
                     const f4 s_alt = *reinterpret_cast<const f4*>(&sh.zsum[buf][set][1][4 * g]);
-                    const f4 m_alt = s_alt / (n_alt + 1e-4f);
+                    const f4 m_alt = s_alt * fast_rcp(n_alt + 1e-4f);
                     gate = (gate + beta * m_alt) + gamma * m_ref;
                 }
                 u[rt][0] = z[rt][0] * gate;
@@ -286,16 +286,18 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_forward_kernel(const PmtMo
     const int nte = (E + 15) >> 4;
     {
         const float* hp = phi;  // head parameters live in phi (materialised parametrizations), mu in theta
-        f4 sig[NTE];
+        f4 sig[NTE], isig[NTE];
         float sum_log_sig = 0.f, sum_log_2sig = 0.f;
 #pragma unroll
         for (int t = 0; t < NTE; ++t) {
             sig[t] = f4{1.f, 1.f, 1.f, 1.f};
+            isig[t] = f4{1.f, 1.f, 1.f, 1.f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int f = feat_of(t, j, g);
                 if (t < nte && f < E) {
                     sig[t][j] = hp[uniform(M->head.stdev_e_phi) + f];
+                    isig[t][j] = 1.0f / sig[t][j];
                     sum_log_sig += logf(sig[t][j]);
                     sum_log_2sig += logf(2.f * sig[t][j]);
                 }
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_forward_kernel(const PmtMo
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (t < nte && feat_of(t, j, g) < E) {
-                        const float r0 = a[rt][t][j] / sig[t][j], r1 = a[rt][t][j] / (2.f * sig[t][j]);
+                        const float r0 = a[rt][t][j] * isig[t][j], r1 = 0.5f * r0;
                         q0 += r0 * r0;
                         q1 += r1 * r1;
                     }
