@@ -59,7 +59,7 @@ template <typename S>
 __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
     const PmtModel* __restrict__ M, const float* __restrict__ theta, const float* __restrict__ phi,
     const float* __restrict__ packed, PmtBatch bt, PmtOutputs out, PmtOutputGrads dout, const float* __restrict__ stash,
-    const float* __restrict__ zsum_stash, float* __restrict__ gtheta, float* __restrict__ gphi,
+    const float* __restrict__ zsum_stash, const float* __restrict__ rstd_stash, float* __restrict__ gtheta, float* __restrict__ gphi,
     float* __restrict__ gvar) {
     constexpr int NTF = S::NTF, NTR = S::NTR, NTD = S::NTD, NTE = S::NTE;
     constexpr bool EX = S::EXACT;
@@ -348,8 +348,9 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
     // ---- gated blocks backward -----------------------------------------------------------------------------------------
     for (int l = (c.dbg & 4) ? -1 : L - 1; l >= 0; --l) {
         // Register discipline (this loop body used to spill thousands of VGPRs): nothing of width D except the running
-        // gradient dy stays live across phases.  x_l is re-read from the stash (L2/HBM, 4 KB per tile) and its LayerNorm
-        // recomputed each of the three times it is needed; z2 / gate are recomputed from z2hat.
+        // gradient dy stays live across phases.  xhat_l = the normalised x_l (stashed by the forward together with one
+        // rstd per read) is re-read from the stash (L2/HBM, 4 KB per tile) each of the three times it is needed; z2 / gate
+        // are recomputed from z2hat.
         const PmtBlock& B = M->blocks[l];
         const PmtLinear& P1 = M->lin[uniform(B.proj1[side])];
         const PmtLinear& P2 = M->lin[uniform(B.proj2[side])];
@@ -358,19 +359,19 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         const float* xs[PMT_RT];
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt) xs[rt] = stash_tile[rt] + (slot_x0 + l) * PMT_SLOT_FLOATS;
-        // n[rt] = LayerNorm_D(x_l[rt]) for every tile of this wave (absent tiles: zeros in, finite out)
+        // n[rt] = LayerNorm_D(x_l[rt]) = xhat * w + b for every tile of this wave (absent tiles: xhat = 0)
         auto recompute_n = [&](f4 (&n)[PMT_RT][NTD]) {
-            f4 lw[NTD], lb[NTD];
-#pragma unroll
-            for (int t = 0; t < NTD; ++t) { lw[t] = load_pvec(lw_p, t, g); lb[t] = load_pvec(lb_p, t, g); }
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) {
-                f4 xr[NTD], xh[NTD];
-                float rs;
 #pragma unroll
-                for (int t = 0; t < NTD; ++t) xr[t] = f4{0.f, 0.f, 0.f, 0.f};
-                if (mask_all & (1u << rt)) stash_load<NTD>(xs[rt], xr);
-                layernorm_tile<NTD>(n[rt], xh, rs, xr, D, lw, lb, g);
+                for (int t = 0; t < NTD; ++t) n[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
+                if (mask_all & (1u << rt)) stash_load<NTD>(xs[rt], n[rt]);
+            }
+#pragma unroll
+            for (int t = 0; t < NTD; ++t) {
+                const f4 lw = load_pvec(lw_p, t, g), lb = load_pvec(lb_p, t, g);
+#pragma unroll
+                for (int rt = 0; rt < PMT_RT; ++rt) n[rt][t] = n[rt][t] * lw + lb;
             }
         };
         t_ph = prof_now();
@@ -440,37 +441,35 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             // proj2 weight gradients of both sides in one exchange round
             wgrad_exchange<NTD, 1, 2>(c, M->lin[uniform(B.proj2[0])], M->lin[uniform(B.proj2[1])], dy, u, 1.0f);
         }
-        __syncthreads();  // gsum complete
+        if (c.dbg & 1) __syncthreads();  // (the exchange's barriers, skipped by that switch, complete gsum)
         prof_add(c, 10, t_ph);
         t_ph = prof_now();
         // per-set coupling: d(m_ref), d(m_alt), d(ref_regularizer), d(reg_weight)
-        for (int i = tid; i < gg.nsets * 16; i += PMT_THREADS) {
-            const int set = i >> 4, p = i & 15;
-            const float n_ref = (float)(sh.off[0][set + 1] - sh.off[0][set]);
-            const float n_alt = (float)(sh.off[1][set + 1] - sh.off[1][set]);
-            const float gr = sh.gsum[set][0][p], ga = sh.gsum[set][1][p];
-            const float dm_ref = beta_ref * gr + gamma * ga, dm_alt = beta_alt * ga;
-            sh.dmean[set][0][p] = dm_ref / (n_ref + w);
-            sh.dmean[set][1][p] = dm_alt / (n_alt + 1e-4f);
-        }
-        if (wave == 0) {  // d(ref_regularizer), d(reg_weight): summed over the sets of the group, one atomic per element
+        // One thread per (set, position); a wave covers 4 sets x 16 positions per pass.  d(ref_regularizer) and
+        // d(reg_weight) are sums over the sets: summed over the passes per lane, over the 4 sets of a pass across the
+        // lane groups, over the waves and into global memory through the small-parameter slab.
+        {
             const int p = lane & 15, f = pos_to_feat(p);
+            const float rho_f = f < h ? theta[B.ref_reg_src + f] : 0.f;
             float a_rho = 0.f, a_w = 0.f;
-            if (f < h && !(c.dbg & 16)) {
-                const float rho_f = theta[B.ref_reg_src + f];
-                for (int set = g; set < gg.nsets; set += 4) {
-                    const float n_ref = (float)(sh.off[0][set + 1] - sh.off[0][set]);
-                    const float dm_ref = beta_ref * sh.gsum[set][0][p] + gamma * sh.gsum[set][1][p];
-                    const float* zs = zsum_stash + ((size_t)(gg.v0 + set) * L + l) * 32;
-                    const float m_ref = (zs[p] + w * rho_f) / (n_ref + w);
-                    a_rho += dm_ref * w / (n_ref + w);
-                    a_w += dm_ref * (rho_f - m_ref) / (n_ref + w);
+            for (int i = tid; i < gg.nsets * 16; i += PMT_THREADS) {
+                const int set = i >> 4;
+                const float n_ref = (float)(sh.off[0][set + 1] - sh.off[0][set]);
+                const float n_alt = (float)(sh.off[1][set + 1] - sh.off[1][set]);
+                const float gr = sh.gsum[set][0][p], ga = sh.gsum[set][1][p];
+                const float dm_ref = beta_ref * gr + gamma * ga, dm_alt = beta_alt * ga;
+                const float inv_ref = fast_rcp(n_ref + w);
+                sh.dmean[set][0][p] = dm_ref * inv_ref;
+                sh.dmean[set][1][p] = dm_alt * fast_rcp(n_alt + 1e-4f);
+                if (f < h) {
+                    const float zs = zsum_stash[((size_t)(gg.v0 + set) * L + l) * 32 + p];
+                    const float m_ref = (zs + w * rho_f) * inv_ref;
+                    a_rho += dm_ref * w * inv_ref;
+                    a_w += dm_ref * (rho_f - m_ref) * inv_ref;
                 }
             }
-            a_rho = group_sum(a_rho);
-            a_w = wave_sum(a_w);
-            if (g == 0 && f < h) atomicAdd(&gtheta[B.ref_reg_src + f], a_rho);
-            if (lane == 0) atomicAdd(&gphi[B.reg_weight_phi], a_w);
+            aux_push_row16(c, uniform(B.ref_reg_src), group_sum(a_rho), h);
+            aux_push_scalar(c, enc_phi(uniform(B.reg_weight_phi)), a_w);
         }
         __syncthreads();
         for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS) (&sh.gsum[0][0][0])[i] = 0.f;
@@ -529,13 +528,12 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
                 // one tile at a time (the scheduling barrier keeps the compiler from interleaving the tiles' temporaries)
                 __builtin_amdgcn_sched_barrier(0);
                 f4 xh[NTD];
-                float rs;
-                {
-                    f4 xr[NTD];
+                float rs = 0.f;
 #pragma unroll
-                    for (int t = 0; t < NTD; ++t) xr[t] = f4{0.f, 0.f, 0.f, 0.f};
-                    if (mask_all & (1u << rt)) stash_load<NTD>(xs[rt], xr);
-                    layernorm_stats_tile<NTD>(xh, rs, xr, D, g);
+                for (int t = 0; t < NTD; ++t) xh[t] = f4{0.f, 0.f, 0.f, 0.f};
+                if (mask_all & (1u << rt)) {
+                    stash_load<NTD>(xs[rt], xh);
+                    rs = rstd_stash[((size_t)(bt.group_tile_base[blockIdx.x] + gg.tile_begin + rt) * L + l) * 16 + (lane & 15)];
                 }
                 layernorm_bwd_inplace_tile<NTD>(dy[rt], dn[rt], xh, rs, D, lw, dlw, dlb, g);
             }
@@ -619,8 +617,9 @@ extern "C" int pmt_backward(const PmtModel* model_host, const PmtModel* model_de
         batch->total_tiles <= 0 || !out->logits_b || !out->logits_bk)
         return PMT_E_INVALID;
     const float* zsum_stash = stash + (size_t)batch->total_tiles * (size_t)pmt_stash_slots(model_host) * PMT_SLOT_FLOATS;
+    const float* rstd_stash = zsum_stash + (size_t)batch->num_variants * (size_t)(model_host->num_blocks > 0 ? model_host->num_blocks : 1) * 32;
     auto kernel = pmt_shape_id(model_host) == 1 ? pmt_backward_kernel<ShapeP0> : pmt_backward_kernel<ShapeAny>;
     hipLaunchKernelGGL(kernel, dim3(batch->num_groups), dim3(PMT_THREADS), 0, reinterpret_cast<hipStream_t>(stream), model_dev,
-                       theta, phi, packed, *batch, *out, *dout, stash, zsum_stash, grad_theta, grad_phi, grad_variant_embed);
+                       theta, phi, packed, *batch, *out, *dout, stash, zsum_stash, rstd_stash, grad_theta, grad_phi, grad_variant_embed);
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }

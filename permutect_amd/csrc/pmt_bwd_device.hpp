@@ -217,6 +217,18 @@ DEV void aux_push_vec(BwdCtx& c, int enc, const f4 (&v)[NT], int dim) {
         }
     c.aux_n += 16 * nt;
 }
+// one 16-position row (tile 0) whose per-position totals already sit in every lane group: lane (g, p) holds position p
+DEV void aux_push_row16(BwdCtx& c, int enc, float v, int dim) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (c.aux_n + 16 > PMT_AUX_CAP) aux_flush(c);
+    if (c.dbg & 16) return;
+    if (lane < 16) {
+        const int f = pos_to_feat(lane);
+        c.aux[wave * PMT_AUX_CAP + c.aux_n + lane] = v;
+        if (wave == 0) c.aux_dst[c.aux_n + lane] = f < dim ? enc_at(enc, f) : -1;
+    }
+    c.aux_n += 16;
+}
 DEV void aux_push_scalar(BwdCtx& c, int enc, float v) {
     if (c.aux_n + 1 > PMT_AUX_CAP) aux_flush(c);
     if (c.dbg & 16) return;

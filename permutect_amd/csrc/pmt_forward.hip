@@ -51,7 +51,8 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_forward_kernel(const PmtMo
                                                                       const float* __restrict__ phi,
                                                                       const float* __restrict__ packed, PmtBatch bt,
                                                                       PmtOutputs out, float* __restrict__ stash,
-                                                                      float* __restrict__ zsum_stash) {
+                                                                      float* __restrict__ zsum_stash,
+                                                                      float* __restrict__ rstd_stash) {
     constexpr int NTF = S::NTF, NTR = S::NTR, NTD = S::NTD, NTE = S::NTE;
     constexpr bool EX = S::EXACT;
     static_assert(EX || (NTF == NTD && NTR == NTD && NTE == NTD), "the generic shape keeps one array width");
@@ -142,12 +143,6 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_forward_kernel(const PmtMo
     // ---- L gated ref/alt blocks; this wave's tiles all use the weights of its side ------------------------------
     for (int l = 0; l < L; ++l) {
         const PmtBlock& B = M->blocks[l];
-        if (TRAIN) {
-#pragma unroll
-            for (int rt = 0; rt < PMT_RT; ++rt)
-                if (mask_all & (1u << rt)) stash_store<NTD>(stash_tile[rt] + slot * PMT_SLOT_FLOATS, x[rt]);
-            ++slot;
-        }
         f4 z[PMT_RT][2];
         // staging region A of this block: [W1_ref | W1_alt | b1_ref | b1_alt | LN(D) w,b | LN(h) w,b | rho] -- everything
         // the first half of the block reads comes out of LDS; no vector-memory load sits behind the in-flight DMA.
@@ -171,7 +166,14 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_forward_kernel(const PmtMo
                 f4 xhat[NTD];
                 float rstd;
                 layernorm_tile<NTD>(n[rt], xhat, rstd, x[rt], D, lw, lb, g);
+                // the backward needs x_l only through its LayerNorm: stash xhat (same bytes as x_l) + one rstd per read
+                if (TRAIN && (mask_all & (1u << rt))) {
+                    stash_store<NTD>(stash_tile[rt] + slot * PMT_SLOT_FLOATS, xhat);
+                    if (g == 0)
+                        rstd_stash[((size_t)(bt.group_tile_base[blockIdx.x] + gg.tile_begin + rt) * L + l) * 16 + (lane & 15)] = rstd;
+                }
             }
+            if (TRAIN) ++slot;
             const float* bp = stA + (uniform(M->lin[uniform(B.proj1[side])].b_pvec) - baseA);
             const f4 b0 = load_pvec(bp, 0, g), b1 = load_pvec(bp, 1, g);
 #pragma unroll
@@ -423,14 +425,16 @@ extern "C" int pmt_forward(const PmtModel* model_host, const PmtModel* model_dev
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool p0 = pmt_shape_id(model_host) == 1;  // tile-exact instance (pmt_device.hpp: ShapeP0) or the generic one
     float* zsum_stash = nullptr;
+    float* rstd_stash = nullptr;
     if (stash) {
         if (!batch->group_tile_base || batch->total_tiles <= 0) return PMT_E_INVALID;
         // per-set z2 sums follow the per-tile activation slots (layout: pmt_stash_bytes)
         zsum_stash = stash + (size_t)batch->total_tiles * (size_t)pmt_stash_slots(model_host) * PMT_SLOT_FLOATS;
+        rstd_stash = zsum_stash + (size_t)batch->num_variants * (size_t)(model_host->num_blocks > 0 ? model_host->num_blocks : 1) * 32;
     }
     auto kernel = stash ? (p0 ? pmt_forward_kernel<true, ShapeP0> : pmt_forward_kernel<true, ShapeAny>)
                         : (p0 ? pmt_forward_kernel<false, ShapeP0> : pmt_forward_kernel<false, ShapeAny>);
     hipLaunchKernelGGL(kernel, dim3(batch->num_groups), dim3(PMT_THREADS), 0, s, model_dev, theta, phi, packed, *batch, *out,
-                       stash, zsum_stash);
+                       stash, zsum_stash, rstd_stash);
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }

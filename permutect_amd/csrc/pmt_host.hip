@@ -284,8 +284,10 @@ extern "C" int pmt_plan_groups(const int32_t* ref_counts, const int32_t* alt_cou
 extern "C" size_t pmt_stash_bytes(const PmtModel* m, int64_t total_tiles, int32_t num_variants) {
     if (!m) return 0;
     const size_t tile_part = (size_t)total_tiles * (size_t)pmt_stash_slots(m) * PMT_SLOT_FLOATS;
-    const size_t zsum_part = (size_t)num_variants * (size_t)(m->num_blocks > 0 ? m->num_blocks : 1) * 32;
-    return (tile_part + zsum_part) * sizeof(float);
+    const size_t nb = (size_t)(m->num_blocks > 0 ? m->num_blocks : 1);
+    const size_t zsum_part = (size_t)num_variants * nb * 32;   // per-set z2 sums of every block
+    const size_t rstd_part = (size_t)total_tiles * nb * 16;    // LayerNorm(D) rstd of every read of every block
+    return (tile_part + zsum_part + rstd_part) * sizeof(float);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
