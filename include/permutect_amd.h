@@ -234,6 +234,37 @@ int pmt_struct_bytes(int which);
 /* Validates a descriptor against the kernels' limits. */
 int pmt_model_check(const PmtModel* model);
 
+/* Materialised parametrizations ("phi"): the reference registers torch parametrizations on a few small tensors
+ * (reference architecture/feature_clustering.py:41-75, exponentially_modified_gaussian.py:66-75, gated_mlp.py:196-201,
+ * euclidean_transformation.py:14-16); one segment per tensor maps theta[theta_off ...] (the `.original` leaf) to
+ * phi[phi_off ...] (the value the kernels consume). */
+#define PMT_PHI_EXP 0           /* phi = exp(theta)                                        (PositiveNumber)          */
+#define PMT_PHI_BOUNDED 1       /* phi = p1 * sigmoid(theta) + p0                          (BoundedNumber)           */
+#define PMT_PHI_UNIT_ROWS 2     /* every row x of [rows][cols]: x / |x|                    (UnitVector)              */
+#define PMT_PHI_LOG_SOFTMAX 3   /* log_softmax of every row                                (LogWeights)              */
+#define PMT_PHI_ORTHOGONAL 4    /* base @ expm(tril(X) - tril(X)^T), X = theta [n][n]      (torch orthogonal, matrix_exp map,
+                                   use_trivialization; base == NULL means identity)                              */
+#define PMT_MAX_PHI_SEGS 48
+#define PMT_MAX_ORTHO_DIM 32
+typedef struct PmtPhiSeg {
+    int32_t kind, theta_off, phi_off, rows, cols, reserved;
+    float p0, p1;
+    int32_t base_rs, base_cs;   /* ORTHOGONAL: element strides of `base` (torch keeps it as a transposed view) */
+    const float* base;          /* ORTHOGONAL: device base matrix, base[i][k] = base[i * base_rs + k * base_cs] */
+} PmtPhiSeg;
+typedef struct PmtPhiProgram {
+    int32_t n_segs, reserved;
+    PmtPhiSeg seg[PMT_MAX_PHI_SEGS];
+} PmtPhiProgram;
+
+/* phi <- parametrizations(theta): one launch, one workgroup per segment.  Replaces the forward of
+ * torch.nn.utils.parametrize for the tensors above (~60 tiny launches per step through torch). */
+int pmt_phi_forward(const PmtPhiProgram* prog, const float* theta, float* phi, void* stream);
+/* grad_theta[segment's leaf] += J^T grad_phi: one launch.  Replaces autograd through the parametrizations (the adjoint of
+ * matrix_exp alone is ~100 launches through torch). */
+int pmt_phi_backward(const PmtPhiProgram* prog, const float* theta, const float* phi, const float* grad_phi,
+                     float* grad_theta, void* stream);
+
 /* Fills model->fwd_sched / bwd_sched from the rest of the descriptor (host, in place). */
 int pmt_build_schedules(PmtModel* model);
 

@@ -19,7 +19,7 @@ from permutect_amd.architecture import modules as M
 from permutect_amd.data.batch import Batch
 from permutect_amd.data.datum import Data
 from permutect_amd.engine import lib as L
-from permutect_amd.engine.runtime import HaplotypeCnnFunction, ReadSetEngine, ReadSetFunction, RowsMlpFunction
+from permutect_amd.engine.runtime import HaplotypeCnnFunction, PhiFunction, ReadSetEngine, ReadSetFunction, RowsMlpFunction
 from permutect_amd.enums import Epoch
 from permutect_amd.parameters import ModelParameters, install_pickle_alias
 
@@ -153,7 +153,8 @@ class ArtifactModel(nn.Module):
 
     def _encode(self, batch: Batch):
         eng = self.engine()
-        phi = eng.plan.materialize_phi(self)
+        prog = eng.plan.phi_program(self)
+        phi = eng.plan.materialize_phi(self) if prog is None else PhiFunction.apply(eng, prog, eng.trigger)
         eng.pack(phi.detach().contiguous())  # weights -> MFMA fragment order, once per forward, before any kernel uses them
         variant_embed = self.variant_embedding(batch)
         outs = ReadSetFunction.apply(eng, batch, phi, variant_embed)

@@ -20,6 +20,7 @@ extern "C" int pmt_struct_bytes(int which) {
         case 7: return (int)sizeof(PmtMlp);
         case 8: return (int)sizeof(PmtBlock);
         case 9: return (int)sizeof(PmtHead);
+        case 10: return (int)sizeof(PmtPhiProgram);
         default: return PMT_E_INVALID;
     }
 }

@@ -107,9 +107,23 @@ class PmtAdamW(C.Structure):
                 ("weight_decay", C.c_float), ("max_grad_norm", C.c_float), ("step", i32), ("reserved", i32)]
 
 
+PHI_EXP, PHI_BOUNDED, PHI_UNIT_ROWS, PHI_LOG_SOFTMAX, PHI_ORTHOGONAL = range(5)
+MAX_PHI_SEGS, MAX_ORTHO_DIM = 48, 32
+
+
+class PmtPhiSeg(C.Structure):
+    _fields_ = [("kind", i32), ("theta_off", i32), ("phi_off", i32), ("rows", i32), ("cols", i32), ("reserved", i32),
+                ("p0", C.c_float), ("p1", C.c_float), ("base_rs", i32), ("base_cs", i32), ("base", vp)]
+
+
+class PmtPhiProgram(C.Structure):
+    _fields_ = [("n_segs", i32), ("reserved", i32), ("seg", PmtPhiSeg * MAX_PHI_SEGS)]
+
+
 EXPORTS = ["pmt_abi_version", "pmt_struct_bytes", "pmt_model_check", "pmt_build_schedules", "pmt_plan_groups", "pmt_stash_bytes", "pmt_pack_params",
            "pmt_scan_counts", "pmt_forward", "pmt_backward", "pmt_clip_adamw",
-           "pmt_rows_stash_bytes", "pmt_rows_forward", "pmt_rows_backward", "pmt_cnn_forward", "pmt_cnn_backward"]
+           "pmt_rows_stash_bytes", "pmt_rows_forward", "pmt_rows_backward", "pmt_cnn_forward", "pmt_cnn_backward",
+           "pmt_phi_forward", "pmt_phi_backward"]
 
 _lib = None
 
@@ -151,6 +165,8 @@ def load() -> C.CDLL:
     lib.pmt_rows_stash_bytes.restype = C.c_size_t
     lib.pmt_rows_forward.argtypes = [P(PmtModel), vp, i32, vp, vp, vp, i64, i32, vp, i64, vp, vp]
     lib.pmt_rows_backward.argtypes = [P(PmtModel), vp, i32, vp, vp, vp, i64, i32, vp, i64, vp, vp, vp, i64, C.c_float, vp]
+    lib.pmt_phi_forward.argtypes = [P(PmtPhiProgram), vp, vp, vp]
+    lib.pmt_phi_backward.argtypes = [P(PmtPhiProgram), vp, vp, vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("pmt_abi_version", "pmt_stash_bytes", "pmt_rows_stash_bytes"):
@@ -159,7 +175,7 @@ def load() -> C.CDLL:
     if lib.pmt_abi_version() != ABI_VERSION:
         raise PmtError("libpermutect_amd.so ABI version mismatch; rebuild it")
     for which, st in enumerate([PmtModel, PmtBatch, PmtOutputs, PmtOutputGrads, PmtAdamW, PmtLinear, PmtOp, PmtMlp,
-                                PmtBlock, PmtHead]):
+                                PmtBlock, PmtHead, PmtPhiProgram]):
         if lib.pmt_struct_bytes(which) != C.sizeof(st):
             raise PmtError(f"ctypes layout of {st.__name__} ({C.sizeof(st)} B) does not match the library "
                            f"({lib.pmt_struct_bytes(which)} B)")

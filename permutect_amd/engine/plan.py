@@ -71,6 +71,7 @@ class EnginePlan:
         self._packed_off = 0
         self._n_lin = 0
         self._phi_off = 0
+        self._phi_prog = None
         self.phi_layout: List[tuple] = []  # (name, offset, numel)
 
         read_mlp: M.MLP = model.read_embedding
@@ -301,8 +302,53 @@ class EnginePlan:
         dst.max_act, dst.sum_act = max_act, off
 
     # ---- phi ------------------------------------------------------------------------------------------------------
+    def phi_program(self, model):
+        """The PmtPhiProgram evaluating every parametrization on the device (pmt_phi_forward / _backward), or None when
+        the model has a parametrization the kernels do not cover (orthogonal matrices wider than MAX_ORTHO_DIM): the torch
+        evaluation `materialize_phi` is then used instead.  Built once; the base-matrix pointer is refreshed per call."""
+        tr, fc, space = model.pre_clustering_transform, model.feature_clustering, self.space
+        e = self.desc.feature_dim
+        if e > L.MAX_ORTHO_DIM:
+            return None
+        if self._phi_prog is None:
+            offs = {name: off for name, off, _ in self.phi_layout}
+            prog = L.PmtPhiProgram()
+            segs = []
+
+            def original(mod, name):
+                return space.offset_of(getattr(mod.parametrizations, name).original)
+
+            def bounded(mod, name):
+                p = getattr(mod.parametrizations, name)[0]
+                return float(p.min_val), float(p.size)
+
+            for i, blk in enumerate(model.ref_alt_reads_encoder.blocks):
+                segs.append((L.PHI_EXP, original(blk.sgu, "reg_weight"), offs[f"reg_weight.{i}"], 1, 1, 0.0, 0.0))
+            segs.append((L.PHI_ORTHOGONAL, original(tr.rotation_ee, "weight"), offs["rotation"], e, e, 0.0, 0.0))
+            k = self.desc.num_clusters
+            segs.append((L.PHI_BOUNDED, original(fc, "nonartifact_stdev_e"), offs["stdev_e"], 1, e) + bounded(fc, "nonartifact_stdev_e"))
+            segs.append((L.PHI_UNIT_ROWS, original(fc, "artifact_directions_ke"), offs["dirs_ke"], k, e, 0.0, 0.0))
+            segs.append((L.PHI_BOUNDED, original(fc, "artifact_stdev_k"), offs["art_stdev_k"], 1, k) + bounded(fc, "artifact_stdev_k"))
+            segs.append((L.PHI_LOG_SOFTMAX, original(fc, "log_cluster_weights_k"), offs["log_w_k"], 1, k, 0.0, 0.0))
+            segs.append((L.PHI_BOUNDED, original(fc.artifact_emg, "sigma_k"), offs["sigma_k"], 1, k) + bounded(fc.artifact_emg, "sigma_k"))
+            segs.append((L.PHI_BOUNDED, original(fc.artifact_emg, "lambda_k"), offs["lambda_k"], 1, k) + bounded(fc.artifact_emg, "lambda_k"))
+            assert len(segs) <= L.MAX_PHI_SEGS
+            prog.n_segs = len(segs)
+            for sg, (kind, toff, poff, rows, cols, p0, p1) in zip(prog.seg, segs):
+                sg.kind, sg.theta_off, sg.phi_off, sg.rows, sg.cols, sg.p0, sg.p1 = kind, toff, poff, rows, cols, p0, p1
+            self._phi_prog = prog
+            self._phi_rot_index = len(model.ref_alt_reads_encoder.blocks)
+        base = getattr(tr.rotation_ee.parametrizations.weight[0], "base", None)
+        sg = self._phi_prog.seg[self._phi_rot_index]
+        if base is None:
+            sg.base, sg.base_rs, sg.base_cs = None, 0, 0
+        else:  # torch keeps the base as a transposed view: pass its strides
+            sg.base, sg.base_rs, sg.base_cs = base.data_ptr(), base.stride(0), base.stride(1)
+        return self._phi_prog
+
     def materialize_phi(self, model) -> torch.Tensor:
-        """Evaluate every parametrization with torch (autograd-tracked) in the order of phi_layout."""
+        """Evaluate every parametrization with torch (autograd-tracked) in the order of phi_layout.  The product path
+        uses the device program above; this is the general path for configurations outside it and the test reference."""
         fc = model.feature_clustering
         parts = [blk.sgu.reg_weight.reshape(1) for blk in model.ref_alt_reads_encoder.blocks]
         parts += [model.pre_clustering_transform.rotation_ee.weight.reshape(-1),

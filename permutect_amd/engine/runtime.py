@@ -128,6 +128,28 @@ class ReadSetEngine:
         return gphi, gvar
 
 
+class PhiFunction(torch.autograd.Function):
+    """theta -> phi (the materialised parametrizations) in one launch; the backward adds J^T d(phi) into the flat gradient
+    buffer that the `.original` leaves' `.grad` alias (one launch).  `trigger` is the engine's dummy leaf."""
+
+    @staticmethod
+    def forward(ctx, engine: "ReadSetEngine", prog, trigger: Tensor):
+        phi = torch.zeros(engine.plan.desc.phi_size, dtype=torch.float32, device=engine.device)
+        L.check(engine.lib.pmt_phi_forward(C.byref(prog), engine.space.theta.data_ptr(), phi.data_ptr(), _stream()), "pmt_phi_forward")
+        ctx.engine, ctx.prog = engine, prog
+        ctx.save_for_backward(phi)
+        return phi
+
+    @staticmethod
+    def backward(ctx, gphi: Tensor):
+        (phi,) = ctx.saved_tensors
+        eng = ctx.engine
+        gphi = gphi.contiguous()
+        L.check(eng.lib.pmt_phi_backward(C.byref(ctx.prog), eng.space.theta.data_ptr(), phi.data_ptr(), gphi.data_ptr(),
+                                         eng.space.gtheta.data_ptr(), _stream()), "pmt_phi_backward")
+        return None, None, None
+
+
 class ReadSetFunction(torch.autograd.Function):
     """(phi, variant_embed) -> (logits_b, logits_bk, features_be, ref_features_be).
 

@@ -116,3 +116,33 @@ def test_weight_staging_schedule_is_in_sync():
     losses.total_loss.backward()
     torch.cuda.synchronize()
     assert int(model.engine().plan.debug_flags[0].item()) == 0
+
+
+@pytest.mark.parametrize("name", ["t0_b8", "p0_b16", "p0_saturated"])
+def test_phi_kernels_match_torch_parametrizations(name):
+    """pmt_phi_forward / pmt_phi_backward (one launch each) against torch.nn.utils.parametrize + autograd for every
+    parametrized tensor, including torch's orthogonal (matrix_exp with trivialization) and its adjoint."""
+    from permutect_amd.engine.runtime import PhiFunction
+    z, sd, b = load_case(name)
+    model, dev = build(name, sd)
+    model.train(True)
+    eng = model.engine()
+    with torch.no_grad():  # move the rotation away from its initial point so that expm and its adjoint are exercised
+        model.pre_clustering_transform.rotation_ee.parametrizations.weight.original.add_(
+            0.3 * torch.randn_like(model.pre_clustering_transform.rotation_ee.parametrizations.weight.original))
+    prog = eng.plan.phi_program(model)
+    assert prog is not None
+    phi_ref = eng.plan.materialize_phi(model)
+    phi = PhiFunction.apply(eng, prog, eng.trigger)
+    np.testing.assert_allclose(phi.detach().cpu().numpy(), phi_ref.detach().cpu().numpy(), rtol=2e-6, atol=2e-6)
+    q = phi.detach()[eng.plan.phi_layout[len(model.ref_alt_reads_encoder.blocks)][1]:][:model.reducer.output_dimension() ** 2]
+    q = q.view(model.reducer.output_dimension(), -1)
+    assert torch.allclose(q @ q.T, torch.eye(q.shape[0], device=q.device), atol=1e-5)
+    gphi = torch.randn_like(phi_ref)
+    originals = [p for n, p in model.named_parameters() if n.endswith(".original")]
+    gref = torch.autograd.grad(phi_ref, originals, gphi)
+    eng.space.gtheta.zero_()
+    phi.backward(gphi)
+    torch.cuda.synchronize()
+    for p, g in zip(originals, gref):
+        np.testing.assert_allclose(p.grad.detach().cpu().numpy(), g.cpu().numpy(), rtol=2e-5, atol=2e-6)
