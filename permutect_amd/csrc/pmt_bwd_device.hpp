@@ -160,7 +160,7 @@ struct BwdCtx {
     int* aux_dst;   // LDS [PMT_AUX_CAP] destination of every slab entry (encoded like PmtLinear.w_src; -1 = none)
     int g;
     unsigned mask_all;  // which of this wave's tiles exist
-    int slot0;      // tile slot (0 .. PMT_GROUP_TILES-1) of this wave's tile 0; the existing tiles of the workgroup are
+    int slot0;      // tile slot (0 .. PMT_WG_TILES-1) of this wave's tile 0; the existing tiles of the workgroup are
     int ntiles;     //   exactly the slots [0, ntiles)
     int tiles_ref;  // slots below this belong to side 0 (ref) of a two-sided linear pair
     int aux_n;      // slab entries in use (wave-uniform, identical in every wave)
@@ -281,7 +281,7 @@ DEV void wgrad_init(WgradAcc<NTO, NTI, SIDES>& a, const PmtLinear& L0) {
 template <int NTO, int NTI, int SIDES>
 DEV void wgrad_accumulate(WgradAcc<NTO, NTI, SIDES>& a, BwdCtx& c, const f4 (&dy)[PMT_RT][NTO], const f4 (&x)[PMT_RT][NTI]) {
     constexpr int P = NTO + NTI;
-    constexpr int TP = (PMT_STAGE_PLANES / P) < PMT_GROUP_TILES ? (PMT_STAGE_PLANES / P) : PMT_GROUP_TILES;
+    constexpr int TP = (PMT_STAGE_PLANES / P) < PMT_WG_TILES ? (PMT_STAGE_PLANES / P) : PMT_WG_TILES;
     static_assert(TP >= 1, "stage too small");
     const int lane = threadIdx.x & 63;
     if (SIDES == 2) { a.any[0] |= c.tiles_ref > 0; a.any[1] |= c.ntiles > c.tiles_ref; } else { a.any[0] |= c.ntiles > 0; }

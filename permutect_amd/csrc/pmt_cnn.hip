@@ -9,12 +9,26 @@
 // linear_acc with the transposed fragments followed by a col2im scatter-add in LDS.  Pooling, activations and the final
 // (wide) linear layer are small and stay on the vector ALU.  The backward kernel recomputes the forward keeping every layer
 // output in LDS.
-#define PMT_STAGE_PLANES 48  // 12 planes per tile (4 of dy + 8 of im2col): 4 tiles per exchange pass; leaves LDS for the activations
+// Wave shape of this translation unit: 4 waves x 2 tiles.  Every layer is a short, latency-bound phase between two
+// workgroup barriers, so the kernels want SEVERAL small workgroups per CU (each with its own barriers) rather than one
+// large one: 256 threads and <= ~78 KB of LDS let two be resident.
+#define PMT_OWN_WAVE_SHAPE
+#define PMT_WAVES 4
+#define PMT_RT 2
+#define PMT_STAGE_PLANES 24  // 12 planes per tile (4 of dy + 8 of im2col): 2 tiles per exchange pass; leaves LDS for the activations
 #include "pmt_device.hpp"
 #include "pmt_bwd_device.hpp"
 
 #define CNN_NTIN (PMT_MAX_ROW_INPUT / 16)
 #define LEAKY_SLOPE 0.01f
+
+// a / b for 0 <= a < 2^22 without the ~35-instruction integer division sequence (inv_b = 1.0f / b)
+DEV int fast_div(int a, int b, float inv_b) {
+    int q = (int)((float)a * inv_b);
+    if (q * b > a) --q;
+    if ((q + 1) * b <= a) ++q;
+    return q;
+}
 
 DEV float act_fwd(int kind, float x) {
     if (kind == PMT_CNN_LEAKY_RELU) return x > 0.f ? x : LEAKY_SLOPE * x;
@@ -29,11 +43,13 @@ DEV float act_bwd(int kind, float x_in, float y_out) {  // d(out)/d(in)
 DEV void build_one_hot(float* __restrict__ dst, int dst_stride, const long long* __restrict__ hap, int seq_len, int nv,
                        long long hap_stride, int v0) {
     const int per = 10 * seq_len;
-    for (int i = threadIdx.x; i < nv * per; i += PMT_THREADS) {
-        const int v = i / per, rem = i - v * per, c = rem / seq_len, s = rem - c * seq_len;
-        const long long base = hap[(size_t)(v0 + v) * hap_stride + (c & 1) * seq_len + s];
-        dst[v * dst_stride + rem] = (base == (c >> 1)) ? 1.f : 0.f;
-    }
+    const float inv_len = 1.0f / (float)seq_len;
+    for (int v = 0; v < nv; ++v)
+        for (int rem = threadIdx.x; rem < per; rem += PMT_THREADS) {
+            const int c = fast_div(rem, seq_len, inv_len), s = rem - c * seq_len;
+            const long long base = hap[(size_t)(v0 + v) * hap_stride + (c & 1) * seq_len + s];
+            dst[v * dst_stride + rem] = (base == (c >> 1)) ? 1.f : 0.f;
+        }
 }
 
 // per-layer tap table: for im2col feature f = ci * kernel + k :  tap[f] = (ci * in_len) | ((k * dilation - padding + 64) << 16)
@@ -57,7 +73,7 @@ DEV ColMeta col_meta(int tile, int ncol, int out_len) {
     ColMeta m;
     const int col = tile * 16 + (threadIdx.x & 15);
     m.valid = col < ncol;
-    m.v = m.valid ? col / out_len : 0;
+    m.v = m.valid ? fast_div(col, out_len, 1.0f / (float)out_len) : 0;
     m.so = m.valid ? col - m.v * out_len : 0;
     return m;
 }
@@ -125,29 +141,30 @@ DEV void small_layer_forward(const PmtCnnLayer& L, const float* __restrict__ the
     const int kind = L.kind;
     if (kind == PMT_CNN_POOL) {
         const int per = L.out_ch * L.out_len;
-        for (int i = threadIdx.x; i < nv * per; i += PMT_THREADS) {
-            const int v = i / per, rem = i - v * per, c = rem / L.out_len, so = rem - c * L.out_len;
-            float m = -INFINITY;
-            for (int k = 0; k < L.kernel; ++k) {
-                const int s = so * L.stride + k;
-                if (s < L.in_len) m = fmaxf(m, in[v * in_stride + c * L.in_len + s]);
+        const float inv_len = 1.0f / (float)L.out_len;
+        for (int v = 0; v < nv; ++v)
+            for (int rem = threadIdx.x; rem < per; rem += PMT_THREADS) {
+                const int c = fast_div(rem, L.out_len, inv_len), so = rem - c * L.out_len;
+                float m = -INFINITY;
+                for (int k = 0; k < L.kernel; ++k) {
+                    const int s = so * L.stride + k;
+                    if (s < L.in_len) m = fmaxf(m, in[v * in_stride + c * L.in_len + s]);
+                }
+                out[v * out_stride + rem] = m;
             }
-            out[v * out_stride + rem] = m;
-        }
     } else if (kind == PMT_CNN_LEAKY_RELU || kind == PMT_CNN_SELU) {
         const int per = L.out_ch * L.out_len;
-        for (int i = threadIdx.x; i < nv * per; i += PMT_THREADS) {
-            const int v = i / per, rem = i - v * per;
-            out[v * out_stride + rem] = act_fwd(kind, in[v * in_stride + rem]);
-        }
+        for (int v = 0; v < nv; ++v)
+            for (int rem = threadIdx.x; rem < per; rem += PMT_THREADS) out[v * out_stride + rem] = act_fwd(kind, in[v * in_stride + rem]);
     } else if (kind == PMT_CNN_LINEAR) {
         // out[v][o] = b[o] + W[o][:] . in[v][:] : the 16 lanes of a lane-group split the dot product, coalesced weight reads
         const float* W = theta + L.w_src;
         const float* b = theta + L.b_src;
         const int nin = L.in_ch * L.in_len;
         const int sub = threadIdx.x & 15, slot = threadIdx.x >> 4, nslots = PMT_THREADS >> 4;
+        const float inv_oc = 1.0f / (float)L.out_ch;
         for (int i = slot; i < nv * L.out_ch; i += nslots) {
-            const int v = i / L.out_ch, o = i - v * L.out_ch;
+            const int v = fast_div(i, L.out_ch, inv_oc), o = i - v * L.out_ch;
             float acc = 0.f;
             for (int k = sub; k < nin; k += 16) acc += W[(size_t)o * nin + k] * in[v * in_stride + k];
             acc += __shfl_xor(acc, 1);
@@ -261,15 +278,16 @@ extern "C" __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn_backward_ke
         const int nin = uniform(L.in_ch) * uniform(L.in_len), nout = uniform(L.out_ch) * uniform(L.out_len);
         const bool need_din = uniform(L.in_off) != 0;  // the one-hot input needs no gradient
         if (kind == PMT_CNN_LEAKY_RELU || kind == PMT_CNN_SELU) {
-            for (int i = tid; i < nv * nout; i += PMT_THREADS) {
-                const int v = i / nout, rem = i - v * nout;
-                gin[v * ma + rem] = gout[v * ma + rem] * act_bwd(kind, xin[v * sa + rem], yout[v * sa + rem]);
-            }
+            for (int v = 0; v < nv; ++v)
+                for (int rem = tid; rem < nout; rem += PMT_THREADS)
+                    gin[v * ma + rem] = gout[v * ma + rem] * act_bwd(kind, xin[v * sa + rem], yout[v * sa + rem]);
         } else if (kind == PMT_CNN_POOL) {
-            for (int i = tid; i < nv * nin; i += PMT_THREADS) gin[(i / nin) * ma + (i % nin)] = 0.f;
+            for (int v = 0; v < nv; ++v)
+                for (int rem = tid; rem < nin; rem += PMT_THREADS) gin[v * ma + rem] = 0.f;
             __syncthreads();
+            const float inv_len = 1.0f / (float)L.out_len;
             for (int i = tid; i < nv * nout; i += PMT_THREADS) {
-                const int v = i / nout, rem = i - v * nout, ch = rem / L.out_len, so = rem - ch * L.out_len;
+                const int v = fast_div(i, nout, 1.0f / (float)nout), rem = i - v * nout, ch = fast_div(rem, L.out_len, inv_len), so = rem - ch * L.out_len;
                 int arg = so * L.stride;
                 float m = -INFINITY;
                 for (int k = 0; k < L.kernel; ++k) {  // first maximum wins, like ATen's max_pool backward
@@ -285,31 +303,32 @@ extern "C" __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn_backward_ke
             }
         } else if (kind == PMT_CNN_LINEAR) {
             const float* W = theta + L.w_src;
-            for (int i = tid; i < L.out_ch * nin; i += PMT_THREADS) {  // dW[o][k] += sum_v dout[v][o] x[v][k]
-                const int o = i / nin, k = i - o * nin;
-                float acc = 0.f;
-                for (int v = 0; v < nv; ++v) acc += gout[v * ma + o] * xin[v * sa + k];
-                atomicAdd(&gtheta[L.w_src + i], acc);
-            }
+            for (int o = 0; o < L.out_ch; ++o)  // dW[o][k] += sum_v dout[v][o] x[v][k]
+                for (int k = tid; k < nin; k += PMT_THREADS) {
+                    float acc = 0.f;
+                    for (int v = 0; v < nv; ++v) acc += gout[v * ma + o] * xin[v * sa + k];
+                    atomicAdd(&gtheta[L.w_src + o * nin + k], acc);
+                }
             for (int o = tid; o < L.out_ch; o += PMT_THREADS) {
                 float acc = 0.f;
                 for (int v = 0; v < nv; ++v) acc += gout[v * ma + o];
                 atomicAdd(&gtheta[L.b_src + o], acc);
             }
             if (need_din)
-                for (int i = tid; i < nv * nin; i += PMT_THREADS) {
-                    const int v = i / nin, k = i - v * nin;
-                    float acc = 0.f;
-                    for (int o = 0; o < L.out_ch; ++o) acc += W[(size_t)o * nin + k] * gout[v * ma + o];
-                    gin[v * ma + k] = acc;
-                }
+                for (int v = 0; v < nv; ++v)
+                    for (int k = tid; k < nin; k += PMT_THREADS) {
+                        float acc = 0.f;
+                        for (int o = 0; o < L.out_ch; ++o) acc += W[(size_t)o * nin + k] * gout[v * ma + o];
+                        gin[v * ma + k] = acc;
+                    }
         } else if (kind == PMT_CNN_CONV) {
             const PmtLinear& Wl = M->lin[uniform(L.lin)];
             const int K = uniform(Wl.in_dim), OC = uniform(Wl.out_dim), out_len = uniform(L.out_len);
             const int ncol = nv * out_len, ntiles = (ncol + 15) >> 4;
             build_taps(sh.tap, L);
             if (need_din)
-                for (int i = tid; i < nv * nin; i += PMT_THREADS) gin[(i / nin) * ma + (i % nin)] = 0.f;
+                for (int v = 0; v < nv; ++v)
+                    for (int rem = tid; rem < nin; rem += PMT_THREADS) gin[v * ma + rem] = 0.f;
             __syncthreads();
             for (int tile0 = 0; tile0 < ntiles; tile0 += PMT_WAVES * PMT_RT) {
                 ColMeta cm[PMT_RT];
@@ -331,7 +350,7 @@ extern "C" __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn_backward_ke
                             dy[rt][t][j] = (cm[rt].valid && co < OC) ? gout[cm[rt].v * ma + co * out_len + cm[rt].so] : 0.f;
                         }
                 c.mask_all = present;
-                c.ntiles = c.tiles_ref = min(PMT_GROUP_TILES, ntiles - tile0);
+                c.ntiles = c.tiles_ref = min(PMT_WG_TILES, ntiles - tile0);
                 linear_wgrad<PMT_NT, CNN_NTIN>(c, Wl, dy, x);  // workgroup barriers inside
                 if (need_din) {
                     f4 dx[PMT_RT][CNN_NTIN];
@@ -414,7 +433,7 @@ extern "C" int pmt_cnn_backward(const PmtModel* model_host, const PmtModel* mode
     if (!model_dev || !theta || !packed || !haplotypes || !d_out || !grad_theta || n < 0) return PMT_E_INVALID;
     if (n == 0) return PMT_OK;
     const size_t per = (size_t)model_host->cnn.sum_act + 2 * (size_t)model_host->cnn.max_act;
-    const int vpb = pick_vpb(per, sizeof(CnnBwdShared), 1);
+    const int vpb = pick_vpb(per, sizeof(CnnBwdShared), 2);
     if (vpb < 1) return PMT_E_UNSUPPORTED;
     hipLaunchKernelGGL(pmt_cnn_backward_kernel, dim3((n + vpb - 1) / vpb), dim3(PMT_THREADS), vpb * per * sizeof(float),
                        reinterpret_cast<hipStream_t>(stream), model_dev, theta, packed, (const long long*)haplotypes,

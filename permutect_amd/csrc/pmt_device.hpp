@@ -35,7 +35,10 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #define PMT_LOG2PI 1.8378770664093453f
 #define PMT_MAX_LOGIT_F 20.0f
 
-static_assert(PMT_GROUP_TILES == PMT_WAVES * PMT_RT, "group capacity");
+#define PMT_WG_TILES (PMT_WAVES * PMT_RT)  // tiles a workgroup processes at once
+#ifndef PMT_OWN_WAVE_SHAPE  // the read-set kernels must match the planner; other kernels may choose their own shape
+static_assert(PMT_GROUP_TILES == PMT_WG_TILES, "group capacity");
+#endif
 
 #define DEV __device__ __forceinline__
 
