@@ -293,6 +293,14 @@ int pmt_pack_params(const PmtModel* model_host, const PmtModel* model_dev, const
 int pmt_scan_counts(const void* ref_counts, const void* alt_counts, int32_t count_elem_bytes, int64_t count_stride,
                     int32_t num_variants, int32_t* ref_offsets, int32_t* alt_offsets, void* stream);
 
+/* Gather index of a batch whose variants are rows of a dataset chunk resident in HBM: row_start[b] = first read row of
+ * variant b inside the chunk (its ref rows, then its alt rows, as on disk: reference data/memory_mapped_data.py:39-40);
+ * read_index[R] lists the chunk rows in batch order (all ref rows of all variants, then all alt rows: reference
+ * data/batch.py:45-47) and is what PmtBatch.read_index consumes.  Replaces the per-Datum Python collate
+ * (reference data/batch.py:41-62) and the re-upload of every read for every batch. */
+int pmt_build_read_index(const int64_t* row_start, const int32_t* ref_offsets, const int32_t* alt_offsets,
+                         int32_t num_variants, int64_t* read_index, void* stream);
+
 /* Fused read-set forward: decode -> read MLP -> concat -> L gated ref/alt blocks -> reducer -> rotation ->
  * clustering head + per-set sums.  Replaces ArtifactModel.calculate_features + FeatureClustering.calculate_logits
  * + RaggedSets.means_over_sets (reference artifact_model.py:239-297).  `stash` = NULL for inference; otherwise the

@@ -443,6 +443,29 @@ extern "C" int pmt_scan_counts(const void* ref_counts, const void* alt_counts, i
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// batch composition on the device: gather index of a batch drawn from a dataset chunk that is resident in HBM
+// ---------------------------------------------------------------------------------------------------------------------
+// On disk (reference data/memory_mapped_data.py:39-40) a datum's rows are its ref reads then its alt reads; a batch wants
+// all ref rows of all its variants, then all alt rows (reference data/batch.py:45-47).  One workgroup per variant.
+__global__ __launch_bounds__(64) void pmt_read_index_kernel(const long long* __restrict__ row_start, const int* __restrict__ ref_off,
+                                                            const int* __restrict__ alt_off, int nb, long long* __restrict__ index) {
+    const int b = blockIdx.x;
+    const int r0 = ref_off[b], nr = ref_off[b + 1] - r0, a0 = alt_off[b], na = alt_off[b + 1] - a0;
+    const long long total_ref = ref_off[nb], start = row_start[b];
+    for (int i = threadIdx.x; i < nr; i += 64) index[r0 + i] = start + i;
+    for (int i = threadIdx.x; i < na; i += 64) index[total_ref + a0 + i] = start + nr + i;
+}
+
+extern "C" int pmt_build_read_index(const int64_t* row_start, const int32_t* ref_offsets, const int32_t* alt_offsets,
+                                    int32_t num_variants, int64_t* read_index, void* stream) {
+    if (!row_start || !ref_offsets || !alt_offsets || !read_index || num_variants < 0) return PMT_E_INVALID;
+    if (num_variants == 0) return PMT_OK;
+    hipLaunchKernelGGL(pmt_read_index_kernel, dim3(num_variants), dim3(64), 0, reinterpret_cast<hipStream_t>(stream),
+                       (const long long*)row_start, ref_offsets, alt_offsets, num_variants, (long long*)read_index);
+    return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // fused clip_grad_norm_(max_norm) + AdamW over one flat buffer (reference misc_utils.py:128-129)
 // ---------------------------------------------------------------------------------------------------------------------
 #define PMT_OPT_BLOCKS 256

@@ -244,5 +244,6 @@ class DownsampledBatch(Batch):
         return self.ref_counts, self.alt_counts, 4, 1
 
     def read_rows(self):
-        t, fmt, row_bytes, _ = self._parent.read_rows()
-        return t, fmt, row_bytes, self.read_indices
+        t, fmt, row_bytes, parent_index = self._parent.read_rows()
+        # a parent that is itself a gather (a batch composed from a device-resident chunk): compose the two indices
+        return t, fmt, row_bytes, self.read_indices if parent_index is None else parent_index[self.read_indices]

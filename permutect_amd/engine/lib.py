@@ -123,7 +123,7 @@ class PmtPhiProgram(C.Structure):
 EXPORTS = ["pmt_abi_version", "pmt_struct_bytes", "pmt_model_check", "pmt_build_schedules", "pmt_plan_groups", "pmt_stash_bytes", "pmt_pack_params",
            "pmt_scan_counts", "pmt_forward", "pmt_backward", "pmt_clip_adamw",
            "pmt_rows_stash_bytes", "pmt_rows_forward", "pmt_rows_backward", "pmt_cnn_forward", "pmt_cnn_backward",
-           "pmt_phi_forward", "pmt_phi_backward"]
+           "pmt_phi_forward", "pmt_phi_backward", "pmt_build_read_index"]
 
 _lib = None
 
@@ -165,6 +165,7 @@ def load() -> C.CDLL:
     lib.pmt_rows_stash_bytes.restype = C.c_size_t
     lib.pmt_rows_forward.argtypes = [P(PmtModel), vp, i32, vp, vp, vp, i64, i32, vp, i64, vp, vp]
     lib.pmt_rows_backward.argtypes = [P(PmtModel), vp, i32, vp, vp, vp, i64, i32, vp, i64, vp, vp, vp, i64, C.c_float, vp]
+    lib.pmt_build_read_index.argtypes = [vp, vp, vp, i32, vp, vp]
     lib.pmt_phi_forward.argtypes = [P(PmtPhiProgram), vp, vp, vp]
     lib.pmt_phi_backward.argtypes = [P(PmtPhiProgram), vp, vp, vp, vp, vp]
     for name in EXPORTS:

@@ -196,5 +196,40 @@ def main():
     print("quirks written")
 
 
+def make_dataset_fixture():
+    """tiny_dataset.tar: written by the reference's own MemoryMappedData (from_generator with small capacity estimates, so
+    the arrays carry unused capacity rows) + what the reference reads back from it and collates from it."""
+    from permutect.data.memory_mapped_data import MemoryMappedData
+    rng = np.random.default_rng(1234)
+    counts = [(int(rng.integers(0, 11)), int(rng.integers(1, 16))) for _ in range(41)]
+    counts[5] = (0, 1)
+    data = make_data(rng, counts, sources=[i % 2 for i in range(41)])
+    mm = MemoryMappedData.from_generator(iter(data), estimated_num_data=16, estimated_num_reads=64)
+    tar_path = os.path.join(HERE, "tiny_dataset.tar")
+    mm.save_to_tarfile(tar_path)
+    back = MemoryMappedData.load_from_tarfile(tar_path)
+    ids = [7, 0, 40, 5, 5, 19]
+    datums = list(back.generate())
+    b = Batch([datums[i] for i in ids])
+    folds = [n for n, _ in enumerate(datums) if n % 3 in {0, 2}]
+    restricted = back.restrict_to_folds(3, [0, 2])
+    np.savez_compressed(
+        os.path.join(HERE, "tiny_dataset_expected.npz"),
+        num_data=back.num_data, num_reads=back.num_reads, read_end_indices=back.read_end_indices,
+        int_array=np.asarray(back.int_mmap[: back.num_data]), float_array=np.asarray(back.float_mmap[: back.num_data]),
+        reads=np.asarray(back.reads_mmap[: back.num_reads]),
+        batch_ids=np.array(ids), batch_int=b.int_tensor.numpy(), batch_float=b.float_tensor.numpy(),
+        batch_reads_f16=b.get_reads_re().numpy(),
+        fold_ids=np.array(folds), fold_num_data=restricted.num_data, fold_num_reads=restricted.num_reads,
+        fold_int=np.asarray(restricted.int_mmap[: restricted.num_data]),
+        fold_reads=np.asarray(restricted.reads_mmap[: restricted.num_reads]),
+    )
+    print("dataset fixture written:", os.path.getsize(tar_path), "bytes")
+
+
 if __name__ == "__main__":
-    main()
+    if "--dataset-only" in sys.argv:  # leaves the model fixtures (and their random streams) untouched
+        make_dataset_fixture()
+    else:
+        main()
+        make_dataset_fixture()

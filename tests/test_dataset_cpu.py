@@ -1,0 +1,79 @@
+"""The on-disk dataset format and the host collate against a tar written by the reference itself
+(tests/golden/tiny_dataset.tar + tiny_dataset_expected.npz, made by tests/golden/make_golden.py --dataset-only)."""
+import os
+
+import numpy as np
+
+from permutect_amd.data.batch import decode_packed_reads
+from permutect_amd.data.memory_mapped_data import MemoryMappedData
+from permutect_amd.data.reads_dataset import ReadsDataset
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _expected():
+    return np.load(os.path.join(GOLDEN, "tiny_dataset_expected.npz"))
+
+
+def test_reads_reference_tar():
+    z = _expected()
+    mm = MemoryMappedData.load_from_tarfile(os.path.join(GOLDEN, "tiny_dataset.tar"))
+    assert mm.num_data == int(z["num_data"]) and mm.num_reads == int(z["num_reads"])
+    assert len(mm.int_mmap) > mm.num_data  # the reference's file carries unused capacity rows: they must be ignored
+    np.testing.assert_array_equal(mm.read_end_indices, z["read_end_indices"])
+    np.testing.assert_array_equal(np.asarray(mm.int_mmap[: mm.num_data]), z["int_array"])
+    np.testing.assert_array_equal(np.asarray(mm.float_mmap[: mm.num_data]), z["float_array"])
+    np.testing.assert_array_equal(np.asarray(mm.reads_mmap[: mm.num_reads]), z["reads"])
+    datums = list(mm.generate())
+    assert len(datums) == mm.num_data and datums[5].reads_re.shape == (1, 12)
+
+
+def test_tar_round_trip(tmp_path):
+    z = _expected()
+    mm = MemoryMappedData.from_arrays(z["int_array"], z["float_array"], z["reads"])
+    path = tmp_path / "out.tar"
+    mm.save_to_tarfile(str(path))
+    back = MemoryMappedData.load_from_tarfile(str(path))
+    assert back.num_data == mm.num_data and back.num_reads == mm.num_reads
+    np.testing.assert_array_equal(np.asarray(back.reads_mmap), z["reads"])
+    np.testing.assert_array_equal(np.asarray(back.float_mmap), z["float_array"])
+    import tarfile
+    with tarfile.open(path) as tar:  # the member names the reference's loader looks for (memory_mapped_data.py:246-249)
+        names = sorted(m.name for m in tar.getmembers())
+    assert names == ["float_array.float_mmap.npy", "int_array.int_mmap.npy", "metadata.metadata.npy", "reads_array.reads_mmap.npy"]
+
+
+def test_fold_split_matches_reference():
+    z = _expected()
+    mm = MemoryMappedData.load_from_tarfile(os.path.join(GOLDEN, "tiny_dataset.tar"))
+    np.testing.assert_array_equal(mm.fold_indices(3, [0, 2]), z["fold_ids"])
+    r = mm.restrict_to_folds(3, [0, 2])
+    assert r.num_data == int(z["fold_num_data"]) and r.num_reads == int(z["fold_num_reads"])
+    np.testing.assert_array_equal(np.asarray(r.int_mmap), z["fold_int"])
+    np.testing.assert_array_equal(np.asarray(r.reads_mmap), z["fold_reads"])
+
+
+def test_host_collate_matches_reference_batch():
+    z = _expected()
+    ds = ReadsDataset(MemoryMappedData.load_from_tarfile(os.path.join(GOLDEN, "tiny_dataset.tar")))
+    assert (ds.num_read_features(), ds.num_info_features(), ds.haplotypes_length(), ds.num_sources()) == (61, 71, 42, 2)
+    b = ds.host_batch(z["batch_ids"])
+    np.testing.assert_array_equal(b.int_tensor.numpy(), z["batch_int"])
+    np.testing.assert_array_equal(b.float_tensor.numpy(), z["batch_float"])
+    # ref rows of every variant, then alt rows, decoded with the reference's uint8 wrap rule
+    np.testing.assert_array_equal(decode_packed_reads(b.packed_reads.numpy()), z["batch_reads_f16"])
+    assert b.plan().num_groups >= 1
+
+
+def test_loader_covers_every_variant_once():
+    ds = ReadsDataset(MemoryMappedData.load_from_tarfile(os.path.join(GOLDEN, "tiny_dataset.tar")))
+    seen = []
+    loader = ds.make_data_loader(batch_size=8, chunk_variants=16, rng=np.random.default_rng(3))
+    for b in loader:
+        assert b.size() <= 8
+        seen.append(b.int_tensor[:, 16:].numpy())
+    assert len(loader) == len(seen)
+    got = np.concatenate(seen)
+    want = np.asarray(ds._ints[: len(ds), 16:]).astype(np.int64)
+    assert got.shape == want.shape
+    assert sorted(map(bytes, got)) == sorted(map(bytes, want))
