@@ -265,6 +265,42 @@ int pmt_phi_forward(const PmtPhiProgram* prog, const float* theta, float* phi, v
 int pmt_phi_backward(const PmtPhiProgram* prog, const float* theta, const float* phi, const float* grad_phi,
                      float* grad_theta, void* stream);
 
+/* Per-variant losses (reference architecture/artifact_model.py:267-325). */
+typedef struct PmtLossArgs {
+    int32_t num_variants, num_clusters, num_sources, reserved;
+    float max_outlier_logit;        /* constants.MAX_OUTLIER_LOGIT: the outlier logit is clipped from above */
+    float max_alt_count;            /* constants.MAX_ALT_COUNT: alt-count target = alt_count / max_alt_count */
+    const float* logits_b;          /* [B]      capped artifact logit (PmtOutputs.logits_b) */
+    const float* logits_bk;         /* [B][K+2] (PmtOutputs.logits_bk) */
+    const float* alt_count_raw;     /* [B]      output of the alt-count adversary's MLP (before the sigmoid) */
+    const float* source_logits;     /* [B][S]   output of the source adversary's MLP, or NULL (num_sources == 1) */
+    const int64_t* labels;          /* Label per variant (0 artifact, 1 variant, 2 unlabeled), element stride label_stride */
+    int64_t label_stride;
+    const int64_t* alt_counts;      /* element stride alt_count_stride */
+    int64_t alt_count_stride;
+    const int64_t* sources;         /* source index per variant (NULL if num_sources == 1), element stride source_stride */
+    int64_t source_stride;
+    const float* weights;           /* [B] BatchOutput.weights */
+    const float* source_weights;    /* [B] BatchOutput.source_weights */
+} PmtLossArgs;
+typedef struct PmtLossOutputs {     /* forward: the five per-variant loss vectors; backward: their upstream gradients (NULL = 0) */
+    float* supervised_b;
+    float* unsupervised_b;
+    float* alt_count_b;
+    float* source_b;
+    float* total_b;                 /* weights * (supervised + unsupervised + alt_count) + source_weights * source */
+} PmtLossOutputs;
+typedef struct PmtLossInputGrads {
+    float* d_logits_b;              /* [B]      */
+    float* d_logits_bk;             /* [B][K+2] */
+    float* d_alt_count_raw;         /* [B]      */
+    float* d_source_logits;         /* [B][S] or NULL */
+} PmtLossInputGrads;
+/* One launch each; replace ~85 elementwise torch launches per training step (BCEWithLogits, clip, logsumexp, sigmoid, MSE,
+ * softmax, products and their autograd). */
+int pmt_losses_forward(const PmtLossArgs* args, const PmtLossOutputs* out, void* stream);
+int pmt_losses_backward(const PmtLossArgs* args, const PmtLossOutputs* grad_out, const PmtLossInputGrads* grad_in, void* stream);
+
 /* Fills model->fwd_sched / bwd_sched from the rest of the descriptor (host, in place). */
 int pmt_build_schedules(PmtModel* model);
 

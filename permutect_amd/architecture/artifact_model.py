@@ -19,7 +19,7 @@ from permutect_amd.architecture import modules as M
 from permutect_amd.data.batch import Batch
 from permutect_amd.data.datum import Data
 from permutect_amd.engine import lib as L
-from permutect_amd.engine.runtime import HaplotypeCnnFunction, PhiFunction, ReadSetEngine, ReadSetFunction, RowsMlpFunction
+from permutect_amd.engine.runtime import HaplotypeCnnFunction, LossesFunction, PhiFunction, ReadSetEngine, ReadSetFunction, RowsMlpFunction
 from permutect_amd.enums import Epoch
 from permutect_amd.parameters import ModelParameters, install_pickle_alias
 
@@ -38,12 +38,20 @@ class BatchOutput:
         self.features_be = features_be
         self.ref_features_be = ref_features_be
         self.logits_b = logits_b
-        self.artifact_probs_b = torch.sigmoid(logits_b)
         self.logits_bk = logits_bk
         self.weights = weights
         self.source_weights = source_weights
-        nonoutlier = torch.logsumexp(torch.cat((logits_bk[:, 0:1], logits_bk[:, 2:]), dim=-1), dim=-1)
-        self.outlier_binary_logits = logits_bk[:, 1] - nonoutlier
+
+    # derived on demand (the reference computes both eagerly; the fused loss kernel needs neither)
+    @property
+    def artifact_probs_b(self) -> Tensor:
+        return torch.sigmoid(self.logits_b)
+
+    @property
+    def outlier_binary_logits(self) -> Tensor:
+        lk = self.logits_bk
+        nonoutlier = torch.logsumexp(torch.cat((lk[:, 0:1], lk[:, 2:]), dim=-1), dim=-1)
+        return lk[:, 1] - nonoutlier
 
 
 class BatchLosses:
@@ -196,6 +204,23 @@ class ArtifactModel(nn.Module):
         return self.alt_count_loss_func(pred, target)
 
     def compute_batch_losses(self, output: BatchOutput, batch: Batch) -> BatchLosses:
+        """All five per-variant loss vectors in one launch (pmt_losses_forward); the two adversaries' MLPs are row
+        kernels with the gradient reversal folded into their input gradient."""
+        eng = self.engine()
+        alt_raw = RowsMlpFunction.apply(eng, L.ROWS_ALT_COUNT, output.features_be, eng.trigger,
+                                        float(self.alt_count_predictor.gradient_reversal.alpha))
+        source_logits, sources = None, None
+        if self.num_sources > 1:
+            source_logits = RowsMlpFunction.apply(eng, L.ROWS_SOURCE, output.features_be, eng.trigger,
+                                                  float(self.source_predictor.gradient_reversal.alpha))
+            sources = batch.get(Data.SOURCE).long()
+        sup, unsup, alt, src, total = LossesFunction.apply(
+            eng, output.logits_b, output.logits_bk, alt_raw, source_logits, batch.get(Data.LABEL).long(),
+            batch.get(Data.ALT_COUNT).long(), sources, output.weights, output.source_weights)
+        return BatchLosses(sup, unsup, alt, src, total)
+
+    def compute_batch_losses_torch(self, output: BatchOutput, batch: Batch) -> BatchLosses:
+        """The same losses as the reference composes them from torch ops (test reference for the fused kernels)."""
         labels_b = batch.get_training_labels()
         is_labeled_b = batch.get_is_labeled_mask()
         supervised = is_labeled_b * _BCE(output.logits_b, labels_b)

@@ -21,6 +21,7 @@ extern "C" int pmt_struct_bytes(int which) {
         case 8: return (int)sizeof(PmtBlock);
         case 9: return (int)sizeof(PmtHead);
         case 10: return (int)sizeof(PmtPhiProgram);
+        case 11: return (int)sizeof(PmtLossArgs);
         default: return PMT_E_INVALID;
     }
 }

@@ -128,6 +128,58 @@ class ReadSetEngine:
         return gphi, gvar
 
 
+class LossesFunction(torch.autograd.Function):
+    """(logits_b, logits_bk, alt-count prediction, source prediction) -> the five per-variant loss vectors of
+    reference artifact_model.py:267-325, one launch forward and one backward (pmt_losses_*)."""
+
+    @staticmethod
+    def _args(engine, logits_b, logits_bk, alt_raw, source_logits, labels, alt_counts, sources, weights, source_weights):
+        from permutect_amd import constants
+        a = L.PmtLossArgs()
+        a.num_variants, a.num_clusters = logits_b.shape[0], logits_bk.shape[1] - 2
+        a.num_sources = 1 if source_logits is None else source_logits.shape[1]
+        a.max_outlier_logit, a.max_alt_count = constants.MAX_OUTLIER_LOGIT, float(constants.MAX_ALT_COUNT)
+        a.logits_b, a.logits_bk, a.alt_count_raw = logits_b.data_ptr(), logits_bk.data_ptr(), alt_raw.data_ptr()
+        a.source_logits = _ptr(source_logits)
+        a.labels, a.label_stride = labels.data_ptr(), labels.stride(0)
+        a.alt_counts, a.alt_count_stride = alt_counts.data_ptr(), alt_counts.stride(0)
+        a.sources, a.source_stride = _ptr(sources), (0 if sources is None else sources.stride(0))
+        a.weights, a.source_weights = weights.data_ptr(), source_weights.data_ptr()
+        return a
+
+    @staticmethod
+    def forward(ctx, engine, logits_b, logits_bk, alt_raw, source_logits, labels, alt_counts, sources, weights, source_weights):
+        alt_shape = alt_raw.shape
+        logits_b, logits_bk, alt_raw = logits_b.contiguous(), logits_bk.contiguous(), alt_raw.contiguous().view(-1)
+        source_logits = None if source_logits is None else source_logits.contiguous()
+        weights, source_weights = weights.contiguous().float(), source_weights.contiguous().float()
+        assert labels.dtype == torch.int64 and alt_counts.dtype == torch.int64 and (sources is None or sources.dtype == torch.int64)
+        b = logits_b.shape[0]
+        outs = [torch.empty(b, dtype=torch.float32, device=logits_b.device) for _ in range(5)]
+        a = LossesFunction._args(engine, logits_b, logits_bk, alt_raw, source_logits, labels, alt_counts, sources, weights, source_weights)
+        o = L.PmtLossOutputs(*[t.data_ptr() for t in outs])
+        L.check(engine.lib.pmt_losses_forward(C.byref(a), C.byref(o), _stream()), "pmt_losses_forward")
+        ctx.engine = engine
+        ctx.alt_shape = alt_shape
+        ctx.save_for_backward(logits_b, logits_bk, alt_raw, labels, alt_counts, weights, source_weights,
+                              *(() if source_logits is None else (source_logits, sources)))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        saved = ctx.saved_tensors
+        logits_b, logits_bk, alt_raw, labels, alt_counts, weights, source_weights = saved[:7]
+        source_logits, sources = (saved[7], saved[8]) if len(saved) > 7 else (None, None)
+        grads = [None if g is None else g.contiguous().float() for g in grads]
+        a = LossesFunction._args(ctx.engine, logits_b, logits_bk, alt_raw, source_logits, labels, alt_counts, sources, weights, source_weights)
+        g = L.PmtLossOutputs(*[_ptr(t) for t in grads])
+        d_b, d_bk, d_alt = torch.empty_like(logits_b), torch.empty_like(logits_bk), torch.empty_like(alt_raw)
+        d_src = None if source_logits is None else torch.empty_like(source_logits)
+        d = L.PmtLossInputGrads(d_b.data_ptr(), d_bk.data_ptr(), d_alt.data_ptr(), _ptr(d_src))
+        L.check(ctx.engine.lib.pmt_losses_backward(C.byref(a), C.byref(g), C.byref(d), _stream()), "pmt_losses_backward")
+        return None, d_b, d_bk, d_alt.view(ctx.alt_shape), d_src, None, None, None, None, None
+
+
 class PhiFunction(torch.autograd.Function):
     """theta -> phi (the materialised parametrizations) in one launch; the backward adds J^T d(phi) into the flat gradient
     buffer that the `.original` leaves' `.grad` alias (one launch).  `trigger` is the engine's dummy leaf."""

@@ -146,3 +146,34 @@ def test_phi_kernels_match_torch_parametrizations(name):
     torch.cuda.synchronize()
     for p, g in zip(originals, gref):
         np.testing.assert_allclose(p.grad.detach().cpu().numpy(), g.cpu().numpy(), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("name", ["p0_b16", "t0_two_sources", "p0_saturated"])
+def test_fused_losses_match_torch_composition(name):
+    """pmt_losses_forward / _backward against the reference's torch composition (BCEWithLogits, clip, logsumexp, MSE on a
+    sigmoid, squared error on a softmax) with arbitrary upstream gradients on all five loss vectors and non-unit weights."""
+    z, model, out, _ = run_step(name)
+    z2, sd, b = load_case(name)
+    batch = Batch.from_arrays(b["int_array"], b["float_array"], b["packed_reads"]).copy_to(out.logits_b.device)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    n = out.logits_b.shape[0]
+    out.weights = (0.5 + torch.rand(n, generator=g)).to(out.logits_b.device)
+    out.source_weights = (0.5 + torch.rand(n, generator=g)).to(out.logits_b.device)
+    ups = [torch.randn(n, generator=g).to(out.logits_b.device) for _ in range(5)]
+    results = []
+    for fn in (model.compute_batch_losses, model.compute_batch_losses_torch):
+        leaves = [t.detach().clone().requires_grad_(True) for t in (out.logits_b, out.logits_bk, out.features_be)]
+        o = type(out)(features_be=leaves[2], ref_features_be=out.ref_features_be, logits_b=leaves[0], logits_bk=leaves[1],
+                      weights=out.weights, source_weights=out.source_weights)
+        model.engine().space.gtheta.zero_()
+        losses = fn(o, batch)
+        vecs = [losses.supervised_losses_b, losses.unsupervised_losses_b, losses.alt_count_losses_b,
+                losses.source_prediction_losses_b, losses.total_losses_b]
+        scalar = sum((u * v).sum() for u, v in zip(ups, vecs))
+        scalar.backward()
+        results.append(([v.detach().cpu().numpy() for v in vecs], [t.grad.cpu().numpy() for t in leaves]))
+    (v1, g1), (v2, g2) = results
+    for a, c in zip(v1, v2):
+        np.testing.assert_allclose(a, c, rtol=2e-5, atol=2e-6)
+    for a, c in zip(g1, g2):
+        np.testing.assert_allclose(a, c, rtol=2e-4, atol=2e-6)
