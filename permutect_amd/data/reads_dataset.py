@@ -145,12 +145,19 @@ class DeviceChunk:
     def __init__(self, dataset: ReadsDataset, lo: int, hi: int, device: torch.device):
         self.lo, self.hi = lo, hi
         r0, r1 = int(dataset._starts[lo]), int(dataset._starts[hi])
-        nb = device.type == "cuda"
-        self.ints_host = np.array(dataset._ints[lo:hi])  # a writable copy of the (read-only) memory map
-        self.ints = torch.from_numpy(self.ints_host).to(device, non_blocking=nb)                       # int16 [n, 16 + H]
-        self.floats = torch.from_numpy(np.array(dataset._floats[lo:hi])).to(device, non_blocking=nb)  # f16
-        self.reads = torch.from_numpy(np.array(dataset._reads[r0:r1])).to(device, non_blocking=nb)  # u8 [R, 12]
-        self.row_start = torch.from_numpy(dataset._starts[lo:hi] - r0).to(device, non_blocking=nb)    # int64 [n]
+        cuda = device.type == "cuda"
+
+        def upload(arr: np.ndarray) -> torch.Tensor:
+            # disk (memory map) -> pinned staging buffer -> HBM; an array already in host memory is staged the same way
+            host = torch.empty(arr.shape, dtype=torch.from_numpy(np.empty(0, arr.dtype)).dtype, pin_memory=cuda)
+            np.copyto(host.numpy(), arr)
+            return host.to(device, non_blocking=cuda)
+
+        self.ints_host = np.array(dataset._ints[lo:hi])  # host copy: the planner needs the counts
+        self.ints = upload(self.ints_host)                               # int16 [n, 16 + H]
+        self.floats = upload(dataset._floats[lo:hi])                     # float16 [n, 6 + I]
+        self.reads = upload(dataset._reads[r0:r1])                       # uint8 [R, 7 + nf]
+        self.row_start = upload(dataset._starts[lo:hi] - r0)             # int64 [n]
         self.ref_host = self.ints_host[:, Data.REF_COUNT.idx].astype(np.int32)
         self.alt_host = self.ints_host[:, Data.ALT_COUNT.idx].astype(np.int32)
         self.nbytes = self.ints.numel() * 2 + self.floats.numel() * 2 + self.reads.numel() + self.row_start.numel() * 8
@@ -223,12 +230,29 @@ class DeviceChunkLoader:
     def __len__(self) -> int:
         return sum(-(-(hi - lo) // self.batch_size) for lo, hi in self.ranges)
 
-    def __iter__(self) -> Iterator[ChunkBatch]:
-        order_c = self.rng.permutation(len(self.ranges)) if self.shuffle else np.arange(len(self.ranges))
-        for c in order_c:
-            lo, hi = self.ranges[c]
+    def _load(self, c: int) -> DeviceChunk:
+        """Runs on the prefetch thread: stage and upload chunk c on a side stream, return when it is resident."""
+        lo, hi = self.ranges[c]
+        if self.device.type != "cuda":
+            return DeviceChunk(self.dataset, lo, hi, self.device)
+        torch.cuda.set_device(self.device)
+        side = torch.cuda.Stream(self.device)
+        with torch.cuda.stream(side):
             chunk = DeviceChunk(self.dataset, lo, hi, self.device)
-            self.bytes_uploaded += chunk.nbytes
-            ids = self.rng.permutation(hi - lo) if self.shuffle else np.arange(hi - lo)
-            for s in range(0, len(ids), self.batch_size):
-                yield ChunkBatch(chunk, ids[s:s + self.batch_size])
+        side.synchronize()
+        return chunk
+
+    def __iter__(self) -> Iterator[ChunkBatch]:
+        """One chunk is trained on while the next is read, staged and uploaded by a background thread."""
+        from concurrent.futures import ThreadPoolExecutor
+        order_c = self.rng.permutation(len(self.ranges)) if self.shuffle else np.arange(len(self.ranges))
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            pending = pool.submit(self._load, int(order_c[0])) if len(order_c) else None
+            for i, c in enumerate(order_c):
+                chunk = pending.result()
+                pending = pool.submit(self._load, int(order_c[i + 1])) if i + 1 < len(order_c) else None
+                self.bytes_uploaded += chunk.nbytes
+                n = self.ranges[c][1] - self.ranges[c][0]
+                ids = self.rng.permutation(n) if self.shuffle else np.arange(n)
+                for s in range(0, len(ids), self.batch_size):
+                    yield ChunkBatch(chunk, ids[s:s + self.batch_size])
