@@ -380,6 +380,13 @@ extern "C" __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn_backward_ke
     }
 }
 
+// pmt_cnn2.hip: 0 = done, 1 = configuration not covered (run the general kernels below), < 0 = error
+extern "C" int pmt_cnn2_try_forward(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* packed,
+                                    const int64_t* haplotypes, int64_t hap_stride, int32_t n, float* out, int64_t out_stride, void* stream);
+extern "C" int pmt_cnn2_try_backward(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* packed,
+                                     const int64_t* haplotypes, int64_t hap_stride, int32_t n, const float* d_out,
+                                     int64_t d_out_stride, float* grad_theta, void* stream);
+
 static int cnn_check(const PmtModel* m) {
     if (!m) return PMT_E_INVALID;
     const PmtCnn* c = &m->cnn;
@@ -416,6 +423,10 @@ extern "C" int pmt_cnn_forward(const PmtModel* model_host, const PmtModel* model
     if (rc) return rc;
     if (!model_dev || !theta || !packed || !haplotypes || !out || n < 0) return PMT_E_INVALID;
     if (n == 0) return PMT_OK;
+    {   // wave-per-variant kernels (pmt_cnn2.hip) when the configuration fits them
+        const int rc2 = pmt_cnn2_try_forward(model_host, model_dev, theta, packed, haplotypes, hap_stride, n, out, out_stride, stream);
+        if (rc2 <= 0) return rc2;
+    }
     const size_t per = 2 * (size_t)model_host->cnn.max_act;
     const int vpb = pick_vpb(per, sizeof(CnnFwdShared), 2);
     if (vpb < 1) return PMT_E_UNSUPPORTED;
@@ -432,6 +443,11 @@ extern "C" int pmt_cnn_backward(const PmtModel* model_host, const PmtModel* mode
     if (rc) return rc;
     if (!model_dev || !theta || !packed || !haplotypes || !d_out || !grad_theta || n < 0) return PMT_E_INVALID;
     if (n == 0) return PMT_OK;
+    {
+        const int rc2 = pmt_cnn2_try_backward(model_host, model_dev, theta, packed, haplotypes, hap_stride, n, d_out, d_out_stride,
+                                              grad_theta, stream);
+        if (rc2 <= 0) return rc2;
+    }
     const size_t per = (size_t)model_host->cnn.sum_act + 2 * (size_t)model_host->cnn.max_act;
     const int vpb = pick_vpb(per, sizeof(CnnBwdShared), 2);
     if (vpb < 1) return PMT_E_UNSUPPORTED;

@@ -279,10 +279,11 @@ class EnginePlan:
                 c.kernel = layer.kernel_size
                 c.stride = layer.stride if layer.stride is not None else layer.kernel_size
                 length = M._pool_len(length, kernel_size=c.kernel, stride=c.stride)
-            elif isinstance(layer, nn.LeakyReLU):
-                c.kind = L.CNN_LEAKY_RELU
-            elif isinstance(layer, nn.SELU):
-                c.kind = L.CNN_SELU
+            elif isinstance(layer, (nn.LeakyReLU, nn.SELU)):
+                # activations run in place (their derivative is taken from the output): no region of their own
+                c.kind = L.CNN_LEAKY_RELU if isinstance(layer, nn.LeakyReLU) else L.CNN_SELU
+                c.out_ch, c.out_len, c.out_off = ch, length, in_off
+                continue
             elif isinstance(layer, nn.Flatten):
                 c.kind = L.CNN_FLATTEN
                 ch, length = ch * length, 1

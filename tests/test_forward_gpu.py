@@ -20,6 +20,7 @@ def kernel_shape(request, monkeypatch):
     fixtures) and with the generic instance forced through PMT_SHAPE=any (read by the library at every launch)."""
     if request.param == "any":
         monkeypatch.setenv("PMT_SHAPE", "any")
+        monkeypatch.setenv("PMT_CNN", "general")  # and the general (workgroup-per-chunk) haplotype-CNN kernels
 
 
 def build(name, sd):
