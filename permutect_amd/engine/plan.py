@@ -137,7 +137,7 @@ class EnginePlan:
 
         self._lower_cnn(d.cnn, model.haplotypes_cnn, model.haplotypes_length() // 2)
         d.n_linear = self._n_lin
-        d.theta_size, d.phi_size, d.packed_size = space.size, max(self._phi_off, 4), self._packed_off + 256
+        d.theta_size, d.phi_size, d.packed_size = space.size, max(self._phi_off, 4), self._packed_off + 512  # slack: the kernels prefetch two fragments ahead
 
         lib = L.load()
         L.check(lib.pmt_model_check(C.byref(d)), "pmt_model_check")
