@@ -46,7 +46,7 @@ DEV float logerfc_dev(float z) {
 }
 
 template <bool TRAIN, typename S>
-__global__ __launch_bounds__(PMT_THREADS, 2) void pmt_forward_kernel(const PmtModel* __restrict__ M,
+__global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_kernel(const PmtModel* __restrict__ M,
                                                                       const float* __restrict__ theta,
                                                                       const float* __restrict__ phi,
                                                                       const float* __restrict__ packed, PmtBatch bt,
