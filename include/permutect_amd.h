@@ -265,6 +265,27 @@ int pmt_phi_forward(const PmtPhiProgram* prog, const float* theta, float* phi, v
 int pmt_phi_backward(const PmtPhiProgram* prog, const float* theta, const float* phi, const float* grad_phi,
                      float* grad_theta, void* stream);
 
+/* Read downsampling of a training batch (reference data/batch.py:389-439, training/downsampler.py:105-123). */
+typedef struct PmtDownsample {
+    int32_t num_variants;
+    int32_t reference_alt_gather;   /* 1: reproduce the reference's un-offset alt gather; 0: the intended rows */
+    uint64_t seed;                  /* counter-based generator: decisions are a function of (seed, row) */
+    int64_t force_random;           /* the reference's randint(0, 100): alt read  end - (force_random % count) - 1  is always kept */
+    const int32_t* ref_offsets;     /* [B+1] exclusive scans of the PARENT batch's counts (pmt_scan_counts) */
+    const int32_t* alt_offsets;
+    const float* ref_weights_b4;    /* [B][4] mixture weights over the Beta shapes (1,1) (1,5) (5,1) (5,5), or NULL = uniform */
+    const float* alt_weights_b4;
+    const float* ref_fracs_in;      /* [B] keep fractions given by the caller (then no fractions are drawn), or NULL */
+    const float* alt_fracs_in;
+} PmtDownsample;
+/* Launch 1: draw the keep fractions (unless given) and count the kept reads per variant. */
+int pmt_downsample_counts(const PmtDownsample* args, float* ref_fracs, float* alt_fracs, int32_t* new_ref_counts,
+                          int32_t* new_alt_counts, void* stream);
+/* Launch 2 (after the exclusive scans of the new counts): the gather index PmtBatch.read_index consumes; kept rows in
+ * ascending order, all kept ref rows of all variants then all kept alt rows, like the reference's read_indices. */
+int pmt_downsample_index(const PmtDownsample* args, const float* ref_fracs, const float* alt_fracs,
+                         const int32_t* new_ref_offsets, const int32_t* new_alt_offsets, int64_t* read_index, void* stream);
+
 /* Per-variant losses (reference architecture/artifact_model.py:267-325). */
 typedef struct PmtLossArgs {
     int32_t num_variants, num_clusters, num_sources, reserved;

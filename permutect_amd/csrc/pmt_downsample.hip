@@ -1,0 +1,147 @@
+// Read downsampling of a training batch on the device (reference data/batch.py:389-439 `DownsampledBatch` and
+// training/downsampler.py:105-123 `Downsampler.calculate_downsampling_fractions`).
+//
+// The reference draws, per variant, a mixture component of four fixed Beta shapes and a keep fraction from it, then a
+// Bernoulli keep decision per read (forcing one alt read per variant), and gathers the kept rows: ~35 small torch
+// launches and a host sync per training step.  Here: one launch decides fractions and new counts, one (after the
+// exclusive scans of the counts) writes the gather index the kernels consume; the decisions come from a counter-based
+// generator keyed by (seed, row), so both launches agree without storing a mask and nothing returns to the host.
+// The random STREAM differs from torch's, the distribution does not (tests/test_downsample_gpu.py).
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "permutect_amd.h"
+
+// splitmix64-style counter hash -> uniform in [0, 1)
+__device__ __forceinline__ float uniform01(unsigned long long seed, unsigned long long stream, unsigned long long counter) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (counter + 1) + 0xD1B54A32D192ED03ull * (stream + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+// Beta(a, b) for the reference's basis shapes (1,1), (1,5), (5,1), (5,5) (training/downsampler.py:27): for integer shapes
+// it is the a-th smallest of a + b - 1 uniforms.
+__device__ float beta_sample(int comp, unsigned long long seed, unsigned long long stream, unsigned long long counter) {
+    const int a = (comp == 2 || comp == 3) ? 5 : 1, b = (comp == 1 || comp == 3) ? 5 : 1;
+    const int n = a + b - 1;
+    float u[9];
+    for (int i = 0; i < n; ++i) u[i] = uniform01(seed, stream + 16 + i, counter);
+    for (int i = 1; i < n; ++i) {  // insertion sort of at most 9 values
+        const float x = u[i];
+        int j = i - 1;
+        for (; j >= 0 && u[j] > x; --j) u[j + 1] = u[j];
+        u[j + 1] = x;
+    }
+    return u[a - 1];
+}
+
+__device__ int pick_component(const float* __restrict__ w4, float u) {
+    if (w4 == nullptr) return min(3, (int)(u * 4.0f));
+    const float tot = w4[0] + w4[1] + w4[2] + w4[3];
+    float c = 0.f;
+    for (int k = 0; k < 3; ++k) {
+        c += w4[k];
+        if (u * tot < c) return k;
+    }
+    return 3;
+}
+
+// stream ids: 0 ref component, 1 alt component, 2 ref keep decisions, 3 alt keep decisions, 16.. Beta order statistics
+__device__ __forceinline__ bool keep_ref(const PmtDownsample& a, long long row, float frac) { return uniform01(a.seed, 2, row) < frac; }
+__device__ __forceinline__ bool keep_alt(const PmtDownsample& a, long long alt_row, float frac, long long forced) {
+    return alt_row == forced || uniform01(a.seed, 3, alt_row) < frac;
+}
+// the reference forces alt read  alt_end - (random_int % alt_count) - 1  of every variant (data/batch.py:418-421)
+__device__ __forceinline__ long long forced_alt(const PmtDownsample& a, int a0, int na) { return na > 0 ? (long long)a0 + na - 1 - (a.force_random % na) : -1; }
+
+__global__ __launch_bounds__(64) void pmt_downsample_counts_kernel(PmtDownsample a, float* __restrict__ ref_fracs,
+                                                                   float* __restrict__ alt_fracs, int* __restrict__ new_ref,
+                                                                   int* __restrict__ new_alt) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    float fr, fa;
+    if (a.ref_fracs_in != nullptr) {
+        fr = a.ref_fracs_in[b];
+        fa = a.alt_fracs_in[b];
+    } else {
+        const int kr = pick_component(a.ref_weights_b4 ? a.ref_weights_b4 + 4 * (size_t)b : nullptr, uniform01(a.seed, 0, b));
+        const int ka = pick_component(a.alt_weights_b4 ? a.alt_weights_b4 + 4 * (size_t)b : nullptr, uniform01(a.seed, 1, b));
+        fr = beta_sample(kr, a.seed, 32, b);
+        fa = beta_sample(ka, a.seed, 64, b);
+    }
+    const int r0 = a.ref_offsets[b], nr = a.ref_offsets[b + 1] - r0, a0 = a.alt_offsets[b], na = a.alt_offsets[b + 1] - a0;
+    const long long forced = forced_alt(a, a0, na);
+    int cr = 0, ca = 0;
+    for (int i = lane; i < nr; i += 64) cr += keep_ref(a, (long long)r0 + i, fr) ? 1 : 0;
+    for (int i = lane; i < na; i += 64) ca += keep_alt(a, (long long)a0 + i, fa, forced) ? 1 : 0;
+    for (int d = 32; d > 0; d >>= 1) {
+        cr += __shfl_xor(cr, d);
+        ca += __shfl_xor(ca, d);
+    }
+    if (lane == 0) {
+        ref_fracs[b] = fr;
+        alt_fracs[b] = fa;
+        new_ref[b] = cr;
+        new_alt[b] = ca;
+    }
+}
+
+__global__ __launch_bounds__(64) void pmt_downsample_index_kernel(PmtDownsample a, const float* __restrict__ ref_fracs,
+                                                                  const float* __restrict__ alt_fracs,
+                                                                  const int* __restrict__ new_ref_off, const int* __restrict__ new_alt_off,
+                                                                  long long* __restrict__ index) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float fr = ref_fracs[b], fa = alt_fracs[b];
+    const int r0 = a.ref_offsets[b], nr = a.ref_offsets[b + 1] - r0, a0 = a.alt_offsets[b], na = a.alt_offsets[b + 1] - a0;
+    const long long total_ref = a.ref_offsets[a.num_variants], new_total_ref = new_ref_off[a.num_variants];
+    const long long forced = forced_alt(a, a0, na);
+    int base = new_ref_off[b];
+    for (int i0 = 0; i0 < nr; i0 += 64) {  // kept rows in ascending order: rank = kept rows before this lane
+        const int i = i0 + lane;
+        const bool k = i < nr && keep_ref(a, (long long)r0 + i, fr);
+        const unsigned long long m = __ballot(k);
+        if (k) index[base + __popcll(m & ((1ull << lane) - 1ull))] = (long long)r0 + i;
+        base += __popcll(m);
+    }
+    base = new_alt_off[b];
+    // reference quirk: the kept alt indices index the ALT-ONLY mask but are used un-offset into the whole read
+    // array; alt_row_offset = 0 reproduces it, total_ref gives the intended rows
+    const long long alt_row_offset = a.reference_alt_gather ? 0 : total_ref;
+    for (int i0 = 0; i0 < na; i0 += 64) {
+        const int i = i0 + lane;
+        const bool k = i < na && keep_alt(a, (long long)a0 + i, fa, forced);
+        const unsigned long long m = __ballot(k);
+        if (k) index[new_total_ref + base + __popcll(m & ((1ull << lane) - 1ull))] = alt_row_offset + a0 + i;
+        base += __popcll(m);
+    }
+}
+
+static int ds_check(const PmtDownsample* a) {
+    if (!a || a->num_variants < 0) return PMT_E_INVALID;
+    if (a->num_variants == 0) return PMT_OK;
+    if (!a->ref_offsets || !a->alt_offsets || (a->ref_fracs_in != nullptr) != (a->alt_fracs_in != nullptr) || a->force_random < 0) return PMT_E_INVALID;
+    return PMT_OK;
+}
+
+extern "C" int pmt_downsample_counts(const PmtDownsample* args, float* ref_fracs, float* alt_fracs, int32_t* new_ref_counts,
+                                     int32_t* new_alt_counts, void* stream) {
+    const int rc = ds_check(args);
+    if (rc) return rc;
+    if (!ref_fracs || !alt_fracs || !new_ref_counts || !new_alt_counts) return PMT_E_INVALID;
+    if (args->num_variants == 0) return PMT_OK;
+    hipLaunchKernelGGL(pmt_downsample_counts_kernel, dim3(args->num_variants), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), *args,
+                       ref_fracs, alt_fracs, new_ref_counts, new_alt_counts);
+    return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
+}
+
+extern "C" int pmt_downsample_index(const PmtDownsample* args, const float* ref_fracs, const float* alt_fracs,
+                                    const int32_t* new_ref_offsets, const int32_t* new_alt_offsets, int64_t* read_index, void* stream) {
+    const int rc = ds_check(args);
+    if (rc) return rc;
+    if (!ref_fracs || !alt_fracs || !new_ref_offsets || !new_alt_offsets || !read_index) return PMT_E_INVALID;
+    if (args->num_variants == 0) return PMT_OK;
+    hipLaunchKernelGGL(pmt_downsample_index_kernel, dim3(args->num_variants), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), *args,
+                       ref_fracs, alt_fracs, new_ref_offsets, new_alt_offsets, (long long*)read_index);
+    return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
+}

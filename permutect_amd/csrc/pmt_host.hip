@@ -22,6 +22,7 @@ extern "C" int pmt_struct_bytes(int which) {
         case 9: return (int)sizeof(PmtHead);
         case 10: return (int)sizeof(PmtPhiProgram);
         case 11: return (int)sizeof(PmtLossArgs);
+        case 12: return (int)sizeof(PmtDownsample);
         default: return PMT_E_INVALID;
     }
 }

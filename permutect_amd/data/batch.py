@@ -222,6 +222,55 @@ class DownsampledBatch(Batch):
         self.read_indices = torch.hstack((kept_ref, kept_alt))
         self._host_counts = None
 
+    @classmethod
+    def on_device(cls, original_batch: Batch, seed: int, ref_fracs_b: Optional[Tensor] = None,
+                  alt_fracs_b: Optional[Tensor] = None, ref_weights_b4: Optional[Tensor] = None,
+                  alt_weights_b4: Optional[Tensor] = None, fix_alt_gather: bool = False, force_random: Optional[int] = None):
+        """The same sampling scheme in two launches and no host sync (pmt_downsample_*): fractions from the Downsampler's
+        Beta mixture (or given), Bernoulli keep per read from a counter-based generator, one forced alt read per variant."""
+        self = cls.__new__(cls)
+        p = original_batch
+        self.int_tensor, self.float_tensor = p.int_tensor, p.float_tensor
+        self.device = dev = self.int_tensor.device
+        self.packed_reads, self.reads_re = p.packed_reads, p.reads_re
+        self._num_read_features, self._size, self._parent = p._num_read_features, p._size, p
+        lib = L.load()
+        stream = torch.cuda.current_stream().cuda_stream
+        b = p._size
+
+        def scan(ref_c, alt_c, elem, stride):
+            ro = torch.empty(b + 1, dtype=torch.int32, device=dev)
+            ao = torch.empty(b + 1, dtype=torch.int32, device=dev)
+            L.check(lib.pmt_scan_counts(ref_c.data_ptr(), alt_c.data_ptr(), elem, stride, b, ro.data_ptr(), ao.data_ptr(), stream),
+                    "pmt_scan_counts")
+            return ro, ao
+
+        if getattr(p, "_offsets", None) is None:
+            p._offsets = scan(*p.device_counts())
+        pro, pao = p._offsets
+        a = L.PmtDownsample()
+        a.num_variants, a.reference_alt_gather, a.seed = b, 0 if fix_alt_gather else 1, seed & 0xFFFFFFFFFFFFFFFF
+        a.force_random = randint(0, 100) if force_random is None else force_random
+        a.ref_offsets, a.alt_offsets = pro.data_ptr(), pao.data_ptr()
+        keep = [t if t is None else t.contiguous().float() for t in (ref_weights_b4, alt_weights_b4, ref_fracs_b, alt_fracs_b)]
+        a.ref_weights_b4, a.alt_weights_b4, a.ref_fracs_in, a.alt_fracs_in = [None if t is None else t.data_ptr() for t in keep]
+        self.ref_fracs = torch.empty(b, dtype=torch.float32, device=dev)
+        self.alt_fracs = torch.empty(b, dtype=torch.float32, device=dev)
+        self.ref_counts = torch.empty(b, dtype=torch.int32, device=dev)
+        self.alt_counts = torch.empty(b, dtype=torch.int32, device=dev)
+        L.check(lib.pmt_downsample_counts(C.byref(a), self.ref_fracs.data_ptr(), self.alt_fracs.data_ptr(),
+                                          self.ref_counts.data_ptr(), self.alt_counts.data_ptr(), stream), "pmt_downsample_counts")
+        self._offsets = scan(self.ref_counts, self.alt_counts, 4, 1)
+        ref_host, alt_host = p.host_counts()
+        # sized for the parent (an upper bound): the number of kept reads never has to come back to the host
+        self.read_indices = torch.empty(int(ref_host.sum()) + int(alt_host.sum()), dtype=torch.int64, device=dev)
+        L.check(lib.pmt_downsample_index(C.byref(a), self.ref_fracs.data_ptr(), self.alt_fracs.data_ptr(),
+                                         self._offsets[0].data_ptr(), self._offsets[1].data_ptr(),
+                                         self.read_indices.data_ptr(), stream), "pmt_downsample_index")
+        self._host_counts = None
+        self._keep = keep
+        return self
+
     def get(self, field: Data) -> Tensor:
         if field == Data.REF_COUNT:
             return self.ref_counts

@@ -120,6 +120,12 @@ class PmtPhiProgram(C.Structure):
     _fields_ = [("n_segs", i32), ("reserved", i32), ("seg", PmtPhiSeg * MAX_PHI_SEGS)]
 
 
+class PmtDownsample(C.Structure):
+    _fields_ = [("num_variants", i32), ("reference_alt_gather", i32), ("seed", C.c_uint64), ("force_random", i64),
+                ("ref_offsets", vp), ("alt_offsets", vp), ("ref_weights_b4", vp), ("alt_weights_b4", vp),
+                ("ref_fracs_in", vp), ("alt_fracs_in", vp)]
+
+
 class PmtLossArgs(C.Structure):
     _fields_ = [("num_variants", i32), ("num_clusters", i32), ("num_sources", i32), ("reserved", i32),
                 ("max_outlier_logit", C.c_float), ("max_alt_count", C.c_float),
@@ -139,7 +145,8 @@ class PmtLossInputGrads(C.Structure):
 EXPORTS = ["pmt_abi_version", "pmt_struct_bytes", "pmt_model_check", "pmt_build_schedules", "pmt_plan_groups", "pmt_stash_bytes", "pmt_pack_params",
            "pmt_scan_counts", "pmt_forward", "pmt_backward", "pmt_clip_adamw",
            "pmt_rows_stash_bytes", "pmt_rows_forward", "pmt_rows_backward", "pmt_cnn_forward", "pmt_cnn_backward",
-           "pmt_phi_forward", "pmt_phi_backward", "pmt_build_read_index", "pmt_losses_forward", "pmt_losses_backward"]
+           "pmt_phi_forward", "pmt_phi_backward", "pmt_build_read_index", "pmt_losses_forward", "pmt_losses_backward",
+           "pmt_downsample_counts", "pmt_downsample_index"]
 
 _lib = None
 
@@ -182,6 +189,8 @@ def load() -> C.CDLL:
     lib.pmt_rows_forward.argtypes = [P(PmtModel), vp, i32, vp, vp, vp, i64, i32, vp, i64, vp, vp]
     lib.pmt_rows_backward.argtypes = [P(PmtModel), vp, i32, vp, vp, vp, i64, i32, vp, i64, vp, vp, vp, i64, C.c_float, vp]
     lib.pmt_build_read_index.argtypes = [vp, vp, vp, i32, vp, vp]
+    lib.pmt_downsample_counts.argtypes = [P(PmtDownsample), vp, vp, vp, vp, vp]
+    lib.pmt_downsample_index.argtypes = [P(PmtDownsample), vp, vp, vp, vp, vp, vp]
     lib.pmt_losses_forward.argtypes = [P(PmtLossArgs), P(PmtLossOutputs), vp]
     lib.pmt_losses_backward.argtypes = [P(PmtLossArgs), P(PmtLossOutputs), P(PmtLossInputGrads), vp]
     lib.pmt_phi_forward.argtypes = [P(PmtPhiProgram), vp, vp, vp]
@@ -194,7 +203,7 @@ def load() -> C.CDLL:
     if lib.pmt_abi_version() != ABI_VERSION:
         raise PmtError("libpermutect_amd.so ABI version mismatch; rebuild it")
     for which, st in enumerate([PmtModel, PmtBatch, PmtOutputs, PmtOutputGrads, PmtAdamW, PmtLinear, PmtOp, PmtMlp,
-                                PmtBlock, PmtHead, PmtPhiProgram, PmtLossArgs]):
+                                PmtBlock, PmtHead, PmtPhiProgram, PmtLossArgs, PmtDownsample]):
         if lib.pmt_struct_bytes(which) != C.sizeof(st):
             raise PmtError(f"ctypes layout of {st.__name__} ({C.sizeof(st)} B) does not match the library "
                            f"({lib.pmt_struct_bytes(which)} B)")
