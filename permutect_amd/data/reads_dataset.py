@@ -73,6 +73,8 @@ class ReadsDataset:
 
     def num_read_features(self) -> int:
         nb = NUMBER_OF_BYTES_IN_PACKED_READ
+        if self._reads is None:  # a dataset without reads (the posterior hand-off)
+            return 0
         return 8 * nb + (self._reads.shape[-1] - nb) if self._reads is not None and self._reads.dtype == np.uint8 else self._reads.shape[-1]
 
     def num_info_features(self) -> int:

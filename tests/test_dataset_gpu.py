@@ -55,3 +55,30 @@ def test_device_loader_and_downsampling_compose():
         assert torch.allclose(a.logits_b, b.logits_b, rtol=1e-5, atol=1e-5)
         assert torch.isfinite(a.logits_b).all()
     assert total == len(ds) and loader.bytes_uploaded > 0
+
+
+def test_posterior_handoff_matches_per_datum_semantics():
+    """tools/posterior_data.make_posterior_mmap against the reference's per-variant construction (filter_variants.py:
+    302-320) emulated with Datum: counts zeroed, logit through float16 into CACHED_ARTIFACT_LOGIT, info := embedding."""
+    from permutect_amd.data.datum import Data, Datum
+    from permutect_amd.tools.posterior_data import make_posterior_mmap
+    dev = torch.device("cuda:0")
+    ds = _dataset()
+    torch.manual_seed(0)
+    model = ArtifactModel(p0_params(), device=dev, **P0_DIMS)
+    post = make_posterior_mmap(ds, model, batch_size=16, chunk_variants=20)
+    assert len(post) == len(ds) and post.reads_mmap is None and post.num_reads == 0
+    with torch.no_grad():
+        out = model.compute_batch_output(ds.host_batch(np.arange(len(ds))).copy_to(dev))
+    logits, feats = out.logits_b.cpu().numpy(), out.features_be.cpu().numpy()
+    for i in (0, 5, 17, len(ds) - 1):
+        d = Datum(np.array(ds._ints[i]), np.array(ds._floats[i]), np.zeros((0, 12), dtype=np.uint8), compressed=True)
+        d.set(Data.REF_COUNT, 0)
+        d.set(Data.ALT_COUNT, 0)
+        d.set(Data.CACHED_ARTIFACT_LOGIT, logits[i])
+        want_float = np.hstack((d.float_array[:6], feats[i]))
+        np.testing.assert_array_equal(post.int_mmap[i], d.int_array)
+        np.testing.assert_allclose(post.float_mmap[i], want_float, rtol=1e-5, atol=2e-3)  # fp16 logit, atomics-order embedding
+        assert abs(float(post.float_mmap[i][5]) - float(np.float16(logits[i]))) <= 2e-2
+    # the posterior dataset loads like any other (no reads)
+    ReadsDataset(post)
