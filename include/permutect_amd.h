@@ -322,6 +322,27 @@ typedef struct PmtLossInputGrads {
 int pmt_losses_forward(const PmtLossArgs* args, const PmtLossOutputs* out, void* stream);
 int pmt_losses_backward(const PmtLossArgs* args, const PmtLossOutputs* grad_out, const PmtLossInputGrads* grad_in, void* stream);
 
+/* Loss bookkeeping (reference training/loss_recorder.py:15-24, metrics/loss_metrics.py:50-54): adds one step's losses into
+ * six histograms [6][num_bins] = (primary totals, primary counts, alt-count totals, alt-count counts, source totals,
+ * source counts), each a flattened [S][3][V][R][A] tensor indexed by source, label, variant type, ref-count bin,
+ * alt-count bin (reference data/count_binning.py:61-66, data/batch.py:228-230).  One launch instead of 8 index_add_. */
+typedef struct PmtRecordArgs {
+    int32_t num_variants, num_bins;                 /* num_bins = S * 3 * V * R * A */
+    int32_t num_variant_types, num_ref_bins, num_alt_bins, count_bin_skip, max_ref_count, max_alt_count;
+    const int64_t* labels;        int64_t label_stride;
+    const int64_t* variant_types; int64_t variant_type_stride;
+    const int64_t* sources;       int64_t source_stride;        /* NULL = source 0 */
+    const int64_t* ref_counts;    int64_t ref_count_stride;
+    const int64_t* alt_counts;    int64_t alt_count_stride;
+    const float* weights;         /* [B] BatchOutput.weights */
+    const float* source_weights;  /* [B] */
+    const float* supervised_b;    /* [B] the four loss vectors of pmt_losses_forward */
+    const float* unsupervised_b;
+    const float* alt_count_b;
+    const float* source_b;
+} PmtRecordArgs;
+int pmt_record_losses(const PmtRecordArgs* args, float* histograms, void* stream);
+
 /* Fills model->fwd_sched / bwd_sched from the rest of the descriptor (host, in place). */
 int pmt_build_schedules(PmtModel* model);
 

@@ -23,6 +23,7 @@ extern "C" int pmt_struct_bytes(int which) {
         case 10: return (int)sizeof(PmtPhiProgram);
         case 11: return (int)sizeof(PmtLossArgs);
         case 12: return (int)sizeof(PmtDownsample);
+        case 13: return (int)sizeof(PmtRecordArgs);
         default: return PMT_E_INVALID;
     }
 }

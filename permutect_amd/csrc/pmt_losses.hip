@@ -132,3 +132,57 @@ extern "C" int pmt_losses_backward(const PmtLossArgs* args, const PmtLossOutputs
                        reinterpret_cast<hipStream_t>(stream), *args, *grad_out, *grad_in);
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Loss bookkeeping of a training / evaluation step (reference training/loss_recorder.py:15-24, metrics/loss_metrics.py:
+// 50-54): three LossMetrics (primary, alt-count, source), each a (totals, counts) pair of [S][L][V][R][A] histograms
+// indexed by source, label, variant type, ref-count bin and alt-count bin (reference data/count_binning.py).  The
+// reference issues 8 index_add_ launches per step; here one launch bins every variant once, accumulates the six
+// histograms of the workgroup in LDS and adds them to global memory once per workgroup.
+// ---------------------------------------------------------------------------------------------------------------------
+#define REC_THREADS 256
+#define REC_MAX_BINS 2048  // S * 3 * 5 * 4 * 5 = 300 S floats per histogram: up to 6 sources
+
+__global__ __launch_bounds__(REC_THREADS) void pmt_record_losses_kernel(PmtRecordArgs a, float* __restrict__ hist) {
+    __shared__ float sh[6][REC_MAX_BINS];
+    const int nb = a.num_bins;
+    for (int i = threadIdx.x; i < 6 * REC_MAX_BINS; i += REC_THREADS) (&sh[0][0])[i] = 0.f;
+    __syncthreads();
+    const int b = blockIdx.x * REC_THREADS + threadIdx.x;
+    if (b < a.num_variants) {
+        const long long label = a.labels[(size_t)b * a.label_stride], vt = a.variant_types[(size_t)b * a.variant_type_stride];
+        const long long src = a.sources ? a.sources[(size_t)b * a.source_stride] : 0;
+        const long long nr = a.ref_counts[(size_t)b * a.ref_count_stride], na = a.alt_counts[(size_t)b * a.alt_count_stride];
+        const int rbin = (int)min(nr, (long long)a.max_ref_count) / a.count_bin_skip;
+        const int abin = ((int)min(na, (long long)a.max_alt_count) - 1) / a.count_bin_skip;
+        const int idx = (int)((((src * 3 + label) * a.num_variant_types + vt) * a.num_ref_bins + rbin) * a.num_alt_bins + abin);
+        if (idx >= 0 && idx < nb) {
+            const float is_labeled = label != 2 ? 1.f : 0.f;
+            const float w = a.weights[b], sw = a.source_weights[b];
+            const float lw = is_labeled * w, uw = (1.f - is_labeled) * w;
+            atomicAdd(&sh[0][idx], a.supervised_b[b] * lw + a.unsupervised_b[b] * uw);  // primary totals
+            atomicAdd(&sh[1][idx], lw + uw);                                              // primary counts
+            atomicAdd(&sh[2][idx], a.alt_count_b[b] * w);                                 // alt-count totals
+            atomicAdd(&sh[3][idx], w);                                                    // alt-count counts
+            atomicAdd(&sh[4][idx], a.source_b[b] * sw);                                   // source totals
+            atomicAdd(&sh[5][idx], sw);                                                   // source counts
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 6 * nb; i += REC_THREADS) {
+        const int hsel = i / nb, j = i - hsel * nb;
+        const float v = sh[hsel][j];
+        if (v != 0.f) atomicAdd(&hist[(size_t)hsel * nb + j], v);
+    }
+}
+
+extern "C" int pmt_record_losses(const PmtRecordArgs* args, float* histograms, void* stream) {
+    if (!args || !histograms || args->num_variants < 0 || args->num_bins < 1 || args->num_bins > REC_MAX_BINS) return PMT_E_INVALID;
+    if (args->num_variants == 0) return PMT_OK;
+    if (!args->labels || !args->variant_types || !args->ref_counts || !args->alt_counts || !args->weights || !args->source_weights ||
+        !args->supervised_b || !args->unsupervised_b || !args->alt_count_b || !args->source_b || args->count_bin_skip < 1)
+        return PMT_E_INVALID;
+    hipLaunchKernelGGL(pmt_record_losses_kernel, dim3((args->num_variants + REC_THREADS - 1) / REC_THREADS), dim3(REC_THREADS), 0,
+                       reinterpret_cast<hipStream_t>(stream), *args, histograms);
+    return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
+}

@@ -126,6 +126,15 @@ class PmtDownsample(C.Structure):
                 ("ref_fracs_in", vp), ("alt_fracs_in", vp)]
 
 
+class PmtRecordArgs(C.Structure):
+    _fields_ = [("num_variants", i32), ("num_bins", i32), ("num_variant_types", i32), ("num_ref_bins", i32),
+                ("num_alt_bins", i32), ("count_bin_skip", i32), ("max_ref_count", i32), ("max_alt_count", i32),
+                ("labels", vp), ("label_stride", i64), ("variant_types", vp), ("variant_type_stride", i64),
+                ("sources", vp), ("source_stride", i64), ("ref_counts", vp), ("ref_count_stride", i64),
+                ("alt_counts", vp), ("alt_count_stride", i64), ("weights", vp), ("source_weights", vp),
+                ("supervised_b", vp), ("unsupervised_b", vp), ("alt_count_b", vp), ("source_b", vp)]
+
+
 class PmtLossArgs(C.Structure):
     _fields_ = [("num_variants", i32), ("num_clusters", i32), ("num_sources", i32), ("reserved", i32),
                 ("max_outlier_logit", C.c_float), ("max_alt_count", C.c_float),
@@ -146,7 +155,7 @@ EXPORTS = ["pmt_abi_version", "pmt_struct_bytes", "pmt_model_check", "pmt_build_
            "pmt_scan_counts", "pmt_forward", "pmt_backward", "pmt_clip_adamw",
            "pmt_rows_stash_bytes", "pmt_rows_forward", "pmt_rows_backward", "pmt_cnn_forward", "pmt_cnn_backward",
            "pmt_phi_forward", "pmt_phi_backward", "pmt_build_read_index", "pmt_losses_forward", "pmt_losses_backward",
-           "pmt_downsample_counts", "pmt_downsample_index"]
+           "pmt_downsample_counts", "pmt_downsample_index", "pmt_record_losses"]
 
 _lib = None
 
@@ -189,6 +198,7 @@ def load() -> C.CDLL:
     lib.pmt_rows_forward.argtypes = [P(PmtModel), vp, i32, vp, vp, vp, i64, i32, vp, i64, vp, vp]
     lib.pmt_rows_backward.argtypes = [P(PmtModel), vp, i32, vp, vp, vp, i64, i32, vp, i64, vp, vp, vp, i64, C.c_float, vp]
     lib.pmt_build_read_index.argtypes = [vp, vp, vp, i32, vp, vp]
+    lib.pmt_record_losses.argtypes = [P(PmtRecordArgs), vp, vp]
     lib.pmt_downsample_counts.argtypes = [P(PmtDownsample), vp, vp, vp, vp, vp]
     lib.pmt_downsample_index.argtypes = [P(PmtDownsample), vp, vp, vp, vp, vp, vp]
     lib.pmt_losses_forward.argtypes = [P(PmtLossArgs), P(PmtLossOutputs), vp]
@@ -203,7 +213,7 @@ def load() -> C.CDLL:
     if lib.pmt_abi_version() != ABI_VERSION:
         raise PmtError("libpermutect_amd.so ABI version mismatch; rebuild it")
     for which, st in enumerate([PmtModel, PmtBatch, PmtOutputs, PmtOutputGrads, PmtAdamW, PmtLinear, PmtOp, PmtMlp,
-                                PmtBlock, PmtHead, PmtPhiProgram, PmtLossArgs, PmtDownsample]):
+                                PmtBlock, PmtHead, PmtPhiProgram, PmtLossArgs, PmtDownsample, PmtRecordArgs]):
         if lib.pmt_struct_bytes(which) != C.sizeof(st):
             raise PmtError(f"ctypes layout of {st.__name__} ({C.sizeof(st)} B) does not match the library "
                            f"({lib.pmt_struct_bytes(which)} B)")

@@ -1,0 +1,90 @@
+"""Loss bookkeeping and the evaluation pass (reference training/loss_recorder.py, metrics/loss_metrics.py:31-60,
+training/model_training.py:204-271).
+
+`LossRecorder.record` adds a step's four loss vectors, weighted like the reference, into the three (totals, counts)
+histograms over (source, label, variant type, ref-count bin, alt-count bin) with ONE launch (pmt_record_losses) instead of
+8 index_add_; nothing is copied to the host until `averages()` / `mean_loss()` are asked for at the end of the epoch
+(the reference's `put_on_cpu`).  `evaluate` is the no-grad pass of an evaluation epoch: forward kernels + losses +
+recording per batch, no per-step `.item()`."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from permutect_amd.data.datum import Data
+from permutect_amd.engine import lib as L
+from permutect_amd.enums import Label, Variation
+from permutect_amd.training.downsampler import (COUNT_BIN_SKIP, MAX_ALT_COUNT, MAX_REF_COUNT, NUM_ALT_COUNT_BINS,
+                                                NUM_REF_COUNT_BINS)
+
+PRIMARY, ALT_COUNT, SOURCE = 0, 1, 2
+
+
+class LossRecorder:
+    def __init__(self, device, num_sources: int):
+        self.device, self.num_sources = torch.device(device), num_sources
+        self.shape = (num_sources, len(Label), len(Variation), NUM_REF_COUNT_BINS, NUM_ALT_COUNT_BINS)
+        self.num_bins = 1
+        for d in self.shape:
+            self.num_bins *= d
+        # [metric][totals | counts][bins]
+        self.hist = torch.zeros(3, 2, self.num_bins, dtype=torch.float32, device=self.device)
+
+    def record(self, output, losses, batch):
+        a = L.PmtRecordArgs()
+        a.num_variants, a.num_bins = batch.size(), self.num_bins
+        a.num_variant_types, a.num_ref_bins, a.num_alt_bins = len(Variation), NUM_REF_COUNT_BINS, NUM_ALT_COUNT_BINS
+        a.count_bin_skip, a.max_ref_count, a.max_alt_count = COUNT_BIN_SKIP, MAX_REF_COUNT, MAX_ALT_COUNT
+        keep = []
+
+        def col(field):
+            t = batch.get(field)
+            t = t if t.dtype == torch.int64 else t.long()
+            keep.append(t)
+            return t.data_ptr(), t.stride(0)
+
+        a.labels, a.label_stride = col(Data.LABEL)
+        a.variant_types, a.variant_type_stride = col(Data.VARIANT_TYPE)
+        a.sources, a.source_stride = col(Data.SOURCE)
+        a.ref_counts, a.ref_count_stride = col(Data.REF_COUNT)
+        a.alt_counts, a.alt_count_stride = col(Data.ALT_COUNT)
+        vecs = [output.weights, output.source_weights, losses.supervised_losses_b, losses.unsupervised_losses_b,
+                losses.alt_count_losses_b, losses.source_prediction_losses_b]
+        vecs = [v.detach().contiguous().float() for v in vecs]
+        keep.extend(vecs)
+        (a.weights, a.source_weights, a.supervised_b, a.unsupervised_b, a.alt_count_b, a.source_b) = [v.data_ptr() for v in vecs]
+        L.check(L.load().pmt_record_losses(C.byref(a), self.hist.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                "pmt_record_losses")
+
+    # ---- read-out (one device -> host copy, at the end of the epoch) -----------------------------------------------------
+    def totals(self, metric: int = PRIMARY) -> torch.Tensor:
+        return self.hist[metric, 0].view(self.shape)
+
+    def counts(self, metric: int = PRIMARY) -> torch.Tensor:
+        return self.hist[metric, 1].view(self.shape)
+
+    def averages(self, metric: int = PRIMARY) -> torch.Tensor:
+        """reference loss_metrics.py:56-57"""
+        return self.totals(metric) / (0.001 + self.counts(metric))
+
+    def mean_loss(self, metric: int = PRIMARY) -> float:
+        """total / count over all bins: what the training loop feeds its LR scheduler (reference model_training.py:170)."""
+        return float((self.totals(metric).sum() / self.counts(metric).sum().clamp_min(1e-12)).item())
+
+    def all_reduce(self, dist):
+        """Sum the histograms over data-parallel ranks before the epoch-level decisions."""
+        dist.all_reduce(self.hist, op=dist.ReduceOp.SUM)
+
+
+@torch.inference_mode()
+def evaluate(model, loader, num_sources: int = 1, balancer=None) -> LossRecorder:
+    """One evaluation pass over `loader` (reference model_training.py:204-271's validation epoch without the plots)."""
+    was_training = model.training
+    model.train(False)
+    rec = LossRecorder(model._device, num_sources)
+    for batch in loader:
+        out = model.compute_batch_output(batch, balancer)
+        rec.record(out, model.compute_batch_losses(out, batch), batch)
+    model.train(was_training)
+    return rec

@@ -82,3 +82,36 @@ def test_posterior_handoff_matches_per_datum_semantics():
         assert abs(float(post.float_mmap[i][5]) - float(np.float16(logits[i]))) <= 2e-2
     # the posterior dataset loads like any other (no reads)
     ReadsDataset(post)
+
+
+def test_loss_recorder_kernel_matches_index_add():
+    """pmt_record_losses (one launch) against the reference's eight index_add_ into [S, L, V, R, A] histograms."""
+    from permutect_amd.data.datum import Data
+    from permutect_amd.training.downsampler import flattened_slvra_index
+    from permutect_amd.training.loss_recorder import ALT_COUNT, PRIMARY, SOURCE, LossRecorder, evaluate
+    dev = torch.device("cuda:0")
+    ds = _dataset()
+    torch.manual_seed(0)
+    model = ArtifactModel(p0_params(), device=dev, **P0_DIMS)
+    rec = LossRecorder(dev, num_sources=2)
+    want = torch.zeros(3, 2, rec.num_bins, device=dev, dtype=torch.float64)
+    for batch in ds.device_loader(16, dev, chunk_variants=20, shuffle=False):
+        with torch.no_grad():
+            out = model.compute_batch_output(batch)
+            out.weights = 0.5 + torch.rand(batch.size(), device=dev)
+            out.source_weights = 0.5 + torch.rand(batch.size(), device=dev)
+            losses = model.compute_batch_losses(out, batch)
+        rec.record(out, losses, batch)
+        idx = flattened_slvra_index(batch)
+        il = batch.get_is_labeled_mask().double()
+        w, sw = out.weights.double(), out.source_weights.double()
+        want[PRIMARY, 0].index_add_(0, idx, losses.supervised_losses_b.double() * il * w + losses.unsupervised_losses_b.double() * (1 - il) * w)
+        want[PRIMARY, 1].index_add_(0, idx, w)
+        want[ALT_COUNT, 0].index_add_(0, idx, losses.alt_count_losses_b.double() * w)
+        want[ALT_COUNT, 1].index_add_(0, idx, w)
+        want[SOURCE, 0].index_add_(0, idx, losses.source_prediction_losses_b.double() * sw)
+        want[SOURCE, 1].index_add_(0, idx, sw)
+    np.testing.assert_allclose(rec.hist.cpu().numpy(), want.float().cpu().numpy(), rtol=1e-5, atol=1e-5)
+    assert rec.mean_loss() > 0 and rec.averages().shape == (2, 3, 5, 4, 5)
+    ev = evaluate(model, ds.device_loader(16, dev, chunk_variants=20, shuffle=False), num_sources=2)
+    assert abs(float(ev.counts().sum()) - len(ds)) < 1e-3
