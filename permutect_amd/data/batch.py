@@ -263,7 +263,8 @@ class DownsampledBatch(Batch):
         self._offsets = scan(self.ref_counts, self.alt_counts, 4, 1)
         ref_host, alt_host = p.host_counts()
         # sized for the parent (an upper bound): the number of kept reads never has to come back to the host
-        self.read_indices = torch.empty(int(ref_host.sum()) + int(alt_host.sum()), dtype=torch.int64, device=dev)
+        # (zero-filled: the unused tail must stay a valid row index, it is composed with a parent's gather index)
+        self.read_indices = torch.zeros(int(ref_host.sum()) + int(alt_host.sum()), dtype=torch.int64, device=dev)
         L.check(lib.pmt_downsample_index(C.byref(a), self.ref_fracs.data_ptr(), self.alt_fracs.data_ptr(),
                                          self._offsets[0].data_ptr(), self._offsets[1].data_ptr(),
                                          self.read_indices.data_ptr(), stream), "pmt_downsample_index")

@@ -83,6 +83,17 @@ T0_CNN = [
 ]
 
 
+class TrainingParameters:
+    """reference parameters.py:160-177"""
+
+    def __init__(self, batch_size: int, num_epochs: int, learning_rate: float = 0.001, weight_decay: float = 0.01,
+                 num_workers: int = 0, num_calibration_epochs: int = 0, inference_batch_size: int = 8192):
+        self.batch_size, self.num_epochs = batch_size, num_epochs
+        self.learning_rate, self.weight_decay = learning_rate, weight_decay
+        self.num_workers, self.num_calibration_epochs = num_workers, num_calibration_epochs
+        self.inference_batch_size = inference_batch_size
+
+
 def p0_params() -> ModelParameters:
     """Production-shaped hyperparameters: 59 845 parameters with F=61, I=71, H=42."""
     return ModelParameters([30, -2, -2, -2], 20, 6, [20, -2, -2, -2], [-2, -2, 10], 4, [10, 10], list(P0_CNN), 0.0, 0.3)

@@ -1,0 +1,140 @@
+"""`train_artifact_model` (reference permutect/training/model_training.py:49-201) on the device engine.
+
+Same structure as the reference: `num_epochs` training epochs (+ calibration epochs that only fit the calibration
+parameters), every parent batch downsampled twice, balancer weights, the adversarial source strength ramp, loss
+bookkeeping per (source, label, variant type, count bins), ReduceLROnPlateau on the epoch's mean loss, best-checkpoint
+keep/rollback, a validation pass per epoch.  What differs is where the work happens: batches are composed on the device
+from HBM-resident chunks, downsampling is two launches, forward / losses / backward / clip + AdamW are the fused kernels,
+and the only host synchronisations are one per epoch (mean loss for the scheduler and the checkpoint decision).  Plots,
+tensorboard and the worst-offender report of the reference are out of scope."""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+
+from permutect_amd.data.reads_dataset import ReadsDataset
+from permutect_amd.enums import Epoch
+from permutect_amd.parameters import TrainingParameters
+from permutect_amd.training.balancer import Balancer
+from permutect_amd.training.distributed import GradAllReduce
+from permutect_amd.training.downsampler import Downsampler
+from permutect_amd.training.loss_recorder import PRIMARY, LossRecorder
+from permutect_amd.training.optimizer import FusedClipAdamW, backpropagate
+
+
+class PlateauScheduler:
+    """torch.optim.lr_scheduler.ReduceLROnPlateau(mode='min', threshold_mode='rel') for an optimizer exposing param_groups
+    (reference model_training.py:74-80: factor 0.2, patience 5, threshold 1e-3, min_lr = lr / 100)."""
+
+    def __init__(self, optimizer, factor=0.2, patience=5, threshold=1e-3, min_lr=0.0):
+        self.opt, self.factor, self.patience, self.threshold, self.min_lr = optimizer, factor, patience, threshold, min_lr
+        self.best, self.bad = math.inf, 0
+
+    def step(self, metric: float):
+        if metric < self.best * (1 - self.threshold):
+            self.best, self.bad = metric, 0
+        else:
+            self.bad += 1
+        if self.bad > self.patience:
+            for g in self.opt.param_groups:
+                g["lr"] = max(g["lr"] * self.factor, self.min_lr)
+            self.bad = 0
+
+
+class Checkpoint:
+    """Keep the best model (by training mean loss) and roll back when the loss blows up (reference training/checkpoint.py)."""
+
+    def __init__(self, model, optimizer):
+        self.model, self.opt = model, optimizer
+        self.best_loss, self.state, self.opt_state = math.inf, None, None
+
+    def save_checkpoint_if_needed(self, epoch: int, loss: float):
+        if loss < self.best_loss:
+            self.best_loss = loss
+            self.state = self.model.engine().space.theta.detach().clone()
+            self.opt_state = self.opt.state_dict()
+
+    def load_checkpoint_if_needed(self, loss: float):
+        if self.state is not None and (not math.isfinite(loss) or loss > 2 * self.best_loss):
+            with torch.no_grad():
+                self.model.engine().space.theta.copy_(self.state)
+            self.opt.load_state_dict(self.opt_state)
+            return True
+        return False
+
+
+def train_artifact_model(model, train_dataset: ReadsDataset, valid_dataset: Optional[ReadsDataset],
+                         training_params: TrainingParameters, chunk_variants: Optional[int] = 1 << 18, seed: int = 0,
+                         dist=None, log=print):
+    device = model._device
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
+    num_sources = train_dataset.num_sources()
+    balancer = Balancer(num_sources=num_sources, device=device)
+    downsampler = Downsampler(num_sources=num_sources).to(device)
+    model.reset_source_predictor(num_sources)
+    opt = FusedClipAdamW(model, lr=training_params.learning_rate, weight_decay=training_params.weight_decay)
+    scheduler = PlateauScheduler(opt, min_lr=training_params.learning_rate / 100)
+    checkpoint = Checkpoint(model, opt)
+    reduce_grads = GradAllReduce() if dist is not None else None
+    rng = np.random.default_rng(seed + rank)
+    history = []
+    last_epoch = training_params.num_epochs + training_params.num_calibration_epochs
+    step_seed = seed * 1_000_003 + rank
+
+    for epoch in range(1, last_epoch + 1):
+        is_calibration = epoch > training_params.num_epochs
+        model.source_predictor.set_adversarial_strength((2 / (1 + math.exp(-0.1 * (epoch - 1)))) - 1)
+        for epoch_type in (Epoch.TRAIN, Epoch.VALID):
+            dataset = train_dataset if epoch_type == Epoch.TRAIN else valid_dataset
+            if dataset is None:
+                continue
+            model.set_epoch_type(epoch_type)
+            recorder = LossRecorder(device, num_sources)
+            cal_opt = None
+            if is_calibration and epoch_type == Epoch.TRAIN:  # only the calibration parameters move (reference :145-147)
+                cal_opt = torch.optim.AdamW(model.calibration_parameters(), lr=opt.param_groups[0]["lr"],
+                                            weight_decay=opt.param_groups[0]["weight_decay"])
+            loader = dataset.device_loader(training_params.batch_size, device, chunk_variants=chunk_variants, rng=rng,
+                                           shuffle=epoch_type == Epoch.TRAIN, rank=rank, world_size=world)
+            # data parallel: every rank must take the same number of optimizer steps (one all-reduce each)
+            max_batches = None
+            if dist is not None and epoch_type == Epoch.TRAIN:
+                max_batches = min(len(dataset.device_loader(training_params.batch_size, device, chunk_variants=chunk_variants,
+                                                            shuffle=False, rank=r, world_size=world)) for r in range(world))
+            for n_parent, parent in enumerate(loader):
+                if max_batches is not None and n_parent >= max_batches:
+                    break
+                for _ in range(2):  # two independent downsamplings of every parent batch (reference :153)
+                    step_seed += 1
+                    batch = downsampler.downsample(parent, seed=step_seed)
+                    with torch.set_grad_enabled(epoch_type == Epoch.TRAIN):
+                        output = model.compute_batch_output(batch, balancer)
+                        losses = model.compute_batch_losses(output, batch)
+                    recorder.record(output, losses, batch)
+                    if epoch_type == Epoch.TRAIN:
+                        if cal_opt is not None:
+                            cal_opt.zero_grad(set_to_none=True)
+                            model.engine().space.gtheta.zero_()
+                            model.engine().space.bind_grads()
+                            losses.total_loss.backward()
+                            torch.nn.utils.clip_grad_norm_(model.calibration_parameters(), max_norm=1.0)
+                            cal_opt.step()
+                        else:
+                            opt.zero_grad()
+                            losses.total_loss.backward()
+                            opt.step(pre_reduce=reduce_grads)
+            if dist is not None:
+                recorder.all_reduce(dist)
+            mean_loss = recorder.mean_loss(PRIMARY)  # the epoch's one host sync
+            history.append((epoch, epoch_type.name, mean_loss))
+            log(f"epoch {epoch} {epoch_type.name}: mean semisupervised loss {mean_loss:.5f}, lr {opt.param_groups[0]['lr']:.2e}")
+            if epoch_type == Epoch.TRAIN:
+                scheduler.step(mean_loss)
+                if not is_calibration:
+                    checkpoint.save_checkpoint_if_needed(epoch, mean_loss)
+                    if checkpoint.load_checkpoint_if_needed(mean_loss):
+                        log(f"epoch {epoch}: loss diverged, restored the best checkpoint")
+    return history

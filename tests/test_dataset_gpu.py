@@ -115,3 +115,28 @@ def test_loss_recorder_kernel_matches_index_add():
     assert rec.mean_loss() > 0 and rec.averages().shape == (2, 3, 5, 4, 5)
     ev = evaluate(model, ds.device_loader(16, dev, chunk_variants=20, shuffle=False), num_sources=2)
     assert abs(float(ev.counts().sum()) - len(ds)) < 1e-3
+
+
+def test_train_artifact_model_loop_end_to_end():
+    """The reference's training loop shape (model_training.py:49-201) on the engine: device-composed batches, two fused
+    downsamplings per parent batch, balancer, recorder, scheduler, checkpoint, a calibration epoch that moves only the
+    calibration parameters."""
+    from permutect_amd.data.reads_dataset import all_but_last_fold, last_fold_only
+    from permutect_amd.parameters import TrainingParameters
+    from permutect_amd.training.model_training import train_artifact_model
+    dev = torch.device("cuda:0")
+    mm = MemoryMappedData.load_from_tarfile(os.path.join(GOLDEN, "tiny_dataset.tar"))
+    train = ReadsDataset(mm, num_folds=5, folds_to_use=all_but_last_fold(5))
+    valid = ReadsDataset(mm, num_folds=5, folds_to_use=last_fold_only(5))
+    assert len(train) + len(valid) == len(mm)
+    torch.manual_seed(0)
+    model = ArtifactModel(p0_params(), device=dev, **P0_DIMS)
+    logs = []
+    hist = train_artifact_model(model, train, valid, TrainingParameters(batch_size=16, num_epochs=2, num_calibration_epochs=1,
+                                                                        learning_rate=1e-3), chunk_variants=24, seed=1, log=logs.append)
+    assert [h[:2] for h in hist] == [(1, "TRAIN"), (1, "VALID"), (2, "TRAIN"), (2, "VALID"), (3, "TRAIN"), (3, "VALID")]
+    assert all(np.isfinite(h[2]) and h[2] > 0 for h in hist) and len(logs) == 6
+    # the model still produces finite outputs after training
+    with torch.no_grad():
+        out = model.compute_batch_output(valid.host_batch(np.arange(len(valid))).copy_to(dev))
+    assert torch.isfinite(out.logits_b).all()
