@@ -161,6 +161,10 @@ class ArtifactModel(nn.Module):
 
     def _encode(self, batch: Batch):
         eng = self.engine()
+        if batch.size() == 0:  # nothing to launch
+            d, dev = eng.plan.desc, self._device
+            z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)  # noqa: E731
+            return (z(0), z(0, d.num_clusters + 2), z(0, d.feature_dim), z(0, d.feature_dim)), z(0, d.variant_embed_dim)
         prog = eng.plan.phi_program(self)
         phi = eng.plan.materialize_phi(self) if prog is None else PhiFunction.apply(eng, prog, eng.trigger)
         eng.pack(phi.detach().contiguous())  # weights -> MFMA fragment order, once per forward, before any kernel uses them

@@ -85,3 +85,52 @@ def test_forward_matches_oracle_on_fresh_inputs(name):
                                      torch.from_numpy(floats[:, 6:].astype(np.float32)), torch.from_numpy(ints[:, 16:].astype(np.int64)))
     z = {"out/" + k: v.numpy() for k, v in ref.items()}
     check_outputs(out, z, name)
+
+
+def _arrays(nref, nalt, seed=7):
+    rng = np.random.default_rng(seed)
+    nb = len(nref)
+    ints = np.zeros((nb, 16 + 42), dtype=np.int16)
+    ints[:, 0], ints[:, 1], ints[:, 2] = nref, nalt, rng.integers(0, 3, nb)
+    ints[:, 16:] = rng.integers(0, 5, (nb, 42))
+    floats = np.zeros((nb, 6 + 71), dtype=np.float16)
+    floats[:, 6:] = rng.standard_normal((nb, 71)).astype(np.float16)
+    packed = rng.integers(0, 256, (int(np.sum(nref) + np.sum(nalt)), 12), dtype=np.uint8)
+    return ints, floats, packed
+
+
+def test_sets_at_the_group_capacity_boundary_match_oracle():
+    """Read sets that fill a whole workgroup (8 + 8 tiles, 16 + 0, 1 + 15 waves' worth), neighbours that must start a new
+    group, zero-ref sets and single-read sets in one batch; forward and input-side gradients against the oracle."""
+    _, sd, _ = load_case("p0_b16")
+    cfg = config_for("p0_b16")
+    nref = np.array([128, 0, 256, 3, 16, 0, 1, 127, 10])
+    nalt = np.array([128, 256, 0 + 1, 1, 224, 1, 15, 113, 15])
+    nalt[2] = 1  # 256 ref + 1 alt does not fit (16 + 1 tiles): use 240 + 1
+    nref[2] = 224
+    ints, floats, packed = _arrays(nref, nalt)
+    model, dev = build("p0_b16", sd)
+    batch = Batch.from_arrays(ints, floats, packed).copy_to(dev)
+    plan = batch.plan()
+    assert plan.num_groups >= 6
+    with torch.no_grad():
+        out = model.compute_batch_output(batch)
+        ref = O.compute_batch_output(sd, cfg, torch.from_numpy(O.decode_packed_reads(packed).astype(np.float32)),
+                                     torch.from_numpy(nref), torch.from_numpy(nalt),
+                                     torch.from_numpy(floats[:, 6:].astype(np.float32)), torch.from_numpy(ints[:, 16:].astype(np.int64)))
+    z = {"out/" + k: v.numpy() for k, v in ref.items()}
+    check_outputs(out, z, "p0_deep")
+
+
+def test_capacity_error_and_empty_batch():
+    _, sd, _ = load_case("p0_b16")
+    model, dev = build("p0_b16", sd)
+    from permutect_amd.engine.lib import PmtError
+    ints, floats, packed = _arrays(np.array([3, 241]), np.array([2, 17]))  # 16 + 2 tiles: more than a workgroup holds
+    with pytest.raises(PmtError, match="variant 1"):
+        Batch.from_arrays(ints, floats, packed).plan()
+    ints, floats, packed = _arrays(np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64))
+    empty = Batch.from_arrays(ints, floats, packed).copy_to(dev)
+    with torch.no_grad():
+        out = model.compute_batch_output(empty)
+    assert out.logits_b.shape == (0,) and out.features_be.shape[0] == 0
