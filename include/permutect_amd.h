@@ -200,6 +200,10 @@ typedef struct PmtBatch {
     int64_t total_tiles;            /* host value of group_tile_base[G] (sizes the stash)             */
     int32_t* debug_flags;           /* device, optional [64]: [0] counts weight-staging schedule misses, [1] development
                                        switches of the backward kernel (0 in production), [8:56] 24 x u64 cycle counters */
+    const int32_t* group_span;      /* device [G][6] or NULL.  With it a group may cover only PART of a read set (read sets
+                                       beyond one workgroup, pmt_plan_groups_split): v0, v1 (variants [v0, v1)), ref_begin,
+                                       ref_end, alt_begin, alt_end (rows of the batch's ref / alt regions); group_start is
+                                       then ignored.  Only pmt_forward_layered accepts it. */
 } PmtBatch;
 
 typedef struct PmtOutputs {
@@ -354,6 +358,27 @@ int pmt_build_schedules(PmtModel* model);
  * (*bad_variant receives its index). */
 int pmt_plan_groups(const int32_t* ref_counts, const int32_t* alt_counts, int32_t num_variants,
                     int32_t* group_start, int32_t* group_tile_base, int32_t* bad_variant);
+
+/* Like pmt_plan_groups, but a variant whose reads exceed one workgroup is split over several groups (each a run of whole
+ * tiles of its ref rows and / or alt rows).  span: host [max_groups][6] (PmtBatch.group_span), tile_base: host
+ * [max_groups + 1].  *needs_layered is set when some group covers only part of a read set (then only pmt_forward_layered
+ * can run the batch).  Returns the number of groups or PMT_E_WORKSPACE if max_groups is too small. */
+int pmt_plan_groups_split(const int32_t* ref_counts, const int32_t* alt_counts, int32_t num_variants, int32_t* span,
+                          int32_t* tile_base, int32_t max_groups, int32_t* needs_layered);
+
+/* Floats of scratch pmt_forward_layered needs. */
+size_t pmt_layered_scratch_floats(const PmtModel* model, int64_t total_tiles, int32_t num_variants);
+
+/* The forward for batches with read sets of ANY size (BASELINE config: 600 reads per variant): the same kernel, run as
+ * num_blocks + 1 launches.  A read set couples its reads only through per-set sums (the gating mean fields of every block,
+ * reference gated_mlp.py:236-239, and the head's sums, feature_clustering.py:111-113); launch s finishes block s - 1 from
+ * the complete sums and starts block s, the sums accumulate in HBM with float atomics, activations rest in `scratch` between
+ * launches, and a last launch finalises the per-set outputs.  Same results as pmt_forward on batches it accepts.
+ * `stash` (optional) as in pmt_forward.  Inference and the training forward; the backward for split read sets is not
+ * implemented (pmt_backward rejects group_span). */
+int pmt_forward_layered(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* phi,
+                        const float* packed, const PmtBatch* batch, const PmtOutputs* out, float* stash, float* scratch,
+                        void* stream);
 
 /* Bytes of activation stash a training forward needs for `total_tiles` tiles (group_tile_base[G]) and B variants. */
 size_t pmt_stash_bytes(const PmtModel* model, int64_t total_tiles, int32_t num_variants);

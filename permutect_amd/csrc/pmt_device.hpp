@@ -234,13 +234,23 @@ DEV bool group_fits(int tiles_ref, int tiles_alt) {
 
 DEV GroupGeom group_geometry(const PmtBatch& bt, int group) {
     GroupGeom gg;
-    gg.v0 = bt.group_start[group];
-    const int v1 = bt.group_start[group + 1];
-    gg.nsets = v1 - gg.v0;
-    gg.ref_base = bt.ref_offsets[gg.v0];
-    gg.nref = bt.ref_offsets[v1] - gg.ref_base;
-    gg.alt_base = bt.alt_offsets[gg.v0];
-    gg.nalt = bt.alt_offsets[v1] - gg.alt_base;
+    if (bt.group_span != nullptr) {  // explicit row ranges: the group may cover only part of a read set
+        const int* sp = bt.group_span + 6 * (size_t)group;
+        gg.v0 = sp[0];
+        gg.nsets = sp[1] - sp[0];
+        gg.ref_base = sp[2];
+        gg.nref = sp[3] - sp[2];
+        gg.alt_base = sp[4];
+        gg.nalt = sp[5] - sp[4];
+    } else {
+        gg.v0 = bt.group_start[group];
+        const int v1 = bt.group_start[group + 1];
+        gg.nsets = v1 - gg.v0;
+        gg.ref_base = bt.ref_offsets[gg.v0];
+        gg.nref = bt.ref_offsets[v1] - gg.ref_base;
+        gg.alt_base = bt.alt_offsets[gg.v0];
+        gg.nalt = bt.alt_offsets[v1] - gg.alt_base;
+    }
     gg.total_ref = bt.ref_offsets[bt.num_variants];
     gg.tiles_ref = (gg.nref + 15) >> 4;
     gg.tiles_alt = (gg.nalt + 15) >> 4;

@@ -45,14 +45,25 @@ DEV float logerfc_dev(float z) {
     return z > 5.f ? asym : builtin;
 }
 
-template <bool TRAIN, typename S>
+// Layered execution (pmt_forward_layered): launch `slice` finishes block slice - 1 and starts block slice; per-set sums
+// live in HBM (zsum_g / fsum_g / hsum_g, float atomics), activations rest in x_scratch / z_scratch between launches.
+struct PmtLayeredArgs {
+    int slice;
+    float* x_scratch;   // [total_tiles][PMT_SLOT_FLOATS]
+    float* z_scratch;   // [total_tiles][512]: z1 (after SELU) and z2 (after SELU + LayerNorm)
+    float* zsum_g;      // [B][L][32] (the training stash's per-set z2 sums have the same layout and ARE this buffer)
+    float* fsum_g;      // [B][2][PMT_MAX_WIDTH]
+    float* hsum_g;      // [B][PMT_MAX_CLUSTERS + 2]
+};
+
+template <bool TRAIN, typename S, bool LAYERED = false>
 __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_kernel(const PmtModel* __restrict__ M,
                                                                       const float* __restrict__ theta,
                                                                       const float* __restrict__ phi,
                                                                       const float* __restrict__ packed, PmtBatch bt,
                                                                       PmtOutputs out, float* __restrict__ stash,
                                                                       float* __restrict__ zsum_stash,
-                                                                      float* __restrict__ rstd_stash) {
+                                                                      float* __restrict__ rstd_stash, PmtLayeredArgs lay) {
     constexpr int NTF = S::NTF, NTR = S::NTR, NTD = S::NTD, NTE = S::NTE;
     constexpr bool EX = S::EXACT;
     static_assert(EX || (NTF == NTD && NTR == NTD && NTE == NTD), "the generic shape keeps one array width");
@@ -95,7 +106,16 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
 
     // ---- decode the packed read rows straight into the B-operand layout, then the read MLP -------------------------
     f4 x[PMT_RT][NTD];
-    {
+    const size_t tile_global = (size_t)(bt.group_tile_base[blockIdx.x] + gg.tile_begin);
+    if (LAYERED && lay.slice > 0) {  // resume: activations of the previous launch
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt) {
+#pragma unroll
+            for (int t = 0; t < NTD; ++t) x[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
+            if (mask_all & (1u << rt)) stash_load<NTD>(lay.x_scratch + (tile_global + rt) * PMT_SLOT_FLOATS, x[rt]);
+        }
+        slot = (n_read_ops - 1) + lay.slice;
+    } else {
         f4 xf[PMT_RT][NTF];
         const int fmt = bt.read_format;
 #pragma unroll
@@ -128,6 +148,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
     }
 
     // ---- broadcast-concat of the per-variant embedding (reference artifact_model.py:246-251) --------------------
+    if (!(LAYERED && lay.slice > 0)) {
 #pragma unroll
     for (int rt = 0; rt < PMT_RT; ++rt) {
         const float* vrow = bt.variant_embed + (size_t)(gg.v0 + tm[rt].set) * (size_t)Ev;
@@ -140,9 +161,11 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
             }
     }
 
+    }
     // ---- L gated ref/alt blocks; this wave's tiles all use the weights of its side ------------------------------
-    for (int l = 0; l < L; ++l) {
+    for (int l = (LAYERED && lay.slice > 0) ? lay.slice - 1 : 0; l < L; ++l) {
         const PmtBlock& B = M->blocks[l];
+        const bool first_half = !LAYERED || l == lay.slice;        // LayerNorm, proj1, SELU, per-set sums of z2
         f4 z[PMT_RT][2];
         // staging region A of this block: [W1_ref | W1_alt | b1_ref | b1_alt | LN(D) w,b | LN(h) w,b | rho] -- everything
         // the first half of the block reads comes out of LDS; no vector-memory load sits behind the in-flight DMA.
@@ -153,7 +176,8 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
         f4 sw[1], sb[1];
         sw[0] = load_pvec(stA + (uniform(B.sgu_norm_w_pvec) - baseA), 0, g);
         sb[0] = load_pvec(stA + (uniform(B.sgu_norm_b_pvec) - baseA), 0, g);
-        {
+        const int buf = l % 3;
+        if (first_half) {
             f4 lw[NTD], lb[NTD];
 #pragma unroll
             for (int t = 0; t < NTD; ++t) {
@@ -179,9 +203,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) { z[rt][0] = b0; z[rt][1] = b1; }
             linear_acc<NTD, 2, false, EX>(z, n, stA + side * frag_floats_dev(P1r), D, 16 + h);
-        }
         // SELU, LayerNorm(h) on z2, per-set sums (reference gated_mlp.py:228-239)
-        const int buf = l % 3;
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt) {
             z[rt][0] = selu4(z[rt][0]);
@@ -198,8 +220,33 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
                     }
             }
         }
+        }
+        if constexpr (LAYERED) {
+            if (first_half) {  // end of this launch: the group's partial sums join the global ones; park x and z
+                __syncthreads();
+                for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS) {
+                    const float v = (&sh.zsum[buf][0][0][0])[i];
+                    if (v != 0.f) atomicAdd(&lay.zsum_g[((size_t)(gg.v0 + (i >> 5)) * L + l) * 32 + (i & 31)], v);
+                }
+#pragma unroll
+                for (int rt = 0; rt < PMT_RT; ++rt)
+                    if (mask_all & (1u << rt)) {
+                        stash_store<NTD>(lay.x_scratch + (tile_global + rt) * PMT_SLOT_FLOATS, x[rt]);
+                        stash_store<2>(lay.z_scratch + (tile_global + rt) * 512, z[rt]);
+                    }
+                return;
+            }
+            // second half of block l = slice - 1: z from the previous launch, the COMPLETE per-set sums from HBM
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt) {
+                z[rt][0] = z[rt][1] = f4{0.f, 0.f, 0.f, 0.f};
+                if (mask_all & (1u << rt)) stash_load<2>(lay.z_scratch + (tile_global + rt) * 512, z[rt]);
+            }
+            for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS)
+                (&sh.zsum[buf][0][0][0])[i] = lay.zsum_g[((size_t)(gg.v0 + (i >> 5)) * L + l) * 32 + (i & 31)];
+        }
         __syncthreads();
-        if (TRAIN) {
+        if (TRAIN && !LAYERED) {
             for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS)
                 zsum_stash[((size_t)(gg.v0 + (i >> 5)) * L + l) * 32 + (i & 31)] = (&sh.zsum[buf][0][0][0])[i];
         }
@@ -383,6 +430,18 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
         }
     }
     __syncthreads();
+    if constexpr (LAYERED) {  // the group's partial head sums join the global ones; pmt_finalize_kernel writes the outputs
+        for (int i = tid; i < gg.nsets * (K + 2); i += PMT_THREADS) {
+            const int set = i / (K + 2), k = i - set * (K + 2);
+            const float v = sh.hsum[set][k];
+            if (v != 0.f) atomicAdd(&lay.hsum_g[(size_t)(gg.v0 + set) * (PMT_MAX_CLUSTERS + 2) + k], v);
+        }
+        for (int i = tid; i < gg.nsets * 2 * PMT_MAX_WIDTH; i += PMT_THREADS) {
+            const float v = (&sh.fsum[0][0][0])[i];
+            if (v != 0.f) atomicAdd(&lay.fsum_g[(size_t)gg.v0 * 2 * PMT_MAX_WIDTH + i], v);
+        }
+        return;
+    }
 
     // ---- per-set finalisation (reference feature_clustering.py:121-135, ragged_sets.py:144-155) -----------------
     for (int i = tid; i < gg.nsets; i += PMT_THREADS) {
@@ -411,6 +470,82 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
     }
 }
 
+// per-set outputs from the global sums of a layered forward (same arithmetic as the finalisation above)
+__global__ __launch_bounds__(256) void pmt_finalize_kernel(const PmtModel* __restrict__ M, const float* __restrict__ phi, PmtBatch bt,
+                                                           PmtOutputs out, const float* __restrict__ fsum_g, const float* __restrict__ hsum_g) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= bt.num_variants) return;
+    const int K = M->num_clusters, E = M->feature_dim;
+    const float* hs = hsum_g + (size_t)b * (PMT_MAX_CLUSTERS + 2);
+    float* lk = out.logits_bk + (size_t)b * (K + 2);
+    const float l0 = hs[0];
+    lk[0] = l0;
+    lk[1] = hs[1];
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k) {
+        const float v = hs[2 + k] + phi[M->head.log_w_k_phi + k];
+        lk[2 + k] = v;
+        mx = fmaxf(mx, v);
+    }
+    float se = 0.f;
+    for (int k = 0; k < K; ++k) se += expf(lk[2 + k] - mx);
+    const float logit = (mx + logf(se)) - l0;
+    out.logits_b[b] = PMT_MAX_LOGIT_F * tanhf(logit / PMT_MAX_LOGIT_F);
+    const float n_ref = (float)(bt.ref_offsets[b + 1] - bt.ref_offsets[b]), n_alt = (float)(bt.alt_offsets[b + 1] - bt.alt_offsets[b]);
+    for (int f = 0; f < E; ++f) {
+        const int pos = 16 * (f >> 4) + 4 * (f & 3) + ((f & 15) >> 2);
+        out.ref_features_be[(size_t)b * E + f] = fsum_g[((size_t)b * 2 + 0) * PMT_MAX_WIDTH + pos] / (n_ref + 1e-4f);
+        out.features_be[(size_t)b * E + f] = fsum_g[((size_t)b * 2 + 1) * PMT_MAX_WIDTH + pos] / (n_alt + 1e-4f);
+    }
+}
+
+extern "C" size_t pmt_layered_scratch_floats(const PmtModel* m, int64_t total_tiles, int32_t num_variants) {
+    if (!m) return 0;
+    const size_t nb = (size_t)(m->num_blocks > 0 ? m->num_blocks : 1);
+    return (size_t)total_tiles * (PMT_SLOT_FLOATS + 512) + (size_t)num_variants * (nb * 32 + 2 * PMT_MAX_WIDTH + PMT_MAX_CLUSTERS + 2);
+}
+
+extern "C" int pmt_forward_layered(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* phi,
+                                   const float* packed, const PmtBatch* batch, const PmtOutputs* out, float* stash, float* scratch,
+                                   void* stream) {
+    if (!model_host || !model_dev || !batch || !out || !scratch) return PMT_E_INVALID;
+    const int rc = pmt_model_check(model_host);
+    if (rc != PMT_OK) return rc;
+    if (batch->num_groups <= 0) return batch->num_groups == 0 ? PMT_OK : PMT_E_INVALID;
+    if (!batch->reads || !batch->ref_offsets || !batch->alt_offsets || !batch->variant_embed || !batch->group_span ||
+        !batch->group_tile_base || batch->total_tiles <= 0 || !out->logits_b || !out->logits_bk || !out->features_be || !out->ref_features_be)
+        return PMT_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool p0 = pmt_shape_id(model_host) == 1;
+    const int L = model_host->num_blocks;
+    const size_t nb = (size_t)(L > 0 ? L : 1), B = (size_t)batch->num_variants;
+    PmtLayeredArgs lay;
+    lay.x_scratch = scratch;
+    lay.z_scratch = lay.x_scratch + (size_t)batch->total_tiles * PMT_SLOT_FLOATS;
+    float* sums = lay.z_scratch + (size_t)batch->total_tiles * 512;
+    float* zsum_stash = nullptr;
+    float* rstd_stash = nullptr;
+    if (stash) {
+        zsum_stash = stash + (size_t)batch->total_tiles * (size_t)pmt_stash_slots(model_host) * PMT_SLOT_FLOATS;
+        rstd_stash = zsum_stash + B * nb * 32;
+    }
+    lay.zsum_g = stash ? zsum_stash : sums;  // training: the stash's per-set sums ARE the global sums
+    lay.fsum_g = sums + B * nb * 32;
+    lay.hsum_g = lay.fsum_g + B * 2 * PMT_MAX_WIDTH;
+    if (hipMemsetAsync(lay.zsum_g, 0, B * nb * 32 * sizeof(float), s) != hipSuccess) return PMT_E_LAUNCH;
+    if (hipMemsetAsync(lay.fsum_g, 0, B * (2 * PMT_MAX_WIDTH + PMT_MAX_CLUSTERS + 2) * sizeof(float), s) != hipSuccess) return PMT_E_LAUNCH;
+    auto kernel = stash ? (p0 ? pmt_forward_kernel<true, ShapeP0, true> : pmt_forward_kernel<true, ShapeAny, true>)
+                        : (p0 ? pmt_forward_kernel<false, ShapeP0, true> : pmt_forward_kernel<false, ShapeAny, true>);
+    for (int slice = 0; slice <= L; ++slice) {
+        lay.slice = slice;
+        hipLaunchKernelGGL(kernel, dim3(batch->num_groups), dim3(PMT_THREADS), 0, s, model_dev, theta, phi, packed, *batch, *out, stash,
+                           zsum_stash, rstd_stash, lay);
+    }
+    hipLaunchKernelGGL(pmt_finalize_kernel, dim3((batch->num_variants + 255) / 256), dim3(256), 0, s, model_dev, phi, *batch, *out,
+                       lay.fsum_g, lay.hsum_g);
+    return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
+}
+
 // ---- host launcher ---------------------------------------------------------------------------------------------------
 extern "C" int pmt_forward(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* phi,
                            const float* packed, const PmtBatch* batch, const PmtOutputs* out, float* stash,
@@ -422,6 +557,7 @@ extern "C" int pmt_forward(const PmtModel* model_host, const PmtModel* model_dev
     if (!batch->reads || !batch->ref_offsets || !batch->alt_offsets || !batch->variant_embed || !batch->group_start ||
         !out->logits_b || !out->logits_bk || !out->features_be || !out->ref_features_be)
         return PMT_E_INVALID;
+    if (batch->group_span) return PMT_E_UNSUPPORTED;  // split read sets: pmt_forward_layered
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool p0 = pmt_shape_id(model_host) == 1;  // tile-exact instance (pmt_device.hpp: ShapeP0) or the generic one
     float* zsum_stash = nullptr;
@@ -435,6 +571,6 @@ extern "C" int pmt_forward(const PmtModel* model_host, const PmtModel* model_dev
     auto kernel = stash ? (p0 ? pmt_forward_kernel<true, ShapeP0> : pmt_forward_kernel<true, ShapeAny>)
                         : (p0 ? pmt_forward_kernel<false, ShapeP0> : pmt_forward_kernel<false, ShapeAny>);
     hipLaunchKernelGGL(kernel, dim3(batch->num_groups), dim3(PMT_THREADS), 0, s, model_dev, theta, phi, packed, *batch, *out,
-                       stash, zsum_stash, rstd_stash);
+                       stash, zsum_stash, rstd_stash, PmtLayeredArgs{});
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }

@@ -285,6 +285,63 @@ extern "C" int pmt_plan_groups(const int32_t* ref_counts, const int32_t* alt_cou
     return groups;
 }
 
+extern "C" int pmt_plan_groups_split(const int32_t* ref_counts, const int32_t* alt_counts, int32_t num_variants, int32_t* span,
+                                     int32_t* tile_base, int32_t max_groups, int32_t* needs_layered) {
+    if (!ref_counts || !alt_counts || !span || !tile_base || !needs_layered || num_variants < 0 || max_groups < 1) return PMT_E_INVALID;
+    const long long per = PMT_GROUP_TILES / PMT_GROUP_WAVES;
+    int g = 0;
+    long long tiles = 0;
+    *needs_layered = 0;
+    auto emit = [&](long long v0, long long v1, long long rb, long long re, long long ab, long long ae) {
+        if (g >= max_groups) return false;
+        int32_t* sp = span + 6 * (size_t)g;
+        sp[0] = (int32_t)v0; sp[1] = (int32_t)v1; sp[2] = (int32_t)rb; sp[3] = (int32_t)re; sp[4] = (int32_t)ab; sp[5] = (int32_t)ae;
+        tile_base[g] = (int32_t)tiles;
+        tiles += (re - rb + 15) / 16 + (ae - ab + 15) / 16;
+        ++g;
+        return true;
+    };
+    long long ref_row = 0, alt_row = 0;         // exclusive scans so far
+    long long gs = 0, gref0 = 0, galt0 = 0;     // the open group: first variant, first rows
+    long long gref = 0, galt = 0;
+    int sets = 0;
+    for (int b = 0; b < num_variants; ++b) {
+        const long long r = ref_counts[b], a = alt_counts[b];
+        if (r < 0 || a < 0) return PMT_E_INVALID;
+        if (!group_fits(r, a)) {  // more reads than a workgroup holds: close the open group, give this set groups of its own
+            if (sets > 0 && !emit(gs, b, gref0, ref_row, galt0, alt_row)) return PMT_E_WORKSPACE;
+            *needs_layered = 1;
+            long long rb = ref_row, ab = alt_row;
+            const long long rend = ref_row + r, aend = alt_row + a;
+            while (rb < rend || ab < aend) {
+                long long tr = (rend - rb + 15) / 16;
+                if (tr > PMT_GROUP_TILES) tr = PMT_GROUP_TILES;
+                const long long take_r = (rend - rb) < tr * 16 ? (rend - rb) : tr * 16;
+                long long take_a = 0;
+                if (rb + take_r >= rend) {  // the ref rows end in this group: fill the remaining waves with alt tiles
+                    const long long ta_max = (PMT_GROUP_WAVES - (tr + per - 1) / per) * per;
+                    take_a = (aend - ab) < ta_max * 16 ? (aend - ab) : ta_max * 16;
+                }
+                if (!emit(b, b + 1, rb, rb + take_r, ab, ab + take_a)) return PMT_E_WORKSPACE;
+                rb += take_r;
+                ab += take_a;
+            }
+            ref_row += r; alt_row += a;
+            gs = b + 1; gref0 = ref_row; galt0 = alt_row; gref = galt = 0; sets = 0;
+            continue;
+        }
+        if (sets > 0 && (!group_fits(gref + r, galt + a) || sets + 1 > PMT_GROUP_MAX_SETS)) {
+            if (!emit(gs, b, gref0, ref_row, galt0, alt_row)) return PMT_E_WORKSPACE;
+            gs = b; gref0 = ref_row; galt0 = alt_row; gref = galt = 0; sets = 0;
+        }
+        gref += r; galt += a; ++sets;
+        ref_row += r; alt_row += a;
+    }
+    if (sets > 0 && !emit(gs, num_variants, gref0, ref_row, galt0, alt_row)) return PMT_E_WORKSPACE;
+    tile_base[g] = (int32_t)tiles;
+    return g;
+}
+
 extern "C" size_t pmt_stash_bytes(const PmtModel* m, int64_t total_tiles, int32_t num_variants) {
     if (!m) return 0;
     const size_t tile_part = (size_t)total_tiles * (size_t)pmt_stash_slots(m) * PMT_SLOT_FLOATS;

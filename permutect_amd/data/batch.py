@@ -36,7 +36,7 @@ def decode_packed_reads(packed: np.ndarray) -> np.ndarray:
 class GroupPlan:
     """Partition of the batch's variants into register-resident groups (host arrays + device copies)."""
 
-    def __init__(self, ref_counts: np.ndarray, alt_counts: np.ndarray):
+    def __init__(self, ref_counts: np.ndarray, alt_counts: np.ndarray, allow_split: bool = False):
         lib = L.load()
         b = len(ref_counts)
         rc = np.ascontiguousarray(ref_counts, dtype=np.int32)
@@ -45,10 +45,20 @@ class GroupPlan:
         gt = np.zeros(b + 1, dtype=np.int32)
         bad = C.c_int32(-1)
         n = lib.pmt_plan_groups(rc.ctypes.data, ac.ctypes.data, b, gs.ctypes.data, gt.ctypes.data, C.byref(bad))
+        self.span = None  # [G, 6] when some read set is split over several groups (forward-only "layered" execution)
         if n == L.E_CAPACITY:
-            raise L.PmtError(
-                f"variant {bad.value} has {int(rc[bad.value])} ref / {int(ac[bad.value])} alt reads: more than the "
-                f"{L.GROUP_TILES * L.TILE}-read register-resident group capacity of the gfx950 kernels")
+            if not allow_split:
+                raise L.PmtError(
+                    f"variant {bad.value} has {int(rc[bad.value])} ref / {int(ac[bad.value])} alt reads: more than the "
+                    f"{L.GROUP_TILES * L.TILE}-read register-resident group capacity of the gfx950 kernels")
+            max_groups = b + int((rc.astype(np.int64).sum() + ac.astype(np.int64).sum()) // (L.TILE * L.GROUP_TILES // 2)) + 8
+            span = np.zeros((max_groups, 6), dtype=np.int32)
+            gt = np.zeros(max_groups + 1, dtype=np.int32)
+            layered = C.c_int32(0)
+            n = lib.pmt_plan_groups_split(rc.ctypes.data, ac.ctypes.data, b, span.ctypes.data, gt.ctypes.data, max_groups, C.byref(layered))
+            L.check(n, "pmt_plan_groups_split")
+            self.span = span[:n].copy()
+            gs = np.zeros(n + 1, dtype=np.int32)  # unused by the layered kernels
         L.check(n, "pmt_plan_groups")
         self.num_groups = n
         self.group_start = gs[: n + 1].copy()
@@ -56,10 +66,15 @@ class GroupPlan:
         self.total_tiles = int(gt[n])
         self._dev = {}
 
+    @property
+    def layered(self) -> bool:
+        return self.span is not None
+
     def on(self, device: torch.device):
         key = str(device)
         if key not in self._dev:
-            self._dev[key] = (torch.from_numpy(self.group_start).to(device), torch.from_numpy(self.group_tile_base).to(device))
+            self._dev[key] = (torch.from_numpy(self.group_start).to(device), torch.from_numpy(self.group_tile_base).to(device),
+                              None if self.span is None else torch.from_numpy(self.span).to(device))
         return self._dev[key]
 
 
@@ -161,9 +176,11 @@ class Batch:
             self._host_counts = (ints[:, 0].astype(np.int32), ints[:, 1].astype(np.int32))
         return self._host_counts
 
-    def plan(self) -> GroupPlan:
+    def plan(self, allow_split: bool = False) -> GroupPlan:
+        """`allow_split`: read sets beyond one workgroup are split over several groups instead of refused; such a plan
+        runs the forward only (pmt_forward_layered)."""
         if self._plan is None:
-            self._plan = GroupPlan(*self.host_counts())
+            self._plan = GroupPlan(*self.host_counts(), allow_split=allow_split)
         return self._plan
 
     def device_counts(self):
@@ -282,8 +299,8 @@ class DownsampledBatch(Batch):
     def get_reads_re(self) -> Tensor:
         return self._parent.get_reads_re()[self.read_indices]
 
-    def plan(self) -> GroupPlan:
-        return self._parent.plan()  # parent counts are upper bounds of the downsampled counts
+    def plan(self, allow_split: bool = False) -> GroupPlan:
+        return self._parent.plan(allow_split=allow_split)  # parent counts are upper bounds of the downsampled counts
 
     def host_counts(self):
         if self._host_counts is None:

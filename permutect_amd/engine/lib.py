@@ -91,7 +91,7 @@ class PmtModel(C.Structure):
 class PmtBatch(C.Structure):
     _fields_ = [("num_variants", i32), ("num_groups", i32), ("read_format", i32), ("read_row_bytes", i32),
                 ("reads", vp), ("read_index", vp), ("ref_offsets", vp), ("alt_offsets", vp), ("variant_embed", vp),
-                ("group_start", vp), ("group_tile_base", vp), ("total_tiles", i64), ("debug_flags", vp)]
+                ("group_start", vp), ("group_tile_base", vp), ("total_tiles", i64), ("debug_flags", vp), ("group_span", vp)]
 
 
 class PmtOutputs(C.Structure):
@@ -155,7 +155,8 @@ EXPORTS = ["pmt_abi_version", "pmt_struct_bytes", "pmt_model_check", "pmt_build_
            "pmt_scan_counts", "pmt_forward", "pmt_backward", "pmt_clip_adamw",
            "pmt_rows_stash_bytes", "pmt_rows_forward", "pmt_rows_backward", "pmt_cnn_forward", "pmt_cnn_backward",
            "pmt_phi_forward", "pmt_phi_backward", "pmt_build_read_index", "pmt_losses_forward", "pmt_losses_backward",
-           "pmt_downsample_counts", "pmt_downsample_index", "pmt_record_losses"]
+           "pmt_downsample_counts", "pmt_downsample_index", "pmt_record_losses",
+           "pmt_plan_groups_split", "pmt_layered_scratch_floats", "pmt_forward_layered"]
 
 _lib = None
 
@@ -199,6 +200,10 @@ def load() -> C.CDLL:
     lib.pmt_rows_backward.argtypes = [P(PmtModel), vp, i32, vp, vp, vp, i64, i32, vp, i64, vp, vp, vp, i64, C.c_float, vp]
     lib.pmt_build_read_index.argtypes = [vp, vp, vp, i32, vp, vp]
     lib.pmt_record_losses.argtypes = [P(PmtRecordArgs), vp, vp]
+    lib.pmt_plan_groups_split.argtypes = [vp, vp, i32, vp, vp, i32, P(i32)]
+    lib.pmt_layered_scratch_floats.argtypes = [P(PmtModel), i64, i32]
+    lib.pmt_layered_scratch_floats.restype = C.c_size_t
+    lib.pmt_forward_layered.argtypes = [P(PmtModel), vp, vp, vp, vp, P(PmtBatch), P(PmtOutputs), vp, vp, vp]
     lib.pmt_downsample_counts.argtypes = [P(PmtDownsample), vp, vp, vp, vp, vp]
     lib.pmt_downsample_index.argtypes = [P(PmtDownsample), vp, vp, vp, vp, vp, vp]
     lib.pmt_losses_forward.argtypes = [P(PmtLossArgs), P(PmtLossOutputs), vp]
@@ -207,7 +212,7 @@ def load() -> C.CDLL:
     lib.pmt_phi_backward.argtypes = [P(PmtPhiProgram), vp, vp, vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("pmt_abi_version", "pmt_stash_bytes", "pmt_rows_stash_bytes"):
+        if name not in ("pmt_abi_version", "pmt_stash_bytes", "pmt_rows_stash_bytes", "pmt_layered_scratch_floats"):
             fn.restype = i32
     lib.pmt_struct_bytes.argtypes = [i32]
     if lib.pmt_abi_version() != ABI_VERSION:

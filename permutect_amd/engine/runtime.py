@@ -67,9 +67,9 @@ class ReadSetEngine:
             batch._offsets = (ref_off, alt_off)
         return batch._offsets
 
-    def batch_view(self, batch, variant_embed: Tensor):
-        plan = batch.plan()
-        gs, gt = plan.on(self.device)
+    def batch_view(self, batch, variant_embed: Tensor, allow_split: bool = False):
+        plan = batch.plan(allow_split=allow_split) if allow_split else batch.plan()
+        gs, gt, span = plan.on(self.device)
         ref_off, alt_off = self.offsets(batch)
         reads, fmt, row_bytes, index = batch.read_rows()
         if reads.device != self.device:
@@ -83,7 +83,8 @@ class ReadSetEngine:
         bv.group_start, bv.group_tile_base = gs.data_ptr(), gt.data_ptr()
         bv.total_tiles = plan.total_tiles
         bv.debug_flags = self.plan.debug_flags.data_ptr()
-        keep = (gs, gt, ref_off, alt_off, reads, index, variant_embed)
+        bv.group_span = _ptr(span)
+        keep = (gs, gt, span, ref_off, alt_off, reads, index, variant_embed)
         return bv, keep, plan
 
     # ---- passes -----------------------------------------------------------------------------------------------------
@@ -93,7 +94,8 @@ class ReadSetEngine:
         variant_embed = variant_embed.contiguous().float()
         assert variant_embed.shape == (b, d.variant_embed_dim), (variant_embed.shape, d.variant_embed_dim)
         phi = phi.contiguous()
-        bv, keep, plan = self.batch_view(batch, variant_embed)
+        # inference accepts read sets of any size (split over workgroups, layered execution); training does not yet
+        bv, keep, plan = self.batch_view(batch, variant_embed, allow_split=not train)
         dev = self.device
         logits_b = torch.empty(b, dtype=torch.float32, device=dev)
         logits_bk = torch.empty(b, k + 2, dtype=torch.float32, device=dev)
@@ -105,9 +107,15 @@ class ReadSetEngine:
             nbytes = self.lib.pmt_stash_bytes(C.byref(d), plan.total_tiles, b)
             stash = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
         ev = self._event_start()
-        L.check(self.lib.pmt_forward(C.byref(d), self.plan.desc_dev.data_ptr(), self.space.theta.data_ptr(),
-                                     phi.data_ptr(), self.plan.packed.data_ptr(), C.byref(bv), C.byref(out),
-                                     _ptr(stash), _stream()), "pmt_forward")
+        if plan.layered:
+            scratch = torch.empty(self.lib.pmt_layered_scratch_floats(C.byref(d), plan.total_tiles, b), dtype=torch.float32, device=dev)
+            L.check(self.lib.pmt_forward_layered(C.byref(d), self.plan.desc_dev.data_ptr(), self.space.theta.data_ptr(),
+                                                 phi.data_ptr(), self.plan.packed.data_ptr(), C.byref(bv), C.byref(out),
+                                                 _ptr(stash), scratch.data_ptr(), _stream()), "pmt_forward_layered")
+        else:
+            L.check(self.lib.pmt_forward(C.byref(d), self.plan.desc_dev.data_ptr(), self.space.theta.data_ptr(),
+                                         phi.data_ptr(), self.plan.packed.data_ptr(), C.byref(bv), C.byref(out),
+                                         _ptr(stash), _stream()), "pmt_forward")
         self._event_stop("pmt_forward", ev)
         return (logits_b, logits_bk, feats, ref_feats), stash, variant_embed, phi
 

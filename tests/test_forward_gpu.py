@@ -134,3 +134,54 @@ def test_capacity_error_and_empty_batch():
     with torch.no_grad():
         out = model.compute_batch_output(empty)
     assert out.logits_b.shape == (0,) and out.features_be.shape[0] == 0
+
+
+def test_read_sets_beyond_one_workgroup_run_layered_and_match_oracle():
+    """BASELINE config 'mean 600 reads per variant': read sets split over several workgroups, num_blocks + 1 launches with
+    the per-set sums accumulated in HBM (pmt_forward_layered), mixed with ordinary sets; against the oracle."""
+    _, sd, _ = load_case("p0_b16")
+    cfg = config_for("p0_b16")
+    nref = np.array([5, 300, 0, 10, 700, 2, 256, 9])
+    nalt = np.array([3, 350, 600, 15, 1, 7, 255, 1])
+    ints, floats, packed = _arrays(nref, nalt, seed=21)
+    model, dev = build("p0_b16", sd)
+    batch = Batch.from_arrays(ints, floats, packed).copy_to(dev)
+    with torch.no_grad():
+        out = model.compute_batch_output(batch)
+    plan = batch.plan()
+    assert plan.layered and plan.num_groups > len(nref)
+    with torch.no_grad():
+        ref = O.compute_batch_output(sd, cfg, torch.from_numpy(O.decode_packed_reads(packed).astype(np.float32)),
+                                     torch.from_numpy(nref), torch.from_numpy(nalt),
+                                     torch.from_numpy(floats[:, 6:].astype(np.float32)), torch.from_numpy(ints[:, 16:].astype(np.int64)))
+    z = {"out/" + k: v.numpy() for k, v in ref.items()}
+    check_outputs(out, z, "p0_deep")
+    # training on such a batch is refused loudly (no backward for split read sets yet)
+    from permutect_amd.engine.lib import PmtError
+    model.train(True)
+    fresh = Batch.from_arrays(ints, floats, packed).copy_to(dev)
+    with pytest.raises(PmtError):
+        model.compute_batch_output(fresh)
+
+
+def test_layered_forward_equals_the_single_launch_forward():
+    """The layered path on a batch the ordinary kernel accepts (forced split plan) gives the same outputs."""
+    z, sd, b = load_case("p0_deep")
+    model, dev = build("p0_deep", sd)
+    batch = Batch.from_arrays(b["int_array"], b["float_array"], b["packed_reads"]).copy_to(dev)
+    with torch.no_grad():
+        a = model.compute_batch_output(batch)
+    forced = Batch.from_arrays(b["int_array"], b["float_array"], b["packed_reads"]).copy_to(dev)
+    from permutect_amd.data.batch import GroupPlan
+    plan = GroupPlan(*forced.host_counts(), allow_split=True)
+    if plan.span is None:  # nothing oversized: build the explicit spans of the ordinary groups
+        gs, counts = plan.group_start, forced.host_counts()
+        ro = np.concatenate([[0], np.cumsum(counts[0])])
+        ao = np.concatenate([[0], np.cumsum(counts[1])])
+        plan.span = np.array([[gs[g], gs[g + 1], ro[gs[g]], ro[gs[g + 1]], ao[gs[g]], ao[gs[g + 1]]] for g in range(plan.num_groups)], dtype=np.int32)
+    forced._plan = plan
+    with torch.no_grad():
+        c = model.compute_batch_output(forced)
+    assert torch.allclose(a.logits_b, c.logits_b, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(a.features_be, c.features_be, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(a.logits_bk, c.logits_bk, rtol=1e-5, atol=2e-4)
