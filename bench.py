@@ -37,7 +37,9 @@ def synth_arrays(rng, num_variants, depth):
     """SURVEY.md 8d synthetic inputs: packed 12-byte read rows, N(0,1) info, U{0..4} haplotypes, cycling labels."""
     if depth == "wgs":
         nref, nalt = rng.integers(0, 11, num_variants), rng.integers(1, 16, num_variants)
-    else:  # high-depth stress: mean 600 reads / variant is beyond the register-resident group capacity of this round
+    elif depth == "stress":  # BASELINE configs[4]: mean 600 reads / variant (300x tumor + normal); read sets span several
+        nref, nalt = rng.poisson(300, num_variants), np.maximum(rng.poisson(300, num_variants), 1)  # workgroups: forward only
+    else:  # high depth inside one workgroup per read set: mean 200 reads / variant
         nref, nalt = np.minimum(rng.poisson(100, num_variants), 120), np.clip(rng.poisson(100, num_variants), 1, 120)
     ints = np.zeros((num_variants, 16 + 42), dtype=np.int16)
     ints[:, 0], ints[:, 1] = nref, nalt
@@ -132,7 +134,7 @@ def main():
     ap.add_argument("--mode", choices=["train", "filter"], default="train")
     ap.add_argument("--batch", type=int, default=65536, help="read sets per step per GPU")
     ap.add_argument("--resident-batches", type=int, default=4, help="distinct synthetic batches kept in HBM per GPU")
-    ap.add_argument("--depth", choices=["wgs", "high"], default="wgs")
+    ap.add_argument("--depth", choices=["wgs", "high", "stress"], default="wgs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--data", choices=["resident", "loader"], default="resident",
                     help="resident: batches already in HBM (the metric's definition); loader: batches drawn from a "
@@ -167,7 +169,7 @@ def main():
         for _ in range(args.resident_batches):
             ints, floats, packed = synth_arrays(rng, args.batch, args.depth)
             b = Batch.from_arrays(ints, floats, packed)
-            b.plan()
+            b.plan(allow_split=True)
             batches.append(b.copy_to(dev))
             reads_total += packed.shape[0]
         reads_per_batch = reads_total / len(batches)

@@ -203,7 +203,7 @@ typedef struct PmtBatch {
     const int32_t* group_span;      /* device [G][6] or NULL.  With it a group may cover only PART of a read set (read sets
                                        beyond one workgroup, pmt_plan_groups_split): v0, v1 (variants [v0, v1)), ref_begin,
                                        ref_end, alt_begin, alt_end (rows of the batch's ref / alt regions); group_start is
-                                       then ignored.  Only pmt_forward_layered accepts it. */
+                                       then ignored.  Only pmt_forward_layered / pmt_backward_layered accept it. */
 } PmtBatch;
 
 typedef struct PmtOutputs {
@@ -374,11 +374,24 @@ size_t pmt_layered_scratch_floats(const PmtModel* model, int64_t total_tiles, in
  * reference gated_mlp.py:236-239, and the head's sums, feature_clustering.py:111-113); launch s finishes block s - 1 from
  * the complete sums and starts block s, the sums accumulate in HBM with float atomics, activations rest in `scratch` between
  * launches, and a last launch finalises the per-set outputs.  Same results as pmt_forward on batches it accepts.
- * `stash` (optional) as in pmt_forward.  Inference and the training forward; the backward for split read sets is not
- * implemented (pmt_backward rejects group_span). */
+ * `stash` (optional) as in pmt_forward; pmt_backward_layered is its backward. */
 int pmt_forward_layered(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* phi,
                         const float* packed, const PmtBatch* batch, const PmtOutputs* out, float* stash, float* scratch,
                         void* stream);
+
+/* Floats of scratch pmt_backward_layered needs. */
+size_t pmt_layered_backward_scratch_floats(const PmtModel* model, int64_t total_tiles, int32_t num_variants);
+
+/* Backward of pmt_forward_layered (same arguments as pmt_backward plus `scratch`): num_blocks + 1 launches of the backward
+ * kernel.  Going down the stack, a block's backward needs the per-set sums of d(gate) over ALL reads of the set before the
+ * gradient can pass its first projection, so launch s finishes block L - s from the complete sums (accumulated in HBM by
+ * launch s - 1) and starts block L - s - 1; the running gradient and the half-finished block's per-read state rest in
+ * `scratch` between launches.  Per-set parameter terms are added by the group that holds the set's first alt read.
+ * grad_variant_embed must be zeroed by the caller (several groups add to a row). */
+int pmt_backward_layered(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* phi,
+                         const float* packed, const PmtBatch* batch, const PmtOutputs* out, const PmtOutputGrads* dout,
+                         const float* stash, float* scratch, float* grad_theta, float* grad_phi, float* grad_variant_embed,
+                         void* stream);
 
 /* Bytes of activation stash a training forward needs for `total_tiles` tiles (group_tile_base[G]) and B variants. */
 size_t pmt_stash_bytes(const PmtModel* model, int64_t total_tiles, int32_t num_variants);

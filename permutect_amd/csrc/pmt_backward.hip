@@ -55,12 +55,22 @@ DEV void load_slot_tiles(const float* const (&stash_tile)[PMT_RT], unsigned mask
     }
 }
 
-template <typename S>
+// Layered execution (pmt_backward_layered; read sets split over several workgroups): launch `slice` finishes block
+// L - slice from the COMPLETE per-set sums of d(gate) and starts block L - slice - 1; the sums accumulate in HBM, the
+// running gradient and the half-finished block's per-read state rest in scratch between launches.
+struct PmtBwdLayered {
+    int slice;
+    float* dy_scratch;  // [total_tiles][PMT_SLOT_FLOATS] running gradient
+    float* park;        // [total_tiles][6][256]: z1, z2 (after SELU), z2hat, d(gate), d(u), rstd of LayerNorm(h)
+    float* gsum_g;      // [B][L][32] per-set sums of d(gate)
+};
+
+template <typename S, bool LAYERED = false>
 __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
     const PmtModel* __restrict__ M, const float* __restrict__ theta, const float* __restrict__ phi,
     const float* __restrict__ packed, PmtBatch bt, PmtOutputs out, PmtOutputGrads dout, const float* __restrict__ stash,
     const float* __restrict__ zsum_stash, const float* __restrict__ rstd_stash, float* __restrict__ gtheta, float* __restrict__ gphi,
-    float* __restrict__ gvar) {
+    float* __restrict__ gvar, PmtBwdLayered lay) {
     constexpr int NTF = S::NTF, NTR = S::NTR, NTD = S::NTD, NTE = S::NTE;
     constexpr bool EX = S::EXACT;
     static_assert(EX || (NTF == NTD && NTR == NTD && NTE == NTD), "the generic shape keeps one array width");
@@ -121,11 +131,15 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
              bt.debug_flags ? uniform(bt.debug_flags[1]) : 0,
              bt.debug_flags ? reinterpret_cast<unsigned long long*>(bt.debug_flags + 8) : nullptr};
     const unsigned long long t_kernel0 = prof_now();
-    if (wave == 0 && !(c.dbg & 16)) {  // d(log cluster weights): summed over the sets of the group, one atomic per cluster
+    // a read set split over several groups is OWNED by the group that holds its first alt read: per-set terms are added once
+    auto owns = [&](int set) { return !LAYERED || (sh.off[1][set] >= 0 && sh.off[1][set] < gg.nalt); };
+    const size_t tile_global = (size_t)(bt.group_tile_base[blockIdx.x] + gg.tile_begin);
+    if (wave == 0 && !(c.dbg & 16) && !(LAYERED && lay.slice > 0)) {  // d(log cluster weights): summed over the sets of the group
         const int k = lane & 15;
         float a = 0.f;
         if (k < K)
-            for (int set = g; set < gg.nsets; set += 4) a += sh.dl[set][2 + k];
+            for (int set = g; set < gg.nsets; set += 4)
+                if (owns(set)) a += sh.dl[set][2 + k];
         a = group_sum(a);
         if (g == 0 && k < K) atomicAdd(&gphi[M->head.log_w_k_phi + k], a);
     }
@@ -136,7 +150,15 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
 
     // ---- recompute the tail of the forward: last reducer op, translation, rotation -> a ----------------------------
     f4 dy[PMT_RT][NTD];  // running gradient (d_model wide)
-    {
+    if (LAYERED && lay.slice > 0) {
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt) {
+#pragma unroll
+            for (int t = 0; t < NTD; ++t) dy[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
+            if (mask_all & (1u << rt)) stash_load<NTD>(lay.dy_scratch + (tile_global + rt) * PMT_SLOT_FLOATS, dy[rt]);
+        }
+    }
+    if (!(LAYERED && lay.slice > 0)) {
         f4 e[PMT_RT][NTE];  // reducer output, then + translation (the rotation's input)
         {
             f4 r[PMT_RT][NTD];
@@ -340,13 +362,15 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
     unsigned long long t_ph = prof_now();
 
     // ---- reducer backward ---------------------------------------------------------------------------------------------
+    if (!(LAYERED && lay.slice > 0))
     mlp_backward<NTD, EX>(c, M->reducer, dy, true,
                           [&](int op, f4 (&x)[PMT_RT][NTD]) { load_slot_tiles<NTD>(stash_tile, mask_all, op == 0 ? slot_x0 + L : slot_red + op - 1, x); },
                           0, EX ? n_red_ops - 1 : n_red_ops);
 
     prof_add(c, 6, t_ph);
     // ---- gated blocks backward -----------------------------------------------------------------------------------------
-    for (int l = (c.dbg & 4) ? -1 : L - 1; l >= 0; --l) {
+    for (int l = (c.dbg & 4) ? -1 : ((LAYERED && lay.slice > 0) ? L - lay.slice : L - 1); l >= 0; --l) {
+        const bool first_half = !LAYERED || l == L - 1 - lay.slice;  // phases 1-2 (up to the per-set sums of d(gate))
         // Register discipline (this loop body used to spill thousands of VGPRs): nothing of width D except the running
         // gradient dy stays live across phases.  xhat_l = the normalised x_l (stashed by the forward together with one
         // rstd per read) is re-read from the stash (L2/HBM, 4 KB per tile) each of the three times it is needed; z2 / gate
@@ -377,7 +401,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         t_ph = prof_now();
         // ---- phase 1: z = selu(W1 n + b1) ---------------------------------------------------------------------------
         f4 z[PMT_RT][2];
-        {
+        if (first_half) {
             f4 n[PMT_RT][NTD];
             recompute_n(n);
             const f4 b0 = load_pvec(packed + uniform(P1.b_pvec), 0, g), b1 = load_pvec(packed + uniform(P1.b_pvec), 1, g);
@@ -411,8 +435,8 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         float d_alpha = 0.f, d_beta = 0.f, d_gamma = 0.f;
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt) du[rt][0] = f4{0.f, 0.f, 0.f, 0.f};
-        linear_acc<NTD, 1, false, EX>(du, dy, packed + uniform(P2.wt_frag), D, h);
-        {
+        if (first_half) linear_acc<NTD, 1, false, EX>(du, dy, packed + uniform(P2.wt_frag), D, h);
+        if (first_half) {
             f4 u[PMT_RT][1];
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) {
@@ -442,6 +466,42 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             wgrad_exchange<NTD, 1, 2>(c, M->lin[uniform(B.proj2[0])], M->lin[uniform(B.proj2[1])], dy, u, 1.0f);
         }
         if (c.dbg & 1) __syncthreads();  // (the exchange's barriers, skipped by that switch, complete gsum)
+        if constexpr (LAYERED) {
+            float* pk[PMT_RT];
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt) pk[rt] = lay.park + (tile_global + rt) * (6 * 256);
+            if (first_half) {  // end of this launch: join the global sums, park the per-read state and the running gradient
+                for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS) {
+                    const float v = (&sh.gsum[0][0][0])[i];
+                    if (v != 0.f) atomicAdd(&lay.gsum_g[((size_t)(gg.v0 + (i >> 5)) * L + l) * 32 + (i & 31)], v);
+                }
+                aux_push_scalar(c, uniform(B.alpha_src[0]), side == 0 ? d_alpha : 0.f);
+                aux_push_scalar(c, uniform(B.alpha_src[1]), side == 1 ? d_alpha : 0.f);
+                aux_push_scalar(c, uniform(B.beta_src[0]), side == 0 ? d_beta : 0.f);
+                aux_push_scalar(c, uniform(B.beta_src[1]), side == 1 ? d_beta : 0.f);
+                aux_push_scalar(c, uniform(B.gamma_src), d_gamma);
+#pragma unroll
+                for (int rt = 0; rt < PMT_RT; ++rt)
+                    if (mask_all & (1u << rt)) {
+                        f4 st[6] = {z[rt][0], z[rt][1], z2hat[rt], dgate[rt], du[rt][0], f4{rstd2[rt], rstd2[rt], rstd2[rt], rstd2[rt]}};
+                        stash_store<6>(pk[rt], st);
+                        stash_store<NTD>(lay.dy_scratch + (tile_global + rt) * PMT_SLOT_FLOATS, dy[rt]);
+                    }
+                aux_flush(c);
+                return;
+            }
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt) {
+                f4 st[6];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) st[q] = f4{0.f, 0.f, 0.f, 0.f};
+                if (mask_all & (1u << rt)) stash_load<6>(pk[rt], st);
+                z[rt][0] = st[0]; z[rt][1] = st[1]; z2hat[rt] = st[2]; dgate[rt] = st[3]; du[rt][0] = st[4]; rstd2[rt] = st[5][0];
+            }
+            for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS)
+                (&sh.gsum[0][0][0])[i] = lay.gsum_g[((size_t)(gg.v0 + (i >> 5)) * L + l) * 32 + (i & 31)];
+            __syncthreads();
+        }
         prof_add(c, 10, t_ph);
         t_ph = prof_now();
         // per-set coupling: d(m_ref), d(m_alt), d(ref_regularizer), d(reg_weight)
@@ -461,7 +521,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
                 const float inv_ref = fast_rcp(n_ref + w);
                 sh.dmean[set][0][p] = dm_ref * inv_ref;
                 sh.dmean[set][1][p] = dm_alt * fast_rcp(n_alt + 1e-4f);
-                if (f < h) {
+                if (f < h && owns(set)) {
                     const float zs = zsum_stash[((size_t)(gg.v0 + set) * L + l) * 32 + p];
                     const float m_ref = (zs + w * rho_f) * inv_ref;
                     a_rho += dm_ref * w * inv_ref;
@@ -496,11 +556,13 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             }
             aux_push_vec<1>(c, uniform(B.sgu_norm_w_src), dsw, h);
             aux_push_vec<1>(c, uniform(B.sgu_norm_b_src), dsb, h);
-            aux_push_scalar(c, uniform(B.alpha_src[0]), side == 0 ? d_alpha : 0.f);
-            aux_push_scalar(c, uniform(B.alpha_src[1]), side == 1 ? d_alpha : 0.f);
-            aux_push_scalar(c, uniform(B.beta_src[0]), side == 0 ? d_beta : 0.f);
-            aux_push_scalar(c, uniform(B.beta_src[1]), side == 1 ? d_beta : 0.f);
-            aux_push_scalar(c, uniform(B.gamma_src), d_gamma);
+            if constexpr (!LAYERED) {  // (layered: pushed at the end of the launch that computed them)
+                aux_push_scalar(c, uniform(B.alpha_src[0]), side == 0 ? d_alpha : 0.f);
+                aux_push_scalar(c, uniform(B.alpha_src[1]), side == 1 ? d_alpha : 0.f);
+                aux_push_scalar(c, uniform(B.beta_src[0]), side == 0 ? d_beta : 0.f);
+                aux_push_scalar(c, uniform(B.beta_src[1]), side == 1 ? d_beta : 0.f);
+                aux_push_scalar(c, uniform(B.gamma_src), d_gamma);
+            }
         }
         prof_add(c, 12, t_ph);
         t_ph = prof_now();
@@ -599,7 +661,8 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
     aux_flush(c);  // ends with a workgroup barrier
     for (int i = tid; i < gg.nsets * Ev; i += PMT_THREADS) {
         const int set = i / Ev, f = i - set * Ev;
-        gvar[(size_t)(gg.v0 + set) * Ev + f] = sh.dv[set][f];
+        if (LAYERED) atomicAdd(&gvar[(size_t)(gg.v0 + set) * Ev + f], sh.dv[set][f]);  // several groups per read set
+        else gvar[(size_t)(gg.v0 + set) * Ev + f] = sh.dv[set][f];
     }
     prof_add(c, 7, t_kernel0);  // whole kernel, per wave
 }
@@ -621,6 +684,44 @@ extern "C" int pmt_backward(const PmtModel* model_host, const PmtModel* model_de
     const float* rstd_stash = zsum_stash + (size_t)batch->num_variants * (size_t)(model_host->num_blocks > 0 ? model_host->num_blocks : 1) * 32;
     auto kernel = pmt_shape_id(model_host) == 1 ? pmt_backward_kernel<ShapeP0> : pmt_backward_kernel<ShapeAny>;
     hipLaunchKernelGGL(kernel, dim3(batch->num_groups), dim3(PMT_THREADS), 0, reinterpret_cast<hipStream_t>(stream), model_dev,
-                       theta, phi, packed, *batch, *out, *dout, stash, zsum_stash, rstd_stash, grad_theta, grad_phi, grad_variant_embed);
+                       theta, phi, packed, *batch, *out, *dout, stash, zsum_stash, rstd_stash, grad_theta, grad_phi, grad_variant_embed,
+                       PmtBwdLayered{});
+    return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
+}
+
+extern "C" size_t pmt_layered_backward_scratch_floats(const PmtModel* m, int64_t total_tiles, int32_t num_variants) {
+    if (!m) return 0;
+    const size_t nb = (size_t)(m->num_blocks > 0 ? m->num_blocks : 1);
+    return (size_t)total_tiles * (PMT_SLOT_FLOATS + 6 * 256) + (size_t)num_variants * nb * 32;
+}
+
+extern "C" int pmt_backward_layered(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* phi,
+                                    const float* packed, const PmtBatch* batch, const PmtOutputs* out, const PmtOutputGrads* dout,
+                                    const float* stash, float* scratch, float* grad_theta, float* grad_phi,
+                                    float* grad_variant_embed, void* stream) {
+    if (!model_host || !model_dev || !batch || !out || !dout || !stash || !scratch || !grad_theta || !grad_phi || !grad_variant_embed)
+        return PMT_E_INVALID;
+    const int rc = pmt_model_check(model_host);
+    if (rc != PMT_OK) return rc;
+    if (batch->num_groups <= 0) return batch->num_groups == 0 ? PMT_OK : PMT_E_INVALID;
+    if (!batch->reads || !batch->ref_offsets || !batch->alt_offsets || !batch->group_span || !batch->group_tile_base ||
+        batch->total_tiles <= 0 || !out->logits_b || !out->logits_bk)
+        return PMT_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int L = model_host->num_blocks;
+    const size_t nb = (size_t)(L > 0 ? L : 1), B = (size_t)batch->num_variants;
+    const float* zsum_stash = stash + (size_t)batch->total_tiles * (size_t)pmt_stash_slots(model_host) * PMT_SLOT_FLOATS;
+    const float* rstd_stash = zsum_stash + B * nb * 32;
+    PmtBwdLayered lay;
+    lay.dy_scratch = scratch;
+    lay.park = lay.dy_scratch + (size_t)batch->total_tiles * PMT_SLOT_FLOATS;
+    lay.gsum_g = lay.park + (size_t)batch->total_tiles * 6 * 256;
+    if (hipMemsetAsync(lay.gsum_g, 0, B * nb * 32 * sizeof(float), s) != hipSuccess) return PMT_E_LAUNCH;
+    auto kernel = pmt_shape_id(model_host) == 1 ? pmt_backward_kernel<ShapeP0, true> : pmt_backward_kernel<ShapeAny, true>;
+    for (int slice = 0; slice <= L; ++slice) {
+        lay.slice = slice;
+        hipLaunchKernelGGL(kernel, dim3(batch->num_groups), dim3(PMT_THREADS), 0, s, model_dev, theta, phi, packed, *batch, *out, *dout,
+                           stash, zsum_stash, rstd_stash, grad_theta, grad_phi, grad_variant_embed, lay);
+    }
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }

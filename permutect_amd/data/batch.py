@@ -45,7 +45,7 @@ class GroupPlan:
         gt = np.zeros(b + 1, dtype=np.int32)
         bad = C.c_int32(-1)
         n = lib.pmt_plan_groups(rc.ctypes.data, ac.ctypes.data, b, gs.ctypes.data, gt.ctypes.data, C.byref(bad))
-        self.span = None  # [G, 6] when some read set is split over several groups (forward-only "layered" execution)
+        self.span = None  # [G, 6] when some read set is split over several groups ("layered" execution)
         if n == L.E_CAPACITY:
             if not allow_split:
                 raise L.PmtError(
@@ -177,8 +177,8 @@ class Batch:
         return self._host_counts
 
     def plan(self, allow_split: bool = False) -> GroupPlan:
-        """`allow_split`: read sets beyond one workgroup are split over several groups instead of refused; such a plan
-        runs the forward only (pmt_forward_layered)."""
+        """`allow_split`: read sets beyond one workgroup are split over several groups instead of refused
+        (pmt_forward_layered / pmt_backward_layered run such a plan)."""
         if self._plan is None:
             self._plan = GroupPlan(*self.host_counts(), allow_split=allow_split)
         return self._plan
@@ -300,7 +300,12 @@ class DownsampledBatch(Batch):
         return self._parent.get_reads_re()[self.read_indices]
 
     def plan(self, allow_split: bool = False) -> GroupPlan:
-        return self._parent.plan(allow_split=allow_split)  # parent counts are upper bounds of the downsampled counts
+        parent = self._parent.plan(allow_split=allow_split)  # parent counts are upper bounds of the downsampled counts
+        if not parent.layered:
+            return parent
+        if getattr(self, "_own_plan", None) is None:  # split groups name explicit rows: plan from the downsampled counts
+            self._own_plan = GroupPlan(*self.host_counts(), allow_split=True)
+        return self._own_plan
 
     def host_counts(self):
         if self._host_counts is None:

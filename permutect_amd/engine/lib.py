@@ -156,7 +156,8 @@ EXPORTS = ["pmt_abi_version", "pmt_struct_bytes", "pmt_model_check", "pmt_build_
            "pmt_rows_stash_bytes", "pmt_rows_forward", "pmt_rows_backward", "pmt_cnn_forward", "pmt_cnn_backward",
            "pmt_phi_forward", "pmt_phi_backward", "pmt_build_read_index", "pmt_losses_forward", "pmt_losses_backward",
            "pmt_downsample_counts", "pmt_downsample_index", "pmt_record_losses",
-           "pmt_plan_groups_split", "pmt_layered_scratch_floats", "pmt_forward_layered"]
+           "pmt_plan_groups_split", "pmt_layered_scratch_floats", "pmt_forward_layered",
+           "pmt_layered_backward_scratch_floats", "pmt_backward_layered"]
 
 _lib = None
 
@@ -204,6 +205,10 @@ def load() -> C.CDLL:
     lib.pmt_layered_scratch_floats.argtypes = [P(PmtModel), i64, i32]
     lib.pmt_layered_scratch_floats.restype = C.c_size_t
     lib.pmt_forward_layered.argtypes = [P(PmtModel), vp, vp, vp, vp, P(PmtBatch), P(PmtOutputs), vp, vp, vp]
+    lib.pmt_layered_backward_scratch_floats.argtypes = [P(PmtModel), i64, i32]
+    lib.pmt_layered_backward_scratch_floats.restype = C.c_size_t
+    lib.pmt_backward_layered.argtypes = [P(PmtModel), vp, vp, vp, vp, P(PmtBatch), P(PmtOutputs), P(PmtOutputGrads), vp, vp, vp,
+                                         vp, vp, vp]
     lib.pmt_downsample_counts.argtypes = [P(PmtDownsample), vp, vp, vp, vp, vp]
     lib.pmt_downsample_index.argtypes = [P(PmtDownsample), vp, vp, vp, vp, vp, vp]
     lib.pmt_losses_forward.argtypes = [P(PmtLossArgs), P(PmtLossOutputs), vp]
@@ -212,7 +217,8 @@ def load() -> C.CDLL:
     lib.pmt_phi_backward.argtypes = [P(PmtPhiProgram), vp, vp, vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("pmt_abi_version", "pmt_stash_bytes", "pmt_rows_stash_bytes", "pmt_layered_scratch_floats"):
+        if name not in ("pmt_abi_version", "pmt_stash_bytes", "pmt_rows_stash_bytes", "pmt_layered_scratch_floats",
+                        "pmt_layered_backward_scratch_floats"):
             fn.restype = i32
     lib.pmt_struct_bytes.argtypes = [i32]
     if lib.pmt_abi_version() != ABI_VERSION:

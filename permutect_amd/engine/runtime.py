@@ -67,8 +67,8 @@ class ReadSetEngine:
             batch._offsets = (ref_off, alt_off)
         return batch._offsets
 
-    def batch_view(self, batch, variant_embed: Tensor, allow_split: bool = False):
-        plan = batch.plan(allow_split=allow_split) if allow_split else batch.plan()
+    def batch_view(self, batch, variant_embed: Tensor, allow_split: bool = True):
+        plan = batch.plan(allow_split=allow_split)
         gs, gt, span = plan.on(self.device)
         ref_off, alt_off = self.offsets(batch)
         reads, fmt, row_bytes, index = batch.read_rows()
@@ -94,8 +94,8 @@ class ReadSetEngine:
         variant_embed = variant_embed.contiguous().float()
         assert variant_embed.shape == (b, d.variant_embed_dim), (variant_embed.shape, d.variant_embed_dim)
         phi = phi.contiguous()
-        # inference accepts read sets of any size (split over workgroups, layered execution); training does not yet
-        bv, keep, plan = self.batch_view(batch, variant_embed, allow_split=not train)
+        # read sets of any size: beyond one workgroup they are split over several groups (layered execution)
+        bv, keep, plan = self.batch_view(batch, variant_embed)
         dev = self.device
         logits_b = torch.empty(b, dtype=torch.float32, device=dev)
         logits_bk = torch.empty(b, k + 2, dtype=torch.float32, device=dev)
@@ -128,10 +128,19 @@ class ReadSetEngine:
         gphi = torch.zeros(d.phi_size, dtype=torch.float32, device=self.device)
         gvar = torch.zeros_like(variant_embed)
         ev = self._event_start()
-        L.check(self.lib.pmt_backward(C.byref(d), self.plan.desc_dev.data_ptr(), self.space.theta.data_ptr(),
-                                      phi.data_ptr(), self.plan.packed.data_ptr(), C.byref(bv), C.byref(out),
-                                      C.byref(dout), stash.data_ptr(), self.space.gtheta.data_ptr(), gphi.data_ptr(),
-                                      gvar.data_ptr(), _stream()), "pmt_backward")
+        if plan.layered:
+            n = self.lib.pmt_layered_backward_scratch_floats(C.byref(d), plan.total_tiles, batch.size())
+            scratch = torch.empty(n, dtype=torch.float32, device=self.device)
+            L.check(self.lib.pmt_backward_layered(C.byref(d), self.plan.desc_dev.data_ptr(), self.space.theta.data_ptr(),
+                                                  phi.data_ptr(), self.plan.packed.data_ptr(), C.byref(bv), C.byref(out),
+                                                  C.byref(dout), stash.data_ptr(), scratch.data_ptr(),
+                                                  self.space.gtheta.data_ptr(), gphi.data_ptr(), gvar.data_ptr(), _stream()),
+                    "pmt_backward_layered")
+        else:
+            L.check(self.lib.pmt_backward(C.byref(d), self.plan.desc_dev.data_ptr(), self.space.theta.data_ptr(),
+                                          phi.data_ptr(), self.plan.packed.data_ptr(), C.byref(bv), C.byref(out),
+                                          C.byref(dout), stash.data_ptr(), self.space.gtheta.data_ptr(), gphi.data_ptr(),
+                                          gvar.data_ptr(), _stream()), "pmt_backward")
         self._event_stop("pmt_backward", ev)
         return gphi, gvar
 

@@ -156,12 +156,6 @@ def test_read_sets_beyond_one_workgroup_run_layered_and_match_oracle():
                                      torch.from_numpy(floats[:, 6:].astype(np.float32)), torch.from_numpy(ints[:, 16:].astype(np.int64)))
     z = {"out/" + k: v.numpy() for k, v in ref.items()}
     check_outputs(out, z, "p0_deep")
-    # training on such a batch is refused loudly (no backward for split read sets yet)
-    from permutect_amd.engine.lib import PmtError
-    model.train(True)
-    fresh = Batch.from_arrays(ints, floats, packed).copy_to(dev)
-    with pytest.raises(PmtError):
-        model.compute_batch_output(fresh)
 
 
 def test_layered_forward_equals_the_single_launch_forward():

@@ -178,3 +178,92 @@ def test_fused_losses_match_torch_composition(name):
         np.testing.assert_allclose(a, c, rtol=2e-5, atol=2e-6)
     for a, c in zip(g1, g2):
         np.testing.assert_allclose(a, c, rtol=2e-4, atol=2e-6)
+
+
+def _compare_gradients(model, gref_by_name):
+    names = [n for n, _ in model.named_parameters()]
+    gref = np.concatenate([gref_by_name[n].ravel() for n in names])
+    gour = np.concatenate([p.grad.detach().cpu().numpy().ravel() for _, p in model.named_parameters()])
+    assert np.all(np.isfinite(gour))
+    gscale = np.abs(gref).max()
+    bad = []
+    for n, p in model.named_parameters():
+        ref = gref_by_name[n]
+        err = np.abs(p.grad.detach().cpu().numpy() - ref).max()
+        if err > 5e-4 * max(np.abs(ref).max(), 1e-3 * gscale):
+            bad.append((n, float(err), float(np.abs(ref).max())))
+    assert not bad, bad[:12]
+    assert np.linalg.norm(gour - gref) <= 1e-4 * np.linalg.norm(gref)
+
+
+def test_training_on_read_sets_beyond_one_workgroup_matches_oracle():
+    """BASELINE config 'mean 600 reads per variant' in training: read sets split over several workgroups, forward and
+    backward as num_blocks + 1 launches each (pmt_forward_layered / pmt_backward_layered); losses and every parameter
+    gradient against the oracle's autograd on the same inputs."""
+    from oracle import artifact_oracle as O
+    from tests.helpers import config_for
+    from tests.test_forward_gpu import _arrays
+    _, sd, _ = load_case("p0_b16")
+    cfg = config_for("p0_b16")
+    nref = np.array([5, 300, 0, 10, 700, 2, 256, 9])
+    nalt = np.array([3, 350, 600, 15, 1, 7, 255, 1])
+    ints, floats, packed = _arrays(nref, nalt, seed=21)
+    model, dev = build("p0_b16", sd)
+    model.train(True)
+    batch = Batch.from_arrays(ints, floats, packed).copy_to(dev)
+    out = model.compute_batch_output(batch)
+    assert batch.plan(allow_split=True).layered
+    losses = model.compute_batch_losses(out, batch)
+    opt = FusedClipAdamW(model, lr=1e-3, weight_decay=0.01)
+    opt.zero_grad()
+    losses.total_loss.backward()
+    torch.cuda.synchronize()
+    i64 = torch.from_numpy(ints.astype(np.int64))
+    ob = dict(reads_re=torch.from_numpy(O.decode_packed_reads(packed).astype(np.float32)), nref=i64[:, O.REF_COUNT],
+              nalt=i64[:, O.ALT_COUNT], labels=i64[:, O.LABEL], sources=i64[:, O.SOURCE],
+              info_be=torch.from_numpy(floats[:, O.INFO_START:].astype(np.float32)), haplotypes_bh=i64[:, O.HAPLOTYPES_START:])
+    _, ref_losses, ref_grads = O.train_step_grads(sd, cfg, ob)
+    ref_total = ref_losses["total_losses_b"].detach().numpy()
+    np.testing.assert_allclose(losses.total_losses_b.detach().cpu().numpy(), ref_total, rtol=1e-4, atol=1e-4 + 1e-5 * np.abs(ref_total).max())
+    _compare_gradients(model, {k: v.numpy() for k, v in ref_grads.items()})
+
+
+def test_layered_backward_on_forced_splits_matches_reference():
+    """The layered forward + backward on a fixture batch whose read sets are cut into many small groups (at most two
+    tiles of ref rows and two of alt rows each, so every larger set spans several workgroups): the reference's gradients."""
+    from permutect_amd.data.batch import GroupPlan
+    z, sd, b = load_case("p0_deep")
+    model, dev = build("p0_deep", sd)
+    model.train(True)
+    batch = Batch.from_arrays(b["int_array"], b["float_array"], b["packed_reads"]).copy_to(dev)
+    nref, nalt = batch.host_counts()
+    plan = GroupPlan(nref, nalt, allow_split=True)
+    spans, tiles, tile_base = [], 0, []
+    ro, ao = np.concatenate([[0], np.cumsum(nref)]), np.concatenate([[0], np.cumsum(nalt)])
+    for v in range(len(nref)):
+        r, a, first = int(ro[v]), int(ao[v]), True
+        while first or r < ro[v + 1] or a < ao[v + 1]:
+            first = False
+            r1, a1 = min(r + 32, int(ro[v + 1])), min(a + 32, int(ao[v + 1]))
+            if r < ro[v + 1]:  # ref rows first, alt rows start once the ref rows are done (as the planner does) ...
+                a1 = a if r1 < ro[v + 1] else a1
+            spans.append([v, v + 1, r, r1, a, a1])
+            tile_base.append(tiles)
+            tiles += (r1 - r + 15) // 16 + (a1 - a + 15) // 16
+            r, a = r1, a1
+    tile_base.append(tiles)
+    plan.span = np.array(spans, dtype=np.int32)
+    plan.num_groups, plan.total_tiles = len(spans), tiles
+    plan.group_tile_base = np.array(tile_base, dtype=np.int32)
+    plan.group_start = np.zeros(len(spans) + 1, dtype=np.int32)
+    assert plan.num_groups > 2 * len(nref)
+    batch._plan = plan
+    out = model.compute_batch_output(batch)
+    losses = model.compute_batch_losses(out, batch)
+    opt = FusedClipAdamW(model, lr=float(z["lr"]), weight_decay=float(z["weight_decay"]))
+    opt.zero_grad()
+    losses.total_loss.backward()
+    torch.cuda.synchronize()
+    ref = z["loss/total_losses_b"]
+    np.testing.assert_allclose(losses.total_losses_b.detach().cpu().numpy(), ref, rtol=1e-4, atol=1e-4 + 1e-5 * np.abs(ref).max())
+    _compare_gradients(model, {k[5:]: z[k] for k in z.files if k.startswith("grad/")})
