@@ -122,6 +122,35 @@ def test_downsampler_drives_the_fused_kernels_in_a_train_step():
     assert torch.isfinite(losses.total_loss) and float(opt.grad_norm.item()) > 0
 
 
+def test_downsampling_a_batch_with_read_sets_beyond_one_workgroup():
+    """A split plan names explicit rows, so a DownsampledBatch of such a parent plans from its own counts: keeping every
+    read reproduces the parent's outputs, and a thinned batch runs a finite training step."""
+    from permutect_amd.training.optimizer import FusedClipAdamW, backpropagate
+    from tests.test_forward_gpu import _arrays
+    nref = np.array([5, 300, 0, 10, 700, 2, 256, 9])
+    nalt = np.array([3, 350, 600, 15, 1, 7, 255, 1])
+    ints, floats, packed = _arrays(nref, nalt, seed=21)
+    torch.manual_seed(0)
+    model = ArtifactModel(p0_params(), device=DEV, **P0_DIMS)
+    batch = Batch.from_arrays(ints, floats, packed).copy_to(DEV)
+    ones = torch.ones(batch.size(), device=DEV)
+    db = DownsampledBatch.on_device(batch, seed=3, ref_fracs_b=ones, alt_fracs_b=ones, fix_alt_gather=True)
+    with torch.no_grad():
+        a = model.compute_batch_output(batch)
+        c = model.compute_batch_output(db)
+    assert batch.plan(allow_split=True).layered and db.plan(allow_split=True).layered
+    assert torch.allclose(a.logits_b, c.logits_b, rtol=1e-5, atol=1e-5)
+    model.train(True)
+    half = 0.5 * ones
+    thin = DownsampledBatch.on_device(batch, seed=4, ref_fracs_b=half, alt_fracs_b=half, fix_alt_gather=True)
+    opt = FusedClipAdamW(model, lr=1e-3, weight_decay=0.01)
+    out = model.compute_batch_output(thin)
+    losses = model.compute_batch_losses(out, thin)
+    backpropagate(opt, losses.total_loss, params_to_clip=model.parameters())
+    torch.cuda.synchronize()
+    assert torch.isfinite(losses.total_loss) and float(opt.grad_norm.item()) > 0
+
+
 def Data_LABEL():
     from permutect_amd.data.datum import Data
     return Data.LABEL
