@@ -38,7 +38,7 @@ def synth_arrays(rng, num_variants, depth):
     if depth == "wgs":
         nref, nalt = rng.integers(0, 11, num_variants), rng.integers(1, 16, num_variants)
     elif depth == "stress":  # BASELINE configs[4]: mean 600 reads / variant (300x tumor + normal); read sets span several
-        nref, nalt = rng.poisson(300, num_variants), np.maximum(rng.poisson(300, num_variants), 1)  # workgroups: forward only
+        nref, nalt = rng.poisson(300, num_variants), np.maximum(rng.poisson(300, num_variants), 1)  # workgroups (layered launches)
     else:  # high depth inside one workgroup per read set: mean 200 reads / variant
         nref, nalt = np.minimum(rng.poisson(100, num_variants), 120), np.clip(rng.poisson(100, num_variants), 1, 120)
     ints = np.zeros((num_variants, 16 + 42), dtype=np.int16)
@@ -66,9 +66,11 @@ def pmc_traffic(kernel, args):
     return None if k is None else k["hbm_bytes_per_launch"]
 
 
-def algorithmic_macs_per_read(model):
-    """Forward MACs per read of the read-set path: read MLP + L gated blocks + reducer + rotation."""
+def algorithmic_macs_per_read(model, padded=False):
+    """Forward MACs per read of the read-set path: read MLP + L gated blocks + reducer + rotation.
+    `padded`: with every dimension rounded up to the 16-wide MFMA tile (what the matrix core actually executes)."""
     d = model.engine().plan.desc
+    up = (lambda n: (n + 15) // 16 * 16) if padded else (lambda n: n)
     macs = 0
     used = set()
 
@@ -81,9 +83,9 @@ def algorithmic_macs_per_read(model):
     mlp(d.read_mlp)
     mlp(d.reducer)
     used.add(d.rotation_lin)
-    macs = sum(d.lin[i].in_dim * d.lin[i].out_dim for i in used)
+    macs = sum(up(d.lin[i].in_dim) * up(d.lin[i].out_dim) for i in used)
     h = d.d_ffn // 2
-    macs += d.num_blocks * (d.d_model * d.d_ffn + h * d.d_model)  # one side's proj1 + proj2 per read
+    macs += d.num_blocks * (up(d.d_model) * (up(h) + up(h)) + up(h) * up(d.d_model))  # one side's proj1 + proj2 per read
     return macs
 
 
@@ -136,6 +138,9 @@ def main():
     ap.add_argument("--resident-batches", type=int, default=4, help="distinct synthetic batches kept in HBM per GPU")
     ap.add_argument("--depth", choices=["wgs", "high", "stress"], default="wgs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="development only: run the N > 1 code path on a box with fewer GPUs than ranks (ranks share the "
+                         "cards, gloo instead of RCCL); the numbers mean nothing")
     ap.add_argument("--data", choices=["resident", "loader"], default="resident",
                     help="resident: batches already in HBM (the metric's definition); loader: batches drawn from a "
                          "synthetic dataset in host memory through the device chunk loader, chunk uploads inside the timed "
@@ -149,12 +154,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+    if args.rehearse:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     torch.manual_seed(0)  # identical initial weights on every rank
     model = ArtifactModel(p0_params(), device=dev, **P0_DIMS)
@@ -235,6 +245,7 @@ def main():
             dom, dom_flops, dom_ms = "pmt_forward_kernel", fwd_flops, kernel_ms["pmt_forward"]
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12
         traffic = pmc_traffic(dom, args)
+        pad_ratio = algorithmic_macs_per_read(model, padded=True) / macs
         value = world * args.batch * args.steps / elapsed
         line = {
             "metric": "read-sets/sec (train fwd+bwd)" if args.mode == "train" else "read-sets/sec (filter fwd)",
@@ -249,6 +260,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "kernel": dom,
                          "kernel_ms": dom_ms, "algorithmic_flops_per_launch": dom_flops,
+                         "padded_flops_per_launch": dom_flops * pad_ratio, "frac_padded": achieved * pad_ratio / PEAK_FP32_MFMA_TFLOPS,
+                         "hbm_frac": None if traffic is None else traffic / (dom_ms * 1e-3) / (PEAK_HBM_GBS * 1e9),
                          "other_kernel_ms": {k: v for k, v in kernel_ms.items()}},
         }
         if world == 1 and not args.no_cpu_baseline:
