@@ -259,7 +259,10 @@ def load_model(path, device: torch.device = None):
     if device is None:
         device = gpu_if_available()
     install_pickle_alias()
-    saved = torch.load(path, map_location=device, weights_only=False)
+    # the restricted unpickler: tensors, containers and the hyperparameter class only (the reference loads with
+    # weights_only=False, architecture/artifact_model.py:352; a checkpoint is untrusted input)
+    with torch.serialization.safe_globals([ModelParameters]):
+        saved = torch.load(path, map_location=device, weights_only=True)
     model = ArtifactModel(saved[constants.HYPERPARAMS_NAME], num_read_features=saved[constants.NUM_READ_FEATURES_NAME],
                           num_info_features=saved[constants.NUM_INFO_FEATURES_NAME],
                           haplotypes_length=saved[constants.REF_SEQUENCE_LENGTH_NAME], device=device)

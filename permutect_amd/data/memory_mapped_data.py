@@ -28,6 +28,16 @@ SUFFIX_FOR_READS_MMAP = ".reads_mmap.npy"
 SUFFIX_FOR_METADATA = ".metadata.npy"
 
 
+def _load_metadata(path):
+    """The metadata member is a torch.save of a small numpy integer array (reference memory_mapped_data.py:208-219).
+    A dataset tar is untrusted input: unpickle with the restricted loader, allowing only what such an array needs."""
+    rec = np._core.multiarray._reconstruct
+    allowed = [rec, (rec, "numpy.core.multiarray._reconstruct"), np.ndarray, np.dtype] + \
+              [type(np.dtype(t)) for t in ("uint32", "int32", "int64", "uint64")]
+    with torch.serialization.safe_globals(allowed):
+        return torch.load(path, weights_only=True)
+
+
 class MemoryMappedData:
     def __init__(self, int_mmap, float_mmap, num_data: int, reads_mmap, num_reads: int):
         self.int_mmap, self.float_mmap, self.reads_mmap = int_mmap, float_mmap, reads_mmap
@@ -127,7 +137,7 @@ class MemoryMappedData:
             assert len(found) == 1 or (not required and not found), f"expected one *{suffix} member, found {len(found)}"
             return found[0] if found else None
 
-        metadata = torch.load(one(SUFFIX_FOR_METADATA), weights_only=False)
+        metadata = _load_metadata(one(SUFFIX_FOR_METADATA))
         num_data, int_dim, float_dim, num_reads, reads_dim = (int(x) for x in np.asarray(metadata)[:5])
         int_mmap = np.load(one(SUFFIX_FOR_INT_MMAP), mmap_mode="r")
         float_mmap = np.load(one(SUFFIX_FOR_FLOAT_MMAP), mmap_mode="r")
