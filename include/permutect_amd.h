@@ -417,6 +417,11 @@ int pmt_scan_counts(const void* ref_counts, const void* alt_counts, int32_t coun
 int pmt_build_read_index(const int64_t* row_start, const int32_t* ref_offsets, const int32_t* alt_offsets,
                          int32_t num_variants, int64_t* read_index, void* stream);
 
+/* Host-side staging copy for the dataset loader (reference data/reads_dataset.py:141-196 reads the memory map Datum by
+ * Datum): copies `bytes` from src (a memory-mapped file or host array) to dst (a pinned staging buffer) with `threads`
+ * worker threads, outside the Python GIL.  Pure host code, no HIP call. */
+int pmt_host_copy(void* dst, const void* src, size_t bytes, int32_t threads);
+
 /* Fused read-set forward: decode -> read MLP -> concat -> L gated ref/alt blocks -> reducer -> rotation ->
  * clustering head + per-set sums.  Replaces ArtifactModel.calculate_features + FeatureClustering.calculate_logits
  * + RaggedSets.means_over_sets (reference artifact_model.py:239-297).  `stash` = NULL for inference; otherwise the

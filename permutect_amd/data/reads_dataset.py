@@ -22,7 +22,7 @@ from typing import Iterator, List, Optional
 import numpy as np
 import torch
 
-from permutect_amd.data.batch import Batch
+from permutect_amd.data.batch import Batch, GroupPlan
 from permutect_amd.data.datum import (Data, Datum, HAPLOTYPES_START_IDX, INFO_START_IDX,
                                       NUMBER_OF_BYTES_IN_PACKED_READ)
 from permutect_amd.data.memory_mapped_data import MemoryMappedData
@@ -141,27 +141,57 @@ class ReadsDataset:
         return DeviceChunkLoader(self, batch_size, device, chunk_variants, rng, shuffle, rank, world_size)
 
 
+_STAGE_THREADS = 6
+_PREFETCH = 2  # chunks being loaded while one is consumed: one loader thread (~10 ms of Python + copies per 114 MB
+               # chunk) cannot keep up with the filter forward (~8 ms per chunk of 262 144 variants)
+
+
+class PinnedStage:
+    """Pinned staging buffers that live as long as their loader (pinning ~100 MB costs 10 - 70 ms, a chunk upload ~2 ms).
+    One buffer per array name, grown with 12 % slack when a chunk needs more.  The user must have finished (synchronised)
+    the copies out of a buffer before asking for it again."""
+
+    def __init__(self):
+        self._bufs = {}
+
+    def get(self, name: str, shape, dtype: torch.dtype) -> torch.Tensor:
+        nbytes = int(np.prod(shape)) * torch.empty(0, dtype=dtype).element_size()
+        buf = self._bufs.get(name)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes * 1.125), 4096), dtype=torch.uint8, pin_memory=True)
+            self._bufs[name] = buf
+        return buf[:nbytes].view(dtype).view(shape)
+
+
 class DeviceChunk:
     """A contiguous range of the dataset in HBM, exactly as it lies on disk."""
 
-    def __init__(self, dataset: ReadsDataset, lo: int, hi: int, device: torch.device):
+    def __init__(self, dataset: ReadsDataset, lo: int, hi: int, device: torch.device, stage: Optional[PinnedStage] = None):
         self.lo, self.hi = lo, hi
         r0, r1 = int(dataset._starts[lo]), int(dataset._starts[hi])
         cuda = device.type == "cuda"
+        names = iter(("ints", "floats", "reads", "row_start"))
 
         def upload(arr: np.ndarray) -> torch.Tensor:
-            # disk (memory map) -> pinned staging buffer -> HBM; an array already in host memory is staged the same way
-            host = torch.empty(arr.shape, dtype=torch.from_numpy(np.empty(0, arr.dtype)).dtype, pin_memory=cuda)
-            np.copyto(host.numpy(), arr)
+            # disk (memory map) -> pinned staging buffer -> HBM; an array already in host memory is staged the same way.
+            # The staging copy runs in the library on a few threads and outside the GIL (pmt_host_copy): one thread moves
+            # ~10 GB/s, well under what the PCIe link takes, and Python worker threads would queue for the GIL behind
+            # the training loop (5 ms per hand-off).
+            dtype = torch.from_numpy(np.empty(0, arr.dtype)).dtype
+            name = next(names)
+            host = stage.get(name, arr.shape, dtype) if (stage is not None and cuda) else torch.empty(arr.shape, dtype=dtype, pin_memory=cuda)
+            if arr.flags["C_CONTIGUOUS"] and arr.nbytes >= (1 << 22):
+                L.check(L.load().pmt_host_copy(host.data_ptr(), arr.ctypes.data, arr.nbytes, _STAGE_THREADS), "pmt_host_copy")
+            else:
+                np.copyto(host.numpy(), arr)
             return host.to(device, non_blocking=cuda)
 
-        self.ints_host = np.array(dataset._ints[lo:hi])  # host copy: the planner needs the counts
-        self.ints = upload(self.ints_host)                               # int16 [n, 16 + H]
+        self.ints = upload(dataset._ints[lo:hi])                         # int16 [n, 16 + H]
         self.floats = upload(dataset._floats[lo:hi])                     # float16 [n, 6 + I]
         self.reads = upload(dataset._reads[r0:r1])                       # uint8 [R, 7 + nf]
         self.row_start = upload(dataset._starts[lo:hi] - r0)             # int64 [n]
-        self.ref_host = self.ints_host[:, Data.REF_COUNT.idx].astype(np.int32)
-        self.alt_host = self.ints_host[:, Data.ALT_COUNT.idx].astype(np.int32)
+        self.ref_host = np.asarray(dataset._ints[lo:hi, Data.REF_COUNT.idx]).astype(np.int32)  # the planner's counts
+        self.alt_host = np.asarray(dataset._ints[lo:hi, Data.ALT_COUNT.idx]).astype(np.int32)
         self.nbytes = self.ints.numel() * 2 + self.floats.numel() * 2 + self.reads.numel() + self.row_start.numel() * 8
 
 
@@ -169,9 +199,13 @@ class ChunkBatch(Batch):
     """A batch whose variants are rows of a `DeviceChunk`: per-variant tensors gathered on the device, reads referenced
     through a gather index (no read row moves)."""
 
-    def __init__(self, chunk: DeviceChunk, ids_host: np.ndarray):
+    def __init__(self, chunk: DeviceChunk, ids_host: np.ndarray, ids_dev: Optional[torch.Tensor] = None,
+                 plan: Optional[GroupPlan] = None):
+        """`ids_dev` / `plan`: the ids already on the device and the batch's group plan with its device arrays, when the
+        loader prepared them with the chunk (no host-to-device copy is left in the per-batch path then: a copy from
+        pageable memory makes the host wait for the previous batch's kernels, so it could not run ahead of the GPU)."""
         dev = chunk.ints.device
-        ids = torch.from_numpy(np.ascontiguousarray(ids_host, dtype=np.int64)).to(dev, non_blocking=dev.type == "cuda")
+        ids = ids_dev if ids_dev is not None else torch.from_numpy(np.ascontiguousarray(ids_host, dtype=np.int64)).to(dev)
         self.int_tensor = chunk.ints.index_select(0, ids).to(torch.long)
         self.float_tensor = chunk.floats.index_select(0, ids).to(torch.float)
         self.packed_reads = chunk.reads
@@ -179,7 +213,7 @@ class ChunkBatch(Batch):
         self._num_read_features = 8 * NUMBER_OF_BYTES_IN_PACKED_READ + chunk.reads.shape[1] - NUMBER_OF_BYTES_IN_PACKED_READ
         self._size = len(ids_host)
         self._host_counts = (chunk.ref_host[ids_host], chunk.alt_host[ids_host])
-        self._plan = None
+        self._plan = plan
         self._offsets = None
         self._row_start = chunk.row_start.index_select(0, ids)
         self._read_index = None
@@ -189,17 +223,19 @@ class ChunkBatch(Batch):
             dev = self.int_tensor.device
             lib = L.load()
             b = self._size
-            ref_off = torch.empty(b + 1, dtype=torch.int32, device=dev)
-            alt_off = torch.empty(b + 1, dtype=torch.int32, device=dev)
-            ref_c, alt_c, elem, stride = self.device_counts()
             stream = torch.cuda.current_stream().cuda_stream
-            L.check(lib.pmt_scan_counts(ref_c.data_ptr(), alt_c.data_ptr(), elem, stride, b, ref_off.data_ptr(),
-                                        alt_off.data_ptr(), stream), "pmt_scan_counts")
+            if self._offsets is None:
+                ref_off = torch.empty(b + 1, dtype=torch.int32, device=dev)
+                alt_off = torch.empty(b + 1, dtype=torch.int32, device=dev)
+                ref_c, alt_c, elem, stride = self.device_counts()
+                L.check(lib.pmt_scan_counts(ref_c.data_ptr(), alt_c.data_ptr(), elem, stride, b, ref_off.data_ptr(),
+                                            alt_off.data_ptr(), stream), "pmt_scan_counts")
+                self._offsets = (ref_off, alt_off)
+            ref_off, alt_off = self._offsets
             total = int(self._host_counts[0].sum()) + int(self._host_counts[1].sum())
             index = torch.empty(total, dtype=torch.int64, device=dev)
             L.check(lib.pmt_build_read_index(self._row_start.data_ptr(), ref_off.data_ptr(), alt_off.data_ptr(), b,
                                              index.data_ptr(), stream), "pmt_build_read_index")
-            self._offsets = (ref_off, alt_off)
             self._read_index = index
         return self._read_index
 
@@ -228,33 +264,75 @@ class DeviceChunkLoader:
         self.hi = (rank + 1) * per if rank < world_size - 1 else n
         self.ranges = dataset._chunk_ranges(chunk_variants, self.lo, self.hi)
         self.bytes_uploaded = 0
+        self._stages = [PinnedStage() for _ in range(_PREFETCH)]  # one per chunk in flight
 
     def __len__(self) -> int:
         return sum(-(-(hi - lo) // self.batch_size) for lo, hi in self.ranges)
 
-    def _load(self, c: int) -> DeviceChunk:
-        """Runs on the prefetch thread: stage and upload chunk c on a side stream, return when it is resident."""
+    def _prepare(self, chunk: DeviceChunk, ids: np.ndarray, stage: PinnedStage):
+        """Everything the chunk's batches need from the host, uploaded ONCE with the chunk: the shuffled variant ids and
+        every batch's group plan (one pinned buffer, one copy); returns per batch (ids_host, ids_dev, plan)."""
+        dev, bs = self.device, self.batch_size
+        slices = [ids[s:s + bs] for s in range(0, len(ids), bs)]
+        plans = [GroupPlan(chunk.ref_host[sl], chunk.alt_host[sl], allow_split=True) for sl in slices]
+        parts = []
+        for p in plans:
+            parts += [p.group_start, p.group_tile_base] + ([] if p.span is None else [p.span.ravel()])
+        flat = np.concatenate([ids.astype(np.int64).view(np.int32)] + parts)  # ids first: stays 8-byte aligned
+        host = stage.get("plans", flat.shape, torch.int32) if dev.type == "cuda" else torch.empty(flat.shape, dtype=torch.int32)
+        host.numpy()[...] = flat
+        flat_dev = host.to(dev, non_blocking=dev.type == "cuda")
+        ids_dev = flat_dev[: 2 * len(ids)].view(torch.int64)
+        at = 2 * len(ids)
+        out = []
+        for k, (sl, p) in enumerate(zip(slices, plans)):
+            views = []
+            for arr in (p.group_start, p.group_tile_base):
+                views.append(flat_dev[at:at + arr.size])
+                at += arr.size
+            span = None
+            if p.span is not None:
+                span = flat_dev[at:at + p.span.size].view(p.span.shape)
+                at += p.span.size
+            p._dev[str(dev)] = (views[0], views[1], span)
+            out.append((sl, ids_dev[k * bs:k * bs + len(sl)], p))
+        return out
+
+    def _load(self, c: int, seed: int, slot: int):
+        """Runs on a prefetch thread: stage and upload chunk c and its batches' ids / plans on a side stream, return when
+        they are resident.  `slot` names the staging buffers (free again once the chunk that used them last was returned)."""
+        stage = self._stages[slot]
         lo, hi = self.ranges[c]
+        n = hi - lo
+        ids = np.random.default_rng(seed).permutation(n) if self.shuffle else np.arange(n)
         if self.device.type != "cuda":
-            return DeviceChunk(self.dataset, lo, hi, self.device)
+            chunk = DeviceChunk(self.dataset, lo, hi, self.device)
+            return chunk, self._prepare(chunk, ids, stage)
         torch.cuda.set_device(self.device)
         side = torch.cuda.Stream(self.device)
         with torch.cuda.stream(side):
-            chunk = DeviceChunk(self.dataset, lo, hi, self.device)
+            chunk = DeviceChunk(self.dataset, lo, hi, self.device, stage)
+            batches = self._prepare(chunk, ids, stage)
         side.synchronize()
-        return chunk
+        return chunk, batches
 
     def __iter__(self) -> Iterator[ChunkBatch]:
-        """One chunk is trained on while the next is read, staged and uploaded by a background thread."""
+        """One chunk is trained on while the next ones are read, staged and uploaded by background threads."""
+        from collections import deque
         from concurrent.futures import ThreadPoolExecutor
         order_c = self.rng.permutation(len(self.ranges)) if self.shuffle else np.arange(len(self.ranges))
-        with ThreadPoolExecutor(max_workers=1) as pool:
-            pending = pool.submit(self._load, int(order_c[0])) if len(order_c) else None
-            for i, c in enumerate(order_c):
-                chunk = pending.result()
-                pending = pool.submit(self._load, int(order_c[i + 1])) if i + 1 < len(order_c) else None
+        seeds = self.rng.integers(0, 2 ** 63 - 1, size=len(order_c))  # one stream per chunk: the prefetch thread shuffles
+        with ThreadPoolExecutor(max_workers=_PREFETCH) as pool:
+            pending = deque()
+
+            def submit(i):
+                if i < len(order_c):
+                    pending.append(pool.submit(self._load, int(order_c[i]), int(seeds[i]), i % _PREFETCH))
+            for i in range(_PREFETCH):
+                submit(i)
+            for i in range(len(order_c)):
+                chunk, batches = pending.popleft().result()
+                submit(i + _PREFETCH)
                 self.bytes_uploaded += chunk.nbytes
-                n = self.ranges[c][1] - self.ranges[c][0]
-                ids = self.rng.permutation(n) if self.shuffle else np.arange(n)
-                for s in range(0, len(ids), self.batch_size):
-                    yield ChunkBatch(chunk, ids[s:s + self.batch_size])
+                for ids_host, ids_dev, plan in batches:
+                    yield ChunkBatch(chunk, ids_host, ids_dev, plan)

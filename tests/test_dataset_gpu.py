@@ -140,3 +140,32 @@ def test_train_artifact_model_loop_end_to_end():
     with torch.no_grad():
         out = model.compute_batch_output(valid.host_batch(np.arange(len(valid))).copy_to(dev))
     assert torch.isfinite(out.logits_b).all()
+
+
+@pytest.mark.parametrize("n", [0, 1, 4095, 4096, 4097, 70001, 300000, 1 << 20])
+@pytest.mark.parametrize("wide", [True, False])
+def test_count_scans_of_any_length(n, wide):
+    """pmt_scan_counts (exclusive scans of the ref / alt count columns, bit-exact): lengths around the 4096-element chunk,
+    beyond one segment and beyond 64 x 4096; int64 counts in a strided table and contiguous int32 counts."""
+    import ctypes as C
+    from permutect_amd.engine import lib as L
+    lib = L.load()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(n + (1 if wide else 0))
+    ref, alt = rng.integers(0, 11, n), rng.integers(1, 16, n)
+    if wide:
+        table = torch.zeros(max(n, 1), 7, dtype=torch.int64)
+        table[:n, 0], table[:n, 1] = torch.from_numpy(ref), torch.from_numpy(alt)
+        table = table.to(dev)
+        rc, ac, elem, stride = table[:, 0], table[:, 1], 8, table.stride(0)
+    else:
+        rc, ac = torch.from_numpy(ref.astype(np.int32)).to(dev), torch.from_numpy(alt.astype(np.int32)).to(dev)
+        if n == 0:
+            rc, ac = torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+        elem, stride = 4, 1
+    ro = torch.full((n + 1,), -1, dtype=torch.int32, device=dev)
+    ao = torch.full((n + 1,), -1, dtype=torch.int32, device=dev)
+    L.check(lib.pmt_scan_counts(rc.data_ptr(), ac.data_ptr(), elem, stride, n, ro.data_ptr(), ao.data_ptr(),
+                                torch.cuda.current_stream().cuda_stream), "pmt_scan_counts")
+    assert np.array_equal(ro.cpu().numpy(), np.concatenate([[0], np.cumsum(ref)]).astype(np.int32))
+    assert np.array_equal(ao.cpu().numpy(), np.concatenate([[0], np.cumsum(alt)]).astype(np.int32))
