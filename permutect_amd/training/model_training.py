@@ -68,7 +68,10 @@ class Checkpoint:
 
 def train_artifact_model(model, train_dataset: ReadsDataset, valid_dataset: Optional[ReadsDataset],
                          training_params: TrainingParameters, chunk_variants: Optional[int] = 1 << 18, seed: int = 0,
-                         dist=None, log=print):
+                         dist=None, log=print, fix_alt_gather: bool = False):
+    """`fix_alt_gather`: the reference's DownsampledBatch gathers the kept alt reads without the offset of the ref region
+    (SURVEY 0.5b), so its training steps see ref rows in place of alt reads; False reproduces that, True gathers the
+    intended rows."""
     device = model._device
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
     num_sources = train_dataset.num_sources()
@@ -109,7 +112,7 @@ def train_artifact_model(model, train_dataset: ReadsDataset, valid_dataset: Opti
                     break
                 for _ in range(2):  # two independent downsamplings of every parent batch (reference :153)
                     step_seed += 1
-                    batch = downsampler.downsample(parent, seed=step_seed)
+                    batch = downsampler.downsample(parent, seed=step_seed, fix_alt_gather=fix_alt_gather)
                     with torch.set_grad_enabled(epoch_type == Epoch.TRAIN):
                         output = model.compute_batch_output(batch, balancer)
                         losses = model.compute_batch_losses(output, batch)
