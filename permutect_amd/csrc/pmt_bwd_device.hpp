@@ -17,19 +17,23 @@ DEV float read_lanes_sum(float v) {  // sum over the 16 reads of a tile (lanes w
 }
 DEV float wave_sum(float v) { return group_sum(read_lanes_sum(v)); }
 
-// C-layout registers of one 16x16 (feature x read) tile -> "reads on k" operand: element ks = value of feature position
-// p = lane & 15 for read 4 * (lane >> 4) + ks.
-//
-// Done on the matrix core, with no LDS round trip: a C-layout register is also a valid A operand (m = read = lane & 15,
-// k = lane >> 4 <-> position 4*(lane>>4) + j at k-step j), so  D = X^T * I  with the 16x16 identity as B lands the tile
-// transposed in C layout (row 4G+J = read, column = position).  Multiplying by exact 0 / 1 makes it bit-exact.  Four
-// MFMAs per tile on a pipe that is mostly idle in this kernel, instead of 4 ds_write + 1 ds_read and two LDS latencies.
-DEV f4 transpose_tile(f4 v) {
-    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
-    f4 o = f4{0.f, 0.f, 0.f, 0.f};
+// The weight-gradient contraction runs over READS, so its operands are the transposes of the C-layout tiles: element ks of
+// lane (G, n) = value of feature position n for read 4 G + ks (position n = 4 g + j is register j of lane group g).
+// The first version transposed in registers on the matrix core (D = X^T * I, bit-exact, 4 MFMAs per tile); once the
+// fp32 pipe became the bound that was a quarter of the block loop's MFMA work.
+// The wgrad exchange needs the transposed tile in LDS, not in registers: there the transposition is free, it is only a
+// matter of WHERE each lane stores its four values.  A plane of the stage is 64 slots of 16 bytes; slot sigma(G, n) holds
+// X[position n][reads 4G .. 4G + 3], exactly what the lane (G, n) of the consuming wave feeds to the matrix core.
+// sigma = 16 (n & 3) + 8 (n >> 3) + 2 (G ^ (n & 3)) + ((n >> 2) & 1)  is chosen so that the producer's four ds_write_b32
+// (32-lane halves, bank = dword address mod 32) and the consumer's ds_read_b128 (lane groups {0-3, 12-15, 20-27}, ...;
+// 16-byte slot mod 16) are both conflict-free (MI355X_MICROARCH.md, LDS).  Four stores on the LDS pipe replace four
+// MFMAs on the fp32 pipe, which bounds this kernel.
+DEV int stage_slot(int G, int n) { return 16 * (n & 3) + 8 * (n >> 3) + 2 * (G ^ (n & 3)) + ((n >> 2) & 1); }
+DEV void stage_store_transposed(f4* __restrict__ plane, f4 v) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15, G = r >> 2, J = r & 3;
+    float* p = reinterpret_cast<float*>(plane) + 32 * (g >> 1) + 4 * (g & 1) + J;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o = mfma16(v[j], (n == 4 * g + j) ? 1.0f : 0.0f, o);
-    return o;
+    for (int j = 0; j < 4; ++j) p[64 * j + 8 * (G ^ j)] = v[j];
 }
 
 DEV int pos_to_feat(int p) { return 16 * (p >> 4) + 4 * (p & 3) + ((p & 15) >> 2); }
@@ -292,13 +296,13 @@ DEV void wgrad_accumulate(WgradAcc<NTO, NTI, SIDES>& a, BwdCtx& c, const f4 (&dy
         for (int rt = 0; rt < PMT_RT; ++rt) {
             const int tau = c.slot0 + rt - t0;
             if (((c.mask_all >> rt) & 1u) && tau >= 0 && tau < TP) {
-                f4* pl = c.stage + (size_t)(tau * P) * 64 + lane;
+                f4* pl = c.stage + (size_t)(tau * P) * 64;
 #pragma unroll
                 for (int ot = 0; ot < NTO; ++ot)
-                    if (ot < a.nmt) pl[ot * 64] = transpose_tile(dy[rt][ot]);
+                    if (ot < a.nmt) stage_store_transposed(pl + ot * 64, dy[rt][ot]);
 #pragma unroll
                 for (int it = 0; it < NTI; ++it)
-                    if (it < a.nkt) pl[(NTO + it) * 64] = transpose_tile(x[rt][it]);
+                    if (it < a.nkt) stage_store_transposed(pl + (NTO + it) * 64, x[rt][it]);
             }
         }
         __syncthreads();
@@ -309,8 +313,9 @@ DEV void wgrad_accumulate(WgradAcc<NTO, NTI, SIDES>& a, BwdCtx& c, const f4 (&dy
             int hi = (SIDES == 2 && a.t_side[k] == 0) ? c.tiles_ref : c.ntiles;
             lo = max(lo, t0) - t0;
             hi = min(hi, t0 + TP) - t0;
-            const f4* pa = c.stage + (size_t)a.t_ot[k] * 64 + lane;
-            const f4* pb = c.stage + (size_t)(NTO + a.t_it[k]) * 64 + lane;
+            const int slot = stage_slot(lane >> 4, lane & 15);
+            const f4* pa = c.stage + (size_t)a.t_ot[k] * 64 + slot;
+            const f4* pb = c.stage + (size_t)(NTO + a.t_it[k]) * 64 + slot;
             const bool with_bias = a.t_it[k] == 0;
             for (int tau = lo; tau < hi; ++tau) {
                 const f4 va = pa[tau * P * 64], vb = pb[tau * P * 64];
