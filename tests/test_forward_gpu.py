@@ -45,7 +45,9 @@ def check_outputs(out, z, name):
         ref = z["out/" + k]
         np.testing.assert_allclose(t.cpu().numpy(), ref, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(ref).max())), err_msg=k)
     ref = z["out/outlier_binary_logits"]
-    np.testing.assert_allclose(out.outlier_binary_logits.cpu().numpy(), ref, rtol=2e-5, atol=1e-4 + 4 * np.spacing(mag.astype(np.float32)).max())
+    # a difference of two summed log-likelihoods (each good to a few ulp of ITS magnitude; the per-set sums are float atomics,
+    # so their rounding varies from run to run): 8 ulp of the larger one
+    np.testing.assert_allclose(out.outlier_binary_logits.cpu().numpy(), ref, rtol=2e-5, atol=1e-4 + 8 * np.spacing(mag.astype(np.float32)).max())
 
 
 @pytest.mark.parametrize("name", CASES)
