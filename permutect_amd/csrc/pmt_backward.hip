@@ -78,9 +78,9 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, wave = uniform((int)(tid >> 6));
     const GroupGeom gg = group_geometry(bt, blockIdx.x);
     const int side = gg.side;
-    const int D = uniform(M->d_model), E = uniform(M->feature_dim), K = uniform(M->num_clusters);
-    const int Er = uniform(M->read_embed_dim), Ev = uniform(M->variant_embed_dim);
-    const int h = uniform(M->d_ffn) >> 1, L = uniform(M->num_blocks), F = uniform(M->num_read_features);
+    const int D = S::DIM_D ? S::DIM_D : uniform(M->d_model), E = S::DIM_E ? S::DIM_E : uniform(M->feature_dim), K = uniform(M->num_clusters);
+    const int Er = S::DIM_R ? S::DIM_R : uniform(M->read_embed_dim), Ev = uniform(M->variant_embed_dim);
+    const int h = S::DIM_H ? S::DIM_H : (uniform(M->d_ffn) >> 1), L = uniform(M->num_blocks), F = S::DIM_F ? S::DIM_F : uniform(M->num_read_features);
     const int nte = (E + 15) >> 4;
 
     // ---- setup ------------------------------------------------------------------------------------------------------
@@ -682,7 +682,8 @@ extern "C" int pmt_backward(const PmtModel* model_host, const PmtModel* model_de
         return PMT_E_INVALID;
     const float* zsum_stash = stash + (size_t)batch->total_tiles * (size_t)pmt_stash_slots(model_host) * PMT_SLOT_FLOATS;
     const float* rstd_stash = zsum_stash + (size_t)batch->num_variants * (size_t)(model_host->num_blocks > 0 ? model_host->num_blocks : 1) * 32;
-    auto kernel = pmt_shape_id(model_host) == 1 ? pmt_backward_kernel<ShapeP0> : pmt_backward_kernel<ShapeAny>;
+    const int shape = pmt_shape_id(model_host);
+    auto kernel = shape == 2 ? pmt_backward_kernel<ShapeP0X> : shape == 1 ? pmt_backward_kernel<ShapeP0> : pmt_backward_kernel<ShapeAny>;
     hipLaunchKernelGGL(kernel, dim3(batch->num_groups), dim3(PMT_THREADS), 0, reinterpret_cast<hipStream_t>(stream), model_dev,
                        theta, phi, packed, *batch, *out, *dout, stash, zsum_stash, rstd_stash, grad_theta, grad_phi, grad_variant_embed,
                        PmtBwdLayered{});
@@ -717,7 +718,7 @@ extern "C" int pmt_backward_layered(const PmtModel* model_host, const PmtModel* 
     lay.park = lay.dy_scratch + (size_t)batch->total_tiles * PMT_SLOT_FLOATS;
     lay.gsum_g = lay.park + (size_t)batch->total_tiles * 6 * 256;
     if (hipMemsetAsync(lay.gsum_g, 0, B * nb * 32 * sizeof(float), s) != hipSuccess) return PMT_E_LAUNCH;
-    auto kernel = pmt_shape_id(model_host) == 1 ? pmt_backward_kernel<ShapeP0, true> : pmt_backward_kernel<ShapeAny, true>;
+    auto kernel = pmt_shape_id(model_host) >= 1 ? pmt_backward_kernel<ShapeP0, true> : pmt_backward_kernel<ShapeAny, true>;
     for (int slice = 0; slice <= L; ++slice) {
         lay.slice = slice;
         hipLaunchKernelGGL(kernel, dim3(batch->num_groups), dim3(PMT_THREADS), 0, s, model_dev, theta, phi, packed, *batch, *out, *dout,

@@ -45,13 +45,18 @@ static_assert(PMT_GROUP_TILES == PMT_WG_TILES, "group capacity");
 // Register-array shapes of the read-set kernels, in 16-feature tiles: F read features, R read-MLP widths (after its first
 // linear), D d_model and reducer widths, E feature_dim.  EXACT: every layer fills its arrays completely, the read MLP
 // starts and the reducer ends with a LINEAR op (the two ops that change the tile count); the host picks the instance.
-template <int F, int R, int D, int E, bool EXACT_>
+// XF .. XE (only with EXACT): the EXACT widths of the model, known at compile time (0 = read from the descriptor).  With them
+// the padding masks (feature < width), the k-steps that hold nothing but padding and most width bookkeeping fold away:
+// the masks alone cost ~30 SGPR pairs that the generic code keeps (and spills) across the block loop.
+template <int F, int R, int D, int E, bool EXACT_, int XF = 0, int XR = 0, int XD = 0, int XH = 0, int XE = 0>
 struct Shape {
     static constexpr int NTF = F, NTR = R, NTD = D, NTE = E;
     static constexpr bool EXACT = EXACT_;
+    static constexpr int DIM_F = XF, DIM_R = XR, DIM_D = XD, DIM_H = XH, DIM_E = XE;  // read features, read width, d_model, d_ffn / 2, feature_dim
 };
 using ShapeAny = Shape<4, 4, 4, 4, false>;   // any supported model
 using ShapeP0 = Shape<4, 2, 4, 1, true>;     // F in 49..64, read widths 17..32, d_model / reducer widths 49..64, E <= 16
+using ShapeP0X = Shape<4, 2, 4, 1, true, 61, 30, 60, 10, 10>;  // exactly the production hyperparameters (SURVEY: P0)
 
 DEV float uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -307,7 +312,7 @@ DEV TileMeta tile_meta(const GroupGeom& gg, int rt, const int* s_off) {
 }
 
 extern "C" int pmt_stash_slots(const PmtModel* m);  // host helper (pmt_host.hip)
-extern "C" int pmt_shape_id(const PmtModel* m);     // host: 1 = the model fits ShapeP0 exactly, 0 = ShapeAny
+extern "C" int pmt_shape_id(const PmtModel* m);     // host: 2 = ShapeP0X (exact widths), 1 = ShapeP0 (exact tiles), 0 = ShapeAny
 
 // ---- LDS weight staging ------------------------------------------------------------------------------------------
 // Every linear's A fragments are consumed by all waves of the workgroup, so they are staged ONCE per workgroup into

@@ -72,9 +72,9 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
     const GroupGeom gg = group_geometry(bt, blockIdx.x);
     const int side = gg.side;
 
-    const int D = uniform(M->d_model), E = uniform(M->feature_dim), K = uniform(M->num_clusters);
-    const int Er = uniform(M->read_embed_dim), Ev = uniform(M->variant_embed_dim);
-    const int h = uniform(M->d_ffn) >> 1, L = uniform(M->num_blocks), F = uniform(M->num_read_features);
+    const int D = S::DIM_D ? S::DIM_D : uniform(M->d_model), E = S::DIM_E ? S::DIM_E : uniform(M->feature_dim), K = uniform(M->num_clusters);
+    const int Er = S::DIM_R ? S::DIM_R : uniform(M->read_embed_dim), Ev = uniform(M->variant_embed_dim);
+    const int h = S::DIM_H ? S::DIM_H : (uniform(M->d_ffn) >> 1), L = uniform(M->num_blocks), F = S::DIM_F ? S::DIM_F : uniform(M->num_read_features);
     const int dbg = bt.debug_flags ? uniform(bt.debug_flags[1]) : 0;  // development switches, 0 in production
 
     // ---- group setup: local offsets, zero the per-set accumulators -------------------------------------------
@@ -516,7 +516,7 @@ extern "C" int pmt_forward_layered(const PmtModel* model_host, const PmtModel* m
         !batch->group_tile_base || batch->total_tiles <= 0 || !out->logits_b || !out->logits_bk || !out->features_be || !out->ref_features_be)
         return PMT_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const bool p0 = pmt_shape_id(model_host) == 1;
+    const bool p0 = pmt_shape_id(model_host) >= 1;  // (the layered launches use the tile-exact instance for P0 too)
     const int L = model_host->num_blocks;
     const size_t nb = (size_t)(L > 0 ? L : 1), B = (size_t)batch->num_variants;
     PmtLayeredArgs lay;
@@ -559,7 +559,8 @@ extern "C" int pmt_forward(const PmtModel* model_host, const PmtModel* model_dev
         return PMT_E_INVALID;
     if (batch->group_span) return PMT_E_UNSUPPORTED;  // split read sets: pmt_forward_layered
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const bool p0 = pmt_shape_id(model_host) == 1;  // tile-exact instance (pmt_device.hpp: ShapeP0) or the generic one
+    const int shape = pmt_shape_id(model_host);  // pmt_device.hpp: 2 ShapeP0X, 1 ShapeP0, 0 ShapeAny
+    const bool p0 = shape == 1;
     float* zsum_stash = nullptr;
     float* rstd_stash = nullptr;
     if (stash) {
@@ -570,6 +571,7 @@ extern "C" int pmt_forward(const PmtModel* model_host, const PmtModel* model_dev
     }
     auto kernel = stash ? (p0 ? pmt_forward_kernel<true, ShapeP0> : pmt_forward_kernel<true, ShapeAny>)
                         : (p0 ? pmt_forward_kernel<false, ShapeP0> : pmt_forward_kernel<false, ShapeAny>);
+    if (shape == 2) kernel = stash ? pmt_forward_kernel<true, ShapeP0X> : pmt_forward_kernel<false, ShapeP0X>;
     hipLaunchKernelGGL(kernel, dim3(batch->num_groups), dim3(PMT_THREADS), 0, s, model_dev, theta, phi, packed, *batch, *out,
                        stash, zsum_stash, rstd_stash, PmtLayeredArgs{});
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;

@@ -36,8 +36,21 @@ extern "C" int pmt_stash_slots(const PmtModel* m) { return (m->read_mlp.n_ops - 
 // Which register-array shape the read-set kernels run with (pmt_device.hpp: Shape).  1 = ShapeP0, every layer fills
 // its tile arrays exactly: F and the first read linear 4 -> 2 tiles, the rest of the read MLP 2 tiles wide, d_model
 // and the reducer 4 tiles wide up to a last LINEAR 4 -> 1, feature_dim 1 tile.  Anything else runs the generic shape.
-// PMT_SHAPE=any in the environment forces the generic instance (used by the parity tests to cover both).
+// 2 = ShapeP0X: additionally every width equals the production hyperparameters' (61 read features, read width 30,
+// d_model 60, d_ffn 20, feature_dim 10), which that instance has compiled in.
+// PMT_SHAPE=any / PMT_SHAPE=tile in the environment force the generic / the tile-exact instance (the parity tests cover all).
 static int tiles_of(int dim) { return (dim + 15) / 16; }
+static bool mlp_ops_have_width(const PmtModel* m, const PmtMlp* mlp, int first, int last, int width) {
+    for (int i = first; i < last; ++i) {
+        const PmtOp* o = &mlp->ops[i];
+        const int nl = o->kind == PMT_OP_SKIP ? o->n_layers : 1;
+        for (int k = 0; k < nl; ++k) {
+            const PmtLinear* L = &m->lin[o->lin[k]];
+            if (L->in_dim != width || L->out_dim != width) return false;
+        }
+    }
+    return true;
+}
 static bool mlp_ops_have_tiles(const PmtModel* m, const PmtMlp* mlp, int first, int last, int nt) {
     for (int i = first; i < last; ++i) {
         const PmtOp* o = &mlp->ops[i];
@@ -64,7 +77,12 @@ extern "C" int pmt_shape_id(const PmtModel* m) {
                     mlp_ops_have_tiles(m, rm, 1, rm->n_ops, 2) && tiles_of(m->read_embed_dim) == 2 &&
                     tiles_of(m->d_model) == 4 && m->d_ffn >= 2 && mlp_ops_have_tiles(m, red, 0, red->n_ops - 1, 4) &&
                     tiles_of(Ll->in_dim) == 4 && tiles_of(Ll->out_dim) == 1 && tiles_of(m->feature_dim) == 1;
-    return ok ? 1 : 0;
+    if (!ok) return 0;
+    if (force && strcmp(force, "tile") == 0) return 1;
+    const bool exact = m->num_read_features == 61 && Lf->in_dim == 61 && Lf->out_dim == 30 && mlp_ops_have_width(m, rm, 1, rm->n_ops, 30) &&
+                       m->read_embed_dim == 30 && m->d_model == 60 && m->d_ffn == 20 &&
+                       mlp_ops_have_width(m, red, 0, red->n_ops - 1, 60) && Ll->in_dim == 60 && Ll->out_dim == 10 && m->feature_dim == 10;
+    return exact ? 2 : 1;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

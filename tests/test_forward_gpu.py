@@ -14,10 +14,13 @@ from tests.helpers import CASES, config_for, load_case
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["auto", "any"], autouse=True)
+@pytest.fixture(params=["auto", "tile", "any"], autouse=True)
 def kernel_shape(request, monkeypatch):
-    """Every case runs twice: with the tile-exact kernel instance the library picks for the model (ShapeP0 for the P0
-    fixtures) and with the generic instance forced through PMT_SHAPE=any (read by the library at every launch)."""
+    """Every case runs three times: with the kernel instance the library picks for the model (for the P0 fixtures ShapeP0X,
+    which has the production widths compiled in), with the tile-exact instance (PMT_SHAPE=tile: ShapeP0, widths read at run
+    time) and with the generic instance (PMT_SHAPE=any); the library reads the variable at every launch."""
+    if request.param == "tile":
+        monkeypatch.setenv("PMT_SHAPE", "tile")
     if request.param == "any":
         monkeypatch.setenv("PMT_SHAPE", "any")
         monkeypatch.setenv("PMT_CNN", "general")  # and the general (workgroup-per-chunk) haplotype-CNN kernels

@@ -13,10 +13,13 @@ from tests.test_forward_gpu import build
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["auto", "any"], autouse=True)
+@pytest.fixture(params=["auto", "tile", "any"], autouse=True)
 def kernel_shape(request, monkeypatch):
-    """Every case runs twice: with the tile-exact kernel instance the library picks for the model (ShapeP0 for the P0
-    fixtures) and with the generic instance forced through PMT_SHAPE=any (read by the library at every launch)."""
+    """Every case runs three times: with the kernel instance the library picks for the model (for the P0 fixtures ShapeP0X,
+    which has the production widths compiled in), with the tile-exact instance (PMT_SHAPE=tile: ShapeP0, widths read at run
+    time) and with the generic instance (PMT_SHAPE=any); the library reads the variable at every launch."""
+    if request.param == "tile":
+        monkeypatch.setenv("PMT_SHAPE", "tile")
     if request.param == "any":
         monkeypatch.setenv("PMT_SHAPE", "any")
         monkeypatch.setenv("PMT_CNN", "general")  # and the general (workgroup-per-chunk) haplotype-CNN kernels
@@ -128,6 +131,7 @@ def test_phi_kernels_match_torch_parametrizations(name):
     model, dev = build(name, sd)
     model.train(True)
     eng = model.engine()
+    torch.manual_seed(11)
     with torch.no_grad():  # move the rotation away from its initial point so that expm and its adjoint are exercised
         model.pre_clustering_transform.rotation_ee.parametrizations.weight.original.add_(
             0.3 * torch.randn_like(model.pre_clustering_transform.rotation_ee.parametrizations.weight.original))
