@@ -374,15 +374,15 @@ DEV void linear_wgrad(BwdCtx& c, const PmtLinear& L, const f4 (&dy)[PMT_RT][NTO]
 
 // Backward of one LINEAR op between register arrays of different tile counts (see run_linear_op): dy is the gradient
 // w.r.t. the op's output (modified: multiplied by the activation derivative), x its input; dx (if wanted) = W^T dy.
-template <int NTI, int NTO, bool EXACT>
+template <int NTI, int NTO, bool EXACT, int WI = 0, int WO = 0>
 DEV void linear_op_backward(BwdCtx& c, const PmtOp& o, f4 (&dy)[PMT_RT][NTO], const f4 (&x)[PMT_RT][NTI],
                             f4 (&dx)[PMT_RT][NTI], bool want_dx) {
     const PmtLinear& L = c.M->lin[uniform(o.lin[0])];
-    const int in_dim = uniform(L.in_dim), out_dim = uniform(L.out_dim);
+    const int in_dim = WI ? WI : uniform(L.in_dim), out_dim = WO ? WO : uniform(L.out_dim);
     if (uniform(o.selu_after) != 0) {  // recompute s = selu(Wx + b); dy <- dy * selu'(s)
         f4 y[PMT_RT][NTO];
         init_bias<NTO>(y, uniform(L.b_pvec) >= 0 ? c.packed + uniform(L.b_pvec) : nullptr, out_dim, c.g);
-        linear_acc<NTI, NTO, false, EXACT>(y, x, c.packed + uniform(L.w_frag), in_dim, out_dim);
+        linear_acc<NTI, NTO, false, EXACT, WI>(y, x, c.packed + uniform(L.w_frag), in_dim, out_dim);
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
@@ -391,13 +391,13 @@ DEV void linear_op_backward(BwdCtx& c, const PmtOp& o, f4 (&dy)[PMT_RT][NTO], co
     linear_wgrad<NTO, NTI>(c, L, dy, x);
     if (want_dx) {
         init_bias<NTI>(dx, nullptr, in_dim, c.g);
-        linear_acc<NTO, NTI, false, EXACT>(dx, dy, c.packed + uniform(L.wt_frag), out_dim, in_dim);
+        linear_acc<NTO, NTI, false, EXACT, WO>(dx, dy, c.packed + uniform(L.wt_frag), out_dim, in_dim);
     }
 }
 
 // backward of one MLP program.  dy (in/out): gradient w.r.t. the MLP output on entry, w.r.t. its input on exit
 // (not computed for op 0 when need_input_grad is false).  in_slot(op) gives the stash slot of op's input.
-template <int NT, bool EXACT, typename LoadInput>
+template <int NT, bool EXACT, int W = 0, typename LoadInput>
 DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool need_input_grad, LoadInput load_input,
                       int op_begin, int op_end) {
     const PmtModel* M = c.M;
@@ -407,11 +407,11 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
         load_input(op, x);
         if (uniform(o.kind) == PMT_OP_LINEAR) {
             const PmtLinear& L = M->lin[uniform(o.lin[0])];
-            const int in_dim = uniform(L.in_dim), out_dim = uniform(L.out_dim);
+            const int in_dim = W ? W : uniform(L.in_dim), out_dim = W ? W : uniform(L.out_dim);
             if (uniform(o.selu_after) != 0) {  // recompute s = selu(Wx + b); dy <- dy * selu'(s)
                 f4 y[PMT_RT][NT];
                 init_bias<NT>(y, uniform(L.b_pvec) >= 0 ? c.packed + uniform(L.b_pvec) : nullptr, out_dim, c.g);
-                linear_acc<NT, NT, false, EXACT>(y, x, c.packed + uniform(L.w_frag), in_dim, out_dim);
+                linear_acc<NT, NT, false, EXACT, W>(y, x, c.packed + uniform(L.w_frag), in_dim, out_dim);
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
@@ -421,7 +421,7 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
             if (op > op_begin || need_input_grad) {
                 f4 dx[PMT_RT][NT];
                 init_bias<NT>(dx, nullptr, in_dim, c.g);
-                linear_acc<NT, NT, false, EXACT>(dx, dy, c.packed + uniform(L.wt_frag), out_dim, in_dim);
+                linear_acc<NT, NT, false, EXACT, W>(dx, dy, c.packed + uniform(L.wt_frag), out_dim, in_dim);
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
@@ -434,12 +434,12 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
             const int nl = uniform(o.n_layers);
             const PmtLinear& L1 = M->lin[uniform(o.lin[0])];
             const PmtLinear& L2 = M->lin[uniform(o.lin[nl - 1])];
-            const int width = uniform(L1.in_dim);
+            const int width = W ? W : uniform(L1.in_dim);
             const float alpha = uniform(c.theta[uniform(o.alpha_src)]);
             f4 s1[PMT_RT][NT];
             if (nl == 2) {  // s1 = selu(L1 selu(x) + b1)
                 init_bias<NT>(s1, c.packed + uniform(L1.b_pvec), width, c.g);
-                linear_acc<NT, NT, true, EXACT>(s1, x, c.packed + uniform(L1.w_frag), width, width);
+                linear_acc<NT, NT, true, EXACT, W>(s1, x, c.packed + uniform(L1.w_frag), width, width);
             }
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
@@ -448,7 +448,7 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
             {   // d(alpha) = sum dy . f,  f = L2 s1 + b2   (x's registers are free from here on)
                 f4 f[PMT_RT][NT];
                 init_bias<NT>(f, c.packed + uniform(L2.b_pvec), width, c.g);
-                linear_acc<NT, NT, false, EXACT>(f, s1, c.packed + uniform(L2.w_frag), width, width);
+                linear_acc<NT, NT, false, EXACT, W>(f, s1, c.packed + uniform(L2.w_frag), width, width);
                 float da = 0.f;
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
@@ -461,7 +461,7 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
             linear_wgrad<NT, NT>(c, L2, dy, s1, alpha);
             f4 d1[PMT_RT][NT];
             init_bias<NT>(d1, nullptr, width, c.g);
-            linear_acc<NT, NT, false, EXACT>(d1, dy, c.packed + uniform(L2.wt_frag), width, width);
+            linear_acc<NT, NT, false, EXACT, W>(d1, dy, c.packed + uniform(L2.wt_frag), width, width);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
@@ -477,7 +477,7 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
                 linear_wgrad<NT, NT>(c, L1, d1, s0);
                 f4 d0[PMT_RT][NT];
                 init_bias<NT>(d0, nullptr, width, c.g);
-                linear_acc<NT, NT, false, EXACT>(d0, d1, c.packed + uniform(L1.wt_frag), width, width);
+                linear_acc<NT, NT, false, EXACT, W>(d0, d1, c.packed + uniform(L1.wt_frag), width, width);
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll

@@ -105,7 +105,14 @@ DEV f4 load_pvec(const float* __restrict__ p, int t, int g) { return *reinterpre
 // acc[rt][mt] += sum_k W[m][k] * in[rt][k]   for every tile of the wave.
 // `frag` = packed A fragments of W ([out_dim][in_dim]).  SELU_IN applies SELU to the input on the fly.
 // ---------------------------------------------------------------------------------------------------------------
-template <int NTI, int NTO, bool SELU_IN, bool EXACT>
+// KDIM / KSPLIT (compile time, 0 = unknown): the input width, or for the split layout of a block's hidden state the width
+// of each 16-position half.  A k-step covers 4 consecutive features; with the width known, the steps that hold nothing
+// but padding are not issued (d_model 60: 15 of 16; d_ffn / 2 = 10: 3 of 4).
+template <int KDIM, int KSPLIT>
+DEV constexpr bool kstep_live(int kt, int j) {
+    return KSPLIT > 0 ? 4 * j < KSPLIT : (KDIM > 0 ? 16 * kt + 4 * j < KDIM : true);
+}
+template <int NTI, int NTO, bool SELU_IN, bool EXACT, int KDIM = 0, int KSPLIT = 0>
 DEV void linear_acc_impl(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], const float* __restrict__ frag, int in_dim,
                          int out_dim, float in_scale) {
     // Fragments are stored kt-major ((kt * nmt + mt) * 256 floats), i.e. in exactly the order this loop nest consumes
@@ -129,9 +136,11 @@ DEV void linear_acc_impl(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], co
                     a_next = fp[0];  // one fragment past the end on the last step: still inside the padded region
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
+                        if (kstep_live<KDIM, KSPLIT>(kt, j)) {
 #pragma unroll
-                        for (int rt = 0; rt < PMT_RT; ++rt)
-                            acc[rt][mt] = mfma16(a[j], b[rt][j], acc[rt][mt]);
+                            for (int rt = 0; rt < PMT_RT; ++rt)
+                                acc[rt][mt] = mfma16(a[j], b[rt][j], acc[rt][mt]);
+                        }
                     }
                 }
             }
@@ -143,11 +152,12 @@ DEV void linear_acc_impl(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], co
 // EXACT (compile time): the caller's Shape guarantees that the layer fills every tile of both register arrays -> one
 // straight-line MFMA chain with no per-tile guards (guards turn every accumulator into a web of PHI copies; they were
 // the source of thousands of VGPR spills).  Otherwise the same test is made at run time.
-template <int NTI, int NTO, bool SELU_IN, bool EXACT = false>
+template <int NTI, int NTO, bool SELU_IN, bool EXACT = false, int KDIM = 0, int KSPLIT = 0>
 DEV void linear_acc(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], const float* __restrict__ frag, int in_dim,
                     int out_dim, float in_scale = 1.0f) {
+    static_assert(EXACT || (KDIM == 0 && KSPLIT == 0), "compile-time widths belong to the exact instances");
     if (EXACT || (((in_dim + 15) >> 4) == NTI && ((out_dim + 15) >> 4) == NTO))
-        linear_acc_impl<NTI, NTO, SELU_IN, true>(acc, in, frag, in_dim, out_dim, in_scale);
+        linear_acc_impl<NTI, NTO, SELU_IN, true, KDIM, KSPLIT>(acc, in, frag, in_dim, out_dim, in_scale);
     else
         linear_acc_impl<NTI, NTO, SELU_IN, false>(acc, in, frag, in_dim, out_dim, in_scale);
 }

@@ -4,14 +4,16 @@
 
 // One LINEAR op between register arrays of different tile counts (the first op of the read MLP, the last op of the
 // reducer, the wide first op of a row MLP): y = act(W x + b).
-template <bool STAGED, int NTI, int NTO, bool EXACT>
+// WI / WO / W (compile time, 0 = read the descriptor): the widths, for the instances that have them compiled in.
+template <bool STAGED, int NTI, int NTO, bool EXACT, int WI = 0, int WO = 0>
 DEV void run_linear_op(const PmtModel* __restrict__ M, const PmtOp& o, f4 (&y)[PMT_RT][NTO], const f4 (&x)[PMT_RT][NTI],
                        int g, WStage& ws) {
     const PmtLinear& L = M->lin[uniform(o.lin[0])];
     const int b_pvec = uniform(L.b_pvec), base = uniform(L.w_frag);
     const float* st = wstage_acquire<STAGED>(ws, base, uniform(L.w_stage));  // [fragments | bias]
-    init_bias<NTO>(y, b_pvec >= 0 ? st + (b_pvec - base) : nullptr, uniform(L.out_dim), g);
-    linear_acc<NTI, NTO, false, EXACT>(y, x, st, uniform(L.in_dim), uniform(L.out_dim));
+    const int in_dim = WI ? WI : uniform(L.in_dim), out_dim = WO ? WO : uniform(L.out_dim);
+    init_bias<NTO>(y, b_pvec >= 0 ? st + (b_pvec - base) : nullptr, out_dim, g);
+    linear_acc<NTI, NTO, false, EXACT, WI>(y, x, st, in_dim, out_dim);
     if (uniform(o.selu_after) != 0) {
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt)
@@ -24,7 +26,7 @@ DEV void run_linear_op(const PmtModel* __restrict__ M, const PmtOp& o, f4 (&y)[P
 // Runs ops [op_begin, op_end) on x in place; every op in the range maps NT tiles to NT tiles.  With TRAIN the INPUT of
 // every op with index >= first_stashed_op is written to consecutive stash slots starting at `slot` (tiles in
 // store_mask only).
-template <bool TRAIN, bool STAGED, int NT, bool EXACT>
+template <bool TRAIN, bool STAGED, int NT, bool EXACT, int W = 0>
 DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_RT][NT], const float* __restrict__ theta,
                  int g, unsigned store_mask, float* const (&stash_tile)[PMT_RT], int& slot, int first_stashed_op,
                  WStage& ws, int op_begin, int op_end) {
@@ -38,7 +40,7 @@ DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_
         }
         f4 y[PMT_RT][NT];
         if (uniform(o.kind) == PMT_OP_LINEAR) {
-            run_linear_op<STAGED, NT, NT, EXACT>(M, o, y, x, g, ws);
+            run_linear_op<STAGED, NT, NT, EXACT, W, W>(M, o, y, x, g, ws);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
@@ -47,7 +49,7 @@ DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_
             // x + alpha * f(x) with one or two (SELU, Linear) layers.  Only two register arrays are live: the last
             // layer accumulates straight into x, with alpha folded into its B operand and bias.
             const int nl = uniform(o.n_layers);
-            const int width = uniform(M->lin[uniform(o.lin[0])].in_dim);
+            const int width = W ? W : uniform(M->lin[uniform(o.lin[0])].in_dim);
             if (nl == 1) {
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
@@ -57,7 +59,7 @@ DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_
                 const PmtLinear& L1 = M->lin[uniform(o.lin[0])];
                 const float* st1 = wstage_acquire<STAGED>(ws, uniform(L1.w_frag), uniform(L1.w_stage));
                 init_bias<NT>(y, st1 + (uniform(L1.b_pvec) - uniform(L1.w_frag)), width, g);
-                linear_acc<NT, NT, true, EXACT>(y, x, st1, width, width);
+                linear_acc<NT, NT, true, EXACT, W>(y, x, st1, width, width);
             }
             const PmtLinear& L2 = M->lin[uniform(o.lin[nl - 1])];
             const float alpha = uniform(theta[uniform(o.alpha_src)]);
@@ -71,7 +73,7 @@ DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_
                     for (int rt = 0; rt < PMT_RT; ++rt) x[rt][t] = x[rt][t] + b;
                 }
             }
-            linear_acc<NT, NT, true, EXACT>(x, y, st2, width, width, alpha);
+            linear_acc<NT, NT, true, EXACT, W>(x, y, st2, width, width, alpha);
         }
     }
 }
