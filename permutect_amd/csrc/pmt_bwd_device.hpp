@@ -128,9 +128,11 @@ DEV void layernorm_bwd_inplace_tile(f4 (&acc)[NT], const f4 (&dyv)[NT], const f4
             if (t < nt && feat_of(t, j, g) < dim) acc[t][j] += rstd * (dyv[t][j] * w[t][j] - m1 - xhat[t][j] * m2);
 }
 
-DEV f4 selu_bwd4(f4 d, f4 s) {
-    return f4{d[0] * selu_grad_from_out(s[0]), d[1] * selu_grad_from_out(s[1]), d[2] * selu_grad_from_out(s[2]),
-              d[3] * selu_grad_from_out(s[3])};
+DEV f4 selu_bwd4(f4 d, f4 s) {  // d * selu'(a) through the output s = selu(a); packed add / multiply
+    const f4 neg = s + PMT_SELU_ALPHA * PMT_SELU_SCALE;
+    const f4 gr = f4{s[0] > 0.f ? PMT_SELU_SCALE : neg[0], s[1] > 0.f ? PMT_SELU_SCALE : neg[1],
+                     s[2] > 0.f ? PMT_SELU_SCALE : neg[2], s[3] > 0.f ? PMT_SELU_SCALE : neg[3]};
+    return d * gr;
 }
 
 // d/dz of the reference's logerfc (exponentially_modified_gaussian.py:30-55)

@@ -90,7 +90,20 @@ DEV float selu1(float x) {
     const float neg = (PMT_SELU_ALPHA * PMT_SELU_SCALE) * (__builtin_amdgcn_exp2f(x * 1.4426950408889634f) - 1.0f);
     return x > 0.f ? PMT_SELU_SCALE * x : neg;
 }
-DEV f4 selu4(f4 v) { return f4{selu1(v[0]), selu1(v[1]), selu1(v[2]), selu1(v[3])}; }
+// Four at a time with the packed fp32 instructions (v_pk_mul_f32 / v_pk_fma_f32 take two lanes' worth per issue slot):
+// 4.5 instead of 7 VALU slots per element; SELU is a third of the non-matrix instructions of the MLP layers.  Same
+// formula and roundings as selu1 except that alpha*scale*(e - 1) is one fused multiply-add (e * c - c).
+typedef float f2 __attribute__((ext_vector_type(2)));
+DEV f4 selu4(f4 v) {
+    const f2 lo = f2{v[0], v[1]}, hi = f2{v[2], v[3]};
+    const f2 tl = lo * 1.4426950408889634f, th = hi * 1.4426950408889634f;
+    const f2 el = f2{__builtin_amdgcn_exp2f(tl[0]), __builtin_amdgcn_exp2f(tl[1])};
+    const f2 eh = f2{__builtin_amdgcn_exp2f(th[0]), __builtin_amdgcn_exp2f(th[1])};
+    constexpr float c = PMT_SELU_ALPHA * PMT_SELU_SCALE;
+    const f2 nl = __builtin_elementwise_fma(el, f2{c, c}, f2{-c, -c}), nh = __builtin_elementwise_fma(eh, f2{c, c}, f2{-c, -c});
+    const f2 pl = lo * PMT_SELU_SCALE, ph = hi * PMT_SELU_SCALE;
+    return f4{v[0] > 0.f ? pl[0] : nl[0], v[1] > 0.f ? pl[1] : nl[1], v[2] > 0.f ? ph[0] : nh[0], v[3] > 0.f ? ph[1] : nh[1]};
+}
 
 // d selu(a) / da expressed through the OUTPUT s = selu(a):  s > 0 ? scale : s + alpha*scale
 DEV float selu_grad_from_out(float s) { return s > 0.f ? PMT_SELU_SCALE : s + PMT_SELU_ALPHA * PMT_SELU_SCALE; }
