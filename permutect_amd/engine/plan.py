@@ -50,10 +50,15 @@ class ParamSpace:
         self.bind_grads()
 
     def bind_grads(self):
-        for p in self.params:
-            o, n = self.offsets[id(p)], p.numel()
-            if p.grad is None or p.grad.data_ptr() != self.gtheta.data_ptr() + 4 * o:
-                p.grad = self.gtheta[o:o + n].view(p.shape)
+        """Every parameter's .grad is a view into the flat gradient buffer (the kernels accumulate there; torch's
+        AccumulateGrad adds in place and keeps the tensor object).  Called once per step: the common case -- nothing was
+        re-bound -- is ~130 identity checks."""
+        views = getattr(self, "_grad_views", None)
+        if views is None:
+            views = self._grad_views = [self.gtheta[self.offsets[id(p)]:self.offsets[id(p)] + p.numel()].view(p.shape) for p in self.params]
+        for p, v in zip(self.params, views):
+            if p.grad is not v:
+                p.grad = v
 
     def offset_of(self, p: nn.Parameter) -> int:
         return self.offsets[id(p)]
