@@ -676,7 +676,7 @@ extern "C" int pmt_backward(const PmtModel* model_host, const PmtModel* model_de
     const int rc = pmt_model_check(model_host);
     if (rc != PMT_OK) return rc;
     if (batch->num_groups <= 0) return batch->num_groups == 0 ? PMT_OK : PMT_E_INVALID;
-    if (batch->group_span) return PMT_E_UNSUPPORTED;  // read sets split over workgroups: forward only (pmt_forward_layered)
+    if (batch->group_span) return PMT_E_UNSUPPORTED;  // read sets split over workgroups: pmt_backward_layered
     if (!batch->reads || !batch->ref_offsets || !batch->alt_offsets || !batch->group_start || !batch->group_tile_base ||
         batch->total_tiles <= 0 || !out->logits_b || !out->logits_bk)
         return PMT_E_INVALID;
