@@ -6,7 +6,9 @@
 #ifndef PMT_STAGE_PLANES
 #define PMT_STAGE_PLANES 96  // LDS operand-exchange capacity in planes of 64 x float4 (1 KiB each); a TU may shrink it
 #endif
+#ifndef PMT_AUX_CAP
 #define PMT_AUX_CAP 256      // floats per wave of the small-parameter gradient slab
+#endif
 
 DEV float read_lanes_sum(float v) {  // sum over the 16 reads of a tile (lanes with equal lane >> 4)
     v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
