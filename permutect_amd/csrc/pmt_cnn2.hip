@@ -181,13 +181,14 @@ extern "C" __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_forward_ke
 
 // dW of one convolution for one variant, straight from LDS in the MFMA operand layout: for k-step s of tile `tile`, lane
 // (m = lane & 15, kg = lane >> 4) supplies A = dY[16 ot + m][col] and B = im2col[16 it + m][col], col = 16 tile + 4 s + kg.
-DEV void c2_conv_wgrad(f4 (&acc)[C2_NTO][C2_NTI], float (&bsum)[C2_NTO], const PmtCnnLayer& L, const float* __restrict__ gout,
+template <int NTI>
+DEV void c2_conv_wgrad(f4 (&acc)[C2_NTO][NTI], float (&bsum)[C2_NTO], const PmtCnnLayer& L, const float* __restrict__ gout,
                        const float* __restrict__ xin, const int* __restrict__ tap, int K, int OC) {
     const int lane = threadIdx.x & 63, m = lane & 15, kg = lane >> 4;
     const int out_len = L.out_len, nmt = (OC + 15) >> 4, nkt = (K + 15) >> 4;
-    int tp[C2_NTI];
+    int tp[NTI];
 #pragma unroll
-    for (int it = 0; it < C2_NTI; ++it) tp[it] = it < nkt ? tap[16 * it + m] : -1;
+    for (int it = 0; it < NTI; ++it) tp[it] = it < nkt ? tap[16 * it + m] : -1;
     for (int tile = 0; tile * 16 < out_len; ++tile) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -201,7 +202,7 @@ DEV void c2_conv_wgrad(f4 (&acc)[C2_NTO][C2_NTI], float (&bsum)[C2_NTO], const P
                 bsum[ot] += a[ot];
             }
 #pragma unroll
-            for (int it = 0; it < C2_NTI; ++it) {
+            for (int it = 0; it < NTI; ++it) {
                 if (it < nkt) {
                     const int pos = col * L.stride + (tp[it] >> 16) - 64;
                     const float b = (cv && tp[it] >= 0 && pos >= 0 && pos < L.in_len) ? xin[(tp[it] & 0xFFFF) + pos] : 0.f;
@@ -214,7 +215,11 @@ DEV void c2_conv_wgrad(f4 (&acc)[C2_NTO][C2_NTI], float (&bsum)[C2_NTO], const P
     }
 }
 
-extern "C" __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_backward_kernel(
+// NTI0 / NTI1: 16-wide k-tiles (in_ch * kernel) of the first / second convolution.  Their weight gradients live in
+// registers for the whole kernel, so the instance is sized to the model (P0: 30 and 96 inputs = 2 and 6 tiles; sizing
+// both for 6 cost 153 spilled VGPRs).
+template <int NTI0, int NTI1>
+__global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_backward_kernel(
     const PmtModel* __restrict__ M, const float* __restrict__ theta, const float* __restrict__ packed,
     const long long* __restrict__ hap, long long hap_stride, int n, int per_wave, const float* __restrict__ d_out,
     long long d_out_stride, float* __restrict__ gtheta) {
@@ -239,16 +244,16 @@ extern "C" __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_backward_k
     float* gA = acts + sa;
     float* gB = gA + ma;
 
-    f4 cacc[C2_MAX_CONVS][C2_NTO][C2_NTI];
+    f4 cacc0[C2_NTO][NTI0], cacc1[C2_NTO][NTI1];
     float cb[C2_MAX_CONVS][C2_NTO];
 #pragma unroll
-    for (int c = 0; c < C2_MAX_CONVS; ++c)
+    for (int ot = 0; ot < C2_NTO; ++ot) {
+        cb[0][ot] = cb[1][ot] = 0.f;
 #pragma unroll
-        for (int ot = 0; ot < C2_NTO; ++ot) {
-            cb[c][ot] = 0.f;
+        for (int it = 0; it < NTI0; ++it) cacc0[ot][it] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int it = 0; it < C2_NTI; ++it) cacc[c][ot][it] = f4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int it = 0; it < NTI1; ++it) cacc1[ot][it] = f4{0.f, 0.f, 0.f, 0.f};
+    }
     // final linear: this wave owns the input columns [k0, k0 + klen) of dW for every variant of the workgroup
     float lw[C2_LIN_REGS], lb = 0.f;
 #pragma unroll
@@ -317,8 +322,8 @@ extern "C" __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_backward_k
                     --conv;
                     const PmtLinear& Wl = M->lin[uniform(L.lin)];
                     const int K = uniform(Wl.in_dim), OC = uniform(Wl.out_dim), out_len = uniform(L.out_len);
-                    if (conv == 0) c2_conv_wgrad(cacc[0], cb[0], L, gout, xin, taps[0], K, OC);
-                    else c2_conv_wgrad(cacc[1], cb[1], L, gout, xin, taps[1], K, OC);
+                    if (conv == 0) c2_conv_wgrad<NTI0>(cacc0, cb[0], L, gout, xin, taps[0], K, OC);
+                    else c2_conv_wgrad<NTI1>(cacc1, cb[1], L, gout, xin, taps[1], K, OC);
                     if (need_din) {
                         for (int i = lane; i < nin; i += 64) gin[i] = 0.f;
                         wave_sync();
@@ -393,7 +398,10 @@ extern "C" __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_backward_k
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int oc = 16 * ot + 4 * g + j, f = 16 * it + r;  // plain C layout: no feature permutation here
-                    if (oc < OC && f < K) atomicAdd(&gw[(size_t)oc * K + f], cacc[c][ot][it][j]);
+                    float v = 0.f;
+                    if (c == 0 && it < NTI0) v = cacc0[ot][it][j];
+                    if (c == 1 && it < NTI1) v = cacc1[ot][it][j];
+                    if (oc < OC && f < K && ((c == 0 && it < NTI0) || (c == 1 && it < NTI1))) atomicAdd(&gw[(size_t)oc * K + f], v);
                 }
             const float tot = group_sum(cb[c][ot]);  // lanes (m, *) hold the sum over all positions for output channel m
             if (g == 0 && 16 * ot + r < OC) atomicAdd(&gb[16 * ot + r], tot);
@@ -434,10 +442,19 @@ static int cnn2_supported(const PmtModel* m) {
     return 1;
 }
 
-// waves per workgroup so that `floats_per_wave` floats of LDS fit (8 at most, 0 = does not fit)
-static int cnn2_waves(size_t floats_per_wave, size_t static_bytes) {
-    const size_t budget = 156 * 1024 - static_bytes;
-    int nw = (int)(budget / (floats_per_wave * sizeof(float)));
+// waves per workgroup so that `floats_per_wave` floats of LDS fit (8 at most, 0 = does not fit).  The kernels are bound by
+// the latency of their short dependent phases, so residency matters more than workgroup size: when two workgroups of at
+// least 4 waves fit a CU, plan for two (*per_cu = 2).
+static int cnn2_waves(size_t floats_per_wave, size_t static_bytes, int* per_cu) {
+    const size_t bytes = floats_per_wave * sizeof(float);
+    int half = (int)((78 * 1024 - static_bytes) / bytes);
+    if (half > PMT_WAVES) half = PMT_WAVES;
+    if (half >= 4) {
+        *per_cu = 2;
+        return half;
+    }
+    *per_cu = 1;
+    const int nw = (int)((156 * 1024 - static_bytes) / bytes);
     return nw > PMT_WAVES ? PMT_WAVES : nw;
 }
 
@@ -445,10 +462,12 @@ extern "C" int pmt_cnn2_try_forward(const PmtModel* model_host, const PmtModel* 
                                     const int64_t* haplotypes, int64_t hap_stride, int32_t n, float* out, int64_t out_stride, void* stream) {
     if (!cnn2_supported(model_host)) return 1;  // not an error: the caller runs the general kernels
     const size_t per = (size_t)model_host->cnn.sum_act;
-    const int nw = cnn2_waves(per, sizeof(int) * C2_MAX_CONVS * PMT_MAX_ROW_INPUT);
+    int per_cu = 1;
+    const int nw = cnn2_waves(per, sizeof(int) * C2_MAX_CONVS * PMT_MAX_ROW_INPUT, &per_cu);
     if (nw < 2) return 1;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    cus *= per_cu;
     const int blocks = (int)(((long long)n + nw - 1) / nw < cus ? ((long long)n + nw - 1) / nw : cus);
     const size_t lds_bytes = (size_t)nw * per * sizeof(float);
     hipLaunchKernelGGL(pmt_cnn2_forward_kernel, dim3(blocks), dim3(64 * nw), lds_bytes, reinterpret_cast<hipStream_t>(stream), model_dev,
@@ -461,7 +480,8 @@ extern "C" int pmt_cnn2_try_backward(const PmtModel* model_host, const PmtModel*
                                      int64_t d_out_stride, float* grad_theta, void* stream) {
     if (!cnn2_supported(model_host)) return 1;
     const size_t per = (size_t)model_host->cnn.sum_act + 2 * (size_t)model_host->cnn.max_act;
-    const int nw = cnn2_waves(per, sizeof(int) * C2_MAX_CONVS * PMT_MAX_ROW_INPUT + sizeof(float) * PMT_WAVES * C2_MAX_LIN_OUT);
+    int per_cu = 1;
+    const int nw = cnn2_waves(per, sizeof(int) * C2_MAX_CONVS * PMT_MAX_ROW_INPUT + sizeof(float) * PMT_WAVES * C2_MAX_LIN_OUT, &per_cu);
     if (nw < 2) return 1;
     // the final linear's dW slice of a wave must fit its registers
     for (int l = 0; l < model_host->cnn.n_layers; ++l) {
@@ -473,9 +493,14 @@ extern "C" int pmt_cnn2_try_backward(const PmtModel* model_host, const PmtModel*
     }
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    cus *= per_cu;
     const int blocks = (int)(((long long)n + nw - 1) / nw < cus ? ((long long)n + nw - 1) / nw : cus);
     const size_t lds_bytes = (size_t)nw * per * sizeof(float);
-    hipLaunchKernelGGL(pmt_cnn2_backward_kernel, dim3(blocks), dim3(64 * nw), lds_bytes, reinterpret_cast<hipStream_t>(stream), model_dev,
+    int kt[C2_MAX_CONVS] = {0, 0}, nc = 0;  // k-tiles of the convolutions: the instance that holds their dW in registers
+    for (int l = 0; l < model_host->cnn.n_layers; ++l)
+        if (model_host->cnn.layers[l].kind == PMT_CNN_CONV) kt[nc++] = (model_host->lin[model_host->cnn.layers[l].lin].in_dim + 15) / 16;
+    auto kernel = (kt[0] <= 2) ? pmt_cnn2_backward_kernel<2, C2_NTI> : pmt_cnn2_backward_kernel<C2_NTI, C2_NTI>;
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64 * nw), lds_bytes, reinterpret_cast<hipStream_t>(stream), model_dev,
                        theta, packed, (const long long*)haplotypes, (long long)hap_stride, n, (int)per, d_out, (long long)d_out_stride,
                        grad_theta);
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
