@@ -86,7 +86,55 @@ DEV void c2_gather(f4 (&x)[1][C2_NTI], const float* __restrict__ in, const int* 
     }
 }
 
-DEV void c2_conv_forward(const PmtModel* __restrict__ M, const PmtCnnLayer& L, const float* __restrict__ packed,
+// Where the kernels read their weights.  The kernels are persistent and every variant uses the same weights, so they
+// are copied into LDS once per workgroup (c2_stage_weights) when the host found room: a fragment then arrives in ~100
+// cycles instead of an L2 round trip per fragment with a one-deep prefetch (~36 such loads per variant before).
+struct C2Weights {
+    const float* w[C2_MAX_CONVS];    // A fragments of the convolution weight viewed as [out_ch][in_ch * kernel]
+    const float* wt[C2_MAX_CONVS];   // ... of its transpose (input gradient)
+    const float* b[C2_MAX_CONVS];    // bias in tile-position order
+    const float* lin_w;              // final linear [out][in], row major
+};
+
+DEV void c2_copy(float* __restrict__ dst, const float* __restrict__ src, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+// `stage`: LDS region of `stage_floats` floats (0: read everything from global memory).  Ends with a workgroup barrier.
+DEV C2Weights c2_stage_weights(const PmtModel* __restrict__ M, const float* __restrict__ theta, const float* __restrict__ packed,
+                               float* __restrict__ stage, int stage_floats, bool with_transposes) {
+    const PmtCnn& C = M->cnn;
+    C2Weights W;
+    int conv = 0;
+    float* cur = stage;
+    W.lin_w = nullptr;
+    for (int c = 0; c < C2_MAX_CONVS; ++c) W.w[c] = W.wt[c] = W.b[c] = nullptr;
+    for (int l = 0; l < C.n_layers; ++l) {
+        const PmtCnnLayer& L = C.layers[l];
+        if (L.kind == PMT_CNN_CONV) {
+            const PmtLinear& Wl = M->lin[L.lin];
+            const int nfl = frag_floats_dev(Wl), nb = 16 * ((Wl.out_dim + 15) >> 4);
+            W.w[conv] = packed + Wl.w_frag;
+            W.wt[conv] = packed + Wl.wt_frag;
+            W.b[conv] = packed + Wl.b_pvec;
+            if (stage_floats > 0) {  // (+256: linear_acc prefetches one fragment past the end)
+                c2_copy(cur, W.w[conv], nfl); W.w[conv] = cur; cur += nfl + 256;
+                c2_copy(cur, W.b[conv], nb); W.b[conv] = cur; cur += nb;
+                if (with_transposes && L.in_off != 0) { c2_copy(cur, W.wt[conv], nfl); W.wt[conv] = cur; cur += nfl + 256; }
+            }
+            ++conv;
+        } else if (L.kind == PMT_CNN_LINEAR) {
+            W.lin_w = theta + L.w_src;
+            if (stage_floats > 0) {
+                const int nfl = (L.out_ch * L.in_ch * L.in_len + 3) & ~3;
+                c2_copy(cur, W.lin_w, L.out_ch * L.in_ch * L.in_len); W.lin_w = cur; cur += nfl;
+            }
+        }
+    }
+    __syncthreads();
+    return W;
+}
+
+DEV void c2_conv_forward(const PmtModel* __restrict__ M, const PmtCnnLayer& L, const float* __restrict__ w_frag, const float* __restrict__ b_pvec,
                          const float* __restrict__ in, float* __restrict__ out, const int* __restrict__ tap) {
     const int lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15;
     const PmtLinear& W = M->lin[uniform(L.lin)];
@@ -96,8 +144,8 @@ DEV void c2_conv_forward(const PmtModel* __restrict__ M, const PmtCnnLayer& L, c
         const bool valid = so < out_len;
         f4 x[1][C2_NTI], y[1][C2_NTO];
         c2_gather(x, in, tap, L, so, valid, nkt, g);
-        init_bias<C2_NTO>(y, packed + uniform(W.b_pvec), OC, g);
-        linear_acc<C2_NTI, C2_NTO, false>(y, x, packed + uniform(W.w_frag), K, OC);
+        init_bias<C2_NTO>(y, b_pvec, OC, g);
+        linear_acc<C2_NTI, C2_NTO, false>(y, x, w_frag, K, OC);
         if (valid) {
 #pragma unroll
             for (int t = 0; t < C2_NTO; ++t)
@@ -111,7 +159,7 @@ DEV void c2_conv_forward(const PmtModel* __restrict__ M, const PmtCnnLayer& L, c
 }
 
 // every layer of one variant, activations at acts + in_off / out_off (this wave's LDS region)
-DEV void c2_forward_variant(const PmtModel* __restrict__ M, const float* __restrict__ theta, const float* __restrict__ packed,
+DEV void c2_forward_variant(const PmtModel* __restrict__ M, const float* __restrict__ theta, const C2Weights& cw,
                             float* __restrict__ acts, const long long* __restrict__ hap_row, const int (*taps)[PMT_MAX_ROW_INPUT]) {
     const PmtCnn& C = M->cnn;
     const int lane = threadIdx.x & 63, nl = uniform(C.n_layers);
@@ -125,7 +173,7 @@ DEV void c2_forward_variant(const PmtModel* __restrict__ M, const float* __restr
         const float* in = acts + uniform(L.in_off);
         float* out = acts + uniform(L.out_off);
         if (kind == PMT_CNN_CONV) {
-            c2_conv_forward(M, L, packed, in, out, taps[conv]);
+            c2_conv_forward(M, L, conv == 0 ? cw.w[0] : cw.w[1], conv == 0 ? cw.b[0] : cw.b[1], in, out, taps[conv]);
             ++conv;
         } else if (kind == PMT_CNN_POOL) {
             const int per = L.out_ch * L.out_len;
@@ -143,7 +191,7 @@ DEV void c2_forward_variant(const PmtModel* __restrict__ M, const float* __restr
             const int per = L.out_ch * L.out_len;
             for (int i = lane; i < per; i += 64) out[i] = c2_act(kind, in[i]);
         } else {  // LINEAR: the lanes split every dot product
-            const float* Wt = theta + L.w_src;
+            const float* Wt = cw.lin_w;
             const int nin = L.in_ch * L.in_len;
             for (int o = 0; o < L.out_ch; ++o) {
                 float acc = 0.f;
@@ -158,7 +206,8 @@ DEV void c2_forward_variant(const PmtModel* __restrict__ M, const float* __restr
 
 extern "C" __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_forward_kernel(
     const PmtModel* __restrict__ M, const float* __restrict__ theta, const float* __restrict__ packed,
-    const long long* __restrict__ hap, long long hap_stride, int n, int per_wave, float* __restrict__ out, long long out_stride) {
+    const long long* __restrict__ hap, long long hap_stride, int n, int per_wave, int stage_floats, float* __restrict__ out,
+    long long out_stride) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ int taps[C2_MAX_CONVS][PMT_MAX_ROW_INPUT];
     const PmtCnn& C = M->cnn;
@@ -166,14 +215,14 @@ extern "C" __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_forward_ke
     int conv = 0;
     for (int l = 0; l < C.n_layers; ++l)
         if (C.layers[l].kind == PMT_CNN_CONV) c2_build_taps(taps[conv++], C.layers[l]);
-    __syncthreads();
+    const C2Weights cw = c2_stage_weights(M, theta, packed, lds + (((size_t)nw * per_wave + 3) & ~(size_t)3), stage_floats, false);
     float* acts = lds + (size_t)wave * per_wave;
     const int od = uniform(C.out_dim);
     // the last layer's output offset
     int last_off = 0;
     for (int l = 0; l < C.n_layers; ++l) last_off = C.layers[l].out_off;
     for (long long v = (long long)blockIdx.x * nw + wave; v < n; v += (long long)gridDim.x * nw) {
-        c2_forward_variant(M, theta, packed, acts, hap + (size_t)v * hap_stride, taps);
+        c2_forward_variant(M, theta, cw, acts, hap + (size_t)v * hap_stride, taps);
         for (int o = lane; o < od; o += 64) out[(size_t)v * out_stride + o] = acts[last_off + o];
         wave_sync();
     }
@@ -221,7 +270,7 @@ DEV void c2_conv_wgrad(f4 (&acc)[C2_NTO][NTI], float (&bsum)[C2_NTO], const PmtC
 template <int NTI0, int NTI1>
 __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_backward_kernel(
     const PmtModel* __restrict__ M, const float* __restrict__ theta, const float* __restrict__ packed,
-    const long long* __restrict__ hap, long long hap_stride, int n, int per_wave, const float* __restrict__ d_out,
+    const long long* __restrict__ hap, long long hap_stride, int n, int per_wave, int stage_floats, const float* __restrict__ d_out,
     long long d_out_stride, float* __restrict__ gtheta) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ int taps[C2_MAX_CONVS][PMT_MAX_ROW_INPUT];
@@ -239,7 +288,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_backward_kernel(
             lin_layer = l;
         }
     }
-    __syncthreads();
+    const C2Weights cw = c2_stage_weights(M, theta, packed, lds + (((size_t)nw * per_wave + 3) & ~(size_t)3), stage_floats, true);
     float* acts = lds + (size_t)wave * per_wave;
     float* gA = acts + sa;
     float* gB = gA + ma;
@@ -271,7 +320,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_backward_kernel(
     for (long long base = (long long)blockIdx.x * nw; base < n; base += per_round) {
         const long long v = base + wave;
         if (v < n) {
-            c2_forward_variant(M, theta, packed, acts, hap + (size_t)v * hap_stride, taps);
+            c2_forward_variant(M, theta, cw, acts, hap + (size_t)v * hap_stride, taps);
             for (int o = lane; o < od; o += 64) {
                 const float d = d_out[(size_t)v * d_out_stride + o];
                 gA[o] = d;
@@ -311,7 +360,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_backward_kernel(
                     }
                 } else if (kind == PMT_CNN_LINEAR) {
                     if (need_din) {
-                        const float* Wt = theta + L.w_src;
+                        const float* Wt = cw.lin_w;
                         for (int k = lane; k < nin; k += 64) {
                             float acc = 0.f;
                             for (int o = 0; o < L.out_ch; ++o) acc += Wt[(size_t)o * nin + k] * gout[o];
@@ -341,7 +390,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_backward_kernel(
                                     dy[0][t][j] = (valid && co < OC) ? gout[co * out_len + so] : 0.f;
                                 }
                             init_bias<C2_NTI>(dx, nullptr, K, g);
-                            linear_acc<C2_NTO, C2_NTI, false>(dx, dy, packed + uniform(Wl.wt_frag), OC, K);
+                            linear_acc<C2_NTO, C2_NTI, false>(dx, dy, conv == 0 ? cw.wt[0] : cw.wt[1], OC, K);
 #pragma unroll
                             for (int t = 0; t < C2_NTI; ++t)
                                 if (t < nkt) {
@@ -442,19 +491,36 @@ static int cnn2_supported(const PmtModel* m) {
     return 1;
 }
 
+// floats of LDS the weights take when staged (c2_stage_weights)
+static size_t cnn2_stage_floats(const PmtModel* m, bool with_transposes) {
+    size_t n = 0;
+    for (int l = 0; l < m->cnn.n_layers; ++l) {
+        const PmtCnnLayer* L = &m->cnn.layers[l];
+        if (L->kind == PMT_CNN_CONV) {
+            const PmtLinear* w = &m->lin[L->lin];
+            const size_t nfl = (size_t)((w->out_dim + 15) / 16) * ((w->in_dim + 15) / 16) * 256;
+            n += nfl + 256 + 16 * (size_t)((w->out_dim + 15) / 16);
+            if (with_transposes && L->in_off != 0) n += nfl + 256;
+        } else if (L->kind == PMT_CNN_LINEAR) {
+            n += ((size_t)L->out_ch * L->in_ch * L->in_len + 3) & ~(size_t)3;
+        }
+    }
+    return n + 4;
+}
+
 // waves per workgroup so that `floats_per_wave` floats of LDS fit (8 at most, 0 = does not fit).  The kernels are bound by
 // the latency of their short dependent phases, so residency matters more than workgroup size: when two workgroups of at
 // least 4 waves fit a CU, plan for two (*per_cu = 2).
 static int cnn2_waves(size_t floats_per_wave, size_t static_bytes, int* per_cu) {
     const size_t bytes = floats_per_wave * sizeof(float);
-    int half = (int)((78 * 1024 - static_bytes) / bytes);
+    int half = 78 * 1024 > static_bytes ? (int)((78 * 1024 - static_bytes) / bytes) : 0;
     if (half > PMT_WAVES) half = PMT_WAVES;
     if (half >= 4) {
         *per_cu = 2;
         return half;
     }
     *per_cu = 1;
-    const int nw = (int)((156 * 1024 - static_bytes) / bytes);
+    const int nw = 156 * 1024 > static_bytes ? (int)((156 * 1024 - static_bytes) / bytes) : 0;
     return nw > PMT_WAVES ? PMT_WAVES : nw;
 }
 
@@ -463,15 +529,21 @@ extern "C" int pmt_cnn2_try_forward(const PmtModel* model_host, const PmtModel* 
     if (!cnn2_supported(model_host)) return 1;  // not an error: the caller runs the general kernels
     const size_t per = (size_t)model_host->cnn.sum_act;
     int per_cu = 1;
-    const int nw = cnn2_waves(per, sizeof(int) * C2_MAX_CONVS * PMT_MAX_ROW_INPUT, &per_cu);
+    const size_t static_fwd = sizeof(int) * C2_MAX_CONVS * PMT_MAX_ROW_INPUT;
+    size_t stage = cnn2_stage_floats(model_host, false);
+    int nw = cnn2_waves(per, static_fwd + stage * sizeof(float), &per_cu);
+    if (nw < 4) {  // no room for the weights next to a useful number of waves: read them from global memory
+        stage = 0;
+        nw = cnn2_waves(per, static_fwd, &per_cu);
+    }
     if (nw < 2) return 1;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     cus *= per_cu;
     const int blocks = (int)(((long long)n + nw - 1) / nw < cus ? ((long long)n + nw - 1) / nw : cus);
-    const size_t lds_bytes = (size_t)nw * per * sizeof(float);
+    const size_t lds_bytes = ((size_t)nw * per + 4 + stage) * sizeof(float);  // (+4: the weights start 16-byte aligned)
     hipLaunchKernelGGL(pmt_cnn2_forward_kernel, dim3(blocks), dim3(64 * nw), lds_bytes, reinterpret_cast<hipStream_t>(stream), model_dev,
-                       theta, packed, (const long long*)haplotypes, (long long)hap_stride, n, (int)per, out, (long long)out_stride);
+                       theta, packed, (const long long*)haplotypes, (long long)hap_stride, n, (int)per, (int)stage, out, (long long)out_stride);
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }
 
@@ -481,7 +553,13 @@ extern "C" int pmt_cnn2_try_backward(const PmtModel* model_host, const PmtModel*
     if (!cnn2_supported(model_host)) return 1;
     const size_t per = (size_t)model_host->cnn.sum_act + 2 * (size_t)model_host->cnn.max_act;
     int per_cu = 1;
-    const int nw = cnn2_waves(per, sizeof(int) * C2_MAX_CONVS * PMT_MAX_ROW_INPUT + sizeof(float) * PMT_WAVES * C2_MAX_LIN_OUT, &per_cu);
+    const size_t static_bwd = sizeof(int) * C2_MAX_CONVS * PMT_MAX_ROW_INPUT + sizeof(float) * PMT_WAVES * C2_MAX_LIN_OUT;
+    size_t stage = cnn2_stage_floats(model_host, true);
+    int nw = cnn2_waves(per, static_bwd + stage * sizeof(float), &per_cu);
+    if (nw < 4) {
+        stage = 0;
+        nw = cnn2_waves(per, static_bwd, &per_cu);
+    }
     if (nw < 2) return 1;
     // the final linear's dW slice of a wave must fit its registers
     for (int l = 0; l < model_host->cnn.n_layers; ++l) {
@@ -495,13 +573,13 @@ extern "C" int pmt_cnn2_try_backward(const PmtModel* model_host, const PmtModel*
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     cus *= per_cu;
     const int blocks = (int)(((long long)n + nw - 1) / nw < cus ? ((long long)n + nw - 1) / nw : cus);
-    const size_t lds_bytes = (size_t)nw * per * sizeof(float);
+    const size_t lds_bytes = ((size_t)nw * per + 4 + stage) * sizeof(float);  // (+4: the weights start 16-byte aligned)
     int kt[C2_MAX_CONVS] = {0, 0}, nc = 0;  // k-tiles of the convolutions: the instance that holds their dW in registers
     for (int l = 0; l < model_host->cnn.n_layers; ++l)
         if (model_host->cnn.layers[l].kind == PMT_CNN_CONV) kt[nc++] = (model_host->lin[model_host->cnn.layers[l].lin].in_dim + 15) / 16;
     auto kernel = (kt[0] <= 2) ? pmt_cnn2_backward_kernel<2, C2_NTI> : pmt_cnn2_backward_kernel<C2_NTI, C2_NTI>;
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64 * nw), lds_bytes, reinterpret_cast<hipStream_t>(stream), model_dev,
-                       theta, packed, (const long long*)haplotypes, (long long)hap_stride, n, (int)per, d_out, (long long)d_out_stride,
+                       theta, packed, (const long long*)haplotypes, (long long)hap_stride, n, (int)per, (int)stage, d_out, (long long)d_out_stride,
                        grad_theta);
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }
