@@ -457,11 +457,17 @@ int pmt_rows_backward(const PmtModel* model_host, const PmtModel* model_dev, int
  * reference data/batch.py:110-130) with the given row stride in elements; out = [n][cnn.out_dim] with row stride.
  * Replaces Batch.get_one_hot_haplotypes_bcs + DNASequenceConvolution.forward (artifact_model.py:245). */
 int pmt_cnn_forward(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* packed,
-                    const int64_t* haplotypes, int64_t hap_stride, int32_t n, float* out, int64_t out_stride, void* stream);
-/* Backward: recomputes the forward in LDS and accumulates parameter gradients into grad_theta (atomics). */
+                    const int64_t* haplotypes, int64_t hap_stride, int32_t n, float* out, int64_t out_stride, float* stash,
+                    void* stream);
+/* Floats per variant of the optional activation stash of a training forward (every layer output, as the backward keeps
+ * them in LDS), or 0 when this model runs on kernels that recompute instead (then pass stash = NULL). */
+size_t pmt_cnn_stash_floats(const PmtModel* model_host);
+/* Backward: accumulates parameter gradients into grad_theta (atomics).  With `stash` (written by pmt_cnn_forward for the
+ * same haplotypes and weights) the layer outputs are loaded; with NULL the forward is recomputed in LDS (a third of the
+ * kernel's time). */
 int pmt_cnn_backward(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* packed,
                      const int64_t* haplotypes, int64_t hap_stride, int32_t n, const float* d_out, int64_t d_out_stride,
-                     float* grad_theta, void* stream);
+                     const float* stash, float* grad_theta, void* stream);
 
 /* Global-norm clip + AdamW over the flat parameter buffer, one launch sequence, no host sync.
  * Replaces nn.utils.clip_grad_norm_(max_norm=1.0) + torch.optim.AdamW.step (reference misc_utils.py:128-129).

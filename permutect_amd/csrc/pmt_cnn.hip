@@ -385,10 +385,11 @@ extern "C" __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn_backward_ke
 
 // pmt_cnn2.hip: 0 = done, 1 = configuration not covered (run the general kernels below), < 0 = error
 extern "C" int pmt_cnn2_try_forward(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* packed,
-                                    const int64_t* haplotypes, int64_t hap_stride, int32_t n, float* out, int64_t out_stride, void* stream);
+                                    const int64_t* haplotypes, int64_t hap_stride, int32_t n, float* out, int64_t out_stride,
+                                    float* stash, void* stream);
 extern "C" int pmt_cnn2_try_backward(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* packed,
                                      const int64_t* haplotypes, int64_t hap_stride, int32_t n, const float* d_out,
-                                     int64_t d_out_stride, float* grad_theta, void* stream);
+                                     int64_t d_out_stride, const float* stash, float* grad_theta, void* stream);
 
 static int cnn_check(const PmtModel* m) {
     if (!m) return PMT_E_INVALID;
@@ -421,17 +422,21 @@ static int pick_vpb(size_t floats_per_variant, size_t static_bytes, int blocks_p
 
 extern "C" int pmt_cnn_forward(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* packed,
                                const int64_t* haplotypes, int64_t hap_stride, int32_t n, float* out, int64_t out_stride,
-                               void* stream) {
+                               float* stash, void* stream) {
     const int rc = cnn_check(model_host);
     if (rc) return rc;
     if (!model_dev || !theta || !packed || !haplotypes || !out || n < 0) return PMT_E_INVALID;
     if (n == 0) return PMT_OK;
+    if (stash) {  // a training forward that keeps its layer outputs: the wave-per-variant kernel writes them in the backward's layout
+        const int rc2 = pmt_cnn2_try_forward(model_host, model_dev, theta, packed, haplotypes, hap_stride, n, out, out_stride, stash, stream);
+        return rc2 <= 0 ? rc2 : PMT_E_UNSUPPORTED;  // (pmt_cnn_stash_floats said 0 for such a model)
+    }
     // The wave-per-variant forward (pmt_cnn2.hip) measures slower than the kernel below (0.54 vs 0.47 ms at 65 536 variants,
     // P0): the forward has no weight gradients to keep resident, which is what the wave-per-variant backward wins with.  It
     // stays selectable (PMT_CNN=wave) and parity-tested.
     const char* pref = getenv("PMT_CNN");
     if (pref && strcmp(pref, "wave") == 0) {
-        const int rc2 = pmt_cnn2_try_forward(model_host, model_dev, theta, packed, haplotypes, hap_stride, n, out, out_stride, stream);
+        const int rc2 = pmt_cnn2_try_forward(model_host, model_dev, theta, packed, haplotypes, hap_stride, n, out, out_stride, nullptr, stream);
         if (rc2 <= 0) return rc2;
     }
     const size_t per = 2 * (size_t)model_host->cnn.max_act;
@@ -445,15 +450,16 @@ extern "C" int pmt_cnn_forward(const PmtModel* model_host, const PmtModel* model
 
 extern "C" int pmt_cnn_backward(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* packed,
                                 const int64_t* haplotypes, int64_t hap_stride, int32_t n, const float* d_out,
-                                int64_t d_out_stride, float* grad_theta, void* stream) {
+                                int64_t d_out_stride, const float* stash, float* grad_theta, void* stream) {
     const int rc = cnn_check(model_host);
     if (rc) return rc;
     if (!model_dev || !theta || !packed || !haplotypes || !d_out || !grad_theta || n < 0) return PMT_E_INVALID;
     if (n == 0) return PMT_OK;
     {
         const int rc2 = pmt_cnn2_try_backward(model_host, model_dev, theta, packed, haplotypes, hap_stride, n, d_out, d_out_stride,
-                                              grad_theta, stream);
+                                              stash, grad_theta, stream);
         if (rc2 <= 0) return rc2;
+        if (stash) return PMT_E_UNSUPPORTED;
     }
     const size_t per = (size_t)model_host->cnn.sum_act + 2 * (size_t)model_host->cnn.max_act;
     const int vpb = pick_vpb(per, sizeof(CnnBwdShared), 2);

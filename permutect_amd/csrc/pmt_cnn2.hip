@@ -207,7 +207,7 @@ DEV void c2_forward_variant(const PmtModel* __restrict__ M, const float* __restr
 extern "C" __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_forward_kernel(
     const PmtModel* __restrict__ M, const float* __restrict__ theta, const float* __restrict__ packed,
     const long long* __restrict__ hap, long long hap_stride, int n, int per_wave, int stage_floats, float* __restrict__ out,
-    long long out_stride) {
+    long long out_stride, float* __restrict__ stash) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ int taps[C2_MAX_CONVS][PMT_MAX_ROW_INPUT];
     const PmtCnn& C = M->cnn;
@@ -224,6 +224,11 @@ extern "C" __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_forward_ke
     for (long long v = (long long)blockIdx.x * nw + wave; v < n; v += (long long)gridDim.x * nw) {
         c2_forward_variant(M, theta, cw, acts, hap + (size_t)v * hap_stride, taps);
         for (int o = lane; o < od; o += 64) out[(size_t)v * out_stride + o] = acts[last_off + o];
+        if (stash) {  // every layer output (the one-hot input is rebuilt by the backward: 10 S floats it need not read)
+            const int first = 10 * uniform(C.seq_len), per = uniform(C.sum_act) - first;
+            float* dst = stash + (size_t)v * per;
+            for (int i = lane; i < per; i += 64) dst[i] = acts[first + i];
+        }
         wave_sync();
     }
 }
@@ -271,7 +276,10 @@ template <int NTI0, int NTI1>
 __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_backward_kernel(
     const PmtModel* __restrict__ M, const float* __restrict__ theta, const float* __restrict__ packed,
     const long long* __restrict__ hap, long long hap_stride, int n, int per_wave, int stage_floats, const float* __restrict__ d_out,
-    long long d_out_stride, float* __restrict__ gtheta) {
+    long long d_out_stride, const float* __restrict__ stash, float* __restrict__ gtheta, int dbg) {
+    // dbg (development, PMT_CNN_DBG; 0 in production, results are wrong otherwise): 1 skip the forward recompute, 2 skip the
+    // convolutions' input gradients, 4 skip their weight gradients, 8 skip the final linear's dW, 16 skip pool / activation /
+    // linear input gradients
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ int taps[C2_MAX_CONVS][PMT_MAX_ROW_INPUT];
     __shared__ float dout_sh[PMT_WAVES][C2_MAX_LIN_OUT];
@@ -320,7 +328,15 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_backward_kernel(
     for (long long base = (long long)blockIdx.x * nw; base < n; base += per_round) {
         const long long v = base + wave;
         if (v < n) {
-            c2_forward_variant(M, theta, cw, acts, hap + (size_t)v * hap_stride, taps);
+            if (stash) {  // the forward kept its layer outputs: load them instead of recomputing
+                const int first = 10 * uniform(C.seq_len), per = sa - first;
+                const float* src = stash + (size_t)v * per;
+                c2_one_hot(acts, hap + (size_t)v * hap_stride, uniform(C.seq_len));
+                for (int i = lane; i < per; i += 64) acts[first + i] = src[i];
+                wave_sync();
+            } else if (!(dbg & 1)) {
+                c2_forward_variant(M, theta, cw, acts, hap + (size_t)v * hap_stride, taps);
+            }
             for (int o = lane; o < od; o += 64) {
                 const float d = d_out[(size_t)v * d_out_stride + o];
                 gA[o] = d;
@@ -338,7 +354,8 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_backward_kernel(
                 const float* yout = acts + uniform(L.out_off);
                 const int nin = uniform(L.in_ch) * uniform(L.in_len), nout = uniform(L.out_ch) * uniform(L.out_len);
                 const bool need_din = uniform(L.in_off) != 0;  // the one-hot input needs no gradient
-                if (kind == PMT_CNN_LEAKY_RELU || kind == PMT_CNN_SELU) {
+                if ((dbg & 16) && kind != PMT_CNN_CONV) {
+                } else if (kind == PMT_CNN_LEAKY_RELU || kind == PMT_CNN_SELU) {
                     for (int i = lane; i < nout; i += 64) gin[i] = gout[i] * c2_act_grad_from_out(kind, yout[i]);
                 } else if (kind == PMT_CNN_POOL) {
                     for (int i = lane; i < nin; i += 64) gin[i] = 0.f;
@@ -371,9 +388,10 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_backward_kernel(
                     --conv;
                     const PmtLinear& Wl = M->lin[uniform(L.lin)];
                     const int K = uniform(Wl.in_dim), OC = uniform(Wl.out_dim), out_len = uniform(L.out_len);
-                    if (conv == 0) c2_conv_wgrad<NTI0>(cacc0, cb[0], L, gout, xin, taps[0], K, OC);
+                    if (dbg & 4) {
+                    } else if (conv == 0) c2_conv_wgrad<NTI0>(cacc0, cb[0], L, gout, xin, taps[0], K, OC);
                     else c2_conv_wgrad<NTI1>(cacc1, cb[1], L, gout, xin, taps[1], K, OC);
-                    if (need_din) {
+                    if (need_din && !(dbg & 2)) {
                         for (int i = lane; i < nin; i += 64) gin[i] = 0.f;
                         wave_sync();
                         const int nkt = (K + 15) >> 4;
@@ -410,7 +428,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_backward_kernel(
         }
         // ---- final linear dW: every wave adds its column slice over the variants of this round ----
         __syncthreads();
-        if (lin_layer >= 0) {
+        if (lin_layer >= 0 && !(dbg & 8)) {
             const int in_off = C.layers[lin_layer].in_off;
             const int nvar = (int)min((long long)nw, (long long)n - base);
 #pragma unroll
@@ -524,8 +542,15 @@ static int cnn2_waves(size_t floats_per_wave, size_t static_bytes, int* per_cu) 
     return nw > PMT_WAVES ? PMT_WAVES : nw;
 }
 
+extern "C" size_t pmt_cnn_stash_floats(const PmtModel* m) {
+    if (!m || !cnn2_supported(m)) return 0;
+    const int per = m->cnn.sum_act - 10 * m->cnn.seq_len;
+    return per > 0 ? (size_t)per : 0;
+}
+
 extern "C" int pmt_cnn2_try_forward(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* packed,
-                                    const int64_t* haplotypes, int64_t hap_stride, int32_t n, float* out, int64_t out_stride, void* stream) {
+                                    const int64_t* haplotypes, int64_t hap_stride, int32_t n, float* out, int64_t out_stride,
+                                    float* stash, void* stream) {
     if (!cnn2_supported(model_host)) return 1;  // not an error: the caller runs the general kernels
     const size_t per = (size_t)model_host->cnn.sum_act;
     int per_cu = 1;
@@ -543,13 +568,13 @@ extern "C" int pmt_cnn2_try_forward(const PmtModel* model_host, const PmtModel* 
     const int blocks = (int)(((long long)n + nw - 1) / nw < cus ? ((long long)n + nw - 1) / nw : cus);
     const size_t lds_bytes = ((size_t)nw * per + 4 + stage) * sizeof(float);  // (+4: the weights start 16-byte aligned)
     hipLaunchKernelGGL(pmt_cnn2_forward_kernel, dim3(blocks), dim3(64 * nw), lds_bytes, reinterpret_cast<hipStream_t>(stream), model_dev,
-                       theta, packed, (const long long*)haplotypes, (long long)hap_stride, n, (int)per, (int)stage, out, (long long)out_stride);
+                       theta, packed, (const long long*)haplotypes, (long long)hap_stride, n, (int)per, (int)stage, out, (long long)out_stride, stash);
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }
 
 extern "C" int pmt_cnn2_try_backward(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* packed,
                                      const int64_t* haplotypes, int64_t hap_stride, int32_t n, const float* d_out,
-                                     int64_t d_out_stride, float* grad_theta, void* stream) {
+                                     int64_t d_out_stride, const float* stash, float* grad_theta, void* stream) {
     if (!cnn2_supported(model_host)) return 1;
     const size_t per = (size_t)model_host->cnn.sum_act + 2 * (size_t)model_host->cnn.max_act;
     int per_cu = 1;
@@ -580,6 +605,6 @@ extern "C" int pmt_cnn2_try_backward(const PmtModel* model_host, const PmtModel*
     auto kernel = (kt[0] <= 2) ? pmt_cnn2_backward_kernel<2, C2_NTI> : pmt_cnn2_backward_kernel<C2_NTI, C2_NTI>;
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64 * nw), lds_bytes, reinterpret_cast<hipStream_t>(stream), model_dev,
                        theta, packed, (const long long*)haplotypes, (long long)hap_stride, n, (int)per, (int)stage, d_out, (long long)d_out_stride,
-                       grad_theta);
+                       stash, grad_theta, getenv("PMT_CNN_DBG") ? atoi(getenv("PMT_CNN_DBG")) : 0);
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }

@@ -153,7 +153,7 @@ class PmtLossInputGrads(C.Structure):
 
 EXPORTS = ["pmt_abi_version", "pmt_struct_bytes", "pmt_model_check", "pmt_build_schedules", "pmt_plan_groups", "pmt_stash_bytes", "pmt_pack_params",
            "pmt_scan_counts", "pmt_forward", "pmt_backward", "pmt_clip_adamw",
-           "pmt_rows_stash_bytes", "pmt_rows_forward", "pmt_rows_backward", "pmt_cnn_forward", "pmt_cnn_backward",
+           "pmt_rows_stash_bytes", "pmt_rows_forward", "pmt_rows_backward", "pmt_cnn_forward", "pmt_cnn_backward", "pmt_cnn_stash_floats",
            "pmt_phi_forward", "pmt_phi_backward", "pmt_build_read_index", "pmt_losses_forward", "pmt_losses_backward",
            "pmt_downsample_counts", "pmt_downsample_index", "pmt_record_losses",
            "pmt_plan_groups_split", "pmt_layered_scratch_floats", "pmt_forward_layered",
@@ -193,8 +193,10 @@ def load() -> C.CDLL:
     lib.pmt_forward.argtypes = [P(PmtModel), vp, vp, vp, vp, P(PmtBatch), P(PmtOutputs), vp, vp]
     lib.pmt_backward.argtypes = [P(PmtModel), vp, vp, vp, vp, P(PmtBatch), P(PmtOutputs), P(PmtOutputGrads), vp, vp, vp, vp, vp]
     lib.pmt_clip_adamw.argtypes = [vp, vp, vp, vp, i64, P(PmtAdamW), vp, vp, vp]
-    lib.pmt_cnn_forward.argtypes = [P(PmtModel), vp, vp, vp, vp, i64, i32, vp, i64, vp]
-    lib.pmt_cnn_backward.argtypes = [P(PmtModel), vp, vp, vp, vp, i64, i32, vp, i64, vp, vp]
+    lib.pmt_cnn_forward.argtypes = [P(PmtModel), vp, vp, vp, vp, i64, i32, vp, i64, vp, vp]
+    lib.pmt_cnn_backward.argtypes = [P(PmtModel), vp, vp, vp, vp, i64, i32, vp, i64, vp, vp, vp]
+    lib.pmt_cnn_stash_floats.argtypes = [P(PmtModel)]
+    lib.pmt_cnn_stash_floats.restype = C.c_size_t
     lib.pmt_rows_stash_bytes.argtypes = [P(PmtModel), i32, i32]
     lib.pmt_rows_stash_bytes.restype = C.c_size_t
     lib.pmt_rows_forward.argtypes = [P(PmtModel), vp, i32, vp, vp, vp, i64, i32, vp, i64, vp, vp]

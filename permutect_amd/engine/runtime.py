@@ -7,6 +7,7 @@ forward = pmt_forward (one fused HIP launch), backward = pmt_backward (one fused
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -257,10 +258,15 @@ class HaplotypeCnnFunction(torch.autograd.Function):
         assert hap.stride(-1) == 1 and hap.shape[1] == 2 * d.cnn.seq_len
         n = hap.shape[0]
         out = torch.empty(n, d.cnn.out_dim, dtype=torch.float32, device=engine.device)
+        train = bool(ctx.needs_input_grad[2])
+        # (PMT_CNN_STASH=0: let the backward recompute the layer outputs instead; the parity tests cover both)
+        per = engine.lib.pmt_cnn_stash_floats(C.byref(d)) if train and os.environ.get("PMT_CNN_STASH", "1") != "0" else 0
+        stash = torch.empty(n * per, dtype=torch.float32, device=engine.device) if per > 0 and n > 0 else None
         L.check(engine.lib.pmt_cnn_forward(C.byref(d), engine.plan.desc_dev.data_ptr(), engine.space.theta.data_ptr(),
-                                           engine.plan.packed.data_ptr(), hap.data_ptr(), hap.stride(0), n, out.data_ptr(), out.stride(0), _stream()),
+                                           engine.plan.packed.data_ptr(), hap.data_ptr(), hap.stride(0), n, out.data_ptr(), out.stride(0),
+                                           _ptr(stash), _stream()),
                 "pmt_cnn_forward")
-        ctx.engine, ctx.train = engine, bool(ctx.needs_input_grad[2])
+        ctx.engine, ctx.train, ctx.stash = engine, train, stash
         ctx.hap = hap  # integer tensor: kept on ctx (save_for_backward is for differentiable tensors' bookkeeping)
         return out
 
@@ -274,7 +280,8 @@ class HaplotypeCnnFunction(torch.autograd.Function):
             d_out = d_out.float().contiguous()
         L.check(eng.lib.pmt_cnn_backward(C.byref(d), eng.plan.desc_dev.data_ptr(), eng.space.theta.data_ptr(),
                                          eng.plan.packed.data_ptr(), hap.data_ptr(), hap.stride(0), hap.shape[0], d_out.data_ptr(), d_out.stride(0),
-                                         eng.space.gtheta.data_ptr(), _stream()), "pmt_cnn_backward")
+                                         _ptr(ctx.stash), eng.space.gtheta.data_ptr(), _stream()), "pmt_cnn_backward")
+        ctx.stash = None
         return None, None, torch.zeros(1, device=eng.device)
 
 

@@ -20,6 +20,7 @@ def kernel_shape(request, monkeypatch):
     time) and with the generic instance (PMT_SHAPE=any); the library reads the variable at every launch."""
     if request.param == "tile":
         monkeypatch.setenv("PMT_SHAPE", "tile")
+        monkeypatch.setenv("PMT_CNN_STASH", "0")  # and the haplotype-CNN backward that recomputes its forward
     if request.param == "any":
         monkeypatch.setenv("PMT_SHAPE", "any")
         monkeypatch.setenv("PMT_CNN", "general")  # and the general (workgroup-per-chunk) haplotype-CNN kernels
