@@ -462,83 +462,94 @@ extern "C" int pmt_pack_params(const PmtModel* model_host, const PmtModel* model
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// exclusive scans of ref / alt counts.  The counts sit in a strided column of the batch's integer table (one cache line
-// per element), so a single workgroup walking the array is latency-bound (100 us at 65 536 variants).  Instead the array
-// is cut into at most 64 segments, one 1024-thread workgroup each: it first sums everything before its segment (all its
-// threads stream over the prefix; no inter-workgroup dependency, no scratch memory), then scans its own segment in
-// 4096-element chunks.
+// exclusive scans of ref / alt counts.  The counts sit in a strided column of the batch's integer table: every element in
+// its own cache line (and, at 464 bytes per row, a new page every 9 rows), so the scan is bound by how many of those loads
+// are in flight, and every element should be read exactly once.  Three small launches, no scratch memory:
+//   1. every 1024-thread workgroup scans its own segment (local exclusive prefixes) and leaves the segment's TOTAL in the
+//      first slot of the next segment (whose own local prefix is known to be 0); the last total goes to o[n];
+//   2. one wave turns the totals in those slots into segment offsets (and completes o[n]);
+//   3. every workgroup adds its offset to the rest of its segment.
 // ---------------------------------------------------------------------------------------------------------------------
+#define PMT_SCAN_SEG 4096
 template <typename T>
-__global__ __launch_bounds__(1024) void pmt_scan_kernel(const T* __restrict__ c0, const T* __restrict__ c1,
-                                                        long long stride, int n, int per_block, int* __restrict__ o0,
-                                                        int* __restrict__ o1) {
+__global__ __launch_bounds__(1024) void pmt_scan_local_kernel(const T* __restrict__ c0, const T* __restrict__ c1,
+                                                              long long stride, int n, int* __restrict__ o0, int* __restrict__ o1) {
     const T* c = blockIdx.y == 0 ? c0 : c1;
     int* o = blockIdx.y == 0 ? o0 : o1;
     __shared__ int wave_tot[16];
-    __shared__ int carry_sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int begin = blockIdx.x * per_block, end = min(n, begin + per_block);
-    int before = 0;
-    for (int i = tid; i < begin; i += 1024) before += (int)c[(size_t)i * stride];
+    const int begin = blockIdx.x * PMT_SCAN_SEG, end = min(n, begin + PMT_SCAN_SEG);
+    int v[4], local = 0;
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d);
-    if (lane == 0) wave_tot[wave] = before;
+    for (int k = 0; k < 4; ++k) {
+        const int i = begin + tid * 4 + k;
+        v[k] = i < end ? (int)c[(size_t)i * stride] : 0;
+        local += v[k];
+    }
+    int incl = local;  // inclusive scan of `local` across the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
     __syncthreads();
+    int wave_prefix = 0, total = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) wave_prefix += wave_tot[w];
+        total += wave_tot[w];
+    }
+    int run = wave_prefix + incl - local;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = begin + tid * 4 + k;
+        if (i < end && i != begin) o[i] = run;  // (slot `begin` belongs to the previous segment's total until step 2)
+        run += v[k];
+    }
     if (tid == 0) {
-        int t = 0;
-        for (int w = 0; w < 16; ++w) t += wave_tot[w];
-        carry_sh = t;
+        if (begin == 0) o[0] = 0;
+        o[end == n ? n : begin + PMT_SCAN_SEG] = total;  // n > 0 here, so end == n only in the last segment
     }
-    __syncthreads();
-    for (int base = begin; base < end; base += 4096) {
-        int v[4], local = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = base + tid * 4 + k;
-            v[k] = i < end ? (int)c[(size_t)i * stride] : 0;
-            local += v[k];
-        }
-        int incl = local;  // inclusive scan of `local` across the wave
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int up = __shfl_up(incl, d);
-            if (lane >= d) incl += up;
-        }
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        int wave_prefix = 0;
-        for (int w = 0; w < wave; ++w) wave_prefix += wave_tot[w];
-        int run = carry_sh + wave_prefix + incl - local;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = base + tid * 4 + k;
-            if (i < end) o[i] = run;
-            run += v[k];
-        }
-        __syncthreads();
-        if (tid == 1023) carry_sh = run;
-        __syncthreads();
+}
+__global__ __launch_bounds__(64) void pmt_scan_offsets_kernel(int n, int* __restrict__ o0, int* __restrict__ o1) {
+    int* o = blockIdx.x == 0 ? o0 : o1;
+    if (threadIdx.x != 0) return;  // at most n / 4096 totals: a serial walk of a few hundred L2 hits at the very most
+    int run = 0;
+    for (int s = PMT_SCAN_SEG; s < n; s += PMT_SCAN_SEG) {
+        run += o[s];
+        o[s] = run;
     }
-    if (tid == 0 && end == n) o[n] = carry_sh;
+    o[n] += run;  // (step 1 left the last segment's total there)
+}
+__global__ __launch_bounds__(1024) void pmt_scan_add_kernel(int n, int* __restrict__ o0, int* __restrict__ o1) {
+    int* o = blockIdx.y == 0 ? o0 : o1;
+    const int begin = (blockIdx.x + 1) * PMT_SCAN_SEG, end = min(n, begin + PMT_SCAN_SEG);
+    const int off = o[begin];
+    for (int i = begin + 1 + threadIdx.x; i < end; i += 1024) o[i] += off;
 }
 
 extern "C" int pmt_scan_counts(const void* ref_counts, const void* alt_counts, int32_t count_elem_bytes,
                                int64_t count_stride, int32_t num_variants, int32_t* ref_offsets, int32_t* alt_offsets,
                                void* stream) {
     if (!ref_counts || !alt_counts || !ref_offsets || !alt_offsets || num_variants < 0 || count_stride < 1) return PMT_E_INVALID;
+    if (count_elem_bytes != 4 && count_elem_bytes != 8) return PMT_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    int per_block = ((num_variants + 63) / 64 + 4095) / 4096 * 4096;
-    if (per_block < 4096) per_block = 4096;
-    int blocks = (num_variants + per_block - 1) / per_block;
-    if (blocks < 1) blocks = 1;
+    if (num_variants == 0) {
+        if (hipMemsetAsync(ref_offsets, 0, sizeof(int32_t), s) != hipSuccess || hipMemsetAsync(alt_offsets, 0, sizeof(int32_t), s) != hipSuccess)
+            return PMT_E_LAUNCH;
+        return PMT_OK;
+    }
+    const int blocks = (num_variants + PMT_SCAN_SEG - 1) / PMT_SCAN_SEG;
     if (count_elem_bytes == 4)
-        hipLaunchKernelGGL(pmt_scan_kernel<int32_t>, dim3(blocks, 2), dim3(1024), 0, s, (const int32_t*)ref_counts,
-                           (const int32_t*)alt_counts, (long long)count_stride, num_variants, per_block, ref_offsets, alt_offsets);
-    else if (count_elem_bytes == 8)
-        hipLaunchKernelGGL(pmt_scan_kernel<int64_t>, dim3(blocks, 2), dim3(1024), 0, s, (const int64_t*)ref_counts,
-                           (const int64_t*)alt_counts, (long long)count_stride, num_variants, per_block, ref_offsets, alt_offsets);
+        hipLaunchKernelGGL(pmt_scan_local_kernel<int32_t>, dim3(blocks, 2), dim3(1024), 0, s, (const int32_t*)ref_counts,
+                           (const int32_t*)alt_counts, (long long)count_stride, num_variants, ref_offsets, alt_offsets);
     else
-        return PMT_E_INVALID;
+        hipLaunchKernelGGL(pmt_scan_local_kernel<int64_t>, dim3(blocks, 2), dim3(1024), 0, s, (const int64_t*)ref_counts,
+                           (const int64_t*)alt_counts, (long long)count_stride, num_variants, ref_offsets, alt_offsets);
+    if (blocks > 1) {
+        hipLaunchKernelGGL(pmt_scan_offsets_kernel, dim3(2), dim3(64), 0, s, num_variants, ref_offsets, alt_offsets);
+        hipLaunchKernelGGL(pmt_scan_add_kernel, dim3(blocks - 1, 2), dim3(1024), 0, s, num_variants, ref_offsets, alt_offsets);
+    }
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }
 
