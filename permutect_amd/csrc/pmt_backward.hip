@@ -718,7 +718,8 @@ extern "C" int pmt_backward_layered(const PmtModel* model_host, const PmtModel* 
     lay.park = lay.dy_scratch + (size_t)batch->total_tiles * PMT_SLOT_FLOATS;
     lay.gsum_g = lay.park + (size_t)batch->total_tiles * 6 * 256;
     if (hipMemsetAsync(lay.gsum_g, 0, B * nb * 32 * sizeof(float), s) != hipSuccess) return PMT_E_LAUNCH;
-    auto kernel = pmt_shape_id(model_host) >= 1 ? pmt_backward_kernel<ShapeP0, true> : pmt_backward_kernel<ShapeAny, true>;
+    const int shape = pmt_shape_id(model_host);
+    auto kernel = shape == 2 ? pmt_backward_kernel<ShapeP0X, true> : shape == 1 ? pmt_backward_kernel<ShapeP0, true> : pmt_backward_kernel<ShapeAny, true>;
     for (int slice = 0; slice <= L; ++slice) {
         lay.slice = slice;
         hipLaunchKernelGGL(kernel, dim3(batch->num_groups), dim3(PMT_THREADS), 0, s, model_dev, theta, phi, packed, *batch, *out, *dout,

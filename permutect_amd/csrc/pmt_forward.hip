@@ -516,7 +516,8 @@ extern "C" int pmt_forward_layered(const PmtModel* model_host, const PmtModel* m
         !batch->group_tile_base || batch->total_tiles <= 0 || !out->logits_b || !out->logits_bk || !out->features_be || !out->ref_features_be)
         return PMT_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const bool p0 = pmt_shape_id(model_host) >= 1;  // (the layered launches use the tile-exact instance for P0 too)
+    const int shape = pmt_shape_id(model_host);
+    const bool p0 = shape == 1;
     const int L = model_host->num_blocks;
     const size_t nb = (size_t)(L > 0 ? L : 1), B = (size_t)batch->num_variants;
     PmtLayeredArgs lay;
@@ -536,6 +537,7 @@ extern "C" int pmt_forward_layered(const PmtModel* model_host, const PmtModel* m
     if (hipMemsetAsync(lay.fsum_g, 0, B * (2 * PMT_MAX_WIDTH + PMT_MAX_CLUSTERS + 2) * sizeof(float), s) != hipSuccess) return PMT_E_LAUNCH;
     auto kernel = stash ? (p0 ? pmt_forward_kernel<true, ShapeP0, true> : pmt_forward_kernel<true, ShapeAny, true>)
                         : (p0 ? pmt_forward_kernel<false, ShapeP0, true> : pmt_forward_kernel<false, ShapeAny, true>);
+    if (shape == 2) kernel = stash ? pmt_forward_kernel<true, ShapeP0X, true> : pmt_forward_kernel<false, ShapeP0X, true>;
     for (int slice = 0; slice <= L; ++slice) {
         lay.slice = slice;
         hipLaunchKernelGGL(kernel, dim3(batch->num_groups), dim3(PMT_THREADS), 0, s, model_dev, theta, phi, packed, *batch, *out, stash,
