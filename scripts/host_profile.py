@@ -51,3 +51,26 @@ for i in range(200):
 pr.disable()
 torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats("tottime").print_stats(40)
+
+# ---- host time inside the autograd backward functions (they run on autograd's device thread, which cProfile does not see)
+import permutect_amd.engine.runtime as RT  # noqa: E402
+
+acc = {}
+for name in ("LossesFunction", "PhiFunction", "ReadSetFunction", "HaplotypeCnnFunction", "RowsMlpFunction"):
+    cls = getattr(RT, name)
+    orig = cls.backward
+
+    def make(orig, name):
+        def timed(ctx, *grads):
+            t = time.perf_counter()
+            out = orig(ctx, *grads)
+            acc[name] = acc.get(name, 0.0) + time.perf_counter() - t
+            return out
+        return staticmethod(timed)
+    cls.backward = make(orig, name)
+t0 = time.perf_counter()
+for i in range(200):
+    step(i)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+print(f"host {1e3 * (t1 - t0) / 200:.3f} ms/step; inside backward functions (us/step):", {k: round(1e6 * v / 200, 1) for k, v in acc.items()})
