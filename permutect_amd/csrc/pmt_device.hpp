@@ -234,7 +234,7 @@ template <int NT>
 DEV void stash_store(float* __restrict__ base, const f4 (&v)[NT]) {
     f4* p = reinterpret_cast<f4*>(base) + (threadIdx.x & 63);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) p[t * 64] = v[t];
+    for (int t = 0; t < NT; ++t) __builtin_nontemporal_store(v[t], p + t * 64);  // written once, read by the backward long after
 }
 template <int NT>
 DEV void stash_load(const float* __restrict__ base, f4 (&v)[NT]) {
