@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PMT_ABI_VERSION 1
+#define PMT_ABI_VERSION 2
 
 /* error codes */
 #define PMT_OK 0
@@ -73,6 +73,9 @@ typedef struct PmtLinear {
                             ref linear's range covers both sides and the alt linear's w_stage is 0.             */
     int32_t out_split;   /* 0, or h: the 2h output rows are laid out as two 16-row tiles (rows 0..h-1 -> tile 0,
                             rows h..2h-1 -> tile 1) so that z1 / z2 of the gating unit are tile aligned       */
+    int32_t wb_frag;     /* packed: W as THREE bf16 pieces (hi + mid + lo = the fp32 value) in the operand order of
+                            v_mfma_f32_16x16x32_bf16: [k block of 32][out tile][piece][lane][8 bf16]; -1 = none */
+    int32_t wtb_frag;    /* the same for W^T                                                                   */
 } PmtLinear;
 
 typedef struct PmtStage {

@@ -48,15 +48,19 @@ static_assert(PMT_GROUP_TILES == PMT_WG_TILES, "group capacity");
 // XF .. XE (only with EXACT): the EXACT widths of the model, known at compile time (0 = read from the descriptor).  With them
 // the padding masks (feature < width), the k-steps that hold nothing but padding and most width bookkeeping fold away:
 // the masks alone cost ~30 SGPR pairs that the generic code keeps (and spills) across the block loop.
-template <int F, int R, int D, int E, bool EXACT_, int XF = 0, int XR = 0, int XD = 0, int XH = 0, int XE = 0>
+// XBF: the layers' matrix products run as SIX bf16 MFMAs on three-piece splits of both operands (linear_acc_bf16) instead
+// of exact-fp32 MFMAs.
+template <int F, int R, int D, int E, bool EXACT_, int XF = 0, int XR = 0, int XD = 0, int XH = 0, int XE = 0, bool XBF = false>
 struct Shape {
     static constexpr int NTF = F, NTR = R, NTD = D, NTE = E;
     static constexpr bool EXACT = EXACT_;
     static constexpr int DIM_F = XF, DIM_R = XR, DIM_D = XD, DIM_H = XH, DIM_E = XE;  // read features, read width, d_model, d_ffn / 2, feature_dim
+    static constexpr bool BF16 = XBF;
+    static_assert(!XBF || EXACT_, "the bf16 path has no tile guards");
 };
 using ShapeAny = Shape<4, 4, 4, 4, false>;   // any supported model
 using ShapeP0 = Shape<4, 2, 4, 1, true>;     // F in 49..64, read widths 17..32, d_model / reducer widths 49..64, E <= 16
-using ShapeP0X = Shape<4, 2, 4, 1, true, 61, 30, 60, 10, 10>;  // exactly the production hyperparameters (SURVEY: P0)
+using ShapeP0X = Shape<4, 2, 4, 1, true, 61, 30, 60, 10, 10, true>;  // exactly the production hyperparameters (SURVEY: P0)
 
 DEV float uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -156,6 +160,64 @@ DEV void linear_acc_impl(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], co
                         }
                     }
                 }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same product on the bf16 matrix pipe.  v_mfma_f32_16x16x32_bf16 does 8x the work of v_mfma_f32_16x16x4_f32 in half
+// the cycles, and an fp32 value is EXACTLY the sum of three bf16 pieces (8 + 8 + 8 significant bits), so
+//     w x = (wh + wm + wl)(xh + xm + xl) = wh xh + (wh xm + wm xh) + (wh xl + wm xm + wl xh) + O(2^-24 |w x|):
+// six bf16 MFMAs (fp32 accumulation inside the matrix core) reproduce the fp32 product to the last bit or two, in
+// 6 x 16 cycles per 32-wide k block instead of 8 x 32.  The weights are split once per step by pmt_pack_params
+// (PmtLinear.wb_frag); the activations are split here, ~5 VALU operations per element.  One k block = two activation
+// tiles in their fp32 register order (see the pack kernel), so layers chain exactly as in linear_acc.
+// ---------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+DEV f4 mfma_bf16(bf8 a, bf8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+DEV void split_bf16x3(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
+    hi = (__bf16)x;
+    const float r1 = x - (float)hi;
+    mid = (__bf16)r1;
+    lo = (__bf16)(r1 - (float)mid);
+}
+template <int NTI, int NTO, bool SELU_IN>
+DEV void linear_acc_bf16(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], const float* __restrict__ fragb, float in_scale = 1.0f) {
+    constexpr int NKB = (NTI + 1) / 2;
+    const bf8* __restrict__ fp = reinterpret_cast<const bf8*>(fragb) + (threadIdx.x & 63);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        bf8 bh[PMT_RT], bm[PMT_RT], bl[PMT_RT];
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt) {
+            const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
+            f4 v0 = in[rt][2 * kb], v1 = (2 * kb + 1 < NTI) ? in[rt][(2 * kb + 1 < NTI) ? 2 * kb + 1 : 0] : zero;
+            if (SELU_IN) {
+                v0 = selu4(v0) * in_scale;
+                if (2 * kb + 1 < NTI) v1 = selu4(v1) * in_scale;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                __bf16 h, m, l;
+                split_bf16x3(v0[e], h, m, l);
+                bh[rt][e] = h; bm[rt][e] = m; bl[rt][e] = l;
+                split_bf16x3(v1[e], h, m, l);
+                bh[rt][4 + e] = h; bm[rt][4 + e] = m; bl[rt][4 + e] = l;
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < NTO; ++mt) {
+            const bf8 ah = fp[0], am = fp[64], al = fp[128];
+            fp += 192;
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt) {  // smallest terms first
+                acc[rt][mt] = mfma_bf16(al, bh[rt], acc[rt][mt]);
+                acc[rt][mt] = mfma_bf16(ah, bl[rt], acc[rt][mt]);
+                acc[rt][mt] = mfma_bf16(am, bm[rt], acc[rt][mt]);
+                acc[rt][mt] = mfma_bf16(am, bh[rt], acc[rt][mt]);
+                acc[rt][mt] = mfma_bf16(ah, bm[rt], acc[rt][mt]);
+                acc[rt][mt] = mfma_bf16(ah, bh[rt], acc[rt][mt]);
             }
         }
     }

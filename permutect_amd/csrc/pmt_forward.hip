@@ -132,8 +132,8 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
         }
         if constexpr (EX) {
             f4 xr[PMT_RT][NTR];
-            run_linear_op<FWD_STAGED, NTF, NTR, true, S::DIM_F, S::DIM_R>(M, M->read_mlp.ops[0], xr, xf, g, ws);
-            run_mlp<TRAIN, FWD_STAGED, NTR, true, S::DIM_R>(M, M->read_mlp, xr, theta, g, mask_all, stash_tile, slot, 1, ws, 1, n_read_ops);
+            run_linear_op<FWD_STAGED, NTF, NTR, true, S::DIM_F, S::DIM_R, S::BF16>(M, M->read_mlp.ops[0], xr, xf, g, ws);
+            run_mlp<TRAIN, FWD_STAGED, NTR, true, S::DIM_R, S::BF16>(M, M->read_mlp, xr, theta, g, mask_all, stash_tile, slot, 1, ws, 1, n_read_ops);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
@@ -202,7 +202,8 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
             const f4 b0 = load_pvec(bp, 0, g), b1 = load_pvec(bp, 1, g);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) { z[rt][0] = b0; z[rt][1] = b1; }
-            linear_acc<NTD, 2, false, EX, S::DIM_D>(z, n, stA + side * frag_floats_dev(P1r), D, 16 + h);
+            if constexpr (S::BF16) linear_acc_bf16<NTD, 2, false>(z, n, packed + uniform(M->lin[uniform(B.proj1[side])].wb_frag));
+            else linear_acc<NTD, 2, false, EX, S::DIM_D>(z, n, stA + side * frag_floats_dev(P1r), D, 16 + h);
         // SELU, LayerNorm(h) on z2, per-set sums (reference gated_mlp.py:228-239)
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt) {
@@ -287,7 +288,8 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt) x[rt][t] = x[rt][t] + b;
             }
-            linear_acc<1, NTD, false, EX, S::DIM_H>(x, u, p2_frags + side * frag_floats_dev(P2r), h, D);
+            if constexpr (S::BF16) linear_acc_bf16<1, NTD, false>(x, u, packed + uniform(M->lin[uniform(B.proj2[side])].wb_frag));
+            else linear_acc<1, NTD, false, EX, S::DIM_H>(x, u, p2_frags + side * frag_floats_dev(P2r), h, D);
         }
     }
     if (TRAIN) {  // x_L, the reducer's input
@@ -300,14 +302,14 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
     // ---- reducer MLP, then translation + rotation ----------------------------------------------------------------
     f4 e[PMT_RT][NTE];
     if constexpr (EX) {
-        run_mlp<TRAIN, FWD_STAGED, NTD, true, S::DIM_D>(M, M->reducer, x, theta, g, mask_all, stash_tile, slot, 1, ws, 0, n_red_ops - 1);
+        run_mlp<TRAIN, FWD_STAGED, NTD, true, S::DIM_D, S::BF16>(M, M->reducer, x, theta, g, mask_all, stash_tile, slot, 1, ws, 0, n_red_ops - 1);
         if (TRAIN && n_red_ops > 1) {
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
                 if (mask_all & (1u << rt)) stash_store<NTD>(stash_tile[rt] + slot * PMT_SLOT_FLOATS, x[rt]);
             ++slot;
         }
-        run_linear_op<FWD_STAGED, NTD, NTE, true, S::DIM_D, S::DIM_E>(M, M->reducer.ops[n_red_ops - 1], e, x, g, ws);
+        run_linear_op<FWD_STAGED, NTD, NTE, true, S::DIM_D, S::DIM_E, S::BF16>(M, M->reducer.ops[n_red_ops - 1], e, x, g, ws);
     } else {
         run_mlp<TRAIN, FWD_STAGED, NTD, false>(M, M->reducer, x, theta, g, mask_all, stash_tile, slot, 1, ws, 0, n_red_ops);
 #pragma unroll
@@ -328,7 +330,8 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
                 a[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        linear_acc<NTE, NTE, false, EX, S::DIM_E>(a, e, stR, E, E);
+        if constexpr (S::BF16) linear_acc_bf16<NTE, NTE, false>(a, e, packed + uniform(R.wb_frag));
+        else linear_acc<NTE, NTE, false, EX, S::DIM_E>(a, e, stR, E, E);
     }
 
     // ---- per-set feature sums (both sides) and the clustering head (alt reads) -------------------------------------

@@ -382,16 +382,49 @@ DEV int split_row(int v, int h) {
     return (v - 16) < h ? h + (v - 16) : -1;
 }
 
-// one job per workgroup: (lin, 0) forward frags, (lin, 1) transposed frags, (lin, 2) bias, then per-block vectors
+// one job per workgroup: (lin, 0) forward frags, (lin, 1) transposed frags, (lin, 2) bias, (lin, 3 / 4) the same two matrices
+// as bf16 pieces, then per-block vectors
 __global__ void pmt_pack_kernel(const PmtModel* __restrict__ M, const float* __restrict__ theta,
                                 const float* __restrict__ phi, float* __restrict__ packed) {
     const int job = blockIdx.x;
-    const int n_lin_jobs = M->n_linear * 3;
+    const int n_lin_jobs = M->n_linear * 5;
     if (job < n_lin_jobs) {
-        const PmtLinear& L = M->lin[job / 3];
-        const int kind = job % 3;
+        const PmtLinear& L = M->lin[job / 5];
+        const int kind = job % 5;
         const int h = L.out_split;
         const int out_v = h > 0 ? 16 + h : L.out_dim;  // virtual output rows
+        if (kind >= 3) {
+            // k block kb of 32 = activation tiles 2 kb and 2 kb + 1; lane (m, kg) element e: tile 2 kb + (e >> 2), register
+            // e & 3 of lane group kg, i.e. the SAME feature order as the fp32 activation registers, so a layer's C-layout
+            // output still feeds the next layer without any shuffle
+            const int off = kind == 3 ? L.wb_frag : L.wtb_frag;
+            if (off < 0) return;
+            const float* W = src_ptr(L.w_src, theta, phi);
+            const int Mv = kind == 3 ? out_v : L.in_dim, Kv = kind == 3 ? L.in_dim : out_v;
+            const int nmt = (Mv + 15) >> 4, nkt = (Kv + 15) >> 4, nkb = (nkt + 1) >> 1;
+            __bf16* dst = reinterpret_cast<__bf16*>(packed + off);
+            const int total = nkb * nmt * 512;
+            for (int i = threadIdx.x; i < total; i += blockDim.x) {
+                const int e = i & 7, lane = (i >> 3) & 63, blk = i >> 9;
+                const int mt = blk % nmt, kb = blk / nmt;
+                const int m = lane & 15, kg = lane >> 4;
+                const int mv = 16 * mt + 4 * (m & 3) + (m >> 2);
+                const int kv = 16 * (2 * kb + (e >> 2)) + 4 * (e & 3) + kg;
+                float val = 0.f;
+                if (mv < Mv && kv < Kv && (2 * kb + (e >> 2)) < nkt) {
+                    const int orow = kind == 3 ? split_row(mv, h) : split_row(kv, h);
+                    const int icol = kind == 3 ? kv : mv;
+                    if (orow >= 0 && orow < L.out_dim && icol < L.in_dim) val = W[(size_t)orow * L.in_dim + icol];
+                }
+                __bf16 hi, mid, lo;
+                split_bf16x3(val, hi, mid, lo);
+                const size_t base = (size_t)blk * 3 * 512 + lane * 8 + e;
+                dst[base] = hi;
+                dst[base + 512] = mid;
+                dst[base + 1024] = lo;
+            }
+            return;
+        }
         if (kind == 2) {
             if (L.b_pvec < 0) return;
             const float* b = src_ptr(L.b_src, theta, phi);
@@ -455,7 +488,7 @@ extern "C" int pmt_pack_params(const PmtModel* model_host, const PmtModel* model
     if (!model_host || !model_dev || !theta || !packed) return PMT_E_INVALID;
     const int rc = pmt_model_check(model_host);
     if (rc) return rc;
-    const int jobs = model_host->n_linear * 3 + model_host->num_blocks * 5 + 1;
+    const int jobs = model_host->n_linear * 5 + model_host->num_blocks * 5 + 1;
     hipLaunchKernelGGL(pmt_pack_kernel, dim3(jobs), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), model_dev, theta,
                        phi, packed);
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;

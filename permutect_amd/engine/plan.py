@@ -142,6 +142,14 @@ class EnginePlan:
 
         self._lower_cnn(d.cnn, model.haplotypes_cnn, model.haplotypes_length() // 2)
         d.n_linear = self._n_lin
+        # the weights once more as three bf16 pieces per value (PmtLinear.wb_frag / wtb_frag): 1 KiB per (32-wide k block,
+        # 16-row tile, piece), one more fragment of slack behind each range
+        for i in range(self._n_lin):
+            lin = d.lin[i]
+            out_v = 16 + lin.out_split if lin.out_split else lin.out_dim
+            nmt, nkt = (out_v + 15) // 16, (lin.in_dim + 15) // 16
+            lin.wb_frag = self._alloc_packed(nmt * ((nkt + 1) // 2) * 3 * 256 + 256)
+            lin.wtb_frag = self._alloc_packed(nkt * ((nmt + 1) // 2) * 3 * 256 + 256)
         d.theta_size, d.phi_size, d.packed_size = space.size, max(self._phi_off, 4), self._packed_off + 512  # slack: the kernels prefetch two fragments ahead
 
         lib = L.load()
