@@ -260,6 +260,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "kernel": dom,
                          "kernel_ms": dom_ms, "algorithmic_flops_per_launch": dom_flops,
+                         "matrix_pipe": "fp32-equivalent: forward / recompute / dgrad as six bf16 MFMAs on three-piece splits of both "
+                                        "operands, wgrad as exact fp32 MFMAs; `peak` is the dense fp32 MFMA rate",
                          "padded_flops_per_launch": dom_flops * pad_ratio, "frac_padded": achieved * pad_ratio / PEAK_FP32_MFMA_TFLOPS,
                          "hbm_frac": None if traffic is None else traffic / (dom_ms * 1e-3) / (PEAK_HBM_GBS * 1e9),
                          "other_kernel_ms": {k: v for k, v in kernel_ms.items()}},

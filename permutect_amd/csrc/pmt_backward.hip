@@ -166,7 +166,8 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             if constexpr (EX) {
                 const PmtLinear& Lr = M->lin[uniform(red_last.lin[0])];
                 init_bias<NTE>(e, uniform(Lr.b_pvec) >= 0 ? packed + uniform(Lr.b_pvec) : nullptr, E, g);
-                linear_acc<NTD, NTE, false, true, S::DIM_D>(e, r, packed + uniform(Lr.w_frag), D, E);
+                if constexpr (S::BF16) linear_acc_bf16<NTD, NTE, false>(e, r, packed + uniform(Lr.wb_frag));
+                else linear_acc<NTD, NTE, false, true, S::DIM_D>(e, r, packed + uniform(Lr.w_frag), D, E);
                 if (uniform(red_last.selu_after) != 0) {
 #pragma unroll
                     for (int rt = 0; rt < PMT_RT; ++rt)
@@ -224,7 +225,8 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
                 a[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        linear_acc<NTE, NTE, false, EX, S::DIM_E>(a, e, packed + uniform(R.w_frag), E, E);
+        if constexpr (S::BF16) linear_acc_bf16<NTE, NTE, false>(a, e, packed + uniform(R.wb_frag));
+        else linear_acc<NTE, NTE, false, EX, S::DIM_E>(a, e, packed + uniform(R.w_frag), E, E);
 
         // ---- head backward (alt reads) + set-mean gradients -> d(a) in da ------------------------------------------
         f4 da[PMT_RT][NTE];
@@ -337,7 +339,8 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         linear_wgrad<NTE, NTE>(c, R, da, e);
         f4 de[PMT_RT][NTE];
         init_bias<NTE>(de, nullptr, E, g);
-        linear_acc<NTE, NTE, false, EX, S::DIM_E>(de, da, packed + uniform(R.wt_frag), E, E);
+        if constexpr (S::BF16) linear_acc_bf16<NTE, NTE, false>(de, da, packed + uniform(R.wtb_frag));
+        else linear_acc<NTE, NTE, false, EX, S::DIM_E>(de, da, packed + uniform(R.wt_frag), E, E);
         f4 dt[NTE];
 #pragma unroll
         for (int t = 0; t < NTE; ++t) {
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         if constexpr (EX) {
             f4 r[PMT_RT][NTD];
             load_slot_tiles<NTD>(stash_tile, mask_all, slot_last_in, r);
-            linear_op_backward<NTD, NTE, true, S::DIM_D, S::DIM_E>(c, red_last, de, r, dy, true);
+            linear_op_backward<NTD, NTE, true, S::DIM_D, S::DIM_E, S::BF16>(c, red_last, de, r, dy, true);
         } else {
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
@@ -363,7 +366,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
 
     // ---- reducer backward ---------------------------------------------------------------------------------------------
     if (!(LAYERED && lay.slice > 0))
-    mlp_backward<NTD, EX, S::DIM_D>(c, M->reducer, dy, true,
+    mlp_backward<NTD, EX, S::DIM_D, S::BF16>(c, M->reducer, dy, true,
                           [&](int op, f4 (&x)[PMT_RT][NTD]) { load_slot_tiles<NTD>(stash_tile, mask_all, op == 0 ? slot_x0 + L : slot_red + op - 1, x); },
                           0, EX ? n_red_ops - 1 : n_red_ops);
 
@@ -407,7 +410,8 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             const f4 b0 = load_pvec(packed + uniform(P1.b_pvec), 0, g), b1 = load_pvec(packed + uniform(P1.b_pvec), 1, g);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) { z[rt][0] = b0; z[rt][1] = b1; }
-            linear_acc<NTD, 2, false, EX, S::DIM_D>(z, n, packed + uniform(P1.w_frag), D, 16 + h);
+            if constexpr (S::BF16) linear_acc_bf16<NTD, 2, false>(z, n, packed + uniform(P1.wb_frag));
+            else linear_acc<NTD, 2, false, EX, S::DIM_D>(z, n, packed + uniform(P1.w_frag), D, 16 + h);
         }
         const f4 sw = load_pvec(packed + uniform(B.sgu_norm_w_pvec), 0, g), sb = load_pvec(packed + uniform(B.sgu_norm_b_pvec), 0, g);
         const float w = uniform(phi[uniform(B.reg_weight_phi)]) + 0.25f;
@@ -435,7 +439,10 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         float d_alpha = 0.f, d_beta = 0.f, d_gamma = 0.f;
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt) du[rt][0] = f4{0.f, 0.f, 0.f, 0.f};
-        if (first_half) linear_acc<NTD, 1, false, EX, S::DIM_D>(du, dy, packed + uniform(P2.wt_frag), D, h);
+        if (first_half) {
+            if constexpr (S::BF16) linear_acc_bf16<NTD, 1, false>(du, dy, packed + uniform(P2.wtb_frag));
+            else linear_acc<NTD, 1, false, EX, S::DIM_D>(du, dy, packed + uniform(P2.wt_frag), D, h);
+        }
         if (first_half) {
             f4 u[PMT_RT][1];
 #pragma unroll
@@ -577,7 +584,8 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         {
             f4 dn[PMT_RT][NTD];
             init_bias<NTD>(dn, nullptr, D, g);
-            linear_acc<2, NTD, false, EX, 0, S::DIM_H>(dn, dz, packed + uniform(P1.wt_frag), 16 + h, D);
+            if constexpr (S::BF16) linear_acc_bf16<2, NTD, false>(dn, dz, packed + uniform(P1.wtb_frag));
+            else linear_acc<2, NTD, false, EX, 0, S::DIM_H>(dn, dz, packed + uniform(P1.wt_frag), 16 + h, D);
             f4 lw[NTD], dlw[NTD], dlb[NTD];
 #pragma unroll
             for (int t = 0; t < NTD; ++t) {
@@ -646,11 +654,11 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
             for (int t = 0; t < NTR; ++t) dr[rt][t] = dy[rt][t < NTD ? t : 0];
-        mlp_backward<NTR, true, S::DIM_R>(c, M->read_mlp, dr, true,
+        mlp_backward<NTR, true, S::DIM_R, S::BF16>(c, M->read_mlp, dr, true,
                                 [&](int op, f4 (&x)[PMT_RT][NTR]) { load_slot_tiles<NTR>(stash_tile, mask_all, op - 1, x); }, 1, n_read_ops);
         f4 xf[PMT_RT][NTF], dxf[PMT_RT][NTF];
         decode_reads(xf);
-        linear_op_backward<NTF, NTR, true, S::DIM_F, S::DIM_R>(c, M->read_mlp.ops[0], dr, xf, dxf, false);
+        linear_op_backward<NTF, NTR, true, S::DIM_F, S::DIM_R, S::BF16>(c, M->read_mlp.ops[0], dr, xf, dxf, false);
     } else {
         mlp_backward<NTD, false>(c, M->read_mlp, dy, false,
                                  [&](int op, f4 (&x)[PMT_RT][NTD]) {

@@ -378,7 +378,7 @@ DEV void linear_wgrad(BwdCtx& c, const PmtLinear& L, const f4 (&dy)[PMT_RT][NTO]
 
 // Backward of one LINEAR op between register arrays of different tile counts (see run_linear_op): dy is the gradient
 // w.r.t. the op's output (modified: multiplied by the activation derivative), x its input; dx (if wanted) = W^T dy.
-template <int NTI, int NTO, bool EXACT, int WI = 0, int WO = 0>
+template <int NTI, int NTO, bool EXACT, int WI = 0, int WO = 0, bool BF = false>
 DEV void linear_op_backward(BwdCtx& c, const PmtOp& o, f4 (&dy)[PMT_RT][NTO], const f4 (&x)[PMT_RT][NTI],
                             f4 (&dx)[PMT_RT][NTI], bool want_dx) {
     const PmtLinear& L = c.M->lin[uniform(o.lin[0])];
@@ -386,7 +386,8 @@ DEV void linear_op_backward(BwdCtx& c, const PmtOp& o, f4 (&dy)[PMT_RT][NTO], co
     if (uniform(o.selu_after) != 0) {  // recompute s = selu(Wx + b); dy <- dy * selu'(s)
         f4 y[PMT_RT][NTO];
         init_bias<NTO>(y, uniform(L.b_pvec) >= 0 ? c.packed + uniform(L.b_pvec) : nullptr, out_dim, c.g);
-        linear_acc<NTI, NTO, false, EXACT, WI>(y, x, c.packed + uniform(L.w_frag), in_dim, out_dim);
+        if constexpr (BF) linear_acc_bf16<NTI, NTO, false>(y, x, c.packed + uniform(L.wb_frag));
+        else linear_acc<NTI, NTO, false, EXACT, WI>(y, x, c.packed + uniform(L.w_frag), in_dim, out_dim);
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
@@ -395,13 +396,14 @@ DEV void linear_op_backward(BwdCtx& c, const PmtOp& o, f4 (&dy)[PMT_RT][NTO], co
     linear_wgrad<NTO, NTI>(c, L, dy, x);
     if (want_dx) {
         init_bias<NTI>(dx, nullptr, in_dim, c.g);
-        linear_acc<NTO, NTI, false, EXACT, WO>(dx, dy, c.packed + uniform(L.wt_frag), out_dim, in_dim);
+        if constexpr (BF) linear_acc_bf16<NTO, NTI, false>(dx, dy, c.packed + uniform(L.wtb_frag));
+        else linear_acc<NTO, NTI, false, EXACT, WO>(dx, dy, c.packed + uniform(L.wt_frag), out_dim, in_dim);
     }
 }
 
 // backward of one MLP program.  dy (in/out): gradient w.r.t. the MLP output on entry, w.r.t. its input on exit
 // (not computed for op 0 when need_input_grad is false).  in_slot(op) gives the stash slot of op's input.
-template <int NT, bool EXACT, int W = 0, typename LoadInput>
+template <int NT, bool EXACT, int W = 0, bool BF = false, typename LoadInput>
 DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool need_input_grad, LoadInput load_input,
                       int op_begin, int op_end) {
     const PmtModel* M = c.M;
@@ -415,7 +417,8 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
             if (uniform(o.selu_after) != 0) {  // recompute s = selu(Wx + b); dy <- dy * selu'(s)
                 f4 y[PMT_RT][NT];
                 init_bias<NT>(y, uniform(L.b_pvec) >= 0 ? c.packed + uniform(L.b_pvec) : nullptr, out_dim, c.g);
-                linear_acc<NT, NT, false, EXACT, W>(y, x, c.packed + uniform(L.w_frag), in_dim, out_dim);
+                if constexpr (BF) linear_acc_bf16<NT, NT, false>(y, x, c.packed + uniform(L.wb_frag));
+                else linear_acc<NT, NT, false, EXACT, W>(y, x, c.packed + uniform(L.w_frag), in_dim, out_dim);
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
@@ -425,7 +428,8 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
             if (op > op_begin || need_input_grad) {
                 f4 dx[PMT_RT][NT];
                 init_bias<NT>(dx, nullptr, in_dim, c.g);
-                linear_acc<NT, NT, false, EXACT, W>(dx, dy, c.packed + uniform(L.wt_frag), out_dim, in_dim);
+                if constexpr (BF) linear_acc_bf16<NT, NT, false>(dx, dy, c.packed + uniform(L.wtb_frag));
+                else linear_acc<NT, NT, false, EXACT, W>(dx, dy, c.packed + uniform(L.wt_frag), out_dim, in_dim);
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
@@ -443,7 +447,8 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
             f4 s1[PMT_RT][NT];
             if (nl == 2) {  // s1 = selu(L1 selu(x) + b1)
                 init_bias<NT>(s1, c.packed + uniform(L1.b_pvec), width, c.g);
-                linear_acc<NT, NT, true, EXACT, W>(s1, x, c.packed + uniform(L1.w_frag), width, width);
+                if constexpr (BF) linear_acc_bf16<NT, NT, true>(s1, x, c.packed + uniform(L1.wb_frag));
+                else linear_acc<NT, NT, true, EXACT, W>(s1, x, c.packed + uniform(L1.w_frag), width, width);
             }
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
@@ -452,7 +457,8 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
             {   // d(alpha) = sum dy . f,  f = L2 s1 + b2   (x's registers are free from here on)
                 f4 f[PMT_RT][NT];
                 init_bias<NT>(f, c.packed + uniform(L2.b_pvec), width, c.g);
-                linear_acc<NT, NT, false, EXACT, W>(f, s1, c.packed + uniform(L2.w_frag), width, width);
+                if constexpr (BF) linear_acc_bf16<NT, NT, false>(f, s1, c.packed + uniform(L2.wb_frag));
+                else linear_acc<NT, NT, false, EXACT, W>(f, s1, c.packed + uniform(L2.w_frag), width, width);
                 float da = 0.f;
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
@@ -465,7 +471,8 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
             linear_wgrad<NT, NT>(c, L2, dy, s1, alpha);
             f4 d1[PMT_RT][NT];
             init_bias<NT>(d1, nullptr, width, c.g);
-            linear_acc<NT, NT, false, EXACT, W>(d1, dy, c.packed + uniform(L2.wt_frag), width, width);
+            if constexpr (BF) linear_acc_bf16<NT, NT, false>(d1, dy, c.packed + uniform(L2.wtb_frag));
+            else linear_acc<NT, NT, false, EXACT, W>(d1, dy, c.packed + uniform(L2.wt_frag), width, width);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
@@ -481,7 +488,8 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
                 linear_wgrad<NT, NT>(c, L1, d1, s0);
                 f4 d0[PMT_RT][NT];
                 init_bias<NT>(d0, nullptr, width, c.g);
-                linear_acc<NT, NT, false, EXACT, W>(d0, d1, c.packed + uniform(L1.wt_frag), width, width);
+                if constexpr (BF) linear_acc_bf16<NT, NT, false>(d0, d1, c.packed + uniform(L1.wtb_frag));
+                else linear_acc<NT, NT, false, EXACT, W>(d0, d1, c.packed + uniform(L1.wt_frag), width, width);
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
