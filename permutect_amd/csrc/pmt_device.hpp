@@ -176,6 +176,13 @@ DEV void linear_acc_impl(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], co
 // ---------------------------------------------------------------------------------------------------------------
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 DEV f4 mfma_bf16(bf8 a, bf8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+// the 16-deep variant on elements 0..3 of both operands (lane (m, kg) supplies k = 4 kg + i: one activation tile)
+typedef short s4v __attribute__((ext_vector_type(4)));
+DEV f4 mfma_bf16_k16(bf8 a, bf8 b, f4 c) {
+    typedef short s8v __attribute__((ext_vector_type(8)));
+    const s8v sa = __builtin_bit_cast(s8v, a), sb = __builtin_bit_cast(s8v, b);
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(s4v{sa[0], sa[1], sa[2], sa[3]}, s4v{sb[0], sb[1], sb[2], sb[3]}, c, 0, 0, 0);
+}
 DEV void split_bf16x3(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
     hi = (__bf16)x;
     const float r1 = x - (float)hi;
@@ -206,18 +213,28 @@ DEV void linear_acc_bf16(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], co
                 bh[rt][4 + e] = h; bm[rt][4 + e] = m; bl[rt][4 + e] = l;
             }
         }
+        const bool half_block = 2 * kb + 1 >= NTI;  // a last k block with one tile only: the 16-deep MFMA on the lower halves
 #pragma unroll
         for (int mt = 0; mt < NTO; ++mt) {
             const bf8 ah = fp[0], am = fp[64], al = fp[128];
             fp += 192;
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) {  // smallest terms first
-                acc[rt][mt] = mfma_bf16(al, bh[rt], acc[rt][mt]);
-                acc[rt][mt] = mfma_bf16(ah, bl[rt], acc[rt][mt]);
-                acc[rt][mt] = mfma_bf16(am, bm[rt], acc[rt][mt]);
-                acc[rt][mt] = mfma_bf16(am, bh[rt], acc[rt][mt]);
-                acc[rt][mt] = mfma_bf16(ah, bm[rt], acc[rt][mt]);
-                acc[rt][mt] = mfma_bf16(ah, bh[rt], acc[rt][mt]);
+                if (half_block) {
+                    acc[rt][mt] = mfma_bf16_k16(al, bh[rt], acc[rt][mt]);
+                    acc[rt][mt] = mfma_bf16_k16(ah, bl[rt], acc[rt][mt]);
+                    acc[rt][mt] = mfma_bf16_k16(am, bm[rt], acc[rt][mt]);
+                    acc[rt][mt] = mfma_bf16_k16(am, bh[rt], acc[rt][mt]);
+                    acc[rt][mt] = mfma_bf16_k16(ah, bm[rt], acc[rt][mt]);
+                    acc[rt][mt] = mfma_bf16_k16(ah, bh[rt], acc[rt][mt]);
+                } else {
+                    acc[rt][mt] = mfma_bf16(al, bh[rt], acc[rt][mt]);
+                    acc[rt][mt] = mfma_bf16(ah, bl[rt], acc[rt][mt]);
+                    acc[rt][mt] = mfma_bf16(am, bm[rt], acc[rt][mt]);
+                    acc[rt][mt] = mfma_bf16(am, bh[rt], acc[rt][mt]);
+                    acc[rt][mt] = mfma_bf16(ah, bm[rt], acc[rt][mt]);
+                    acc[rt][mt] = mfma_bf16(ah, bh[rt], acc[rt][mt]);
+                }
             }
         }
     }
