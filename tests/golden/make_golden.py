@@ -227,9 +227,65 @@ def make_dataset_fixture():
     print("dataset fixture written:", os.path.getsize(tar_path), "bytes")
 
 
+def make_training_helpers_fixture():
+    """training_helpers.npz: the reference's bin indexing (BatchIndices.flattened_idx), its Balancer run over a sequence of
+    batches that crosses the recompute threshold, and its Downsampler's constants and per-variant mixture weights."""
+    from permutect.training.balancer import Balancer
+    from permutect.training.downsampler import Downsampler
+    rng = np.random.default_rng(77)
+    torch.manual_seed(77)
+    nb, per = 12, 1000
+    n = nb * per
+    ref = rng.integers(0, 40, n)
+    alt = rng.integers(1, 30, n)
+    labels = rng.integers(0, 3, n)
+    vtypes = rng.integers(0, 5, n)
+    sources = rng.integers(0, 2, n)
+    probs = rng.random(n).astype(np.float32)
+    int_array = np.zeros((n, 16 + 42), dtype=np.int16)
+    flat, weights, source_weights = [], [], []
+    bal = Balancer(num_sources=2, device=CPU)
+    down = Downsampler(num_sources=2)
+    with torch.no_grad():
+        down.parametrizations.log_ref_weights_slvrak.original.add_(torch.randn_like(down.parametrizations.log_ref_weights_slvrak.original))
+        down.parametrizations.log_alt_weights_slvrah.original.add_(torch.randn_like(down.parametrizations.log_alt_weights_slvrah.original))
+    ref_w, alt_w = [], []
+    for k in range(nb):
+        data = []
+        for i in range(k * per, (k + 1) * per):
+            ints = np.zeros(16 + 42, dtype=np.int16)
+            floats = np.zeros(6 + 71, dtype=np.float16)
+            d = Datum(ints, floats, np.zeros((1, 12), dtype=np.uint8), compressed=True)  # (reads are irrelevant here)
+            d.set(Data.REF_COUNT, int(ref[i])); d.set(Data.ALT_COUNT, int(alt[i])); d.set(Data.LABEL, int(labels[i]))
+            d.set(Data.VARIANT_TYPE, int(vtypes[i])); d.set(Data.SOURCE, int(sources[i]))
+            int_array[i] = d.get_int_array()
+            data.append(d)
+        batch = Batch(data)
+        flat.append(batch.batch_indices().flattened_idx.numpy())
+        w, sw = bal.process_batch_and_compute_weights(batch, torch.from_numpy(probs[k * per:(k + 1) * per]))
+        weights.append(w.numpy().copy()); source_weights.append(sw.numpy().copy())
+        ref_w.append(torch.exp(down.log_ref_weights_slvrak).view(-1, 4)[batch.batch_indices().flattened_idx].detach().numpy())
+        alt_w.append(torch.exp(down.log_alt_weights_slvrah).view(-1, 4)[batch.batch_indices().flattened_idx].detach().numpy())
+    np.savez_compressed(
+        os.path.join(HERE, "training_helpers.npz"),
+        int_array=int_array, probs=probs, batch=np.int64(per), flattened_idx=np.concatenate(flat),
+        weights=np.concatenate(weights), source_weights=np.concatenate(source_weights),
+        final_weights_slvra=bal.weights_slvra.detach().numpy(), final_unlabeled_weights_slvra=bal.unlabeled_weights_slvra.detach().numpy(),
+        final_source_weights_s=bal.source_weights_s.detach().numpy(), final_counts_slvra=bal.counts_slvra.detach().numpy(),
+        binned_ref_trans_kry=down.binned_ref_trans_kry.detach().numpy(), binned_alt_trans_haz=down.binned_alt_trans_haz.detach().numpy(),
+        log_ref_weights_original=down.parametrizations.log_ref_weights_slvrak.original.detach().numpy(),
+        log_alt_weights_original=down.parametrizations.log_alt_weights_slvrah.original.detach().numpy(),
+        ref_weights_bk=np.concatenate(ref_w), alt_weights_bk=np.concatenate(alt_w),
+    )
+    print("training helpers fixture written")
+
+
 if __name__ == "__main__":
     if "--dataset-only" in sys.argv:  # leaves the model fixtures (and their random streams) untouched
         make_dataset_fixture()
+    elif "--helpers-only" in sys.argv:
+        make_training_helpers_fixture()
     else:
         main()
         make_dataset_fixture()
+        make_training_helpers_fixture()
