@@ -193,7 +193,8 @@ def main():
 
         def endless():
             while True:
-                for cb in dataset.device_loader(args.batch, dev, chunk_variants=args.chunk_variants, rng=rng):
+                # (training draws shuffled batches; filter_variants walks the candidates in order)
+                for cb in dataset.device_loader(args.batch, dev, chunk_variants=args.chunk_variants, rng=rng, shuffle=args.mode == "train"):
                     if cb.size() == args.batch:
                         yield cb
         stream_batches = endless()
