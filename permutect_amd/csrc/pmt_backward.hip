@@ -2,11 +2,12 @@
 // kernel walks the network in reverse; inside each layer group it RECOMPUTES the forward from the stashed layer-group
 // input (pmt_forward<TRAIN> wrote those), so only ~0.7 K floats per read cross HBM between the two passes.
 //
-//   dgrad  dx = W^T dy      : MFMA with the transposed A fragments (wt_frag); dy is already the B operand.
-//   wgrad  dW += dy x^T     : contraction over READS.  Both operands are transposed on the matrix core (reads move
-//                             from the lane axis to the MFMA k axis) and exchanged through LDS; each wave then owns
-//                             distinct 16x16 blocks of dW, contracts them over all reads of the workgroup with
-//                             v_mfma_f32_16x16x4_f32 and adds them with global float atomics into the flat gradient
+//   dgrad  dx = W^T dy      : MFMA with the transposed A fragments (wt_frag, or their bf16 pieces wtb_frag in the
+//                             exact-width instance); dy is already the B operand.
+//   wgrad  dW += dy x^T     : contraction over READS.  Both operands are written transposed into an LDS stage (reads move
+//                             from the lane axis to the MFMA k axis purely by the store addressing) and exchanged; each
+//                             wave then owns distinct 16x16 blocks of dW, contracts them over all reads of the workgroup
+//                             with v_mfma_f32_16x16x4_f32 and adds them with global float atomics into the flat gradient
 //                             buffer (pmt_bwd_device.hpp: wgrad_exchange).  No LDS atomics.
 //   set-coupled terms       : per-set sums of d(gate) go through LDS exactly like the forward's z2 sums.
 //
