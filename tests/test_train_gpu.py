@@ -272,3 +272,39 @@ def test_layered_backward_on_forced_splits_matches_reference():
     ref = z["loss/total_losses_b"]
     np.testing.assert_allclose(losses.total_losses_b.detach().cpu().numpy(), ref, rtol=1e-4, atol=1e-4 + 1e-5 * np.abs(ref).max())
     _compare_gradients(model, {k[5:]: z[k] for k in z.files if k.startswith("grad/")})
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_mixed_batches_match_oracle(seed):
+    """Randomly mixed batches -- singletons, zero-ref sets, ordinary sets, sets that fill a workgroup exactly and sets of
+    several hundred reads (split over workgroups) side by side, random labels: losses and every parameter gradient against
+    the oracle's autograd."""
+    from oracle import artifact_oracle as O
+    from tests.helpers import config_for
+    from tests.test_forward_gpu import _arrays
+    rng = np.random.default_rng(100 + seed)
+    kinds = rng.integers(0, 6, 28)
+    nref = np.where(kinds == 0, 0, np.where(kinds == 1, 1, np.where(kinds == 2, rng.integers(0, 11, 28), np.where(
+        kinds == 3, 128, np.where(kinds == 4, rng.integers(100, 420, 28), rng.integers(0, 60, 28))))))
+    nalt = np.where(kinds == 0, 1, np.where(kinds == 1, 1, np.where(kinds == 2, rng.integers(1, 16, 28), np.where(
+        kinds == 3, 128, np.where(kinds == 4, rng.integers(1, 420, 28), rng.integers(1, 60, 28))))))
+    _, sd, _ = load_case("p0_b16")
+    cfg = config_for("p0_b16")
+    ints, floats, packed = _arrays(nref, nalt, seed=200 + seed)
+    model, dev = build("p0_b16", sd)
+    model.train(True)
+    batch = Batch.from_arrays(ints, floats, packed).copy_to(dev)
+    out = model.compute_batch_output(batch)
+    losses = model.compute_batch_losses(out, batch)
+    opt = FusedClipAdamW(model, lr=1e-3, weight_decay=0.01)
+    opt.zero_grad()
+    losses.total_loss.backward()
+    torch.cuda.synchronize()
+    i64 = torch.from_numpy(ints.astype(np.int64))
+    ob = dict(reads_re=torch.from_numpy(O.decode_packed_reads(packed).astype(np.float32)), nref=i64[:, O.REF_COUNT],
+              nalt=i64[:, O.ALT_COUNT], labels=i64[:, O.LABEL], sources=i64[:, O.SOURCE],
+              info_be=torch.from_numpy(floats[:, O.INFO_START:].astype(np.float32)), haplotypes_bh=i64[:, O.HAPLOTYPES_START:])
+    _, ref_losses, ref_grads = O.train_step_grads(sd, cfg, ob)
+    ref_total = ref_losses["total_losses_b"].detach().numpy()
+    np.testing.assert_allclose(losses.total_losses_b.detach().cpu().numpy(), ref_total, rtol=1e-4, atol=1e-4 + 1e-5 * np.abs(ref_total).max())
+    _compare_gradients(model, {k: v.numpy() for k, v in ref_grads.items()})
