@@ -389,8 +389,13 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
                 atomicAdd(&sh.hsum[set][0], c0 - 0.5f * q0);
                 atomicAdd(&sh.hsum[set][1], c1 - 0.5f * q1);
             }
-            // artifact clusters: projection on the unit direction, orthogonal distance, EMG along the direction
-            for (int k = 0; k < K; ++k) {
+            // artifact clusters: projection on the unit direction, orthogonal distance, EMG along the direction.  The cheap
+            // part (p, o2: a few FMAs and two cross-group sums) runs for every cluster in all lanes; the expensive scalar part
+            // (erfc, logs) runs ONCE per four clusters, cluster k0 + g in lane group g, instead of once per cluster with a
+            // quarter of the lanes enabled.
+            for (int k0 = 0; k0 < K; k0 += 4) {
+              float p_sel = 0.f, o2_sel = 0.f;
+              for (int k = k0; k < min(K, k0 + 4); ++k) {
                 const float* vk = hp + uniform(M->head.dirs_ke_phi) + k * E;
                 f4 v[NTE];
                 float p = 0.f;
@@ -417,11 +422,16 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
                             o2 += d * d;
                         }
                 o2 = group_sum(o2);
-                if (tm[rt].valid && g == (k & 3)) {
-                    const float tau = uniform(hp[uniform(M->head.art_stdev_k_phi) + k]);
-                    const float mu = uniform(theta[uniform(M->head.mu_k_src) + k]);
-                    const float sg = uniform(hp[uniform(M->head.sigma_k_phi) + k]);
-                    const float lam = uniform(hp[uniform(M->head.lambda_k_phi) + k]);
+                if (g == (k & 3)) { p_sel = p; o2_sel = o2; }
+              }
+              {
+                const int k = k0 + g;
+                const float p = p_sel, o2 = o2_sel;
+                if (tm[rt].valid && k < K) {
+                    const float tau = hp[uniform(M->head.art_stdev_k_phi) + k];
+                    const float mu = theta[uniform(M->head.mu_k_src) + k];
+                    const float sg = hp[uniform(M->head.sigma_k_phi) + k];
+                    const float lam = hp[uniform(M->head.lambda_k_phi) + k];
                     const float od = sqrtf(o2);
                     const float orth = -(0.5f * (float)(E - 1)) * PMT_LOG2PI - (float)(E - 1) * logf(tau) - (od * od) / (2.f * (tau * tau));
                     const float var = sg * sg;
@@ -429,6 +439,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
                     const float par = logf(lam * 0.5f) + logerfc_dev(zz) + (lam * 0.5f) * (2.f * mu + lam * var - 2.f * p);
                     atomicAdd(&sh.hsum[set][2 + k], orth + par);
                 }
+              }
             }
         }
     }
