@@ -210,19 +210,29 @@ DEV void aux_push_vec(BwdCtx& c, int enc, const f4 (&v)[NT], int dim) {
     const int nt = (dim + 15) >> 4, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (c.aux_n + 16 * nt > PMT_AUX_CAP) aux_flush(c);
     if (c.dbg & 16) return;
+    // all the cross-lane sums first, then ONE region with a sixteenth of the lanes enabled that stores them
+    // (a region per element costs an exec save / restore and a branch each, and runs at full instruction cost)
+    f4 sums[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
-        if (t < nt) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float s = read_lanes_sum(v[t][j]);
-                if ((lane & 15) == 0) {
-                    const int p = c.aux_n + 16 * t + 4 * c.g + j, f = feat_of(t, j, c.g);
-                    c.aux[wave * PMT_AUX_CAP + p] = s;
-                    if (wave == 0) c.aux_dst[p] = f < dim ? enc_at(enc, f) : -1;
+        for (int j = 0; j < 4; ++j) sums[t][j] = t < nt ? read_lanes_sum(v[t][j]) : 0.f;
+    if ((lane & 15) == 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (t < nt) {
+                const int p = c.aux_n + 16 * t + 4 * c.g;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c.aux[wave * PMT_AUX_CAP + p + j] = sums[t][j];  // (p need not be 16-byte aligned)
+                if (wave == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int f = feat_of(t, j, c.g);
+                        c.aux_dst[p + j] = f < dim ? enc_at(enc, f) : -1;
+                    }
                 }
             }
-        }
+    }
     c.aux_n += 16 * nt;
 }
 // one 16-position row (tile 0) whose per-position totals already sit in every lane group: lane (g, p) holds position p
