@@ -178,7 +178,7 @@ def main():
     if args.data == "resident":
         for _ in range(args.resident_batches):
             ints, floats, packed = synth_arrays(rng, args.batch, args.depth)
-            b = Batch.from_arrays(ints, floats, packed)
+            b = Batch.from_arrays(ints, floats, packed, pack=True)  # variants in the order that fills the workgroups best
             b.plan(allow_split=True)
             batches.append(b.copy_to(dev))
             reads_total += packed.shape[0]

@@ -362,6 +362,16 @@ int pmt_build_schedules(PmtModel* model);
 int pmt_plan_groups(const int32_t* ref_counts, const int32_t* alt_counts, int32_t num_variants,
                     int32_t* group_start, int32_t* group_tile_base, int32_t* bad_variant);
 
+/* An order of the batch's variants in which pmt_plan_groups packs fuller groups (a workgroup costs the same full or not, so
+ * the number of groups is what a batch costs): the group under construction takes, out of the next `window` unplaced
+ * variants, the first that still fits.  order[i] (host, num_variants ints) = the variant to put at position i of the batch.
+ * The reference composes batches in random order (data/reads_dataset.py:141-196), so any order is as good to it. */
+int pmt_pack_order(const int32_t* ref_counts, const int32_t* alt_counts, int32_t num_variants, int32_t window, int32_t* order);
+/* The same for consecutive batches of `batch` variants (the batches of a dataset chunk) in one call, on `threads` host
+ * threads: order[k * batch + i] = position in the whole array of the variant to put at place i of batch k. */
+int pmt_pack_order_batches(const int32_t* ref_counts, const int32_t* alt_counts, int32_t num_variants, int32_t batch,
+                           int32_t window, int32_t threads, int32_t* order);
+
 /* Like pmt_plan_groups, but a variant whose reads exceed one workgroup is split over several groups (each a run of whole
  * tiles of its ref rows and / or alt rows).  span: host [max_groups][6] (PmtBatch.group_span), tile_base: host
  * [max_groups + 1].  *needs_layered is set when some group covers only part of a read set (then only pmt_forward_layered

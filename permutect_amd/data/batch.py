@@ -33,6 +33,24 @@ def decode_packed_reads(packed: np.ndarray) -> np.ndarray:
     return np.hstack((bits, (wrapped / 32.0).astype(np.float16)))
 
 
+def pack_order(ref_counts: np.ndarray, alt_counts: np.ndarray, window: int = 64) -> np.ndarray:
+    """An order of a batch's variants that packs fuller workgroups (pmt_pack_order): a workgroup costs the same full or not,
+    and the order of the variants inside a batch means nothing to the model (the reference shuffles them)."""
+    rc = np.ascontiguousarray(ref_counts, dtype=np.int32)
+    ac = np.ascontiguousarray(alt_counts, dtype=np.int32)
+    order = np.empty(len(rc), dtype=np.int32)
+    L.check(L.load().pmt_pack_order(rc.ctypes.data, ac.ctypes.data, len(rc), window, order.ctypes.data), "pmt_pack_order")
+    return order.astype(np.int64)
+
+
+def _segment_rows(starts: np.ndarray, lengths: np.ndarray) -> np.ndarray:
+    """Concatenation of the row ranges [starts[i], starts[i] + lengths[i])."""
+    total = int(lengths.sum())
+    out_start = np.zeros(len(lengths) + 1, dtype=np.int64)
+    np.cumsum(lengths, out=out_start[1:])
+    return np.repeat(starts - out_start[:-1], lengths) + np.arange(total, dtype=np.int64)
+
+
 class GroupPlan:
     """Partition of the batch's variants into register-resident groups (host arrays + device copies)."""
 
@@ -79,6 +97,8 @@ class GroupPlan:
 
 
 class Batch:
+    order = None  # set by from_arrays(pack=True): batch position -> row of the arrays the batch was built from
+
     def __init__(self, data: List[Datum]):
         ints = np.vstack([d.get_int_array() for d in data])
         floats = np.vstack([d.get_float_array() for d in data])
@@ -86,10 +106,22 @@ class Batch:
         self._init_from_arrays(ints, floats, reads)
 
     @classmethod
-    def from_arrays(cls, int_array: np.ndarray, float_array: np.ndarray, reads: np.ndarray) -> "Batch":
+    def from_arrays(cls, int_array: np.ndarray, float_array: np.ndarray, reads: np.ndarray, pack: bool = False) -> "Batch":
         """int_array [B, 16+H] (int16), float_array [B, 6+I] (float16), reads in batch order (all ref rows of all
-        variants, then all alt rows): uint8 [R, 7+nf] packed, or float16 [R, F]."""
+        variants, then all alt rows): uint8 [R, 7+nf] packed, or float16 [R, F].  `pack`: put the variants in the order
+        that fills the kernels' workgroups best (`pack_order`); `self.order` then maps batch positions to rows of the
+        arrays given."""
         self = cls.__new__(cls)
+        self.order = None
+        if pack and len(int_array) > 1:
+            ref = np.asarray(int_array[:, Data.REF_COUNT.idx]).astype(np.int64)
+            alt = np.asarray(int_array[:, Data.ALT_COUNT.idx]).astype(np.int64)
+            order = pack_order(ref, alt)
+            ref_start = np.concatenate([[0], np.cumsum(ref)[:-1]])
+            alt_start = int(ref.sum()) + np.concatenate([[0], np.cumsum(alt)[:-1]])
+            rows = np.concatenate([_segment_rows(ref_start[order], ref[order]), _segment_rows(alt_start[order], alt[order])])
+            int_array, float_array, reads = int_array[order], float_array[order], reads[rows]
+            self.order = order
         self._init_from_arrays(int_array, float_array, reads)
         return self
 

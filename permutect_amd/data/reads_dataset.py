@@ -17,6 +17,7 @@ batches do not straddle chunks (the reference's DataLoader lets the last batch o
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Iterator, List, Optional
 
 import numpy as np
@@ -142,8 +143,8 @@ class ReadsDataset:
 
 
 _STAGE_THREADS = 6
-_PREFETCH = 2  # chunks being loaded while one is consumed: one loader thread (~10 ms of Python + copies per 114 MB
-               # chunk) cannot keep up with the filter forward (~8 ms per chunk of 262 144 variants)
+_PREFETCH = 3  # chunks being loaded while one is consumed: one loader thread (~15 ms of copies, packing and planning per
+               # 114 MB chunk) cannot keep up with the filter forward (~6 ms per chunk of 262 144 variants)
 
 
 class PinnedStage:
@@ -273,6 +274,12 @@ class DeviceChunkLoader:
         """Everything the chunk's batches need from the host, uploaded ONCE with the chunk: the shuffled variant ids and
         every batch's group plan (one pinned buffer, one copy); returns per batch (ids_host, ids_dev, plan)."""
         dev, bs = self.device, self.batch_size
+        # inside a batch the variants go in the order that fills the workgroups best (the batch is a random draw anyway):
+        # one GIL-free call for all batches of the chunk
+        rc, ac = np.ascontiguousarray(chunk.ref_host[ids]), np.ascontiguousarray(chunk.alt_host[ids])
+        order = np.empty(len(ids), dtype=np.int32)
+        L.check(L.load().pmt_pack_order_batches(rc.ctypes.data, ac.ctypes.data, len(ids), bs, 64, 4, order.ctypes.data), "pmt_pack_order_batches")
+        ids = ids[order]
         slices = [ids[s:s + bs] for s in range(0, len(ids), bs)]
         plans = [GroupPlan(chunk.ref_host[sl], chunk.alt_host[sl], allow_split=True) for sl in slices]
         parts = []
@@ -310,10 +317,17 @@ class DeviceChunkLoader:
             return chunk, self._prepare(chunk, ids, stage)
         torch.cuda.set_device(self.device)
         side = torch.cuda.Stream(self.device)
+        import time
+        t0 = time.perf_counter()
         with torch.cuda.stream(side):
             chunk = DeviceChunk(self.dataset, lo, hi, self.device, stage)
+            t1 = time.perf_counter()
             batches = self._prepare(chunk, ids, stage)
+        t2 = time.perf_counter()
         side.synchronize()
+        t3 = time.perf_counter()
+        if os.environ.get("PMT_LOADER_TIMING"):
+            print(f"[loader] chunk {c}: stage+enqueue {1e3 * (t1 - t0):.1f} ms, prepare {1e3 * (t2 - t1):.1f} ms, wait {1e3 * (t3 - t2):.1f} ms", flush=True)
         return chunk, batches
 
     def __iter__(self) -> Iterator[ChunkBatch]:

@@ -157,7 +157,7 @@ EXPORTS = ["pmt_abi_version", "pmt_struct_bytes", "pmt_model_check", "pmt_build_
            "pmt_phi_forward", "pmt_phi_backward", "pmt_build_read_index", "pmt_losses_forward", "pmt_losses_backward",
            "pmt_downsample_counts", "pmt_downsample_index", "pmt_record_losses",
            "pmt_plan_groups_split", "pmt_layered_scratch_floats", "pmt_forward_layered",
-           "pmt_layered_backward_scratch_floats", "pmt_backward_layered", "pmt_host_copy"]
+           "pmt_layered_backward_scratch_floats", "pmt_backward_layered", "pmt_host_copy", "pmt_pack_order", "pmt_pack_order_batches"]
 
 _lib = None
 
@@ -208,6 +208,8 @@ def load() -> C.CDLL:
     lib.pmt_layered_scratch_floats.restype = C.c_size_t
     lib.pmt_forward_layered.argtypes = [P(PmtModel), vp, vp, vp, vp, P(PmtBatch), P(PmtOutputs), vp, vp, vp]
     lib.pmt_host_copy.argtypes = [vp, vp, C.c_size_t, i32]
+    lib.pmt_pack_order.argtypes = [vp, vp, i32, i32, vp]
+    lib.pmt_pack_order_batches.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     lib.pmt_layered_backward_scratch_floats.argtypes = [P(PmtModel), i64, i32]
     lib.pmt_layered_backward_scratch_floats.restype = C.c_size_t
     lib.pmt_backward_layered.argtypes = [P(PmtModel), vp, vp, vp, vp, P(PmtBatch), P(PmtOutputs), P(PmtOutputGrads), vp, vp, vp,

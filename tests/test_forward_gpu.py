@@ -185,3 +185,23 @@ def test_layered_forward_equals_the_single_launch_forward():
     assert torch.allclose(a.logits_b, c.logits_b, rtol=1e-5, atol=1e-5)
     assert torch.allclose(a.features_be, c.features_be, rtol=1e-5, atol=1e-5)
     assert torch.allclose(a.logits_bk, c.logits_bk, rtol=1e-5, atol=2e-4)
+
+
+def test_packed_order_gives_the_same_outputs_per_variant():
+    """Batch.from_arrays(pack=True) only reorders the variants (to fill the workgroups): every variant's outputs are the same."""
+    _, sd, _ = load_case("p0_b16")
+    rng = np.random.default_rng(9)
+    nb = 600
+    nref, nalt = rng.integers(0, 11, nb), rng.integers(1, 16, nb)
+    ints, floats, packed = _arrays(nref, nalt, seed=31)
+    model, dev = build("p0_b16", sd)
+    plain = Batch.from_arrays(ints, floats, packed).copy_to(dev)
+    tight = Batch.from_arrays(ints, floats, packed, pack=True).copy_to(dev)
+    assert tight.plan().num_groups < plain.plan().num_groups
+    with torch.no_grad():
+        a = model.compute_batch_output(plain)
+        c = model.compute_batch_output(tight)
+    o = torch.from_numpy(tight.order).to(dev)
+    assert torch.allclose(a.logits_b[o], c.logits_b, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(a.features_be[o], c.features_be, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(a.logits_bk[o], c.logits_bk, rtol=1e-5, atol=2e-4)

@@ -163,3 +163,42 @@ def test_downsampler_bin_index_matches_reference_layout():
     ds = D.Downsampler(num_sources=2)
     rf, af = ds.calculate_downsampling_fractions(b)
     assert rf.shape == (3,) and bool(((rf >= 0) & (rf <= 1)).all()) and bool(((af >= 0) & (af <= 1)).all())
+
+
+def test_pack_order_fills_groups_and_keeps_every_variant():
+    """pmt_pack_order: a permutation of the batch's variants under which the planner needs fewer groups (the WGS-shaped
+    draw of the bench: 3643 -> 3414), with oversized variants (left to the split planner) kept."""
+    import ctypes as C
+    from permutect_amd.data.batch import GroupPlan, pack_order
+    rng = np.random.default_rng(0)
+    n = 65536
+    ref, alt = rng.integers(0, 11, n), rng.integers(1, 16, n)
+    order = pack_order(ref, alt)
+    assert np.array_equal(np.sort(order), np.arange(n))
+    before, after = GroupPlan(ref, alt).num_groups, GroupPlan(ref[order], alt[order]).num_groups
+    assert before == 3643 and after <= 3420, (before, after)
+    assert after * 256 >= int(ref.sum() + alt.sum())  # (nothing can beat full workgroups)
+    ref[7], alt[4000] = 700, 900
+    order = pack_order(ref, alt)
+    assert np.array_equal(np.sort(order), np.arange(n))
+    assert GroupPlan(ref[order], alt[order], allow_split=True).layered
+    for tiny in (0, 1, 2):
+        o = pack_order(ref[:tiny], alt[:tiny])
+        assert np.array_equal(np.sort(o), np.arange(tiny))
+
+
+def test_packed_batch_is_the_same_batch_reordered():
+    z, sd, b = load_case("p0_deep")
+    plain = Batch.from_arrays(b["int_array"], b["float_array"], b["packed_reads"])
+    packed = Batch.from_arrays(b["int_array"], b["float_array"], b["packed_reads"], pack=True)
+    o = packed.order
+    assert o is not None and np.array_equal(np.sort(o), np.arange(plain.size()))
+    assert torch.equal(packed.int_tensor, plain.int_tensor[o]) and torch.equal(packed.float_tensor, plain.float_tensor[o])
+    # read rows: every variant keeps its own reads, ref block then alt block
+    nref, nalt = plain.host_counts()
+    r0 = np.concatenate([[0], np.cumsum(nref)]); a0 = int(nref.sum()) + np.concatenate([[0], np.cumsum(nalt)])
+    pr, pa = packed.host_counts()
+    pr0 = np.concatenate([[0], np.cumsum(pr)]); pa0 = int(pr.sum()) + np.concatenate([[0], np.cumsum(pa)])
+    for i, v in enumerate(o):
+        assert torch.equal(packed.packed_reads[pr0[i]:pr0[i + 1]], plain.packed_reads[r0[v]:r0[v + 1]])
+        assert torch.equal(packed.packed_reads[pa0[i]:pa0[i + 1]], plain.packed_reads[a0[v]:a0[v + 1]])
