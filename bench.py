@@ -183,6 +183,7 @@ def main():
             batches.append(b.copy_to(dev))
             reads_total += packed.shape[0]
         reads_per_batch = reads_total / len(batches)
+        groups_per_batch = float(np.mean([b.plan(allow_split=True).num_groups for b in batches]))
     else:
         from permutect_amd.data.memory_mapped_data import MemoryMappedData
         from permutect_amd.data.reads_dataset import ReadsDataset
@@ -190,6 +191,7 @@ def main():
         # on-disk order: per datum its ref rows then its alt rows (synth rows are i.i.d., so the order is immaterial)
         dataset = ReadsDataset(MemoryMappedData.from_arrays(ints, floats, packed))
         reads_per_batch = packed.shape[0] / args.dataset_variants * args.batch
+        groups_per_batch = None
 
         def endless():
             while True:
@@ -256,6 +258,7 @@ def main():
             "config": {"workload": ("train_model" if args.mode == "train" else "filter_variants forward")
                        + f" on synthetic 1M-variant-scale {args.depth.upper()} ReadSet batches, hyperparameters P0 (59845 params)",
                        "batch_read_sets_per_gpu": args.batch, "mean_reads_per_set": reads_per_batch / args.batch,
+                       "workgroups_per_batch": groups_per_batch,  # what a batch costs: rounds of 256 (backward) / 512 (forward)
                        "step": "fwd + losses + bwd + grad all-reduce + clip + AdamW" if args.mode == "train" else "compute_batch_output under inference_mode",
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
