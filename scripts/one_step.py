@@ -15,7 +15,7 @@ torch.manual_seed(0)
 model = ArtifactModel(p0_params(), device=dev, **P0_DIMS)
 model.train(True)
 ints, floats, packed = synth_arrays(np.random.default_rng(0), B, "wgs")
-batch = Batch.from_arrays(ints, floats, packed).copy_to(dev)
+batch = Batch.from_arrays(ints, floats, packed, pack=True).copy_to(dev)  # as bench.py builds its batches
 opt = FusedClipAdamW(model, lr=1e-3, weight_decay=0.01)
 for i in range(steps):
     out = model.compute_batch_output(batch)
