@@ -1,20 +1,32 @@
 #!/usr/bin/env python3
 """Benchmark of the Permutect artifact-model hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
 
-Metric (BASELINE.json): read-sets/sec.  Default workload = BASELINE.json configs[1]: train_model on a synthetic
-1M-variant WGS-shaped dataset with the production-shaped hyperparameters P0 (59 845 parameters): one "step" is
-forward + losses + backward + (DP: RCCL gradient all-reduce) + global-norm clip + AdamW on one prepared batch that is
-already resident in HBM.  `--mode filter` times the filter_variants forward (configs[2]) instead.
+N > 1 without a process group in the environment: bench.py starts `python -m torch.distributed.run` with N ranks itself
+(before anything touches a GPU) and relays rank 0's line; the driver's own torchrun launch works as before.
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed inside the timed region) and
-`cpu_baseline` (the CPU oracle = PyTorch-CPU restatement of the reference path, timed on this box's host cores on a
-bounded sample; N = 1 only).
+Metric (BASELINE.json): read-sets/sec, "train fwd+bwd; filter fwd".  The headline `value` is BASELINE.json configs[1]:
+train_model on synthetic WGS-shaped ReadSet batches with the production-shaped hyperparameters P0 (59 845 parameters):
+one "step" = forward + losses + backward + (DP: bucketed RCCL gradient all-reduce, the big bucket under the rest of the
+backward) + global-norm clip + AdamW on one prepared batch already resident in HBM.  The SAME run then times the
+filter_variants forward (configs[2]) over the same resident batches and prints it as `"filter": {...}` inside the line.
+
+ONE JSON line on rank 0 carries, besides the contract's keys:
+  roofline      dominant kernel (pmt_backward_kernel), HIP-event timed inside the timed region; `traffic` only from a
+                profiles/*.json whose recorded hash of the kernel sources equals this tree's
+  filter        the filter-forward half of the metric: value, ms_per_step, its own roofline (pmt_forward_kernel)
+  small_batch   the reference's default batch sizes (training 64, inference 8192: parameters.py:214,236-242), N = 1 only
+  parity_check_max_logit_err   first 2048 variants of resident batch 0 against the CPU oracle, after the timed regions
+  cpu_baseline  the CPU oracle (PyTorch-CPU restatement of the reference path) on this box's host cores, thread count
+                swept and the best reported, B = 8192 and B = 64, train and filter; N = 1 only
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,11 +35,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-from permutect_amd.architecture.artifact_model import ArtifactModel  # noqa: E402
-from permutect_amd.data.batch import Batch  # noqa: E402
-from permutect_amd.parameters import P0_DIMS, p0_params  # noqa: E402
-from permutect_amd.training.optimizer import FusedClipAdamW  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_HBM_GBS = 8000.0
@@ -51,19 +58,36 @@ def synth_arrays(rng, num_variants, depth):
     return ints, floats, packed
 
 
-def pmc_traffic(kernel, args):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json:
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-byte-per-lane streaming reads on gfx950, + WRITE_SIZE),
-    or None when no committed measurement matches this workload."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        rec = json.load(f)
-    if rec.get("batch_read_sets") != args.batch or rec.get("depth") != args.depth:
-        return None
-    k = rec.get("kernels", {}).get(kernel)
-    return None if k is None else k["hbm_bytes_per_launch"]
+def kernels_sha():
+    """Hash of everything the device code is built from: a PMC measurement describes ONE build of the kernels."""
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "permutect_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "permutect_amd", "csrc", "*.hpp"))
+                   + glob.glob(os.path.join(ROOT, "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel, batch, depth):
+    """HBM bytes per launch of `kernel` from a committed rocprofv3 --pmc measurement (profiles/*pmc_traffic*.json, written by
+    scripts/pmc_traffic.py: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-byte-per-lane streaming reads on
+    gfx950, + WRITE_SIZE).  Only a record taken on THIS build of the kernels (same hash of csrc/ + include/) and this
+    workload counts; anything else is stale and yields None."""
+    sha = kernels_sha()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if rec.get("kernels_sha") != sha or rec.get("batch_read_sets") != batch or rec.get("depth") != depth:
+            continue
+        k = rec.get("kernels", {}).get(kernel)
+        if k is not None:
+            return k["hbm_bytes_per_launch"]
+    return None
 
 
 def algorithmic_macs_per_read(model, padded=False):
@@ -71,11 +95,9 @@ def algorithmic_macs_per_read(model, padded=False):
     `padded`: with every dimension rounded up to the 16-wide MFMA tile (what the matrix core actually executes)."""
     d = model.engine().plan.desc
     up = (lambda n: (n + 15) // 16 * 16) if padded else (lambda n: n)
-    macs = 0
     used = set()
 
     def mlp(m):
-        nonlocal macs
         for i in range(m.n_ops):
             o = m.ops[i]
             for k in range(o.n_layers):
@@ -89,25 +111,31 @@ def algorithmic_macs_per_read(model, padded=False):
     return macs
 
 
-def cpu_baseline(mode, seconds=15.0):
-    """The reference path as restated by oracle/artifact_oracle.py, on the host cores, bounded sample."""
+# ---- the CPU baseline ---------------------------------------------------------------------------------------------------
+def _oracle_problem(b):
     from oracle import artifact_oracle as O  # checker / baseline only -- never the product path
+    from permutect_amd.architecture.artifact_model import ArtifactModel
+    from permutect_amd.parameters import P0_DIMS, p0_params
     from tests.helpers import config_for
-
     torch.manual_seed(0)
-    cfg = config_for("p0")
     ref_model = ArtifactModel(p0_params(), device=torch.device("cpu"), **P0_DIMS)
     sd = {k: v.detach().clone() for k, v in ref_model.state_dict().items()}
-    b = 8192
     ints, floats, packed = synth_arrays(np.random.default_rng(1), b, "wgs")
     batch = dict(reads_re=torch.from_numpy(O.decode_packed_reads(packed).astype(np.float32)),
                  nref=torch.from_numpy(ints[:, 0].astype(np.int64)), nalt=torch.from_numpy(ints[:, 1].astype(np.int64)),
                  labels=torch.from_numpy(ints[:, 2].astype(np.int64)), sources=torch.zeros(b, dtype=torch.int64),
                  info_be=torch.from_numpy(floats[:, 6:].astype(np.float32)),
                  haplotypes_bh=torch.from_numpy(ints[:, 16:].astype(np.int64)))
+    return O, config_for("p0"), sd, batch, packed.shape[0]
+
+
+def _oracle_rate(mode, b, threads, seconds, min_steps=2):
+    """read-sets/s of the oracle's train step / filter forward at batch b on `threads` host threads, timed for ~`seconds`."""
+    O, cfg, sd, batch, _ = _oracle_problem(b)
     names = [k for k, v in sd.items() if v.is_floating_point() and not k.endswith(".base")]
     m = [torch.zeros_like(sd[n]) for n in names]
     v = [torch.zeros_like(sd[n]) for n in names]
+    torch.set_num_threads(threads)
 
     def step(i):
         if mode == "train":
@@ -119,25 +147,71 @@ def cpu_baseline(mode, seconds=15.0):
 
     step(0)
     t0, n = time.perf_counter(), 0
-    while n < 3 or time.perf_counter() - t0 < seconds:
+    while n < min_steps or time.perf_counter() - t0 < seconds:
         step(n + 1)
         n += 1
-    dt = time.perf_counter() - t0
-    return {"value": b * n / dt, "unit": "read-sets/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} {mode} steps of B={b} WGS-shaped read sets ({packed.shape[0]} reads), P0, fp32, "
-                      f"oracle/artifact_oracle.py (PyTorch-CPU restatement of the reference path)"}
+    return b * n / (time.perf_counter() - t0), n
+
+
+def cpu_baseline():
+    """The reference path as restated by oracle/artifact_oracle.py on the host cores.  ~18 000 small ATen ops per step do not
+    scale with threads (128 threads on them is oversubscription), so the thread count is swept on the B = 8192 train step and
+    the best one is used for the other three points.  Bounded: about 25 s of CPU work in all."""
+    ncores = os.cpu_count() or 1
+    before = torch.get_num_threads()
+    candidates = sorted({t for t in (4, 8, 16, 32, 64, ncores) if t <= ncores})
+    sweep = {}
+    for t in candidates:
+        sweep[t], _ = _oracle_rate("train", 8192, t, seconds=1.0)
+    best = max(sweep, key=sweep.get)
+    train8k, n1 = _oracle_rate("train", 8192, best, seconds=5.0)
+    filt8k, n2 = _oracle_rate("filter", 8192, best, seconds=3.0)
+    t64 = min(best, 8)  # 812 reads per step: more threads only add hand-off cost
+    train64, n3 = _oracle_rate("train", 64, t64, seconds=3.0, min_steps=10)
+    filt64, n4 = _oracle_rate("filter", 64, t64, seconds=2.0, min_steps=10)
+    torch.set_num_threads(before)
+    reads = _oracle_problem(8192)[4]
+    return {"value": train8k, "unit": "read-sets/s", "cores": best, "kind": "port",
+            "sample": f"{n1} train steps of B=8192 WGS-shaped read sets ({reads} reads), P0, fp32, oracle/artifact_oracle.py "
+                      f"(PyTorch-CPU restatement of the reference path, fwd + losses + autograd bwd + clip + AdamW); thread "
+                      f"count swept over {candidates} of {ncores} host cores, best = {best}",
+            "host_cores": ncores, "thread_sweep_train_b8192": {str(k): v for k, v in sweep.items()},
+            "filter": {"value": filt8k, "unit": "read-sets/s", "cores": best, "sample": f"{n2} forwards of B=8192 under inference_mode"},
+            "b64": {"train": train64, "filter": filt64, "unit": "read-sets/s", "cores": t64,
+                    "sample": f"{n3} train steps / {n4} forwards of B=64 (the reference's default training batch)"}}
+
+
+# ---- launching ----------------------------------------------------------------------------------------------------------
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a process group in the environment: run N ranks under torch.distributed.run as a
+    child process (this process has not touched a GPU and never will) and relay rank 0's JSON line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout.splitlines():
+        if line.startswith("{"):
+            print(line, flush=True)
+    raise SystemExit(proc.returncode)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--mode", choices=["train", "filter"], default="train")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--mode", choices=["both", "train", "filter"], default="both",
+                    help="both: the headline is the train step and the filter forward is timed in the same run (\"filter\" key); "
+                         "train / filter: only that half (filter: the headline keys describe the filter forward)")
     ap.add_argument("--batch", type=int, default=65536, help="read sets per step per GPU")
     ap.add_argument("--resident-batches", type=int, default=4, help="distinct synthetic batches kept in HBM per GPU")
     ap.add_argument("--depth", choices=["wgs", "high", "stress"], default="wgs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the small-batch points and the oracle parity check")
     ap.add_argument("--rehearse", action="store_true",
                     help="development only: run the N > 1 code path on a box with fewer GPUs than ranks (ranks share the "
                          "cards, gloo instead of RCCL); the numbers mean nothing")
@@ -149,11 +223,20 @@ def main():
     ap.add_argument("--chunk-variants", type=int, default=1 << 18, help="--data loader: variants per HBM-resident chunk")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)  # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    from permutect_amd.architecture.artifact_model import ArtifactModel
+    from permutect_amd.data.batch import Batch
+    from permutect_amd.parameters import P0_DIMS, p0_params
+    from permutect_amd.training.distributed import BucketedGradAllReduce
+    from permutect_amd.training.optimizer import FusedClipAdamW
+
     if args.rehearse:
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -168,16 +251,23 @@ def main():
 
     torch.manual_seed(0)  # identical initial weights on every rank
     model = ArtifactModel(p0_params(), device=dev, **P0_DIMS)
-    model.train(args.mode == "train")
     opt = FusedClipAdamW(model, lr=1e-3, weight_decay=0.01)
     eng = model.engine()
+    reduce_grads = None
+    if dist is not None:
+        dist.broadcast(eng.space.theta, src=0)
+        reduce_grads = BucketedGradAllReduce()  # loss is a batch SUM (reference artifact_model.py:90) -> SUM all-reduce
+        eng.grad_hook = reduce_grads            # the early bucket goes out under the haplotype-CNN / info-MLP backward
 
     rng = np.random.default_rng(1000 + rank)  # each rank owns a different shard of the synthetic dataset
     batches, reads_total = [], 0
     stream_batches = None
+    first_host = None
     if args.data == "resident":
-        for _ in range(args.resident_batches):
+        for i in range(args.resident_batches):
             ints, floats, packed = synth_arrays(rng, args.batch, args.depth)
+            if i == 0:
+                first_host = (ints, floats, packed)
             b = Batch.from_arrays(ints, floats, packed, pack=True)  # variants in the order that fills the workgroups best
             b.plan(allow_split=True)
             batches.append(b.copy_to(dev))
@@ -192,87 +282,153 @@ def main():
         dataset = ReadsDataset(MemoryMappedData.from_arrays(ints, floats, packed))
         reads_per_batch = packed.shape[0] / args.dataset_variants * args.batch
         groups_per_batch = None
+        loader_shuffle = [True]
 
         def endless():
             while True:
                 # (training draws shuffled batches; filter_variants walks the candidates in order)
-                for cb in dataset.device_loader(args.batch, dev, chunk_variants=args.chunk_variants, rng=rng, shuffle=args.mode == "train"):
+                for cb in dataset.device_loader(args.batch, dev, chunk_variants=args.chunk_variants, rng=rng, shuffle=loader_shuffle[0]):
                     if cb.size() == args.batch:
                         yield cb
         stream_batches = endless()
     torch.cuda.synchronize()
 
-    def all_reduce_grads(flat):
+    def train_step(batch):
+        opt.zero_grad()
+        out = model.compute_batch_output(batch)
+        losses = model.compute_batch_losses(out, batch)
+        losses.total_loss.backward()
+        opt.step(pre_reduce=reduce_grads)
+        return out, losses
+
+    def filter_step(batch):
+        with torch.inference_mode():
+            return model.compute_batch_output(batch)
+
+    def timed(mode, pool, steps, warmup):
+        """W untimed + exactly K timed steps between barrier + synchronize brackets; max over ranks."""
+        model.train(mode == "train")
+        fn = train_step if mode == "train" else filter_step
+        nxt = (lambda i: pool[i % len(pool)]) if stream_batches is None or pool is not batches else (lambda i: next(stream_batches))
+        for i in range(warmup):
+            fn(nxt(i))
+        eng.timers = {"pmt_forward": [], "pmt_backward": []}
+        torch.cuda.synchronize()
         if dist is not None:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)  # loss is a batch SUM (reference artifact_model.py:90)
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            fn(nxt(warmup + i))
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        kernel_ms = {k: (sum(s.elapsed_time(e) for s, e in v) / len(v) if v else None) for k, v in eng.timers.items()}
+        eng.timers = None
+        return elapsed, kernel_ms
 
-    def step(i):
-        batch = batches[i % len(batches)] if stream_batches is None else next(stream_batches)
-        if args.mode == "train":
-            opt.zero_grad()
-            out = model.compute_batch_output(batch)
-            losses = model.compute_batch_losses(out, batch)
-            losses.total_loss.backward()
-            opt.step(pre_reduce=all_reduce_grads)
-        else:
-            with torch.inference_mode():
-                model.compute_batch_output(batch)
+    macs = algorithmic_macs_per_read(model)
+    pad_ratio = algorithmic_macs_per_read(model, padded=True) / macs
+    fwd_flops = 2.0 * macs * reads_per_batch
 
-    for i in range(args.warmup):
-        step(i)
-    eng.timers = {"pmt_forward": [], "pmt_backward": []}
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def roofline(kernel, flops, ms):
+        achieved = flops / (ms * 1e-3) / 1e12
+        traffic = pmc_traffic(kernel, args.batch, args.depth)
+        return {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "kernel": kernel, "kernel_ms": ms,
+                "algorithmic_flops_per_launch": flops, "padded_flops_per_launch": flops * pad_ratio,
+                "frac_padded": achieved * pad_ratio / PEAK_FP32_MFMA_TFLOPS,
+                "hbm_frac": None if traffic is None else traffic / (ms * 1e-3) / (PEAK_HBM_GBS * 1e9)}
 
-    kernel_ms = {k: (sum(s.elapsed_time(e) for s, e in v) / len(v) if v else None) for k, v in eng.timers.items()}
-    eng.timers = None
+    results = {}
+    if args.mode in ("both", "train"):
+        elapsed, kms = timed("train", batches, args.steps, args.warmup)
+        r = roofline("pmt_backward_kernel", 2.0 * fwd_flops, kms["pmt_backward"])  # dgrad + wgrad; in-kernel recompute not counted
+        r["matrix_pipe"] = ("fp32-equivalent on the bf16 matrix pipe: forward / recompute / dgrad as six bf16 MFMAs on three-piece "
+                            "splits of both operands, wgrad as three bf16 MFMAs on two-piece splits; `peak` is the dense fp32 MFMA rate")
+        r["other_kernel_ms"] = kms
+        results["train"] = (elapsed, r)
+    if args.mode in ("both", "filter"):
+        if stream_batches is not None:
+            loader_shuffle[0] = False
+        elapsed, kms = timed("filter", batches, args.steps, args.warmup)
+        results["filter"] = (elapsed, roofline("pmt_forward_kernel", fwd_flops, kms["pmt_forward"]))
+
+    # ---- the reference's default batch sizes beside the build's best (SURVEY 8d): N = 1, resident batches only ------------
+    small = None
+    if world == 1 and not args.no_extras and args.data == "resident" and args.depth == "wgs":
+        small = {}
+        for bsz, k in ((64, 200), (8192, 40)):
+            pool = []
+            srng = np.random.default_rng(77 + bsz)
+            for _ in range(4):
+                b = Batch.from_arrays(*synth_arrays(srng, bsz, "wgs"), pack=True)
+                b.plan(allow_split=True)
+                pool.append(b.copy_to(dev))
+            et, _ = timed("train", pool, k, 10)
+            ef, _ = timed("filter", pool, k, 10)
+            small[f"b{bsz}"] = {"train_read_sets_per_s": bsz * k / et, "train_ms_per_step": 1e3 * et / k,
+                                "filter_read_sets_per_s": bsz * k / ef, "filter_ms_per_step": 1e3 * ef / k}
+
+    # ---- parity of what was just timed: first 2048 variants of resident batch 0 against the CPU oracle ---------------------
+    parity = None
+    if rank == 0 and not args.no_extras and first_host is not None and args.depth == "wgs":
+        from oracle import artifact_oracle as O  # the checker, never the product path
+        from tests.helpers import config_for
+        ints, floats, packed = first_host
+        n = min(2048, len(ints))
+        nref, nalt = ints[:, 0].astype(np.int64), ints[:, 1].astype(np.int64)
+        tr = int(nref.sum())
+        rows = np.concatenate([np.arange(int(nref[:n].sum())), tr + np.arange(int(nalt[:n].sum()))])
+        sub = Batch.from_arrays(ints[:n], floats[:n], packed[rows]).copy_to(dev)
+        model.train(False)
+        with torch.inference_mode():
+            out = model.compute_batch_output(sub)
+        sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        i64 = torch.from_numpy(ints[:n].astype(np.int64))
+        ref = O.compute_batch_output(sd, config_for("p0"), torch.from_numpy(O.decode_packed_reads(packed[rows]).astype(np.float32)),
+                                     i64[:, 0], i64[:, 1], torch.from_numpy(floats[:n, 6:].astype(np.float32)), i64[:, 16:])
+        parity = float((out.logits_b.cpu() - ref["logits_b"]).abs().max())
+        full = model.compute_batch_output(batches[0]) if batches else out
+        finite = bool(torch.isfinite(full.logits_b).all() and torch.isfinite(full.features_be).all()
+                      and torch.isfinite(eng.space.theta).all() and torch.isfinite(eng.space.gtheta).all())
+        if not finite or not parity < 1e-3:
+            raise SystemExit(f"bench: outputs diverge from the oracle (max |logit err| {parity}, finite {finite})")
+
     if rank == 0:
-        macs = algorithmic_macs_per_read(model)
-        fwd_flops = 2.0 * macs * reads_per_batch
-        if args.mode == "train":
-            dom, dom_flops = "pmt_backward_kernel", 2.0 * fwd_flops  # dgrad + wgrad; the in-kernel recompute is not counted
-            dom_ms = kernel_ms["pmt_backward"]
-        else:
-            dom, dom_flops, dom_ms = "pmt_forward_kernel", fwd_flops, kernel_ms["pmt_forward"]
-        achieved = dom_flops / (dom_ms * 1e-3) / 1e12
-        traffic = pmc_traffic(dom, args)
-        pad_ratio = algorithmic_macs_per_read(model, padded=True) / macs
+        head = "train" if "train" in results else "filter"
+        elapsed, roof = results[head]
         value = world * args.batch * args.steps / elapsed
         line = {
-            "metric": "read-sets/sec (train fwd+bwd)" if args.mode == "train" else "read-sets/sec (filter fwd)",
+            "metric": "read-sets/sec (train fwd+bwd)" if head == "train" else "read-sets/sec (filter fwd)",
             "value": value, "unit": "read-sets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic" if args.data == "resident" else "synthetic, streamed through the device chunk loader (H2D inclusive)",
-            "config": {"workload": ("train_model" if args.mode == "train" else "filter_variants forward")
+            "config": {"workload": ("train_model" if head == "train" else "filter_variants forward")
                        + f" on synthetic 1M-variant-scale {args.depth.upper()} ReadSet batches, hyperparameters P0 (59845 params)",
                        "batch_read_sets_per_gpu": args.batch, "mean_reads_per_set": reads_per_batch / args.batch,
                        "workgroups_per_batch": groups_per_batch,  # what a batch costs: rounds of 256 (backward) / 512 (forward)
-                       "step": "fwd + losses + bwd + grad all-reduce + clip + AdamW" if args.mode == "train" else "compute_batch_output under inference_mode",
-                       "parallelism": f"dp{world}" if world > 1 else "single"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "kernel": dom,
-                         "kernel_ms": dom_ms, "algorithmic_flops_per_launch": dom_flops,
-                         "matrix_pipe": "fp32-equivalent: forward / recompute / dgrad as six bf16 MFMAs on three-piece splits of both "
-                                        "operands, wgrad as exact fp32 MFMAs; `peak` is the dense fp32 MFMA rate",
-                         "padded_flops_per_launch": dom_flops * pad_ratio, "frac_padded": achieved * pad_ratio / PEAK_FP32_MFMA_TFLOPS,
-                         "hbm_frac": None if traffic is None else traffic / (dom_ms * 1e-3) / (PEAK_HBM_GBS * 1e9),
-                         "other_kernel_ms": {k: v for k, v in kernel_ms.items()}},
+                       "step": ("fwd + losses + bwd + bucketed grad all-reduce + clip + AdamW" if head == "train"
+                                else "compute_batch_output under inference_mode"),
+                       "parallelism": f"dp{world}" if world > 1 else "single", "kernels_sha": kernels_sha()},
+            "roofline": roof,
         }
+        if head == "train" and "filter" in results:
+            ef, rf = results["filter"]
+            line["filter"] = {"metric": "read-sets/sec (filter fwd)", "value": world * args.batch * args.steps / ef,
+                              "unit": "read-sets/s", "ms_per_step": 1e3 * ef / args.steps, "steps": args.steps,
+                              "step": "compute_batch_output under inference_mode, same resident batches", "roofline": rf}
+        if small is not None:
+            line["small_batch"] = small
+        if parity is not None:
+            line["parity_check_max_logit_err"] = parity
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.mode)
-        print(json.dumps(line))
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

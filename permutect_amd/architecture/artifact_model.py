@@ -155,7 +155,7 @@ class ArtifactModel(nn.Module):
         """[B, E_info + E_hap]: the per-variant part of every read's input (reference artifact_model.py:244-246).
         The info MLP is a HIP row kernel (pmt_rows_forward); requires packed weights to be current (see _encode)."""
         eng = self.engine()
-        info = RowsMlpFunction.apply(eng, L.ROWS_INFO, batch.get_info_be(), eng.trigger, 0.0)
+        info = RowsMlpFunction.apply(eng, L.ROWS_INFO, batch.get_info_be(), eng.trigger, None)
         hap = HaplotypeCnnFunction.apply(eng, batch.get_haplotypes_bs(), eng.trigger)
         return torch.hstack((info, hap))
 

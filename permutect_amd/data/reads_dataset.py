@@ -213,6 +213,10 @@ class ChunkBatch(Batch):
         self.reads_re = None
         self._num_read_features = 8 * NUMBER_OF_BYTES_IN_PACKED_READ + chunk.reads.shape[1] - NUMBER_OF_BYTES_IN_PACKED_READ
         self._size = len(ids_host)
+        # position of every variant of the batch in the dataset the loader iterates (its restricted folds): the loader orders
+        # the variants INSIDE a batch for the group packer even when it does not shuffle, so a consumer that needs the
+        # dataset's order (the posterior hand-off) scatters by this index
+        self.dataset_index = chunk.lo + np.asarray(ids_host, dtype=np.int64)
         self._host_counts = (chunk.ref_host[ids_host], chunk.alt_host[ids_host])
         self._plan = plan
         self._offsets = None

@@ -30,15 +30,33 @@ def _ceil16(n: int) -> int:
 class ParamSpace:
     """Flat parameter / gradient buffers with the model's Parameters re-bound as views."""
 
+    # Gradients become final in two waves during loss.backward(): the read-set kernel (pmt_backward) and the adversaries'
+    # row kernels finish every leaf they own first; the per-variant branches that autograd runs AFTER it (info MLP,
+    # haplotype CNN) and the parametrization adjoint (pmt_phi_backward, the last node of the graph) finish the rest.  The
+    # flat buffer is laid out in that order, [early | late], so that the data-parallel all-reduce of the early bucket can
+    # run on a side stream underneath the late kernels (training/distributed.py: BucketedGradAllReduce).
+    LATE_PREFIXES = ("info_embedding.", "haplotypes_cnn.")
+
+    @classmethod
+    def is_late(cls, name: str) -> bool:
+        return name.startswith(cls.LATE_PREFIXES) or name.endswith(".original")
+
     def __init__(self, module: nn.Module, device: torch.device):
-        params = [p for p in module.parameters()]
+        named = list(module.named_parameters())
+        named = [(n, p) for n, p in named if not self.is_late(n)] + [(n, p) for n, p in named if self.is_late(n)]
+        params = [p for _, p in named]
         self.offsets: Dict[int, int] = {}
         off = 0
-        for p in params:
+        self.late_start = None
+        for n, p in named:
             assert p.dtype == torch.float32, "the engine computes in fp32 (reference data/datum.py:37-38)"
+            if self.late_start is None and self.is_late(n):
+                self.late_start = off
             self.offsets[id(p)] = off
             off += (p.numel() + 3) // 4 * 4  # keep every tensor 16-byte aligned
         self.size = max(off, 4)
+        if self.late_start is None:
+            self.late_start = self.size
         self.theta = torch.zeros(self.size, dtype=torch.float32, device=device)
         self.gtheta = torch.zeros(self.size, dtype=torch.float32, device=device)
         self.params = params

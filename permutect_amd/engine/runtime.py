@@ -36,6 +36,7 @@ class ReadSetEngine:
         self.plan = EnginePlan(model, self.space, device)
         self.trigger = torch.zeros(1, dtype=torch.float32, device=device, requires_grad=True)  # see RowsMlpFunction
         self.timers = None  # bench.py sets {'pmt_forward': [], 'pmt_backward': []} to collect (start, end) HIP events
+        self.grad_hook = None  # data parallel: BucketedGradAllReduce, told when the early gradient bucket is final
 
     def _event_start(self):
         if self.timers is None:
@@ -143,6 +144,8 @@ class ReadSetEngine:
                                           C.byref(dout), stash.data_ptr(), self.space.gtheta.data_ptr(), gphi.data_ptr(),
                                           gvar.data_ptr(), _stream()), "pmt_backward")
         self._event_stop("pmt_backward", ev)
+        if self.grad_hook is not None:  # every leaf in [0, late_start) has its final gradient at this point of the stream
+            self.grad_hook.early(self.space.gtheta, self.space.late_start)
         return gphi, gvar
 
 
@@ -289,11 +292,12 @@ class RowsMlpFunction(torch.autograd.Function):
     """One of the per-variant row MLPs (pmt_rows_forward / pmt_rows_backward): info embedding, alt-count adversary,
     source adversary.  `x` is [N, in_dim] fp32 (any row stride); the result is [N, out_dim].  `trigger` is the engine's
     1-element leaf that makes autograd call backward even when x itself needs no gradient (the MLP's own parameters
-    live in the flat buffer and receive their gradients by atomics inside the kernel).  `reverse_alpha` > 0 applies the
-    reference's gradient reversal to d(x) (architecture/adversarial.py:23-27)."""
+    live in the flat buffer and receive their gradients by atomics inside the kernel).  `reverse_alpha`: None = d(x) passes
+    unchanged; a number (0.0 included: the source adversary's strength in epoch 1, reference model_training.py:92) applies
+    the reference's gradient reversal d(x) <- -alpha * d(x) (gradient_reversal/functional.py:18-22)."""
 
     @staticmethod
-    def forward(ctx, engine: ReadSetEngine, which: int, x: Tensor, trigger: Tensor, reverse_alpha: float):
+    def forward(ctx, engine: ReadSetEngine, which: int, x: Tensor, trigger: Tensor, reverse_alpha: Optional[float]):
         lib, d = engine.lib, engine.plan.desc
         mlp = d.row_mlp[which]
         n = x.shape[0]
@@ -326,7 +330,7 @@ class RowsMlpFunction(torch.autograd.Function):
             d_out = d_out.float().contiguous()
         n = x.shape[0]
         d_in = torch.empty_like(x) if ctx.x_needs_grad else None
-        scale = -ctx.alpha if ctx.alpha else 1.0
+        scale = 1.0 if ctx.alpha is None else -float(ctx.alpha)
         L.check(eng.lib.pmt_rows_backward(C.byref(d), eng.plan.desc_dev.data_ptr(), ctx.which, eng.space.theta.data_ptr(),
                                           eng.plan.packed.data_ptr(), x.data_ptr(), x.stride(0), n, d_out.data_ptr(),
                                           d_out.stride(0), stash.data_ptr(), eng.space.gtheta.data_ptr(), _ptr(d_in),

@@ -45,8 +45,10 @@ def make_posterior_mmap(dataset: ReadsDataset, model, batch_size: int, device: O
         out = model.compute_batch_output(batch)
         ints, floats = posterior_rows(batch.int_tensor, batch.float_tensor, out.logits_b, out.features_be)
         b = batch.size()
-        ints_out[done:done + b] = ints.cpu().numpy()
-        floats_out[done:done + b] = floats.cpu().numpy()
+        # the loader packs the variants of a batch in the order that fills the workgroups (also without shuffling):
+        # rows go back to their place in the dataset
+        ints_out[batch.dataset_index] = ints.cpu().numpy()
+        floats_out[batch.dataset_index] = floats.cpu().numpy()
         done += b
     assert done == n
     result = MemoryMappedData(ints_out, floats_out, n, None, 0)

@@ -3,10 +3,14 @@
 The reference has no distributed code at all; the semantics implemented here are fixed in
 SURVEY.md section 8e:
   * filter_variants: the candidate index range is cut into `world` contiguous shards; no collective.
-  * training: every rank runs forward/backward on its own batch, then ONE all-reduce (SUM) of the flat gradient buffer
-    (about 240 KB at P0: latency-bound, so a single bucket), then the identical clip + AdamW on every rank.  SUM, not
-    mean, because the reference's total_loss is a batch sum (artifact_model.py:90): N ranks with batch B are exactly one
-    process with batch N*B.
+  * training: every rank runs forward/backward on its own batch; the flat gradient buffer (about 240 KB at P0) is
+    all-reduced (SUM) in TWO buckets, then the identical clip + AdamW runs on every rank.  SUM, not mean, because the
+    reference's total_loss is a batch sum (artifact_model.py:90): N ranks with batch B are exactly one process with
+    batch N*B.  The buffer is laid out [early | late] (engine/plan.py: ParamSpace): the early bucket (every leaf the
+    read-set backward kernel and the adversaries' row kernels own, ~93 % of the parameters) is final as soon as
+    pmt_backward has been enqueued and is reduced on a side stream UNDERNEATH the kernels autograd still has to run
+    (haplotype-CNN backward ~1 ms, info-MLP backward, parametrization adjoint); the late bucket follows on the main
+    stream.  Order per step (reference misc_utils.py:125-129): backward -> reduce -> clip -> step.
   * per-epoch decisions (lr scheduler input, checkpoint rollback) use all-reduced loss statistics, decided on rank 0 and
     broadcast.
 """
@@ -34,6 +38,56 @@ class GradAllReduce:
     def __call__(self, flat_grad: torch.Tensor) -> None:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+
+
+class BucketedGradAllReduce:
+    """The overlapped form of `GradAllReduce` for a flat buffer laid out [early | late]:
+
+        hook = BucketedGradAllReduce(group);  engine.grad_hook = hook        # ReadSetEngine.backward calls hook.early(...)
+        optimizer.step(pre_reduce=hook)                                      # reduces the rest and joins
+
+    `early(flat, late_start)` is called right after the read-set backward kernel has been enqueued: flat[:late_start] is
+    final from that point of the stream on, and its all-reduce is issued on a side stream that waits for exactly that
+    point.  `__call__(flat)` (the optimizer's pre-reduce hook, after loss.backward() has returned) reduces
+    flat[late_start:] and makes the current stream wait for both.  The sum of the two bucket reductions is the flat SUM
+    all-reduce (tests/test_distributed_cpu.py).  Without a call to `early` since the last step (no read-set backward ran,
+    e.g. an empty batch) the whole buffer is reduced in one piece.  Works on CPU tensors (gloo) without streams."""
+
+    def __init__(self, group: Optional[dist.ProcessGroup] = None):
+        self.group = group
+        self._pending = None   # (work, late_start)
+        self._side = None
+
+    def _active(self) -> bool:
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def early(self, flat_grad: torch.Tensor, late_start: int) -> None:
+        if not self._active() or late_start <= 0 or self._pending is not None:
+            return
+        bucket = flat_grad[:late_start]
+        if flat_grad.is_cuda:
+            if self._side is None:
+                self._side = torch.cuda.Stream(flat_grad.device)
+            self._side.wait_stream(torch.cuda.current_stream(flat_grad.device))  # the read-set gradients are final here
+            with torch.cuda.stream(self._side):
+                work = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            work = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending = (work, late_start)
+
+    def __call__(self, flat_grad: torch.Tensor) -> None:
+        if not self._active():
+            return
+        if self._pending is None:
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        work, late_start = self._pending
+        self._pending = None
+        if late_start < flat_grad.numel():
+            dist.all_reduce(flat_grad[late_start:], op=dist.ReduceOp.SUM, group=self.group)
+        work.wait()  # CUDA: the current stream waits for the side-stream reduction; CPU: blocks
+        if flat_grad.is_cuda:
+            torch.cuda.current_stream(flat_grad.device).wait_stream(self._side)
 
 
 def all_reduce_sum_(t: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:

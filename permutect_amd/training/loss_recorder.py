@@ -68,9 +68,21 @@ class LossRecorder:
         """reference loss_metrics.py:56-57"""
         return self.totals(metric) / (0.001 + self.counts(metric))
 
+    def marginal_by_label(self, metric: int = PRIMARY):
+        """(totals_l, counts_l): the histograms summed over every axis but the label's (reference
+        metrics/loss_metrics.py:59-60 `get_marginal(BatchProperty.LABEL)` is their quotient)."""
+        return self.totals(metric).sum(dim=(0, 2, 3, 4)), self.counts(metric).sum(dim=(0, 2, 3, 4))
+
     def mean_loss(self, metric: int = PRIMARY) -> float:
-        """total / count over all bins: what the training loop feeds its LR scheduler (reference model_training.py:170)."""
-        return float((self.totals(metric).sum() / self.counts(metric).sum().clamp_min(1e-12)).item())
+        """What the training loop feeds its LR scheduler and its checkpoint decisions (reference model_training.py:170,198):
+        the UNWEIGHTED mean over labels of each label's average loss, `torch.mean(get_marginal(LABEL))` -- not the pooled
+        total / count, which follows the most frequent label.  Deviation, on purpose: a label without any data makes the
+        reference's quotient 0 / 0 = NaN (its scheduler and checkpoint then stop working for the whole run); here the
+        mean runs over the labels that have data."""
+        totals_l, counts_l = self.marginal_by_label(metric)
+        present = counts_l > 0
+        per_label = torch.where(present, totals_l / counts_l.clamp_min(1e-30), torch.zeros_like(totals_l))
+        return float((per_label.sum() / present.sum().clamp_min(1)).item())
 
     def all_reduce(self, dist):
         """Sum the histograms over data-parallel ranks before the epoch-level decisions."""

@@ -19,7 +19,7 @@ from permutect_amd.data.reads_dataset import ReadsDataset
 from permutect_amd.enums import Epoch
 from permutect_amd.parameters import TrainingParameters
 from permutect_amd.training.balancer import Balancer
-from permutect_amd.training.distributed import GradAllReduce
+from permutect_amd.training.distributed import BucketedGradAllReduce, rank0_decides
 from permutect_amd.training.downsampler import Downsampler
 from permutect_amd.training.loss_recorder import PRIMARY, LossRecorder
 from permutect_amd.training.optimizer import FusedClipAdamW, backpropagate
@@ -57,13 +57,19 @@ class Checkpoint:
             self.state = self.model.engine().space.theta.detach().clone()
             self.opt_state = self.opt.state_dict()
 
+    def should_roll_back(self, loss: float) -> bool:
+        return self.state is not None and (not math.isfinite(loss) or loss > 2 * self.best_loss)
+
+    def load_checkpoint(self) -> bool:
+        if self.state is None:
+            return False
+        with torch.no_grad():
+            self.model.engine().space.theta.copy_(self.state)
+        self.opt.load_state_dict(self.opt_state)  # moments, step count and learning rate (reference checkpoint.py:29-31)
+        return True
+
     def load_checkpoint_if_needed(self, loss: float):
-        if self.state is not None and (not math.isfinite(loss) or loss > 2 * self.best_loss):
-            with torch.no_grad():
-                self.model.engine().space.theta.copy_(self.state)
-            self.opt.load_state_dict(self.opt_state)
-            return True
-        return False
+        return self.should_roll_back(loss) and self.load_checkpoint()
 
 
 def train_artifact_model(model, train_dataset: ReadsDataset, valid_dataset: Optional[ReadsDataset],
@@ -81,7 +87,12 @@ def train_artifact_model(model, train_dataset: ReadsDataset, valid_dataset: Opti
     opt = FusedClipAdamW(model, lr=training_params.learning_rate, weight_decay=training_params.weight_decay)
     scheduler = PlateauScheduler(opt, min_lr=training_params.learning_rate / 100)
     checkpoint = Checkpoint(model, opt)
-    reduce_grads = GradAllReduce() if dist is not None else None
+    reduce_grads = None
+    if dist is not None:
+        # replicas start from rank 0's weights (reset_source_predictor drew fresh ones from every rank's own generator)
+        dist.broadcast(model.engine().space.theta, src=0)
+        reduce_grads = BucketedGradAllReduce()
+        model.engine().grad_hook = reduce_grads  # early bucket: reduced on a side stream under the rest of the backward
     rng = np.random.default_rng(seed + rank)
     history = []
     last_epoch = training_params.num_epochs + training_params.num_calibration_epochs
@@ -123,6 +134,8 @@ def train_artifact_model(model, train_dataset: ReadsDataset, valid_dataset: Opti
                             model.engine().space.gtheta.zero_()
                             model.engine().space.bind_grads()
                             losses.total_loss.backward()
+                            if reduce_grads is not None:  # same order as the main step: backward -> reduce -> clip -> step
+                                reduce_grads(model.engine().space.gtheta)
                             torch.nn.utils.clip_grad_norm_(model.calibration_parameters(), max_norm=1.0)
                             cal_opt.step()
                         else:
@@ -138,6 +151,9 @@ def train_artifact_model(model, train_dataset: ReadsDataset, valid_dataset: Opti
                 scheduler.step(mean_loss)
                 if not is_calibration:
                     checkpoint.save_checkpoint_if_needed(epoch, mean_loss)
-                    if checkpoint.load_checkpoint_if_needed(mean_loss):
+                    rollback = checkpoint.should_roll_back(mean_loss)
+                    if dist is not None:  # the statistics were all-reduced, so the ranks agree; rank 0's word makes it certain
+                        rollback = rank0_decides(rollback, device)
+                    if rollback and checkpoint.load_checkpoint():
                         log(f"epoch {epoch}: loss diverged, restored the best checkpoint")
     return history

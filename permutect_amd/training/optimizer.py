@@ -52,13 +52,17 @@ class FusedClipAdamW:
                 "pmt_clip_adamw")
 
     def state_dict(self):
-        return {"step": self.step_count, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone()}
+        self._bind()
+        return {"step": self.step_count, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
+                "param_groups": [dict(g) for g in self.param_groups]}  # torch optimizers keep lr / weight decay here too
 
     def load_state_dict(self, state):
         self._bind()
         self.step_count = state["step"]
         self.exp_avg.copy_(state["exp_avg"])
         self.exp_avg_sq.copy_(state["exp_avg_sq"])
+        for g, saved in zip(self.param_groups, state.get("param_groups", [])):
+            g.update(saved)
 
 
 def backpropagate(optimizer, loss: torch.Tensor, params_to_clip=()):

@@ -66,12 +66,19 @@ def test_posterior_handoff_matches_per_datum_semantics():
     ds = _dataset()
     torch.manual_seed(0)
     model = ArtifactModel(p0_params(), device=dev, **P0_DIMS)
-    post = make_posterior_mmap(ds, model, batch_size=16, chunk_variants=20)
+    # one batch of all 41 variants: the loader's group packer reorders the variants inside it (also without shuffling),
+    # the rows must come back in dataset order all the same
+    reordered = [not np.all(np.diff(cb.dataset_index) > 0) for cb in ds.device_loader(64, dev, shuffle=False)]
+    assert any(reordered)
+    post = make_posterior_mmap(ds, model, batch_size=64)
+    post16 = make_posterior_mmap(ds, model, batch_size=16, chunk_variants=20)  # (batches the packer leaves in order)
+    np.testing.assert_array_equal(post.int_mmap[:len(ds)], post16.int_mmap[:len(ds)])
+    np.testing.assert_allclose(post.float_mmap[:len(ds)], post16.float_mmap[:len(ds)], rtol=1e-5, atol=2e-3)
     assert len(post) == len(ds) and post.reads_mmap is None and post.num_reads == 0
     with torch.no_grad():
         out = model.compute_batch_output(ds.host_batch(np.arange(len(ds))).copy_to(dev))
     logits, feats = out.logits_b.cpu().numpy(), out.features_be.cpu().numpy()
-    for i in (0, 5, 17, len(ds) - 1):
+    for i in range(len(ds)):
         d = Datum(np.array(ds._ints[i]), np.array(ds._floats[i]), np.zeros((0, 12), dtype=np.uint8), compressed=True)
         d.set(Data.REF_COUNT, 0)
         d.set(Data.ALT_COUNT, 0)

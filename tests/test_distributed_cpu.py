@@ -9,7 +9,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import artifact_oracle as O
-from permutect_amd.training.distributed import GradAllReduce, rank0_decides, shard_range
+from permutect_amd.training.distributed import BucketedGradAllReduce, GradAllReduce, rank0_decides, shard_range
 from tests.helpers import config_for, load_case
 
 
@@ -71,3 +71,41 @@ def test_two_rank_step_equals_single_process_full_batch():
     ref_after = np.concatenate([z["after/" + n].ravel() for n in names])
     assert np.abs(r0["params"].numpy() - ref_after).max() <= 0.02 * 1e-3
     assert r0["decision"] is True and r1["decision"] is True  # rank 0's flag wins everywhere
+
+
+def _bucket_worker(rank, world, init_file, result_file):
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(59848, generator=g)
+    want = flat.clone()
+    GradAllReduce()(want)                                   # the flat SUM all-reduce
+    out = {}
+    for late_start in (0, 1, 55000, 59848):                 # empty early bucket, tiny, the real split, empty late bucket
+        hook = BucketedGradAllReduce()
+        got = flat.clone()
+        hook.early(got, late_start)                         # (what ReadSetEngine.backward does after pmt_backward)
+        got[late_start:] += 0.0                             # the late kernels still write behind the early bucket
+        hook(got)                                           # (what FusedClipAdamW.step(pre_reduce=hook) does)
+        out[late_start] = torch.equal(got, want)
+    hook = BucketedGradAllReduce()
+    got = flat.clone()
+    hook(got)                                               # no early() since the last step: one flat reduction
+    out["flat"] = torch.equal(got, want)
+    got2 = flat.clone()
+    hook.early(got2, 55000)
+    hook.early(got2, 55000)                                 # a second backward before the step does not reduce twice
+    hook(got2)
+    out["twice"] = torch.equal(got2, want)
+    torch.save(out, f"{result_file}.{rank}")
+    dist.destroy_process_group()
+
+
+def test_bucketed_all_reduce_equals_flat_sum():
+    """The overlapped two-bucket hook's arithmetic: early bucket + late bucket == one flat SUM all-reduce, bit for bit
+    (a SUM all-reduce of a slice is the slice of the SUM all-reduce), for every split point and on both ranks."""
+    with tempfile.TemporaryDirectory() as d:
+        init_file, result_file = os.path.join(d, "init"), os.path.join(d, "res")
+        mp.spawn(_bucket_worker, args=(2, init_file, result_file), nprocs=2, join=True)
+        for r in range(2):
+            res = torch.load(result_file + f".{r}")
+            assert all(res.values()), res

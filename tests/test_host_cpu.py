@@ -202,3 +202,37 @@ def test_packed_batch_is_the_same_batch_reordered():
     for i, v in enumerate(o):
         assert torch.equal(packed.packed_reads[pr0[i]:pr0[i + 1]], plain.packed_reads[r0[v]:r0[v + 1]])
         assert torch.equal(packed.packed_reads[pa0[i]:pa0[i + 1]], plain.packed_reads[a0[v]:a0[v + 1]])
+
+
+def test_flat_parameter_space_is_laid_out_early_then_late():
+    """engine/plan.py: ParamSpace orders the flat buffer [early | late] for the overlapped data-parallel reduction: every
+    leaf whose gradient the per-variant kernels or the parametrization adjoint finish AFTER the read-set backward (info
+    MLP, haplotype CNN, `.original` leaves) lies behind `late_start`; everything else in front of it."""
+    from permutect_amd.engine.plan import ParamSpace
+    torch.manual_seed(0)
+    model = ArtifactModel(p0_params(), device=torch.device("cpu"), **P0_DIMS)
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    space = ParamSpace(model, torch.device("cpu"))
+    assert 0 < space.late_start < space.size
+    for n, p in model.named_parameters():
+        off = space.offset_of(p)
+        late = n.startswith(("info_embedding.", "haplotypes_cnn.")) or n.endswith(".original")
+        assert (off >= space.late_start) == late, n
+        assert torch.equal(p.detach(), before[n])            # re-binding into the flat buffer keeps the values
+        assert p.data_ptr() == space.theta.data_ptr() + 4 * off
+    early_params = sum(p.numel() for n, p in model.named_parameters() if not ParamSpace.is_late(n))
+    assert early_params > 0.75 * sum(p.numel() for p in model.parameters())  # the bucket that overlaps is the big one
+
+
+def test_mean_loss_is_the_unweighted_mean_over_labels():
+    """reference model_training.py:170 feeds the scheduler torch.mean(get_marginal(LABEL)): each label's average loss,
+    averaged over labels -- not the pooled total / count."""
+    from permutect_amd.training.loss_recorder import PRIMARY, LossRecorder
+    rec = LossRecorder(torch.device("cpu"), num_sources=1)
+    tot, cnt = rec.totals(PRIMARY), rec.counts(PRIMARY)
+    tot[0, 0, 0, 1, 1], cnt[0, 0, 0, 1, 1] = 30.0, 10.0      # label 0: average 3
+    tot[0, 0, 1, 2, 0], cnt[0, 0, 1, 2, 0] = 10.0, 10.0      # label 0 again: pooled average (30 + 10) / 20 = 2
+    tot[0, 1, 0, 0, 0], cnt[0, 1, 0, 0, 0] = 8.0, 1.0        # label 1: average 8 on a single variant
+    assert abs(rec.mean_loss() - (2.0 + 8.0) / 2) < 1e-6       # label 2 has no data: left out (the reference gives NaN)
+    tot[0, 2, 0, 0, 0], cnt[0, 2, 0, 0, 0] = 5.0, 5.0
+    assert abs(rec.mean_loss() - (2.0 + 8.0 + 1.0) / 3) < 1e-6

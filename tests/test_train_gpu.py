@@ -308,3 +308,40 @@ def test_random_mixed_batches_match_oracle(seed):
     ref_total = ref_losses["total_losses_b"].detach().numpy()
     np.testing.assert_allclose(losses.total_losses_b.detach().cpu().numpy(), ref_total, rtol=1e-4, atol=1e-4 + 1e-5 * np.abs(ref_total).max())
     _compare_gradients(model, {k: v.numpy() for k, v in ref_grads.items()})
+
+
+def test_zero_adversarial_strength_sends_no_gradient_upstream():
+    """Epoch 1 of train_artifact_model sets the source adversary's strength to 2 / (1 + e^0) - 1 = 0 (reference
+    training/model_training.py:92); GradientReversal then returns -0 * g = 0 to the features (reference
+    gradient_reversal/functional.py:18-22) while the adversary's own parameters still learn.  `None` (the info MLP) passes
+    the gradient through unchanged."""
+    from permutect_amd.engine import lib as L
+    from permutect_amd.engine.runtime import RowsMlpFunction
+    z, sd, b = load_case("t0_two_sources")
+    model, dev = build("t0_two_sources", sd)
+    model.train(True)
+    eng = model.engine()
+    eng.pack(eng.plan.materialize_phi(model).detach().contiguous())
+    torch.manual_seed(5)
+    feats = torch.randn(24, model.reducer.output_dimension(), device=dev)
+    grads = {}
+    for alpha in (0.0, 0.3, None):
+        which = L.ROWS_SOURCE if alpha is not None else L.ROWS_INFO
+        x = feats if alpha is not None else torch.randn(24, model.info_embedding.input_dimension(), device=dev)
+        leaf = x.clone().requires_grad_(True)
+        eng.space.gtheta.zero_()
+        out = RowsMlpFunction.apply(eng, which, leaf, eng.trigger, alpha)
+        out.square().sum().backward()
+        torch.cuda.synchronize()
+        grads[alpha] = (leaf.grad.clone(), eng.space.gtheta.clone())
+    assert torch.count_nonzero(grads[0.0][0]) == 0               # nothing flows upstream at strength 0
+    assert torch.count_nonzero(grads[0.0][1]) > 0                # ... but the adversary's parameters get their gradient
+    assert torch.allclose(grads[0.0][1], grads[0.3][1])          # (which does not depend on the strength)
+    assert torch.count_nonzero(grads[0.3][0]) > 0
+    assert torch.count_nonzero(grads[None][0]) > 0               # no reversal: the plain input gradient
+    # reversal at 0.3 == -0.3 x the un-reversed gradient of the same head
+    leaf = feats.clone().requires_grad_(True)
+    out = RowsMlpFunction.apply(eng, L.ROWS_SOURCE, leaf, eng.trigger, None)
+    out.square().sum().backward()
+    torch.cuda.synchronize()
+    assert torch.allclose(grads[0.3][0], -0.3 * leaf.grad, rtol=1e-6, atol=1e-7)
