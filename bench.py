@@ -36,6 +36,15 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+_T0 = time.perf_counter()
+
+
+def note(msg):
+    """Progress on stderr (rank 0): the JSON line stays alone on stdout, and a long CPU leg never looks like a hang."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_HBM_GBS = 8000.0
 
@@ -153,28 +162,60 @@ def _oracle_rate(mode, b, threads, seconds, min_steps=2):
     return b * n / (time.perf_counter() - t0), n
 
 
+def usable_cpus():
+    """Host threads this process can really run at once: the smallest of the machine's cores, its affinity mask and its
+    cgroup CPU quota (a GPU box hands a job a share of a 128-core host; OpenMP teams wider than that share spin on each
+    other and a step takes minutes)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                quota = int(parts[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = int(f.read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+        except (OSError, ValueError, IndexError):
+            pass
+    return min(n, 64)
+
+
 def cpu_baseline():
     """The reference path as restated by oracle/artifact_oracle.py on the host cores.  ~18 000 small ATen ops per step do not
     scale with threads (128 threads on them is oversubscription), so the thread count is swept on the B = 8192 train step and
     the best one is used for the other three points.  Bounded: about 25 s of CPU work in all."""
-    ncores = os.cpu_count() or 1
+    ncores = usable_cpus()
     before = torch.get_num_threads()
     candidates = sorted({t for t in (4, 8, 16, 32, 64, ncores) if t <= ncores})
     sweep = {}
     for t in candidates:
         sweep[t], _ = _oracle_rate("train", 8192, t, seconds=1.0)
+        note(f"cpu baseline: train B=8192 on {t} threads: {sweep[t]:.0f} read-sets/s")
+        if sweep[t] < 0.6 * max(sweep.values()):  # past the knee more threads only add hand-off cost (and, beyond the
+            break                                  # process's CPU share, spinning OpenMP workers that crawl)
     best = max(sweep, key=sweep.get)
     train8k, n1 = _oracle_rate("train", 8192, best, seconds=5.0)
     filt8k, n2 = _oracle_rate("filter", 8192, best, seconds=3.0)
+    note(f"cpu baseline: B=8192 on {best} threads: train {train8k:.0f}, filter {filt8k:.0f} read-sets/s")
     t64 = min(best, 8)  # 812 reads per step: more threads only add hand-off cost
     train64, n3 = _oracle_rate("train", 64, t64, seconds=3.0, min_steps=10)
     filt64, n4 = _oracle_rate("filter", 64, t64, seconds=2.0, min_steps=10)
+    note(f"cpu baseline: B=64 on {t64} threads: train {train64:.0f}, filter {filt64:.0f} read-sets/s")
     torch.set_num_threads(before)
     reads = _oracle_problem(8192)[4]
     return {"value": train8k, "unit": "read-sets/s", "cores": best, "kind": "port",
             "sample": f"{n1} train steps of B=8192 WGS-shaped read sets ({reads} reads), P0, fp32, oracle/artifact_oracle.py "
                       f"(PyTorch-CPU restatement of the reference path, fwd + losses + autograd bwd + clip + AdamW); thread "
-                      f"count swept over {candidates} of {ncores} host cores, best = {best}",
+                      f"count swept over {sorted(sweep)} (usable host threads: {ncores} of {os.cpu_count()} cores), best = {best}",
             "host_cores": ncores, "thread_sweep_train_b8192": {str(k): v for k, v in sweep.items()},
             "filter": {"value": filt8k, "unit": "read-sets/s", "cores": best, "sample": f"{n2} forwards of B=8192 under inference_mode"},
             "b64": {"train": train64, "filter": filt64, "unit": "read-sets/s", "cores": t64,
@@ -292,6 +333,7 @@ def main():
                         yield cb
         stream_batches = endless()
     torch.cuda.synchronize()
+    note(f"{len(batches)} resident batches of {args.batch} read sets built")
 
     def train_step(batch):
         opt.zero_grad()
@@ -352,11 +394,13 @@ def main():
                             "splits of both operands, wgrad as three bf16 MFMAs on two-piece splits; `peak` is the dense fp32 MFMA rate")
         r["other_kernel_ms"] = kms
         results["train"] = (elapsed, r)
+        note(f"train: {1e3 * elapsed / args.steps:.3f} ms/step, kernels {kms}")
     if args.mode in ("both", "filter"):
         if stream_batches is not None:
             loader_shuffle[0] = False
         elapsed, kms = timed("filter", batches, args.steps, args.warmup)
         results["filter"] = (elapsed, roofline("pmt_forward_kernel", fwd_flops, kms["pmt_forward"]))
+        note(f"filter: {1e3 * elapsed / args.steps:.3f} ms/step, kernels {kms}")
 
     # ---- the reference's default batch sizes beside the build's best: N = 1, resident batches only ------------
     small = None
@@ -371,6 +415,7 @@ def main():
                 pool.append(b.copy_to(dev))
             et, _ = timed("train", pool, k, 10)
             ef, _ = timed("filter", pool, k, 10)
+            note(f"B={bsz}: train {1e3 * et / k:.3f} ms/step, filter {1e3 * ef / k:.3f} ms/step")
             small[f"b{bsz}"] = {"train_read_sets_per_s": bsz * k / et, "train_ms_per_step": 1e3 * et / k,
                                 "filter_read_sets_per_s": bsz * k / ef, "filter_ms_per_step": 1e3 * ef / k}
 
@@ -393,6 +438,7 @@ def main():
         ref = O.compute_batch_output(sd, config_for("p0"), torch.from_numpy(O.decode_packed_reads(packed[rows]).astype(np.float32)),
                                      i64[:, 0], i64[:, 1], torch.from_numpy(floats[:n, 6:].astype(np.float32)), i64[:, 16:])
         parity = float((out.logits_b.cpu() - ref["logits_b"]).abs().max())
+        note(f"parity: max |logit - oracle| over {n} variants = {parity:.3e}")
         full = model.compute_batch_output(batches[0]) if batches else out
         finite = bool(torch.isfinite(full.logits_b).all() and torch.isfinite(full.features_be).all()
                       and torch.isfinite(eng.space.theta).all() and torch.isfinite(eng.space.gtheta).all())

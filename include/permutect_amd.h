@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PMT_ABI_VERSION 2
+#define PMT_ABI_VERSION 3
 
 /* error codes */
 #define PMT_OK 0
@@ -76,6 +76,12 @@ typedef struct PmtLinear {
     int32_t wb_frag;     /* packed: W as THREE bf16 pieces (hi + mid + lo = the fp32 value) in the operand order of
                             v_mfma_f32_16x16x32_bf16: [k block of 32][out tile][piece][lane][8 bf16]; -1 = none */
     int32_t wtb_frag;    /* the same for W^T                                                                   */
+    int32_t emit_tab;    /* packed (read as int32): where the weight-gradient blocks of this linear go.  For every 16 x 16
+                            block (out tile ot, in tile it) of dW in the matrix core's C layout, [(ot * nkt + it)][lane][4]
+                            element offsets into the buffer w_src names (theta, or phi when w_src <= -2), -1 = padding;
+                            then per out tile 16 offsets of the bias gradient in position order (theta), -1 = none.
+                            Written by pmt_pack_params; lets pmt_backward add a block with four atomics and no index
+                            arithmetic.  -1 = none                                                                */
 } PmtLinear;
 
 typedef struct PmtStage {

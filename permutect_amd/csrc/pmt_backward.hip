@@ -31,7 +31,9 @@ struct BwdShared {
     float aux[PMT_WAVES][PMT_AUX_CAP];                          // small-parameter gradient slabs (BwdCtx.aux)
     int aux_dst[PMT_AUX_CAP];
     f4 stage[PMT_STAGE_PLANES * 64];                            // weight-gradient operand exchange (BwdCtx.stage)
+    float pf_sink[64];                                          // where stash_prefetch's LDS-DMA drops its dwords (never read)
 };
+
 static_assert(sizeof(BwdShared) <= 160 * 1024, "LDS budget");
 
 DEV float read_feature_b(const unsigned char* __restrict__ row, int fmt, int f, int F) {
@@ -46,13 +48,18 @@ DEV float read_feature_b(const unsigned char* __restrict__ row, int fmt, int f, 
     return reinterpret_cast<const float*>(row)[f];
 }
 
+// The backward walks a tile's stash slots from the last to the first, each slot an HBM miss (the forward wrote them gigabytes
+// ago).  `sink` != nullptr: while slot `slot` is loaded, slot - 1 -- the next one the walk needs -- is touched into L2.
 template <int NT>
-DEV void load_slot_tiles(const float* const (&stash_tile)[PMT_RT], unsigned mask, int slot, f4 (&v)[PMT_RT][NT]) {
+DEV void load_slot_tiles(const float* const (&stash_tile)[PMT_RT], unsigned mask, int slot, f4 (&v)[PMT_RT][NT], float* sink = nullptr) {
 #pragma unroll
     for (int rt = 0; rt < PMT_RT; ++rt) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) v[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
-        if (mask & (1u << rt)) stash_load<NT>(stash_tile[rt] + slot * PMT_SLOT_FLOATS, v[rt]);
+        if (mask & (1u << rt)) {
+            stash_load<NT>(stash_tile[rt] + slot * PMT_SLOT_FLOATS, v[rt]);
+            if (sink != nullptr && slot > 0) stash_prefetch(stash_tile[rt] + (slot - 1) * PMT_SLOT_FLOATS, sink);
+        }
     }
 }
 
@@ -126,11 +133,16 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         tm[rt] = tile_meta(gg, rt, &sh.off[0][0]);
         if (tm[rt].present) mask_all |= 1u << rt;
         stash_tile[rt] = stash + (size_t)(bt.group_tile_base[blockIdx.x] + gg.tile_begin + rt) * (size_t)(nslots * PMT_SLOT_FLOATS);
+        if (bt.debug_flags && (uniform(bt.debug_flags[1]) & 256)) stash_tile[rt] = stash + (size_t)rt * (size_t)(nslots * PMT_SLOT_FLOATS);  // timing experiment: every read hits L2
     }
     BwdCtx c{M, theta, phi, packed, gtheta, gphi, &sh.stage[0], &sh.aux[0][0], &sh.aux_dst[0], g, mask_all,
              gg.tile_begin, gg.ntiles, gg.tiles_ref, 0,
              bt.debug_flags ? uniform(bt.debug_flags[1]) : 0,
              bt.debug_flags ? reinterpret_cast<unsigned long long*>(bt.debug_flags + 8) : nullptr};
+    c.wr = gg.wr;
+    c.wbase = stage_wbase(lane);
+    c.rbase = stage_rbase(lane);
+    c.pf_sink = (c.dbg & 64) ? &sh.pf_sink[0] : nullptr;  // stash prefetch: OFF (measured slower, see DESIGN)
     const unsigned long long t_kernel0 = prof_now();
     // a read set split over several groups is OWNED by the group that holds its first alt read: per-set terms are added once
     auto owns = [&](int set) { return !LAYERED || (sh.off[1][set] >= 0 && sh.off[1][set] < gg.nalt); };
@@ -163,7 +175,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         f4 e[PMT_RT][NTE];  // reducer output, then + translation (the rotation's input)
         {
             f4 r[PMT_RT][NTD];
-            load_slot_tiles<NTD>(stash_tile, mask_all, slot_last_in, r);
+            load_slot_tiles<NTD>(stash_tile, mask_all, slot_last_in, r, c.pf_sink);
             if constexpr (EX) {
                 const PmtLinear& Lr = M->lin[uniform(red_last.lin[0])];
                 init_bias<NTE>(e, uniform(Lr.b_pvec) >= 0 ? packed + uniform(Lr.b_pvec) : nullptr, E, g);
@@ -326,18 +338,18 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
                 }
             }
             if (k >= 0) {  // every wave pushes (zeros from a ref wave): the slab layout is workgroup-uniform
-                aux_push_vec<NTE>(c, enc_phi(uniform(M->head.dirs_ke_phi) + k * E), dvk, E);
+                aux_push_vec_x<NTE, EX>(c, enc_phi(uniform(M->head.dirs_ke_phi) + k * E), dvk, E);
                 aux_push_scalar(c, enc_phi(uniform(M->head.art_stdev_k_phi) + k), d_tau);
                 aux_push_scalar(c, uniform(M->head.mu_k_src) + k, d_mu);
                 aux_push_scalar(c, enc_phi(uniform(M->head.lambda_k_phi) + k), d_lam);
                 aux_push_scalar(c, enc_phi(uniform(M->head.sigma_k_phi) + k), d_sg);
             }
         }
-        aux_push_vec<NTE>(c, enc_phi(uniform(M->head.stdev_e_phi)), dsig, E);
+        aux_push_vec_x<NTE, EX>(c, enc_phi(uniform(M->head.stdev_e_phi)), dsig, E);
         prof_add(c, 4, t_kernel0);
         unsigned long long t_rot = prof_now();
         // ---- rotation + translation backward: a = Q (e + t) ------------------------------------------------------------
-        linear_wgrad<NTE, NTE>(c, R, da, e);
+        linear_wgrad<NTE, NTE, S::BF16>(c, R, da, e);
         f4 de[PMT_RT][NTE];
         init_bias<NTE>(de, nullptr, E, g);
         if constexpr (S::BF16) linear_acc_bf16<NTE, NTE, false>(de, da, packed + uniform(R.wtb_frag));
@@ -349,7 +361,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) dt[t] = dt[t] + de[rt][t];
         }
-        aux_push_vec<NTE>(c, uniform(M->translation_src), dt, E);
+        aux_push_vec_x<NTE, EX>(c, uniform(M->translation_src), dt, E);
         prof_add(c, 5, t_rot);
         // ---- last reducer op ------------------------------------------------------------------------------------------
         if constexpr (EX) {
@@ -368,7 +380,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
     // ---- reducer backward ---------------------------------------------------------------------------------------------
     if (!(LAYERED && lay.slice > 0))
     mlp_backward<NTD, EX, S::DIM_D, S::BF16>(c, M->reducer, dy, true,
-                          [&](int op, f4 (&x)[PMT_RT][NTD]) { load_slot_tiles<NTD>(stash_tile, mask_all, op == 0 ? slot_x0 + L : slot_red + op - 1, x); },
+                          [&](int op, f4 (&x)[PMT_RT][NTD]) { load_slot_tiles<NTD>(stash_tile, mask_all, op == 0 ? slot_x0 + L : slot_red + op - 1, x, c.pf_sink); },
                           0, EX ? n_red_ops - 1 : n_red_ops);
 
     prof_add(c, 6, t_ph);
@@ -388,12 +400,15 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt) xs[rt] = stash_tile[rt] + (slot_x0 + l) * PMT_SLOT_FLOATS;
         // n[rt] = LayerNorm_D(x_l[rt]) = xhat * w + b for every tile of this wave (absent tiles: xhat = 0)
-        auto recompute_n = [&](f4 (&n)[PMT_RT][NTD]) {
+        auto recompute_n = [&](f4 (&n)[PMT_RT][NTD], bool touch_next = false) {
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) {
 #pragma unroll
                 for (int t = 0; t < NTD; ++t) n[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
-                if (mask_all & (1u << rt)) stash_load<NTD>(xs[rt], n[rt]);
+                if (mask_all & (1u << rt)) {
+                    stash_load<NTD>(xs[rt], n[rt]);
+                    if (touch_next && c.pf_sink != nullptr && slot_x0 + l > 0) stash_prefetch(xs[rt] - PMT_SLOT_FLOATS, c.pf_sink);  // the slot the walk needs next
+                }
             }
 #pragma unroll
             for (int t = 0; t < NTD; ++t) {
@@ -407,7 +422,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         f4 z[PMT_RT][2];
         if (first_half) {
             f4 n[PMT_RT][NTD];
-            recompute_n(n);
+            recompute_n(n, true);
             const f4 b0 = load_pvec(packed + uniform(P1.b_pvec), 0, g), b1 = load_pvec(packed + uniform(P1.b_pvec), 1, g);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) { z[rt][0] = b0; z[rt][1] = b1; }
@@ -471,7 +486,8 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             prof_add(c, 9, t_ph);
             t_ph = prof_now();
             // proj2 weight gradients of both sides in one exchange round
-            wgrad_exchange<NTD, 1, 2>(c, M->lin[uniform(B.proj2[0])], M->lin[uniform(B.proj2[1])], dy, u, 1.0f);
+            if constexpr (S::BF16) wgrad_exchange_bf<NTD, 1, 2>(c, M->lin[uniform(B.proj2[0])], M->lin[uniform(B.proj2[1])], dy, u, 1.0f);
+            else wgrad_exchange<NTD, 1, 2>(c, M->lin[uniform(B.proj2[0])], M->lin[uniform(B.proj2[1])], dy, u, 1.0f);
         }
         if (c.dbg & 1) __syncthreads();  // (the exchange's barriers, skipped by that switch, complete gsum)
         if constexpr (LAYERED) {
@@ -562,8 +578,8 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
                 dz[rt][0] = selu_bwd4(dz1, z[rt][0]);
                 dz[rt][1] = selu_bwd4(dxr[0], z[rt][1]);
             }
-            aux_push_vec<1>(c, uniform(B.sgu_norm_w_src), dsw, h);
-            aux_push_vec<1>(c, uniform(B.sgu_norm_b_src), dsb, h);
+            aux_push_vec_x<1, EX>(c, uniform(B.sgu_norm_w_src), dsw, h);
+            aux_push_vec_x<1, EX>(c, uniform(B.sgu_norm_b_src), dsb, h);
             if constexpr (!LAYERED) {  // (layered: pushed at the end of the launch that computed them)
                 aux_push_scalar(c, uniform(B.alpha_src[0]), side == 0 ? d_alpha : 0.f);
                 aux_push_scalar(c, uniform(B.alpha_src[1]), side == 1 ? d_alpha : 0.f);
@@ -578,7 +594,8 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         {
             f4 n[PMT_RT][NTD];
             recompute_n(n);
-            wgrad_exchange<2, NTD, 2>(c, M->lin[uniform(B.proj1[0])], M->lin[uniform(B.proj1[1])], dz, n, 1.0f);
+            if constexpr (S::BF16) wgrad_exchange_bf<2, NTD, 2>(c, M->lin[uniform(B.proj1[0])], M->lin[uniform(B.proj1[1])], dz, n, 1.0f);
+            else wgrad_exchange<2, NTD, 2>(c, M->lin[uniform(B.proj1[0])], M->lin[uniform(B.proj1[1])], dz, n, 1.0f);
         }
         prof_add(c, 13, t_ph);
         t_ph = prof_now();
@@ -609,8 +626,8 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
                 layernorm_bwd_inplace_tile<NTD>(dy[rt], dn[rt], xh, rs, D, lw, dlw, dlb, g);
             }
             __builtin_amdgcn_sched_barrier(0);
-            aux_push_vec<NTD>(c, uniform(B.norm_w_src), dlw, D);
-            aux_push_vec<NTD>(c, uniform(B.norm_b_src), dlb, D);
+            aux_push_vec_x<NTD, EX>(c, uniform(B.norm_w_src), dlw, D);
+            aux_push_vec_x<NTD, EX>(c, uniform(B.norm_b_src), dlb, D);
         }
         prof_add(c, 14, t_ph);
     }
@@ -656,7 +673,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
 #pragma unroll
             for (int t = 0; t < NTR; ++t) dr[rt][t] = dy[rt][t < NTD ? t : 0];
         mlp_backward<NTR, true, S::DIM_R, S::BF16>(c, M->read_mlp, dr, true,
-                                [&](int op, f4 (&x)[PMT_RT][NTR]) { load_slot_tiles<NTR>(stash_tile, mask_all, op - 1, x); }, 1, n_read_ops);
+                                [&](int op, f4 (&x)[PMT_RT][NTR]) { load_slot_tiles<NTR>(stash_tile, mask_all, op - 1, x, c.pf_sink); }, 1, n_read_ops);
         f4 xf[PMT_RT][NTF], dxf[PMT_RT][NTF];
         decode_reads(xf);
         linear_op_backward<NTF, NTR, true, S::DIM_F, S::DIM_R, S::BF16>(c, M->read_mlp.ops[0], dr, xf, dxf, false);

@@ -19,6 +19,18 @@ DEV float read_lanes_sum(float v) {  // sum over the 16 reads of a tile (lanes w
 }
 DEV float wave_sum(float v) { return group_sum(read_lanes_sum(v)); }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence + barrier and drains this
+// wave's GLOBAL memory queue too (s_waitcnt vmcnt(0)): every gradient atomic and every load in flight would have to come
+// home before each of the ~70 exchange barriers of a workgroup.  The exchanges hand over LDS data only.
+DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Touch one 4 KiB stash slot of a tile (64 lanes x one dword, 64 bytes apart) so that the lines are in L2 when the real load
+// comes an op later.  The dwords land in a 256-byte LDS sink by LDS-DMA: no VGPR is written, nothing has to be waited for.
+DEV void stash_prefetch(const float* __restrict__ slot, float* __restrict__ sink) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slot + (threadIdx.x & 63) * 16),
+                                     (__attribute__((address_space(3))) void*)sink, 4, 0, 0);
+}
+
 // The weight-gradient contraction runs over READS, so its operands are the transposes of the C-layout tiles: element ks of
 // lane (G, n) = value of feature position n for read 4 G + ks (position n = 4 g + j is register j of lane group g).
 // The first version transposed in registers on the matrix core (D = X^T * I, bit-exact, 4 MFMAs per tile); once the
@@ -176,6 +188,11 @@ struct BwdCtx {
                     // global atomics, bit 2 skip the gated blocks, bit 3 collect cycle counters, bit 4 drop small-parameter
                     // gradients.  0 in production.
     unsigned long long* prof;  // device, 24 counters (see scripts/bwd_ablate.py); only touched when dbg bit 3 is set
+    // bf16 weight-gradient exchange (wgrad_exchange_bf; read-set kernel, exact-width instance only)
+    int wr;         // waves [0, wr) hold ref tiles, [wr, PMT_WAVES) alt tiles (GroupGeom.wr)
+    int wbase;      // this lane's byte offset inside a 1 KiB operand plane when it STORES its reads (stage_pair_bf16)
+    int rbase;      // ... when it LOADS its MFMA operand (16 bytes)
+    float* pf_sink; // LDS, 64 floats: where stash_prefetch drops its dwords
 };
 DEV unsigned long long prof_now() { return __builtin_readcyclecounter(); }
 DEV void prof_add(const BwdCtx& c, int slot, unsigned long long t0) {
@@ -234,6 +251,77 @@ DEV void aux_push_vec(BwdCtx& c, int enc, const f4 (&v)[NT], int dim) {
             }
     }
     c.aux_n += 16 * nt;
+}
+// The same for arrays that fill their NT tiles (the exact instances): a HALVING butterfly over the 16 lanes of a row instead of
+// 4 NT independent 4-step reductions.  At each step a lane keeps one half of its values and hands the other half to its
+// partner (DPP: rotate by 4, rotate by 8, quad swaps), so the work halves every step: 15 exchange-adds for 16 values
+// instead of 64, and at the end every lane holds ONE finished sum -- value index (b2 b3 b1 b0) of its lane number's bits
+// -- which it stores itself: no 1-in-16 store region.
+#define PMT_DPP_ADD(NAME, CTRL)                                                                                                 \
+    DEV float NAME(float keep, float send) { /* keep + (send of the partner lane); s_nop: 2 wait states VALU write -> DPP read */ \
+        float r;                                                                                                                \
+        asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 " CTRL " row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(send), "v"(keep));      \
+        return r;                                                                                                               \
+    }
+PMT_DPP_ADD(dpp_add_ror4, "row_ror:4")
+PMT_DPP_ADD(dpp_add_ror8, "row_ror:8")
+PMT_DPP_ADD(dpp_add_x2, "quad_perm:[2,3,0,1]")
+PMT_DPP_ADD(dpp_add_x1, "quad_perm:[1,0,3,2]")
+template <int STEP>
+DEV float dpp_add_step(float keep, float send) {
+    return STEP == 0 ? dpp_add_ror4(keep, send) : STEP == 1 ? dpp_add_ror8(keep, send) : STEP == 2 ? dpp_add_x2(keep, send) : dpp_add_x1(keep, send);
+}
+template <int N, int STEP>
+DEV float row_halving_sum(const float (&v)[N], int lane) {  // returns the total of value index idx over the row's 16 lanes
+    constexpr int BIT[4] = {4, 8, 2, 1};
+    if constexpr (N == 1) {
+        float r = v[0];
+        if constexpr (STEP < 4) {
+            const float one[1] = {dpp_add_step<STEP>(r, r)};
+            return row_halving_sum<1, STEP + 1>(one, lane);
+        }
+        return r;
+    } else {
+        const bool up = (lane & BIT[STEP]) != 0;
+        float h[N / 2];
+#pragma unroll
+        for (int k = 0; k < N / 2; ++k) h[k] = dpp_add_step<STEP>(up ? v[N / 2 + k] : v[k], up ? v[k] : v[N / 2 + k]);
+        return row_halving_sum<N / 2, STEP + 1>(h, lane);
+    }
+}
+template <int NT>
+DEV void aux_push_vec_full(BwdCtx& c, int enc, const f4 (&v)[NT], int dim) {
+    static_assert(NT == 1 || NT == 2 || NT == 4, "4, 8 or 16 values per lane");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (c.aux_n + 16 * NT > PMT_AUX_CAP) aux_flush(c);
+    if (c.dbg & 16) return;
+    float vals[4 * NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vals[4 * t + j] = v[t][j];
+    const float total = row_halving_sum<4 * NT, 0>(vals, lane);
+    // which value this lane ended up with: the halving steps took bits 2, 3, 1, 0 of the lane number, most significant first
+    constexpr int STEPS = NT == 4 ? 4 : NT == 2 ? 3 : 2;
+    const int bits[4] = {(lane >> 2) & 1, (lane >> 3) & 1, (lane >> 1) & 1, lane & 1};
+    int idx = 0, spare = 0;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        if (st < STEPS) idx = 2 * idx + bits[st];
+        else spare |= bits[st];  // lanes that differ only in a bit summed AFTER the halving hold the same total: one of them stores
+    }
+    const int p = c.aux_n + 16 * (idx >> 2) + 4 * c.g + (idx & 3);
+    if (spare == 0) c.aux[wave * PMT_AUX_CAP + p] = total;
+    if (wave == 0 && spare == 0) {
+        const int f = feat_of(idx >> 2, idx & 3, c.g);
+        c.aux_dst[p] = f < dim ? enc_at(enc, f) : -1;
+    }
+    c.aux_n += 16 * NT;
+}
+template <int NT, bool FULL>
+DEV void aux_push_vec_x(BwdCtx& c, int enc, const f4 (&v)[NT], int dim) {
+    if constexpr (FULL && (NT == 1 || NT == 2 || NT == 4)) aux_push_vec_full<NT>(c, enc, v, dim);
+    else aux_push_vec<NT>(c, enc, v, dim);
 }
 // one 16-position row (tile 0) whose per-position totals already sit in every lane group: lane (g, p) holds position p
 DEV void aux_push_row16(BwdCtx& c, int enc, float v, int dim) {
@@ -380,10 +468,194 @@ DEV void wgrad_exchange(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, con
     prof_add(c, 2, t0c);
 }
 
-template <int NTO, int NTI>
+// ---- weight gradients on the bf16 matrix pipe ------------------------------------------------------------------------
+// dW = sum over reads of dy x^T is a LEAF result: its rounding error goes no further (unlike the dgrad chain, which keeps its
+// three-piece products).  Here both operands are split into TWO bf16 pieces (hi + mid: 16 significant bits, relative error
+// <= 2^-17 per element, random in sign over the reads of a sum) and a 16 x 16 block of dW over 32 reads is THREE
+// v_mfma_f32_16x16x32_bf16 (mid.hi + hi.mid + hi.hi, fp32 accumulation): 48 matrix-pipe cycles instead of the 8 x 32 of the
+// exact fp32 MFMA -- which also holds the vector ALU while it runs, and the vector ALU is what bounds this kernel.
+//
+// Exchange layout.  The contraction index of one MFMA is 32 reads = the two tiles of ONE wave, and any order of the reads
+// inside it will do as long as both operands use the same one.  Taking  k = 8 kg + 2 q + tile  for read 4 kg + q of the
+// wave's tile `tile`, the two values a lane holds for one feature position (one per tile) are NEIGHBOURS in k: one
+// v_cvt_pk_bf16_f32 packs them and one ds_write_b32 stores them -- no cross-lane shuffle at all.  A plane (16 positions x
+// the wave's 32 reads, one piece) is 64 slots of 16 bytes; slot(kg, m) = 16 kg + (m ^ kg) holds position m, reads
+// 4 kg .. 4 kg + 3 of both tiles: the consumer lane (m, kg) loads exactly its MFMA operand with one ds_read_b128, and the
+// XOR keeps the producers' ds_write_b32 (banks = dword address mod 32) and the consumers' ds_read_b128 conflict-free.
+// Stage: [wave][plane][piece hi | mid][1 KiB].
+DEV unsigned pack_bf16x2(float lo, float hi) {  // v_cvt_pk_bf16_f32: round to nearest even
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    const bf2 p = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, p);
+}
+DEV int stage_wbase(int lane) {  // byte offset of (kg = r >> 2, position 4 g, dword q = r & 3); position 4 g + j: XOR 16 j
+    const int g = lane >> 4, r = lane & 15, kg = r >> 2, q = r & 3;
+    return 256 * kg + 64 * g + 16 * kg + 4 * q;
+}
+DEV int stage_rbase(int lane) {  // lane (m = lane & 15, kg = lane >> 4) -> slot 16 kg + (m ^ kg)
+    const int m = lane & 15, kg = lane >> 4;
+    return 16 * (16 * kg + (m ^ kg));
+}
+// one operand plane of this wave: v0 / v1 = the plane's registers of tile 0 / tile 1 (zero for padding reads and absent tiles)
+DEV void stage_pair_bf16(char* __restrict__ plane, int wbase, f4 v0, f4 v1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned hi = pack_bf16x2(v0[j], v1[j]);
+        const float h0 = __builtin_bit_cast(float, hi << 16), h1 = __builtin_bit_cast(float, hi & 0xFFFF0000u);
+        const unsigned mid = pack_bf16x2(v0[j] - h0, v1[j] - h1);
+        char* p = plane + (wbase ^ (16 * j));
+        *reinterpret_cast<unsigned*>(p) = hi;
+        *reinterpret_cast<unsigned*>(p + 1024) = mid;
+    }
+}
+
+#define PMT_BF_PLANE_BYTES 2048  // hi + mid piece of one (wave, plane)
+template <int NTO, int NTI, int SIDES>
+DEV void wgrad_exchange_bf(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, const f4 (&dy)[PMT_RT][NTO],
+                           const f4 (&x)[PMT_RT][NTI], float scale) {
+    static_assert(PMT_RT == 2, "a wave's two tiles are the 32 reads of one MFMA");
+    static_assert(SIDES == 2 || PMT_WAVES % NTI == 0, "one column of blocks per wave");
+    if (c.dbg & 1) return;
+    constexpr int P = NTO + NTI, NB = NTO * NTI;
+    constexpr int PW_CAP = (PMT_STAGE_PLANES * 1024) / (P * PMT_BF_PLANE_BYTES);          // waves whose operands fit the stage
+    constexpr int PW = PW_CAP < PMT_WAVES ? PW_CAP : PMT_WAVES;
+    static_assert(PW >= 1, "stage too small");
+    // Blocks of this wave.  One linear: the wave owns column `it` = wave % NTI and the rows wave / NTI + k * (waves / NTI): its
+    // blocks share the x operand, loaded once per pair of tiles.  A ref / alt pair: task q = wave + waves * k of the
+    // 2 NB blocks, side-major (a wave's k-th blocks of the two sides have equal coordinates: the work is balanced
+    // whatever the split of the group between the sides).
+    constexpr int ROWS = SIDES == 1 ? PMT_WAVES / NTI : 1;
+    constexpr int TPW = SIDES == 1 ? (NTO + ROWS - 1) / ROWS : (2 * NB + PMT_WAVES - 1) / PMT_WAVES;
+    const int lane = threadIdx.x & 63, g = lane >> 4, wave = uniform((int)(threadIdx.x >> 6));
+    int t_ot[TPW], t_it[TPW], t_side[TPW];
+    f4 acc[TPW], accb[TPW];
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+        acc[k] = accb[k] = f4{0.f, 0.f, 0.f, 0.f};
+        if (SIDES == 1) {
+            t_it[k] = wave % NTI;
+            t_ot[k] = wave / NTI + ROWS * k;
+            t_side[k] = t_ot[k] < NTO ? 0 : -1;
+        } else {
+            const int q = wave + PMT_WAVES * k;
+            t_side[k] = q >= 2 * NB ? -1 : (q >= NB ? 1 : 0);
+            const int rem = q - (q >= NB ? NB : 0);
+            t_ot[k] = rem / NTI;
+            t_it[k] = rem - t_ot[k] * NTI;
+        }
+    }
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    const bf8 ones = __builtin_bit_cast(bf8, u4v{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});  // 1.0 everywhere
+    // destinations of this wave's blocks (PmtLinear.emit_tab), fetched now: the loads are long back when the sums are ready
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    i4 e[TPW], eb[TPW];
+    bool with_bias[TPW];
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+        e[k] = eb[k] = i4{-1, -1, -1, -1};
+        with_bias[k] = false;
+        if (t_side[k] < 0) continue;
+        const PmtLinear& L = (SIDES == 2 && t_side[k] == 1) ? L1 : L0;
+        const int* tab = reinterpret_cast<const int*>(c.packed + uniform(L.emit_tab));
+        e[k] = *reinterpret_cast<const i4*>(tab + ((t_ot[k] * NTI + t_it[k]) * 64 + lane) * 4);
+        with_bias[k] = t_it[k] == t_ot[k] % NTI;  // the one block of row ot that also sums the bias gradient (dy x ones)
+        if (with_bias[k]) eb[k] = *reinterpret_cast<const i4*>(tab + NB * 256 + t_ot[k] * 16 + 4 * g);
+    }
+    char* stage = reinterpret_cast<char*>(c.stage);
+    unsigned long long t0c = prof_now();
+    for (int w0 = 0; w0 < PMT_WAVES; w0 += PW) {
+        if (c.dbg & 128) __syncthreads(); else lds_barrier();  // the stage (and the slabs) of the previous round have been consumed
+        if (w0 == 0) aux_reduce(c);
+        if (wave >= w0 && wave < w0 + PW) {
+            char* mine = stage + (wave - w0) * (P * PMT_BF_PLANE_BYTES);
+#pragma unroll
+            for (int ot = 0; ot < NTO; ++ot) stage_pair_bf16(mine + ot * PMT_BF_PLANE_BYTES, c.wbase, dy[0][ot], dy[1][ot]);
+#pragma unroll
+            for (int it = 0; it < NTI; ++it) stage_pair_bf16(mine + (NTO + it) * PMT_BF_PLANE_BYTES, c.wbase, x[0][it], x[1][it]);
+        }
+        if (c.dbg & 128) __syncthreads(); else lds_barrier();
+        const int whi_all = min(w0 + PW, PMT_WAVES);
+        const char* rd = stage + c.rbase;
+        if (SIDES == 1) {
+            if (t_side[0] >= 0) {
+#pragma unroll
+                for (int w = 0; w < PW; ++w) {  // branch-free body: the scheduler overlaps the reads of one pair with the MFMAs of another
+                    if (w0 + w >= PMT_WAVES) break;
+                    const char* pw = rd + w * (P * PMT_BF_PLANE_BYTES);
+                    const bf8 bh = *reinterpret_cast<const bf8*>(pw + (NTO + t_it[0]) * PMT_BF_PLANE_BYTES);
+                    const bf8 bm = *reinterpret_cast<const bf8*>(pw + (NTO + t_it[0]) * PMT_BF_PLANE_BYTES + 1024);
+#pragma unroll
+                    for (int k = 0; k < TPW; ++k) {
+                        const int ot = t_side[k] >= 0 ? t_ot[k] : 0;  // (a missing block reads row 0 and is never emitted)
+                        const bf8 ah = *reinterpret_cast<const bf8*>(pw + ot * PMT_BF_PLANE_BYTES);
+                        const bf8 am = *reinterpret_cast<const bf8*>(pw + ot * PMT_BF_PLANE_BYTES + 1024);
+                        acc[k] = mfma_bf16(am, bh, acc[k]);
+                        acc[k] = mfma_bf16(ah, bm, acc[k]);
+                        acc[k] = mfma_bf16(ah, bh, acc[k]);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < TPW; ++k) {
+                if (t_side[k] < 0) continue;
+                const int lo = max(t_side[k] == 1 ? c.wr : 0, w0), hi = min(t_side[k] == 0 ? c.wr : PMT_WAVES, whi_all);
+                const char* pa = rd + t_ot[k] * PMT_BF_PLANE_BYTES;
+                const char* pb = rd + (NTO + t_it[k]) * PMT_BF_PLANE_BYTES;
+#pragma unroll 2
+                for (int w = lo; w < hi; ++w) {
+                    const int o = (w - w0) * (P * PMT_BF_PLANE_BYTES);
+                    const bf8 ah = *reinterpret_cast<const bf8*>(pa + o), am = *reinterpret_cast<const bf8*>(pa + o + 1024);
+                    const bf8 bh = *reinterpret_cast<const bf8*>(pb + o), bm = *reinterpret_cast<const bf8*>(pb + o + 1024);
+                    acc[k] = mfma_bf16(am, bh, acc[k]);
+                    acc[k] = mfma_bf16(ah, bm, acc[k]);
+                    acc[k] = mfma_bf16(ah, bh, acc[k]);
+                }
+            }
+        }
+        // bias gradients: the row sums of dy, by one block per row (its A operand once more against a plane of ones)
+#pragma unroll
+        for (int k = 0; k < TPW; ++k) {
+            if (!with_bias[k]) continue;
+            const int lo = SIDES == 1 ? w0 : max(t_side[k] == 1 ? c.wr : 0, w0);
+            const int hi = SIDES == 1 ? whi_all : min(t_side[k] == 0 ? c.wr : PMT_WAVES, whi_all);
+            const char* pa = rd + t_ot[k] * PMT_BF_PLANE_BYTES;
+            for (int w = lo; w < hi; ++w) {
+                const int o = (w - w0) * (P * PMT_BF_PLANE_BYTES);
+                const bf8 ah = *reinterpret_cast<const bf8*>(pa + o), am = *reinterpret_cast<const bf8*>(pa + o + 1024);
+                accb[k] = mfma_bf16(am, ones, accb[k]);
+                accb[k] = mfma_bf16(ah, ones, accb[k]);
+            }
+        }
+    }
+    prof_add(c, 0, t0c);
+    if (c.dbg & 2) return;
+    t0c = prof_now();
+    // emit: four atomics per block at the tabulated offsets; no index arithmetic here
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+        if (t_side[k] < 0) continue;
+        const bool side1 = SIDES == 2 && t_side[k] == 1;
+        if (SIDES == 2 && (side1 ? c.ntiles <= c.tiles_ref : c.tiles_ref <= 0)) continue;  // no tiles on that side
+        const PmtLinear& L = side1 ? L1 : L0;
+        float* gw = uniform(L.w_src) >= 0 ? c.gtheta : c.gphi;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (e[k][j] >= 0) atomicAdd(gw + e[k][j], scale * acc[k][j]);
+        if (with_bias[k] && (lane & 15) == 0) {  // every column of accb holds the row sums: the lanes of column 0 add them
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (eb[k][j] >= 0) atomicAdd(c.gtheta + eb[k][j], scale * accb[k][j]);
+        }
+    }
+    prof_add(c, 2, t0c);
+}
+
+template <int NTO, int NTI, bool BF = false>
 DEV void linear_wgrad(BwdCtx& c, const PmtLinear& L, const f4 (&dy)[PMT_RT][NTO], const f4 (&x)[PMT_RT][NTI],
                       float scale = 1.0f) {
-    wgrad_exchange<NTO, NTI, 1>(c, L, L, dy, x, scale);
+    if constexpr (BF) wgrad_exchange_bf<NTO, NTI, 1>(c, L, L, dy, x, scale);
+    else wgrad_exchange<NTO, NTI, 1>(c, L, L, dy, x, scale);
 }
 
 // Backward of one LINEAR op between register arrays of different tile counts (see run_linear_op): dy is the gradient
@@ -403,7 +675,7 @@ DEV void linear_op_backward(BwdCtx& c, const PmtOp& o, f4 (&dy)[PMT_RT][NTO], co
 #pragma unroll
             for (int t = 0; t < NTO; ++t) dy[rt][t] = selu_bwd4(dy[rt][t], selu4(y[rt][t]));
     }
-    linear_wgrad<NTO, NTI>(c, L, dy, x);
+    linear_wgrad<NTO, NTI, BF>(c, L, dy, x);
     if (want_dx) {
         init_bias<NTI>(dx, nullptr, in_dim, c.g);
         if constexpr (BF) linear_acc_bf16<NTO, NTI, false>(dx, dy, c.packed + uniform(L.wtb_frag));
@@ -434,7 +706,7 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
 #pragma unroll
                     for (int t = 0; t < NT; ++t) dy[rt][t] = selu_bwd4(dy[rt][t], selu4(y[rt][t]));
             }
-            linear_wgrad<NT, NT>(c, L, dy, x);
+            linear_wgrad<NT, NT, BF>(c, L, dy, x);
             if (op > op_begin || need_input_grad) {
                 f4 dx[PMT_RT][NT];
                 init_bias<NT>(dx, nullptr, in_dim, c.g);
@@ -464,25 +736,26 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
             for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) s1[rt][t] = selu4(nl == 2 ? s1[rt][t] : x[rt][t]);
-            {   // d(alpha) = sum dy . f,  f = L2 s1 + b2   (x's registers are free from here on)
-                f4 f[PMT_RT][NT];
-                init_bias<NT>(f, c.packed + uniform(L2.b_pvec), width, c.g);
-                if constexpr (BF) linear_acc_bf16<NT, NT, false>(f, s1, c.packed + uniform(L2.wb_frag));
-                else linear_acc<NT, NT, false, EXACT, W>(f, s1, c.packed + uniform(L2.w_frag), width, width);
-                float da = 0.f;
-#pragma unroll
-                for (int rt = 0; rt < PMT_RT; ++rt)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) da += (dy[rt][t][0] * f[rt][t][0] + dy[rt][t][1] * f[rt][t][1]) + (dy[rt][t][2] * f[rt][t][2] + dy[rt][t][3] * f[rt][t][3]);
-                aux_push_scalar(c, uniform(o.alpha_src), da);
-            }
-            __builtin_amdgcn_sched_barrier(0);
             // last layer: d(f) = alpha * dy
-            linear_wgrad<NT, NT>(c, L2, dy, s1, alpha);
+            linear_wgrad<NT, NT, BF>(c, L2, dy, s1, alpha);
             f4 d1[PMT_RT][NT];
             init_bias<NT>(d1, nullptr, width, c.g);
             if constexpr (BF) linear_acc_bf16<NT, NT, false>(d1, dy, c.packed + uniform(L2.wtb_frag));
             else linear_acc<NT, NT, false, EXACT, W>(d1, dy, c.packed + uniform(L2.wt_frag), width, width);
+            {   // d(alpha) = sum dy . f with f = W2 s1 + b2, i.e. sum (W2^T dy) . s1 + sum dy . b2: the first factor is d1 as it
+                // stands here, so the forward product f is never formed (it was a quarter of this op's matrix work)
+                float da = 0.f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const f4 b2 = load_pvec(c.packed + uniform(L2.b_pvec), t, c.g);
+#pragma unroll
+                    for (int rt = 0; rt < PMT_RT; ++rt) {
+                        const f4 p = d1[rt][t] * s1[rt][t] + dy[rt][t] * b2;
+                        da += (p[0] + p[1]) + (p[2] + p[3]);
+                    }
+                }
+                aux_push_scalar(c, uniform(o.alpha_src), da);
+            }
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
@@ -495,7 +768,7 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
                 for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
                     for (int t = 0; t < NT; ++t) s0[rt][t] = selu4(s0[rt][t]);
-                linear_wgrad<NT, NT>(c, L1, d1, s0);
+                linear_wgrad<NT, NT, BF>(c, L1, d1, s0);
                 f4 d0[PMT_RT][NT];
                 init_bias<NT>(d0, nullptr, width, c.g);
                 if constexpr (BF) linear_acc_bf16<NT, NT, false>(d0, d1, c.packed + uniform(L1.wtb_frag));

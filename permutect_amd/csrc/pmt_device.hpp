@@ -331,6 +331,7 @@ struct GroupGeom {
     int tiles_ref, tiles_alt, ntiles;
     int tile_begin, tile_count;  // this wave's contiguous tile range
     int side;                    // the side (0 ref / 1 alt) of ALL of this wave's tiles
+    int wr;                      // waves [0, wr) hold the ref tiles, waves [wr, PMT_WAVES) the alt tiles
 };
 
 // A group fits a workgroup when its ref tiles and its alt tiles can be dealt to disjoint sets of waves, PMT_RT per wave
@@ -368,6 +369,7 @@ DEV GroupGeom group_geometry(const PmtBatch& bt, int group) {
     const int need_r = (gg.tiles_ref + PMT_RT - 1) / PMT_RT, need_a = (gg.tiles_alt + PMT_RT - 1) / PMT_RT;
     int wr = gg.ntiles > 0 ? (PMT_WAVES * gg.tiles_ref + gg.ntiles / 2) / gg.ntiles : 0;
     wr = min(max(wr, need_r), PMT_WAVES - need_a);
+    gg.wr = wr;
     gg.side = wave < wr ? 0 : 1;
     const int nw = gg.side == 0 ? wr : PMT_WAVES - wr, i = gg.side == 0 ? wave : wave - wr;
     const int nt = gg.side == 0 ? gg.tiles_ref : gg.tiles_alt;

@@ -465,16 +465,38 @@ DEV int split_row(int v, int h) {
 }
 
 // one job per workgroup: (lin, 0) forward frags, (lin, 1) transposed frags, (lin, 2) bias, (lin, 3 / 4) the same two matrices
-// as bf16 pieces, then per-block vectors
+// as bf16 pieces, (lin, 5) the weight-gradient emit table, then per-block vectors
 __global__ void pmt_pack_kernel(const PmtModel* __restrict__ M, const float* __restrict__ theta,
                                 const float* __restrict__ phi, float* __restrict__ packed) {
     const int job = blockIdx.x;
-    const int n_lin_jobs = M->n_linear * 5;
+    const int n_lin_jobs = M->n_linear * 6;
     if (job < n_lin_jobs) {
-        const PmtLinear& L = M->lin[job / 5];
-        const int kind = job % 5;
+        const PmtLinear& L = M->lin[job / 6];
+        const int kind = job % 6;
         const int h = L.out_split;
         const int out_v = h > 0 ? 16 + h : L.out_dim;  // virtual output rows
+        if (kind == 5) {
+            // PmtLinear.emit_tab: destination of every element of every 16 x 16 block of dW as the matrix core leaves it
+            // (C layout: lane (g, c) register j = row position 4 g + j, column position c; position p of a tile = feature
+            // 4 (p & 3) + (p >> 2), pmt_device.hpp), then the bias gradient's destinations per out tile in position order
+            if (L.emit_tab < 0) return;
+            int* tab = reinterpret_cast<int*>(packed + L.emit_tab);
+            const int nmt = (out_v + 15) >> 4, nkt = (L.in_dim + 15) >> 4;
+            const int w_off = L.w_src >= 0 ? L.w_src : -(L.w_src + 2);
+            for (int i = threadIdx.x; i < nmt * nkt * 256; i += blockDim.x) {
+                const int j = i & 3, lane = (i >> 2) & 63, blk = i >> 8;
+                const int ot = blk / nkt, it = blk - ot * nkt;
+                const int pf = 16 * ot + 4 * j + (lane >> 4), o = pf < out_v ? split_row(pf, h) : -1;
+                const int cp = lane & 15, col = 16 * it + 4 * (cp & 3) + (cp >> 2);
+                tab[i] = (o >= 0 && o < L.out_dim && col < L.in_dim) ? w_off + o * L.in_dim + col : -1;
+            }
+            int* btab = tab + nmt * nkt * 256;
+            for (int i = threadIdx.x; i < nmt * 16; i += blockDim.x) {
+                const int p = i & 15, pf = 16 * (i >> 4) + 4 * (p & 3) + (p >> 2), o = pf < out_v ? split_row(pf, h) : -1;
+                btab[i] = (L.b_src >= 0 && o >= 0 && o < L.out_dim) ? L.b_src + o : -1;
+            }
+            return;
+        }
         if (kind >= 3) {
             // k block kb of 32 = activation tiles 2 kb and 2 kb + 1; lane (m, kg) element e: tile 2 kb + (e >> 2), register
             // e & 3 of lane group kg, i.e. the SAME feature order as the fp32 activation registers, so a layer's C-layout
@@ -570,7 +592,7 @@ extern "C" int pmt_pack_params(const PmtModel* model_host, const PmtModel* model
     if (!model_host || !model_dev || !theta || !packed) return PMT_E_INVALID;
     const int rc = pmt_model_check(model_host);
     if (rc) return rc;
-    const int jobs = model_host->n_linear * 5 + model_host->num_blocks * 5 + 1;
+    const int jobs = model_host->n_linear * 6 + model_host->num_blocks * 5 + 1;
     hipLaunchKernelGGL(pmt_pack_kernel, dim3(jobs), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), model_dev, theta,
                        phi, packed);
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;

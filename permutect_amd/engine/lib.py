@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_HERE, "libpermutect_amd.so")
 
 # ---- limits (must match the header) -------------------------------------------------------------------------------
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_WIDTH, MAX_HALF_FFN, MAX_CLUSTERS = 64, 16, 16
 MAX_ROW_INPUT = 128
 ROWS_INFO, ROWS_ALT_COUNT, ROWS_SOURCE = 0, 1, 2
@@ -33,7 +33,7 @@ i32, i64, vp = C.c_int32, C.c_int64, C.c_void_p
 
 class PmtLinear(C.Structure):
     _fields_ = [("in_dim", i32), ("out_dim", i32), ("w_frag", i32), ("wt_frag", i32), ("b_pvec", i32),
-                ("w_src", i32), ("b_src", i32), ("w_stage", i32), ("out_split", i32), ("wb_frag", i32), ("wtb_frag", i32)]
+                ("w_src", i32), ("b_src", i32), ("w_stage", i32), ("out_split", i32), ("wb_frag", i32), ("wtb_frag", i32), ("emit_tab", i32)]
 
 
 class PmtStage(C.Structure):

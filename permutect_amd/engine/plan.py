@@ -168,6 +168,7 @@ class EnginePlan:
             nmt, nkt = (out_v + 15) // 16, (lin.in_dim + 15) // 16
             lin.wb_frag = self._alloc_packed(nmt * ((nkt + 1) // 2) * 3 * 256 + 256)
             lin.wtb_frag = self._alloc_packed(nkt * ((nmt + 1) // 2) * 3 * 256 + 256)
+            lin.emit_tab = self._alloc_packed(nmt * nkt * 256 + nmt * 16)  # int32 offsets of the dW blocks and the bias rows
         d.theta_size, d.phi_size, d.packed_size = space.size, max(self._phi_off, 4), self._packed_off + 512  # slack: the kernels prefetch two fragments ahead
 
         lib = L.load()
