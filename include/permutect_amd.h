@@ -190,6 +190,13 @@ typedef struct PmtModel {
     int32_t n_fwd_sched, n_bwd_sched;
     PmtStage fwd_sched[PMT_MAX_SCHED];
     PmtStage bwd_sched[PMT_MAX_SCHED];
+    /* Kernel-instance selection, part of the descriptor (the library reads no environment variables and keeps no state).
+     * 0 everywhere = the library's own choice; the other values exist so that the parity tests can run every instance. */
+    int32_t force_shape;        /* read-set kernels: 0 auto, 1 at most the tile-exact instance, 2 the generic instance   */
+    int32_t force_cnn;          /* haplotype CNN: 0 auto, 1 general (workgroup-per-chunk) kernels, 2 wave-per-variant
+                                   kernels (pmt_cnn2), 3 batched-column kernels (pmt_cnn3)                               */
+    int32_t cnn_debug;          /* development switches of pmt_cnn2_backward (0 in production)                           */
+    int32_t reserved_sel;
 } PmtModel;
 
 /* Inputs of one forward / backward pass.  Reads are ordered as the reference's Batch orders them: all ref reads

@@ -391,6 +391,13 @@ extern "C" int pmt_cnn2_try_backward(const PmtModel* model_host, const PmtModel*
                                      const int64_t* haplotypes, int64_t hap_stride, int32_t n, const float* d_out,
                                      int64_t d_out_stride, const float* stash, float* grad_theta, void* stream);
 
+// pmt_cnn3.hip (batched-column kernels for the production-shaped stack): same return convention
+extern "C" int pmt_cnn3_try_forward(const PmtModel* model_host, const float* theta, const int64_t* haplotypes, int64_t hap_stride, int32_t n,
+                                    float* out, int64_t out_stride, float* stash, void* stream);
+extern "C" int pmt_cnn3_try_backward(const PmtModel* model_host, const float* theta, const int64_t* haplotypes, int64_t hap_stride, int32_t n,
+                                     const float* d_out, int64_t d_out_stride, const float* stash, float* grad_theta, void* stream);
+extern "C" size_t pmt_cnn3_stash_floats(const PmtModel* m);
+
 static int cnn_check(const PmtModel* m) {
     if (!m) return PMT_E_INVALID;
     const PmtCnn* c = &m->cnn;
@@ -427,6 +434,10 @@ extern "C" int pmt_cnn_forward(const PmtModel* model_host, const PmtModel* model
     if (rc) return rc;
     if (!model_dev || !theta || !packed || !haplotypes || !out || n < 0) return PMT_E_INVALID;
     if (n == 0) return PMT_OK;
+    {   // the batched-column kernels where they cover the model (with `stash`: in the layout their backward reads)
+        const int rc3 = pmt_cnn3_try_forward(model_host, theta, haplotypes, hap_stride, n, out, out_stride, stash, stream);
+        if (rc3 <= 0) return rc3;
+    }
     if (stash) {  // a training forward that keeps its layer outputs: the wave-per-variant kernel writes them in the backward's layout
         const int rc2 = pmt_cnn2_try_forward(model_host, model_dev, theta, packed, haplotypes, hap_stride, n, out, out_stride, stash, stream);
         return rc2 <= 0 ? rc2 : PMT_E_UNSUPPORTED;  // (pmt_cnn_stash_floats said 0 for such a model)
@@ -434,8 +445,7 @@ extern "C" int pmt_cnn_forward(const PmtModel* model_host, const PmtModel* model
     // The wave-per-variant forward (pmt_cnn2.hip) measures slower than the kernel below (0.54 vs 0.47 ms at 65 536 variants,
     // P0): the forward has no weight gradients to keep resident, which is what the wave-per-variant backward wins with.  It
     // stays selectable (PMT_CNN=wave) and parity-tested.
-    const char* pref = getenv("PMT_CNN");
-    if (pref && strcmp(pref, "wave") == 0) {
+    if (model_host->force_cnn == 2) {
         const int rc2 = pmt_cnn2_try_forward(model_host, model_dev, theta, packed, haplotypes, hap_stride, n, out, out_stride, nullptr, stream);
         if (rc2 <= 0) return rc2;
     }
@@ -455,6 +465,11 @@ extern "C" int pmt_cnn_backward(const PmtModel* model_host, const PmtModel* mode
     if (rc) return rc;
     if (!model_dev || !theta || !packed || !haplotypes || !d_out || !grad_theta || n < 0) return PMT_E_INVALID;
     if (n == 0) return PMT_OK;
+    {
+        const int rc3 = pmt_cnn3_try_backward(model_host, theta, haplotypes, hap_stride, n, d_out, d_out_stride, stash, grad_theta, stream);
+        if (rc3 <= 0) return rc3;
+        if (stash && pmt_cnn3_stash_floats(model_host) > 0) return PMT_E_INVALID;  // (the stash is in pmt_cnn3's layout)
+    }
     {
         const int rc2 = pmt_cnn2_try_backward(model_host, model_dev, theta, packed, haplotypes, hap_stride, n, d_out, d_out_stride,
                                               stash, grad_theta, stream);

@@ -490,8 +490,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_backward_kernel(
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
 static int cnn2_supported(const PmtModel* m) {
-    const char* force = getenv("PMT_CNN");  // PMT_CNN=general: always the general kernels (the parity tests cover both)
-    if (force && strcmp(force, "general") == 0) return 0;
+    if (m->force_cnn == 1) return 0;  // always the general kernels (the parity tests cover every instance)
     const PmtCnn* c = &m->cnn;
     int nconv = 0, nlin = 0;
     for (int l = 0; l < c->n_layers; ++l) {
@@ -542,7 +541,12 @@ static int cnn2_waves(size_t floats_per_wave, size_t static_bytes, int* per_cu) 
     return nw > PMT_WAVES ? PMT_WAVES : nw;
 }
 
+extern "C" size_t pmt_cnn3_stash_floats(const PmtModel* m);
 extern "C" size_t pmt_cnn_stash_floats(const PmtModel* m) {
+    if (m) {
+        const size_t per3 = pmt_cnn3_stash_floats(m);  // the batched-column kernels take the model when they cover it
+        if (per3 > 0) return per3;
+    }
     if (!m || !cnn2_supported(m)) return 0;
     const int per = m->cnn.sum_act - 10 * m->cnn.seq_len;
     return per > 0 ? (size_t)per : 0;
@@ -605,6 +609,6 @@ extern "C" int pmt_cnn2_try_backward(const PmtModel* model_host, const PmtModel*
     auto kernel = (kt[0] <= 2) ? pmt_cnn2_backward_kernel<2, C2_NTI> : pmt_cnn2_backward_kernel<C2_NTI, C2_NTI>;
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64 * nw), lds_bytes, reinterpret_cast<hipStream_t>(stream), model_dev,
                        theta, packed, (const long long*)haplotypes, (long long)hap_stride, n, (int)per, (int)stage, d_out, (long long)d_out_stride,
-                       stash, grad_theta, getenv("PMT_CNN_DBG") ? atoi(getenv("PMT_CNN_DBG")) : 0);
+                       stash, grad_theta, model_host->cnn_debug);
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }

@@ -1,0 +1,606 @@
+// Haplotype CNN, batched-column kernels: the production-shaped stack
+//     Conv1d(10 -> C1, k1) -> MaxPool1d(2) -> act -> Conv1d(C1 -> C2, k2) -> act -> Flatten -> Linear(C2 * L2 -> O)
+// (reference architecture/dna_sequence_convolution.py:31-111 on the one-hot of data/batch.py:115-130) as plain GEMMs on the
+// fp32 matrix core (v_mfma_f32_16x16x4_f32: exact fp32, like the reference).
+//
+// pmt_cnn2.hip gives a wave ONE variant: a convolution's 7 or 19 output positions half-fill its 16-column tiles, every B
+// operand is an im2col gather through a tap table (~10 instructions per element) and the input gradient is a col2im of LDS
+// atomics: 18 vector instructions per MFMA, 6.7 % of the matrix peak.  Here a wave takes V = 8 variants at a time and a GEMM
+// COLUMN is a (variant, position) pair, so the tiles are full.  Activations rest in the wave's private LDS region as
+// [column][channel block of 16, in the register ("tile-position") order of pmt_device.hpp]:
+//   * a convolution is one GEMM PER TAP, whose B operand is the input's column shifted by the tap: ONE ds_read_b128 per
+//     16 channels, no index arithmetic, no tap table; its output registers are stored with one ds_write_b128 per 16 channels;
+//   * the input gradient is the same gather with the transposed weights (out[q] = sum_k W_k^T dY[q - k]): plain stores, no
+//     atomics;
+//   * weight gradients contract over columns, their operands read from the same LDS arrays (a scalar per lane and k-step),
+//     accumulated in registers over ALL the variants a wave sees (the kernels are persistent) and added to global memory once
+//     per wave;
+//   * the one-hot input is never materialised: a B operand of the first convolution is a byte compare on the haplotype;
+//   * max-pooling pairs neighbouring columns of the first convolution's output with one DPP shift (its argmax goes into the
+//     stash as one bit per channel); the first convolution's weight gradient uses the pooled gradient directly, split by argmax.
+// No workgroup barrier after the prologue: a wave's LDS traffic completes in order (wave_sync).
+//
+// Covers exactly the layer pattern above with C1, C2 <= 32, O <= 16, kernels <= 7, stride 1, no padding / dilation, pool 2/2;
+// everything else runs pmt_cnn2.hip / pmt_cnn.hip.  The backward needs the forward's stash (pooled activations, second
+// convolution's output, pool argmax: P1 * 33 + L2 * 32 floats per variant).
+#define PMT_OWN_WAVE_SHAPE
+#define PMT_WAVES 8   // (pmt_device.hpp wants one; the kernels here take their wave count NW and batch size V as template parameters)
+#define PMT_RT 1
+#include "pmt_device.hpp"
+
+// V variants per wave and batch, NW waves per workgroup: the forward runs <4, 8> (two waves per SIMD hide its LDS latencies), the
+// backward <8, 4> (its register-resident weight gradients want the whole register file of a SIMD: measured 485 vs 633 us).
+#define C3_FWD_V 4
+#define C3_FWD_NW 8
+#define C3_BWD_V 8
+#define C3_BWD_NW 4
+#define C3_MAXK 7
+
+struct C3Cfg {
+    int S, K1, L1, P1, K2, L2, C1, C2, F, O;   // sequence length, kernel 1, its output length, pooled length, kernel 2, its output length
+    int st1, st2;                              // columns per variant of the conv1 / conv2 GEMMs (st1 even: pool pairs never straddle a tile)
+    int n1t, n2t, nPt;                         // 16-column tiles of the conv1 / conv2 / pooled-gradient GEMMs over C3_V variants
+    int act1, act2;                            // PMT_CNN_LEAKY_RELU | PMT_CNN_SELU
+    int w1, b1, w2, b2, wl, bl;                // theta offsets
+    int per_wave;                              // floats of LDS per wave
+    int stash_per;                             // floats of stash per variant
+};
+
+DEV void c3_wave_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+DEV int c3_row(int m) { return 4 * (m & 3) + (m >> 2); }  // A-fragment row m / block element e -> channel within the 16-block
+DEV float c3_act(int kind, float x) { return kind == PMT_CNN_LEAKY_RELU ? (x > 0.f ? x : 0.01f * x) : selu1(x); }
+DEV float c3_act_grad(int kind, float y) { return kind == PMT_CNN_LEAKY_RELU ? (y > 0.f ? 1.f : 0.01f) : selu_grad_from_out(y); }
+DEV f4 c3_act4(int kind, f4 v) { return f4{c3_act(kind, v[0]), c3_act(kind, v[1]), c3_act(kind, v[2]), c3_act(kind, v[3])}; }
+DEV f4 c3_act_grad4(int kind, f4 y) { return f4{c3_act_grad(kind, y[0]), c3_act_grad(kind, y[1]), c3_act_grad(kind, y[2]), c3_act_grad(kind, y[3])}; }
+DEV f4 c3_mfma4(f4 a, f4 b, f4 c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = mfma16(a[j], b[j], c);
+    return c;
+}
+DEV f4 c3_zero() { return f4{0.f, 0.f, 0.f, 0.f}; }
+template <int CTRL>
+DEV f4 c3_dpp4(f4 v) { return f4{dpp_mov<CTRL>(v[0]), dpp_mov<CTRL>(v[1]), dpp_mov<CTRL>(v[2]), dpp_mov<CTRL>(v[3])}; }
+
+// ---- weights as A fragments in LDS (built once per workgroup from the natural layouts in theta) -----------------------------
+// fragment element [lane = 16 g + m][j]: row = 16 mt + c3_row(m), k = 16 kt + 4 j + g   (pmt_device.hpp's convention)
+struct C3Weights {
+    const float *w1f, *w2f, *wlf;     // forward:  [K1][2][256], [K2][2 mt][2 kt][256], [L2][2][256]
+    const float *w2tf, *wltf;         // backward: W2^T [K2][2 mt = ci][2 kt = co][256], Wl^T [L2][2][256] (rows = channels, k = outputs)
+    const float *b1p, *b2p, *blp;     // biases in position order (element 4 g + j = feature 4 j + g): [2][16], [2][16], [16]
+};
+DEV int c3_weight_floats(const C3Cfg& c, bool backward) {
+    const int fwd = c.K1 * 2 * 256 + c.K2 * 4 * 256 + c.L2 * 2 * 256 + 80;
+    const int bwd = c.K2 * 4 * 256 + c.L2 * 2 * 256;
+    return backward ? bwd : fwd;
+}
+DEV C3Weights c3_build_weights(const C3Cfg& c, const float* __restrict__ theta, float* __restrict__ lds, bool backward) {
+    C3Weights W{};
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    float* cur = lds;
+    if (!backward) {
+        float* w1f = cur; cur += c.K1 * 2 * 256;
+        for (int i = tid; i < c.K1 * 2 * 256; i += nthr) {
+            const int j = i & 3, lane = (i >> 2) & 63, mt = (i >> 8) & 1, tap = i >> 9;
+            const int co = 16 * mt + c3_row(lane & 15), ci = 4 * j + (lane >> 4);
+            w1f[i] = (co < c.C1 && ci < 10) ? theta[c.w1 + (co * 10 + ci) * c.K1 + tap] : 0.f;
+        }
+        float* w2f = cur; cur += c.K2 * 4 * 256;
+        for (int i = tid; i < c.K2 * 4 * 256; i += nthr) {
+            const int j = i & 3, lane = (i >> 2) & 63, kt = (i >> 8) & 1, mt = (i >> 9) & 1, tap = i >> 10;
+            const int co = 16 * mt + c3_row(lane & 15), ci = 16 * kt + 4 * j + (lane >> 4);
+            w2f[i] = (co < c.C2 && ci < c.C1) ? theta[c.w2 + (co * c.C1 + ci) * c.K2 + tap] : 0.f;
+        }
+        float* wlf = cur; cur += c.L2 * 2 * 256;
+        for (int i = tid; i < c.L2 * 2 * 256; i += nthr) {
+            const int j = i & 3, lane = (i >> 2) & 63, t = (i >> 8) & 1, p = i >> 9;
+            const int o = c3_row(lane & 15), ch = 16 * t + 4 * j + (lane >> 4);
+            wlf[i] = (o < c.O && ch < c.C2) ? theta[c.wl + o * c.F + ch * c.L2 + p] : 0.f;
+        }
+        float* bp = cur; cur += 80;
+        for (int i = tid; i < 80; i += nthr) {
+            const int e = i & 15, f = 16 * ((i >> 4) & 1) + c3_row(e);
+            float v = 0.f;
+            if (i < 32) v = f < c.C1 ? theta[c.b1 + f] : 0.f;
+            else if (i < 64) v = f < c.C2 ? theta[c.b2 + f] : 0.f;
+            else v = c3_row(e) < c.O ? theta[c.bl + c3_row(e)] : 0.f;
+            bp[i] = v;
+        }
+        W.w1f = w1f; W.w2f = w2f; W.wlf = wlf; W.b1p = bp; W.b2p = bp + 32; W.blp = bp + 64;
+    } else {
+        float* w2tf = cur; cur += c.K2 * 4 * 256;
+        for (int i = tid; i < c.K2 * 4 * 256; i += nthr) {
+            const int j = i & 3, lane = (i >> 2) & 63, kt = (i >> 8) & 1, mt = (i >> 9) & 1, tap = i >> 10;
+            const int ci = 16 * mt + c3_row(lane & 15), co = 16 * kt + 4 * j + (lane >> 4);
+            w2tf[i] = (co < c.C2 && ci < c.C1) ? theta[c.w2 + (co * c.C1 + ci) * c.K2 + tap] : 0.f;
+        }
+        float* wltf = cur; cur += c.L2 * 2 * 256;
+        for (int i = tid; i < c.L2 * 2 * 256; i += nthr) {
+            const int j = i & 3, lane = (i >> 2) & 63, t = (i >> 8) & 1, p = i >> 9;
+            const int ch = 16 * t + c3_row(lane & 15), o = 4 * j + (lane >> 4);
+            wltf[i] = (o < c.O && ch < c.C2) ? theta[c.wl + o * c.F + ch * c.L2 + p] : 0.f;
+        }
+        W.w2tf = w2tf; W.wltf = wltf;
+    }
+    __syncthreads();
+    return W;
+}
+
+// per-wave LDS region (floats): [V records][x: V * st2 * 32 (backward scratch)][dout: V * 16][hap: V * 2 S bytes].
+// A RECORD is what the forward leaves of one variant and the backward needs: [a1: P1 * 32][a2: st2 * 32][pool argmax: P1 words],
+// padded to a multiple of 4 floats -- in LDS exactly as in the stash, so a batch's stash moves with 16-byte copies whose
+// loads are all issued before the first store (a load / store loop exposes one HBM latency per iteration).
+#define C3_COPY_F4 20   // f4 per lane a batch copy may take: V * rec / 4 <= 64 * C3_COPY_F4
+#define C3_HAP_LOADS 8  // V * 2 S <= 64 * C3_HAP_LOADS
+struct C3Wave {
+    float* rec;
+    int rec_floats, a2_off, arg_off;
+    float* x;
+    float* dout;
+    unsigned char* hap;
+    int P1, st2;
+    DEV float* a1(int v, int q) const { return rec + v * rec_floats + q * 32; }
+    DEV float* a2(int v, int p) const { return rec + v * rec_floats + a2_off + p * 32; }
+    DEV unsigned* argb(int v, int q) const { return reinterpret_cast<unsigned*>(rec + v * rec_floats + arg_off) + q; }
+};
+template <int V>
+DEV C3Wave c3_wave_region(const C3Cfg& c, float* base) {
+    C3Wave w;
+    w.rec = base;
+    w.rec_floats = c.stash_per;
+    w.a2_off = c.P1 * 32;
+    w.arg_off = c.P1 * 32 + c.st2 * 32;
+    w.P1 = c.P1; w.st2 = c.st2;
+    w.x = base + V * c.stash_per;
+    w.dout = w.x + V * c.st2 * 32;
+    w.hap = reinterpret_cast<unsigned char*>(w.dout + V * 16);
+    return w;
+}
+template <int V>
+DEV void c3_load_haplotypes(const C3Cfg& c, const C3Wave& w, const long long* __restrict__ hap, long long hap_stride, long long v0, int nv) {
+    const int lane = threadIdx.x & 63, n2s = 2 * c.S;
+    long long b[C3_HAP_LOADS];
+#pragma unroll
+    for (int k = 0; k < C3_HAP_LOADS; ++k) {  // every load is in flight before the first byte is stored
+        const int i = lane + 64 * k, v = i / n2s, e = i - v * n2s;
+        b[k] = 255;
+        if (i < V * n2s && v < nv) b[k] = hap[(size_t)(v0 + v) * hap_stride + e];
+    }
+#pragma unroll
+    for (int k = 0; k < C3_HAP_LOADS; ++k) {
+        const int i = lane + 64 * k;
+        if (i < V * n2s) w.hap[i] = (b[k] >= 0 && b[k] < 5) ? (unsigned char)b[k] : (unsigned char)255;  // anything else matches no one-hot channel
+    }
+}
+// the records of a batch: stash -> LDS (zeros for variants beyond the end) / LDS -> stash
+template <int V>
+DEV void c3_load_records(const C3Wave& w, const float* __restrict__ src, int nv) {
+    const int lane = threadIdx.x & 63, have = nv * w.rec_floats / 4, all = V * w.rec_floats / 4;
+    f4 t[C3_COPY_F4];
+#pragma unroll
+    for (int k = 0; k < C3_COPY_F4; ++k) {
+        const int i = lane + 64 * k;
+        t[k] = f4{0.f, 0.f, 0.f, 0.f};
+        if (i < have) t[k] = reinterpret_cast<const f4*>(src)[i];
+    }
+#pragma unroll
+    for (int k = 0; k < C3_COPY_F4; ++k) {
+        const int i = lane + 64 * k;
+        if (i < all) reinterpret_cast<f4*>(w.rec)[i] = t[k];
+    }
+}
+DEV void c3_store_records(const C3Wave& w, float* __restrict__ dst, int nv) {
+    const int lane = threadIdx.x & 63, have = nv * w.rec_floats / 4;
+#pragma unroll
+    for (int k = 0; k < C3_COPY_F4; ++k) {
+        const int i = lane + 64 * k;
+        if (i < have) reinterpret_cast<f4*>(dst)[i] = reinterpret_cast<const f4*>(w.rec)[i];
+    }
+}
+// one-hot B operand of the first convolution for (variant v, input position pos): channel ci = 4 j + g is base (ci >> 1) of the
+// ref (ci even) / alt (ci odd) haplotype (reference data/batch.py:115-130)
+DEV f4 c3_one_hot(const C3Cfg& c, const C3Wave& w, int v, int pos, int g) {
+    const int base = w.hap[v * 2 * c.S + (g & 1) * c.S + pos];
+    const int b0 = g >> 1;
+    return f4{base == b0 ? 1.f : 0.f, base == b0 + 2 ? 1.f : 0.f, (g < 2 && base == b0 + 4) ? 1.f : 0.f, 0.f};
+}
+
+// ================================================ forward ===========================================================
+template <int V, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_forward_kernel(
+    C3Cfg c, const float* __restrict__ theta, const long long* __restrict__ hap, long long hap_stride, int n, float* __restrict__ out,
+    long long out_stride, float* __restrict__ stash) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const C3Weights W = c3_build_weights(c, theta, lds, false);
+    const int lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15, wave = uniform((int)(threadIdx.x >> 6));
+    const C3Wave w = c3_wave_region<V>(c, lds + ((c3_weight_floats(c, false) + 3) & ~3) + wave * c.per_wave);
+    const int nbatches = (n + V - 1) / V;
+    const float inv_st1 = 1.0f / (float)c.st1, inv_st2 = 1.0f / (float)c.st2;
+    const f4 b1v[2] = {*reinterpret_cast<const f4*>(W.b1p + 4 * g), *reinterpret_cast<const f4*>(W.b1p + 16 + 4 * g)};
+    const f4 b2v[2] = {*reinterpret_cast<const f4*>(W.b2p + 4 * g), *reinterpret_cast<const f4*>(W.b2p + 16 + 4 * g)};
+    const f4 blv = *reinterpret_cast<const f4*>(W.blp + 4 * g);
+    for (int batch = blockIdx.x * NW + wave; batch < nbatches; batch += gridDim.x * NW) {
+        const long long v0 = (long long)batch * V;
+        const int nv = (int)min((long long)V, (long long)n - v0);
+        c3_load_haplotypes<V>(c, w, hap, hap_stride, v0, nv);
+        c3_wave_sync();
+        // ---- conv1 (+ bias) -> max-pool over column pairs -> activation -> a1 ------------------------------------------
+        for (int T = 0; T < c.n1t; ++T) {
+            const int col = 16 * T + r;
+            int v = (int)((float)col * inv_st1 + 1e-3f);
+            int p = col - v * c.st1;
+            const bool in_range = v < V;
+            v = min(v, V - 1);
+            f4 acc[2] = {b1v[0], b1v[1]};
+            for (int tap = 0; tap < c.K1; ++tap) {
+                const f4 b = c3_one_hot(c, w, v, min(p + tap, c.S - 1), g);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const f4 a = *reinterpret_cast<const f4*>(W.w1f + ((tap * 2 + mt) * 64 + lane) * 4);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc[mt] = mfma16(a[j], b[j], acc[mt]);  // ci = 4 j + g < 10: j = 3 is empty
+                }
+            }
+            const int q = p >> 1;
+            const bool store = in_range && !(p & 1) && q < c.P1;  // (p + 1 < L1 follows from q < P1 = L1 / 2)
+            unsigned bits = 0;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const f4 nxt = c3_dpp4<0x101>(acc[mt]);  // row_shl:1 -- the column to the right (position p + 1 of the same variant)
+                f4 m;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool second = nxt[j] > acc[mt][j];  // the first maximum wins, like ATen's max_pool1d
+                    m[j] = second ? nxt[j] : acc[mt][j];
+                    bits |= second ? 1u << (4 * mt + j) : 0u;
+                }
+                if (store) *reinterpret_cast<f4*>(w.a1(v, q) + 16 * mt + 4 * g) = c3_act4(c.act1, m);
+            }
+            if (store) reinterpret_cast<unsigned char*>(w.argb(v, q))[g] = (unsigned char)bits;
+        }
+        c3_wave_sync();
+        // ---- conv2 (+ bias) -> activation -> a2 --------------------------------------------------------------------------
+        for (int T = 0; T < c.n2t; ++T) {
+            const int col = 16 * T + r;
+            int v = (int)((float)col * inv_st2 + 1e-3f);
+            const int p = col - v * c.st2;
+            const bool valid = v < V && p < c.L2;
+            v = min(v, V - 1);
+            f4 acc[2] = {b2v[0], b2v[1]};
+            for (int tap = 0; tap < c.K2; ++tap) {
+                const float* src = w.a1(v, min(p + tap, c.P1 - 1)) + 4 * g;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    const f4 b = *reinterpret_cast<const f4*>(src + 16 * kt);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        acc[mt] = c3_mfma4(*reinterpret_cast<const f4*>(W.w2f + (((tap * 2 + mt) * 2 + kt) * 64 + lane) * 4), b, acc[mt]);
+                }
+            }
+            if (v < V && p < c.st2 && col < V * c.st2) {  // (padding columns hold zeros: they travel with the record)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) *reinterpret_cast<f4*>(w.a2(v, p) + 16 * mt + 4 * g) = valid ? c3_act4(c.act2, acc[mt]) : c3_zero();
+            }
+        }
+        c3_wave_sync();
+        // ---- flatten + linear: a column per variant ------------------------------------------------------------------------
+        {
+            const int v = min(r, V - 1);
+            f4 acc = blv;
+            for (int p = 0; p < c.L2; ++p)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    acc = c3_mfma4(*reinterpret_cast<const f4*>(W.wlf + ((p * 2 + t) * 64 + lane) * 4),
+                                   *reinterpret_cast<const f4*>(w.a2(v, p) + 16 * t + 4 * g), acc);
+            if (r < nv) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (4 * j + g < c.O) out[(size_t)(v0 + r) * out_stride + 4 * j + g] = acc[j];
+            }
+        }
+        // ---- stash for the backward: the records as they lie in LDS ----------------------------------------------------------
+        if (stash) {
+            c3_wave_sync();
+            c3_store_records(w, stash + (size_t)v0 * c.stash_per, nv);
+        }
+        c3_wave_sync();
+    }
+}
+
+// ================================================ backward ==========================================================
+// K1 / K2 / L2 (kernel sizes, second convolution's output length) are compile-time: the weight gradients are register arrays
+// indexed by tap / position, and a run-time index would push them to scratch memory.
+template <int V, int NW, int K1, int K2, int L2>
+__global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_backward_kernel(
+    C3Cfg c, const float* __restrict__ theta, const long long* __restrict__ hap, long long hap_stride, int n, const float* __restrict__ d_out,
+    long long d_out_stride, const float* __restrict__ stash, float* __restrict__ gtheta) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const C3Weights W = c3_build_weights(c, theta, lds, true);
+    const int lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15, wave = uniform((int)(threadIdx.x >> 6));
+    const int m = r, kk = g;  // names of the same lane coordinates when the lane feeds an A / B operand: row (or column) m, k-slot kk
+    const C3Wave w = c3_wave_region<V>(c, lds + ((c3_weight_floats(c, true) + 3) & ~3) + wave * c.per_wave);
+    const int nbatches = (n + V - 1) / V;
+    const float inv_st2 = 1.0f / (float)c.st2, inv_p1 = 1.0f / (float)c.P1;
+    // register-resident weight gradients over every variant this wave sees.  C layout: acc[j] of lane (g, col) = row 4 g + j.
+    f4 gw1[K1][2], gw2[K2][2][2], gwl[L2][2];  // rows = out channels (position order) | linear outputs; cols below
+    f4 gb1[2] = {c3_zero(), c3_zero()}, gb2[2] = {c3_zero(), c3_zero()};  // per-lane partial sums over this lane's columns
+    float gbl = 0.f;
+#pragma unroll
+    for (int k = 0; k < K1; ++k) gw1[k][0] = gw1[k][1] = c3_zero();
+#pragma unroll
+    for (int k = 0; k < K2; ++k) gw2[k][0][0] = gw2[k][0][1] = gw2[k][1][0] = gw2[k][1][1] = c3_zero();
+#pragma unroll
+    for (int k = 0; k < L2; ++k) gwl[k][0] = gwl[k][1] = c3_zero();
+    for (int batch = blockIdx.x * NW + wave; batch < nbatches; batch += gridDim.x * NW) {
+        const long long v0 = (long long)batch * V;
+        const int nv = (int)min((long long)V, (long long)n - v0);
+        // ---- this batch's inputs: haplotypes, upstream gradient, the forward's stash ------------------------------------
+        c3_load_haplotypes<V>(c, w, hap, hap_stride, v0, nv);
+        c3_load_records<V>(w, stash + (size_t)v0 * c.stash_per, nv);
+#pragma unroll
+        for (int k = 0; k < (V * 16) / 64; ++k) {
+            const int i = lane + 64 * k, v = i >> 4, o = i & 15;
+            w.dout[i] = (v < nv && o < c.O) ? d_out[(size_t)(v0 + v) * d_out_stride + o] : 0.f;
+        }
+        c3_wave_sync();
+        // ---- 1. linear: d(a2) = Wl^T d(out), a column per variant; d(bias) -------------------------------------------------
+        {
+            const int v = min(r, V - 1);
+            f4 bo;  // B operand: k = output o = 4 j + g of variant column r
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bo[j] = (r < V) ? w.dout[v * 16 + 4 * j + g] : 0.f;
+#pragma unroll
+            for (int p = 0; p < L2; ++p)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const f4 d = c3_mfma4(*reinterpret_cast<const f4*>(W.wltf + ((p * 2 + t) * 64 + lane) * 4), bo, c3_zero());
+                    if (r < V) *reinterpret_cast<f4*>(w.x + (v * c.st2 + p) * 32 + 16 * t + 4 * g) = d;  // rows = channels 16 t + 4 j + g
+                }
+        }
+        c3_wave_sync();
+        // ---- 2. through the second activation: dY2 = d(a2) * act2'(a2), zero on padding columns; back to LDS for the
+        //         transposed reads; linear weight gradient ------------------------------------------------------------------
+        for (int T = 0; T < c.n2t; ++T) {
+            const int col = 16 * T + r;
+            int v = (int)((float)col * inv_st2 + 1e-3f);
+            const int p = col - v * c.st2;
+            const bool valid = v < V && p < c.L2;
+            v = min(v, V - 1);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float* px = w.x + (v * c.st2 + p) * 32 + 16 * t + 4 * g;
+                const f4 y = *reinterpret_cast<const f4*>(w.a2(v, p) + 16 * t + 4 * g);
+                f4 d = *reinterpret_cast<const f4*>(px) * c3_act_grad4(c.act2, y);
+                if (!valid) d = c3_zero();
+                if (v < V && col < V * c.st2) *reinterpret_cast<f4*>(px) = d;
+                gb2[t] = gb2[t] + d;
+            }
+        }
+        {   // dWl[o][(ch, p)] += sum_v d(out)[v][o] a2[v][p][ch]: k = variants
+#pragma unroll
+            for (int s = 0; s < V / 4; ++s) {
+                const int v = 4 * s + kk;
+                const float a = w.dout[v * 16 + m];  // A row m = output o (zero beyond O and beyond nv)
+                gbl += a;
+#pragma unroll
+                for (int p = 0; p < L2; ++p)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) gwl[p][t] = mfma16(a, w.a2(v, p)[16 * t + m], gwl[p][t]);  // B col m = element m of the block
+            }
+        }
+        c3_wave_sync();
+        // ---- 3. second convolution's weight gradient: dW2_k[co][ci] += sum_cols dY2[co][col] a1[ci][col + k] ----------------
+        for (int s = 0; s < (V * c.st2) / 4; ++s) {
+            const int col = 4 * s + kk;
+            const int v = (int)((float)col * inv_st2 + 1e-3f), p = col - v * c.st2;
+            const float a0 = w.x[col * 32 + m], a1v = w.x[col * 32 + 16 + m];  // rows = element m of channel block 0 / 1
+#pragma unroll
+            for (int tap = 0; tap < K2; ++tap) {
+                const float* src = w.a1(v, min(p + tap, c.P1 - 1)) + m;  // (padding columns: dY2 is zero there)
+                const float b0 = src[0], b1 = src[16];
+                gw2[tap][0][0] = mfma16(a0, b0, gw2[tap][0][0]);
+                gw2[tap][0][1] = mfma16(a0, b1, gw2[tap][0][1]);
+                gw2[tap][1][0] = mfma16(a1v, b0, gw2[tap][1][0]);
+                gw2[tap][1][1] = mfma16(a1v, b1, gw2[tap][1][1]);
+            }
+        }
+        c3_wave_sync();
+        // ---- 4. second convolution's input gradient (gather with the transposed weights), through the first activation:
+        //         d(pooled)[v][q] -> written over a1[v][q] (each lane reads its block of a1 before it overwrites it) ---------------
+        for (int T = 0; T < c.nPt; ++T) {
+            const int idx = 16 * T + r;  // flat (variant, pooled position)
+            int v = (int)((float)idx * inv_p1 + 1e-3f);
+            const int q = idx - v * c.P1;
+            const bool valid = v < V;
+            v = min(v, V - 1);
+            f4 acc[2] = {c3_zero(), c3_zero()};
+#pragma unroll
+            for (int tap = 0; tap < K2; ++tap) {
+                const int p = q - tap;
+                const bool ok = valid && p >= 0 && p < c.L2;
+                const float* src = w.x + (v * c.st2 + (ok ? p : 0)) * 32 + 4 * g;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    f4 b = *reinterpret_cast<const f4*>(src + 16 * kt);
+                    if (!ok) b = c3_zero();
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        acc[mt] = c3_mfma4(*reinterpret_cast<const f4*>(W.w2tf + (((tap * 2 + mt) * 2 + kt) * 64 + lane) * 4), b, acc[mt]);
+                }
+            }
+            if (valid) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    float* pa = w.a1(v, q) + 16 * mt + 4 * g;
+                    const f4 d = acc[mt] * c3_act_grad4(c.act1, *reinterpret_cast<const f4*>(pa));
+                    *reinterpret_cast<f4*>(pa) = d;
+                    gb1[mt] = gb1[mt] + d;  // the pool routes every pooled gradient to exactly one position: d(bias1) = its sum
+                }
+            }
+        }
+        c3_wave_sync();
+        // ---- 5. first convolution's weight gradient from the pooled gradient, split by the pool's argmax:
+        //         dW1_k[co][ci] += sum_(v,q) [arg = 0] dP one_hot[2 q + k] + [arg = 1] dP one_hot[2 q + 1 + k] -----------------------
+        for (int s = 0; s < (V * c.P1 + 3) / 4; ++s) {
+            const int idx = 4 * s + kk;
+            const bool valid = idx < V * c.P1;
+            const int ii = valid ? idx : 0;
+            const int v = (int)((float)ii * inv_p1 + 1e-3f), q = ii - v * c.P1;
+            const unsigned word = *w.argb(v, q);
+            float a[2][2];  // [argmax][channel block]
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const float d = valid ? w.a1(v, q)[16 * mt + m] : 0.f;
+                const bool second = (word >> (8 * (m >> 2) + 4 * mt + (m & 3))) & 1u;  // byte g' = m >> 2, bit 4 mt + j' (j' = m & 3)
+                a[0][mt] = second ? 0.f : d;
+                a[1][mt] = second ? d : 0.f;
+            }
+            // one-hot B operands of input positions 2 q .. 2 q + K1: column m = input channel (base m >> 1 of the ref / alt haplotype)
+            float oh[K1 + 1];
+#pragma unroll
+            for (int off = 0; off <= K1; ++off) {
+                oh[off] = 0.f;
+                if (m < 10) {
+                    const int base = w.hap[v * 2 * c.S + (m & 1) * c.S + min(2 * q + off, c.S - 1)];
+                    oh[off] = base == (m >> 1) ? 1.f : 0.f;
+                }
+            }
+#pragma unroll
+            for (int tap = 0; tap < K1; ++tap)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    gw1[tap][mt] = mfma16(a[0][mt], oh[tap], gw1[tap][mt]);
+                    gw1[tap][mt] = mfma16(a[1][mt], oh[tap + 1], gw1[tap][mt]);
+                }
+        }
+        c3_wave_sync();
+    }
+    // ---- the register-resident gradients reach global memory once per wave -----------------------------------------------
+    // C layout: acc[j] of lane (g, col) is row rho = 4 g + j; rows are in position order (channel 16 t + c3_row(rho)), columns too.
+#pragma unroll
+    for (int tap = 0; tap < K1; ++tap)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = 16 * mt + c3_row(4 * g + j), ci = r;  // conv1's columns are the input channels themselves
+                if (co < c.C1 && ci < 10) atomicAdd(&gtheta[c.w1 + (co * 10 + ci) * K1 + tap], gw1[tap][mt][j]);
+            }
+#pragma unroll
+    for (int tap = 0; tap < K2; ++tap)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int co = 16 * mt + c3_row(4 * g + j), ci = 16 * kt + c3_row(r);
+                    if (co < c.C2 && ci < c.C1) atomicAdd(&gtheta[c.w2 + (co * c.C1 + ci) * K2 + tap], gw2[tap][mt][kt][j]);
+                }
+#pragma unroll
+    for (int p = 0; p < L2; ++p)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int o = 4 * g + j, ch = 16 * t + c3_row(r);  // A rows were the outputs themselves
+                if (o < c.O && ch < c.C2) atomicAdd(&gtheta[c.wl + o * c.F + ch * L2 + p], gwl[p][t][j]);
+            }
+    // biases: per-lane partial sums over columns (lanes r) of the C-layout gradients: rows 16 t + 4 j + g
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s1 = gb1[t][j], s2 = gb2[t][j];
+            s1 += dpp_mov<0xB1>(s1); s1 += dpp_mov<0x4E>(s1); s1 += dpp_mov<0x124>(s1); s1 += dpp_mov<0x128>(s1);
+            s2 += dpp_mov<0xB1>(s2); s2 += dpp_mov<0x4E>(s2); s2 += dpp_mov<0x124>(s2); s2 += dpp_mov<0x128>(s2);
+            const int ch = 16 * t + 4 * j + g;
+            if (r == 0 && ch < c.C1) atomicAdd(&gtheta[c.b1 + ch], s1);
+            if (r == 0 && ch < c.C2) atomicAdd(&gtheta[c.b2 + ch], s2);
+        }
+    {
+        const float tot = group_sum(gbl);  // over the k-slots: lanes (m, *) hold d(bias)[o = m]
+        if (g == 0 && m < c.O) atomicAdd(&gtheta[c.bl + m], tot);
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------
+// `V`: variants per wave and batch of the kernel the configuration is for (tile counts and the wave's LDS region depend on it)
+static bool cnn3_config(const PmtModel* m, C3Cfg* c, int V) {
+    if (m->force_cnn == 1 || m->force_cnn == 2) return false;
+    const PmtCnn* n = &m->cnn;
+    if (n->n_layers != 7) return false;
+    const PmtCnnLayer* L = n->layers;
+    const bool act1 = L[2].kind == PMT_CNN_LEAKY_RELU || L[2].kind == PMT_CNN_SELU, act2 = L[4].kind == PMT_CNN_LEAKY_RELU || L[4].kind == PMT_CNN_SELU;
+    if (L[0].kind != PMT_CNN_CONV || L[1].kind != PMT_CNN_POOL || !act1 || L[3].kind != PMT_CNN_CONV || !act2 ||
+        L[5].kind != PMT_CNN_FLATTEN || L[6].kind != PMT_CNN_LINEAR)
+        return false;
+    for (int l = 0; l < 4; l += 3)
+        if (L[l].stride != 1 || L[l].padding != 0 || L[l].dilation != 1 || L[l].kernel < 1 || L[l].kernel > C3_MAXK || L[l].out_ch > 32) return false;
+    if (L[1].kernel != 2 || L[1].stride != 2 || L[1].padding != 0 || L[1].dilation != 1) return false;
+    if (L[0].in_ch != 10 || L[6].out_ch > 16 || L[3].out_len > C3_MAXK || L[3].out_len < 1) return false;
+    if (L[0].kernel != 3 || L[3].kernel != 3 || L[3].out_len != 7) return false;  // the backward instance compiled below: <K1 = 3, K2 = 3, L2 = 7>
+    c->S = n->seq_len; c->K1 = L[0].kernel; c->L1 = L[0].out_len; c->P1 = L[1].out_len; c->K2 = L[3].kernel; c->L2 = L[3].out_len;
+    c->C1 = L[0].out_ch; c->C2 = L[3].out_ch; c->F = c->C2 * c->L2; c->O = L[6].out_ch;
+    if (c->L1 != c->S - c->K1 + 1 || c->P1 != c->L1 / 2 || c->L2 != c->P1 - c->K2 + 1 || L[3].in_ch != c->C1 || L[6].in_ch * L[6].in_len != c->F) return false;
+    c->st1 = (c->L1 + 1) & ~1;
+    c->st2 = c->L2 <= 4 ? 4 : 8;  // V * st2 is a multiple of 16: whole tiles, and the columns split evenly over the k-slots
+    c->n1t = (V * c->st1 + 15) / 16;
+    c->n2t = (V * c->st2 + 15) / 16;
+    c->nPt = (V * c->P1 + 15) / 16;
+    c->act1 = L[2].kind; c->act2 = L[4].kind;
+    c->w1 = L[0].w_src; c->b1 = L[0].b_src; c->w2 = L[3].w_src; c->b2 = L[3].b_src; c->wl = L[6].w_src; c->bl = L[6].b_src;
+    c->stash_per = (c->P1 * 32 + c->st2 * 32 + c->P1 + 3) & ~3;  // one record (C3Wave)
+    if (V * c->stash_per > 4 * 64 * C3_COPY_F4 || V * 2 * c->S > 64 * C3_HAP_LOADS || (V * c->st2) % 16 != 0) return false;
+    const int hap_floats = (V * 2 * c->S + 3) / 4;
+    c->per_wave = (V * c->stash_per + V * c->st2 * 32 + V * 16 + hap_floats + 3) & ~3;
+    return true;
+}
+static size_t cnn3_lds_bytes(const C3Cfg* c, bool backward, int nw) {
+    const int wf = backward ? c->K2 * 4 * 256 + c->L2 * 2 * 256 : c->K1 * 2 * 256 + c->K2 * 4 * 256 + c->L2 * 2 * 256 + 80;
+    return ((size_t)((wf + 3) & ~3) + (size_t)nw * c->per_wave) * sizeof(float);
+}
+static bool cnn3_covers(const PmtModel* m, C3Cfg* fwd, C3Cfg* bwd) {
+    return cnn3_config(m, fwd, C3_FWD_V) && cnn3_config(m, bwd, C3_BWD_V) && cnn3_lds_bytes(fwd, false, C3_FWD_NW) <= 160 * 1024 &&
+           cnn3_lds_bytes(bwd, true, C3_BWD_NW) <= 160 * 1024;
+}
+
+// floats of stash per variant, 0 when these kernels do not cover the model (pmt_cnn_stash_floats asks here first)
+extern "C" size_t pmt_cnn3_stash_floats(const PmtModel* m) {
+    C3Cfg f, b;
+    return (m && cnn3_covers(m, &f, &b)) ? (size_t)b.stash_per : 0;
+}
+
+static int cnn3_grid(int n, int v, int nw) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const long long batches = ((long long)n + v - 1) / v, wgs = (batches + nw - 1) / nw;
+    return (int)(wgs < cus ? wgs : cus);
+}
+
+// 0 = done, 1 = configuration not covered (the caller runs the other kernels), < 0 = error
+extern "C" int pmt_cnn3_try_forward(const PmtModel* model_host, const float* theta, const int64_t* haplotypes, int64_t hap_stride, int32_t n,
+                                    float* out, int64_t out_stride, float* stash, void* stream) {
+    C3Cfg c, cb;
+    if (!cnn3_covers(model_host, &c, &cb)) return 1;
+    const size_t lds = cnn3_lds_bytes(&c, false, C3_FWD_NW);
+    auto kernel = pmt_cnn3_forward_kernel<C3_FWD_V, C3_FWD_NW>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PMT_E_LAUNCH;
+    hipLaunchKernelGGL(kernel, dim3(cnn3_grid(n, C3_FWD_V, C3_FWD_NW)), dim3(64 * C3_FWD_NW), lds, reinterpret_cast<hipStream_t>(stream), c, theta,
+                       (const long long*)haplotypes, (long long)hap_stride, n, out, (long long)out_stride, stash);
+    return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
+}
+
+extern "C" int pmt_cnn3_try_backward(const PmtModel* model_host, const float* theta, const int64_t* haplotypes, int64_t hap_stride, int32_t n,
+                                     const float* d_out, int64_t d_out_stride, const float* stash, float* grad_theta, void* stream) {
+    C3Cfg cf, c;
+    if (!stash || !cnn3_covers(model_host, &cf, &c)) return 1;
+    const size_t lds = cnn3_lds_bytes(&c, true, C3_BWD_NW);
+    auto kernel = pmt_cnn3_backward_kernel<C3_BWD_V, C3_BWD_NW, 3, 3, 7>;  // (cnn3_config admits exactly the instances compiled here)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PMT_E_LAUNCH;
+    hipLaunchKernelGGL(kernel, dim3(cnn3_grid(n, C3_BWD_V, C3_BWD_NW)), dim3(64 * C3_BWD_NW), lds, reinterpret_cast<hipStream_t>(stream), c, theta,
+                       (const long long*)haplotypes, (long long)hap_stride, n, d_out, (long long)d_out_stride, stash, grad_theta);
+    return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
+}

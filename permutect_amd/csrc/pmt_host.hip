@@ -38,7 +38,7 @@ extern "C" int pmt_stash_slots(const PmtModel* m) { return (m->read_mlp.n_ops - 
 // and the reducer 4 tiles wide up to a last LINEAR 4 -> 1, feature_dim 1 tile.  Anything else runs the generic shape.
 // 2 = ShapeP0X: additionally every width equals the production hyperparameters' (61 read features, read width 30,
 // d_model 60, d_ffn 20, feature_dim 10), which that instance has compiled in.
-// PMT_SHAPE=any / PMT_SHAPE=tile in the environment force the generic / the tile-exact instance (the parity tests cover all).
+// PmtModel.force_shape = 2 / 1 forces the generic / the tile-exact instance (the parity tests cover all).
 static int tiles_of(int dim) { return (dim + 15) / 16; }
 static bool mlp_ops_have_width(const PmtModel* m, const PmtMlp* mlp, int first, int last, int width) {
     for (int i = first; i < last; ++i) {
@@ -63,8 +63,7 @@ static bool mlp_ops_have_tiles(const PmtModel* m, const PmtMlp* mlp, int first, 
     return true;
 }
 extern "C" int pmt_shape_id(const PmtModel* m) {
-    const char* force = getenv("PMT_SHAPE");
-    if (force && strcmp(force, "any") == 0) return 0;
+    if (m->force_shape == 2) return 0;
     const PmtMlp* rm = &m->read_mlp;
     const PmtMlp* red = &m->reducer;
     if (rm->n_ops < 1 || red->n_ops < 1 || m->num_blocks < 0) return 0;
@@ -78,7 +77,7 @@ extern "C" int pmt_shape_id(const PmtModel* m) {
                     tiles_of(m->d_model) == 4 && m->d_ffn >= 2 && mlp_ops_have_tiles(m, red, 0, red->n_ops - 1, 4) &&
                     tiles_of(Ll->in_dim) == 4 && tiles_of(Ll->out_dim) == 1 && tiles_of(m->feature_dim) == 1;
     if (!ok) return 0;
-    if (force && strcmp(force, "tile") == 0) return 1;
+    if (m->force_shape == 1) return 1;
     const bool exact = m->num_read_features == 61 && Lf->in_dim == 61 && Lf->out_dim == 30 && mlp_ops_have_width(m, rm, 1, rm->n_ops, 30) &&
                        m->read_embed_dim == 30 && m->d_model == 60 && m->d_ffn == 20 &&
                        mlp_ops_have_width(m, red, 0, red->n_ops - 1, 60) && Ll->in_dim == 60 && Ll->out_dim == 10 && m->feature_dim == 10;

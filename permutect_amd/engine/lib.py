@@ -85,7 +85,8 @@ class PmtModel(C.Structure):
                 ("translation_src", i32), ("translation_pvec", i32), ("rotation_lin", i32),
                 ("read_mlp", PmtMlp), ("reducer", PmtMlp), ("row_mlp", PmtMlp * 3), ("blocks", PmtBlock * MAX_BLOCKS), ("head", PmtHead), ("cnn", PmtCnn),
                 ("lin", PmtLinear * MAX_LINEAR), ("n_fwd_sched", i32), ("n_bwd_sched", i32),
-                ("fwd_sched", PmtStage * MAX_SCHED), ("bwd_sched", PmtStage * MAX_SCHED)]
+                ("fwd_sched", PmtStage * MAX_SCHED), ("bwd_sched", PmtStage * MAX_SCHED),
+                ("force_shape", i32), ("force_cnn", i32), ("cnn_debug", i32), ("reserved_sel", i32)]
 
 
 class PmtBatch(C.Structure):
