@@ -47,8 +47,6 @@ extern "C" {
 #define PMT_MAX_SKIP_LAYERS 4
 #define PMT_MAX_BLOCKS 16
 #define PMT_MAX_LINEAR 96
-#define PMT_MAX_SCHED 192       /* entries of a weight-staging schedule */
-#define PMT_STAGE_FLOATS 4608   /* floats per LDS weight-staging buffer: 4096 of fragments + 512 of vectors */
 #define PMT_GROUP_WAVES 8       /* waves per workgroup */
 #define PMT_GROUP_TILES 16      /* 16-read tiles per group (8 waves x 2 tiles) */
 #define PMT_GROUP_MAX_SETS 64   /* read sets (variants) per group */
@@ -67,10 +65,6 @@ typedef struct PmtLinear {
     int32_t b_pvec;      /* packed: bias in tile-position order, -1 = no bias                       */
     int32_t w_src;       /* natural-layout source of W: offset into theta (>=0) or phi (<= -2: -(off+2)) */
     int32_t b_src;       /* same for the bias, -1 = none                                            */
-    int32_t w_stage;     /* floats staged into LDS with the forward fragments: [w_frag, w_frag + w_stage) holds the
-                            fragments, then this linear's bias (and, for a block's first projection, the block's
-                            per-feature vectors); a multiple of 256, <= PMT_STAGE_FLOATS.  For a ref/alt pair the
-                            ref linear's range covers both sides and the alt linear's w_stage is 0.             */
     int32_t out_split;   /* 0, or h: the 2h output rows are laid out as two 16-row tiles (rows 0..h-1 -> tile 0,
                             rows h..2h-1 -> tile 1) so that z1 / z2 of the gating unit are tile aligned       */
     int32_t wb_frag;     /* packed: W as THREE bf16 pieces (hi + mid + lo = the fp32 value) in the operand order of
@@ -83,10 +77,6 @@ typedef struct PmtLinear {
                             Written by pmt_pack_params; lets pmt_backward add a block with four atomics and no index
                             arithmetic.  -1 = none                                                                */
 } PmtLinear;
-
-typedef struct PmtStage {
-    int32_t off, n;     /* range [off, off + n) of the packed buffer, n a multiple of 256 and <= PMT_STAGE_FLOATS */
-} PmtStage;
 
 #define PMT_OP_LINEAR 0         /* y = W x + b, optional SELU after   (reference mlp.py:55-61)          */
 #define PMT_OP_SKIP 1           /* y = x + alpha * f(x), f = (SELU, Linear) x n   (reference mlp.py:15-22) */
@@ -184,12 +174,6 @@ typedef struct PmtModel {
     PmtHead head;
     PmtCnn cnn;                 /* haplotypes_cnn */
     PmtLinear lin[PMT_MAX_LINEAR];
-    /* Weight-staging schedules (filled by pmt_build_schedules): the ranges of the packed buffer in the order the
-     * forward / backward kernels consume them.  The kernels DMA entry i+1 into LDS while computing with entry i.
-     * A wrong schedule costs speed, never correctness (the kernel re-stages synchronously and raises a debug flag). */
-    int32_t n_fwd_sched, n_bwd_sched;
-    PmtStage fwd_sched[PMT_MAX_SCHED];
-    PmtStage bwd_sched[PMT_MAX_SCHED];
     /* Kernel-instance selection, part of the descriptor (the library reads no environment variables and keeps no state).
      * 0 everywhere = the library's own choice; the other values exist so that the parity tests can run every instance. */
     int32_t force_shape;        /* read-set kernels: 0 auto, 1 at most the tile-exact instance, 2 the generic instance   */
@@ -214,7 +198,7 @@ typedef struct PmtBatch {
     const int32_t* group_start;     /* device [G+1] first variant of each group (pmt_plan_groups) */
     const int32_t* group_tile_base; /* device [G+1] first stash tile of each group (pmt_plan_groups) */
     int64_t total_tiles;            /* host value of group_tile_base[G] (sizes the stash)             */
-    int32_t* debug_flags;           /* device, optional [64]: [0] counts weight-staging schedule misses, [1] development
+    int32_t* debug_flags;           /* device, optional [64]: [0] unused, [1] development
                                        switches of the backward kernel (0 in production), [8:56] 24 x u64 cycle counters */
     const int32_t* group_span;      /* device [G][6] or NULL.  With it a group may cover only PART of a read set (read sets
                                        beyond one workgroup, pmt_plan_groups_split): v0, v1 (variants [v0, v1)), ref_begin,
@@ -362,9 +346,6 @@ typedef struct PmtRecordArgs {
     const float* source_b;
 } PmtRecordArgs;
 int pmt_record_losses(const PmtRecordArgs* args, float* histograms, void* stream);
-
-/* Fills model->fwd_sched / bwd_sched from the rest of the descriptor (host, in place). */
-int pmt_build_schedules(PmtModel* model);
 
 /* Partition variants into register-resident groups: greedy over consecutive variants so that each group has
  * <= PMT_GROUP_MAX_SETS sets and its tiles fit the workgroup: ref tiles and alt tiles go to disjoint waves, two per wave,

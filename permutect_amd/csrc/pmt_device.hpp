@@ -418,57 +418,6 @@ DEV TileMeta tile_meta(const GroupGeom& gg, int rt, const int* s_off) {
 extern "C" int pmt_stash_slots(const PmtModel* m);  // host helper (pmt_host.hip)
 extern "C" int pmt_shape_id(const PmtModel* m);     // host: 2 = ShapeP0X (exact widths), 1 = ShapeP0 (exact tiles), 0 = ShapeAny
 
-// ---- LDS weight staging ------------------------------------------------------------------------------------------
-// Every linear's A fragments are consumed by all waves of the workgroup, so they are staged ONCE per workgroup into
-// LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPRs), double buffered: while the waves
-// run the MFMAs of schedule entry i out of one buffer, entry i+1 lands in the other.  One workgroup barrier per
-// entry.  The order of entries comes from the descriptor (pmt_build_schedules); each acquire names the range it
-// needs, and a mismatch is repaired by a synchronous re-stage (slower, still correct) and counted in debug_flags[0].
-struct WStage {
-    float* buf;               // LDS, 2 * PMT_STAGE_FLOATS floats, 16-byte aligned
-    const PmtStage* sched;    // device descriptor array
-    int n;                    // entries
-    int idx;                  // next entry to be acquired (its DMA is already in flight)
-    const float* packed;
-    int* debug_flags;
-};
-
-DEV void wstage_dma(const WStage& ws, int off, int nfloats, float* dst) {
-    const int lane = threadIdx.x & 63, wave = uniform((int)(threadIdx.x >> 6));
-    const int nchunks = nfloats >> 8;
-    for (int c = wave; c < nchunks; c += PMT_WAVES)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ws.packed + off + c * 256 + lane * 4),
-                                         (__attribute__((address_space(3))) void*)(dst + c * 256), 16, 0, 0);
-}
-
-template <bool STAGED>
-DEV void wstage_begin(WStage& ws) {  // kick off entry 0; call once, before the first acquire
-    ws.idx = 0;
-    if (STAGED && ws.n > 0) wstage_dma(ws, uniform(ws.sched[0].off), uniform(ws.sched[0].n), ws.buf);
-}
-
-// Returns the LDS address of the fragments at packed[off .. off + nfloats).  Must be called by ALL threads of the
-// workgroup in uniform control flow.
-template <bool STAGED>
-DEV const float* wstage_acquire(WStage& ws, int off, int nfloats) {
-    if (!STAGED) return ws.packed + off;  // direct path: fragments and vectors come straight from L2 / HBM
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
-    __syncthreads();                                   // everybody's have, and nobody still reads the other buffer
-    const int i = ws.idx;
-    if (i < ws.n && uniform(ws.sched[i].off) == off) {
-        if (i + 1 < ws.n) wstage_dma(ws, uniform(ws.sched[i + 1].off), uniform(ws.sched[i + 1].n), ws.buf + ((i + 1) & 1) * PMT_STAGE_FLOATS);
-        ws.idx = i + 1;
-        return ws.buf + (i & 1) * PMT_STAGE_FLOATS;
-    }
-    // schedule miss: stage synchronously into the buffer that is free (entry i, if any, stays parked in its buffer)
-    if (ws.debug_flags != nullptr && threadIdx.x == 0) atomicAdd(ws.debug_flags, 1);
-    float* dst = ws.buf + ((i + 1) & 1) * PMT_STAGE_FLOATS;
-    wstage_dma(ws, off, nfloats, dst);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    return dst;
-}
-
 DEV int frag_floats_dev(const PmtLinear& L) {
     const int h = uniform(L.out_split);
     const int out_v = h > 0 ? 16 + h : uniform(L.out_dim);

@@ -7,17 +7,11 @@
 #include "pmt_device.hpp"
 #include "pmt_mlp_device.hpp"
 
-// LDS weight staging in the forward: with 8 waves (2 per SIMD) the L2 latency of the fragment loads is already
-// covered by the partner wave and the one-fragment-ahead prefetch in linear_acc, and the per-linear workgroup barrier
-// of the staged path costs more than it saves (measured 2.46 ms staged vs 2.0 ms direct at B = 65536, P0).
-#define FWD_STAGED false
-
 struct FwdShared {
     int off[2][PMT_GROUP_MAX_SETS + 1];
     float zsum[3][PMT_GROUP_MAX_SETS][2][16];
     float fsum[PMT_GROUP_MAX_SETS][2][PMT_MAX_WIDTH];
     float hsum[PMT_GROUP_MAX_SETS][PMT_MAX_CLUSTERS + 2];
-    float wbuf[FWD_STAGED ? 2 * PMT_STAGE_FLOATS : 4];  // LDS weight staging, double buffered
 };
 
 // ---- input decode ------------------------------------------------------------------------------------------------
@@ -99,8 +93,6 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
             stash_tile[rt] = stash + (size_t)(bt.group_tile_base[blockIdx.x] + gg.tile_begin + rt) * (size_t)(stash_num_slots(M) * PMT_SLOT_FLOATS);
     }
 
-    WStage ws{&sh.wbuf[0], M->fwd_sched, uniform(M->n_fwd_sched), 0, packed, bt.debug_flags};
-    wstage_begin<FWD_STAGED>(ws);
     int slot = 0;
     const int n_read_ops = uniform(M->read_mlp.n_ops), n_red_ops = uniform(M->reducer.n_ops);
 
@@ -132,14 +124,14 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
         }
         if constexpr (EX) {
             f4 xr[PMT_RT][NTR];
-            run_linear_op<FWD_STAGED, NTF, NTR, true, S::DIM_F, S::DIM_R, S::BF16>(M, M->read_mlp.ops[0], xr, xf, g, ws);
-            run_mlp<TRAIN, FWD_STAGED, NTR, true, S::DIM_R, S::BF16>(M, M->read_mlp, xr, theta, g, mask_all, stash_tile, slot, 1, ws, 1, n_read_ops);
+            run_linear_op<NTF, NTR, true, S::DIM_F, S::DIM_R, S::BF16>(M, M->read_mlp.ops[0], xr, xf, g, packed);
+            run_mlp<TRAIN, NTR, true, S::DIM_R, S::BF16>(M, M->read_mlp, xr, theta, g, mask_all, stash_tile, slot, 1, packed, 1, n_read_ops);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
                 for (int t = 0; t < NTD; ++t) x[rt][t] = t < NTR ? xr[rt][t < NTR ? t : 0] : f4{0.f, 0.f, 0.f, 0.f};
         } else {
-            run_mlp<TRAIN, FWD_STAGED, NTD, false>(M, M->read_mlp, xf, theta, g, mask_all, stash_tile, slot, 1, ws, 0, n_read_ops);
+            run_mlp<TRAIN, NTD, false>(M, M->read_mlp, xf, theta, g, mask_all, stash_tile, slot, 1, packed, 0, n_read_ops);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
@@ -167,11 +159,10 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
         const PmtBlock& B = M->blocks[l];
         const bool first_half = !LAYERED || l == lay.slice;        // LayerNorm, proj1, SELU, per-set sums of z2
         f4 z[PMT_RT][2];
-        // staging region A of this block: [W1_ref | W1_alt | b1_ref | b1_alt | LN(D) w,b | LN(h) w,b | rho] -- everything
-        // the first half of the block reads comes out of LDS; no vector-memory load sits behind the in-flight DMA.
+        // packed region A of this block: [W1_ref | W1_alt | b1_ref | b1_alt | LN(D) w,b | LN(h) w,b | rho]
         const PmtLinear& P1r = M->lin[uniform(B.proj1[0])];
         const int baseA = uniform(P1r.w_frag);
-        const float* stA = wstage_acquire<FWD_STAGED>(ws, baseA, uniform(P1r.w_stage));
+        const float* stA = packed + baseA;
         const f4 rho = load_pvec(stA + (uniform(B.ref_reg_pvec) - baseA), 0, g);
         f4 sw[1], sb[1];
         sw[0] = load_pvec(stA + (uniform(B.sgu_norm_w_pvec) - baseA), 0, g);
@@ -280,7 +271,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
             }
             const PmtLinear& P2r = M->lin[uniform(B.proj2[0])];
             const int baseB = uniform(P2r.w_frag);
-            const float* p2_frags = wstage_acquire<FWD_STAGED>(ws, baseB, uniform(P2r.w_stage));  // [W2_ref | W2_alt | b2_ref | b2_alt]
+            const float* p2_frags = packed + baseB;  // [W2_ref | W2_alt | b2_ref | b2_alt]
             const float* bp = p2_frags + (uniform(M->lin[uniform(B.proj2[side])].b_pvec) - baseB);
 #pragma unroll
             for (int t = 0; t < NTD; ++t) {
@@ -302,16 +293,16 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
     // ---- reducer MLP, then translation + rotation ----------------------------------------------------------------
     f4 e[PMT_RT][NTE];
     if constexpr (EX) {
-        run_mlp<TRAIN, FWD_STAGED, NTD, true, S::DIM_D, S::BF16>(M, M->reducer, x, theta, g, mask_all, stash_tile, slot, 1, ws, 0, n_red_ops - 1);
+        run_mlp<TRAIN, NTD, true, S::DIM_D, S::BF16>(M, M->reducer, x, theta, g, mask_all, stash_tile, slot, 1, packed, 0, n_red_ops - 1);
         if (TRAIN && n_red_ops > 1) {
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
                 if (mask_all & (1u << rt)) stash_store<NTD>(stash_tile[rt] + slot * PMT_SLOT_FLOATS, x[rt]);
             ++slot;
         }
-        run_linear_op<FWD_STAGED, NTD, NTE, true, S::DIM_D, S::DIM_E, S::BF16>(M, M->reducer.ops[n_red_ops - 1], e, x, g, ws);
+        run_linear_op<NTD, NTE, true, S::DIM_D, S::DIM_E, S::BF16>(M, M->reducer.ops[n_red_ops - 1], e, x, g, packed);
     } else {
-        run_mlp<TRAIN, FWD_STAGED, NTD, false>(M, M->reducer, x, theta, g, mask_all, stash_tile, slot, 1, ws, 0, n_red_ops);
+        run_mlp<TRAIN, NTD, false>(M, M->reducer, x, theta, g, mask_all, stash_tile, slot, 1, packed, 0, n_red_ops);
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
@@ -320,7 +311,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
     f4 a[PMT_RT][NTE];
     {
         const PmtLinear& R = M->lin[uniform(M->rotation_lin)];
-        const float* stR = wstage_acquire<FWD_STAGED>(ws, uniform(R.w_frag), uniform(R.w_stage));  // [Q fragments | translation]
+        const float* stR = packed + uniform(R.w_frag);  // [Q fragments | translation]
 #pragma unroll
         for (int t = 0; t < NTE; ++t) {
             const f4 tr = load_pvec(stR + (uniform(M->translation_pvec) - uniform(R.w_frag)), t, g);

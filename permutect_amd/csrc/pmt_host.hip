@@ -94,7 +94,6 @@ static int check_linear(const PmtModel* m, int id, int in_dim, int out_dim, int 
     if (in_dim < 1 || out_dim < 1 || in_dim > max_in || out_dim > PMT_MAX_WIDTH) return PMT_E_UNSUPPORTED;
     if (l->w_frag < 0 || l->wt_frag < 0 || (l->w_frag & 3) || (l->wt_frag & 3)) return PMT_E_INVALID;
     if (l->b_pvec >= 0 && (l->b_pvec & 3)) return PMT_E_INVALID;
-    if (l->b_pvec >= 0 && l->w_stage > 0 && (l->b_pvec < l->w_frag || l->b_pvec >= l->w_frag + l->w_stage)) return PMT_E_INVALID;
     return PMT_OK;
 }
 
@@ -155,106 +154,6 @@ extern "C" int pmt_model_check(const PmtModel* m) {
         }
     }
     if ((rc = check_linear(m, m->rotation_lin, m->feature_dim, m->feature_dim))) return rc;
-    // staging regions: every vector that a kernel reads through the staged copy must lie inside its region
-    for (int i = 0; i < m->n_linear; ++i) {
-        const PmtLinear* l = &m->lin[i];
-        if (l->w_stage < 0 || (l->w_stage & 255) || l->w_stage > PMT_STAGE_FLOATS || (l->w_frag & 255)) return PMT_E_INVALID;
-    }
-    for (int l = 0; l < m->num_blocks; ++l) {
-        const PmtBlock* b = &m->blocks[l];
-        const PmtLinear *p1 = &m->lin[b->proj1[0]], *p1a = &m->lin[b->proj1[1]], *p2 = &m->lin[b->proj2[0]], *p2a = &m->lin[b->proj2[1]];
-        const int lo1 = p1->w_frag, hi1 = p1->w_frag + p1->w_stage, lo2 = p2->w_frag, hi2 = p2->w_frag + p2->w_stage;
-        const int v1[] = {b->norm_w_pvec, b->norm_b_pvec, b->sgu_norm_w_pvec, b->sgu_norm_b_pvec, b->ref_reg_pvec, p1->b_pvec, p1a->b_pvec};
-        for (int k = 0; k < 7; ++k)
-            if (v1[k] < lo1 || v1[k] + PMT_MAX_WIDTH > hi1 + PMT_MAX_WIDTH - 16 || v1[k] >= hi1) return PMT_E_INVALID;
-        if (p2->b_pvec < lo2 || p2->b_pvec >= hi2 || p2a->b_pvec < lo2 || p2a->b_pvec >= hi2) return PMT_E_INVALID;
-    }
-    {
-        const PmtLinear* r = &m->lin[m->rotation_lin];
-        if (m->translation_pvec < r->w_frag || m->translation_pvec >= r->w_frag + r->w_stage) return PMT_E_INVALID;
-    }
-    return PMT_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// weight-staging schedules: the packed ranges in the order pmt_forward_kernel / pmt_backward_kernel consume them.
-// MUST mirror the kernels' control flow (the kernels verify every entry and count mismatches in debug_flags[0]).
-// ---------------------------------------------------------------------------------------------------------------------
-static int frag_floats(const PmtLinear* l) {
-    const int out_v = l->out_split > 0 ? 16 + l->out_split : l->out_dim;
-    return ((out_v + 15) / 16) * ((l->in_dim + 15) / 16) * 256;
-}
-struct SchedBuilder {
-    PmtStage* s;
-    int n;
-    bool overflow;
-    void push(int off, int nfl) {
-        if (n >= PMT_MAX_SCHED || nfl > PMT_STAGE_FLOATS) { overflow = true; return; }
-        s[n].off = off;
-        s[n].n = nfl;
-        ++n;
-    }
-};
-static void sched_mlp_fwd_op(SchedBuilder& b, const PmtModel* m, const PmtOp* o) {
-    for (int k = 0; k < o->n_layers; ++k) b.push(m->lin[o->lin[k]].w_frag, m->lin[o->lin[k]].w_stage);
-}
-static void sched_mlp_bwd(SchedBuilder& b, const PmtModel* m, const PmtMlp* mlp, bool need_input_grad) {
-    for (int op = mlp->n_ops - 1; op >= 0; --op) {
-        const PmtOp* o = &mlp->ops[op];
-        if (o->kind == PMT_OP_LINEAR) {
-            const PmtLinear* l = &m->lin[o->lin[0]];
-            if (o->selu_after) b.push(l->w_frag, l->w_stage);
-            if (op > 0 || need_input_grad) b.push(l->wt_frag, frag_floats(l));
-        } else {
-            const PmtLinear* l1 = &m->lin[o->lin[0]];
-            const PmtLinear* l2 = &m->lin[o->lin[o->n_layers - 1]];
-            if (o->n_layers == 2) b.push(l1->w_frag, l1->w_stage);
-            b.push(l2->w_frag, l2->w_stage);
-            b.push(l2->wt_frag, frag_floats(l2));
-            if (o->n_layers == 2) b.push(l1->wt_frag, frag_floats(l1));
-        }
-    }
-}
-
-extern "C" int pmt_build_schedules(PmtModel* m) {
-    if (!m) return PMT_E_INVALID;
-    const int rc = pmt_model_check(m);
-    if (rc) return rc;
-    // proj1 / proj2 fragments of the two sides must be adjacent (ref then alt) so that one range stages both
-    for (int l = 0; l < m->num_blocks; ++l) {
-        const PmtBlock* B = &m->blocks[l];
-        const PmtLinear *p1r = &m->lin[B->proj1[0]], *p1a = &m->lin[B->proj1[1]];
-        const PmtLinear *p2r = &m->lin[B->proj2[0]], *p2a = &m->lin[B->proj2[1]];
-        if (p1a->w_frag != p1r->w_frag + frag_floats(p1r) || p1a->wt_frag != p1r->wt_frag + frag_floats(p1r) ||
-            p2a->w_frag != p2r->w_frag + frag_floats(p2r) || p2a->wt_frag != p2r->wt_frag + frag_floats(p2r))
-            return PMT_E_INVALID;
-    }
-    SchedBuilder f{m->fwd_sched, 0, false}, b{m->bwd_sched, 0, false};
-    const PmtLinear* rot = &m->lin[m->rotation_lin];
-    // ---- forward ----
-    for (int i = 0; i < m->read_mlp.n_ops; ++i) sched_mlp_fwd_op(f, m, &m->read_mlp.ops[i]);
-    for (int l = 0; l < m->num_blocks; ++l) {
-        const PmtBlock* B = &m->blocks[l];
-        f.push(m->lin[B->proj1[0]].w_frag, m->lin[B->proj1[0]].w_stage);
-        f.push(m->lin[B->proj2[0]].w_frag, m->lin[B->proj2[0]].w_stage);
-    }
-    for (int i = 0; i < m->reducer.n_ops; ++i) sched_mlp_fwd_op(f, m, &m->reducer.ops[i]);
-    f.push(rot->w_frag, rot->w_stage);
-    // ---- backward ----
-    sched_mlp_fwd_op(b, m, &m->reducer.ops[m->reducer.n_ops - 1]);  // recompute of the last reducer op
-    b.push(rot->w_frag, rot->w_stage);
-    b.push(rot->wt_frag, frag_floats(rot));
-    sched_mlp_bwd(b, m, &m->reducer, true);
-    for (int l = m->num_blocks - 1; l >= 0; --l) {
-        const PmtBlock* B = &m->blocks[l];
-        b.push(m->lin[B->proj1[0]].w_frag, m->lin[B->proj1[0]].w_stage);
-        b.push(m->lin[B->proj2[0]].wt_frag, 2 * frag_floats(&m->lin[B->proj2[0]]));
-        b.push(m->lin[B->proj1[0]].wt_frag, 2 * frag_floats(&m->lin[B->proj1[0]]));
-    }
-    sched_mlp_bwd(b, m, &m->read_mlp, false);
-    if (f.overflow || b.overflow) return PMT_E_UNSUPPORTED;
-    m->n_fwd_sched = f.n;
-    m->n_bwd_sched = b.n;
     return PMT_OK;
 }
 

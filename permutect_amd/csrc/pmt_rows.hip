@@ -49,7 +49,6 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_forward_kernel(const 
         if ((tile0 + rt) * 16 < n_rows) present |= 1u << rt;
         stash_tile[rt] = TRAIN ? stash + (size_t)(tile0 + rt) * (size_t)((n_ops - 1) * PMT_SLOT_FLOATS) : nullptr;
     }
-    WStage ws{nullptr, nullptr, 0, 0, packed, nullptr};
     f4 x[PMT_RT][PMT_NT];
     int slot = 0, op_begin = 0;
     if (in_dim > PMT_MAX_WIDTH) {  // wide first linear (checked on the host: op 0 is LINEAR)
@@ -70,7 +69,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_forward_kernel(const 
     } else {
         load_rows<PMT_NT>(x, in, in_stride, n_rows, in_dim, tile0, g);
     }
-    run_mlp<TRAIN, false, PMT_NT, false>(M, mlp, x, theta, g, present, stash_tile, slot, 1, ws, op_begin, uniform(mlp.n_ops));
+    run_mlp<TRAIN, PMT_NT, false>(M, mlp, x, theta, g, present, stash_tile, slot, 1, packed, op_begin, uniform(mlp.n_ops));
     const int r = lane & 15;
 #pragma unroll
     for (int rt = 0; rt < PMT_RT; ++rt) {

@@ -17,7 +17,6 @@ MAX_WIDTH, MAX_HALF_FFN, MAX_CLUSTERS = 64, 16, 16
 MAX_ROW_INPUT = 128
 ROWS_INFO, ROWS_ALT_COUNT, ROWS_SOURCE = 0, 1, 2
 MAX_OPS, MAX_SKIP_LAYERS, MAX_BLOCKS, MAX_LINEAR = 8, 4, 16, 96
-MAX_SCHED, STAGE_FLOATS = 192, 4608
 GROUP_WAVES, GROUP_TILES, GROUP_MAX_SETS, TILE = 8, 16, 64, 16
 READS_PACKED_U8, READS_F16, READS_F32 = 0, 1, 2
 OP_LINEAR, OP_SKIP = 0, 1
@@ -33,11 +32,7 @@ i32, i64, vp = C.c_int32, C.c_int64, C.c_void_p
 
 class PmtLinear(C.Structure):
     _fields_ = [("in_dim", i32), ("out_dim", i32), ("w_frag", i32), ("wt_frag", i32), ("b_pvec", i32),
-                ("w_src", i32), ("b_src", i32), ("w_stage", i32), ("out_split", i32), ("wb_frag", i32), ("wtb_frag", i32), ("emit_tab", i32)]
-
-
-class PmtStage(C.Structure):
-    _fields_ = [("off", i32), ("n", i32)]
+                ("w_src", i32), ("b_src", i32), ("out_split", i32), ("wb_frag", i32), ("wtb_frag", i32), ("emit_tab", i32)]
 
 
 class PmtOp(C.Structure):
@@ -84,8 +79,7 @@ class PmtModel(C.Structure):
                 ("theta_size", i32), ("phi_size", i32), ("packed_size", i32),
                 ("translation_src", i32), ("translation_pvec", i32), ("rotation_lin", i32),
                 ("read_mlp", PmtMlp), ("reducer", PmtMlp), ("row_mlp", PmtMlp * 3), ("blocks", PmtBlock * MAX_BLOCKS), ("head", PmtHead), ("cnn", PmtCnn),
-                ("lin", PmtLinear * MAX_LINEAR), ("n_fwd_sched", i32), ("n_bwd_sched", i32),
-                ("fwd_sched", PmtStage * MAX_SCHED), ("bwd_sched", PmtStage * MAX_SCHED),
+                ("lin", PmtLinear * MAX_LINEAR),
                 ("force_shape", i32), ("force_cnn", i32), ("cnn_debug", i32), ("reserved_sel", i32)]
 
 
@@ -152,7 +146,7 @@ class PmtLossInputGrads(C.Structure):
     _fields_ = [("d_logits_b", vp), ("d_logits_bk", vp), ("d_alt_count_raw", vp), ("d_source_logits", vp)]
 
 
-EXPORTS = ["pmt_abi_version", "pmt_struct_bytes", "pmt_model_check", "pmt_build_schedules", "pmt_plan_groups", "pmt_stash_bytes", "pmt_pack_params",
+EXPORTS = ["pmt_abi_version", "pmt_struct_bytes", "pmt_model_check", "pmt_plan_groups", "pmt_stash_bytes", "pmt_pack_params",
            "pmt_scan_counts", "pmt_forward", "pmt_backward", "pmt_clip_adamw",
            "pmt_rows_stash_bytes", "pmt_rows_forward", "pmt_rows_backward", "pmt_cnn_forward", "pmt_cnn_backward", "pmt_cnn_stash_floats",
            "pmt_phi_forward", "pmt_phi_backward", "pmt_build_read_index", "pmt_losses_forward", "pmt_losses_backward",
@@ -185,7 +179,6 @@ def load() -> C.CDLL:
     P = C.POINTER
     lib.pmt_abi_version.restype = i32
     lib.pmt_model_check.argtypes = [P(PmtModel)]
-    lib.pmt_build_schedules.argtypes = [P(PmtModel)]
     lib.pmt_plan_groups.argtypes = [vp, vp, i32, vp, vp, P(i32)]
     lib.pmt_stash_bytes.argtypes = [P(PmtModel), i64, i32]
     lib.pmt_stash_bytes.restype = C.c_size_t

@@ -121,7 +121,7 @@ class EnginePlan:
             b.norm_w_src, b.norm_b_src = space.offset_of(blk.norm.weight), space.offset_of(blk.norm.bias)
             b.sgu_norm_w_src, b.sgu_norm_b_src = space.offset_of(s.norm.weight), space.offset_of(s.norm.bias)
             b.ref_reg_src = space.offset_of(s.ref_regularizer)
-            # One LDS staging region per projection pair: [W_ref | W_alt | vectors used with them | pad to 256].
+            # One packed region per projection pair: [W_ref | W_alt | vectors used with them | pad to 256].
             # The first region also carries the block's LayerNorm / gating vectors.
             vecs = {}
             b.proj1[0], b.proj1[1] = self._add_linear_pair(
@@ -179,12 +179,11 @@ class EnginePlan:
 
         lib = L.load()
         L.check(lib.pmt_model_check(C.byref(d)), "pmt_model_check")
-        L.check(lib.pmt_build_schedules(C.byref(d)), "pmt_build_schedules")
         self.packed = torch.zeros(d.packed_size, dtype=torch.float32, device=device)
         self.gphi_size = d.phi_size
         raw = bytes(d)
         self.desc_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
-        self.debug_flags = torch.zeros(64, dtype=torch.int32, device=device)  # [0] staging misses, [1] debug switches, [8:56] 24 x u64 cycle counters
+        self.debug_flags = torch.zeros(64, dtype=torch.int32, device=device)  # [0] unused, [1] debug switches, [8:56] 24 x u64 cycle counters
         self.stash_slots = (d.read_mlp.n_ops - 1) + (d.num_blocks + 1) + (d.reducer.n_ops - 1)
 
     # ---- allocation helpers --------------------------------------------------------------------------------------
@@ -203,8 +202,6 @@ class EnginePlan:
         """Pad the packed cursor to a multiple of 256 floats past `start` (LDS-DMA moves 1 KiB pieces); returns the
         region length."""
         n = (self._packed_off - start + 255) // 256 * 256
-        if n > L.STAGE_FLOATS:
-            raise L.PmtError("a weight-staging region exceeds the LDS staging buffer")
         self._packed_off = start + n
         return n
 
@@ -219,13 +216,13 @@ class EnginePlan:
         nmt, nkt = (out_v + 15) // 16, (in_dim + 15) // 16
         lin.in_dim, lin.out_dim, lin.out_split = in_dim, out_dim, out_split
         if alloc:
-            # staging region: [forward fragments | bias | extra vectors | pad]; the transposed fragments follow
+            # packed region: [forward fragments | bias | extra vectors | pad]; the transposed fragments follow
             self._packed_off = (self._packed_off + 255) // 256 * 256
             lin.w_frag = self._alloc_packed(nmt * nkt * 256)
             lin.b_pvec = self._alloc_packed(nmt * 16) if has_bias else -1
             for name, n in extra_vectors:
                 out[name] = self._alloc_packed(n)
-            lin.w_stage = self._close_region(lin.w_frag)
+            self._close_region(lin.w_frag)
             lin.wt_frag = self._alloc_packed(nmt * nkt * 256)
         lin.w_src, lin.b_src = w_src, b_src
         self._n_lin += 1
@@ -245,7 +242,7 @@ class EnginePlan:
         lr.b_pvec = self._alloc_packed(nb); la.b_pvec = self._alloc_packed(nb)
         for name, n in extra_vectors:
             out[name] = self._alloc_packed(n)
-        lr.w_stage, la.w_stage = self._close_region(lr.w_frag), 0
+        self._close_region(lr.w_frag)
         lr.wt_frag = self._alloc_packed(nfl); la.wt_frag = self._alloc_packed(nfl)
         return ids[0], ids[1]
 

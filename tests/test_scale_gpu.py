@@ -1,0 +1,107 @@
+"""Parity at the reference's inference batch size (parameters.py:236-242: 8 192 read sets = 427 workgroups, two rounds of
+the backward kernel, ~107 K reads): forward, losses and EVERY parameter gradient against the oracle's autograd on the same
+seeded inputs, in all three kernel instances.  At this size every weight-gradient element is the sum of ~430 float atomics
+from as many workgroups; the tolerances are the same as at 16 read sets (tests/test_train_gpu.py).  The measured errors go
+to gpurun_out/parity_errors.jsonl (DESIGN.md section 2 quotes them)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import artifact_oracle as O
+from permutect_amd.data.batch import Batch, pack_order
+from permutect_amd.training.optimizer import FusedClipAdamW
+from tests.helpers import config_for, load_case
+from tests.test_forward_gpu import build
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(params=["auto", "tile", "any"])
+def kernel_shape(request, monkeypatch):
+    if request.param == "tile":
+        monkeypatch.setenv("PMT_SHAPE", "tile")
+        monkeypatch.setenv("PMT_CNN_STASH", "0")
+    if request.param == "any":
+        monkeypatch.setenv("PMT_SHAPE", "any")
+        monkeypatch.setenv("PMT_CNN", "general")
+    return request.param
+
+
+def record(**kw):
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "parity_errors.jsonl"), "a") as f:
+            f.write(json.dumps(kw) + "\n")
+    except OSError:
+        pass
+
+
+def synth(nb, seed):
+    from bench import synth_arrays
+    ints, floats, packed = synth_arrays(np.random.default_rng(seed), nb, "wgs")
+    # the order bench.py and the device loader give a batch (fullest workgroups); the oracle sees the same order
+    nref, nalt = ints[:, 0].astype(np.int64), ints[:, 1].astype(np.int64)
+    order = pack_order(nref, nalt)
+    rs, as_ = np.concatenate([[0], np.cumsum(nref)[:-1]]), int(nref.sum()) + np.concatenate([[0], np.cumsum(nalt)[:-1]])
+    rows = np.concatenate([np.concatenate([np.arange(rs[v], rs[v] + nref[v]) for v in order]),
+                           np.concatenate([np.arange(as_[v], as_[v] + nalt[v]) for v in order])])
+    return ints[order], floats[order], packed[rows]
+
+
+def test_forward_and_every_gradient_at_8192_read_sets(kernel_shape):
+    nb = 8192
+    _, sd, _ = load_case("p0_b16")
+    cfg = config_for("p0_b16")
+    ints, floats, packed = synth(nb, seed=11)
+    model, dev = build("p0_b16", sd)
+    model.train(True)
+    batch = Batch.from_arrays(ints, floats, packed).copy_to(dev)
+    assert batch.plan().num_groups > 256  # more than one round of the backward kernel
+    out = model.compute_batch_output(batch)
+    losses = model.compute_batch_losses(out, batch)
+    opt = FusedClipAdamW(model, lr=1e-3, weight_decay=0.01)
+    opt.zero_grad()
+    losses.total_loss.backward()
+    torch.cuda.synchronize()
+
+    i64 = torch.from_numpy(ints.astype(np.int64))
+    ob = dict(reads_re=torch.from_numpy(O.decode_packed_reads(packed).astype(np.float32)), nref=i64[:, O.REF_COUNT],
+              nalt=i64[:, O.ALT_COUNT], labels=i64[:, O.LABEL], sources=i64[:, O.SOURCE],
+              info_be=torch.from_numpy(floats[:, O.INFO_START:].astype(np.float32)), haplotypes_bh=i64[:, O.HAPLOTYPES_START:])
+    ref_out, ref_losses, ref_grads = O.train_step_grads(sd, cfg, ob)
+
+    # ---- forward: the north-star bound on the capped logit, per element; log-likelihood sums to a few ulp of THEIR OWN size --
+    logit_err = np.abs(out.logits_b.detach().cpu().numpy() - ref_out["logits_b"].detach().numpy())
+    lk, ref_lk = out.logits_bk.detach().cpu().numpy(), ref_out["logits_bk"].detach().numpy()
+    lk_err = np.abs(lk - ref_lk)
+    lk_tol = 2e-5 + 8 * np.spacing(np.abs(ref_lk).astype(np.float32))
+    feat_err = np.abs(out.features_be.detach().cpu().numpy() - ref_out["features_be"].detach().numpy()).max()
+    assert logit_err.max() <= 1e-4, logit_err.max()
+    assert np.all(lk_err <= lk_tol), (lk_err / lk_tol).max()
+    assert feat_err <= 2e-5 * max(1.0, float(np.abs(ref_out["features_be"].detach().numpy()).max()))
+    ref_total = ref_losses["total_losses_b"].detach().numpy()
+    loss_err = np.abs(losses.total_losses_b.detach().cpu().numpy() - ref_total).max()
+    assert loss_err <= 1e-4 + 1e-5 * np.abs(ref_total).max()
+
+    # ---- every parameter gradient ----------------------------------------------------------------------------------------
+    names = [n for n, _ in model.named_parameters()]
+    assert set(names) == set(ref_grads)
+    gref = np.concatenate([ref_grads[n].numpy().ravel() for n in names])
+    gour = np.concatenate([p.grad.detach().cpu().numpy().ravel() for _, p in model.named_parameters()])
+    assert np.all(np.isfinite(gour))
+    gscale = np.abs(gref).max()
+    worst, worst_name = 0.0, ""
+    for n, p in model.named_parameters():
+        ref = ref_grads[n].numpy()
+        rel = np.abs(p.grad.detach().cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-3 * gscale)
+        if rel > worst:
+            worst, worst_name = float(rel), n
+    rel_l2 = float(np.linalg.norm(gour - gref) / np.linalg.norm(gref))
+    record(test="scale_8192", instance=kernel_shape, max_logit_err=float(logit_err.max()), max_lk_err_over_tol=float((lk_err / lk_tol).max()),
+           max_feature_err=float(feat_err), max_loss_err=float(loss_err), grad_rel_l2=rel_l2, worst_tensor=worst_name, worst_tensor_rel=worst)
+    assert worst <= 5e-4, (worst_name, worst)
+    assert rel_l2 <= 1e-4, rel_l2
