@@ -67,10 +67,29 @@ class ReadsDataset:
         self.totals_by_label_l = torch.from_numpy(np.bincount(labels, minlength=3).astype(np.float32))
         sources = np.asarray(self._ints[: self._size, Data.SOURCE.idx]).astype(np.int64)
         self._num_sources = int(sources.max()) + 1 if self._size else 1
+        self._totals_slvra = None
 
     # ---- reference accessors (reference :95-112, :198-221) ---------------------------------------------------------------
     def totals_by_label(self):
         return self.totals_by_label_l
+
+    @property
+    def totals_slvra(self) -> torch.Tensor:
+        """Number of data per (source, label, variant type, ref-count bin, alt-count bin): the reference's
+        `totals_slvra` (reads_dataset.py:84-88 records every datum), one vectorised pass here.  Input of the downsampler's
+        balance fit (training/model_training.py:60)."""
+        if self._totals_slvra is None:
+            from permutect_amd.enums import Label, Variation
+            from permutect_amd.training.downsampler import (COUNT_BIN_SKIP, MAX_ALT_COUNT, MAX_REF_COUNT, NUM_ALT_COUNT_BINS,
+                                                            NUM_REF_COUNT_BINS)
+            ints = np.asarray(self._ints[: self._size]).astype(np.int64)
+            s, lab, v = ints[:, Data.SOURCE.idx], ints[:, Data.LABEL.idx], ints[:, Data.VARIANT_TYPE.idx]
+            r = np.minimum(ints[:, Data.REF_COUNT.idx], MAX_REF_COUNT) // COUNT_BIN_SKIP
+            a = (np.minimum(ints[:, Data.ALT_COUNT.idx], MAX_ALT_COUNT) - 1) // COUNT_BIN_SKIP
+            shape = (self._num_sources, len(Label), len(Variation), NUM_REF_COUNT_BINS, NUM_ALT_COUNT_BINS)
+            flat = np.ravel_multi_index((s, lab, v, r, a), shape) if self._size else np.zeros(0, dtype=np.int64)
+            self._totals_slvra = torch.from_numpy(np.bincount(flat, minlength=int(np.prod(shape))).astype(np.float32)).view(shape)
+        return self._totals_slvra
 
     def num_read_features(self) -> int:
         nb = NUMBER_OF_BYTES_IN_PACKED_READ

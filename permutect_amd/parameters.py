@@ -87,7 +87,11 @@ class TrainingParameters:
     """reference parameters.py:160-177"""
 
     def __init__(self, batch_size: int, num_epochs: int, learning_rate: float = 0.001, weight_decay: float = 0.01,
-                 num_workers: int = 0, num_calibration_epochs: int = 0, inference_batch_size: int = 8192):
+                 num_workers: int = 0, num_calibration_epochs: int = 0, inference_batch_size: int = 8192,
+                 fit_downsampler: bool = True):
+        """`fit_downsampler` (not in the reference, which always fits): run Downsampler.optimize_downsampling_balance before
+        training (reference training/model_training.py:60); False keeps the uniform mixture weights."""
+        self.fit_downsampler = fit_downsampler
         self.batch_size, self.num_epochs = batch_size, num_epochs
         self.learning_rate, self.weight_decay = learning_rate, weight_decay
         self.num_workers, self.num_calibration_epochs = num_workers, num_calibration_epochs

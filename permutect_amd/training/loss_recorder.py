@@ -100,3 +100,52 @@ def evaluate(model, loader, num_sources: int = 1, balancer=None) -> LossRecorder
         rec.record(out, model.compute_batch_losses(out, batch), batch)
     model.train(was_training)
     return rec
+
+
+class EvaluationCounts:
+    """What an evaluation pass leaves behind: per epoch type (TRAIN / VALID) and label, the weighted numbers of variants
+    called artifact / not artifact (logit > 0) and the weighted sum of logits -- on the device, read once at the end.  The
+    reference feeds the same (batch, logits, weights) triples to its EvaluationMetrics for plots (metrics/*: out of scope)."""
+
+    def __init__(self, device):
+        self.counts = torch.zeros(2, len(Label), 2, dtype=torch.float32, device=device)      # [epoch type][label][called artifact]
+        self.logit_sums = torch.zeros(2, len(Label), dtype=torch.float32, device=device)
+        self.batches = 0
+
+    def record_batch(self, epoch_index: int, batch, logits: torch.Tensor, weights: torch.Tensor):
+        labels = batch.get(Data.LABEL).long()
+        called = (logits > 0).long()
+        self.counts[epoch_index].view(-1).index_add_(0, labels * 2 + called, weights.float())
+        self.logit_sums[epoch_index].index_add_(0, labels, (weights * logits).float())
+        self.batches += 1
+
+    def accuracy(self, epoch_index: int) -> float:
+        """weighted fraction of labeled variants on the right side of logit 0"""
+        c = self.counts[epoch_index]
+        right = c[int(Label.ARTIFACT), 1] + c[int(Label.VARIANT), 0]
+        total = c[int(Label.ARTIFACT)].sum() + c[int(Label.VARIANT)].sum()
+        return float((right / total.clamp_min(1e-12)).item())
+
+
+@torch.inference_mode()
+def collect_evaluation_data(model, balancer, downsampler, train_loader, valid_loader, seed: int = 0,
+                            fix_alt_gather: bool = False, passes: int = 3) -> EvaluationCounts:
+    """The evaluation pass as the reference runs it after every validation epoch (training/model_training.py:204-228):
+    over the training AND the validation loader, every parent batch downsampled `passes` = 3 times (fresh fractions each
+    time), forward with the balancer's weights, results recorded.  Here each downsampling is two launches and each forward
+    the fused filter kernel; nothing returns to the host inside the loop."""
+    was_training = model.training
+    model.train(False)
+    ev = EvaluationCounts(model._device)
+    step = seed * 7_368_787
+    for epoch_index, loader in enumerate((train_loader, valid_loader)):
+        if loader is None:
+            continue
+        for parent in loader:
+            for _ in range(passes):
+                step += 1
+                batch = downsampler.downsample(parent, seed=step, fix_alt_gather=fix_alt_gather)
+                out = model.compute_batch_output(batch, balancer)
+                ev.record_batch(epoch_index, batch, out.logits_b, out.weights)
+    model.train(was_training)
+    return ev

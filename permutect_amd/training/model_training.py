@@ -21,7 +21,7 @@ from permutect_amd.parameters import TrainingParameters
 from permutect_amd.training.balancer import Balancer
 from permutect_amd.training.distributed import BucketedGradAllReduce, rank0_decides
 from permutect_amd.training.downsampler import Downsampler
-from permutect_amd.training.loss_recorder import PRIMARY, LossRecorder
+from permutect_amd.training.loss_recorder import PRIMARY, LossRecorder, collect_evaluation_data
 from permutect_amd.training.optimizer import FusedClipAdamW, backpropagate
 
 
@@ -72,9 +72,16 @@ class Checkpoint:
         return self.should_roll_back(loss) and self.load_checkpoint()
 
 
+def training_params_fit_downsampler(training_params) -> bool:
+    """The balance fit can be skipped (uniform mixture weights) with `fit_downsampler = False` on the parameters object --
+    tests that train for a few steps do; the reference always fits."""
+    return bool(getattr(training_params, "fit_downsampler", True))
+
+
 def train_artifact_model(model, train_dataset: ReadsDataset, valid_dataset: Optional[ReadsDataset],
                          training_params: TrainingParameters, chunk_variants: Optional[int] = 1 << 18, seed: int = 0,
-                         dist=None, log=print, fix_alt_gather: bool = False):
+                         dist=None, log=print, fix_alt_gather: bool = False, evaluate_every_epoch: bool = True,
+                         evaluations: Optional[list] = None):
     """`fix_alt_gather`: the reference's DownsampledBatch gathers the kept alt reads without the offset of the ref region
     (SURVEY 0.5b), so its training steps see ref rows in place of alt reads; False reproduces that, True gathers the
     intended rows."""
@@ -82,7 +89,12 @@ def train_artifact_model(model, train_dataset: ReadsDataset, valid_dataset: Opti
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
     num_sources = train_dataset.num_sources()
     balancer = Balancer(num_sources=num_sources, device=device)
-    downsampler = Downsampler(num_sources=num_sources).to(device)
+    downsampler = Downsampler(num_sources=num_sources)
+    if training_params_fit_downsampler(training_params):
+        # reference :58-60: fit the Beta-mixture weights so that the downsampled counts spread over the count bins
+        # (deterministic, on the CPU: ~15 s of tiny einsums; identical on every rank, which all see the whole dataset's totals)
+        downsampler.optimize_downsampling_balance(train_dataset.totals_slvra)
+    downsampler = downsampler.to(device)
     model.reset_source_predictor(num_sources)
     opt = FusedClipAdamW(model, lr=training_params.learning_rate, weight_decay=training_params.weight_decay)
     scheduler = PlateauScheduler(opt, min_lr=training_params.learning_rate / 100)
@@ -95,6 +107,7 @@ def train_artifact_model(model, train_dataset: ReadsDataset, valid_dataset: Opti
         model.engine().grad_hook = reduce_grads  # early bucket: reduced on a side stream under the rest of the backward
     rng = np.random.default_rng(seed + rank)
     history = []
+    evaluations = [] if evaluations is None else evaluations
     last_epoch = training_params.num_epochs + training_params.num_calibration_epochs
     step_seed = seed * 1_000_003 + rank
 
@@ -147,6 +160,21 @@ def train_artifact_model(model, train_dataset: ReadsDataset, valid_dataset: Opti
             mean_loss = recorder.mean_loss(PRIMARY)  # the epoch's one host sync
             history.append((epoch, epoch_type.name, mean_loss))
             log(f"epoch {epoch} {epoch_type.name}: mean semisupervised loss {mean_loss:.5f}, lr {opt.param_groups[0]['lr']:.2e}")
+            if epoch_type == Epoch.VALID and evaluate_every_epoch:
+                # reference :184-195: after every validation epoch, an evaluation pass over BOTH datasets, three downsamplings
+                # of every parent batch (its plots are out of scope; the accuracies go to the log)
+                ev = collect_evaluation_data(
+                    model, balancer, downsampler,
+                    train_dataset.device_loader(training_params.inference_batch_size, device, chunk_variants=chunk_variants, shuffle=False,
+                                                rank=rank, world_size=world),
+                    valid_dataset.device_loader(training_params.inference_batch_size, device, chunk_variants=chunk_variants, shuffle=False,
+                                                rank=rank, world_size=world),
+                    seed=seed * 1000 + epoch, fix_alt_gather=fix_alt_gather)
+                if dist is not None:
+                    ev.counts = ev.counts.clone()  # (made under inference_mode: not updatable in place out here)
+                    dist.all_reduce(ev.counts, op=dist.ReduceOp.SUM)
+                log(f"epoch {epoch} evaluation: accuracy train {ev.accuracy(0):.4f}, valid {ev.accuracy(1):.4f}")
+                evaluations.append((epoch, ev.accuracy(0), ev.accuracy(1)))
             if epoch_type == Epoch.TRAIN:
                 scheduler.step(mean_loss)
                 if not is_calibration:

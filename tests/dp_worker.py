@@ -29,7 +29,7 @@ def main(out_dir: str):
     torch.manual_seed(100 + rank)  # DIFFERENT initial weights per rank: the loop must make the replicas identical itself
     model = ArtifactModel(p0_params(), device=dev, **P0_DIMS)
     hist = train_artifact_model(model, train, valid, TrainingParameters(batch_size=8, num_epochs=2, num_calibration_epochs=1,
-                                                                        learning_rate=1e-3),
+                                                                        learning_rate=1e-3, fit_downsampler=False),
                                 chunk_variants=None, seed=3, dist=dist, log=lambda *_: None)
     eng = model.engine()
     torch.cuda.synchronize()

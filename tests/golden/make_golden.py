@@ -280,8 +280,70 @@ def make_training_helpers_fixture():
     print("training helpers fixture written")
 
 
+def make_downsampler_fit_fixture():
+    """downsampler_fit.npz: the reference's `Downsampler.optimize_downsampling_balance` (training/downsampler.py:141-158:
+    10 000 AdamW steps, deterministic) on a seeded table of dataset counts, and the expected downsampled counts before and
+    after the fit."""
+    import time
+    from permutect.training.downsampler import Downsampler
+    rng = np.random.default_rng(5)
+    counts = torch.from_numpy(rng.integers(0, 2000, size=(2, 3, 5, 4, 5)).astype(np.float32))
+    counts[:, :, 3, 0, :] = 0   # count bins without data are fine ...
+    counts[1, 2, 4] = 0
+    counts[1, 2, 4, 1, 2] = 7   # ... but a whole (source, label, variant type) cell without data makes the reference's loss
+    # 0 / 0 = NaN and with it every weight (its training then dies in torch.multinomial): every cell here has some data
+    torch.manual_seed(0)
+    down = Downsampler(num_sources=2)
+    before = down.calculate_expected_downsampled_counts(counts).detach().numpy()
+    t0 = time.time()
+    down.optimize_downsampling_balance(counts)
+    print("reference fit took", time.time() - t0, "s")
+    after = down.calculate_expected_downsampled_counts(counts).detach().numpy()
+    np.savez_compressed(
+        os.path.join(HERE, "downsampler_fit.npz"), counts_slvra=counts.numpy(), expected_before=before, expected_after=after,
+        log_ref_weights_original=down.parametrizations.log_ref_weights_slvrak.original.detach().numpy(),
+        log_alt_weights_original=down.parametrizations.log_alt_weights_slvrah.original.detach().numpy(),
+        state_dict_keys=np.array(sorted(down.state_dict().keys())),
+    )
+    print("downsampler fit fixture written")
+
+
+def make_posterior_rows_fixture():
+    """posterior_rows.npz: what the reference's per-variant loop in `generate_posterior_data` (tools/filter_variants.py:
+    302-320) makes of a batch -- counts zeroed, the logit stored through the float16 scalar array, the info columns replaced
+    by the embedding -- for the variants of tiny_dataset.tar with seeded logits / embeddings standing in for the model's."""
+    from permutect.data.datum import COMPRESSED_READS_ARRAY_DTYPE
+    from permutect.data.memory_mapped_data import MemoryMappedData
+    back = MemoryMappedData.load_from_tarfile(os.path.join(HERE, "tiny_dataset.tar"))
+    datums = list(back.generate())
+    batch = Batch(datums)
+    rng = np.random.default_rng(9)
+    n, e = len(datums), 10
+    logits = torch.from_numpy((20 * np.tanh(rng.standard_normal(n) * 2)).astype(np.float32))
+    logits[0], logits[1], logits[2] = 20.0, -20.0, 1e-4
+    features = torch.from_numpy(rng.standard_normal((n, e)).astype(np.float32))
+    ints, floats = [], []
+    for int_array, float_array, logit, embedding in zip(batch.get_int_array_be(), batch.get_float_array_be(), logits.tolist(), features):
+        d = Datum(int_array=int_array, float_array=float_array, reads_re=np.zeros((0, 0), dtype=COMPRESSED_READS_ARRAY_DTYPE), compressed=True)
+        d.set(Data.REF_COUNT, 0)
+        d.set(Data.ALT_COUNT, 0)
+        d.set(Data.CACHED_ARTIFACT_LOGIT, logit)
+        d.set_info_1d(embedding)
+        ints.append(np.asarray(d.get_int_array()).copy())
+        floats.append(np.asarray(d.get_float_array()).copy())
+    print("posterior rows: int dtype", ints[0].dtype, "float dtype", floats[0].dtype, floats[0].shape)
+    np.savez_compressed(os.path.join(HERE, "posterior_rows.npz"), batch_int=batch.int_tensor.numpy(), batch_float=batch.float_tensor.numpy(),
+                        logits_b=logits.numpy(), features_be=features.numpy(), out_int=np.stack(ints), out_float=np.stack(floats),
+                        out_float_dtype=str(floats[0].dtype))
+    print("posterior rows fixture written")
+
+
 if __name__ == "__main__":
-    if "--dataset-only" in sys.argv:  # leaves the model fixtures (and their random streams) untouched
+    if "--downsampler-only" in sys.argv:
+        make_downsampler_fit_fixture()
+    elif "--posterior-only" in sys.argv:
+        make_posterior_rows_fixture()
+    elif "--dataset-only" in sys.argv:  # leaves the model fixtures (and their random streams) untouched
         make_dataset_fixture()
     elif "--helpers-only" in sys.argv:
         make_training_helpers_fixture()
@@ -289,3 +351,5 @@ if __name__ == "__main__":
         main()
         make_dataset_fixture()
         make_training_helpers_fixture()
+        make_downsampler_fit_fixture()
+        make_posterior_rows_fixture()

@@ -77,3 +77,20 @@ def test_loader_covers_every_variant_once():
     want = np.asarray(ds._ints[: len(ds), 16:]).astype(np.int64)
     assert got.shape == want.shape
     assert sorted(map(bytes, got)) == sorted(map(bytes, want))
+
+
+def test_posterior_rows_match_the_reference_per_datum_loop():
+    """tools/posterior_data.posterior_rows against what the REFERENCE's loop in generate_posterior_data
+    (tools/filter_variants.py:302-320) made of the same batch (tests/golden/posterior_rows.npz, written by make_golden.py
+    --posterior-only): counts zeroed, the logit stored through the float16 scalar array, info := embedding.  Integers bit for
+    bit; floats exactly too (the logit's float16 rounding included)."""
+    import torch
+    from permutect_amd.tools.posterior_data import posterior_rows
+    z = np.load(os.path.join(GOLDEN, "posterior_rows.npz"))
+    ints, floats = posterior_rows(torch.from_numpy(z["batch_int"]), torch.from_numpy(z["batch_float"]),
+                                  torch.from_numpy(z["logits_b"]), torch.from_numpy(z["features_be"]))
+    assert ints.dtype == torch.int16 and str(z["out_float_dtype"]) == "float32" and floats.dtype == torch.float32
+    np.testing.assert_array_equal(ints.numpy(), z["out_int"])
+    np.testing.assert_array_equal(floats.numpy(), z["out_float"])
+    # saturated and tiny logits survive the float16 hop as the reference's do
+    assert floats[0, 5] == 20.0 and floats[1, 5] == -20.0 and float(floats[2, 5]) == float(np.float16(1e-4))

@@ -139,10 +139,14 @@ def test_train_artifact_model_loop_end_to_end():
     torch.manual_seed(0)
     model = ArtifactModel(p0_params(), device=dev, **P0_DIMS)
     logs = []
+    evals = []
     hist = train_artifact_model(model, train, valid, TrainingParameters(batch_size=16, num_epochs=2, num_calibration_epochs=1,
-                                                                        learning_rate=1e-3), chunk_variants=24, seed=1, log=logs.append)
+                                                                        learning_rate=1e-3), chunk_variants=24, seed=1, log=logs.append,
+                                evaluations=evals)
     assert [h[:2] for h in hist] == [(1, "TRAIN"), (1, "VALID"), (2, "TRAIN"), (2, "VALID"), (3, "TRAIN"), (3, "VALID")]
-    assert all(np.isfinite(h[2]) and h[2] > 0 for h in hist) and len(logs) == 6
+    assert all(np.isfinite(h[2]) and h[2] > 0 for h in hist)
+    # one line per epoch half plus the evaluation pass after every validation epoch (3 downsamplings of train + valid)
+    assert len(logs) == 9 and len(evals) == 3 and all(0.0 <= a <= 1.0 and 0.0 <= b <= 1.0 for _, a, b in evals)
     # the model still produces finite outputs after training
     with torch.no_grad():
         out = model.compute_batch_output(valid.host_batch(np.arange(len(valid))).copy_to(dev))
@@ -205,7 +209,7 @@ def test_training_loop_learns_a_separable_dataset():
     valid = ReadsDataset(mm, num_folds=5, folds_to_use=last_fold_only(5))
     torch.manual_seed(1)
     model = ArtifactModel(p0_params(), device=dev, **P0_DIMS)
-    hist = train_artifact_model(model, train, valid, TrainingParameters(batch_size=64, num_epochs=6, learning_rate=2e-3),
+    hist = train_artifact_model(model, train, valid, TrainingParameters(batch_size=64, num_epochs=6, learning_rate=2e-3, fit_downsampler=False),
                                 chunk_variants=2048, seed=2, log=lambda *_: None, fix_alt_gather=True)
     valid_losses = [h[2] for h in hist if h[1] == "VALID"]
     assert max(valid_losses[-2:]) < 0.2, valid_losses  # chance level is log 2 = 0.69 plus the adversary terms
@@ -221,6 +225,29 @@ def test_training_loop_learns_a_separable_dataset():
     # signal that lives only in the alt reads is invisible to it: same data, same loop, the loss stays at chance.
     torch.manual_seed(1)
     quirk = ArtifactModel(p0_params(), device=dev, **P0_DIMS)
-    hist_q = train_artifact_model(quirk, train, valid, TrainingParameters(batch_size=64, num_epochs=3, learning_rate=2e-3),
+    hist_q = train_artifact_model(quirk, train, valid, TrainingParameters(batch_size=64, num_epochs=3, learning_rate=2e-3, fit_downsampler=False),
                                   chunk_variants=2048, seed=2, log=lambda *_: None)
     assert min(h[2] for h in hist_q if h[1] == "VALID") > 0.4, hist_q
+
+
+def test_evaluation_pass_runs_three_downsamplings_over_both_loaders():
+    """collect_evaluation_data (reference training/model_training.py:204-228): every parent batch of the training and of the
+    validation loader is downsampled three times and run forward; the weighted label counts add up to 3 x the data."""
+    from permutect_amd.data.reads_dataset import all_but_last_fold, last_fold_only
+    from permutect_amd.training.balancer import Balancer
+    from permutect_amd.training.downsampler import Downsampler
+    from permutect_amd.training.loss_recorder import collect_evaluation_data
+    dev = torch.device("cuda:0")
+    mm = MemoryMappedData.load_from_tarfile(os.path.join(GOLDEN, "tiny_dataset.tar"))
+    train = ReadsDataset(mm, num_folds=5, folds_to_use=all_but_last_fold(5))
+    valid = ReadsDataset(mm, num_folds=5, folds_to_use=last_fold_only(5))
+    torch.manual_seed(0)
+    model = ArtifactModel(p0_params(), device=dev, **P0_DIMS)
+    ev = collect_evaluation_data(model, None, Downsampler(2).to(dev), train.device_loader(16, dev, shuffle=False),
+                                 valid.device_loader(16, dev, shuffle=False), seed=4, fix_alt_gather=True)
+    counts = ev.counts.cpu().numpy()
+    assert abs(counts[0].sum() - 3 * len(train)) < 1e-3 and abs(counts[1].sum() - 3 * len(valid)) < 1e-3  # unit weights
+    assert ev.batches == 3 * (len(train.device_loader(16, dev)) + len(valid.device_loader(16, dev)))
+    labels = np.asarray(train._ints[: len(train), 2])
+    np.testing.assert_allclose(counts[0].sum(axis=1), 3 * np.bincount(labels, minlength=3), atol=1e-3)
+    assert 0.0 <= ev.accuracy(0) <= 1.0

@@ -108,7 +108,7 @@ def test_downsampler_drives_the_fused_kernels_in_a_train_step():
     model.train(True)
     ds = Downsampler(num_sources=1).to(DEV)
     with torch.no_grad():  # all weight on Beta(1,5) for SNV artifacts: their reads are thinned hardest
-        ds.log_ref_weights_slvrak[0, 0, 0, :, :, 1] = 20.0
+        ds.parametrizations.log_ref_weights_slvrak.original[0, 0, 0, :, :, 1] = 20.0
     db = ds.downsample(batch, seed=9, fix_alt_gather=True)
     _check_structure(db, nref, nalt, True)
     labels = batch.get(Data_LABEL()).cpu().numpy()
@@ -149,6 +149,56 @@ def test_downsampling_a_batch_with_read_sets_beyond_one_workgroup():
     backpropagate(opt, losses.total_loss, params_to_clip=model.parameters())
     torch.cuda.synchronize()
     assert torch.isfinite(losses.total_loss) and float(opt.grad_norm.item()) > 0
+
+
+def test_device_kernels_reproduce_the_reference_quirk_fixture():
+    """tests/golden/quirk_downsample.npz was written by the REFERENCE's DownsampledBatch (data/batch.py:389-439): with every
+    read kept its `read_indices` are all ref rows, then the alt rows WITHOUT the offset of the ref region.
+    pmt_downsample_counts / _index in reference mode must give exactly that index and those counts; in fixed mode the alt
+    rows carry the offset."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "quirk_downsample.npz"))
+    nref, nalt = z["ref_counts"], z["alt_counts"]
+    ints = np.zeros((len(nref), 58), dtype=np.int16)
+    ints[:, 0], ints[:, 1] = nref, nalt
+    floats = np.zeros((len(nref), 77), dtype=np.float16)
+    packed = np.zeros((int(nref.sum() + nalt.sum()), 12), dtype=np.uint8)
+    batch = Batch.from_arrays(ints, floats, packed).copy_to(DEV)
+    ones = torch.ones(batch.size(), device=DEV)
+    want = z["read_indices_all_kept"]
+    quirk = DownsampledBatch.on_device(batch, seed=1, ref_fracs_b=ones, alt_fracs_b=ones)
+    assert np.array_equal(quirk.read_indices[: len(want)].cpu().numpy(), want)
+    assert np.array_equal(quirk.ref_counts.cpu().numpy(), z["new_ref_counts_all_kept"])
+    assert np.array_equal(quirk.alt_counts.cpu().numpy(), z["new_alt_counts_all_kept"])
+    fixed = DownsampledBatch.on_device(batch, seed=1, ref_fracs_b=ones, alt_fracs_b=ones, fix_alt_gather=True)
+    tr = int(nref.sum())
+    assert np.array_equal(fixed.read_indices[: len(want)].cpu().numpy(), np.concatenate([want[:tr], want[tr:] + tr]))
+    # the reference's half-kept draw has the same STRUCTURE (its random stream is torch's, not reproducible on the device):
+    # kept rows ascending per side, counts within bounds, at least one alt read per variant
+    rc, ac, idx = z["new_ref_counts_half"], z["new_alt_counts_half"], z["read_indices_half"]
+    assert np.all(rc <= nref) and np.all(ac <= nalt) and np.all(ac >= 1) and len(idx) == rc.sum() + ac.sum()
+    half = DownsampledBatch.on_device(batch, seed=2, ref_fracs_b=0.5 * ones, alt_fracs_b=0.5 * ones)
+    _check_structure(half, nref, nalt, False)
+
+
+@pytest.mark.parametrize("component", [0, 1, 2, 3])
+def test_keep_fractions_follow_each_beta_component(component):
+    """Kolmogorov-Smirnov test of the device's keep fractions against the Beta shape of every mixture component
+    (reference training/downsampler.py:27,118-122: Beta(1,1), Beta(1,5), Beta(5,1), Beta(5,5)), ref and alt."""
+    from scipy import stats
+    batch, _, _ = _batch(nvar=20000, seed=3 + component)
+    w = torch.zeros(batch.size(), 4, device=DEV)
+    w[:, component] = 1.0
+    db = DownsampledBatch.on_device(batch, seed=40 + component, ref_weights_b4=w, alt_weights_b4=w)
+    a, b = [(1.0, 1.0), (1.0, 5.0), (5.0, 1.0), (5.0, 5.0)][component]
+    for f in (db.ref_fracs.cpu().numpy(), db.alt_fracs.cpu().numpy()):
+        d, pval = stats.kstest(f.astype(np.float64), stats.beta(a, b).cdf)
+        assert d < 0.02 and pval > 1e-4, (component, d, pval)  # n = 20 000: the 1e-4 critical distance is ~0.016
+    # the uniform mixture: KS against the mixture's cdf
+    db = DownsampledBatch.on_device(batch, seed=77)
+    mix = lambda x: 0.25 * sum(stats.beta(p, q).cdf(x) for p, q in [(1, 1), (1, 5), (5, 1), (5, 5)])  # noqa: E731
+    d, pval = stats.kstest(db.ref_fracs.cpu().numpy().astype(np.float64), mix)
+    assert d < 0.02 and pval > 1e-4, (d, pval)
 
 
 def Data_LABEL():
