@@ -176,7 +176,9 @@ typedef struct PmtModel {
     PmtLinear lin[PMT_MAX_LINEAR];
     /* Kernel-instance selection, part of the descriptor (the library reads no environment variables and keeps no state).
      * 0 everywhere = the library's own choice; the other values exist so that the parity tests can run every instance. */
-    int32_t force_shape;        /* read-set kernels: 0 auto, 1 at most the tile-exact instance, 2 the generic instance   */
+    int32_t force_shape;        /* read-set kernels: 0 auto, 1 at most the tile-exact instance, 2 the generic instance,
+                                   3 plain bf16 products where the exact-width instance applies (NOT a parity mode:
+                                   one bf16 MFMA per product instead of the fp32-equivalent six; bench.py --dtype bf16) */
     int32_t force_cnn;          /* haplotype CNN: 0 auto, 1 general (workgroup-per-chunk) kernels, 2 wave-per-variant
                                    kernels (pmt_cnn2), 3 batched-column kernels (pmt_cnn3)                               */
     int32_t cnn_debug;          /* development switches of pmt_cnn2_backward (0 in production)                           */

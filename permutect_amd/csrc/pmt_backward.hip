@@ -179,7 +179,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             if constexpr (EX) {
                 const PmtLinear& Lr = M->lin[uniform(red_last.lin[0])];
                 init_bias<NTE>(e, uniform(Lr.b_pvec) >= 0 ? packed + uniform(Lr.b_pvec) : nullptr, E, g);
-                if constexpr (S::BF16) linear_acc_bf16<NTD, NTE, false>(e, r, packed + uniform(Lr.wb_frag));
+                if constexpr (S::BF16) linear_acc_bf16<NTD, NTE, false, S::BF16>(e, r, packed + uniform(Lr.wb_frag));
                 else linear_acc<NTD, NTE, false, true, S::DIM_D>(e, r, packed + uniform(Lr.w_frag), D, E);
                 if (uniform(red_last.selu_after) != 0) {
 #pragma unroll
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
                 a[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        if constexpr (S::BF16) linear_acc_bf16<NTE, NTE, false>(a, e, packed + uniform(R.wb_frag));
+        if constexpr (S::BF16) linear_acc_bf16<NTE, NTE, false, S::BF16>(a, e, packed + uniform(R.wb_frag));
         else linear_acc<NTE, NTE, false, EX, S::DIM_E>(a, e, packed + uniform(R.w_frag), E, E);
 
         // ---- head backward (alt reads) + set-mean gradients -> d(a) in da ------------------------------------------
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         linear_wgrad<NTE, NTE, S::BF16>(c, R, da, e);
         f4 de[PMT_RT][NTE];
         init_bias<NTE>(de, nullptr, E, g);
-        if constexpr (S::BF16) linear_acc_bf16<NTE, NTE, false>(de, da, packed + uniform(R.wtb_frag));
+        if constexpr (S::BF16) linear_acc_bf16<NTE, NTE, false, S::BF16>(de, da, packed + uniform(R.wtb_frag));
         else linear_acc<NTE, NTE, false, EX, S::DIM_E>(de, da, packed + uniform(R.wt_frag), E, E);
         f4 dt[NTE];
 #pragma unroll
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             const f4 b0 = load_pvec(packed + uniform(P1.b_pvec), 0, g), b1 = load_pvec(packed + uniform(P1.b_pvec), 1, g);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) { z[rt][0] = b0; z[rt][1] = b1; }
-            if constexpr (S::BF16) linear_acc_bf16<NTD, 2, false>(z, n, packed + uniform(P1.wb_frag));
+            if constexpr (S::BF16) linear_acc_bf16<NTD, 2, false, S::BF16>(z, n, packed + uniform(P1.wb_frag));
             else linear_acc<NTD, 2, false, EX, S::DIM_D>(z, n, packed + uniform(P1.w_frag), D, 16 + h);
         }
         const f4 sw = load_pvec(packed + uniform(B.sgu_norm_w_pvec), 0, g), sb = load_pvec(packed + uniform(B.sgu_norm_b_pvec), 0, g);
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt) du[rt][0] = f4{0.f, 0.f, 0.f, 0.f};
         if (first_half) {
-            if constexpr (S::BF16) linear_acc_bf16<NTD, 1, false>(du, dy, packed + uniform(P2.wtb_frag));
+            if constexpr (S::BF16) linear_acc_bf16<NTD, 1, false, S::BF16>(du, dy, packed + uniform(P2.wtb_frag));
             else linear_acc<NTD, 1, false, EX, S::DIM_D>(du, dy, packed + uniform(P2.wt_frag), D, h);
         }
         if (first_half) {
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             prof_add(c, 9, t_ph);
             t_ph = prof_now();
             // proj2 weight gradients of both sides in one exchange round
-            if constexpr (S::BF16) wgrad_exchange_bf<NTD, 1, 2>(c, M->lin[uniform(B.proj2[0])], M->lin[uniform(B.proj2[1])], dy, u, 1.0f);
+            if constexpr (S::BF16 != 0) wgrad_exchange_bf<NTD, 1, 2, S::BF16>(c, M->lin[uniform(B.proj2[0])], M->lin[uniform(B.proj2[1])], dy, u, 1.0f);
             else wgrad_exchange<NTD, 1, 2>(c, M->lin[uniform(B.proj2[0])], M->lin[uniform(B.proj2[1])], dy, u, 1.0f);
         }
         if (c.dbg & 1) __syncthreads();  // (the exchange's barriers, skipped by that switch, complete gsum)
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         {
             f4 n[PMT_RT][NTD];
             recompute_n(n);
-            if constexpr (S::BF16) wgrad_exchange_bf<2, NTD, 2>(c, M->lin[uniform(B.proj1[0])], M->lin[uniform(B.proj1[1])], dz, n, 1.0f);
+            if constexpr (S::BF16 != 0) wgrad_exchange_bf<2, NTD, 2, S::BF16>(c, M->lin[uniform(B.proj1[0])], M->lin[uniform(B.proj1[1])], dz, n, 1.0f);
             else wgrad_exchange<2, NTD, 2>(c, M->lin[uniform(B.proj1[0])], M->lin[uniform(B.proj1[1])], dz, n, 1.0f);
         }
         prof_add(c, 13, t_ph);
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         {
             f4 dn[PMT_RT][NTD];
             init_bias<NTD>(dn, nullptr, D, g);
-            if constexpr (S::BF16) linear_acc_bf16<2, NTD, false>(dn, dz, packed + uniform(P1.wtb_frag));
+            if constexpr (S::BF16) linear_acc_bf16<2, NTD, false, S::BF16>(dn, dz, packed + uniform(P1.wtb_frag));
             else linear_acc<2, NTD, false, EX, 0, S::DIM_H>(dn, dz, packed + uniform(P1.wt_frag), 16 + h, D);
             f4 lw[NTD], dlw[NTD], dlb[NTD];
 #pragma unroll
@@ -709,7 +709,7 @@ extern "C" int pmt_backward(const PmtModel* model_host, const PmtModel* model_de
     const float* zsum_stash = stash + (size_t)batch->total_tiles * (size_t)pmt_stash_slots(model_host) * PMT_SLOT_FLOATS;
     const float* rstd_stash = zsum_stash + (size_t)batch->num_variants * (size_t)(model_host->num_blocks > 0 ? model_host->num_blocks : 1) * 32;
     const int shape = pmt_shape_id(model_host);
-    auto kernel = shape == 2 ? pmt_backward_kernel<ShapeP0X> : shape == 1 ? pmt_backward_kernel<ShapeP0> : pmt_backward_kernel<ShapeAny>;
+    auto kernel = shape == 3 ? pmt_backward_kernel<ShapeP0XB> : shape == 2 ? pmt_backward_kernel<ShapeP0X> : shape == 1 ? pmt_backward_kernel<ShapeP0> : pmt_backward_kernel<ShapeAny>;
     hipLaunchKernelGGL(kernel, dim3(batch->num_groups), dim3(PMT_THREADS), 0, reinterpret_cast<hipStream_t>(stream), model_dev,
                        theta, phi, packed, *batch, *out, *dout, stash, zsum_stash, rstd_stash, grad_theta, grad_phi, grad_variant_embed,
                        PmtBwdLayered{});
@@ -745,7 +745,7 @@ extern "C" int pmt_backward_layered(const PmtModel* model_host, const PmtModel* 
     lay.gsum_g = lay.park + (size_t)batch->total_tiles * 6 * 256;
     if (hipMemsetAsync(lay.gsum_g, 0, B * nb * 32 * sizeof(float), s) != hipSuccess) return PMT_E_LAUNCH;
     const int shape = pmt_shape_id(model_host);
-    auto kernel = shape == 2 ? pmt_backward_kernel<ShapeP0X, true> : shape == 1 ? pmt_backward_kernel<ShapeP0, true> : pmt_backward_kernel<ShapeAny, true>;
+    auto kernel = shape >= 2 ? pmt_backward_kernel<ShapeP0X, true> : shape == 1 ? pmt_backward_kernel<ShapeP0, true> : pmt_backward_kernel<ShapeAny, true>;
     for (int slice = 0; slice <= L; ++slice) {
         lay.slice = slice;
         hipLaunchKernelGGL(kernel, dim3(batch->num_groups), dim3(PMT_THREADS), 0, s, model_dev, theta, phi, packed, *batch, *out, *dout,

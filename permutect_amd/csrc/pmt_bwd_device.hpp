@@ -497,20 +497,20 @@ DEV int stage_rbase(int lane) {  // lane (m = lane & 15, kg = lane >> 4) -> slot
     return 16 * (16 * kg + (m ^ kg));
 }
 // one operand plane of this wave: v0 / v1 = the plane's registers of tile 0 / tile 1 (zero for padding reads and absent tiles)
+template <int PIECES = 3>
 DEV void stage_pair_bf16(char* __restrict__ plane, int wbase, f4 v0, f4 v1) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const unsigned hi = pack_bf16x2(v0[j], v1[j]);
         const float h0 = __builtin_bit_cast(float, hi << 16), h1 = __builtin_bit_cast(float, hi & 0xFFFF0000u);
-        const unsigned mid = pack_bf16x2(v0[j] - h0, v1[j] - h1);
         char* p = plane + (wbase ^ (16 * j));
         *reinterpret_cast<unsigned*>(p) = hi;
-        *reinterpret_cast<unsigned*>(p + 1024) = mid;
+        if constexpr (PIECES != 1) *reinterpret_cast<unsigned*>(p + 1024) = pack_bf16x2(v0[j] - h0, v1[j] - h1);
     }
 }
 
 #define PMT_BF_PLANE_BYTES 2048  // hi + mid piece of one (wave, plane)
-template <int NTO, int NTI, int SIDES>
+template <int NTO, int NTI, int SIDES, int PIECES = 3>
 DEV void wgrad_exchange_bf(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, const f4 (&dy)[PMT_RT][NTO],
                            const f4 (&x)[PMT_RT][NTI], float scale) {
     static_assert(PMT_RT == 2, "a wave's two tiles are the 32 reads of one MFMA");
@@ -569,9 +569,9 @@ DEV void wgrad_exchange_bf(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, 
         if (wave >= w0 && wave < w0 + PW) {
             char* mine = stage + (wave - w0) * (P * PMT_BF_PLANE_BYTES);
 #pragma unroll
-            for (int ot = 0; ot < NTO; ++ot) stage_pair_bf16(mine + ot * PMT_BF_PLANE_BYTES, c.wbase, dy[0][ot], dy[1][ot]);
+            for (int ot = 0; ot < NTO; ++ot) stage_pair_bf16<PIECES>(mine + ot * PMT_BF_PLANE_BYTES, c.wbase, dy[0][ot], dy[1][ot]);
 #pragma unroll
-            for (int it = 0; it < NTI; ++it) stage_pair_bf16(mine + (NTO + it) * PMT_BF_PLANE_BYTES, c.wbase, x[0][it], x[1][it]);
+            for (int it = 0; it < NTI; ++it) stage_pair_bf16<PIECES>(mine + (NTO + it) * PMT_BF_PLANE_BYTES, c.wbase, x[0][it], x[1][it]);
         }
         if (c.dbg & 128) __syncthreads(); else lds_barrier();
         const int whi_all = min(w0 + PW, PMT_WAVES);
@@ -589,8 +589,10 @@ DEV void wgrad_exchange_bf(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, 
                         const int ot = t_side[k] >= 0 ? t_ot[k] : 0;  // (a missing block reads row 0 and is never emitted)
                         const bf8 ah = *reinterpret_cast<const bf8*>(pw + ot * PMT_BF_PLANE_BYTES);
                         const bf8 am = *reinterpret_cast<const bf8*>(pw + ot * PMT_BF_PLANE_BYTES + 1024);
-                        acc[k] = mfma_bf16(am, bh, acc[k]);
-                        acc[k] = mfma_bf16(ah, bm, acc[k]);
+                        if constexpr (PIECES != 1) {
+                            acc[k] = mfma_bf16(am, bh, acc[k]);
+                            acc[k] = mfma_bf16(ah, bm, acc[k]);
+                        }
                         acc[k] = mfma_bf16(ah, bh, acc[k]);
                     }
                 }
@@ -607,8 +609,10 @@ DEV void wgrad_exchange_bf(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, 
                     const int o = (w - w0) * (P * PMT_BF_PLANE_BYTES);
                     const bf8 ah = *reinterpret_cast<const bf8*>(pa + o), am = *reinterpret_cast<const bf8*>(pa + o + 1024);
                     const bf8 bh = *reinterpret_cast<const bf8*>(pb + o), bm = *reinterpret_cast<const bf8*>(pb + o + 1024);
-                    acc[k] = mfma_bf16(am, bh, acc[k]);
-                    acc[k] = mfma_bf16(ah, bm, acc[k]);
+                    if constexpr (PIECES != 1) {
+                        acc[k] = mfma_bf16(am, bh, acc[k]);
+                        acc[k] = mfma_bf16(ah, bm, acc[k]);
+                    }
                     acc[k] = mfma_bf16(ah, bh, acc[k]);
                 }
             }
@@ -623,7 +627,7 @@ DEV void wgrad_exchange_bf(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, 
             for (int w = lo; w < hi; ++w) {
                 const int o = (w - w0) * (P * PMT_BF_PLANE_BYTES);
                 const bf8 ah = *reinterpret_cast<const bf8*>(pa + o), am = *reinterpret_cast<const bf8*>(pa + o + 1024);
-                accb[k] = mfma_bf16(am, ones, accb[k]);
+                if constexpr (PIECES != 1) accb[k] = mfma_bf16(am, ones, accb[k]);
                 accb[k] = mfma_bf16(ah, ones, accb[k]);
             }
         }
@@ -651,16 +655,16 @@ DEV void wgrad_exchange_bf(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, 
     prof_add(c, 2, t0c);
 }
 
-template <int NTO, int NTI, bool BF = false>
+template <int NTO, int NTI, int BF = 0>
 DEV void linear_wgrad(BwdCtx& c, const PmtLinear& L, const f4 (&dy)[PMT_RT][NTO], const f4 (&x)[PMT_RT][NTI],
                       float scale = 1.0f) {
-    if constexpr (BF) wgrad_exchange_bf<NTO, NTI, 1>(c, L, L, dy, x, scale);
+    if constexpr (BF != 0) wgrad_exchange_bf<NTO, NTI, 1, BF>(c, L, L, dy, x, scale);
     else wgrad_exchange<NTO, NTI, 1>(c, L, L, dy, x, scale);
 }
 
 // Backward of one LINEAR op between register arrays of different tile counts (see run_linear_op): dy is the gradient
 // w.r.t. the op's output (modified: multiplied by the activation derivative), x its input; dx (if wanted) = W^T dy.
-template <int NTI, int NTO, bool EXACT, int WI = 0, int WO = 0, bool BF = false>
+template <int NTI, int NTO, bool EXACT, int WI = 0, int WO = 0, int BF = 0>
 DEV void linear_op_backward(BwdCtx& c, const PmtOp& o, f4 (&dy)[PMT_RT][NTO], const f4 (&x)[PMT_RT][NTI],
                             f4 (&dx)[PMT_RT][NTI], bool want_dx) {
     const PmtLinear& L = c.M->lin[uniform(o.lin[0])];
@@ -668,7 +672,7 @@ DEV void linear_op_backward(BwdCtx& c, const PmtOp& o, f4 (&dy)[PMT_RT][NTO], co
     if (uniform(o.selu_after) != 0) {  // recompute s = selu(Wx + b); dy <- dy * selu'(s)
         f4 y[PMT_RT][NTO];
         init_bias<NTO>(y, uniform(L.b_pvec) >= 0 ? c.packed + uniform(L.b_pvec) : nullptr, out_dim, c.g);
-        if constexpr (BF) linear_acc_bf16<NTI, NTO, false>(y, x, c.packed + uniform(L.wb_frag));
+        if constexpr (BF) linear_acc_bf16<NTI, NTO, false, BF>(y, x, c.packed + uniform(L.wb_frag));
         else linear_acc<NTI, NTO, false, EXACT, WI>(y, x, c.packed + uniform(L.w_frag), in_dim, out_dim);
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt)
@@ -678,14 +682,14 @@ DEV void linear_op_backward(BwdCtx& c, const PmtOp& o, f4 (&dy)[PMT_RT][NTO], co
     linear_wgrad<NTO, NTI, BF>(c, L, dy, x);
     if (want_dx) {
         init_bias<NTI>(dx, nullptr, in_dim, c.g);
-        if constexpr (BF) linear_acc_bf16<NTO, NTI, false>(dx, dy, c.packed + uniform(L.wtb_frag));
+        if constexpr (BF) linear_acc_bf16<NTO, NTI, false, BF>(dx, dy, c.packed + uniform(L.wtb_frag));
         else linear_acc<NTO, NTI, false, EXACT, WO>(dx, dy, c.packed + uniform(L.wt_frag), out_dim, in_dim);
     }
 }
 
 // backward of one MLP program.  dy (in/out): gradient w.r.t. the MLP output on entry, w.r.t. its input on exit
 // (not computed for op 0 when need_input_grad is false).  in_slot(op) gives the stash slot of op's input.
-template <int NT, bool EXACT, int W = 0, bool BF = false, typename LoadInput>
+template <int NT, bool EXACT, int W = 0, int BF = 0, typename LoadInput>
 DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool need_input_grad, LoadInput load_input,
                       int op_begin, int op_end) {
     const PmtModel* M = c.M;
@@ -699,7 +703,7 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
             if (uniform(o.selu_after) != 0) {  // recompute s = selu(Wx + b); dy <- dy * selu'(s)
                 f4 y[PMT_RT][NT];
                 init_bias<NT>(y, uniform(L.b_pvec) >= 0 ? c.packed + uniform(L.b_pvec) : nullptr, out_dim, c.g);
-                if constexpr (BF) linear_acc_bf16<NT, NT, false>(y, x, c.packed + uniform(L.wb_frag));
+                if constexpr (BF) linear_acc_bf16<NT, NT, false, BF>(y, x, c.packed + uniform(L.wb_frag));
                 else linear_acc<NT, NT, false, EXACT, W>(y, x, c.packed + uniform(L.w_frag), in_dim, out_dim);
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
@@ -710,7 +714,7 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
             if (op > op_begin || need_input_grad) {
                 f4 dx[PMT_RT][NT];
                 init_bias<NT>(dx, nullptr, in_dim, c.g);
-                if constexpr (BF) linear_acc_bf16<NT, NT, false>(dx, dy, c.packed + uniform(L.wtb_frag));
+                if constexpr (BF) linear_acc_bf16<NT, NT, false, BF>(dx, dy, c.packed + uniform(L.wtb_frag));
                 else linear_acc<NT, NT, false, EXACT, W>(dx, dy, c.packed + uniform(L.wt_frag), out_dim, in_dim);
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
@@ -729,7 +733,7 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
             f4 s1[PMT_RT][NT];
             if (nl == 2) {  // s1 = selu(L1 selu(x) + b1)
                 init_bias<NT>(s1, c.packed + uniform(L1.b_pvec), width, c.g);
-                if constexpr (BF) linear_acc_bf16<NT, NT, true>(s1, x, c.packed + uniform(L1.wb_frag));
+                if constexpr (BF) linear_acc_bf16<NT, NT, true, BF>(s1, x, c.packed + uniform(L1.wb_frag));
                 else linear_acc<NT, NT, true, EXACT, W>(s1, x, c.packed + uniform(L1.w_frag), width, width);
             }
 #pragma unroll
@@ -740,7 +744,7 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
             linear_wgrad<NT, NT, BF>(c, L2, dy, s1, alpha);
             f4 d1[PMT_RT][NT];
             init_bias<NT>(d1, nullptr, width, c.g);
-            if constexpr (BF) linear_acc_bf16<NT, NT, false>(d1, dy, c.packed + uniform(L2.wtb_frag));
+            if constexpr (BF) linear_acc_bf16<NT, NT, false, BF>(d1, dy, c.packed + uniform(L2.wtb_frag));
             else linear_acc<NT, NT, false, EXACT, W>(d1, dy, c.packed + uniform(L2.wt_frag), width, width);
             {   // d(alpha) = sum dy . f with f = W2 s1 + b2, i.e. sum (W2^T dy) . s1 + sum dy . b2: the first factor is d1 as it
                 // stands here, so the forward product f is never formed (it was a quarter of this op's matrix work)
@@ -771,7 +775,7 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
                 linear_wgrad<NT, NT, BF>(c, L1, d1, s0);
                 f4 d0[PMT_RT][NT];
                 init_bias<NT>(d0, nullptr, width, c.g);
-                if constexpr (BF) linear_acc_bf16<NT, NT, false>(d0, d1, c.packed + uniform(L1.wtb_frag));
+                if constexpr (BF) linear_acc_bf16<NT, NT, false, BF>(d0, d1, c.packed + uniform(L1.wtb_frag));
                 else linear_acc<NT, NT, false, EXACT, W>(d0, d1, c.packed + uniform(L1.wt_frag), width, width);
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)

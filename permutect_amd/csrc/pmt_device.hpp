@@ -48,19 +48,21 @@ static_assert(PMT_GROUP_TILES == PMT_WG_TILES, "group capacity");
 // XF .. XE (only with EXACT): the EXACT widths of the model, known at compile time (0 = read from the descriptor).  With them
 // the padding masks (feature < width), the k-steps that hold nothing but padding and most width bookkeeping fold away:
 // the masks alone cost ~30 SGPR pairs that the generic code keeps (and spills) across the block loop.
-// XBF: the layers' matrix products run as SIX bf16 MFMAs on three-piece splits of both operands (linear_acc_bf16) instead
-// of exact-fp32 MFMAs.
-template <int F, int R, int D, int E, bool EXACT_, int XF = 0, int XR = 0, int XD = 0, int XH = 0, int XE = 0, bool XBF = false>
+// XBF: 0 = exact-fp32 MFMAs; 3 = the layers' matrix products as SIX bf16 MFMAs on three-piece splits of both operands
+// (linear_acc_bf16: fp32-equivalent); 1 = ONE bf16 MFMA per product on single bf16 roundings of both operands -- the plain
+// bf16 mode BASELINE.json's training configuration names: no parity claim, measured and labelled as such (bench.py --dtype bf16).
+template <int F, int R, int D, int E, bool EXACT_, int XF = 0, int XR = 0, int XD = 0, int XH = 0, int XE = 0, int XBF = 0>
 struct Shape {
     static constexpr int NTF = F, NTR = R, NTD = D, NTE = E;
     static constexpr bool EXACT = EXACT_;
     static constexpr int DIM_F = XF, DIM_R = XR, DIM_D = XD, DIM_H = XH, DIM_E = XE;  // read features, read width, d_model, d_ffn / 2, feature_dim
-    static constexpr bool BF16 = XBF;
+    static constexpr int BF16 = XBF;  // pieces per operand (0: fp32 MFMA)
     static_assert(!XBF || EXACT_, "the bf16 path has no tile guards");
 };
 using ShapeAny = Shape<4, 4, 4, 4, false>;   // any supported model
 using ShapeP0 = Shape<4, 2, 4, 1, true>;     // F in 49..64, read widths 17..32, d_model / reducer widths 49..64, E <= 16
-using ShapeP0X = Shape<4, 2, 4, 1, true, 61, 30, 60, 10, 10, true>;  // exactly the production hyperparameters (SURVEY: P0)
+using ShapeP0X = Shape<4, 2, 4, 1, true, 61, 30, 60, 10, 10, 3>;  // exactly the production hyperparameters (SURVEY: P0)
+using ShapeP0XB = Shape<4, 2, 4, 1, true, 61, 30, 60, 10, 10, 1>; // the same widths, plain bf16 products (not a parity mode)
 
 DEV float uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -189,8 +191,9 @@ DEV void split_bf16x3(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
     mid = (__bf16)r1;
     lo = (__bf16)(r1 - (float)mid);
 }
-template <int NTI, int NTO, bool SELU_IN>
+template <int NTI, int NTO, bool SELU_IN, int PIECES = 3>
 DEV void linear_acc_bf16(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], const float* __restrict__ fragb, float in_scale = 1.0f) {
+    static_assert(PIECES == 3 || PIECES == 1, "three-piece (fp32-equivalent) or single-piece (plain bf16) products");
     constexpr int NKB = (NTI + 1) / 2;
     const bf8* __restrict__ fp = reinterpret_cast<const bf8*>(fragb) + (threadIdx.x & 63);
 #pragma unroll
@@ -206,34 +209,46 @@ DEV void linear_acc_bf16(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], co
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                __bf16 h, m, l;
-                split_bf16x3(v0[e], h, m, l);
-                bh[rt][e] = h; bm[rt][e] = m; bl[rt][e] = l;
-                split_bf16x3(v1[e], h, m, l);
-                bh[rt][4 + e] = h; bm[rt][4 + e] = m; bl[rt][4 + e] = l;
+                if constexpr (PIECES == 1) {
+                    bh[rt][e] = (__bf16)v0[e];
+                    bh[rt][4 + e] = (__bf16)v1[e];
+                } else {
+                    __bf16 h, m, l;
+                    split_bf16x3(v0[e], h, m, l);
+                    bh[rt][e] = h; bm[rt][e] = m; bl[rt][e] = l;
+                    split_bf16x3(v1[e], h, m, l);
+                    bh[rt][4 + e] = h; bm[rt][4 + e] = m; bl[rt][4 + e] = l;
+                }
             }
         }
         const bool half_block = 2 * kb + 1 >= NTI;  // a last k block with one tile only: the 16-deep MFMA on the lower halves
 #pragma unroll
         for (int mt = 0; mt < NTO; ++mt) {
-            const bf8 ah = fp[0], am = fp[64], al = fp[128];
-            fp += 192;
+            const bf8 ah = fp[0];
+            if constexpr (PIECES == 1) {
+                fp += 192;  // (the weights keep their three-piece layout; the hi piece alone is the bf16 rounding of the weight)
 #pragma unroll
-            for (int rt = 0; rt < PMT_RT; ++rt) {  // smallest terms first
-                if (half_block) {
-                    acc[rt][mt] = mfma_bf16_k16(al, bh[rt], acc[rt][mt]);
-                    acc[rt][mt] = mfma_bf16_k16(ah, bl[rt], acc[rt][mt]);
-                    acc[rt][mt] = mfma_bf16_k16(am, bm[rt], acc[rt][mt]);
-                    acc[rt][mt] = mfma_bf16_k16(am, bh[rt], acc[rt][mt]);
-                    acc[rt][mt] = mfma_bf16_k16(ah, bm[rt], acc[rt][mt]);
-                    acc[rt][mt] = mfma_bf16_k16(ah, bh[rt], acc[rt][mt]);
-                } else {
-                    acc[rt][mt] = mfma_bf16(al, bh[rt], acc[rt][mt]);
-                    acc[rt][mt] = mfma_bf16(ah, bl[rt], acc[rt][mt]);
-                    acc[rt][mt] = mfma_bf16(am, bm[rt], acc[rt][mt]);
-                    acc[rt][mt] = mfma_bf16(am, bh[rt], acc[rt][mt]);
-                    acc[rt][mt] = mfma_bf16(ah, bm[rt], acc[rt][mt]);
-                    acc[rt][mt] = mfma_bf16(ah, bh[rt], acc[rt][mt]);
+                for (int rt = 0; rt < PMT_RT; ++rt) acc[rt][mt] = half_block ? mfma_bf16_k16(ah, bh[rt], acc[rt][mt]) : mfma_bf16(ah, bh[rt], acc[rt][mt]);
+            } else {
+                const bf8 am = fp[64], al = fp[128];
+                fp += 192;
+#pragma unroll
+                for (int rt = 0; rt < PMT_RT; ++rt) {  // smallest terms first
+                    if (half_block) {
+                        acc[rt][mt] = mfma_bf16_k16(al, bh[rt], acc[rt][mt]);
+                        acc[rt][mt] = mfma_bf16_k16(ah, bl[rt], acc[rt][mt]);
+                        acc[rt][mt] = mfma_bf16_k16(am, bm[rt], acc[rt][mt]);
+                        acc[rt][mt] = mfma_bf16_k16(am, bh[rt], acc[rt][mt]);
+                        acc[rt][mt] = mfma_bf16_k16(ah, bm[rt], acc[rt][mt]);
+                        acc[rt][mt] = mfma_bf16_k16(ah, bh[rt], acc[rt][mt]);
+                    } else {
+                        acc[rt][mt] = mfma_bf16(al, bh[rt], acc[rt][mt]);
+                        acc[rt][mt] = mfma_bf16(ah, bl[rt], acc[rt][mt]);
+                        acc[rt][mt] = mfma_bf16(am, bm[rt], acc[rt][mt]);
+                        acc[rt][mt] = mfma_bf16(am, bh[rt], acc[rt][mt]);
+                        acc[rt][mt] = mfma_bf16(ah, bm[rt], acc[rt][mt]);
+                        acc[rt][mt] = mfma_bf16(ah, bh[rt], acc[rt][mt]);
+                    }
                 }
             }
         }

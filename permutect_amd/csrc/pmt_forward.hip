@@ -193,7 +193,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
             const f4 b0 = load_pvec(bp, 0, g), b1 = load_pvec(bp, 1, g);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) { z[rt][0] = b0; z[rt][1] = b1; }
-            if constexpr (S::BF16) linear_acc_bf16<NTD, 2, false>(z, n, packed + uniform(M->lin[uniform(B.proj1[side])].wb_frag));
+            if constexpr (S::BF16) linear_acc_bf16<NTD, 2, false, S::BF16>(z, n, packed + uniform(M->lin[uniform(B.proj1[side])].wb_frag));
             else linear_acc<NTD, 2, false, EX, S::DIM_D>(z, n, stA + side * frag_floats_dev(P1r), D, 16 + h);
         // SELU, LayerNorm(h) on z2, per-set sums (reference gated_mlp.py:228-239)
 #pragma unroll
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt) x[rt][t] = x[rt][t] + b;
             }
-            if constexpr (S::BF16) linear_acc_bf16<1, NTD, false>(x, u, packed + uniform(M->lin[uniform(B.proj2[side])].wb_frag));
+            if constexpr (S::BF16) linear_acc_bf16<1, NTD, false, S::BF16>(x, u, packed + uniform(M->lin[uniform(B.proj2[side])].wb_frag));
             else linear_acc<1, NTD, false, EX, S::DIM_H>(x, u, p2_frags + side * frag_floats_dev(P2r), h, D);
         }
     }
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
                 a[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        if constexpr (S::BF16) linear_acc_bf16<NTE, NTE, false>(a, e, packed + uniform(R.wb_frag));
+        if constexpr (S::BF16) linear_acc_bf16<NTE, NTE, false, S::BF16>(a, e, packed + uniform(R.wb_frag));
         else linear_acc<NTE, NTE, false, EX, S::DIM_E>(a, e, stR, E, E);
     }
 
@@ -542,7 +542,7 @@ extern "C" int pmt_forward_layered(const PmtModel* model_host, const PmtModel* m
     if (hipMemsetAsync(lay.fsum_g, 0, B * (2 * PMT_MAX_WIDTH + PMT_MAX_CLUSTERS + 2) * sizeof(float), s) != hipSuccess) return PMT_E_LAUNCH;
     auto kernel = stash ? (p0 ? pmt_forward_kernel<true, ShapeP0, true> : pmt_forward_kernel<true, ShapeAny, true>)
                         : (p0 ? pmt_forward_kernel<false, ShapeP0, true> : pmt_forward_kernel<false, ShapeAny, true>);
-    if (shape == 2) kernel = stash ? pmt_forward_kernel<true, ShapeP0X, true> : pmt_forward_kernel<false, ShapeP0X, true>;
+    if (shape >= 2) kernel = stash ? pmt_forward_kernel<true, ShapeP0X, true> : pmt_forward_kernel<false, ShapeP0X, true>;  // (layered: no plain-bf16 instance)
     for (int slice = 0; slice <= L; ++slice) {
         lay.slice = slice;
         hipLaunchKernelGGL(kernel, dim3(batch->num_groups), dim3(PMT_THREADS), 0, s, model_dev, theta, phi, packed, *batch, *out, stash,
@@ -579,6 +579,7 @@ extern "C" int pmt_forward(const PmtModel* model_host, const PmtModel* model_dev
     auto kernel = stash ? (p0 ? pmt_forward_kernel<true, ShapeP0> : pmt_forward_kernel<true, ShapeAny>)
                         : (p0 ? pmt_forward_kernel<false, ShapeP0> : pmt_forward_kernel<false, ShapeAny>);
     if (shape == 2) kernel = stash ? pmt_forward_kernel<true, ShapeP0X> : pmt_forward_kernel<false, ShapeP0X>;
+    if (shape == 3) kernel = stash ? pmt_forward_kernel<true, ShapeP0XB> : pmt_forward_kernel<false, ShapeP0XB>;  // plain bf16 products
     hipLaunchKernelGGL(kernel, dim3(batch->num_groups), dim3(PMT_THREADS), 0, s, model_dev, theta, phi, packed, *batch, *out,
                        stash, zsum_stash, rstd_stash, PmtLayeredArgs{});
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;

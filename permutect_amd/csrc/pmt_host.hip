@@ -81,7 +81,7 @@ extern "C" int pmt_shape_id(const PmtModel* m) {
     const bool exact = m->num_read_features == 61 && Lf->in_dim == 61 && Lf->out_dim == 30 && mlp_ops_have_width(m, rm, 1, rm->n_ops, 30) &&
                        m->read_embed_dim == 30 && m->d_model == 60 && m->d_ffn == 20 &&
                        mlp_ops_have_width(m, red, 0, red->n_ops - 1, 60) && Ll->in_dim == 60 && Ll->out_dim == 10 && m->feature_dim == 10;
-    return exact ? 2 : 1;
+    return exact ? (m->force_shape == 3 ? 3 : 2) : 1;  // 3: the exact widths with plain bf16 products (asked for explicitly only)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -6,7 +6,7 @@
 // reducer, the wide first op of a row MLP): y = act(W x + b).
 // WI / WO / W (compile time, 0 = read the descriptor): the widths, for the instances that have them compiled in.
 // BF: the matrix products on the bf16 pipe (linear_acc_bf16; exact instances, direct weight path only).
-template <int NTI, int NTO, bool EXACT, int WI = 0, int WO = 0, bool BF = false>
+template <int NTI, int NTO, bool EXACT, int WI = 0, int WO = 0, int BF = 0>
 DEV void run_linear_op(const PmtModel* __restrict__ M, const PmtOp& o, f4 (&y)[PMT_RT][NTO], const f4 (&x)[PMT_RT][NTI],
                        int g, const float* __restrict__ packed) {
     const PmtLinear& L = M->lin[uniform(o.lin[0])];
@@ -14,7 +14,7 @@ DEV void run_linear_op(const PmtModel* __restrict__ M, const PmtOp& o, f4 (&y)[P
     const float* st = packed + base;  // [fragments | bias]
     const int in_dim = WI ? WI : uniform(L.in_dim), out_dim = WO ? WO : uniform(L.out_dim);
     init_bias<NTO>(y, b_pvec >= 0 ? st + (b_pvec - base) : nullptr, out_dim, g);
-    if constexpr (BF) linear_acc_bf16<NTI, NTO, false>(y, x, packed + uniform(L.wb_frag));
+    if constexpr (BF) linear_acc_bf16<NTI, NTO, false, BF>(y, x, packed + uniform(L.wb_frag));
     else linear_acc<NTI, NTO, false, EXACT, WI>(y, x, st, in_dim, out_dim);
     if (uniform(o.selu_after) != 0) {
 #pragma unroll
@@ -28,7 +28,7 @@ DEV void run_linear_op(const PmtModel* __restrict__ M, const PmtOp& o, f4 (&y)[P
 // Runs ops [op_begin, op_end) on x in place; every op in the range maps NT tiles to NT tiles.  With TRAIN the INPUT of
 // every op with index >= first_stashed_op is written to consecutive stash slots starting at `slot` (tiles in
 // store_mask only).
-template <bool TRAIN, int NT, bool EXACT, int W = 0, bool BF = false>
+template <bool TRAIN, int NT, bool EXACT, int W = 0, int BF = 0>
 DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_RT][NT], const float* __restrict__ theta,
                  int g, unsigned store_mask, float* const (&stash_tile)[PMT_RT], int& slot, int first_stashed_op,
                  const float* __restrict__ packed, int op_begin, int op_end) {
@@ -61,7 +61,7 @@ DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_
                 const PmtLinear& L1 = M->lin[uniform(o.lin[0])];
                 const float* st1 = packed + uniform(L1.w_frag);
                 init_bias<NT>(y, st1 + (uniform(L1.b_pvec) - uniform(L1.w_frag)), width, g);
-                if constexpr (BF) linear_acc_bf16<NT, NT, true>(y, x, packed + uniform(L1.wb_frag));
+                if constexpr (BF) linear_acc_bf16<NT, NT, true, BF>(y, x, packed + uniform(L1.wb_frag));
                 else linear_acc<NT, NT, true, EXACT, W>(y, x, st1, width, width);
             }
             const PmtLinear& L2 = M->lin[uniform(o.lin[nl - 1])];
@@ -76,7 +76,7 @@ DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_
                     for (int rt = 0; rt < PMT_RT; ++rt) x[rt][t] = x[rt][t] + b;
                 }
             }
-            if constexpr (BF) linear_acc_bf16<NT, NT, true>(x, y, packed + uniform(L2.wb_frag), alpha);
+            if constexpr (BF) linear_acc_bf16<NT, NT, true, BF>(x, y, packed + uniform(L2.wb_frag), alpha);
             else linear_acc<NT, NT, true, EXACT, W>(x, y, st2, width, width, alpha);
         }
     }

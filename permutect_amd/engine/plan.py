@@ -173,7 +173,7 @@ class EnginePlan:
         d.theta_size, d.phi_size, d.packed_size = space.size, max(self._phi_off, 4), self._packed_off + 512  # slack: the kernels prefetch two fragments ahead
         # Which kernel instances run is part of the descriptor (the library itself reads no environment).  The parity tests
         # select the non-default instances through these variables, read HERE, once, when the model is lowered.
-        d.force_shape = {"tile": 1, "any": 2}.get(os.environ.get("PMT_SHAPE", ""), 0)
+        d.force_shape = {"tile": 1, "any": 2, "bf16": 3}.get(os.environ.get("PMT_SHAPE", ""), 0)
         d.force_cnn = {"general": 1, "wave": 2, "batched": 3}.get(os.environ.get("PMT_CNN", ""), 0)
         d.cnn_debug = int(os.environ.get("PMT_CNN_DBG", "0"))
 

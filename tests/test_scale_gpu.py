@@ -105,3 +105,36 @@ def test_forward_and_every_gradient_at_8192_read_sets(kernel_shape):
            max_feature_err=float(feat_err), max_loss_err=float(loss_err), grad_rel_l2=rel_l2, worst_tensor=worst_name, worst_tensor_rel=worst)
     assert worst <= 5e-4, (worst_name, worst)
     assert rel_l2 <= 1e-4, rel_l2
+
+
+def test_plain_bf16_mode_is_a_labelled_approximation(monkeypatch):
+    """PMT_SHAPE=bf16 (bench.py --dtype bf16): one bf16 MFMA per product.  NOT a parity mode -- this test only pins that it runs,
+    stays finite, lands near the fp32-equivalent answer, and records how near (DESIGN.md quotes the numbers)."""
+    monkeypatch.setenv("PMT_SHAPE", "bf16")
+    nb = 2048
+    _, sd, _ = load_case("p0_b16")
+    cfg = config_for("p0_b16")
+    ints, floats, packed = synth(nb, seed=12)
+    model, dev = build("p0_b16", sd)
+    assert model.engine().plan.desc.force_shape == 3
+    model.train(True)
+    batch = Batch.from_arrays(ints, floats, packed).copy_to(dev)
+    out = model.compute_batch_output(batch)
+    losses = model.compute_batch_losses(out, batch)
+    opt = FusedClipAdamW(model, lr=1e-3, weight_decay=0.01)
+    opt.zero_grad()
+    losses.total_loss.backward()
+    torch.cuda.synchronize()
+    i64 = torch.from_numpy(ints.astype(np.int64))
+    ob = dict(reads_re=torch.from_numpy(O.decode_packed_reads(packed).astype(np.float32)), nref=i64[:, O.REF_COUNT],
+              nalt=i64[:, O.ALT_COUNT], labels=i64[:, O.LABEL], sources=i64[:, O.SOURCE],
+              info_be=torch.from_numpy(floats[:, O.INFO_START:].astype(np.float32)), haplotypes_bh=i64[:, O.HAPLOTYPES_START:])
+    ref_out, _, ref_grads = O.train_step_grads(sd, cfg, ob)
+    logit_err = np.abs(out.logits_b.detach().cpu().numpy() - ref_out["logits_b"].detach().numpy())
+    names = [n for n, _ in model.named_parameters()]
+    gref = np.concatenate([ref_grads[n].numpy().ravel() for n in names])
+    gour = np.concatenate([p.grad.detach().cpu().numpy().ravel() for _, p in model.named_parameters()])
+    rel_l2 = float(np.linalg.norm(gour - gref) / np.linalg.norm(gref))
+    record(test="plain_bf16_2048", max_logit_err=float(logit_err.max()), median_logit_err=float(np.median(logit_err)), grad_rel_l2=rel_l2)
+    assert np.all(np.isfinite(gour)) and np.all(np.isfinite(logit_err))
+    assert np.median(logit_err) < 0.5 and rel_l2 < 0.2, (float(np.median(logit_err)), rel_l2)
