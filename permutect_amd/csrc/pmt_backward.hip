@@ -16,6 +16,9 @@
 // architectural VGPRs, so a 512-register "fat wave" (4 x 4) just shuffles values through AGPRs: measured slower.
 #define PMT_WAVES 8
 #define PMT_RT 2
+#ifndef PMT_BWD_PIECES
+#define PMT_BWD_PIECES 3  // (2 was measured: 3.50 -> 3.45 ms, one tensor's error 9e-5 -> 2.4e-4 of its scale: not worth it)
+#endif
 #include "pmt_device.hpp"
 #include "pmt_bwd_device.hpp"
 
@@ -81,6 +84,9 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
     float* __restrict__ gvar, PmtBwdLayered lay) {
     constexpr int NTF = S::NTF, NTR = S::NTR, NTD = S::NTD, NTE = S::NTE;
     constexpr bool EX = S::EXACT;
+    // Pieces of the activations / gradients in the backward's products (PMT_BWD_PIECES): three, like the forward.  Two (hi + mid,
+    // five MFMAs and a shorter split) measured 1.4 % faster with a visibly larger error on single tensors, and stays off.
+    constexpr int BFB = S::BF16 == 3 ? PMT_BWD_PIECES : S::BF16;
     static_assert(EX || (NTF == NTD && NTR == NTD && NTE == NTD), "the generic shape keeps one array width");
     __shared__ __attribute__((aligned(16))) BwdShared sh;
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, wave = uniform((int)(tid >> 6));
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             if constexpr (EX) {
                 const PmtLinear& Lr = M->lin[uniform(red_last.lin[0])];
                 init_bias<NTE>(e, uniform(Lr.b_pvec) >= 0 ? packed + uniform(Lr.b_pvec) : nullptr, E, g);
-                if constexpr (S::BF16) linear_acc_bf16<NTD, NTE, false, S::BF16>(e, r, packed + uniform(Lr.wb_frag));
+                if constexpr (S::BF16) linear_acc_bf16<NTD, NTE, false, BFB>(e, r, packed + uniform(Lr.wb_frag));
                 else linear_acc<NTD, NTE, false, true, S::DIM_D>(e, r, packed + uniform(Lr.w_frag), D, E);
                 if (uniform(red_last.selu_after) != 0) {
 #pragma unroll
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
                 a[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        if constexpr (S::BF16) linear_acc_bf16<NTE, NTE, false, S::BF16>(a, e, packed + uniform(R.wb_frag));
+        if constexpr (S::BF16) linear_acc_bf16<NTE, NTE, false, BFB>(a, e, packed + uniform(R.wb_frag));
         else linear_acc<NTE, NTE, false, EX, S::DIM_E>(a, e, packed + uniform(R.w_frag), E, E);
 
         // ---- head backward (alt reads) + set-mean gradients -> d(a) in da ------------------------------------------
@@ -349,10 +355,10 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         prof_add(c, 4, t_kernel0);
         unsigned long long t_rot = prof_now();
         // ---- rotation + translation backward: a = Q (e + t) ------------------------------------------------------------
-        linear_wgrad<NTE, NTE, S::BF16>(c, R, da, e);
+        linear_wgrad<NTE, NTE, BFB>(c, R, da, e);
         f4 de[PMT_RT][NTE];
         init_bias<NTE>(de, nullptr, E, g);
-        if constexpr (S::BF16) linear_acc_bf16<NTE, NTE, false, S::BF16>(de, da, packed + uniform(R.wtb_frag));
+        if constexpr (S::BF16) linear_acc_bf16<NTE, NTE, false, BFB>(de, da, packed + uniform(R.wtb_frag));
         else linear_acc<NTE, NTE, false, EX, S::DIM_E>(de, da, packed + uniform(R.wt_frag), E, E);
         f4 dt[NTE];
 #pragma unroll
@@ -367,7 +373,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         if constexpr (EX) {
             f4 r[PMT_RT][NTD];
             load_slot_tiles<NTD>(stash_tile, mask_all, slot_last_in, r);
-            linear_op_backward<NTD, NTE, true, S::DIM_D, S::DIM_E, S::BF16>(c, red_last, de, r, dy, true);
+            linear_op_backward<NTD, NTE, true, S::DIM_D, S::DIM_E, BFB>(c, red_last, de, r, dy, true);
         } else {
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
@@ -379,7 +385,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
 
     // ---- reducer backward ---------------------------------------------------------------------------------------------
     if (!(LAYERED && lay.slice > 0))
-    mlp_backward<NTD, EX, S::DIM_D, S::BF16>(c, M->reducer, dy, true,
+    mlp_backward<NTD, EX, S::DIM_D, BFB>(c, M->reducer, dy, true,
                           [&](int op, f4 (&x)[PMT_RT][NTD]) { load_slot_tiles<NTD>(stash_tile, mask_all, op == 0 ? slot_x0 + L : slot_red + op - 1, x, c.pf_sink); },
                           0, EX ? n_red_ops - 1 : n_red_ops);
 
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             const f4 b0 = load_pvec(packed + uniform(P1.b_pvec), 0, g), b1 = load_pvec(packed + uniform(P1.b_pvec), 1, g);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) { z[rt][0] = b0; z[rt][1] = b1; }
-            if constexpr (S::BF16) linear_acc_bf16<NTD, 2, false, S::BF16>(z, n, packed + uniform(P1.wb_frag));
+            if constexpr (S::BF16) linear_acc_bf16<NTD, 2, false, BFB>(z, n, packed + uniform(P1.wb_frag));
             else linear_acc<NTD, 2, false, EX, S::DIM_D>(z, n, packed + uniform(P1.w_frag), D, 16 + h);
         }
         const f4 sw = load_pvec(packed + uniform(B.sgu_norm_w_pvec), 0, g), sb = load_pvec(packed + uniform(B.sgu_norm_b_pvec), 0, g);
@@ -456,7 +462,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt) du[rt][0] = f4{0.f, 0.f, 0.f, 0.f};
         if (first_half) {
-            if constexpr (S::BF16) linear_acc_bf16<NTD, 1, false, S::BF16>(du, dy, packed + uniform(P2.wtb_frag));
+            if constexpr (S::BF16) linear_acc_bf16<NTD, 1, false, BFB>(du, dy, packed + uniform(P2.wtb_frag));
             else linear_acc<NTD, 1, false, EX, S::DIM_D>(du, dy, packed + uniform(P2.wt_frag), D, h);
         }
         if (first_half) {
@@ -486,7 +492,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             prof_add(c, 9, t_ph);
             t_ph = prof_now();
             // proj2 weight gradients of both sides in one exchange round
-            if constexpr (S::BF16 != 0) wgrad_exchange_bf<NTD, 1, 2, S::BF16>(c, M->lin[uniform(B.proj2[0])], M->lin[uniform(B.proj2[1])], dy, u, 1.0f);
+            if constexpr (S::BF16 != 0) wgrad_exchange_bf<NTD, 1, 2, BFB>(c, M->lin[uniform(B.proj2[0])], M->lin[uniform(B.proj2[1])], dy, u, 1.0f);
             else wgrad_exchange<NTD, 1, 2>(c, M->lin[uniform(B.proj2[0])], M->lin[uniform(B.proj2[1])], dy, u, 1.0f);
         }
         if (c.dbg & 1) __syncthreads();  // (the exchange's barriers, skipped by that switch, complete gsum)
@@ -594,7 +600,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         {
             f4 n[PMT_RT][NTD];
             recompute_n(n);
-            if constexpr (S::BF16 != 0) wgrad_exchange_bf<2, NTD, 2, S::BF16>(c, M->lin[uniform(B.proj1[0])], M->lin[uniform(B.proj1[1])], dz, n, 1.0f);
+            if constexpr (S::BF16 != 0) wgrad_exchange_bf<2, NTD, 2, BFB>(c, M->lin[uniform(B.proj1[0])], M->lin[uniform(B.proj1[1])], dz, n, 1.0f);
             else wgrad_exchange<2, NTD, 2>(c, M->lin[uniform(B.proj1[0])], M->lin[uniform(B.proj1[1])], dz, n, 1.0f);
         }
         prof_add(c, 13, t_ph);
@@ -602,7 +608,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         {
             f4 dn[PMT_RT][NTD];
             init_bias<NTD>(dn, nullptr, D, g);
-            if constexpr (S::BF16) linear_acc_bf16<2, NTD, false, S::BF16>(dn, dz, packed + uniform(P1.wtb_frag));
+            if constexpr (S::BF16) linear_acc_bf16<2, NTD, false, BFB>(dn, dz, packed + uniform(P1.wtb_frag));
             else linear_acc<2, NTD, false, EX, 0, S::DIM_H>(dn, dz, packed + uniform(P1.wt_frag), 16 + h, D);
             f4 lw[NTD], dlw[NTD], dlb[NTD];
 #pragma unroll
@@ -672,11 +678,11 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
             for (int t = 0; t < NTR; ++t) dr[rt][t] = dy[rt][t < NTD ? t : 0];
-        mlp_backward<NTR, true, S::DIM_R, S::BF16>(c, M->read_mlp, dr, true,
+        mlp_backward<NTR, true, S::DIM_R, BFB>(c, M->read_mlp, dr, true,
                                 [&](int op, f4 (&x)[PMT_RT][NTR]) { load_slot_tiles<NTR>(stash_tile, mask_all, op - 1, x, c.pf_sink); }, 1, n_read_ops);
         f4 xf[PMT_RT][NTF], dxf[PMT_RT][NTF];
         decode_reads(xf);
-        linear_op_backward<NTF, NTR, true, S::DIM_F, S::DIM_R, S::BF16>(c, M->read_mlp.ops[0], dr, xf, dxf, false);
+        linear_op_backward<NTF, NTR, true, S::DIM_F, S::DIM_R, BFB>(c, M->read_mlp.ops[0], dr, xf, dxf, false);
     } else {
         mlp_backward<NTD, false>(c, M->read_mlp, dy, false,
                                  [&](int op, f4 (&x)[PMT_RT][NTD]) {

@@ -193,7 +193,9 @@ DEV void split_bf16x3(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
 }
 template <int NTI, int NTO, bool SELU_IN, int PIECES = 3>
 DEV void linear_acc_bf16(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], const float* __restrict__ fragb, float in_scale = 1.0f) {
-    static_assert(PIECES == 3 || PIECES == 1, "three-piece (fp32-equivalent) or single-piece (plain bf16) products");
+    // PIECES = pieces of the ACTIVATION: 3 fp32-equivalent (six MFMAs), 2 hi + mid (16 significant bits; five MFMAs against the
+    // three-piece weights; the backward uses it: see pmt_backward.hip), 1 plain bf16
+    static_assert(PIECES >= 1 && PIECES <= 3, "pieces");
     constexpr int NKB = (NTI + 1) / 2;
     const bf8* __restrict__ fp = reinterpret_cast<const bf8*>(fragb) + (threadIdx.x & 63);
 #pragma unroll
@@ -212,6 +214,10 @@ DEV void linear_acc_bf16(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], co
                 if constexpr (PIECES == 1) {
                     bh[rt][e] = (__bf16)v0[e];
                     bh[rt][4 + e] = (__bf16)v1[e];
+                } else if constexpr (PIECES == 2) {
+                    const __bf16 h0 = (__bf16)v0[e], h1 = (__bf16)v1[e];
+                    bh[rt][e] = h0; bm[rt][e] = (__bf16)(v0[e] - (float)h0);
+                    bh[rt][4 + e] = h1; bm[rt][4 + e] = (__bf16)(v1[e] - (float)h1);
                 } else {
                     __bf16 h, m, l;
                     split_bf16x3(v0[e], h, m, l);
@@ -236,14 +242,14 @@ DEV void linear_acc_bf16(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], co
                 for (int rt = 0; rt < PMT_RT; ++rt) {  // smallest terms first
                     if (half_block) {
                         acc[rt][mt] = mfma_bf16_k16(al, bh[rt], acc[rt][mt]);
-                        acc[rt][mt] = mfma_bf16_k16(ah, bl[rt], acc[rt][mt]);
+                        if constexpr (PIECES == 3) acc[rt][mt] = mfma_bf16_k16(ah, bl[rt], acc[rt][mt]);
                         acc[rt][mt] = mfma_bf16_k16(am, bm[rt], acc[rt][mt]);
                         acc[rt][mt] = mfma_bf16_k16(am, bh[rt], acc[rt][mt]);
                         acc[rt][mt] = mfma_bf16_k16(ah, bm[rt], acc[rt][mt]);
                         acc[rt][mt] = mfma_bf16_k16(ah, bh[rt], acc[rt][mt]);
                     } else {
                         acc[rt][mt] = mfma_bf16(al, bh[rt], acc[rt][mt]);
-                        acc[rt][mt] = mfma_bf16(ah, bl[rt], acc[rt][mt]);
+                        if constexpr (PIECES == 3) acc[rt][mt] = mfma_bf16(ah, bl[rt], acc[rt][mt]);
                         acc[rt][mt] = mfma_bf16(am, bm[rt], acc[rt][mt]);
                         acc[rt][mt] = mfma_bf16(am, bh[rt], acc[rt][mt]);
                         acc[rt][mt] = mfma_bf16(ah, bm[rt], acc[rt][mt]);
