@@ -425,8 +425,25 @@ def main():
                 pool.append(b.copy_to(dev))
             et, _ = timed("train", pool, k, 10)
             ef, _ = timed("filter", pool, k, 10)
-            note(f"B={bsz}: train {1e3 * et / k:.3f} ms/step, filter {1e3 * ef / k:.3f} ms/step")
+            # the same train step as ONE captured HIP graph (engine/graph.py); every replay is preceded by the upload of a new
+            # batch into the graph's static buffers, as a training loop would do it
+            from permutect_amd.engine.graph import GraphedTrainStep, StaticBatch
+            hosts = [Batch.from_arrays(*synth_arrays(srng, bsz, "wgs"), pack=True).pin_memory() for _ in range(4)]
+            static = StaticBatch(bsz, max_reads=26 * bsz, device=dev, int_cols=58, float_cols=77)
+            gstep = GraphedTrainStep(model, opt, static)
+            for i in range(10):
+                static.load(hosts[i % 4])
+                gstep()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(k):
+                static.load(hosts[i % 4])
+                gstep()
+            torch.cuda.synchronize()
+            eg = time.perf_counter() - t0
+            note(f"B={bsz}: train {1e3 * et / k:.3f} ms/step (captured graph incl. batch upload: {1e3 * eg / k:.3f}), filter {1e3 * ef / k:.3f} ms/step")
             small[f"b{bsz}"] = {"train_read_sets_per_s": bsz * k / et, "train_ms_per_step": 1e3 * et / k,
+                                "train_graph_read_sets_per_s": bsz * k / eg, "train_graph_ms_per_step": 1e3 * eg / k,
                                 "filter_read_sets_per_s": bsz * k / ef, "filter_ms_per_step": 1e3 * ef / k}
 
     # ---- parity of what was just timed: first 2048 variants of resident batch 0 against the CPU oracle ---------------------

@@ -206,6 +206,10 @@ typedef struct PmtBatch {
                                        beyond one workgroup, pmt_plan_groups_split): v0, v1 (variants [v0, v1)), ref_begin,
                                        ref_end, alt_begin, alt_end (rows of the batch's ref / alt regions); group_start is
                                        then ignored.  Only pmt_forward_layered / pmt_backward_layered accept it. */
+    const int32_t* num_groups_dev;  /* device, optional [1]: the number of groups of THIS batch when num_groups is only the
+                                       capacity the launch is sized for: workgroups beyond it return at once.  Lets one
+                                       captured HIP graph (fixed grids) serve batches with different group plans;
+                                       pmt_forward / pmt_backward only */
 } PmtBatch;
 
 typedef struct PmtOutputs {
@@ -225,9 +229,13 @@ typedef struct PmtOutputGrads {
 
 typedef struct PmtAdamW {
     float lr, beta1, beta2, eps, weight_decay, max_grad_norm;
-    int32_t step;                   /* 1-based step number of this update */
+    int32_t step;                   /* 1-based step number of this update, or PMT_STEP_ON_DEVICE: the step count lives in
+                                       `scratch` (int32 at float index PMT_STEP_SLOT, zero before the first step) and the
+                                       launch increments it itself, so that a captured graph can be replayed */
     int32_t reserved;
 } PmtAdamW;
+#define PMT_STEP_ON_DEVICE (-1)
+#define PMT_STEP_SLOT 1000
 
 /* ---- host-side helpers (no GPU needed) ------------------------------------------------------------------- */
 

@@ -90,6 +90,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
     static_assert(EX || (NTF == NTD && NTR == NTD && NTE == NTD), "the generic shape keeps one array width");
     __shared__ __attribute__((aligned(16))) BwdShared sh;
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, wave = uniform((int)(tid >> 6));
+    if (bt.num_groups_dev != nullptr && (int)blockIdx.x >= uniform(bt.num_groups_dev[0])) return;  // grid sized for a capacity (graph replay)
     const GroupGeom gg = group_geometry(bt, blockIdx.x);
     const int side = gg.side;
     const int D = S::DIM_D ? S::DIM_D : uniform(M->d_model), E = S::DIM_E ? S::DIM_E : uniform(M->feature_dim), K = uniform(M->num_clusters);

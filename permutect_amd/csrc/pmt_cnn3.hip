@@ -580,6 +580,19 @@ static int cnn3_grid(int n, int v, int nw) {
     return (int)(wgs < cus ? wgs : cus);
 }
 
+// More than 64 KiB of dynamic LDS needs the function attribute.  It is raised once per device and kernel (a property of the
+// loaded code object, not library state that results depend on) and not touched again: the call is not a stream operation and
+// must stay out of a stream capture (engine/graph.py warms up eagerly first).
+static bool cnn3_allow_lds(const void* kernel, size_t bytes, int which) {
+    static size_t allowed[16][2] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (bytes <= allowed[dev][which]) return true;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+    allowed[dev][which] = bytes;
+    return true;
+}
+
 // 0 = done, 1 = configuration not covered (the caller runs the other kernels), < 0 = error
 extern "C" int pmt_cnn3_try_forward(const PmtModel* model_host, const float* theta, const int64_t* haplotypes, int64_t hap_stride, int32_t n,
                                     float* out, int64_t out_stride, float* stash, void* stream) {
@@ -587,7 +600,7 @@ extern "C" int pmt_cnn3_try_forward(const PmtModel* model_host, const float* the
     if (!cnn3_covers(model_host, &c, &cb)) return 1;
     const size_t lds = cnn3_lds_bytes(&c, false, C3_FWD_NW);
     auto kernel = pmt_cnn3_forward_kernel<C3_FWD_V, C3_FWD_NW>;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PMT_E_LAUNCH;
+    if (!cnn3_allow_lds(reinterpret_cast<const void*>(kernel), lds, 0)) return PMT_E_LAUNCH;
     hipLaunchKernelGGL(kernel, dim3(cnn3_grid(n, C3_FWD_V, C3_FWD_NW)), dim3(64 * C3_FWD_NW), lds, reinterpret_cast<hipStream_t>(stream), c, theta,
                        (const long long*)haplotypes, (long long)hap_stride, n, out, (long long)out_stride, stash);
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
@@ -599,7 +612,7 @@ extern "C" int pmt_cnn3_try_backward(const PmtModel* model_host, const float* th
     if (!stash || !cnn3_covers(model_host, &cf, &c)) return 1;
     const size_t lds = cnn3_lds_bytes(&c, true, C3_BWD_NW);
     auto kernel = pmt_cnn3_backward_kernel<C3_BWD_V, C3_BWD_NW, 3, 3, 7>;  // (cnn3_config admits exactly the instances compiled here)
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PMT_E_LAUNCH;
+    if (!cnn3_allow_lds(reinterpret_cast<const void*>(kernel), lds, 1)) return PMT_E_LAUNCH;
     hipLaunchKernelGGL(kernel, dim3(cnn3_grid(n, C3_BWD_V, C3_BWD_NW)), dim3(64 * C3_BWD_NW), lds, reinterpret_cast<hipStream_t>(stream), c, theta,
                        (const long long*)haplotypes, (long long)hap_stride, n, d_out, (long long)d_out_stride, stash, grad_theta);
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;

@@ -63,6 +63,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
     static_assert(EX || (NTF == NTD && NTR == NTD && NTE == NTD), "the generic shape keeps one array width");
     __shared__ __attribute__((aligned(16))) FwdShared sh;
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+    if (bt.num_groups_dev != nullptr && (int)blockIdx.x >= uniform(bt.num_groups_dev[0])) return;  // grid sized for a capacity (graph replay)
     const GroupGeom gg = group_geometry(bt, blockIdx.x);
     const int side = gg.side;
 

@@ -615,7 +615,9 @@ extern "C" int pmt_build_read_index(const int64_t* row_start, const int32_t* ref
 // fused clip_grad_norm_(max_norm) + AdamW over one flat buffer (reference misc_utils.py:128-129)
 // ---------------------------------------------------------------------------------------------------------------------
 #define PMT_OPT_BLOCKS 256
-__global__ __launch_bounds__(256) void pmt_sumsq_kernel(const float* __restrict__ g, long long n, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void pmt_sumsq_kernel(const float* __restrict__ g, long long n, float* __restrict__ partial,
+                                                        int* __restrict__ step_counter) {
+    if (step_counter != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *step_counter += 1;  // this update's 1-based step number
     double acc = 0.0;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += 256ll * gridDim.x) acc += (double)g[i] * (double)g[i];
     __shared__ double sh[256];
@@ -631,7 +633,8 @@ __global__ __launch_bounds__(256) void pmt_sumsq_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void pmt_adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, long long n,
                                                         PmtAdamW hp, const float* __restrict__ partial, int n_partial,
-                                                        float* __restrict__ norm_out) {
+                                                        float* __restrict__ norm_out, const int* __restrict__ step_counter) {
+    if (step_counter != nullptr) hp.step = *step_counter;  // (incremented by pmt_sumsq_kernel of this launch pair)
     __shared__ double sh[256];
     double acc = 0.0;
     for (int i = threadIdx.x; i < n_partial; i += 256) acc += (double)partial[i];
@@ -662,15 +665,17 @@ __global__ __launch_bounds__(256) void pmt_adamw_kernel(float* __restrict__ p, c
 
 extern "C" int pmt_clip_adamw(float* theta, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                               const PmtAdamW* hyper, float* scratch, float* grad_norm_out, void* stream) {
-    if (!theta || !grad || !exp_avg || !exp_avg_sq || !hyper || !scratch || n < 0 || hyper->step < 1) return PMT_E_INVALID;
+    if (!theta || !grad || !exp_avg || !exp_avg_sq || !hyper || !scratch || n < 0 || (hyper->step < 1 && hyper->step != PMT_STEP_ON_DEVICE))
+        return PMT_E_INVALID;
+    int* step_counter = hyper->step == PMT_STEP_ON_DEVICE ? reinterpret_cast<int*>(scratch) + PMT_STEP_SLOT : nullptr;
     if (n == 0) return PMT_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int blocks = (int)((n + 1023) / 1024);
     if (blocks > PMT_OPT_BLOCKS) blocks = PMT_OPT_BLOCKS;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(pmt_sumsq_kernel, dim3(blocks), dim3(256), 0, s, grad, (long long)n, scratch);
+    hipLaunchKernelGGL(pmt_sumsq_kernel, dim3(blocks), dim3(256), 0, s, grad, (long long)n, scratch, step_counter);
     hipLaunchKernelGGL(pmt_adamw_kernel, dim3(blocks), dim3(256), 0, s, theta, grad, exp_avg, exp_avg_sq, (long long)n,
-                       *hyper, (const float*)scratch, blocks, grad_norm_out);
+                       *hyper, (const float*)scratch, blocks, grad_norm_out, (const int*)step_counter);
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }
 

@@ -22,6 +22,7 @@ READS_PACKED_U8, READS_F16, READS_F32 = 0, 1, 2
 OP_LINEAR, OP_SKIP = 0, 1
 SLOT_FLOATS = 4 * 256
 
+STEP_ON_DEVICE, STEP_SLOT = -1, 1000
 E_INVALID, E_UNSUPPORTED, E_CAPACITY, E_LAUNCH, E_WORKSPACE = -1, -2, -3, -4, -5
 _ERR = {-1: "invalid argument/descriptor", -2: "configuration not supported by the gfx950 kernels",
         -3: "a read set exceeds the register-resident group capacity", -4: "HIP launch failure",
@@ -86,7 +87,8 @@ class PmtModel(C.Structure):
 class PmtBatch(C.Structure):
     _fields_ = [("num_variants", i32), ("num_groups", i32), ("read_format", i32), ("read_row_bytes", i32),
                 ("reads", vp), ("read_index", vp), ("ref_offsets", vp), ("alt_offsets", vp), ("variant_embed", vp),
-                ("group_start", vp), ("group_tile_base", vp), ("total_tiles", i64), ("debug_flags", vp), ("group_span", vp)]
+                ("group_start", vp), ("group_tile_base", vp), ("total_tiles", i64), ("debug_flags", vp), ("group_span", vp),
+                ("num_groups_dev", vp)]
 
 
 class PmtOutputs(C.Structure):

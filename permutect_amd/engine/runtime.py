@@ -86,6 +86,7 @@ class ReadSetEngine:
         bv.total_tiles = plan.total_tiles
         bv.debug_flags = self.plan.debug_flags.data_ptr()
         bv.group_span = _ptr(span)
+        bv.num_groups_dev = _ptr(getattr(plan, "num_groups_dev", None))  # (engine/graph.py: a plan sized for a capacity)
         keep = (gs, gt, span, ref_off, alt_off, reads, index, variant_embed)
         return bv, keep, plan
 

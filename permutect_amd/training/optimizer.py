@@ -38,18 +38,28 @@ class FusedClipAdamW:
         space.gtheta.zero_()
         space.bind_grads()
 
-    def step(self, pre_reduce=None):
-        """`pre_reduce(flat_grad)` (optional) runs before the clip: the data-parallel all-reduce hook."""
+    def step(self, pre_reduce=None, step_on_device: bool = False):
+        """`pre_reduce(flat_grad)` (optional) runs before the clip: the data-parallel all-reduce hook.
+        `step_on_device`: the step number (Adam's bias correction) is read from, and incremented in, device memory by the
+        launch itself (PMT_STEP_ON_DEVICE) -- what a captured graph needs; the caller keeps `step_count` in step
+        (engine/graph.py)."""
         space = self._bind()
         if pre_reduce is not None:
             pre_reduce(space.gtheta)
-        self.step_count += 1
+        if not step_on_device:
+            self.step_count += 1
         hp = L.PmtAdamW(self.param_groups[0]["lr"], self.betas[0], self.betas[1], self.eps,
-                        self.param_groups[0]["weight_decay"], self.max_grad_norm, self.step_count, 0)
+                        self.param_groups[0]["weight_decay"], self.max_grad_norm,
+                        L.STEP_ON_DEVICE if step_on_device else self.step_count, 0)
         L.check(L.load().pmt_clip_adamw(space.theta.data_ptr(), space.gtheta.data_ptr(), self.exp_avg.data_ptr(),
                                         self.exp_avg_sq.data_ptr(), space.size, C.byref(hp), self.scratch.data_ptr(),
                                         self.grad_norm.data_ptr(), torch.cuda.current_stream().cuda_stream),
                 "pmt_clip_adamw")
+
+    def set_device_step(self, n: int):
+        """the device-resident step counter of `step(step_on_device=True)`: n steps taken so far"""
+        self._bind()
+        self.scratch.view(torch.int32)[L.STEP_SLOT] = n
 
     def state_dict(self):
         self._bind()
