@@ -37,13 +37,34 @@ def build(name, sd):
     return model, dev
 
 
-def check_outputs(out, z, name):
+def _record(name, logit_err, logit_over_tol, lk_over_tol):
+    """measured errors per fixture, for DESIGN.md section 2 (gpurun_out/parity_errors.jsonl)"""
+    import json
+    import os
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "parity_errors.jsonl"), "a") as f:
+            f.write(json.dumps({"test": "forward_fixture", "case": name, "instance": os.environ.get("PMT_SHAPE", "auto"),
+                                "max_logit_err": logit_err, "max_logit_err_over_tol": logit_over_tol, "max_lk_err_over_tol": lk_over_tol}) + "\n")
+    except OSError:
+        pass
+
+
+def check_outputs(out, z, name, lk_ulps=8):
     lk = out.logits_bk.cpu().numpy()
     ref_lk = z["out/logits_bk"]
     mag = np.abs(ref_lk).max(axis=1)
     tol_b = 1e-4 + 4 * np.spacing(mag.astype(np.float32))  # fp32 resolution of the summed log-likelihoods
-    assert np.all(np.abs(out.logits_b.cpu().numpy() - z["out/logits_b"]) <= tol_b), name
-    np.testing.assert_allclose(lk, ref_lk, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(ref_lk).max())))
+    logit_err = np.abs(out.logits_b.cpu().numpy() - z["out/logits_b"])
+    assert np.all(logit_err <= tol_b), name
+    # every summed log-likelihood on ITS OWN scale: 2e-5 + 8 ulp of that element (a cluster's 5.0 next to another's 2000.0 is
+    # held to 2e-5, not to 2e-5 of the batch maximum)
+    # (sums over several hundred reads carry ~sqrt(N) ulp of rounding in ANY summation order, the oracle's included: the
+    #  tests with 300-700-read sets pass lk_ulps = 16)
+    lk_tol = 2e-5 + lk_ulps * np.spacing(np.abs(ref_lk).astype(np.float32))
+    assert np.all(np.abs(lk - ref_lk) <= lk_tol), (name, float((np.abs(lk - ref_lk) / lk_tol).max()))
+    _record(name, float(logit_err.max()), float((logit_err / tol_b).max()), float((np.abs(lk - ref_lk) / lk_tol).max()))
     for k, t in (("features_be", out.features_be), ("ref_features_be", out.ref_features_be),
                  ("artifact_probs_b", out.artifact_probs_b)):
         ref = z["out/" + k]
@@ -161,7 +182,7 @@ def test_read_sets_beyond_one_workgroup_run_layered_and_match_oracle():
                                      torch.from_numpy(nref), torch.from_numpy(nalt),
                                      torch.from_numpy(floats[:, 6:].astype(np.float32)), torch.from_numpy(ints[:, 16:].astype(np.int64)))
     z = {"out/" + k: v.numpy() for k, v in ref.items()}
-    check_outputs(out, z, "p0_deep")
+    check_outputs(out, z, "p0_deep", lk_ulps=16)
 
 
 def test_layered_forward_equals_the_single_launch_forward():
