@@ -19,6 +19,8 @@
 #ifndef PMT_BWD_PIECES
 #define PMT_BWD_PIECES 3  // (2 was measured: 3.50 -> 3.45 ms, one tensor's error 9e-5 -> 2.4e-4 of its scale: not worth it)
 #endif
+#define PMT_STAGE_PLANES 128  // every wave's operands of a 4 + 4 tile linear at once (8 waves x 8 planes x (hi + mid))
+#define PMT_FRAG_AHEAD 1  // weight fragments one MFMA group ahead (2 waves per SIMD do not hide an L2 round trip): 3.59 -> 3.52 ms
 #include "pmt_device.hpp"
 #include "pmt_bwd_device.hpp"
 
@@ -27,15 +29,20 @@ struct BwdShared {
     float gsum[PMT_GROUP_MAX_SETS][2][16];                      // per-set sums of d(gate), current block
     float dmean[PMT_GROUP_MAX_SETS][2][16];                     // d(m_ref), d(m_alt) already divided by (n + w)
     float dl[PMT_GROUP_MAX_SETS][PMT_MAX_CLUSTERS + 2];         // d(loss)/d(Lambda[b][j]) incl. the logit path
-    union {                                                     // the two never overlap in time (head / input split)
-        float dfeat[PMT_GROUP_MAX_SETS][2][PMT_MAX_WIDTH];      // d(loss)/d(set mean) / (n + 1e-4), position order
-        float dv[PMT_GROUP_MAX_SETS][PMT_MAX_WIDTH];            // per-set sum of d(x_0) (variant-embedding part)
-    };
     float aux[PMT_WAVES][PMT_AUX_CAP];                          // small-parameter gradient slabs (BwdCtx.aux)
     int aux_dst[PMT_AUX_CAP];
-    f4 stage[PMT_STAGE_PLANES * 64];                            // weight-gradient operand exchange (BwdCtx.stage)
+    // Weight-gradient operand exchange (BwdCtx.stage).  Its last 32 KiB double as two short-lived tables that are never
+    // alive while an exchange runs: dfeat (read once, before the first exchange) and dv (filled and written out between the
+    // blocks' last exchange and the read MLP's first).
+    f4 stage[PMT_STAGE_PLANES * 64];
     float pf_sink[64];                                          // where stash_prefetch's LDS-DMA drops its dwords (never read)
+    typedef float DFeat[2][PMT_MAX_WIDTH];                      // d(loss)/d(set mean) / (n + 1e-4), position order
+    typedef float DVar[PMT_MAX_WIDTH];                          // per-set sum of d(x_0) (variant-embedding part)
+    static constexpr int ALIAS_F4 = (PMT_STAGE_PLANES * 1024 - (int)sizeof(DFeat) * PMT_GROUP_MAX_SETS) / 16;
+    __device__ DFeat* dfeat() { return reinterpret_cast<DFeat*>(&stage[ALIAS_F4]); }
+    __device__ DVar* dv() { return reinterpret_cast<DVar*>(&stage[ALIAS_F4]); }
 };
+static_assert(sizeof(BwdShared::DFeat) * PMT_GROUP_MAX_SETS <= PMT_STAGE_PLANES * 1024, "the aliased tables fit the stage");
 
 static_assert(sizeof(BwdShared) <= 160 * 1024, "LDS budget");
 
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         const int f = pos_to_feat(p);
         const float* src = s == 1 ? dout.d_features_be : dout.d_ref_features_be;
         const float n = (float)(sh.off[s][set + 1] - sh.off[s][set]);
-        sh.dfeat[set][s][p] = (src && f < E) ? src[(size_t)(gg.v0 + set) * E + f] / (n + 1e-4f) : 0.f;
+        sh.dfeat()[set][s][p] = (src && f < E) ? src[(size_t)(gg.v0 + set) * E + f] / (n + 1e-4f) : 0.f;
     }
     __syncthreads();
 
@@ -266,7 +273,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             for (int t = 0; t < NTE; ++t)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    da[rt][t][j] = (tm[rt].valid && t < nte) ? sh.dfeat[set][side][16 * t + 4 * g + j] : 0.f;
+                    da[rt][t][j] = (tm[rt].valid && t < nte) ? sh.dfeat()[set][side][16 * t + 4 * g + j] : 0.f;
         }
         for (int k = -1; k < K; ++k) {  // k = -1: the two diagonal Gaussians; k >= 0: artifact cluster k
             f4 v[NTE], dvk[NTE];
@@ -641,8 +648,8 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
     t_ph = prof_now();
 
     // ---- split d(x_0): variant-embedding part -> per-set sums; read-embedding part -> read MLP backward --------------
-    __syncthreads();  // dfeat (head) is dead in every wave: its LDS becomes dv
-    for (int i = tid; i < PMT_GROUP_MAX_SETS * PMT_MAX_WIDTH; i += PMT_THREADS) (&sh.dv[0][0])[i] = 0.f;
+    __syncthreads();  // the last exchange has been consumed by every wave: the end of the stage becomes dv
+    for (int i = tid; i < PMT_GROUP_MAX_SETS * PMT_MAX_WIDTH; i += PMT_THREADS) (&sh.dv()[0][0])[i] = 0.f;
     __syncthreads();
 #pragma unroll
     for (int rt = 0; rt < PMT_RT; ++rt) {
@@ -653,10 +660,16 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             for (int j = 0; j < 4; ++j) {
                 const int f = feat_of(t, j, g);
                 if (f >= Er) {
-                    if (tm[rt].valid && f < D) atomicAdd(&sh.dv[set][f - Er], dy[rt][t][j]);
+                    if (tm[rt].valid && f < D) atomicAdd(&sh.dv()[set][f - Er], dy[rt][t][j]);
                     dy[rt][t][j] = 0.f;
                 }
             }
+    }
+    __syncthreads();
+    for (int i = tid; i < gg.nsets * Ev; i += PMT_THREADS) {  // (written out now: the read MLP's exchanges reuse the LDS)
+        const int set = i / Ev, f = i - set * Ev;
+        if (LAYERED) atomicAdd(&gvar[(size_t)(gg.v0 + set) * Ev + f], sh.dv()[set][f]);  // several groups per read set
+        else gvar[(size_t)(gg.v0 + set) * Ev + f] = sh.dv()[set][f];
     }
     const int fmt = bt.read_format;
     auto decode_reads = [&](f4 (&x)[PMT_RT][NTF]) {
@@ -691,12 +704,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
                                  }, 0, n_read_ops);
     }
     prof_add(c, 16, t_ph);
-    aux_flush(c);  // ends with a workgroup barrier
-    for (int i = tid; i < gg.nsets * Ev; i += PMT_THREADS) {
-        const int set = i / Ev, f = i - set * Ev;
-        if (LAYERED) atomicAdd(&gvar[(size_t)(gg.v0 + set) * Ev + f], sh.dv[set][f]);  // several groups per read set
-        else gvar[(size_t)(gg.v0 + set) * Ev + f] = sh.dv[set][f];
-    }
+    aux_flush(c);
     prof_add(c, 7, t_kernel0);  // whole kernel, per wave
 }
 

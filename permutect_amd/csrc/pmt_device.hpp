@@ -191,53 +191,73 @@ DEV void split_bf16x3(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
     mid = (__bf16)r1;
     lo = (__bf16)(r1 - (float)mid);
 }
+// the bf16 pieces of k block `kb` of the input (two activation tiles in register order), SELU applied on the way if asked
+template <int NTI, bool SELU_IN, int PIECES>
+DEV void split_kblock(const f4 (&in)[PMT_RT][NTI], int kb, float in_scale, bf8 (&bh)[PMT_RT], bf8 (&bm)[PMT_RT], bf8 (&bl)[PMT_RT]) {
+#pragma unroll
+    for (int rt = 0; rt < PMT_RT; ++rt) {
+        const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
+        f4 v0 = in[rt][2 * kb], v1 = (2 * kb + 1 < NTI) ? in[rt][(2 * kb + 1 < NTI) ? 2 * kb + 1 : 0] : zero;
+        if (SELU_IN) {
+            v0 = selu4(v0) * in_scale;
+            if (2 * kb + 1 < NTI) v1 = selu4(v1) * in_scale;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if constexpr (PIECES == 1) {
+                bh[rt][e] = (__bf16)v0[e];
+                bh[rt][4 + e] = (__bf16)v1[e];
+            } else if constexpr (PIECES == 2) {
+                const __bf16 h0 = (__bf16)v0[e], h1 = (__bf16)v1[e];
+                bh[rt][e] = h0; bm[rt][e] = (__bf16)(v0[e] - (float)h0);
+                bh[rt][4 + e] = h1; bm[rt][4 + e] = (__bf16)(v1[e] - (float)h1);
+            } else {
+                __bf16 h, m, l;
+                split_bf16x3(v0[e], h, m, l);
+                bh[rt][e] = h; bm[rt][e] = m; bl[rt][e] = l;
+                split_bf16x3(v1[e], h, m, l);
+                bh[rt][4 + e] = h; bm[rt][4 + e] = m; bl[rt][4 + e] = l;
+            }
+        }
+    }
+}
+#ifndef PMT_FRAG_AHEAD
+#define PMT_FRAG_AHEAD 0  // the forward (4 waves per SIMD hide the latency; no registers to spare): 1.15 ms -> 1.18 with 1
+#endif
 template <int NTI, int NTO, bool SELU_IN, int PIECES = 3>
 DEV void linear_acc_bf16(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], const float* __restrict__ fragb, float in_scale = 1.0f) {
     // PIECES = pieces of the ACTIVATION: 3 fp32-equivalent (six MFMAs), 2 hi + mid (16 significant bits; five MFMAs against the
-    // three-piece weights; the backward uses it: see pmt_backward.hip), 1 plain bf16
+    // three-piece weights), 1 plain bf16.
+    // The weight fragments of step (kb, mt) lie 3 KiB apart in consumption order and come from L2 (a step's weights are
+    // ~0.7 MB: far beyond the 32 KiB L1), ~2 x the 12 MFMAs of a step away: they are fetched PMT_FRAG_AHEAD steps ahead, the
+    // first ones before the input is split, so that no MFMA group waits for its own loads.
     static_assert(PIECES >= 1 && PIECES <= 3, "pieces");
-    constexpr int NKB = (NTI + 1) / 2;
+    constexpr int NKB = (NTI + 1) / 2, NSTEP = NKB * NTO, AH = PMT_FRAG_AHEAD < NSTEP ? PMT_FRAG_AHEAD : NSTEP;
+    constexpr int NP = PIECES == 1 ? 1 : 3;  // (the weights keep their three-piece layout; the hi piece alone is the bf16 rounding)
     const bf8* __restrict__ fp = reinterpret_cast<const bf8*>(fragb) + (threadIdx.x & 63);
+    bf8 q[AH + 1][NP];
+#pragma unroll
+    for (int s = 0; s < AH; ++s)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) q[s][p] = fp[192 * s + 64 * p];
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
         bf8 bh[PMT_RT], bm[PMT_RT], bl[PMT_RT];
-#pragma unroll
-        for (int rt = 0; rt < PMT_RT; ++rt) {
-            const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
-            f4 v0 = in[rt][2 * kb], v1 = (2 * kb + 1 < NTI) ? in[rt][(2 * kb + 1 < NTI) ? 2 * kb + 1 : 0] : zero;
-            if (SELU_IN) {
-                v0 = selu4(v0) * in_scale;
-                if (2 * kb + 1 < NTI) v1 = selu4(v1) * in_scale;
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if constexpr (PIECES == 1) {
-                    bh[rt][e] = (__bf16)v0[e];
-                    bh[rt][4 + e] = (__bf16)v1[e];
-                } else if constexpr (PIECES == 2) {
-                    const __bf16 h0 = (__bf16)v0[e], h1 = (__bf16)v1[e];
-                    bh[rt][e] = h0; bm[rt][e] = (__bf16)(v0[e] - (float)h0);
-                    bh[rt][4 + e] = h1; bm[rt][4 + e] = (__bf16)(v1[e] - (float)h1);
-                } else {
-                    __bf16 h, m, l;
-                    split_bf16x3(v0[e], h, m, l);
-                    bh[rt][e] = h; bm[rt][e] = m; bl[rt][e] = l;
-                    split_bf16x3(v1[e], h, m, l);
-                    bh[rt][4 + e] = h; bm[rt][4 + e] = m; bl[rt][4 + e] = l;
-                }
-            }
-        }
+        split_kblock<NTI, SELU_IN, PIECES>(in, kb, in_scale, bh, bm, bl);
         const bool half_block = 2 * kb + 1 >= NTI;  // a last k block with one tile only: the 16-deep MFMA on the lower halves
 #pragma unroll
         for (int mt = 0; mt < NTO; ++mt) {
-            const bf8 ah = fp[0];
+            const int step = kb * NTO + mt;
+            if (step + AH < NSTEP) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) q[(step + AH) % (AH + 1)][p] = fp[192 * (step + AH) + 64 * p];
+            }
+            const bf8 ah = q[step % (AH + 1)][0];
             if constexpr (PIECES == 1) {
-                fp += 192;  // (the weights keep their three-piece layout; the hi piece alone is the bf16 rounding of the weight)
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt) acc[rt][mt] = half_block ? mfma_bf16_k16(ah, bh[rt], acc[rt][mt]) : mfma_bf16(ah, bh[rt], acc[rt][mt]);
             } else {
-                const bf8 am = fp[64], al = fp[128];
-                fp += 192;
+                const bf8 am = q[step % (AH + 1)][NP > 1 ? 1 : 0], al = q[step % (AH + 1)][NP > 2 ? 2 : 0];
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt) {  // smallest terms first
                     if (half_block) {

@@ -16,7 +16,8 @@ model.train(True)
 ints, floats, packed = synth_arrays(np.random.default_rng(0), B, "wgs")
 batch = Batch.from_arrays(ints, floats, packed).copy_to(dev)
 eng = model.engine()
-for mask, name in [(0, "full"), (64, "no stash prefetch"), (256, "stash reads from L2 (wrong results)"), (256 + 64, "same, no prefetch"), (0, "full again"), (2, "no flush"), (1, "no wgrad"), (4, "no blocks"), (5, "no blocks, no wgrad"), (16, "no small-param atomics")]:
+MASKS = [] if os.environ.get("PMT_PROFILE_ONLY") else None
+for mask, name in MASKS if MASKS is not None else [(0, "full"), (64, "no stash prefetch"), (256, "stash reads from L2 (wrong results)"), (256 + 64, "same, no prefetch"), (0, "full again"), (2, "no flush"), (1, "no wgrad"), (4, "no blocks"), (5, "no blocks, no wgrad"), (16, "no small-param atomics")]:
     eng.plan.debug_flags[1] = mask
     ts = []
     for i in range(6):
@@ -38,5 +39,5 @@ model.compute_batch_losses(out, batch).total_loss.backward()
 torch.cuda.synchronize()
 prof = eng.plan.debug_flags[8:56].cpu().numpy().view(np.uint64)
 tot = float(prof[7])
-for i, nm in enumerate(["mlp wgrad accumulate", "mlp wgrad barrier", "mlp wgrad flush", "-", "tail recompute + head", "rotation", "reducer backward", "whole kernel (sum over waves)", "blk p1 recompute proj1", "blk p2 dgrad proj2 + gate", "blk proj2 wgrad", "blk set coupling", "blk p3 LN(h)/selu bwd", "blk proj1 wgrad", "blk dgrad proj1 + LN(D) bwd", "-", "split + read MLP backward", "wgrad: barrier before staging", "wgrad: split + stage stores", "wgrad: barrier after staging"]):
+for i, nm in enumerate(["mlp wgrad accumulate", "mlp wgrad barrier", "mlp wgrad flush", "-", "tail recompute + head", "rotation", "reducer backward", "whole kernel (sum over waves)", "blk p1 recompute proj1", "blk p2 dgrad proj2 + gate", "blk proj2 wgrad", "blk set coupling", "blk p3 LN(h)/selu bwd", "blk proj1 wgrad", "blk dgrad proj1 + LN(D) bwd", "-", "split + read MLP backward", "wgrad exchange: barrier before staging", "wgrad exchange: split + stage stores", "wgrad exchange: barrier after staging"]):
     if prof[i]: print(f"  {nm:32s} {prof[i]:.3e} cycles  {100 * prof[i] / tot:5.1f} %")
