@@ -200,7 +200,7 @@ typedef struct PmtBatch {
     const int32_t* group_start;     /* device [G+1] first variant of each group (pmt_plan_groups) */
     const int32_t* group_tile_base; /* device [G+1] first stash tile of each group (pmt_plan_groups) */
     int64_t total_tiles;            /* host value of group_tile_base[G] (sizes the stash)             */
-    int32_t* debug_flags;           /* device, optional [64]: [0] unused, [1] development
+    int32_t* debug_flags;           /* device, optional [64 + 4096]: [0] unused, [1] development
                                        switches of the backward kernel (0 in production), [8:56] 24 x u64 cycle counters */
     const int32_t* group_span;      /* device [G][6] or NULL.  With it a group may cover only PART of a read set (read sets
                                        beyond one workgroup, pmt_plan_groups_split): v0, v1 (variants [v0, v1)), ref_begin,

@@ -154,6 +154,8 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
              bt.debug_flags ? uniform(bt.debug_flags[1]) : 0,
              bt.debug_flags ? reinterpret_cast<unsigned long long*>(bt.debug_flags + 8) : nullptr};
     c.wr = gg.wr;
+    if (PMT_BWD_TRACE && bt.debug_flags && uniform(bt.debug_flags[2]) == (int)blockIdx.x + 1) c.trace = bt.debug_flags + 64 + wave * 512;
+    trace_ev(c, 1);
     c.wbase = stage_wbase(lane);
     c.rbase = stage_rbase(lane);
     c.pf_sink = (c.dbg & 64) ? &sh.pf_sink[0] : nullptr;  // stash prefetch: OFF (measured slower, see DESIGN)
@@ -361,6 +363,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         }
         aux_push_vec_x<NTE, EX>(c, enc_phi(uniform(M->head.stdev_e_phi)), dsig, E);
         prof_add(c, 4, t_kernel0);
+        trace_ev(c, 14);
         unsigned long long t_rot = prof_now();
         // ---- rotation + translation backward: a = Q (e + t) ------------------------------------------------------------
         linear_wgrad<NTE, NTE, BFB>(c, R, da, e);
@@ -377,6 +380,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         }
         aux_push_vec_x<NTE, EX>(c, uniform(M->translation_src), dt, E);
         prof_add(c, 5, t_rot);
+        trace_ev(c, 15);
         // ---- last reducer op ------------------------------------------------------------------------------------------
         if constexpr (EX) {
             f4 r[PMT_RT][NTD];
@@ -398,6 +402,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
                           0, EX ? n_red_ops - 1 : n_red_ops);
 
     prof_add(c, 6, t_ph);
+    trace_ev(c, 16);
     // ---- gated blocks backward -----------------------------------------------------------------------------------------
     for (int l = (c.dbg & 4) ? -1 : ((LAYERED && lay.slice > 0) ? L - lay.slice : L - 1); l >= 0; --l) {
         const bool first_half = !LAYERED || l == L - 1 - lay.slice;  // phases 1-2 (up to the per-set sums of d(gate))
@@ -462,6 +467,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             return side == 0 ? gt + beta * m_ref : (gt + beta * m_alt) + gamma * m_ref;
         };
         prof_add(c, 8, t_ph);
+        trace_ev(c, 18);
         t_ph = prof_now();
         // ---- phase 2: d(u) = W2^T dy, d(gate), per-set sums of d(gate), proj2 weight gradient ------------------------------
         f4 z2hat[PMT_RT], dgate[PMT_RT], du[PMT_RT][1];
@@ -498,6 +504,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
                 }
             }
             prof_add(c, 9, t_ph);
+            trace_ev(c, 19);
             t_ph = prof_now();
             // proj2 weight gradients of both sides in one exchange round
             if constexpr (S::BF16 != 0) wgrad_exchange_bf<NTD, 1, 2, BFB>(c, M->lin[uniform(B.proj2[0])], M->lin[uniform(B.proj2[1])], dy, u, 1.0f);
@@ -541,6 +548,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             __syncthreads();
         }
         prof_add(c, 10, t_ph);
+        trace_ev(c, 20);
         t_ph = prof_now();
         // per-set coupling: d(m_ref), d(m_alt), d(ref_regularizer), d(reg_weight)
         // One thread per (set, position); a wave covers 4 sets x 16 positions per pass.  d(ref_regularizer) and
@@ -572,6 +580,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         __syncthreads();
         for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS) (&sh.gsum[0][0][0])[i] = 0.f;
         prof_add(c, 11, t_ph);
+        trace_ev(c, 21);
         t_ph = prof_now();
         // ---- phase 3: finish d(z2), LayerNorm(h) backward, SELU backward -> d(zpre) ---------------------------------------
         f4 dz[PMT_RT][2];
@@ -603,6 +612,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             }
         }
         prof_add(c, 12, t_ph);
+        trace_ev(c, 22);
         t_ph = prof_now();
         // ---- phase 4: proj1 weight gradient (needs n again), d(n) = W1^T d(zpre), LayerNorm(D) backward ---------------------
         {
@@ -612,6 +622,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             else wgrad_exchange<2, NTD, 2>(c, M->lin[uniform(B.proj1[0])], M->lin[uniform(B.proj1[1])], dz, n, 1.0f);
         }
         prof_add(c, 13, t_ph);
+        trace_ev(c, 23);
         t_ph = prof_now();
         {
             f4 dn[PMT_RT][NTD];
@@ -644,6 +655,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             aux_push_vec_x<NTD, EX>(c, uniform(B.norm_b_src), dlb, D);
         }
         prof_add(c, 14, t_ph);
+        trace_ev(c, 24);
     }
     t_ph = prof_now();
 
@@ -704,8 +716,10 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
                                  }, 0, n_read_ops);
     }
     prof_add(c, 16, t_ph);
+    trace_ev(c, 26);
     aux_flush(c);
-    prof_add(c, 7, t_kernel0);  // whole kernel, per wave
+    prof_add(c, 7, t_kernel0);
+    trace_ev(c, 17);  // whole kernel, per wave
 }
 
 extern "C" int pmt_backward(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* phi,

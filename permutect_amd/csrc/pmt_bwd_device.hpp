@@ -193,7 +193,22 @@ struct BwdCtx {
     int wbase;      // this lane's byte offset inside a 1 KiB operand plane when it STORES its reads (stage_pair_bf16)
     int rbase;      // ... when it LOADS its MFMA operand (16 bytes)
     float* pf_sink; // LDS, 64 floats: where stash_prefetch drops its dwords
+    int* trace = nullptr;  // development: this wave's event log (PmtBatch.debug_flags[2] selects ONE workgroup; scripts/bwd_trace.py)
+    int trace_n = 0;
 };
+// one (event id, clock) pair per call; 250 events per wave at most.  Compiled in with -DPMT_BWD_TRACE=1 only (the log
+// pointer and counter cost scalar registers the kernel does not have to spare).
+#ifndef PMT_BWD_TRACE
+#define PMT_BWD_TRACE 0
+#endif
+DEV void trace_ev(BwdCtx& c, int id) {
+    if (!PMT_BWD_TRACE || c.trace == nullptr) return;
+    if (c.trace_n < 250 && (threadIdx.x & 63) == 0) {
+        c.trace[2 * c.trace_n] = id;
+        c.trace[2 * c.trace_n + 1] = (int)__builtin_readcyclecounter();
+    }
+    ++c.trace_n;
+}
 DEV unsigned long long prof_now() { return __builtin_readcyclecounter(); }
 DEV void prof_add(const BwdCtx& c, int slot, unsigned long long t0) {
     if ((c.dbg & 8) && c.prof != nullptr && (threadIdx.x & 63) == 0) atomicAdd(c.prof + slot, prof_now() - t0);
@@ -583,7 +598,9 @@ DEV void wgrad_exchange_bf(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, 
     unsigned long long t0c = prof_now();
     for (int w0 = 0; w0 < PMT_WAVES; w0 += PW) {
         unsigned long long t1 = prof_now();
+        trace_ev(c, 100);
         if (c.dbg & 128) __syncthreads(); else lds_barrier();  // the stage (and the slabs) of the previous round have been consumed
+        trace_ev(c, 101);
         prof_add(c, 17, t1);
         if (w0 == 0) aux_reduce(c);
         t1 = prof_now();
@@ -597,7 +614,9 @@ DEV void wgrad_exchange_bf(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, 
         }
         prof_add(c, 18, t1);
         t1 = prof_now();
+        trace_ev(c, 102);
         if (c.dbg & 128) __syncthreads(); else lds_barrier();
+        trace_ev(c, 103);
         prof_add(c, 19, t1);
         const int whi_all = min(w0 + PW, PMT_WAVES);
         const char* rd = stage + c.rbase;
@@ -658,6 +677,7 @@ DEV void wgrad_exchange_bf(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, 
         }
     }
     prof_add(c, 0, t0c);
+    trace_ev(c, 104);
     if (c.dbg & 2) return;
     t0c = prof_now();
     // emit: four atomics per block at the tabulated offsets; no index arithmetic here
@@ -678,6 +698,7 @@ DEV void wgrad_exchange_bf(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, 
         }
     }
     prof_add(c, 2, t0c);
+    trace_ev(c, 105);
 }
 
 template <int NTO, int NTI, int BF = 0>
@@ -721,6 +742,7 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
     for (int op = op_end - 1; op >= op_begin; --op) {
         const PmtOp& o = mlp.ops[op];
         f4 x[PMT_RT][NT];
+        trace_ev(c, 200 + op);
         load_input(op, x);
         if (uniform(o.kind) == PMT_OP_LINEAR) {
             const PmtLinear& L = M->lin[uniform(o.lin[0])];
@@ -766,6 +788,7 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
 #pragma unroll
                 for (int t = 0; t < NT; ++t) s1[rt][t] = selu4(nl == 2 ? s1[rt][t] : x[rt][t]);
             // last layer: d(f) = alpha * dy
+            trace_ev(c, 220);
             linear_wgrad<NT, NT, BF>(c, L2, dy, s1, alpha);
             f4 d1[PMT_RT][NT];
             init_bias<NT>(d1, nullptr, width, c.g);
@@ -790,6 +813,7 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
 #pragma unroll
                 for (int t = 0; t < NT; ++t) d1[rt][t] = alpha * selu_bwd4(d1[rt][t], s1[rt][t]);  // d(h1) (n=2) or d(x) part (n=1)
             __builtin_amdgcn_sched_barrier(0);
+            trace_ev(c, 221);
             if (nl == 2) {
                 f4 s0[PMT_RT][NT];  // second read of x (s1's registers are free now)
                 load_input(op, s0);
@@ -797,6 +821,7 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
                 for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
                     for (int t = 0; t < NT; ++t) s0[rt][t] = selu4(s0[rt][t]);
+                trace_ev(c, 222);
                 linear_wgrad<NT, NT, BF>(c, L1, d1, s0);
                 f4 d0[PMT_RT][NT];
                 init_bias<NT>(d0, nullptr, width, c.g);
