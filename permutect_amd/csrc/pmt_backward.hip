@@ -404,7 +404,20 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
     prof_add(c, 6, t_ph);
     trace_ev(c, 16);
     // ---- gated blocks backward -----------------------------------------------------------------------------------------
-    for (int l = (c.dbg & 4) ? -1 : ((LAYERED && lay.slice > 0) ? L - lay.slice : L - 1); l >= 0; --l) {
+    // xhat_l (the normalised block input, stashed by the forward with one rstd per read) is needed three times per block: by
+    // phase 1 and twice by phase 4, which keeps its copy for both uses.  (Requesting either read a phase early -- under the
+    // LDS-only exchange before it -- was measured SLOWER, 3.48 -> 3.55 / 3.96 ms: the 32 registers held across the phases
+    // in between spill, and every small parameter load behind the request waits for it, the memory counter being in order.)
+    auto load_xhat = [&](f4 (&xh)[PMT_RT][NTD], int l) {
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt) {
+#pragma unroll
+            for (int t = 0; t < NTD; ++t) xh[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
+            if (mask_all & (1u << rt)) stash_load<NTD>(stash_tile[rt] + (slot_x0 + l) * PMT_SLOT_FLOATS, xh[rt]);
+        }
+    };
+    const int l_first = (c.dbg & 4) ? -1 : ((LAYERED && lay.slice > 0) ? L - lay.slice : L - 1);
+    for (int l = l_first; l >= 0; --l) {
         const bool first_half = !LAYERED || l == L - 1 - lay.slice;  // phases 1-2 (up to the per-set sums of d(gate))
         // Register discipline (this loop body used to spill thousands of VGPRs): nothing of width D except the running
         // gradient dy stays live across phases.  xhat_l = the normalised x_l (stashed by the forward together with one
@@ -415,33 +428,30 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         const PmtLinear& P2 = M->lin[uniform(B.proj2[side])];
         const float* lw_p = packed + uniform(B.norm_w_pvec);
         const float* lb_p = packed + uniform(B.norm_b_pvec);
-        const float* xs[PMT_RT];
-#pragma unroll
-        for (int rt = 0; rt < PMT_RT; ++rt) xs[rt] = stash_tile[rt] + (slot_x0 + l) * PMT_SLOT_FLOATS;
         // n[rt] = LayerNorm_D(x_l[rt]) = xhat * w + b for every tile of this wave (absent tiles: xhat = 0)
-        auto recompute_n = [&](f4 (&n)[PMT_RT][NTD], bool touch_next = false) {
-#pragma unroll
-            for (int rt = 0; rt < PMT_RT; ++rt) {
-#pragma unroll
-                for (int t = 0; t < NTD; ++t) n[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
-                if (mask_all & (1u << rt)) {
-                    stash_load<NTD>(xs[rt], n[rt]);
-                    if (touch_next && c.pf_sink != nullptr && slot_x0 + l > 0) stash_prefetch(xs[rt] - PMT_SLOT_FLOATS, c.pf_sink);  // the slot the walk needs next
-                }
-            }
+        auto affine_n = [&](f4 (&n)[PMT_RT][NTD], const f4 (&xh)[PMT_RT][NTD]) {
 #pragma unroll
             for (int t = 0; t < NTD; ++t) {
                 const f4 lw = load_pvec(lw_p, t, g), lb = load_pvec(lb_p, t, g);
 #pragma unroll
-                for (int rt = 0; rt < PMT_RT; ++rt) n[rt][t] = n[rt][t] * lw + lb;
+                for (int rt = 0; rt < PMT_RT; ++rt) n[rt][t] = xh[rt][t] * lw + lb;
             }
+        };
+        f4 xh4[PMT_RT][NTD];  // phase 4's xhat_l and rstd
+        float rs4[PMT_RT];
+        auto load_xh4 = [&]() {
+            load_xhat(xh4, l);
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt)
+                rs4[rt] = (mask_all & (1u << rt)) ? rstd_stash[((size_t)(bt.group_tile_base[blockIdx.x] + gg.tile_begin + rt) * L + l) * 16 + (lane & 15)] : 0.f;
         };
         t_ph = prof_now();
         // ---- phase 1: z = selu(W1 n + b1) ---------------------------------------------------------------------------
         f4 z[PMT_RT][2];
         if (first_half) {
-            f4 n[PMT_RT][NTD];
-            recompute_n(n, true);
+            f4 n[PMT_RT][NTD], xq[PMT_RT][NTD];
+            load_xhat(xq, l);
+            affine_n(n, xq);
             const f4 b0 = load_pvec(packed + uniform(P1.b_pvec), 0, g), b1 = load_pvec(packed + uniform(P1.b_pvec), 1, g);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) { z[rt][0] = b0; z[rt][1] = b1; }
@@ -617,7 +627,8 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         // ---- phase 4: proj1 weight gradient (needs n again), d(n) = W1^T d(zpre), LayerNorm(D) backward ---------------------
         {
             f4 n[PMT_RT][NTD];
-            recompute_n(n);
+            load_xh4();
+            affine_n(n, xh4);
             if constexpr (S::BF16 != 0) wgrad_exchange_bf<2, NTD, 2, BFB>(c, M->lin[uniform(B.proj1[0])], M->lin[uniform(B.proj1[1])], dz, n, 1.0f);
             else wgrad_exchange<2, NTD, 2>(c, M->lin[uniform(B.proj1[0])], M->lin[uniform(B.proj1[1])], dz, n, 1.0f);
         }
@@ -640,15 +651,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             for (int rt = 0; rt < PMT_RT; ++rt) {
                 // one tile at a time (the scheduling barrier keeps the compiler from interleaving the tiles' temporaries)
                 __builtin_amdgcn_sched_barrier(0);
-                f4 xh[NTD];
-                float rs = 0.f;
-#pragma unroll
-                for (int t = 0; t < NTD; ++t) xh[t] = f4{0.f, 0.f, 0.f, 0.f};
-                if (mask_all & (1u << rt)) {
-                    stash_load<NTD>(xs[rt], xh);
-                    rs = rstd_stash[((size_t)(bt.group_tile_base[blockIdx.x] + gg.tile_begin + rt) * L + l) * 16 + (lane & 15)];
-                }
-                layernorm_bwd_inplace_tile<NTD>(dy[rt], dn[rt], xh, rs, D, lw, dlw, dlb, g);
+                layernorm_bwd_inplace_tile<NTD>(dy[rt], dn[rt], xh4[rt], rs4[rt], D, lw, dlw, dlb, g);
             }
             __builtin_amdgcn_sched_barrier(0);
             aux_push_vec_x<NTD, EX>(c, uniform(B.norm_w_src), dlw, D);
