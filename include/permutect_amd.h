@@ -47,9 +47,11 @@ extern "C" {
 #define PMT_MAX_SKIP_LAYERS 4
 #define PMT_MAX_BLOCKS 16
 #define PMT_MAX_LINEAR 96
+#ifndef PMT_GROUP_WAVES
 #define PMT_GROUP_WAVES 8       /* waves per workgroup */
-#define PMT_GROUP_TILES 16      /* 16-read tiles per group (8 waves x 2 tiles) */
-#define PMT_GROUP_MAX_SETS 64   /* read sets (variants) per group */
+#endif
+#define PMT_GROUP_TILES (2 * PMT_GROUP_WAVES)      /* 16-read tiles per group (two per wave) */
+#define PMT_GROUP_MAX_SETS (8 * PMT_GROUP_WAVES)   /* read sets (variants) per group */
 #define PMT_TILE 16
 
 /* read-row formats accepted at the boundary (reference data/batch.py:41-62, data/datum.py:35) */

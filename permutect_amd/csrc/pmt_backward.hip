@@ -14,12 +14,13 @@
 // Replaces autograd over reference artifact_model.py:239-297 (misc_utils.py:127 `loss.backward()`).
 // Wave shape: 8 waves x 2 read tiles (2 waves per SIMD, 256 VGPRs each).  VALU instructions only address the 256
 // architectural VGPRs, so a 512-register "fat wave" (4 x 4) just shuffles values through AGPRs: measured slower.
-#define PMT_WAVES 8
+#define PMT_WAVES PMT_GROUP_WAVES
 #define PMT_RT 2
 #ifndef PMT_BWD_PIECES
 #define PMT_BWD_PIECES 3  // (2 was measured: 3.50 -> 3.45 ms, one tensor's error 9e-5 -> 2.4e-4 of its scale: not worth it)
 #endif
-#define PMT_STAGE_PLANES 128  // every wave's operands of a 4 + 4 tile linear at once (8 waves x 8 planes x (hi + mid))
+#define PMT_STAGE_PLANES (16 * PMT_GROUP_WAVES)  // every wave's operands of a 4 + 4 tile linear at once (8 waves x 8 planes x (hi + mid))
+#include "permutect_amd.h"
 #define PMT_FRAG_AHEAD 1  // weight fragments one MFMA group ahead (2 waves per SIMD do not hide an L2 round trip): 3.59 -> 3.52 ms
 #include "pmt_device.hpp"
 #include "pmt_bwd_device.hpp"
