@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PMT_ABI_VERSION 3
+#define PMT_ABI_VERSION 4
 
 /* error codes */
 #define PMT_OK 0
@@ -184,7 +184,8 @@ typedef struct PmtModel {
     int32_t force_cnn;          /* haplotype CNN: 0 auto, 1 general (workgroup-per-chunk) kernels, 2 wave-per-variant
                                    kernels (pmt_cnn2), 3 batched-column kernels (pmt_cnn3)                               */
     int32_t cnn_debug;          /* development switches of pmt_cnn2_backward (0 in production)                           */
-    int32_t reserved_sel;
+    int32_t emit_base;          /* packed: the linears' emit tables lie back to back in [emit_base, emit_base + emit_len) */
+    int32_t emit_len;           /*   (floats); a row of pmt_backward's `grad_partials` mirrors exactly this region        */
 } PmtModel;
 
 /* Inputs of one forward / backward pass.  Reads are ordered as the reference's Batch orders them: all ref reads
@@ -410,7 +411,7 @@ size_t pmt_layered_backward_scratch_floats(const PmtModel* model, int64_t total_
 int pmt_backward_layered(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* phi,
                          const float* packed, const PmtBatch* batch, const PmtOutputs* out, const PmtOutputGrads* dout,
                          const float* stash, float* scratch, float* grad_theta, float* grad_phi, float* grad_variant_embed,
-                         void* stream);
+                         float* grad_partials, int32_t num_partials, void* stream);
 
 /* Bytes of activation stash a training forward needs for `total_tiles` tiles (group_tile_base[G]) and B variants. */
 size_t pmt_stash_bytes(const PmtModel* model, int64_t total_tiles, int32_t num_variants);
@@ -448,12 +449,17 @@ int pmt_host_copy(void* dst, const void* src, size_t bytes, int32_t threads);
 int pmt_forward(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* phi,
                 const float* packed, const PmtBatch* batch, const PmtOutputs* out, float* stash, void* stream);
 
-/* Fused backward of pmt_forward.  Accumulates (atomic adds) into grad_theta / grad_phi (same layouts as theta /
- * phi; the caller zeroes them) and writes grad_variant_embed [B][E_v].  Replaces autograd over the same graph
- * (reference misc_utils.py:127). */
+/* Fused backward of pmt_forward.  Accumulates into grad_theta / grad_phi (same layouts as theta / phi; the caller zeroes
+ * them) and writes grad_variant_embed [B][E_v].  Replaces autograd over the same graph (reference misc_utils.py:127).
+ * grad_partials (optional, device): [num_partials][PmtModel.emit_len] floats, ALL ZERO on entry and all zero again on return.
+ * With it the kernel runs as min(groups, num_partials) persistent workgroups, each adding its weight-gradient blocks into its
+ * OWN row with plain loads and stores, and a second small launch folds the rows into grad_theta / grad_phi; without it
+ * (NULL / 0) every block goes out as global float atomics, whose throughput then costs a tenth of the kernel's time.  One
+ * row per compute unit (256) is the intended size. */
 int pmt_backward(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* phi,
                  const float* packed, const PmtBatch* batch, const PmtOutputs* out, const PmtOutputGrads* dout,
-                 const float* stash, float* grad_theta, float* grad_phi, float* grad_variant_embed, void* stream);
+                 const float* stash, float* grad_theta, float* grad_phi, float* grad_variant_embed, float* grad_partials,
+                 int32_t num_partials, void* stream);
 
 /* Row-wise MLP over N independent rows -- the per-variant branches: `which` = PMT_ROWS_INFO (info_embedding,
  * reference artifact_model.py:244), PMT_ROWS_ALT_COUNT (alt_count_predictor, :180-183, :276-279) or PMT_ROWS_SOURCE

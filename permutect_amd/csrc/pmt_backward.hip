@@ -21,6 +21,7 @@
 #endif
 #define PMT_STAGE_PLANES (16 * PMT_GROUP_WAVES)  // every wave's operands of a 4 + 4 tile linear at once (8 waves x 8 planes x (hi + mid))
 #include "permutect_amd.h"
+#define PMT_OPAQUE_TID 1  // the kernel loops over groups (persistent launch): see pmt_tid
 #define PMT_FRAG_AHEAD 1  // weight fragments one MFMA group ahead (2 waves per SIMD do not hide an L2 round trip): 3.59 -> 3.52 ms
 #include "pmt_device.hpp"
 #include "pmt_bwd_device.hpp"
@@ -84,22 +85,22 @@ struct PmtBwdLayered {
     float* gsum_g;      // [B][L][32] per-set sums of d(gate)
 };
 
-template <typename S, bool LAYERED = false>
-__global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
+// One group (blockIdx.x of the one-group-per-workgroup launch; `grp` of the persistent one).  priv: this workgroup's private
+// row of weight-gradient partial sums, biased so that a PmtLinear.emit_tab offset indexes it directly; nullptr = atomics.
+template <typename S, bool LAYERED>
+DEV void backward_group(
     const PmtModel* __restrict__ M, const float* __restrict__ theta, const float* __restrict__ phi,
-    const float* __restrict__ packed, PmtBatch bt, PmtOutputs out, PmtOutputGrads dout, const float* __restrict__ stash,
+    const float* __restrict__ packed, const PmtBatch& bt, const PmtOutputs& out, const PmtOutputGrads& dout, const float* __restrict__ stash,
     const float* __restrict__ zsum_stash, const float* __restrict__ rstd_stash, float* __restrict__ gtheta, float* __restrict__ gphi,
-    float* __restrict__ gvar, PmtBwdLayered lay) {
+    float* __restrict__ gvar, const PmtBwdLayered& lay, const int grp, BwdShared& sh, float* __restrict__ priv) {
     constexpr int NTF = S::NTF, NTR = S::NTR, NTD = S::NTD, NTE = S::NTE;
     constexpr bool EX = S::EXACT;
     // Pieces of the activations / gradients in the backward's products (PMT_BWD_PIECES): three, like the forward.  Two (hi + mid,
     // five MFMAs and a shorter split) measured 1.4 % faster with a visibly larger error on single tensors, and stays off.
     constexpr int BFB = S::BF16 == 3 ? PMT_BWD_PIECES : S::BF16;
     static_assert(EX || (NTF == NTD && NTR == NTD && NTE == NTD), "the generic shape keeps one array width");
-    __shared__ __attribute__((aligned(16))) BwdShared sh;
-    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, wave = uniform((int)(tid >> 6));
-    if (bt.num_groups_dev != nullptr && (int)blockIdx.x >= uniform(bt.num_groups_dev[0])) return;  // grid sized for a capacity (graph replay)
-    const GroupGeom gg = group_geometry(bt, blockIdx.x);
+    const int tid = pmt_tid(), lane = tid & 63, g = lane >> 4, wave = uniform((int)(tid >> 6));
+    const GroupGeom gg = group_geometry(bt, grp);
     const int side = gg.side;
     const int D = S::DIM_D ? S::DIM_D : uniform(M->d_model), E = S::DIM_E ? S::DIM_E : uniform(M->feature_dim), K = uniform(M->num_clusters);
     const int Er = S::DIM_R ? S::DIM_R : uniform(M->read_embed_dim), Ev = uniform(M->variant_embed_dim);
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
     for (int rt = 0; rt < PMT_RT; ++rt) {
         tm[rt] = tile_meta(gg, rt, &sh.off[0][0]);
         if (tm[rt].present) mask_all |= 1u << rt;
-        stash_tile[rt] = stash + (size_t)(bt.group_tile_base[blockIdx.x] + gg.tile_begin + rt) * (size_t)(nslots * PMT_SLOT_FLOATS);
+        stash_tile[rt] = stash + (size_t)(bt.group_tile_base[grp] + gg.tile_begin + rt) * (size_t)(nslots * PMT_SLOT_FLOATS);
         if (bt.debug_flags && (uniform(bt.debug_flags[1]) & 256)) stash_tile[rt] = stash + (size_t)rt * (size_t)(nslots * PMT_SLOT_FLOATS);  // timing experiment: every read hits L2
     }
     BwdCtx c{M, theta, phi, packed, gtheta, gphi, &sh.stage[0], &sh.aux[0][0], &sh.aux_dst[0], g, mask_all,
@@ -155,7 +156,8 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
              bt.debug_flags ? uniform(bt.debug_flags[1]) : 0,
              bt.debug_flags ? reinterpret_cast<unsigned long long*>(bt.debug_flags + 8) : nullptr};
     c.wr = gg.wr;
-    if (PMT_BWD_TRACE && bt.debug_flags && uniform(bt.debug_flags[2]) == (int)blockIdx.x + 1) c.trace = bt.debug_flags + 64 + wave * 512;
+    c.priv = priv;
+    if (PMT_BWD_TRACE && bt.debug_flags && uniform(bt.debug_flags[2]) == grp + 1) c.trace = bt.debug_flags + 64 + wave * 512;
     trace_ev(c, 1);
     c.wbase = stage_wbase(lane);
     c.rbase = stage_rbase(lane);
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
     const unsigned long long t_kernel0 = prof_now();
     // a read set split over several groups is OWNED by the group that holds its first alt read: per-set terms are added once
     auto owns = [&](int set) { return !LAYERED || (sh.off[1][set] >= 0 && sh.off[1][set] < gg.nalt); };
-    const size_t tile_global = (size_t)(bt.group_tile_base[blockIdx.x] + gg.tile_begin);
+    const size_t tile_global = (size_t)(bt.group_tile_base[grp] + gg.tile_begin);
     if (wave == 0 && !(c.dbg & 16) && !(LAYERED && lay.slice > 0)) {  // d(log cluster weights): summed over the sets of the group
         const int k = lane & 15;
         float a = 0.f;
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
             load_xhat(xh4, l);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
-                rs4[rt] = (mask_all & (1u << rt)) ? rstd_stash[((size_t)(bt.group_tile_base[blockIdx.x] + gg.tile_begin + rt) * L + l) * 16 + (lane & 15)] : 0.f;
+                rs4[rt] = (mask_all & (1u << rt)) ? rstd_stash[((size_t)(bt.group_tile_base[grp] + gg.tile_begin + rt) * L + l) * 16 + (lane & 15)] : 0.f;
         };
         t_ph = prof_now();
         // ---- phase 1: z = selu(W1 n + b1) ---------------------------------------------------------------------------
@@ -726,10 +728,82 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
     trace_ev(c, 17);  // whole kernel, per wave
 }
 
+// Launched either with one workgroup per group or (partials != nullptr) as a fixed number of PERSISTENT workgroups that
+// take the groups round-robin: a workgroup then owns row blockIdx.x of `partials` ([gridDim.x][emit_len], a mirror of the
+// emit-table region of `packed`) and adds its weight-gradient blocks there with plain 16-byte loads and stores -- the ~250 M
+// float atomics per step this replaces are throughput-bound in L2 and cost a tenth of the kernel.
+// pmt_grad_fold_kernel sums the rows into the gradient buffers afterwards.
+template <typename S, bool LAYERED = false>
+__global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
+    const PmtModel* __restrict__ M, const float* __restrict__ theta, const float* __restrict__ phi,
+    const float* __restrict__ packed, PmtBatch bt, PmtOutputs out, PmtOutputGrads dout, const float* __restrict__ stash,
+    const float* __restrict__ zsum_stash, const float* __restrict__ rstd_stash, float* __restrict__ gtheta, float* __restrict__ gphi,
+    float* __restrict__ gvar, PmtBwdLayered lay, float* __restrict__ partials, int emit_base, int emit_len) {
+    __shared__ __attribute__((aligned(16))) BwdShared sh;
+    const int ngroups = bt.num_groups_dev != nullptr ? uniform(bt.num_groups_dev[0]) : bt.num_groups;  // (device count: graph replay)
+    float* priv = partials != nullptr ? partials + (size_t)blockIdx.x * (size_t)emit_len - emit_base : nullptr;
+#ifdef PMT_X_NOLOOP
+    const int grp = blockIdx.x;
+    if (grp < ngroups) {
+#else
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+#endif
+        backward_group<S, LAYERED>(M, theta, phi, packed, bt, out, dout, stash, zsum_stash, rstd_stash, gtheta, gphi, gvar, lay, grp, sh, priv);
+        __syncthreads();  // the next group reuses the LDS
+    }
+}
+
+// rows of partial sums -> gradient buffers (and the rows back to zero).  grid (blocks over a linear's entries, linear); a
+// block = 32 float4 entries x 8 slices of the rows, joined in LDS: ~100 MB of rows stream through at HBM / MALL speed
+__global__ __launch_bounds__(256) void pmt_grad_fold_kernel(const PmtModel* __restrict__ M, const float* __restrict__ packed,
+                                                            float* __restrict__ partials, int rows, float* __restrict__ gtheta,
+                                                            float* __restrict__ gphi) {
+    __shared__ f4 part[8][32];
+    const PmtLinear& L = M->lin[blockIdx.y];
+    const int tab = L.emit_tab;
+    if (tab < 0) return;
+    const int out_v = L.out_split > 0 ? 16 + L.out_split : L.out_dim;
+    const int nmt = (out_v + 15) >> 4, nkt = (L.in_dim + 15) >> 4, nw = nmt * nkt * 256, n = nw + nmt * 16;  // (multiples of 4)
+    const int q = threadIdx.x & 31, slice = threadIdx.x >> 5, i = (blockIdx.x * 32 + q) * 4;
+    if (blockIdx.x * 128 >= n) return;
+    const size_t emit_len = (size_t)M->emit_len;
+    f4 s = f4{0.f, 0.f, 0.f, 0.f};
+    if (i < n) {
+        float* p = partials + (tab - M->emit_base) + i;
+        for (int r = slice; r < rows; r += 8) {
+            f4* pr = reinterpret_cast<f4*>(p + (size_t)r * emit_len);
+            s = s + *pr;
+            *pr = f4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    part[slice][q] = s;
+    __syncthreads();
+    if (slice == 0 && i < n) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) s = s + part[k][q];
+        const int* dst = reinterpret_cast<const int*>(packed) + tab + i;
+        float* g = (i < nw && L.w_src < 0) ? gphi : gtheta;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (dst[j] >= 0 && s[j] != 0.f) atomicAdd(g + dst[j], s[j]);
+    }
+}
+
+// persistent launch with private partial sums: only the bf16-exchange instances know them
+static bool use_partials(const PmtModel* m, int shape, const float* partials, int rows) {
+    return partials != nullptr && rows > 0 && m->emit_len > 0 && shape >= 2;
+}
+static int fold_partials(const PmtModel* model_host, const PmtModel* model_dev, const float* packed, float* partials, int rows,
+                         float* grad_theta, float* grad_phi, hipStream_t s) {
+    hipLaunchKernelGGL(pmt_grad_fold_kernel, dim3((PMT_MAX_WIDTH * PMT_MAX_WIDTH + PMT_MAX_WIDTH + 127) / 128, model_host->n_linear), dim3(256), 0, s,
+                       model_dev, packed, partials, rows, grad_theta, grad_phi);
+    return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
+}
+
 extern "C" int pmt_backward(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* phi,
                             const float* packed, const PmtBatch* batch, const PmtOutputs* out, const PmtOutputGrads* dout,
                             const float* stash, float* grad_theta, float* grad_phi, float* grad_variant_embed,
-                            void* stream) {
+                            float* grad_partials, int32_t num_partials, void* stream) {
     if (!model_host || !model_dev || !batch || !out || !dout || !stash || !grad_theta || !grad_phi || !grad_variant_embed)
         return PMT_E_INVALID;
     const int rc = pmt_model_check(model_host);
@@ -742,11 +816,15 @@ extern "C" int pmt_backward(const PmtModel* model_host, const PmtModel* model_de
     const float* zsum_stash = stash + (size_t)batch->total_tiles * (size_t)pmt_stash_slots(model_host) * PMT_SLOT_FLOATS;
     const float* rstd_stash = zsum_stash + (size_t)batch->num_variants * (size_t)(model_host->num_blocks > 0 ? model_host->num_blocks : 1) * 32;
     const int shape = pmt_shape_id(model_host);
+    const bool part = use_partials(model_host, shape, grad_partials, num_partials);
+    const int grid = part && num_partials < batch->num_groups ? num_partials : batch->num_groups;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     auto kernel = shape == 3 ? pmt_backward_kernel<ShapeP0XB> : shape == 2 ? pmt_backward_kernel<ShapeP0X> : shape == 1 ? pmt_backward_kernel<ShapeP0> : pmt_backward_kernel<ShapeAny>;
-    hipLaunchKernelGGL(kernel, dim3(batch->num_groups), dim3(PMT_THREADS), 0, reinterpret_cast<hipStream_t>(stream), model_dev,
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(PMT_THREADS), 0, s, model_dev,
                        theta, phi, packed, *batch, *out, *dout, stash, zsum_stash, rstd_stash, grad_theta, grad_phi, grad_variant_embed,
-                       PmtBwdLayered{});
-    return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
+                       PmtBwdLayered{}, part ? grad_partials : nullptr, model_host->emit_base, model_host->emit_len);
+    if (hipGetLastError() != hipSuccess) return PMT_E_LAUNCH;
+    return part ? fold_partials(model_host, model_dev, packed, grad_partials, grid, grad_theta, grad_phi, s) : PMT_OK;
 }
 
 extern "C" size_t pmt_layered_backward_scratch_floats(const PmtModel* m, int64_t total_tiles, int32_t num_variants) {
@@ -758,7 +836,7 @@ extern "C" size_t pmt_layered_backward_scratch_floats(const PmtModel* m, int64_t
 extern "C" int pmt_backward_layered(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* phi,
                                     const float* packed, const PmtBatch* batch, const PmtOutputs* out, const PmtOutputGrads* dout,
                                     const float* stash, float* scratch, float* grad_theta, float* grad_phi,
-                                    float* grad_variant_embed, void* stream) {
+                                    float* grad_variant_embed, float* grad_partials, int32_t num_partials, void* stream) {
     if (!model_host || !model_dev || !batch || !out || !dout || !stash || !scratch || !grad_theta || !grad_phi || !grad_variant_embed)
         return PMT_E_INVALID;
     const int rc = pmt_model_check(model_host);
@@ -778,11 +856,15 @@ extern "C" int pmt_backward_layered(const PmtModel* model_host, const PmtModel* 
     lay.gsum_g = lay.park + (size_t)batch->total_tiles * 6 * 256;
     if (hipMemsetAsync(lay.gsum_g, 0, B * nb * 32 * sizeof(float), s) != hipSuccess) return PMT_E_LAUNCH;
     const int shape = pmt_shape_id(model_host);
+    const bool part = use_partials(model_host, shape, grad_partials, num_partials);
+    const int grid = part && num_partials < batch->num_groups ? num_partials : batch->num_groups;
     auto kernel = shape >= 2 ? pmt_backward_kernel<ShapeP0X, true> : shape == 1 ? pmt_backward_kernel<ShapeP0, true> : pmt_backward_kernel<ShapeAny, true>;
     for (int slice = 0; slice <= L; ++slice) {
         lay.slice = slice;
-        hipLaunchKernelGGL(kernel, dim3(batch->num_groups), dim3(PMT_THREADS), 0, s, model_dev, theta, phi, packed, *batch, *out, *dout,
-                           stash, zsum_stash, rstd_stash, grad_theta, grad_phi, grad_variant_embed, lay);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(PMT_THREADS), 0, s, model_dev, theta, phi, packed, *batch, *out, *dout,
+                           stash, zsum_stash, rstd_stash, grad_theta, grad_phi, grad_variant_embed, lay,
+                           part ? grad_partials : nullptr, model_host->emit_base, model_host->emit_len);
     }
-    return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
+    if (hipGetLastError() != hipSuccess) return PMT_E_LAUNCH;
+    return part ? fold_partials(model_host, model_dev, packed, grad_partials, grid, grad_theta, grad_phi, s) : PMT_OK;
 }

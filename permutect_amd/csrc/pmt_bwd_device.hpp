@@ -27,7 +27,7 @@ DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "m
 // Touch one 4 KiB stash slot of a tile (64 lanes x one dword, 64 bytes apart) so that the lines are in L2 when the real load
 // comes an op later.  The dwords land in a 256-byte LDS sink by LDS-DMA: no VGPR is written, nothing has to be waited for.
 DEV void stash_prefetch(const float* __restrict__ slot, float* __restrict__ sink) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slot + (threadIdx.x & 63) * 16),
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slot + (pmt_tid() & 63) * 16),
                                      (__attribute__((address_space(3))) void*)sink, 4, 0, 0);
 }
 
@@ -44,7 +44,7 @@ DEV void stash_prefetch(const float* __restrict__ slot, float* __restrict__ sink
 // MFMAs on the fp32 pipe, which bounds this kernel.
 DEV int stage_slot(int G, int n) { return 16 * (n & 3) + 8 * (n >> 3) + 2 * (G ^ (n & 3)) + ((n >> 2) & 1); }
 DEV void stage_store_transposed(f4* __restrict__ plane, f4 v) {
-    const int lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15, G = r >> 2, J = r & 3;
+    const int lane = pmt_tid() & 63, g = lane >> 4, r = lane & 15, G = r >> 2, J = r & 3;
     float* p = reinterpret_cast<float*>(plane) + 32 * (g >> 1) + 4 * (g & 1) + J;
 #pragma unroll
     for (int j = 0; j < 4; ++j) p[64 * j + 8 * (G ^ j)] = v[j];
@@ -193,6 +193,7 @@ struct BwdCtx {
     int wbase;      // this lane's byte offset inside a 1 KiB operand plane when it STORES its reads (stage_pair_bf16)
     int rbase;      // ... when it LOADS its MFMA operand (16 bytes)
     float* pf_sink; // LDS, 64 floats: where stash_prefetch drops its dwords
+    float* priv = nullptr; // this workgroup's private row of weight-gradient partial sums, biased by -emit_base (pmt_backward.hip); nullptr = global atomics
     int* trace = nullptr;  // development: this wave's event log (PmtBatch.debug_flags[2] selects ONE workgroup; scripts/bwd_trace.py)
     int trace_n = 0;
 };
@@ -203,15 +204,20 @@ struct BwdCtx {
 #endif
 DEV void trace_ev(BwdCtx& c, int id) {
     if (!PMT_BWD_TRACE || c.trace == nullptr) return;
-    if (c.trace_n < 250 && (threadIdx.x & 63) == 0) {
+    if (c.trace_n < 250 && (pmt_tid() & 63) == 0) {
         c.trace[2 * c.trace_n] = id;
         c.trace[2 * c.trace_n + 1] = (int)__builtin_readcyclecounter();
     }
     ++c.trace_n;
 }
-DEV unsigned long long prof_now() { return __builtin_readcyclecounter(); }
+// cycle counters per phase (scripts/bwd_ablate.py): compiled in with -DPMT_BWD_PROF=1 only -- the start stamps are live
+// scalar registers through every phase, and the kernel has none to spare
+#ifndef PMT_BWD_PROF
+#define PMT_BWD_PROF 0
+#endif
+DEV unsigned long long prof_now() { return PMT_BWD_PROF ? __builtin_readcyclecounter() : 0ull; }
 DEV void prof_add(const BwdCtx& c, int slot, unsigned long long t0) {
-    if ((c.dbg & 8) && c.prof != nullptr && (threadIdx.x & 63) == 0) atomicAdd(c.prof + slot, prof_now() - t0);
+    if (PMT_BWD_PROF && (c.dbg & 8) && c.prof != nullptr && (pmt_tid() & 63) == 0) atomicAdd(c.prof + slot, prof_now() - t0);
 }
 
 // ---- small-parameter gradients ---------------------------------------------------------------------------------------
@@ -220,7 +226,7 @@ DEV int enc_at(int enc, int f) { return enc >= 0 ? enc + f : enc - f; }
 
 // sum the slabs over the waves and add to global memory; callers bracket it with workgroup barriers
 DEV void aux_reduce(BwdCtx& c) {
-    for (int i = threadIdx.x; i < c.aux_n; i += PMT_THREADS) {
+    for (int i = pmt_tid(); i < c.aux_n; i += PMT_THREADS) {
         const int d = c.aux_dst[i];
         if (d != -1) {
             float s = 0.f;
@@ -239,7 +245,7 @@ DEV void aux_flush(BwdCtx& c) {
 // per-feature parameter gradient (tile-position registers, summed here over this wave's reads)
 template <int NT>
 DEV void aux_push_vec(BwdCtx& c, int enc, const f4 (&v)[NT], int dim) {
-    const int nt = (dim + 15) >> 4, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nt = (dim + 15) >> 4, lane = pmt_tid() & 63, wave = pmt_tid() >> 6;
     if (c.aux_n + 16 * nt > PMT_AUX_CAP) aux_flush(c);
     if (c.dbg & 16) return;
     // all the cross-lane sums first, then ONE region with a sixteenth of the lanes enabled that stores them
@@ -307,7 +313,7 @@ DEV float row_halving_sum(const float (&v)[N], int lane) {  // returns the total
 template <int NT>
 DEV void aux_push_vec_full(BwdCtx& c, int enc, const f4 (&v)[NT], int dim) {
     static_assert(NT == 1 || NT == 2 || NT == 4, "4, 8 or 16 values per lane");
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = pmt_tid() & 63, wave = pmt_tid() >> 6;
     if (c.aux_n + 16 * NT > PMT_AUX_CAP) aux_flush(c);
     if (c.dbg & 16) return;
     float vals[4 * NT];
@@ -340,7 +346,7 @@ DEV void aux_push_vec_x(BwdCtx& c, int enc, const f4 (&v)[NT], int dim) {
 }
 // one 16-position row (tile 0) whose per-position totals already sit in every lane group: lane (g, p) holds position p
 DEV void aux_push_row16(BwdCtx& c, int enc, float v, int dim) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = pmt_tid() & 63, wave = pmt_tid() >> 6;
     if (c.aux_n + 16 > PMT_AUX_CAP) aux_flush(c);
     if (c.dbg & 16) return;
     if (lane < 16) {
@@ -354,9 +360,9 @@ DEV void aux_push_scalar(BwdCtx& c, int enc, float v) {
     if (c.aux_n + 1 > PMT_AUX_CAP) aux_flush(c);
     if (c.dbg & 16) return;
     const float s = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) {
-        c.aux[(threadIdx.x >> 6) * PMT_AUX_CAP + c.aux_n] = s;
-        if (threadIdx.x == 0) c.aux_dst[c.aux_n] = enc;
+    if ((pmt_tid() & 63) == 0) {
+        c.aux[(pmt_tid() >> 6) * PMT_AUX_CAP + c.aux_n] = s;
+        if (pmt_tid() == 0) c.aux_dst[c.aux_n] = enc;
     }
     c.aux_n += 1;
 }
@@ -377,7 +383,7 @@ struct WgradAcc {
 
 template <int NTO, int NTI, int SIDES>
 DEV void wgrad_init(WgradAcc<NTO, NTI, SIDES>& a, const PmtLinear& L0) {
-    const int wave = uniform((int)(threadIdx.x >> 6));
+    const int wave = uniform((int)(pmt_tid() >> 6));
     a.h = uniform(L0.out_split); a.out_dim = uniform(L0.out_dim); a.in_dim = uniform(L0.in_dim);
     a.out_v = a.h > 0 ? 16 + a.h : a.out_dim;
     a.nmt = (a.out_v + 15) >> 4; a.nkt = (a.in_dim + 15) >> 4;
@@ -404,7 +410,7 @@ DEV void wgrad_accumulate(WgradAcc<NTO, NTI, SIDES>& a, BwdCtx& c, const f4 (&dy
     constexpr int P = NTO + NTI;
     constexpr int TP = (PMT_STAGE_PLANES / P) < PMT_WG_TILES ? (PMT_STAGE_PLANES / P) : PMT_WG_TILES;
     static_assert(TP >= 1, "stage too small");
-    const int lane = threadIdx.x & 63;
+    const int lane = pmt_tid() & 63;
     if (SIDES == 2) { a.any[0] |= c.tiles_ref > 0; a.any[1] |= c.ntiles > c.tiles_ref; } else { a.any[0] |= c.ntiles > 0; }
     for (int t0 = 0; t0 < c.ntiles; t0 += TP) {
         __syncthreads();  // the stage (and the slabs) of the previous round have been consumed
@@ -446,7 +452,7 @@ DEV void wgrad_accumulate(WgradAcc<NTO, NTI, SIDES>& a, BwdCtx& c, const f4 (&dy
 
 template <int NTO, int NTI, int SIDES>
 DEV void wgrad_emit(WgradAcc<NTO, NTI, SIDES>& a, BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, float scale) {
-    const int lane = threadIdx.x & 63, g = lane >> 4;
+    const int lane = pmt_tid() & 63, g = lane >> 4;
 #pragma unroll
     for (int k = 0; k < a.TPW; ++k) {
         if (a.t_side[k] < 0) continue;
@@ -559,7 +565,7 @@ DEV void wgrad_exchange_bf(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, 
     // whatever the split of the group between the sides).
     constexpr int ROWS = SIDES == 1 ? PMT_WAVES / NTI : 1;
     constexpr int TPW = SIDES == 1 ? (NTO + ROWS - 1) / ROWS : (2 * NB + PMT_WAVES - 1) / PMT_WAVES;
-    const int lane = threadIdx.x & 63, g = lane >> 4, wave = uniform((int)(threadIdx.x >> 6));
+    const int lane = pmt_tid() & 63, g = lane >> 4, wave = uniform((int)(pmt_tid() >> 6));
     int t_ot[TPW], t_it[TPW], t_side[TPW];
     f4 acc[TPW], accb[TPW];
 #pragma unroll
@@ -589,7 +595,8 @@ DEV void wgrad_exchange_bf(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, 
         with_bias[k] = false;
         if (t_side[k] < 0) continue;
         const PmtLinear& L = (SIDES == 2 && t_side[k] == 1) ? L1 : L0;
-        const int* tab = reinterpret_cast<const int*>(c.packed + uniform(L.emit_tab));
+        // (private partial sums: the same 16 bytes are this lane's running sums of the block instead of its destinations)
+        const int* tab = reinterpret_cast<const int*>(c.priv != nullptr ? c.priv + uniform(L.emit_tab) : c.packed + uniform(L.emit_tab));
         e[k] = *reinterpret_cast<const i4*>(tab + ((t_ot[k] * NTI + t_it[k]) * 64 + lane) * 4);
         with_bias[k] = t_it[k] == t_ot[k] % NTI;  // the one block of row ot that also sums the bias gradient (dy x ones)
         if (with_bias[k]) eb[k] = *reinterpret_cast<const i4*>(tab + NB * 256 + t_ot[k] * 16 + 4 * g);
@@ -687,6 +694,13 @@ DEV void wgrad_exchange_bf(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, 
         const bool side1 = SIDES == 2 && t_side[k] == 1;
         if (SIDES == 2 && (side1 ? c.ntiles <= c.tiles_ref : c.tiles_ref <= 0)) continue;  // no tiles on that side
         const PmtLinear& L = side1 ? L1 : L0;
+        if (c.priv != nullptr) {  // running sums + this group's block, back to the private row (one 16-byte store per lane)
+            float* row = c.priv + uniform(L.emit_tab);
+            *reinterpret_cast<f4*>(row + ((t_ot[k] * NTI + t_it[k]) * 64 + lane) * 4) = __builtin_bit_cast(f4, e[k]) + scale * acc[k];
+            if (with_bias[k] && (lane & 15) == 0)
+                *reinterpret_cast<f4*>(row + NB * 256 + t_ot[k] * 16 + 4 * g) = __builtin_bit_cast(f4, eb[k]) + scale * accb[k];
+            continue;
+        }
         float* gw = uniform(L.w_src) >= 0 ? c.gtheta : c.gphi;
 #pragma unroll
         for (int j = 0; j < 4; ++j)

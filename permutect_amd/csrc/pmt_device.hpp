@@ -41,6 +41,18 @@ static_assert(PMT_GROUP_TILES == PMT_WG_TILES, "group capacity");
 #endif
 
 #define DEV __device__ __forceinline__
+// threadIdx.x; a translation unit whose kernel LOOPS over groups sets PMT_OPAQUE_TID so that nothing derived from the thread id
+// is loop invariant (hoisted values would be live across the whole loop body, in registers the body does not have)
+#ifndef PMT_OPAQUE_TID
+#define PMT_OPAQUE_TID 0
+#endif
+DEV int pmt_tid() {
+    int t = threadIdx.x;
+#if PMT_OPAQUE_TID
+    asm volatile("" : "+v"(t));
+#endif
+    return t;
+}
 
 // Register-array shapes of the read-set kernels, in 16-feature tiles: F read features, R read-MLP widths (after its first
 // linear), D d_model and reducer widths, E feature_dim.  EXACT: every layer fills its arrays completely, the read MLP
@@ -139,7 +151,7 @@ DEV void linear_acc_impl(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], co
     // (or L2) latency hides behind 4 * PMT_RT MFMAs.  All 4 k-steps of a tile always run: the fragment rows / columns
     // beyond the layer's true dimensions are zero, and so are the activations there.
     const int nkt = (in_dim + 15) >> 4, nmt = (out_dim + 15) >> 4;
-    const f4* __restrict__ fp = reinterpret_cast<const f4*>(frag) + (threadIdx.x & 63);
+    const f4* __restrict__ fp = reinterpret_cast<const f4*>(frag) + (pmt_tid() & 63);
     f4 a_next = fp[0];
 #pragma unroll
     for (int kt = 0; kt < NTI; ++kt) {
@@ -234,7 +246,7 @@ DEV void linear_acc_bf16(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], co
     static_assert(PIECES >= 1 && PIECES <= 3, "pieces");
     constexpr int NKB = (NTI + 1) / 2, NSTEP = NKB * NTO, AH = PMT_FRAG_AHEAD < NSTEP ? PMT_FRAG_AHEAD : NSTEP;
     constexpr int NP = PIECES == 1 ? 1 : 3;  // (the weights keep their three-piece layout; the hi piece alone is the bf16 rounding)
-    const bf8* __restrict__ fp = reinterpret_cast<const bf8*>(fragb) + (threadIdx.x & 63);
+    const bf8* __restrict__ fp = reinterpret_cast<const bf8*>(fragb) + (pmt_tid() & 63);
     bf8 q[AH + 1][NP];
 #pragma unroll
     for (int s = 0; s < AH; ++s)
@@ -352,13 +364,13 @@ DEV int stash_num_slots(const PmtModel* M) { return (M->read_mlp.n_ops - 1) + (M
 
 template <int NT>
 DEV void stash_store(float* __restrict__ base, const f4 (&v)[NT]) {
-    f4* p = reinterpret_cast<f4*>(base) + (threadIdx.x & 63);
+    f4* p = reinterpret_cast<f4*>(base) + (pmt_tid() & 63);
 #pragma unroll
     for (int t = 0; t < NT; ++t) __builtin_nontemporal_store(v[t], p + t * 64);  // written once, read by the backward long after
 }
 template <int NT>
 DEV void stash_load(const float* __restrict__ base, f4 (&v)[NT]) {
-    const f4* p = reinterpret_cast<const f4*>(base) + (threadIdx.x & 63);
+    const f4* p = reinterpret_cast<const f4*>(base) + (pmt_tid() & 63);
 #pragma unroll
     for (int t = 0; t < NT; ++t) v[t] = p[t * 64];
 }
@@ -406,7 +418,7 @@ DEV GroupGeom group_geometry(const PmtBatch& bt, int group) {
     gg.ntiles = gg.tiles_ref + gg.tiles_alt;
     // Waves are side-homogeneous: the first wr waves share the ref tiles, the others the alt tiles, each side dealt
     // contiguously and evenly; wr is the proportional share clamped so that no wave gets more than PMT_RT tiles.
-    const int wave = uniform((int)(threadIdx.x >> 6));
+    const int wave = uniform((int)(pmt_tid() >> 6));
     const int need_r = (gg.tiles_ref + PMT_RT - 1) / PMT_RT, need_a = (gg.tiles_alt + PMT_RT - 1) / PMT_RT;
     int wr = gg.ntiles > 0 ? (PMT_WAVES * gg.tiles_ref + gg.ntiles / 2) / gg.ntiles : 0;
     wr = min(max(wr, need_r), PMT_WAVES - need_a);
@@ -433,7 +445,7 @@ struct TileMeta {
 // s_off: LDS array [2][PMT_GROUP_MAX_SETS + 1] of group-local exclusive offsets per side
 DEV TileMeta tile_meta(const GroupGeom& gg, int rt, const int* s_off) {
     TileMeta tm;
-    const int r = threadIdx.x & 15;
+    const int r = pmt_tid() & 15;
     tm.present = rt < gg.tile_count;
     tm.side = gg.side;
     if (!tm.present) {

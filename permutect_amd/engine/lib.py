@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_HERE, "libpermutect_amd.so")
 
 # ---- limits (must match the header) -------------------------------------------------------------------------------
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_WIDTH, MAX_HALF_FFN, MAX_CLUSTERS = 64, 16, 16
 MAX_ROW_INPUT = 128
 ROWS_INFO, ROWS_ALT_COUNT, ROWS_SOURCE = 0, 1, 2
@@ -82,7 +82,7 @@ class PmtModel(C.Structure):
                 ("translation_src", i32), ("translation_pvec", i32), ("rotation_lin", i32),
                 ("read_mlp", PmtMlp), ("reducer", PmtMlp), ("row_mlp", PmtMlp * 3), ("blocks", PmtBlock * MAX_BLOCKS), ("head", PmtHead), ("cnn", PmtCnn),
                 ("lin", PmtLinear * MAX_LINEAR),
-                ("force_shape", i32), ("force_cnn", i32), ("cnn_debug", i32), ("reserved_sel", i32)]
+                ("force_shape", i32), ("force_cnn", i32), ("cnn_debug", i32), ("emit_base", i32), ("emit_len", i32)]
 
 
 class PmtBatch(C.Structure):
@@ -188,7 +188,7 @@ def load() -> C.CDLL:
     lib.pmt_pack_params.argtypes = [P(PmtModel), vp, vp, vp, vp, vp]
     lib.pmt_scan_counts.argtypes = [vp, vp, i32, i64, i32, vp, vp, vp]
     lib.pmt_forward.argtypes = [P(PmtModel), vp, vp, vp, vp, P(PmtBatch), P(PmtOutputs), vp, vp]
-    lib.pmt_backward.argtypes = [P(PmtModel), vp, vp, vp, vp, P(PmtBatch), P(PmtOutputs), P(PmtOutputGrads), vp, vp, vp, vp, vp]
+    lib.pmt_backward.argtypes = [P(PmtModel), vp, vp, vp, vp, P(PmtBatch), P(PmtOutputs), P(PmtOutputGrads), vp, vp, vp, vp, vp, i32, vp]
     lib.pmt_clip_adamw.argtypes = [vp, vp, vp, vp, i64, P(PmtAdamW), vp, vp, vp]
     lib.pmt_cnn_forward.argtypes = [P(PmtModel), vp, vp, vp, vp, i64, i32, vp, i64, vp, vp]
     lib.pmt_cnn_backward.argtypes = [P(PmtModel), vp, vp, vp, vp, i64, i32, vp, i64, vp, vp, vp]
@@ -210,7 +210,7 @@ def load() -> C.CDLL:
     lib.pmt_layered_backward_scratch_floats.argtypes = [P(PmtModel), i64, i32]
     lib.pmt_layered_backward_scratch_floats.restype = C.c_size_t
     lib.pmt_backward_layered.argtypes = [P(PmtModel), vp, vp, vp, vp, P(PmtBatch), P(PmtOutputs), P(PmtOutputGrads), vp, vp, vp,
-                                         vp, vp, vp]
+                                         vp, vp, vp, i32, vp]
     lib.pmt_downsample_counts.argtypes = [P(PmtDownsample), vp, vp, vp, vp, vp]
     lib.pmt_downsample_index.argtypes = [P(PmtDownsample), vp, vp, vp, vp, vp, vp]
     lib.pmt_losses_forward.argtypes = [P(PmtLossArgs), P(PmtLossOutputs), vp]

@@ -136,6 +136,7 @@ class EnginePlan:
             b.gamma_src = space.offset_of(s.gamma)
             b.reg_weight_phi = self._alloc_phi(f"reg_weight.{i}", 1)
         self._lower_mlp(d.reducer, reducer)
+        n_readset_lin = self._n_lin  # the linears of the read-set kernels so far (+ the rotation below)
         # per-variant row MLPs (pmt_rows_*)
         self._lower_mlp(d.row_mlp[L.ROWS_INFO], model.info_embedding, max_in=L.MAX_ROW_INPUT)
         self._lower_mlp(d.row_mlp[L.ROWS_ALT_COUNT], model.alt_count_predictor.wrapped_module)
@@ -169,7 +170,19 @@ class EnginePlan:
             nmt, nkt = (out_v + 15) // 16, (lin.in_dim + 15) // 16
             lin.wb_frag = self._alloc_packed(nmt * ((nkt + 1) // 2) * 3 * 256 + 256)
             lin.wtb_frag = self._alloc_packed(nkt * ((nmt + 1) // 2) * 3 * 256 + 256)
-            lin.emit_tab = self._alloc_packed(nmt * nkt * 256 + nmt * 16)  # int32 offsets of the dW blocks and the bias rows
+        # the emit tables (int32 destinations of the dW blocks and the bias rows) lie back to back: a row of the backward's
+        # private partial sums mirrors this region entry for entry (pmt_backward: grad_partials)
+        # (only the read-set backward emits through tables; the row kernels compute their few destinations)
+        d.emit_base = self._packed_off
+        for i in range(d.n_linear):
+            lin = d.lin[i]
+            lin.emit_tab = -1
+            if i >= n_readset_lin and i != d.rotation_lin:
+                continue
+            out_v = 16 + lin.out_split if lin.out_split > 0 else lin.out_dim
+            nmt, nkt = (out_v + 15) // 16, (lin.in_dim + 15) // 16
+            lin.emit_tab = self._alloc_packed(nmt * nkt * 256 + nmt * 16)
+        d.emit_len = self._packed_off - d.emit_base
         d.theta_size, d.phi_size, d.packed_size = space.size, max(self._phi_off, 4), self._packed_off + 512  # slack: the kernels prefetch two fragments ahead
         # Which kernel instances run is part of the descriptor (the library itself reads no environment).  The parity tests
         # select the non-default instances through these variables, read HERE, once, when the model is lowered.
@@ -180,6 +193,12 @@ class EnginePlan:
         lib = L.load()
         L.check(lib.pmt_model_check(C.byref(d)), "pmt_model_check")
         self.packed = torch.zeros(d.packed_size, dtype=torch.float32, device=device)
+        # private partial sums of the backward's weight-gradient blocks: one row per compute unit (pmt_backward: grad_partials;
+        # the kernel leaves them zero).  PMT_GRAD_PARTIALS=0 falls back to global atomics (the parity tests run both).
+        rows = torch.cuda.get_device_properties(device).multi_processor_count if torch.device(device).type == "cuda" else 0
+        rows = int(os.environ.get("PMT_GRAD_PARTIALS", rows))
+        self.partial_rows = rows if d.emit_len > 0 else 0
+        self.grad_partials = torch.zeros(max(self.partial_rows * d.emit_len, 4), dtype=torch.float32, device=device)
         self.gphi_size = d.phi_size
         raw = bytes(d)
         self.desc_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)

@@ -137,13 +137,15 @@ class ReadSetEngine:
             L.check(self.lib.pmt_backward_layered(C.byref(d), self.plan.desc_dev.data_ptr(), self.space.theta.data_ptr(),
                                                   phi.data_ptr(), self.plan.packed.data_ptr(), C.byref(bv), C.byref(out),
                                                   C.byref(dout), stash.data_ptr(), scratch.data_ptr(),
-                                                  self.space.gtheta.data_ptr(), gphi.data_ptr(), gvar.data_ptr(), _stream()),
+                                                  self.space.gtheta.data_ptr(), gphi.data_ptr(), gvar.data_ptr(),
+                                                  self.plan.grad_partials.data_ptr(), self.plan.partial_rows, _stream()),
                     "pmt_backward_layered")
         else:
             L.check(self.lib.pmt_backward(C.byref(d), self.plan.desc_dev.data_ptr(), self.space.theta.data_ptr(),
                                           phi.data_ptr(), self.plan.packed.data_ptr(), C.byref(bv), C.byref(out),
                                           C.byref(dout), stash.data_ptr(), self.space.gtheta.data_ptr(), gphi.data_ptr(),
-                                          gvar.data_ptr(), _stream()), "pmt_backward")
+                                          gvar.data_ptr(), self.plan.grad_partials.data_ptr(), self.plan.partial_rows, _stream()),
+                    "pmt_backward")
         self._event_stop("pmt_backward", ev)
         if self.grad_hook is not None:  # every leaf in [0, late_start) has its final gradient at this point of the stream
             self.grad_hook.early(self.space.gtheta, self.space.late_start)

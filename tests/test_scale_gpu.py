@@ -138,3 +138,48 @@ def test_plain_bf16_mode_is_a_labelled_approximation(monkeypatch):
     record(test="plain_bf16_2048", max_logit_err=float(logit_err.max()), median_logit_err=float(np.median(logit_err)), grad_rel_l2=rel_l2)
     assert np.all(np.isfinite(gour)) and np.all(np.isfinite(logit_err))
     assert np.median(logit_err) < 0.5 and rel_l2 < 0.2, (float(np.median(logit_err)), rel_l2)
+
+
+def test_private_partial_sums_match_the_atomic_path_at_65536_read_sets(monkeypatch):
+    """pmt_backward's two ways of adding weight-gradient blocks -- persistent workgroups with private rows of partial sums
+    (the default: every workgroup walks ~13 groups here, reading back its own earlier stores) and one workgroup per group
+    with global float atomics (PMT_GRAD_PARTIALS=0) -- must give the same gradients up to summation order, and the rows must
+    be back to zero afterwards."""
+    nb = 65536
+    _, sd, _ = load_case("p0_b16")
+    ints, floats, packed = synth(nb, seed=13)
+
+    def grads(rows):
+        if rows is not None:
+            monkeypatch.setenv("PMT_GRAD_PARTIALS", str(rows))
+        else:
+            monkeypatch.delenv("PMT_GRAD_PARTIALS", raising=False)
+        model, dev = build("p0_b16", sd)
+        model.train(True)
+        batch = Batch.from_arrays(ints, floats, packed).copy_to(dev)
+        out = model.compute_batch_output(batch)
+        losses = model.compute_batch_losses(out, batch)
+        opt = FusedClipAdamW(model, lr=1e-3, weight_decay=0.01)
+        opt.zero_grad()
+        losses.total_loss.backward()
+        torch.cuda.synchronize()
+        plan = model.engine().plan
+        assert float(plan.grad_partials.abs().max()) == 0.0
+        return plan, np.concatenate([p.grad.detach().cpu().numpy().ravel() for _, p in model.named_parameters()])
+
+    plan, g_rows = grads(None)
+    assert plan.partial_rows > 0 and batch_groups(ints) > 8 * plan.partial_rows
+    plan0, g_atomic = grads(0)
+    assert plan0.partial_rows == 0
+    _, g_few = grads(7)  # fewer rows than compute units: longer walks, same sums
+    assert np.all(np.isfinite(g_rows)) and np.all(np.isfinite(g_atomic))
+    scale = np.linalg.norm(g_atomic)
+    rel, rel_few = float(np.linalg.norm(g_rows - g_atomic) / scale), float(np.linalg.norm(g_few - g_atomic) / scale)
+    record(test="partials_vs_atomics_65536", grad_rel_l2=rel, grad_rel_l2_7_rows=rel_few)
+    assert rel <= 2e-6 and rel_few <= 2e-6, (rel, rel_few)
+
+
+def batch_groups(ints):
+    from permutect_amd.engine import lib as L
+    reads = int(ints[:, 0].astype(np.int64).sum() + ints[:, 1].astype(np.int64).sum())
+    return reads // (L.GROUP_TILES * L.TILE)  # a lower bound on the number of groups
