@@ -22,7 +22,10 @@
 #define PMT_STAGE_PLANES (16 * PMT_GROUP_WAVES)  // every wave's operands of a 4 + 4 tile linear at once (8 waves x 8 planes x (hi + mid))
 #include "permutect_amd.h"
 #define PMT_OPAQUE_TID 1  // the kernel loops over groups (persistent launch): see pmt_tid
-#define PMT_FRAG_AHEAD 1  // weight fragments one MFMA group ahead (2 waves per SIMD do not hide an L2 round trip): 3.59 -> 3.52 ms
+#ifndef PMT_BWD_FRAG_AHEAD
+#define PMT_BWD_FRAG_AHEAD 3
+#endif
+#define PMT_FRAG_AHEAD PMT_BWD_FRAG_AHEAD  // weight fragments three MFMA groups ahead (2 waves per SIMD do not hide an L2 round trip): 0 -> 1: 3.59 -> 3.52 ms; 1 -> 3: 3.31 -> 3.27 ms
 #include "pmt_device.hpp"
 #include "pmt_bwd_device.hpp"
 
