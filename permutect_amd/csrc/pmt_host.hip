@@ -302,43 +302,68 @@ extern "C" int pmt_plan_groups_split(const int32_t* ref_counts, const int32_t* a
         ++g;
         return true;
     };
+    bool oversized = false;
+    for (int b = 0; b < num_variants; ++b) {
+        if (ref_counts[b] < 0 || alt_counts[b] < 0) return PMT_E_INVALID;
+        oversized = oversized || !group_fits(ref_counts[b], alt_counts[b]);
+    }
     long long ref_row = 0, alt_row = 0;         // exclusive scans so far
-    long long gs = 0, gref0 = 0, galt0 = 0;     // the open group: first variant, first rows
-    long long gref = 0, galt = 0;
+    if (!oversized) {  // every set fits a workgroup: whole sets per group, exactly pmt_plan_groups
+        long long gs = 0, gref0 = 0, galt0 = 0, gref = 0, galt = 0;
+        int sets = 0;
+        for (int b = 0; b < num_variants; ++b) {
+            const long long r = ref_counts[b], a = alt_counts[b];
+            if (sets > 0 && (!group_fits(gref + r, galt + a) || sets + 1 > PMT_GROUP_MAX_SETS)) {
+                if (!emit(gs, b, gref0, ref_row, galt0, alt_row)) return PMT_E_WORKSPACE;
+                gs = b; gref0 = ref_row; galt0 = alt_row; gref = galt = 0; sets = 0;
+            }
+            gref += r; galt += a; ++sets;
+            ref_row += r; alt_row += a;
+        }
+        if (sets > 0 && !emit(gs, num_variants, gref0, ref_row, galt0, alt_row)) return PMT_E_WORKSPACE;
+        tile_base[g] = (int32_t)tiles;
+        return g;
+    }
+    // Some set exceeds a workgroup: the batch runs layered, where a group may hold ANY contiguous run of ref rows and of alt
+    // rows (per-set sums are joined in HBM).  So the rows are STREAMED into groups -- a set's ref rows, then its alt rows, the
+    // next set right behind -- and a group is closed only when nothing more fits: ~ceil(tiles / 16) groups instead of one
+    // partly empty last group per oversized set (600-read sets: 3 groups of 16 tile slots for 38 tiles each before).
+    *needs_layered = 1;
+    auto waves_of = [&](long long rows) { return ((rows + 15) / 16 + per - 1) / per; };
+    long long g_v0 = 0, g_rb = 0, g_ab = 0, gref = 0, galt = 0;
     int sets = 0;
+    bool open = false;
     for (int b = 0; b < num_variants; ++b) {
         const long long r = ref_counts[b], a = alt_counts[b];
-        if (r < 0 || a < 0) return PMT_E_INVALID;
-        if (!group_fits(r, a)) {  // more reads than a workgroup holds: close the open group, give this set groups of its own
-            if (sets > 0 && !emit(gs, b, gref0, ref_row, galt0, alt_row)) return PMT_E_WORKSPACE;
-            *needs_layered = 1;
-            long long rb = ref_row, ab = alt_row;
-            const long long rend = ref_row + r, aend = alt_row + a;
-            while (rb < rend || ab < aend) {
-                long long tr = (rend - rb + 15) / 16;
-                if (tr > PMT_GROUP_TILES) tr = PMT_GROUP_TILES;
-                const long long take_r = (rend - rb) < tr * 16 ? (rend - rb) : tr * 16;
-                long long take_a = 0;
-                if (rb + take_r >= rend) {  // the ref rows end in this group: fill the remaining waves with alt tiles
-                    const long long ta_max = (PMT_GROUP_WAVES - (tr + per - 1) / per) * per;
-                    take_a = (aend - ab) < ta_max * 16 ? (aend - ab) : ta_max * 16;
-                }
-                if (!emit(b, b + 1, rb, rb + take_r, ab, ab + take_a)) return PMT_E_WORKSPACE;
-                rb += take_r;
-                ab += take_a;
+        long long rdone = 0, adone = 0;
+        bool counted = false;  // set b has rows in the open group
+        while (rdone < r || adone < a) {
+            if (!open) {
+                g_v0 = b; g_rb = ref_row + rdone; g_ab = alt_row + adone; gref = galt = 0; sets = 0;
+                open = true; counted = false;
             }
-            ref_row += r; alt_row += a;
-            gs = b + 1; gref0 = ref_row; galt0 = alt_row; gref = galt = 0; sets = 0;
-            continue;
+            bool placed = false;
+            if (counted || sets < PMT_GROUP_MAX_SETS) {
+                if (rdone < r) {
+                    const long long room = (PMT_GROUP_WAVES - waves_of(galt)) * per * 16 - gref;
+                    const long long x = (r - rdone) < room ? (r - rdone) : room;
+                    if (x > 0) { gref += x; rdone += x; placed = true; }
+                }
+                if (rdone == r && adone < a) {
+                    const long long room = (PMT_GROUP_WAVES - waves_of(gref)) * per * 16 - galt;
+                    const long long y = (a - adone) < room ? (a - adone) : room;
+                    if (y > 0) { galt += y; adone += y; placed = true; }
+                }
+            }
+            if (placed && !counted) { counted = true; ++sets; }
+            if (rdone < r || adone < a) {  // the group is full (or has its sets): close it; set b continues in the next one
+                if (!emit(g_v0, counted ? b + 1 : b, g_rb, g_rb + gref, g_ab, g_ab + galt)) return PMT_E_WORKSPACE;
+                open = false;
+            }
         }
-        if (sets > 0 && (!group_fits(gref + r, galt + a) || sets + 1 > PMT_GROUP_MAX_SETS)) {
-            if (!emit(gs, b, gref0, ref_row, galt0, alt_row)) return PMT_E_WORKSPACE;
-            gs = b; gref0 = ref_row; galt0 = alt_row; gref = galt = 0; sets = 0;
-        }
-        gref += r; galt += a; ++sets;
         ref_row += r; alt_row += a;
     }
-    if (sets > 0 && !emit(gs, num_variants, gref0, ref_row, galt0, alt_row)) return PMT_E_WORKSPACE;
+    if (open && gref + galt > 0 && !emit(g_v0, num_variants, g_rb, g_rb + gref, g_ab, g_ab + galt)) return PMT_E_WORKSPACE;
     tile_base[g] = (int32_t)tiles;
     return g;
 }

@@ -236,3 +236,37 @@ def test_mean_loss_is_the_unweighted_mean_over_labels():
     assert abs(rec.mean_loss() - (2.0 + 8.0) / 2) < 1e-6       # label 2 has no data: left out (the reference gives NaN)
     tot[0, 2, 0, 0, 0], cnt[0, 2, 0, 0, 0] = 5.0, 5.0
     assert abs(rec.mean_loss() - (2.0 + 8.0 + 1.0) / 3) < 1e-6
+
+
+def test_split_planner_streams_rows_into_full_groups():
+    """pmt_plan_groups_split with oversized sets: every ref / alt row lies in exactly one group, a group's rows are one
+    contiguous run per side that fits the wave layout (ref tiles and alt tiles on disjoint waves, two per wave), its variant
+    range covers exactly the sets it holds rows of, and the groups are full: ~tiles / 16 of them, not a partly empty last
+    group per oversized set."""
+    from permutect_amd.data.batch import GroupPlan
+    from permutect_amd.engine import lib as L
+    rng = np.random.default_rng(3)
+    for ref, alt in [(rng.poisson(300, 200), np.maximum(rng.poisson(300, 200), 1)),          # the stress shape
+                     (rng.integers(0, 11, 500), rng.integers(1, 16, 500)),                    # WGS-shaped ...
+                     (np.array([0, 700, 3, 0, 256, 5]), np.array([1, 1, 2, 600, 1, 9]))]:     # ... and a ragged mix
+        ref, alt = ref.astype(np.int64), alt.astype(np.int64)
+        if ref.max() + alt.max() < 200:
+            ref[17], alt[400] = 290, 310  # two oversized sets among small ones
+        plan = GroupPlan(ref, alt, allow_split=True)
+        assert plan.layered
+        span = plan.span[: plan.num_groups]
+        ro, ao = np.concatenate([[0], np.cumsum(ref)]), np.concatenate([[0], np.cumsum(alt)])
+        rpos = apos = 0
+        for v0, v1, rb, re, ab, ae in span:
+            assert rb == rpos and ab == apos and re >= rb and ae >= ab and (re - rb) + (ae - ab) > 0
+            rpos, apos = re, ae
+            tr, ta = -(-(re - rb) // 16), -(-(ae - ab) // 16)
+            assert -(-tr // 2) + -(-ta // 2) <= L.GROUP_WAVES
+            assert 0 < v1 - v0 <= L.GROUP_MAX_SETS
+            held = [v for v in range(len(ref)) if (min(re, ro[v + 1]) > max(rb, ro[v])) or (min(ae, ao[v + 1]) > max(ab, ao[v]))]
+            assert held and held[0] == v0 and held[-1] == v1 - 1
+        assert rpos == ref.sum() and apos == alt.sum()
+        tiles = int(np.diff(plan.group_tile_base[: plan.num_groups + 1]).sum())
+        assert plan.total_tiles == tiles
+        if len(ref) == 200:  # 600-read sets: 38 tiles each used to take 3 groups (48 tile slots)
+            assert plan.num_groups <= 1.08 * tiles / L.GROUP_TILES + 1, (plan.num_groups, tiles)
