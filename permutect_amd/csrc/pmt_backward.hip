@@ -701,6 +701,14 @@ DEV void backward_group(
                 const long long src = bt.read_index ? bt.read_index[tm[rt].row] : (long long)tm[rt].row;
                 rowp = reinterpret_cast<const unsigned char*>(bt.reads) + (size_t)src * (size_t)bt.read_row_bytes;
             }
+            if (NTF == 4 && S::DIM_F == 61 && fmt == PMT_READS_PACKED_U8 && bt.read_row_bytes == 12) {
+#pragma unroll
+                for (int t = 0; t < NTF; ++t) x[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (NTF == 4) {
+                    if (rowp) decode_packed12(x[rt], rowp, g);
+                }
+                continue;
+            }
 #pragma unroll
             for (int t = 0; t < NTF; ++t)
 #pragma unroll

@@ -375,6 +375,31 @@ DEV void stash_load(const float* __restrict__ base, f4 (&v)[NT]) {
     for (int t = 0; t < NT; ++t) v[t] = p[t * 64];
 }
 
+// ---- packed read rows ------------------------------------------------------------------------------------------------
+// One row of the reference's packed read layout with five quantile bytes (data/batch.py:51-56, data/datum.py:35: seven
+// MSB-first bit bytes, then (uint8 + 128) / 32 with the uint8 wrap of plain_text_data.py:510-511) = 12 bytes = F 61: three
+// dword loads per row, after which each of the lane's 16 features (16 t + 4 j + g) is a bit field of a register -- instead of
+// up to ten byte loads per row and lane.
+DEV void decode_packed12(f4 (&x)[4], const unsigned char* __restrict__ row, int g) {
+    const unsigned* p = reinterpret_cast<const unsigned*>(row);
+    const unsigned d0 = p[0], d1 = p[1], d2 = p[2];
+    const unsigned long long hi = ((unsigned long long)d2 << 32) | d1;  // bytes 4 .. 11
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (16 * t + 4 * j + 3 < 56) {  // bit features: byte 2 t + (j >> 1), bit 7 - (4 (j & 1) + g)
+                const unsigned d = (t >> 1) ? d1 : d0;
+                const int sh = 8 * ((2 * t + (j >> 1)) & 3) + 7 - 4 * (j & 1) - g;
+                x[t][j] = (float)((d >> sh) & 1u);
+            } else {                        // quantile features 56 .. 60: byte 7 + idx
+                const int idx = 4 * (j - 2) + g;
+                const unsigned u = (unsigned)(hi >> (8 * (3 + (idx < 5 ? idx : 0)))) & 0xFFu;
+                x[t][j] = idx < 5 ? (float)((u + 128u) & 0xFFu) * (1.0f / 32.0f) : 0.f;
+            }
+        }
+}
+
 // ---- group geometry ----------------------------------------------------------------------------------------------
 struct GroupGeom {
     int v0, nsets;           // first variant, number of sets

@@ -50,6 +50,24 @@ struct PmtLayeredArgs {
     float* hsum_g;      // [B][PMT_MAX_CLUSTERS + 2]
 };
 
+// development: per-wave event log of ONE workgroup (PmtBatch.debug_flags[2] = workgroup + 1; scripts/fwd_trace.py); compiled in
+// with -DPMT_FWD_TRACE=1 only
+#ifndef PMT_FWD_TRACE
+#define PMT_FWD_TRACE 0
+#endif
+struct FwdTrace {
+    int* buf = nullptr;
+    int n = 0;
+    DEV void ev(int id) {
+        if (!PMT_FWD_TRACE || buf == nullptr) return;
+        if (n < 250 && (threadIdx.x & 63) == 0) {
+            buf[2 * n] = id;
+            buf[2 * n + 1] = (int)__builtin_readcyclecounter();
+        }
+        ++n;
+    }
+};
+
 template <bool TRAIN, typename S, bool LAYERED = false>
 __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_kernel(const PmtModel* __restrict__ M,
                                                                       const float* __restrict__ theta,
@@ -71,6 +89,9 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
     const int Er = S::DIM_R ? S::DIM_R : uniform(M->read_embed_dim), Ev = uniform(M->variant_embed_dim);
     const int h = S::DIM_H ? S::DIM_H : (uniform(M->d_ffn) >> 1), L = uniform(M->num_blocks), F = S::DIM_F ? S::DIM_F : uniform(M->num_read_features);
     const int dbg = bt.debug_flags ? uniform(bt.debug_flags[1]) : 0;  // development switches, 0 in production
+    FwdTrace tr;
+    if (PMT_FWD_TRACE && bt.debug_flags && uniform(bt.debug_flags[2]) == (int)blockIdx.x + 1) tr.buf = bt.debug_flags + 64 + (tid >> 6) * 512;
+    tr.ev(1);
 
     // ---- group setup: local offsets, zero the per-set accumulators -------------------------------------------
     for (int i = tid; i <= gg.nsets; i += PMT_THREADS) {
@@ -81,6 +102,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
     for (int i = tid; i < PMT_GROUP_MAX_SETS * 2 * PMT_MAX_WIDTH; i += PMT_THREADS) (&sh.fsum[0][0][0])[i] = 0.f;
     for (int i = tid; i < PMT_GROUP_MAX_SETS * (PMT_MAX_CLUSTERS + 2); i += PMT_THREADS) (&sh.hsum[0][0])[i] = 0.f;
     __syncthreads();
+    tr.ev(2);
 
     TileMeta tm[PMT_RT];
     unsigned mask_all = 0;  // tiles that exist: gates memory traffic only
@@ -118,14 +140,24 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
                 const long long src = bt.read_index ? bt.read_index[tm[rt].row] : (long long)tm[rt].row;
                 rowp = reinterpret_cast<const unsigned char*>(bt.reads) + (size_t)src * (size_t)bt.read_row_bytes;
             }
+            if (NTF == 4 && S::DIM_F == 61 && fmt == PMT_READS_PACKED_U8 && bt.read_row_bytes == 12) {
+#pragma unroll
+                for (int t = 0; t < NTF; ++t) xf[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (NTF == 4) {
+                    if (rowp) decode_packed12(xf[rt], rowp, g);
+                }
+                continue;
+            }
 #pragma unroll
             for (int t = 0; t < NTF; ++t)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) xf[rt][t][j] = rowp ? read_feature(rowp, fmt, feat_of(t, j, g), F) : 0.f;
         }
+        tr.ev(5);
         if constexpr (EX) {
             f4 xr[PMT_RT][NTR];
             run_linear_op<NTF, NTR, true, S::DIM_F, S::DIM_R, S::BF16>(M, M->read_mlp.ops[0], xr, xf, g, packed);
+            tr.ev(6);
             run_mlp<TRAIN, NTR, true, S::DIM_R, S::BF16>(M, M->read_mlp, xr, theta, g, mask_all, stash_tile, slot, 1, packed, 1, n_read_ops);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
@@ -140,6 +172,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
         }
     }
 
+    tr.ev(3);
     // ---- broadcast-concat of the per-variant embedding (reference artifact_model.py:246-251) --------------------
     if (!(LAYERED && lay.slice > 0)) {
 #pragma unroll
@@ -155,6 +188,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
     }
 
     }
+    tr.ev(4);
     // ---- L gated ref/alt blocks; this wave's tiles all use the weights of its side ------------------------------
     for (int l = (LAYERED && lay.slice > 0) ? lay.slice - 1 : 0; l < L; ++l) {
         const PmtBlock& B = M->blocks[l];
@@ -238,7 +272,9 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
             for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS)
                 (&sh.zsum[buf][0][0][0])[i] = lay.zsum_g[((size_t)(gg.v0 + (i >> 5)) * L + l) * 32 + (i & 31)];
         }
+        tr.ev(10);
         __syncthreads();
+        tr.ev(11);
         if (TRAIN && !LAYERED) {
             for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS)
                 zsum_stash[((size_t)(gg.v0 + (i >> 5)) * L + l) * 32 + (i & 31)] = (&sh.zsum[buf][0][0][0])[i];
@@ -283,6 +319,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
             if constexpr (S::BF16) linear_acc_bf16<1, NTD, false, S::BF16>(x, u, packed + uniform(M->lin[uniform(B.proj2[side])].wb_frag));
             else linear_acc<1, NTD, false, EX, S::DIM_H>(x, u, p2_frags + side * frag_floats_dev(P2r), h, D);
         }
+        tr.ev(12);
     }
     if (TRAIN) {  // x_L, the reducer's input
 #pragma unroll
@@ -291,6 +328,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
         ++slot;
     }
 
+    tr.ev(19);
     // ---- reducer MLP, then translation + rotation ----------------------------------------------------------------
     f4 e[PMT_RT][NTE];
     if constexpr (EX) {
@@ -326,6 +364,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
         else linear_acc<NTE, NTE, false, EX, S::DIM_E>(a, e, stR, E, E);
     }
 
+    tr.ev(21);
     // ---- per-set feature sums (both sides) and the clustering head (alt reads) -------------------------------------
     const int nte = (E + 15) >> 4;
     {
@@ -435,6 +474,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
             }
         }
     }
+    tr.ev(22);
     __syncthreads();
     if constexpr (LAYERED) {  // the group's partial head sums join the global ones; pmt_finalize_kernel writes the outputs
         for (int i = tid; i < gg.nsets * (K + 2); i += PMT_THREADS) {
@@ -449,6 +489,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
         return;
     }
 
+    tr.ev(23);
     // ---- per-set finalisation (reference feature_clustering.py:121-135, ragged_sets.py:144-155) -----------------
     for (int i = tid; i < gg.nsets; i += PMT_THREADS) {
         const int b = gg.v0 + i;

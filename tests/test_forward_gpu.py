@@ -85,7 +85,9 @@ def test_forward_matches_reference(name, fmt):
     with torch.no_grad():
         out = model.compute_batch_output(batch)
     torch.cuda.synchronize()
-    check_outputs(out, z, name)
+    # (the deep fixture's sets are summed with float atomics whose order varies from run to run: measured 0.7 - 1.1 x the
+    #  8-ulp bound, so it gets the 16 ulp of the other tests with long sums)
+    check_outputs(out, z, name, lk_ulps=16 if "deep" in name else 8)
 
 
 @pytest.mark.parametrize("name", ["t0_b8", "p0_b16"])
