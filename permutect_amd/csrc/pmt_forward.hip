@@ -7,11 +7,11 @@
 #include "pmt_device.hpp"
 #include "pmt_mlp_device.hpp"
 
-struct FwdShared {
-    int off[2][PMT_GROUP_MAX_SETS + 1];
+struct FwdShared {  // (the float tables first: their rows are read and cleared 16 bytes at a time)
     float zsum[3][PMT_GROUP_MAX_SETS][2][16];
     float fsum[PMT_GROUP_MAX_SETS][2][PMT_MAX_WIDTH];
     float hsum[PMT_GROUP_MAX_SETS][PMT_MAX_CLUSTERS + 2];
+    int off[2][PMT_GROUP_MAX_SETS + 1];
 };
 
 // ---- input decode ------------------------------------------------------------------------------------------------
@@ -98,9 +98,15 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
         sh.off[0][i] = bt.ref_offsets[gg.v0 + i] - gg.ref_base;
         sh.off[1][i] = bt.alt_offsets[gg.v0 + i] - gg.alt_base;
     }
-    for (int i = tid; i < 3 * PMT_GROUP_MAX_SETS * 32; i += PMT_THREADS) (&sh.zsum[0][0][0][0])[i] = 0.f;
-    for (int i = tid; i < PMT_GROUP_MAX_SETS * 2 * PMT_MAX_WIDTH; i += PMT_THREADS) (&sh.fsum[0][0][0])[i] = 0.f;
-    for (int i = tid; i < PMT_GROUP_MAX_SETS * (PMT_MAX_CLUSTERS + 2); i += PMT_THREADS) (&sh.hsum[0][0])[i] = 0.f;
+    {   // only the rows of the group's sets (typically a third of the capacity), 16 bytes per store
+        const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
+        for (int i = tid; i < 3 * gg.nsets * 8; i += PMT_THREADS) {
+            const int b = i / (gg.nsets * 8), r = i - b * (gg.nsets * 8);
+            reinterpret_cast<f4*>(&sh.zsum[b][0][0][0])[r] = zero;
+        }
+        for (int i = tid; i < gg.nsets * (2 * PMT_MAX_WIDTH / 4); i += PMT_THREADS) reinterpret_cast<f4*>(&sh.fsum[0][0][0])[i] = zero;
+        for (int i = tid; i < gg.nsets * (PMT_MAX_CLUSTERS + 2); i += PMT_THREADS) (&sh.hsum[0][0])[i] = 0.f;
+    }
     __syncthreads();
     tr.ev(2);
 
