@@ -1,4 +1,4 @@
-"""A few training steps at the bench workload (development aid for rocprofv3 --pmc runs: few dispatches, no CPU baseline)."""
+"""A few training steps and filter forwards at the bench workload (development aid for rocprofv3 --pmc runs: few dispatches, no CPU baseline)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -21,5 +21,9 @@ for i in range(steps):
     out = model.compute_batch_output(batch)
     loss = model.compute_batch_losses(out, batch).total_loss
     backpropagate(opt, loss, params_to_clip=model.parameters())
+model.train(False)
+with torch.inference_mode():  # and the filter forward (its kernel instance has its own counters)
+    for i in range(steps):
+        model.compute_batch_output(batch)
 torch.cuda.synchronize()
 print("done", float(loss))
