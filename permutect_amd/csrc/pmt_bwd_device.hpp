@@ -519,32 +519,16 @@ DEV int stage_rbase(int lane) {  // lane (m = lane & 15, kg = lane >> 4) -> slot
 }
 // one operand plane of this wave: v0 / v1 = the plane's registers of tile 0 / tile 1 (zero for padding reads and absent tiles);
 // pj[j] = the wave's stage + (wbase ^ 16 j), off = the plane's byte offset (compile time: it lands in the DS offset fields).
-// Six VALU operations and one ds_write2st64_b32 per pair of values.  The two instructions are spelled out because the
-// optimizer otherwise (a) re-converts v0 alone to get hi << 16 and (b) moves v0, v1 into an aligned register pair to use one
-// v_pk_add_f32 for the two subtractions: nine operations instead of six, a tenth of the backward kernel's VALU work.
-DEV unsigned cvt_pk_bf16(float lo, float hi) {  // round to nearest even
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
-DEV float sub_f32(float a, float b) {
-    float r;
-    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
+// Four VALU operations (split_pair: pack, two residuals on the dot unit, pack) and one ds_write2st64_b32 per pair of values.
 template <int PIECES = 3>
 DEV void stage_pair_bf16(char* const (&pj)[4], int off, f4 v0, f4 v1) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         char* p = pj[j] + off;
-        if constexpr (PIECES == 1) {
-            *reinterpret_cast<unsigned*>(p) = pack_bf16x2(v0[j], v1[j]);
-        } else {
-            const unsigned hi = cvt_pk_bf16(v0[j], v1[j]);
-            const float h0 = __builtin_bit_cast(float, hi << 16), h1 = __builtin_bit_cast(float, hi & 0xFFFF0000u);
-            *reinterpret_cast<unsigned*>(p) = hi;
-            *reinterpret_cast<unsigned*>(p + 1024) = cvt_pk_bf16(sub_f32(v0[j], h0), sub_f32(v1[j], h1));
-        }
+        unsigned hi, mid = 0u, lo = 0u;
+        split_pair<(PIECES == 1 ? 1 : 2)>(v0[j], v1[j], hi, mid, lo);
+        *reinterpret_cast<unsigned*>(p) = hi;
+        if constexpr (PIECES != 1) *reinterpret_cast<unsigned*>(p + 1024) = mid;
     }
 }
 

@@ -203,9 +203,46 @@ DEV void split_bf16x3(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
     mid = (__bf16)r1;
     lo = (__bf16)(r1 - (float)mid);
 }
+// Splitting a pair of values into bf16 pieces: pack (v_cvt_pk_bf16_f32), subtract each half back (shift / mask the half
+// into a float, one v_pk_add_f32 for both), pack the residuals, ...: 9 VALU operations for three pieces, 6 for two.
+// PMT_SPLIT_DOT2 = 1 forms the residuals on the dot-product unit instead (v_dot2c_f32_bf16 with the multiplier pair (-1, 0) or
+// (0, -1): acc - one half, exact, 7 / 4 operations): measured equal in the backward and 6 % SLOWER in the filter forward
+// (0.81 -> 0.86 ms) -- the instruction is not full rate.  Kept as a switch.
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+DEV unsigned pack_bf16_pair(float lo, float hi) {  // v_cvt_pk_bf16_f32, round to nearest even
+    const bf2 p = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, p);
+}
+// (the multiplier pairs travel in registers: as a compile-time constant hipcc 7.2 encodes the pair (-1, 0) = 0x0000BF80 as the
+//  INLINE constant -1.0, which the instruction reads as 0xBF800000 = the pair (0, -1))
+DEV unsigned opaque_bits(unsigned v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
+#ifndef PMT_SPLIT_DOT2
+#define PMT_SPLIT_DOT2 0
+#endif
+DEV float minus_lo_half(unsigned pk, float acc) {
+    if (!PMT_SPLIT_DOT2) return acc - __builtin_bit_cast(float, pk << 16);
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, pk), __builtin_bit_cast(bf2, opaque_bits(0x0000BF80u)), acc, false);
+}
+DEV float minus_hi_half(unsigned pk, float acc) {
+    if (!PMT_SPLIT_DOT2) return acc - __builtin_bit_cast(float, pk & 0xFFFF0000u);
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, pk), __builtin_bit_cast(bf2, opaque_bits(0xBF800000u)), acc, false);
+}
+template <int PIECES>
+DEV void split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    h = pack_bf16_pair(a, b);
+    if constexpr (PIECES >= 2) {
+        const float ra = minus_lo_half(h, a), rb = minus_hi_half(h, b);
+        m = pack_bf16_pair(ra, rb);
+        if constexpr (PIECES >= 3) l = pack_bf16_pair(minus_lo_half(m, ra), minus_hi_half(m, rb));
+    }
+}
 // the bf16 pieces of k block `kb` of the input (two activation tiles in register order), SELU applied on the way if asked
 template <int NTI, bool SELU_IN, int PIECES>
 DEV void split_kblock(const f4 (&in)[PMT_RT][NTI], int kb, float in_scale, bf8 (&bh)[PMT_RT], bf8 (&bm)[PMT_RT], bf8 (&bl)[PMT_RT]) {
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int rt = 0; rt < PMT_RT; ++rt) {
         const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
@@ -214,23 +251,17 @@ DEV void split_kblock(const f4 (&in)[PMT_RT][NTI], int kb, float in_scale, bf8 (
             v0 = selu4(v0) * in_scale;
             if (2 * kb + 1 < NTI) v1 = selu4(v1) * in_scale;
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if constexpr (PIECES == 1) {
-                bh[rt][e] = (__bf16)v0[e];
-                bh[rt][4 + e] = (__bf16)v1[e];
-            } else if constexpr (PIECES == 2) {
-                const __bf16 h0 = (__bf16)v0[e], h1 = (__bf16)v1[e];
-                bh[rt][e] = h0; bm[rt][e] = (__bf16)(v0[e] - (float)h0);
-                bh[rt][4 + e] = h1; bm[rt][4 + e] = (__bf16)(v1[e] - (float)h1);
-            } else {
-                __bf16 h, m, l;
-                split_bf16x3(v0[e], h, m, l);
-                bh[rt][e] = h; bm[rt][e] = m; bl[rt][e] = l;
-                split_bf16x3(v1[e], h, m, l);
-                bh[rt][4 + e] = h; bm[rt][4 + e] = m; bl[rt][4 + e] = l;
-            }
+        unsigned hh[4] = {0u, 0u, 0u, 0u}, mm[4] = {0u, 0u, 0u, 0u}, ll[4] = {0u, 0u, 0u, 0u};
+        split_pair<PIECES>(v0[0], v0[1], hh[0], mm[0], ll[0]);
+        split_pair<PIECES>(v0[2], v0[3], hh[1], mm[1], ll[1]);
+        if (2 * kb + 1 < NTI) {
+            split_pair<PIECES>(v1[0], v1[1], hh[2], mm[2], ll[2]);
+            split_pair<PIECES>(v1[2], v1[3], hh[3], mm[3], ll[3]);
         }
+        const u4v h = {hh[0], hh[1], hh[2], hh[3]}, m = {mm[0], mm[1], mm[2], mm[3]}, l = {ll[0], ll[1], ll[2], ll[3]};
+        bh[rt] = __builtin_bit_cast(bf8, h);
+        if constexpr (PIECES >= 2) bm[rt] = __builtin_bit_cast(bf8, m);
+        if constexpr (PIECES >= 3) bl[rt] = __builtin_bit_cast(bf8, l);
     }
 }
 #ifndef PMT_FRAG_AHEAD
