@@ -519,16 +519,35 @@ DEV int stage_rbase(int lane) {  // lane (m = lane & 15, kg = lane >> 4) -> slot
 }
 // one operand plane of this wave: v0 / v1 = the plane's registers of tile 0 / tile 1 (zero for padding reads and absent tiles);
 // pj[j] = the wave's stage + (wbase ^ 16 j), off = the plane's byte offset (compile time: it lands in the DS offset fields).
-// Four VALU operations (split_pair: pack, two residuals on the dot unit, pack) and one ds_write2st64_b32 per pair of values.
+// Six VALU operations and one ds_write2st64_b32 per pair of values.  The two instructions are spelled out because the
+// optimizer otherwise (a) re-converts v0 alone to get hi << 16 and (b) moves v0, v1 into an aligned register pair to use one
+// v_pk_add_f32 for the two subtractions: nine operations instead of six, a tenth of the backward kernel's VALU work.
+DEV unsigned cvt_pk_bf16(float lo, float hi) {  // round to nearest even
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+DEV float sub_f32(float a, float b) {
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+DEV char* lds_ptr(unsigned byte_address) {  // an LDS address back as a pointer (address space 3 -> generic)
+    return (char*)((__attribute__((address_space(3))) char*)(size_t)byte_address);
+}
 template <int PIECES = 3>
 DEV void stage_pair_bf16(char* const (&pj)[4], int off, f4 v0, f4 v1) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         char* p = pj[j] + off;
-        unsigned hi, mid = 0u, lo = 0u;
-        split_pair<(PIECES == 1 ? 1 : 2)>(v0[j], v1[j], hi, mid, lo);
-        *reinterpret_cast<unsigned*>(p) = hi;
-        if constexpr (PIECES != 1) *reinterpret_cast<unsigned*>(p + 1024) = mid;
+        if constexpr (PIECES == 1) {
+            *reinterpret_cast<unsigned*>(p) = pack_bf16x2(v0[j], v1[j]);
+        } else {
+            const unsigned hi = cvt_pk_bf16(v0[j], v1[j]);
+            const float h0 = __builtin_bit_cast(float, hi << 16), h1 = __builtin_bit_cast(float, hi & 0xFFFF0000u);
+            *reinterpret_cast<unsigned*>(p) = hi;
+            *reinterpret_cast<unsigned*>(p + 1024) = cvt_pk_bf16(sub_f32(v0[j], h0), sub_f32(v1[j], h1));
+        }
     }
 }
 
@@ -597,7 +616,11 @@ DEV void wgrad_exchange_bf(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, 
         t1 = prof_now();
         if (PW == PMT_WAVES || (wave >= w0 && wave < w0 + PW)) {
             char* mine = stage + (wave - w0) * (P * PMT_BF_PLANE_BYTES);
-            char* const pj[4] = {mine + c.wbase, mine + (c.wbase ^ 16), mine + (c.wbase ^ 32), mine + (c.wbase ^ 48)};
+            // (through an empty asm: computed ONCE per exchange; the compiler otherwise rebuilds each address at every store)
+            unsigned a0 = (unsigned)(size_t)(mine + c.wbase), a1 = (unsigned)(size_t)(mine + (c.wbase ^ 16)),
+                     a2 = (unsigned)(size_t)(mine + (c.wbase ^ 32)), a3 = (unsigned)(size_t)(mine + (c.wbase ^ 48));
+            asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+            char* const pj[4] = {lds_ptr(a0), lds_ptr(a1), lds_ptr(a2), lds_ptr(a3)};
 #pragma unroll
             for (int ot = 0; ot < NTO; ++ot) stage_pair_bf16<PIECES>(pj, ot * PMT_BF_PLANE_BYTES, dy[0][ot], dy[1][ot]);
 #pragma unroll
