@@ -72,6 +72,18 @@ class Checkpoint:
         return self.should_roll_back(loss) and self.load_checkpoint()
 
 
+
+def check_for_nan(model):
+    """Reference misc_utils.py:159-166: fail the run when a parameter's gradient holds a NaN or an Inf.  One reduction over the
+    flat gradient buffer that every `.grad` aliases; the parameters are only named once something is wrong."""
+    gtheta = model.engine().space.gtheta
+    if bool(torch.isfinite(gtheta).all()):
+        return
+    for name, param in model.named_parameters():
+        if param.grad is not None and not bool(torch.isfinite(param.grad).all()):
+            print(f"Invalid gradient (NaN or Inf) found in parameter: {name}")
+    raise AssertionError("invalid gradient (NaN or Inf)")
+
 def training_params_fit_downsampler(training_params) -> bool:
     """The balance fit can be skipped (uniform mixture weights) with `fit_downsampler = False` on the parameters object --
     tests that train for a few steps do; the reference always fits."""
@@ -155,6 +167,7 @@ def train_artifact_model(model, train_dataset: ReadsDataset, valid_dataset: Opti
                             opt.zero_grad()
                             losses.total_loss.backward()
                             opt.step(pre_reduce=reduce_grads)
+            check_for_nan(model)  # reference model_training.py:168, after every epoch
             if dist is not None:
                 recorder.all_reduce(dist)
             mean_loss = recorder.mean_loss(PRIMARY)  # the epoch's one host sync

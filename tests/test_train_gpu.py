@@ -333,3 +333,21 @@ def test_zero_adversarial_strength_sends_no_gradient_upstream():
     out.square().sum().backward()
     torch.cuda.synchronize()
     assert torch.allclose(grads[0.3][0], -0.3 * leaf.grad, rtol=1e-6, atol=1e-7)
+
+
+def test_check_for_nan_fails_the_run_on_a_poisoned_gradient(capsys):
+    """reference misc_utils.py:159-166 (called after every epoch, model_training.py:168): names the parameter, then asserts."""
+    from permutect_amd.training.model_training import check_for_nan
+    z, sd, b = load_case("t0_b8")
+    model, dev = build("t0_b8", sd)
+    model.train(True)
+    batch = Batch.from_arrays(b["int_array"], b["float_array"], b["packed_reads"]).copy_to(dev)
+    opt = FusedClipAdamW(model, lr=1e-3, weight_decay=0.01)
+    opt.zero_grad()
+    model.compute_batch_losses(model.compute_batch_output(batch), batch).total_loss.backward()
+    check_for_nan(model)  # a healthy step passes
+    name, param = next((n, p) for n, p in model.named_parameters() if n.startswith("reducer."))
+    param.grad.view(-1)[0] = float("inf")
+    with pytest.raises(AssertionError):
+        check_for_nan(model)
+    assert name in capsys.readouterr().out
