@@ -106,6 +106,18 @@ class ReadsDataset:
     def num_sources(self) -> int:
         return self._num_sources
 
+    def validate_sources(self) -> int:
+        """Reference reads_dataset.py:212-221: every source index below the largest one must have data."""
+        n = self.num_sources()
+        if n == 1:
+            print("Data come from a single source")
+        else:
+            totals_s = self.totals_slvra.sum(dim=(1, 2, 3, 4))
+            for source in range(n):
+                assert totals_s[source].item() >= 1, f"No data for source {source}."
+            print(f"Data come from multiple sources, with counts {totals_s.tolist()}.")
+        return n
+
     def __len__(self) -> int:
         return self._size
 

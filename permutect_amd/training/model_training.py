@@ -99,7 +99,7 @@ def train_artifact_model(model, train_dataset: ReadsDataset, valid_dataset: Opti
     intended rows."""
     device = model._device
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
-    num_sources = train_dataset.num_sources()
+    num_sources = train_dataset.validate_sources()  # (reference :63)
     balancer = Balancer(num_sources=num_sources, device=device)
     downsampler = Downsampler(num_sources=num_sources)
     if training_params_fit_downsampler(training_params):

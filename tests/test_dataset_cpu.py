@@ -94,3 +94,22 @@ def test_posterior_rows_match_the_reference_per_datum_loop():
     np.testing.assert_array_equal(floats.numpy(), z["out_float"])
     # saturated and tiny logits survive the float16 hop as the reference's do
     assert floats[0, 5] == 20.0 and floats[1, 5] == -20.0 and float(floats[2, 5]) == float(np.float16(1e-4))
+
+
+
+def test_validate_sources_requires_data_for_every_source():
+    """reference data/reads_dataset.py:212-221"""
+    import pytest
+    from permutect_amd.data.datum import Data
+    z = _expected()
+    ints = z["int_array"].copy()
+    ints[:, Data.SOURCE.idx] = 0
+    ds = ReadsDataset(MemoryMappedData.from_arrays(ints, z["float_array"], z["reads"]))
+    assert ds.validate_sources() == 1
+    ints[::2, Data.SOURCE.idx] = 2  # sources 0 and 2 present, 1 missing
+    ds = ReadsDataset(MemoryMappedData.from_arrays(ints, z["float_array"], z["reads"]))
+    assert ds.num_sources() == 3
+    with pytest.raises(AssertionError, match="No data for source 1"):
+        ds.validate_sources()
+    ints[1::4, Data.SOURCE.idx] = 1
+    assert ReadsDataset(MemoryMappedData.from_arrays(ints, z["float_array"], z["reads"])).validate_sources() == 3
