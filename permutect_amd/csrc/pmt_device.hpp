@@ -85,6 +85,52 @@ template <int CTRL>
 DEV float dpp_mov(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
 }
+// ---- wavefront segmented reduce over the reads of a tile (reference sets/ragged_sets.py:144-158: sums over sets) -----------
+// The 16 reads of a tile sit in the 16 lanes of a DPP row, the reads of one set in CONTIGUOUS lanes.  A Hillis-Steele scan with
+// row shifts 1, 2, 4, 8 that only adds across equal set ids leaves every set's total in the LAST lane of its run; that lane
+// alone adds to the per-set LDS accumulator.  One ds_add per (set, tile, value) without address conflicts inside the
+// instruction, where every read used to add for itself and up to 16 lanes hit one address (serialised, ~100 cycles).
+template <int CTRL>
+DEV int dpp_mov_int(int v, int absent) {  // `absent`: what lanes without a source lane read
+    return __builtin_amdgcn_update_dpp(absent, v, CTRL, 0xF, 0xF, false);
+}
+struct SegPlan {
+    bool t1, t2, t4, t8;  // lane r - d holds the same set
+    bool last;            // the run ends in this lane
+};
+DEV SegPlan seg_plan(int key) {  // key: the read's set, < 0 for lanes without a read
+    SegPlan p;
+    const bool ok = key >= 0;
+    int k1 = dpp_mov_int<0x111>(key, -2), k2 = dpp_mov_int<0x112>(key, -2), k4 = dpp_mov_int<0x114>(key, -2),  // row_shr:1, 2, 4, 8
+        k8 = dpp_mov_int<0x118>(key, -2), kn = dpp_mov_int<0x101>(key, -2);                                     // row_shl:1: the next lane's set
+    asm volatile("" : "+v"(k1), "+v"(k2), "+v"(k4), "+v"(k8), "+v"(kn));  // (all lanes shift: see dpp_mov_all)
+    p.t1 = ok && k1 == key;
+    p.t2 = ok && k2 == key;
+    p.t4 = ok && k4 == key;
+    p.t8 = ok && k8 == key;
+    p.last = ok && kn != key;
+    return p;
+}
+template <int CTRL>
+DEV float dpp_mov_all(float v) {
+    // every lane of the row must execute the shift (a lane that sits it out cannot be a SOURCE either): the empty asm keeps
+    // hipcc 7.2 from sinking the cross-lane move into the select that consumes it
+    float t = dpp_mov<CTRL>(v);
+    asm volatile("" : "+v"(t));
+    return t;
+}
+DEV float seg_sum(float v, const SegPlan& p) {  // v must be 0 in lanes without a read
+    float t = dpp_mov_all<0x111>(v);
+    v += p.t1 ? t : 0.f;
+    t = dpp_mov_all<0x112>(v);
+    v += p.t2 ? t : 0.f;
+    t = dpp_mov_all<0x114>(v);
+    v += p.t4 ? t : 0.f;
+    t = dpp_mov_all<0x118>(v);
+    v += p.t8 ? t : 0.f;
+    return v;
+}
+
 // sum over the 4 lane groups (lanes r, r+16, r+32, r+48): completes a per-read reduction over features
 DEV float group_sum(float v) {
     // Inline asm, not __builtin_amdgcn_permlane{16,32}_swap: hipcc 7.2 folds the builtin's two results into one register

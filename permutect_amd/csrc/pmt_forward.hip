@@ -88,7 +88,6 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
     const int D = S::DIM_D ? S::DIM_D : uniform(M->d_model), E = S::DIM_E ? S::DIM_E : uniform(M->feature_dim), K = uniform(M->num_clusters);
     const int Er = S::DIM_R ? S::DIM_R : uniform(M->read_embed_dim), Ev = uniform(M->variant_embed_dim);
     const int h = S::DIM_H ? S::DIM_H : (uniform(M->d_ffn) >> 1), L = uniform(M->num_blocks), F = S::DIM_F ? S::DIM_F : uniform(M->num_read_features);
-    const int dbg = bt.debug_flags ? uniform(bt.debug_flags[1]) : 0;  // development switches, 0 in production
     FwdTrace tr;
     if (PMT_FWD_TRACE && bt.debug_flags && uniform(bt.debug_flags[2]) == (int)blockIdx.x + 1) tr.buf = bt.debug_flags + 64 + (tid >> 6) * 512;
     tr.ev(1);
@@ -244,13 +243,14 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
             float rstd;
             layernorm_tile<1>(zo, zh, rstd, zin, h, sw, sb, g);
             z[rt][1] = zo[0];
-            if (tm[rt].valid) {
+            {   // per-set sums of z2: segmented reduce over the tile's reads, one LDS add per set and value
+                const SegPlan sp = seg_plan(tm[rt].valid ? tm[rt].set : -1);
                 float* dst = &sh.zsum[buf][tm[rt].set][side][4 * g];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (feat_of(0, j, g) < h) {
-                        if (dbg & 64) dst[j] = z[rt][1][j]; else atomicAdd(dst + j, z[rt][1][j]);
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    const float s = seg_sum(tm[rt].valid ? z[rt][1][j] : 0.f, sp);
+                    if (sp.last && feat_of(0, j, g) < h) atomicAdd(dst + j, s);
+                }
             }
         }
         }
@@ -401,13 +401,15 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
         for (int rt = 0; rt < PMT_RT; ++rt) {
             if (!(mask_all & (1u << rt))) continue;
             const int set = tm[rt].set;
-            if (tm[rt].valid) {
+            const SegPlan sp = seg_plan(tm[rt].valid ? set : -1);
 #pragma unroll
-                for (int t = 0; t < NTE; ++t)
+            for (int t = 0; t < NTE; ++t)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (t < nte && feat_of(t, j, g) < E) atomicAdd(&sh.fsum[set][side][16 * t + 4 * g + j], a[rt][t][j]);
-            }
+                for (int j = 0; j < 4; ++j)
+                    if (t < nte && 16 * t + 4 * j < E) {  // (any lane group holds a feature of this register)
+                        const float s = seg_sum(tm[rt].valid ? a[rt][t][j] : 0.f, sp);
+                        if (sp.last && feat_of(t, j, g) < E) atomicAdd(&sh.fsum[set][side][16 * t + 4 * g + j], s);
+                    }
             if (side != 1) continue;
             // nonartifact / outlier diagonal Gaussians
             float q0 = 0.f, q1 = 0.f;
@@ -422,9 +424,12 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
                     }
             q0 = group_sum(q0);
             q1 = group_sum(q1);
-            if (tm[rt].valid && g == 0) {
-                atomicAdd(&sh.hsum[set][0], c0 - 0.5f * q0);
-                atomicAdd(&sh.hsum[set][1], c1 - 0.5f * q1);
+            {
+                const float s0 = seg_sum(tm[rt].valid ? c0 - 0.5f * q0 : 0.f, sp), s1 = seg_sum(tm[rt].valid ? c1 - 0.5f * q1 : 0.f, sp);
+                if (sp.last && g == 0) {
+                    atomicAdd(&sh.hsum[set][0], s0);
+                    atomicAdd(&sh.hsum[set][1], s1);
+                }
             }
             // artifact clusters: projection on the unit direction, orthogonal distance, EMG along the direction.  The cheap
             // part (p, o2: a few FMAs and two cross-group sums) runs for every cluster in all lanes; the expensive scalar part
@@ -464,6 +469,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
               {
                 const int k = k0 + g;
                 const float p = p_sel, o2 = o2_sel;
+                float lk = 0.f;
                 if (tm[rt].valid && k < K) {
                     const float tau = hp[uniform(M->head.art_stdev_k_phi) + k];
                     const float mu = theta[uniform(M->head.mu_k_src) + k];
@@ -474,8 +480,10 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
                     const float var = sg * sg;
                     const float zz = (mu + lam * var - p) / (1.4142135623730951f * sg);
                     const float par = logf(lam * 0.5f) + logerfc_dev(zz) + (lam * 0.5f) * (2.f * mu + lam * var - 2.f * p);
-                    atomicAdd(&sh.hsum[set][2 + k], orth + par);
+                    lk = orth + par;
                 }
+                const float s = seg_sum(lk, sp);  // (every lane of the row takes part in the scan)
+                if (sp.last && k < K) atomicAdd(&sh.hsum[set][2 + k], s);
               }
             }
         }
