@@ -509,6 +509,7 @@ DEV void backward_group(
                 u[rt][0] = z[rt][0] * gt;
                 const int set = tm[rt].set;
                 const bool ok = tm[rt].valid;
+                const SegPlan sp = seg_plan(ok ? set : -1);  // per-set sums of d(gate): segmented reduce over the tile's reads
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float dg = (ok && feat_of(0, j, g) < h) ? du[rt][0][j] * z[rt][0][j] : 0.f;
@@ -516,7 +517,8 @@ DEV void backward_group(
                     d_alpha += dg * z2v[j];
                     d_beta += dg * (side == 0 ? m_ref[j] : m_alt[j]);
                     if (side == 1) d_gamma += dg * m_ref[j];
-                    if (ok && feat_of(0, j, g) < h) atomicAdd(&sh.gsum[set][side][4 * g + j], dg);
+                    const float sg = seg_sum(dg, sp);
+                    if (sp.last && feat_of(0, j, g) < h) atomicAdd(&sh.gsum[set][side][4 * g + j], sg);
                 }
             }
             prof_add(c, 9, t_ph);
@@ -675,13 +677,16 @@ DEV void backward_group(
 #pragma unroll
     for (int rt = 0; rt < PMT_RT; ++rt) {
         const int set = tm[rt].set;
+        const SegPlan sp = seg_plan(tm[rt].valid ? set : -1);
 #pragma unroll
         for (int t = 0; t < NTD; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                if (16 * t + 4 * j + 3 < Er) continue;  // (no lane group holds a variant-embedding feature in this register)
                 const int f = feat_of(t, j, g);
+                const float s = seg_sum((tm[rt].valid && f >= Er && f < D) ? dy[rt][t][j] : 0.f, sp);
                 if (f >= Er) {
-                    if (tm[rt].valid && f < D) atomicAdd(&sh.dv()[set][f - Er], dy[rt][t][j]);
+                    if (sp.last && f < D) atomicAdd(&sh.dv()[set][f - Er], s);
                     dy[rt][t][j] = 0.f;
                 }
             }
