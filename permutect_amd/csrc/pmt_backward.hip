@@ -22,6 +22,9 @@
 #define PMT_STAGE_PLANES (16 * PMT_GROUP_WAVES)  // every wave's operands of a 4 + 4 tile linear at once (8 waves x 8 planes x (hi + mid))
 #include "permutect_amd.h"
 #define PMT_OPAQUE_TID 1  // the kernel loops over groups (persistent launch): see pmt_tid
+#ifndef PMT_BWD_XH4_AT_P3
+#define PMT_BWD_XH4_AT_P3 0  // (measured: 2.94 -> 3.04 ms: the in-order memory counter makes the phase's small loads wait for it)
+#endif
 #ifndef PMT_BWD_FRAG_AHEAD
 #define PMT_BWD_FRAG_AHEAD 3
 #endif
@@ -601,6 +604,7 @@ DEV void backward_group(
         trace_ev(c, 21);
         t_ph = prof_now();
         // ---- phase 3: finish d(z2), LayerNorm(h) backward, SELU backward -> d(zpre) ---------------------------------------
+        if (PMT_BWD_XH4_AT_P3) load_xh4();  // phase 4's stash read, requested here: phase 3 is ~3.6 k cycles of arithmetic to hide it under
         f4 dz[PMT_RT][2];
         {
             f4 dsw[1] = {f4{0.f, 0.f, 0.f, 0.f}}, dsb[1] = {f4{0.f, 0.f, 0.f, 0.f}};
@@ -635,7 +639,7 @@ DEV void backward_group(
         // ---- phase 4: proj1 weight gradient (needs n again), d(n) = W1^T d(zpre), LayerNorm(D) backward ---------------------
         {
             f4 n[PMT_RT][NTD];
-            load_xh4();
+            if (!PMT_BWD_XH4_AT_P3) load_xh4();
             affine_n(n, xh4);
             if constexpr (S::BF16 != 0) wgrad_exchange_bf<2, NTD, 2, BFB>(c, M->lin[uniform(B.proj1[0])], M->lin[uniform(B.proj1[1])], dz, n, 1.0f);
             else wgrad_exchange<2, NTD, 2>(c, M->lin[uniform(B.proj1[0])], M->lin[uniform(B.proj1[1])], dz, n, 1.0f);
