@@ -604,7 +604,7 @@ DEV void backward_group(
         trace_ev(c, 21);
         t_ph = prof_now();
         // ---- phase 3: finish d(z2), LayerNorm(h) backward, SELU backward -> d(zpre) ---------------------------------------
-        if (PMT_BWD_XH4_AT_P3) load_xh4();  // phase 4's stash read, requested here: phase 3 is ~3.6 k cycles of arithmetic to hide it under
+        if (PMT_BWD_XH4_AT_P3 == 1) load_xh4();  // phase 4's stash read, requested here: phase 3 is ~3.6 k cycles of arithmetic to hide it under
         f4 dz[PMT_RT][2];
         {
             f4 dsw[1] = {f4{0.f, 0.f, 0.f, 0.f}}, dsb[1] = {f4{0.f, 0.f, 0.f, 0.f}};
@@ -623,6 +623,11 @@ DEV void backward_group(
                 dz[rt][0] = selu_bwd4(dz1, z[rt][0]);
                 dz[rt][1] = selu_bwd4(dxr[0], z[rt][1]);
             }
+            if (PMT_BWD_XH4_AT_P3 == 2) {  // behind the phase's last global load, ahead of its cross-lane sums (LDS only)
+                __builtin_amdgcn_sched_barrier(0);
+                load_xh4();
+                __builtin_amdgcn_sched_barrier(0);
+            }
             aux_push_vec_x<1, EX>(c, uniform(B.sgu_norm_w_src), dsw, h);
             aux_push_vec_x<1, EX>(c, uniform(B.sgu_norm_b_src), dsb, h);
             if constexpr (!LAYERED) {  // (layered: pushed at the end of the launch that computed them)
@@ -639,7 +644,7 @@ DEV void backward_group(
         // ---- phase 4: proj1 weight gradient (needs n again), d(n) = W1^T d(zpre), LayerNorm(D) backward ---------------------
         {
             f4 n[PMT_RT][NTD];
-            if (!PMT_BWD_XH4_AT_P3) load_xh4();
+            if (PMT_BWD_XH4_AT_P3 == 0) load_xh4();
             affine_n(n, xh4);
             if constexpr (S::BF16 != 0) wgrad_exchange_bf<2, NTD, 2, BFB>(c, M->lin[uniform(B.proj1[0])], M->lin[uniform(B.proj1[1])], dz, n, 1.0f);
             else wgrad_exchange<2, NTD, 2>(c, M->lin[uniform(B.proj1[0])], M->lin[uniform(B.proj1[1])], dz, n, 1.0f);
