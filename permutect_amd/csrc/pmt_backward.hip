@@ -119,7 +119,7 @@ DEV void backward_group(
         sh.off[1][i] = bt.alt_offsets[gg.v0 + i] - gg.alt_base;
     }
     for (int i = tid; i < PMT_GROUP_MAX_SETS * 32; i += PMT_THREADS) (&sh.gsum[0][0][0])[i] = 0.f;
-    __syncthreads();
+    lds_barrier();
     // per-set upstream gradients (reference feature_clustering.py:121-135 differentiated)
     for (int i = tid; i < gg.nsets; i += PMT_THREADS) {
         const int b = gg.v0 + i;
@@ -144,7 +144,7 @@ DEV void backward_group(
         const float n = (float)(sh.off[s][set + 1] - sh.off[s][set]);
         sh.dfeat()[set][s][p] = (src && f < E) ? src[(size_t)(gg.v0 + set) * E + f] / (n + 1e-4f) : 0.f;
     }
-    __syncthreads();
+    lds_barrier();
 
     TileMeta tm[PMT_RT];
     unsigned mask_all = 0;
@@ -566,7 +566,7 @@ DEV void backward_group(
             }
             for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS)
                 (&sh.gsum[0][0][0])[i] = lay.gsum_g[((size_t)(gg.v0 + (i >> 5)) * L + l) * 32 + (i & 31)];
-            __syncthreads();
+            lds_barrier();
         }
         prof_add(c, 10, t_ph);
         trace_ev(c, 20);
@@ -598,7 +598,7 @@ DEV void backward_group(
             aux_push_row16(c, uniform(B.ref_reg_src), group_sum(a_rho), h);
             aux_push_scalar(c, enc_phi(uniform(B.reg_weight_phi)), a_w);
         }
-        __syncthreads();
+        lds_barrier();
         for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS) (&sh.gsum[0][0][0])[i] = 0.f;
         prof_add(c, 11, t_ph);
         trace_ev(c, 21);
@@ -680,9 +680,9 @@ DEV void backward_group(
     t_ph = prof_now();
 
     // ---- split d(x_0): variant-embedding part -> per-set sums; read-embedding part -> read MLP backward --------------
-    __syncthreads();  // the last exchange has been consumed by every wave: the end of the stage becomes dv
+    lds_barrier();  // the last exchange has been consumed by every wave: the end of the stage becomes dv
     for (int i = tid; i < PMT_GROUP_MAX_SETS * PMT_MAX_WIDTH; i += PMT_THREADS) (&sh.dv()[0][0])[i] = 0.f;
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int rt = 0; rt < PMT_RT; ++rt) {
         const int set = tm[rt].set;
@@ -700,7 +700,7 @@ DEV void backward_group(
                 }
             }
     }
-    __syncthreads();
+    lds_barrier();
     for (int i = tid; i < gg.nsets * Ev; i += PMT_THREADS) {  // (written out now: the read MLP's exchanges reuse the LDS)
         const int set = i / Ev, f = i - set * Ev;
         if (LAYERED) atomicAdd(&gvar[(size_t)(gg.v0 + set) * Ev + f], sh.dv()[set][f]);  // several groups per read set
@@ -774,7 +774,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
 #endif
         backward_group<S, LAYERED>(M, theta, phi, packed, bt, out, dout, stash, zsum_stash, rstd_stash, gtheta, gphi, gvar, lay, grp, sh, priv);
-        __syncthreads();  // the next group reuses the LDS
+        lds_barrier();  // the next group reuses the LDS
     }
 }
 

@@ -19,11 +19,6 @@ DEV float read_lanes_sum(float v) {  // sum over the 16 reads of a tile (lanes w
 }
 DEV float wave_sum(float v) { return group_sum(read_lanes_sum(v)); }
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence + barrier and drains this
-// wave's GLOBAL memory queue too (s_waitcnt vmcnt(0)): every gradient atomic and every load in flight would have to come
-// home before each of the ~70 exchange barriers of a workgroup.  The exchanges hand over LDS data only.
-DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 // Touch one 4 KiB stash slot of a tile (64 lanes x one dword, 64 bytes apart) so that the lines are in L2 when the real load
 // comes an op later.  The dwords land in a 256-byte LDS sink by LDS-DMA: no VGPR is written, nothing has to be waited for.
 DEV void stash_prefetch(const float* __restrict__ slot, float* __restrict__ sink) {
@@ -238,9 +233,9 @@ DEV void aux_reduce(BwdCtx& c) {
     c.aux_n = 0;
 }
 DEV void aux_flush(BwdCtx& c) {
-    __syncthreads();
+    lds_barrier();
     aux_reduce(c);
-    __syncthreads();
+    lds_barrier();
 }
 // per-feature parameter gradient (tile-position registers, summed here over this wave's reads)
 template <int NT>

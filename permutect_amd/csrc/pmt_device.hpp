@@ -85,6 +85,11 @@ template <int CTRL>
 DEV float dpp_mov(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
 }
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence + barrier and drains this
+// wave's GLOBAL memory queue too (s_waitcnt vmcnt(0)): every stash store, gradient atomic and load in flight would have to
+// come home before each of a workgroup's barriers.  The kernels' barriers hand over LDS data only.
+DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---- wavefront segmented reduce over the reads of a tile (reference sets/ragged_sets.py:144-158: sums over sets) -----------
 // The 16 reads of a tile sit in the 16 lanes of a DPP row, the reads of one set in CONTIGUOUS lanes.  A Hillis-Steele scan with
 // row shifts 1, 2, 4, 8 that only adds across equal set ids leaves every set's total in the LAST lane of its run; that lane

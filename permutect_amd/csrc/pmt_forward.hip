@@ -106,7 +106,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
         for (int i = tid; i < gg.nsets * (2 * PMT_MAX_WIDTH / 4); i += PMT_THREADS) reinterpret_cast<f4*>(&sh.fsum[0][0][0])[i] = zero;
         for (int i = tid; i < gg.nsets * (PMT_MAX_CLUSTERS + 2); i += PMT_THREADS) (&sh.hsum[0][0])[i] = 0.f;
     }
-    __syncthreads();
+    lds_barrier();
     tr.ev(2);
 
     TileMeta tm[PMT_RT];
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
         }
         if constexpr (LAYERED) {
             if (first_half) {  // end of this launch: the group's partial sums join the global ones; park x and z
-                __syncthreads();
+                lds_barrier();
                 for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS) {
                     const float v = (&sh.zsum[buf][0][0][0])[i];
                     if (v != 0.f) atomicAdd(&lay.zsum_g[((size_t)(gg.v0 + (i >> 5)) * L + l) * 32 + (i & 31)], v);
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
                 (&sh.zsum[buf][0][0][0])[i] = lay.zsum_g[((size_t)(gg.v0 + (i >> 5)) * L + l) * 32 + (i & 31)];
         }
         tr.ev(10);
-        __syncthreads();
+        lds_barrier();
         tr.ev(11);
         if (TRAIN && !LAYERED) {
             for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS)
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
         }
     }
     tr.ev(22);
-    __syncthreads();
+    lds_barrier();
     if constexpr (LAYERED) {  // the group's partial head sums join the global ones; pmt_finalize_kernel writes the outputs
         for (int i = tid; i < gg.nsets * (K + 2); i += PMT_THREADS) {
             const int set = i / (K + 2), k = i - set * (K + 2);
