@@ -183,6 +183,7 @@ DEV void backward_group(
     }
     const int n_read_ops = uniform(M->read_mlp.n_ops), n_red_ops = uniform(M->reducer.n_ops);
     const int slot_x0 = n_read_ops - 1, slot_red = slot_x0 + L + 1;
+    const int slot_z0 = slot_red + (n_red_ops - 1);  // the blocks' z (stash_num_slots)
     const int slot_last_in = n_red_ops > 1 ? slot_red + (n_red_ops - 2) : slot_x0 + L;  // input of the last reducer op
     const PmtOp& red_last = M->reducer.ops[n_red_ops - 1];
 
@@ -455,17 +456,32 @@ DEV void backward_group(
                 rs4[rt] = (mask_all & (1u << rt)) ? rstd_stash[((size_t)(bt.group_tile_base[grp] + gg.tile_begin + rt) * L + l) * 16 + (lane & 15)] : 0.f;
         };
         t_ph = prof_now();
-        // ---- phase 1: z = selu(W1 n + b1) ---------------------------------------------------------------------------
+        // ---- phase 1: z = selu(W1 n + b1).  The exact-width instances take it from the stash, where the forward left both halves
+        // after their SELU (2 KiB per tile): recomputing it from xhat_l -- a stash read twice the size, a LayerNorm affine and the
+        // 60 -> 2 x 10 projection with its splits -- was 6 % of the kernel.  The generic instance still recomputes.
         f4 z[PMT_RT][2];
         if (first_half) {
-            f4 n[PMT_RT][NTD], xq[PMT_RT][NTD];
-            load_xhat(xq, l);
-            affine_n(n, xq);
-            const f4 b0 = load_pvec(packed + uniform(P1.b_pvec), 0, g), b1 = load_pvec(packed + uniform(P1.b_pvec), 1, g);
+            if constexpr (EX && PMT_STASH_Z) {
 #pragma unroll
-            for (int rt = 0; rt < PMT_RT; ++rt) { z[rt][0] = b0; z[rt][1] = b1; }
-            if constexpr (S::BF16) linear_acc_bf16<NTD, 2, false, BFB>(z, n, packed + uniform(P1.wb_frag));
-            else linear_acc<NTD, 2, false, EX, S::DIM_D>(z, n, packed + uniform(P1.w_frag), D, 16 + h);
+                for (int rt = 0; rt < PMT_RT; ++rt) {
+                    z[rt][0] = z[rt][1] = f4{0.f, 0.f, 0.f, 0.f};
+                    if (mask_all & (1u << rt)) stash_load<2>(stash_tile[rt] + (size_t)(slot_z0 + l) * PMT_SLOT_FLOATS, z[rt]);
+                }
+            } else {
+                f4 n[PMT_RT][NTD], xq[PMT_RT][NTD];
+                load_xhat(xq, l);
+                affine_n(n, xq);
+                const f4 b0 = load_pvec(packed + uniform(P1.b_pvec), 0, g), b1 = load_pvec(packed + uniform(P1.b_pvec), 1, g);
+#pragma unroll
+                for (int rt = 0; rt < PMT_RT; ++rt) { z[rt][0] = b0; z[rt][1] = b1; }
+                if constexpr (S::BF16) linear_acc_bf16<NTD, 2, false, BFB>(z, n, packed + uniform(P1.wb_frag));
+                else linear_acc<NTD, 2, false, EX, S::DIM_D>(z, n, packed + uniform(P1.w_frag), D, 16 + h);
+#pragma unroll
+                for (int rt = 0; rt < PMT_RT; ++rt) {
+                    z[rt][0] = selu4(z[rt][0]);
+                    z[rt][1] = selu4(z[rt][1]);
+                }
+            }
         }
         const f4 sw = load_pvec(packed + uniform(B.sgu_norm_w_pvec), 0, g), sb = load_pvec(packed + uniform(B.sgu_norm_b_pvec), 0, g);
         const float w = uniform(phi[uniform(B.reg_weight_phi)]) + 0.25f;
@@ -502,8 +518,6 @@ DEV void backward_group(
             f4 u[PMT_RT][1];
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) {
-                z[rt][0] = selu4(z[rt][0]);
-                z[rt][1] = selu4(z[rt][1]);
                 f4 zin[1] = {z[rt][1]}, zo[1], zh[1], sw1[1] = {sw}, sb1[1] = {sb};
                 layernorm_tile<1>(zo, zh, rstd2[rt], zin, h, sw1, sb1, g);
                 z2hat[rt] = zh[0];

@@ -796,7 +796,8 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
             f4 s1[PMT_RT][NT];
             if (nl == 2) {  // s1 = selu(L1 selu(x) + b1)
                 init_bias<NT>(s1, c.packed + uniform(L1.b_pvec), width, c.g);
-                if constexpr (BF) linear_acc_bf16<NT, NT, true, BF>(s1, x, c.packed + uniform(L1.wb_frag));
+                if (c.dbg & 4096) {}  // knock-out (wrong results): the most that stashing s1 could save
+                else if constexpr (BF) linear_acc_bf16<NT, NT, true, BF>(s1, x, c.packed + uniform(L1.wb_frag));
                 else linear_acc<NT, NT, true, EXACT, W>(s1, x, c.packed + uniform(L1.w_frag), width, width);
             }
 #pragma unroll

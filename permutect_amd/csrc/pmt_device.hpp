@@ -441,7 +441,12 @@ DEV float* grad_ptr(int src, float* gtheta, float* gphi) { return src >= 0 ? gth
 
 // ---- stash layout (floats per 16-read tile) ---------------------------------------------------------------------
 // slots: [read-MLP op boundaries 1..n-1][x_0 .. x_L][reducer op boundaries 1..n-1], each slot NT*256 floats
-DEV int stash_num_slots(const PmtModel* M) { return (M->read_mlp.n_ops - 1) + (M->num_blocks + 1) + (M->reducer.n_ops - 1); }
+#ifndef PMT_STASH_Z
+#define PMT_STASH_Z 1  // the blocks' z in the stash (0: the backward recomputes it)
+#endif
+// stash slots per tile: the inputs of the read MLP's ops 1.., xhat_0 .. xhat_{L-1} and x_L, the inputs of the reducer's ops 1..,
+// then every block's z (after SELU; half a slot used)
+DEV int stash_num_slots(const PmtModel* M) { return (M->read_mlp.n_ops - 1) + (M->num_blocks + 1) + (M->reducer.n_ops - 1) + M->num_blocks; }
 #define PMT_SLOT_FLOATS (PMT_NT * 256)
 
 template <int NT>

@@ -123,6 +123,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
 
     int slot = 0;
     const int n_read_ops = uniform(M->read_mlp.n_ops), n_red_ops = uniform(M->reducer.n_ops);
+    const int slot_z0 = (n_read_ops - 1) + (L + 1) + (n_red_ops - 1);  // the blocks' z (stash_num_slots)
 
     // ---- decode the packed read rows straight into the B-operand layout, then the read MLP -------------------------
     f4 x[PMT_RT][NTD];
@@ -240,6 +241,10 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
         for (int rt = 0; rt < PMT_RT; ++rt) {
             z[rt][0] = selu4(z[rt][0]);
             f4 zin[1] = {selu4(z[rt][1])}, zo[1], zh[1];
+            if (TRAIN && EX && PMT_STASH_Z && (mask_all & (1u << rt))) {  // the (exact-width) backward starts the block from these instead of recomputing them
+                const f4 zs[2] = {z[rt][0], zin[0]};
+                stash_store<2>(stash_tile[rt] + (size_t)(slot_z0 + l) * PMT_SLOT_FLOATS, zs);
+            }
             float rstd;
             layernorm_tile<1>(zo, zh, rstd, zin, h, sw, sb, g);
             z[rt][1] = zo[0];

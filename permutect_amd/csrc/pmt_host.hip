@@ -31,7 +31,7 @@ extern "C" int pmt_struct_bytes(int which) {
     }
 }
 
-extern "C" int pmt_stash_slots(const PmtModel* m) { return (m->read_mlp.n_ops - 1) + (m->num_blocks + 1) + (m->reducer.n_ops - 1); }
+extern "C" int pmt_stash_slots(const PmtModel* m) { return (m->read_mlp.n_ops - 1) + (m->num_blocks + 1) + (m->reducer.n_ops - 1) + m->num_blocks; }
 
 // Which register-array shape the read-set kernels run with (pmt_device.hpp: Shape).  1 = ShapeP0, every layer fills
 // its tile arrays exactly: F and the first read linear 4 -> 2 tiles, the rest of the read MLP 2 tiles wide, d_model

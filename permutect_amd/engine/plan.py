@@ -203,7 +203,7 @@ class EnginePlan:
         raw = bytes(d)
         self.desc_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
         self.debug_flags = torch.zeros(64 + 8 * 512, dtype=torch.int32, device=device)  # [0] unused, [1] debug switches, [2] traced workgroup + 1, [8:56] 24 x u64 cycle counters, [64:] event log of the traced workgroup (8 waves x 256 x (id, clock))
-        self.stash_slots = (d.read_mlp.n_ops - 1) + (d.num_blocks + 1) + (d.reducer.n_ops - 1)
+        self.stash_slots = (d.read_mlp.n_ops - 1) + (d.num_blocks + 1) + (d.reducer.n_ops - 1) + d.num_blocks  # = pmt_stash_slots
 
     # ---- allocation helpers --------------------------------------------------------------------------------------
     def _alloc_packed(self, n: int) -> int:
