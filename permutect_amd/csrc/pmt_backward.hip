@@ -17,7 +17,8 @@
 #define PMT_WAVES PMT_GROUP_WAVES
 #define PMT_RT 2
 #ifndef PMT_BWD_PIECES
-#define PMT_BWD_PIECES 3  // (2 was measured: 3.50 -> 3.45 ms, one tensor's error 9e-5 -> 2.4e-4 of its scale: not worth it)
+#define PMT_BWD_PIECES 3  // (2 was measured again on the final build: 2.83 -> 2.71 ms, gradient rel. L2 unchanged at 2.2e-5, one tensor's worst
+                          //  element 9e-5 -> 2.4e-4 of its scale; the parity headline keeps the fp32-equivalent three)
 #endif
 #define PMT_STAGE_PLANES (16 * PMT_GROUP_WAVES)  // every wave's operands of a 4 + 4 tile linear at once (8 waves x 8 planes x (hi + mid))
 #include "permutect_amd.h"
