@@ -129,7 +129,8 @@ class ReadSetEngine:
         dout = L.PmtOutputGrads(_ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]))
         out = L.PmtOutputs(*[t.data_ptr() for t in outs])
         gphi = torch.zeros(d.phi_size, dtype=torch.float32, device=self.device)
-        gvar = torch.zeros_like(variant_embed)
+        # (the one-launch backward writes every row of d(variant embedding); the layered one adds into it from several groups)
+        gvar = torch.zeros_like(variant_embed) if plan.layered else torch.empty_like(variant_embed)
         ev = self._event_start()
         if plan.layered:
             n = self.lib.pmt_layered_backward_scratch_floats(C.byref(d), plan.total_tiles, batch.size())
