@@ -71,7 +71,7 @@ def kernels_sha():
     """Hash of everything the device code is built from: a PMC measurement describes ONE build of the kernels."""
     h = hashlib.sha256()
     files = sorted(glob.glob(os.path.join(ROOT, "permutect_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "permutect_amd", "csrc", "*.hpp"))
-                   + glob.glob(os.path.join(ROOT, "include", "*.h")))
+                   + glob.glob(os.path.join(ROOT, "include", "*.h")) + [os.path.join(ROOT, "permutect_amd", "csrc", "Makefile")])  # (+ the build flags)
     for f in files:
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:

@@ -407,7 +407,8 @@ size_t pmt_layered_backward_scratch_floats(const PmtModel* model, int64_t total_
  * gradient can pass its first projection, so launch s finishes block L - s from the complete sums (accumulated in HBM by
  * launch s - 1) and starts block L - s - 1; the running gradient and the half-finished block's per-read state rest in
  * `scratch` between launches.  Per-set parameter terms are added by the group that holds the set's first alt read.
- * grad_variant_embed must be zeroed by the caller (several groups add to a row). */
+ * grad_variant_embed must be zeroed by the caller (several groups add to a row).  grad_partials / num_partials: as in
+ * pmt_backward (the rows are folded once, after the last launch). */
 int pmt_backward_layered(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* phi,
                          const float* packed, const PmtBatch* batch, const PmtOutputs* out, const PmtOutputGrads* dout,
                          const float* stash, float* scratch, float* grad_theta, float* grad_phi, float* grad_variant_embed,
