@@ -16,7 +16,8 @@ ONE JSON line on rank 0 carries, besides the contract's keys:
   roofline      dominant kernel (pmt_backward_kernel), HIP-event timed inside the timed region; `traffic` only from a
                 profiles/*.json whose recorded hash of the kernel sources equals this tree's
   filter        the filter-forward half of the metric: value, ms_per_step, its own roofline (pmt_forward_kernel)
-  small_batch   the reference's default batch sizes (training 64, inference 8192: parameters.py:214,236-242), N = 1 only
+  small_batch   the reference's default batch sizes (training 64, inference 8192: parameters.py:214,236-242) and twice the
+                headline's batch (131072), N = 1 only
   parity_check_max_logit_err   first 2048 variants of resident batch 0 against the CPU oracle, after the timed regions
   cpu_baseline  the CPU oracle (PyTorch-CPU restatement of the reference path) on this box's host cores, thread count
                 swept and the best reported, B = 8192 and B = 64, train and filter; N = 1 only
@@ -416,15 +417,20 @@ def main():
     small = None
     if world == 1 and not args.no_extras and args.data == "resident" and args.depth == "wgs":
         small = {}
-        for bsz, k in ((64, 200), (8192, 40)):
+        for bsz, k in ((64, 200), (8192, 40), (131072, 10)):  # (the last: twice the headline's batch)
             pool = []
             srng = np.random.default_rng(77 + bsz)
-            for _ in range(4):
+            for _ in range(4 if bsz <= 8192 else 2):
                 b = Batch.from_arrays(*synth_arrays(srng, bsz, "wgs"), pack=True)
                 b.plan(allow_split=True)
                 pool.append(b.copy_to(dev))
             et, _ = timed("train", pool, k, 10)
             ef, _ = timed("filter", pool, k, 10)
+            if bsz > 8192:
+                note(f"B={bsz}: train {1e3 * et / k:.3f} ms/step, filter {1e3 * ef / k:.3f} ms/step")
+                small[f"b{bsz}"] = {"train_read_sets_per_s": bsz * k / et, "train_ms_per_step": 1e3 * et / k,
+                                    "filter_read_sets_per_s": bsz * k / ef, "filter_ms_per_step": 1e3 * ef / k}
+                continue
             # the same train step as ONE captured HIP graph (engine/graph.py); every replay is preceded by the upload of a new
             # batch into the graph's static buffers, as a training loop would do it
             from permutect_amd.engine.graph import GraphedTrainStep, StaticBatch
