@@ -244,8 +244,8 @@ def spawn_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)  # ~1 s of train steps, ~0.2 s of filter forwards
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--mode", choices=["both", "train", "filter"], default="both",
                     help="both: the headline is the train step and the filter forward is timed in the same run (\"filter\" key); "
                          "train / filter: only that half (filter: the headline keys describe the filter forward)")
