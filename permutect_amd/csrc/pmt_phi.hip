@@ -46,9 +46,20 @@ __device__ double block_sum(double v, double* red) {
 __device__ void matmul(double* __restrict__ Cm, const double* __restrict__ A, const double* __restrict__ B, int N, double scale) {
     for (int idx = threadIdx.x; idx < N * N; idx += PHI_THREADS) {
         const int i = idx / N, j = idx - i * N;
-        double acc = 0.0;
-        for (int k = 0; k < N; ++k) acc += A[i * N + k] * B[k * N + j];
-        Cm[idx] = acc * scale;
+        // four independent partial sums: the LDS round trip of a load (~100 cycles) is the cost of a step, and one dependent chain
+        // of N = 20 of them was most of this single-workgroup kernel's 70 us
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        const double* ar = A + i * N;
+        const double* bc = B + j;
+        int k = 0;
+        for (; k + 3 < N; k += 4) {
+            a0 += ar[k] * bc[k * N];
+            a1 += ar[k + 1] * bc[(k + 1) * N];
+            a2 += ar[k + 2] * bc[(k + 2) * N];
+            a3 += ar[k + 3] * bc[(k + 3) * N];
+        }
+        for (; k < N; ++k) a0 += ar[k] * bc[k * N];
+        Cm[idx] = ((a0 + a1) + (a2 + a3)) * scale;
     }
     __syncthreads();
 }
