@@ -181,12 +181,13 @@ class ArtifactModel(nn.Module):
     def compute_batch_output(self, batch: Batch, balancer=None) -> BatchOutput:
         (logits_b, logits_bk, feats, ref_feats), _ = self._encode(batch)
         if balancer is None:
-            weights_b, source_weights_b = torch.ones_like(logits_b), torch.ones_like(logits_b)
+            weights_b = source_weights = torch.ones_like(logits_b)  # (1 * 1: one fill instead of two and a product)
         else:
             weights_b, source_weights_b = balancer.process_batch_and_compute_weights(
                 batch, artifact_probs_b=torch.sigmoid(logits_b).detach())
+            source_weights = weights_b * source_weights_b
         return BatchOutput(features_be=feats, ref_features_be=ref_feats, logits_b=logits_b, logits_bk=logits_bk,
-                           weights=weights_b, source_weights=weights_b * source_weights_b)
+                           weights=weights_b, source_weights=source_weights)
 
     # ---- losses (reference artifact_model.py:267-325) --------------------------------------------------------------------
     def compute_source_prediction_losses(self, features_be: Tensor, batch: Batch) -> Tensor:

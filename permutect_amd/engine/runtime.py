@@ -186,6 +186,7 @@ class LossesFunction(torch.autograd.Function):
         L.check(engine.lib.pmt_losses_forward(C.byref(a), C.byref(o), _stream()), "pmt_losses_forward")
         ctx.engine = engine
         ctx.alt_shape = alt_shape
+        ctx.set_materialize_grads(False)  # loss vectors nobody differentiates arrive as None (a null pointer), not as zero fills
         ctx.save_for_backward(logits_b, logits_bk, alt_raw, labels, alt_counts, weights, source_weights,
                               *(() if source_logits is None else (source_logits, sources)))
         return tuple(outs)
@@ -239,6 +240,7 @@ class ReadSetFunction(torch.autograd.Function):
         train = bool(ctx.needs_input_grad[2] or ctx.needs_input_grad[3])  # False under no_grad / inference_mode
         outs, stash, ve, ph = engine.forward(batch, phi.detach(), variant_embed.detach(), train)
         ctx.engine, ctx.batch, ctx.train = engine, batch, train
+        ctx.set_materialize_grads(False)  # outputs the loss does not use (ref_features_be) arrive as None = a null pointer
         if train:
             ctx.save_for_backward(ph, ve, stash, *outs)
         return outs
@@ -289,7 +291,7 @@ class HaplotypeCnnFunction(torch.autograd.Function):
                                          eng.plan.packed.data_ptr(), hap.data_ptr(), hap.stride(0), hap.shape[0], d_out.data_ptr(), d_out.stride(0),
                                          _ptr(ctx.stash), eng.space.gtheta.data_ptr(), _stream()), "pmt_cnn_backward")
         ctx.stash = None
-        return None, None, torch.zeros(1, device=eng.device)
+        return None, None, None  # (the trigger only makes autograd call this node; it needs no gradient of its own)
 
 
 class RowsMlpFunction(torch.autograd.Function):
@@ -339,4 +341,4 @@ class RowsMlpFunction(torch.autograd.Function):
                                           eng.plan.packed.data_ptr(), x.data_ptr(), x.stride(0), n, d_out.data_ptr(),
                                           d_out.stride(0), stash.data_ptr(), eng.space.gtheta.data_ptr(), _ptr(d_in),
                                           d_in.stride(0) if d_in is not None else 0, scale, _stream()), "pmt_rows_backward")
-        return None, None, d_in, torch.zeros(1, device=eng.device), None
+        return None, None, d_in, None, None
