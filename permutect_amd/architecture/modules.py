@@ -81,10 +81,14 @@ class MLP(nn.Module):
     def __init__(self, layer_sizes: List[int], batch_normalize: bool = False, dropout_p: float = 0,
                  prepend_activation: bool = False):
         super().__init__()
-        if batch_normalize or dropout_p > 0:
-            # BatchNorm1d / Dropout are off by default in the reference CLI (parameters.py:139-156) and are not
-            # part of the MI355X read-set kernels.
-            raise NotImplementedError("permutect_amd supports batch_normalize=False and dropout_p=0 only")
+        if batch_normalize:
+            # BatchNorm1d is off by default in the reference CLI (parameters.py:139-156) and is not part of the MI355X
+            # kernels (its training statistics span the whole batch in the middle of the fused read-set pass).
+            raise NotImplementedError("permutect_amd supports batch_normalize=False only")
+        # dropout_p > 0 (reference mlp.py:57-58; default 0): the nn.Dropout modules are kept in the Sequential so that the
+        # state_dict keys of a reference checkpoint line up; the kernels run them as the identity, which is what they are
+        # in eval mode (filter_variants).  TRAINING with dropout is refused loudly (ArtifactModel._encode).
+        self.dropout_p = float(dropout_p)
         layers: List[nn.Module] = [nn.SELU()] if prepend_activation else []
         self._input_dim = layer_sizes[0]
         width = layer_sizes[0]
@@ -94,6 +98,8 @@ class MLP(nn.Module):
                 layers.append(DenseSkipBlock(width, -out, batch_normalize, dropout_p))
                 continue
             layers.append(nn.Linear(width, out))
+            if dropout_p > 0:
+                layers.append(nn.Dropout(p=dropout_p))
             if k < last:
                 layers.append(nn.SELU())
             width = out

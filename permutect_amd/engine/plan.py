@@ -271,7 +271,8 @@ class EnginePlan:
                                     layer.bias is not None, out_split, max_in=max_in)
 
     def _lower_mlp(self, dst: L.PmtMlp, mlp: M.MLP, max_in: int = L.MAX_WIDTH):
-        children = list(mlp._model.children())
+        # (nn.Dropout: identity in eval mode, the only mode the engine runs a model with dropout_p > 0 in)
+        children = [c for c in mlp._model.children() if not isinstance(c, nn.Dropout)]
         ops = []
         i = 0
         while i < len(children):
@@ -281,7 +282,7 @@ class EnginePlan:
                 ops.append(("lin", c, selu_after))
                 i += 2 if selu_after else 1
             elif isinstance(c, M.DenseSkipBlock):
-                inner = list(c.mlp._model.children())  # (SELU, Linear) * n
+                inner = [m for m in c.mlp._model.children() if not isinstance(m, nn.Dropout)]  # (SELU, Linear) * n
                 lins = [m for m in inner if isinstance(m, nn.Linear)]
                 assert len(inner) == 2 * len(lins) and all(isinstance(m, nn.SELU) for m in inner[0::2])
                 ops.append(("skip", c, lins))

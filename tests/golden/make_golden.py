@@ -338,8 +338,38 @@ def make_posterior_rows_fixture():
     print("posterior rows fixture written")
 
 
+def make_dropout_eval_fixture():
+    """p0_dropout_eval.npz: a P0-shaped model built with dropout_p = 0.25 (nn.Dropout modules inside every MLP: the
+    state_dict keys shift, reference architecture/mlp.py:57-58) in EVAL mode, as filter_variants runs it: state_dict,
+    inputs and the forward outputs.  Leaves the other fixtures and their random streams untouched."""
+    torch.manual_seed(11)
+    p = ModelParameters([30, -2, -2, -2], 20, 6, [20, -2, -2, -2], [-2, -2, 10], 4, [10, 10], list(P0_CNN), 0.25, 0.3, False)
+    m = ArtifactModel(p, 61, 71, 42, device=CPU)
+    with torch.no_grad():
+        for q in m.parameters():
+            q.add_(0.05 * torch.randn_like(q))
+    m.eval()
+    rng = np.random.default_rng(11)
+    counts = [(int(rng.integers(0, 12)), int(rng.integers(1, 9))) for _ in range(24)]
+    data = make_data(rng, counts)
+    batch = Batch(data)
+    packed = np.vstack([d.get_ref_reads_re() for d in data] + [d.get_alt_reads_re() for d in data])
+    out = {"packed_reads": packed, "int_array": batch.int_tensor.numpy().astype(np.int16),
+           "float_array": batch.float_tensor.numpy().astype(np.float16), "dropout_p": np.float64(0.25)}
+    for k, v in m.state_dict().items():
+        out["sd/" + k] = v.detach().numpy().copy()
+    with torch.inference_mode():
+        output = m.compute_batch_output(batch, None)
+    for k in ("features_be", "ref_features_be", "logits_b", "logits_bk", "artifact_probs_b", "outlier_binary_logits"):
+        out["out/" + k] = getattr(output, k).detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "p0_dropout_eval.npz"), **out)
+    print("dropout eval fixture written;", len(m.state_dict()), "state_dict entries; logits", out["out/logits_b"][:4])
+
+
 if __name__ == "__main__":
-    if "--downsampler-only" in sys.argv:
+    if "--dropout-only" in sys.argv:
+        make_dropout_eval_fixture()
+    elif "--downsampler-only" in sys.argv:
         make_downsampler_fit_fixture()
     elif "--posterior-only" in sys.argv:
         make_posterior_rows_fixture()
@@ -353,3 +383,4 @@ if __name__ == "__main__":
         make_training_helpers_fixture()
         make_downsampler_fit_fixture()
         make_posterior_rows_fixture()
+        make_dropout_eval_fixture()

@@ -75,6 +75,24 @@ def check_outputs(out, z, name, lk_ulps=8):
     np.testing.assert_allclose(out.outlier_binary_logits.cpu().numpy(), ref, rtol=2e-5, atol=1e-4 + 8 * np.spacing(mag.astype(np.float32)).max())
 
 
+def test_eval_forward_of_a_dropout_model_matches_reference():
+    """A reference model built with dropout_p = 0.25, run in eval mode as filter_variants does (tests/golden/p0_dropout_eval.npz):
+    the nn.Dropout modules only shift the state_dict keys; the forward is the dropout-free one."""
+    z, sd, b = load_case("p0_dropout_eval")
+    params = p0_params()
+    params.dropout_p = float(z["dropout_p"])
+    model = ArtifactModel(params, device=torch.device("cuda"), **P0_DIMS)
+    model.load_state_dict(sd)
+    model.eval()
+    batch = Batch.from_arrays(b["int_array"], b["float_array"], b["packed_reads"]).copy_to(torch.device("cuda"))
+    with torch.inference_mode():
+        out = model.compute_batch_output(batch)
+    check_outputs(out, z, "p0_dropout_eval")
+    model.train(True)
+    with pytest.raises(NotImplementedError, match="dropout"):
+        model.compute_batch_output(batch)
+
+
 @pytest.mark.parametrize("name", CASES)
 @pytest.mark.parametrize("fmt", ["packed", "f16", "f32"])
 def test_forward_matches_reference(name, fmt):

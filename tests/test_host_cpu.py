@@ -30,6 +30,25 @@ def test_state_dict_matches_reference_keys_and_shapes(name, params):
     assert sum(p.numel() for p in model.parameters()) == sum(v.numel() for k, v in sd.items() if not k.endswith(".base"))
 
 
+def test_dropout_model_keeps_the_reference_state_dict_layout():
+    """reference architecture/mlp.py:57-58: with dropout_p > 0 an nn.Dropout sits behind every Linear and shifts the Sequential
+    indices in the state_dict keys (p0_dropout_eval.npz: a reference model built with dropout_p = 0.25)."""
+    z, sd, _ = load_case("p0_dropout_eval")
+    params = p0_params()
+    params.dropout_p = float(z["dropout_p"])
+    model = ArtifactModel(params, device=CPU, **P0_DIMS)
+    assert list(model.state_dict().keys()) == list(sd.keys())
+    assert list(sd.keys()) != list(ArtifactModel(p0_params(), device=CPU, **P0_DIMS).state_dict().keys())  # (the indices do shift)
+    model.load_state_dict(sd)  # strict
+    model.train(True)
+    _, _, b = load_case("p0_dropout_eval")
+    with pytest.raises(NotImplementedError, match="dropout"):  # never silently trained without its dropout
+        model.compute_batch_output(Batch.from_arrays(b["int_array"], b["float_array"], b["packed_reads"]))
+    params.batch_normalize = True
+    with pytest.raises(NotImplementedError, match="batch_normalize"):
+        ArtifactModel(params, device=CPU, **P0_DIMS)
+
+
 def test_p0_parameter_count():
     model = ArtifactModel(p0_params(), device=CPU, **P0_DIMS)
     assert sum(p.numel() for p in model.parameters()) == 59845  # SURVEY.md section 6
