@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PMT_ABI_VERSION 4
+#define PMT_ABI_VERSION 5
 
 /* error codes */
 #define PMT_OK 0
@@ -471,13 +471,18 @@ size_t pmt_rows_stash_bytes(const PmtModel* model, int which, int32_t n_rows);
 int pmt_rows_forward(const PmtModel* model_host, const PmtModel* model_dev, int which, const float* theta,
                      const float* packed, const float* in, int64_t in_stride, int32_t n_rows, float* out,
                      int64_t out_stride, float* stash, void* stream);
-/* Backward of pmt_rows_forward: accumulates parameter gradients into grad_theta (atomics) and, if d_in != NULL, writes
+/* Backward of pmt_rows_forward: accumulates parameter gradients into grad_theta and, if d_in != NULL, writes
  * d_in = d_in_scale * dL/d(in)  (d_in_scale = -alpha implements the reference's gradient reversal,
- * gradient_reversal/functional.py:18-22). */
+ * gradient_reversal/functional.py:18-22).
+ * `workspace` (optional, device, >= pmt_rows_workspace_floats(model, which) floats, ALL ZERO at the first use; every call
+ * leaves it zero again; may be shared by the three MLPs if sized for the largest): the workgroups add their weight-gradient
+ * blocks into replicas of the MLP's parameter range and a second launch sums the replicas into grad_theta.  With NULL every
+ * workgroup adds to grad_theta itself: hundreds of float atomics per address at the same moment, which the L2 serialises. */
 int pmt_rows_backward(const PmtModel* model_host, const PmtModel* model_dev, int which, const float* theta,
                       const float* packed, const float* in, int64_t in_stride, int32_t n_rows, const float* d_out,
                       int64_t d_out_stride, const float* stash, float* grad_theta, float* d_in, int64_t d_in_stride,
-                      float d_in_scale, void* stream);
+                      float d_in_scale, float* workspace, size_t workspace_floats, void* stream);
+size_t pmt_rows_workspace_floats(const PmtModel* model_host, int which);
 
 /* Haplotype CNN: haplotypes = device int64 [n][H] rows (values 0..4: A, C, G, T, indel; ref half then alt half,
  * reference data/batch.py:110-130) with the given row stride in elements; out = [n][cnn.out_dim] with row stride.
@@ -488,12 +493,18 @@ int pmt_cnn_forward(const PmtModel* model_host, const PmtModel* model_dev, const
 /* Floats per variant of the optional activation stash of a training forward (every layer output, as the backward keeps
  * them in LDS), or 0 when this model runs on kernels that recompute instead (then pass stash = NULL). */
 size_t pmt_cnn_stash_floats(const PmtModel* model_host);
-/* Backward: accumulates parameter gradients into grad_theta (atomics).  With `stash` (written by pmt_cnn_forward for the
+/* Backward: accumulates parameter gradients into grad_theta.  With `stash` (written by pmt_cnn_forward for the
  * same haplotypes and weights) the layer outputs are loaded; with NULL the forward is recomputed in LDS (a third of the
- * kernel's time). */
+ * kernel's time).
+ * `workspace` (optional, device, >= pmt_cnn_workspace_floats(model) floats, contents irrelevant before and after): the
+ * workgroups store their weight-gradient sums as private rows and a second launch folds the rows into grad_theta.  With
+ * NULL (or too small a workspace) every wave adds its sums with global float atomics: thousands of adds to each address
+ * within a few microseconds, which the L2 serialises (half of the kernel's time at 65 536 variants). */
 int pmt_cnn_backward(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* packed,
                      const int64_t* haplotypes, int64_t hap_stride, int32_t n, const float* d_out, int64_t d_out_stride,
-                     const float* stash, float* grad_theta, void* stream);
+                     const float* stash, float* grad_theta, float* workspace, size_t workspace_floats, void* stream);
+/* Floats of workspace pmt_cnn_backward can use for this model on the current device (0: its kernels for this model use atomics). */
+size_t pmt_cnn_workspace_floats(const PmtModel* model_host);
 
 /* Global-norm clip + AdamW over the flat parameter buffer, one launch sequence, no host sync.
  * Replaces nn.utils.clip_grad_norm_(max_norm=1.0) + torch.optim.AdamW.step (reference misc_utils.py:128-129).

@@ -395,8 +395,10 @@ extern "C" int pmt_cnn2_try_backward(const PmtModel* model_host, const PmtModel*
 extern "C" int pmt_cnn3_try_forward(const PmtModel* model_host, const float* theta, const int64_t* haplotypes, int64_t hap_stride, int32_t n,
                                     float* out, int64_t out_stride, float* stash, void* stream);
 extern "C" int pmt_cnn3_try_backward(const PmtModel* model_host, const float* theta, const int64_t* haplotypes, int64_t hap_stride, int32_t n,
-                                     const float* d_out, int64_t d_out_stride, const float* stash, float* grad_theta, void* stream);
+                                     const float* d_out, int64_t d_out_stride, const float* stash, float* grad_theta, float* workspace,
+                                     size_t workspace_floats, void* stream);
 extern "C" size_t pmt_cnn3_stash_floats(const PmtModel* m);
+extern "C" size_t pmt_cnn3_workspace_floats(const PmtModel* m);
 
 static int cnn_check(const PmtModel* m) {
     if (!m) return PMT_E_INVALID;
@@ -458,15 +460,22 @@ extern "C" int pmt_cnn_forward(const PmtModel* model_host, const PmtModel* model
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }
 
+extern "C" size_t pmt_cnn_workspace_floats(const PmtModel* model_host) {
+    if (cnn_check(model_host)) return 0;
+    return pmt_cnn3_workspace_floats(model_host);
+}
+
 extern "C" int pmt_cnn_backward(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* packed,
                                 const int64_t* haplotypes, int64_t hap_stride, int32_t n, const float* d_out,
-                                int64_t d_out_stride, const float* stash, float* grad_theta, void* stream) {
+                                int64_t d_out_stride, const float* stash, float* grad_theta, float* workspace, size_t workspace_floats,
+                                void* stream) {
     const int rc = cnn_check(model_host);
     if (rc) return rc;
     if (!model_dev || !theta || !packed || !haplotypes || !d_out || !grad_theta || n < 0) return PMT_E_INVALID;
     if (n == 0) return PMT_OK;
     {
-        const int rc3 = pmt_cnn3_try_backward(model_host, theta, haplotypes, hap_stride, n, d_out, d_out_stride, stash, grad_theta, stream);
+        const int rc3 = pmt_cnn3_try_backward(model_host, theta, haplotypes, hap_stride, n, d_out, d_out_stride, stash, grad_theta, workspace,
+                                                  workspace_floats, stream);
         if (rc3 <= 0) return rc3;
         if (stash && pmt_cnn3_stash_floats(model_host) > 0) return PMT_E_INVALID;  // (the stash is in pmt_cnn3's layout)
     }

@@ -35,6 +35,8 @@
 #define C3_BWD_V 8
 #define C3_BWD_NW 4
 #define C3_MAXK 7
+#define C3_NACC(K1, K2, L2) ((K1) * 2 + (K2) * 4 + (L2) * 2)   // 16x16 weight-gradient tiles a backward wave accumulates
+#define C3_NBIAS 80                                             // d(bias1)[32], d(bias2)[32], d(linear bias)[16]
 
 struct C3Cfg {
     int S, K1, L1, P1, K2, L2, C1, C2, F, O;   // sequence length, kernel 1, its output length, pooled length, kernel 2, its output length
@@ -310,15 +312,29 @@ __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_forward_kernel(
 }
 
 // ================================================ backward ==========================================================
+// Development: -DC3_TRACE=1 makes wave 0 of workgroup 0 log the cycle counter at every phase boundary over the stash rows of its
+// own first batch (dead once loaded; scripts/cnn3_trace.py reads them back).  Timing only.
+#ifndef C3_TRACE
+#define C3_TRACE 0
+#endif
+#define C3_EV()                                                                                                      \
+    do {                                                                                                             \
+        if (C3_TRACE && tracing) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0 && tr_n < 120) tr[tr_n] = t_; ++tr_n; } \
+    } while (0)
 // K1 / K2 / L2 (kernel sizes, second convolution's output length) are compile-time: the weight gradients are register arrays
 // indexed by tap / position, and a run-time index would push them to scratch memory.
 template <int V, int NW, int K1, int K2, int L2>
 __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_backward_kernel(
     C3Cfg c, const float* __restrict__ theta, const long long* __restrict__ hap, long long hap_stride, int n, const float* __restrict__ d_out,
-    long long d_out_stride, const float* __restrict__ stash, float* __restrict__ gtheta) {
+    long long d_out_stride, const float* __restrict__ stash, float* __restrict__ gtheta, float* __restrict__ ws, int ws_stride) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const unsigned long long t_begin = C3_TRACE ? __builtin_readcyclecounter() : 0ull;
     const C3Weights W = c3_build_weights(c, theta, lds, true);
+    const unsigned long long t_weights = C3_TRACE ? __builtin_readcyclecounter() : 0ull;
     const int lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15, wave = uniform((int)(threadIdx.x >> 6));
+    const bool tracing = C3_TRACE && blockIdx.x == 0 && wave == 0;
+    unsigned long long* tr = reinterpret_cast<unsigned long long*>(const_cast<float*>(stash));
+    int tr_n = 2;
     const int m = r, kk = g;  // names of the same lane coordinates when the lane feeds an A / B operand: row (or column) m, k-slot kk
     const C3Wave w = c3_wave_region<V>(c, lds + ((c3_weight_floats(c, true) + 3) & ~3) + wave * c.per_wave);
     const int nbatches = (n + V - 1) / V;
@@ -345,6 +361,8 @@ __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_backward_kernel(
             w.dout[i] = (v < nv && o < c.O) ? d_out[(size_t)(v0 + v) * d_out_stride + o] : 0.f;
         }
         c3_wave_sync();
+        if (C3_TRACE && tracing && lane == 0 && tr_n == 2) { tr[0] = t_begin; tr[1] = t_weights; }
+        C3_EV();  // inputs in LDS
         // ---- 1. linear: d(a2) = Wl^T d(out), a column per variant; d(bias) -------------------------------------------------
         {
             const int v = min(r, V - 1);
@@ -360,6 +378,7 @@ __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_backward_kernel(
                 }
         }
         c3_wave_sync();
+        C3_EV();  // 1 done
         // ---- 2. through the second activation: dY2 = d(a2) * act2'(a2), zero on padding columns; back to LDS for the
         //         transposed reads; linear weight gradient ------------------------------------------------------------------
         for (int T = 0; T < c.n2t; ++T) {
@@ -391,6 +410,7 @@ __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_backward_kernel(
             }
         }
         c3_wave_sync();
+        C3_EV();  // 2 done
         // ---- 3. second convolution's weight gradient: dW2_k[co][ci] += sum_cols dY2[co][col] a1[ci][col + k] ----------------
         for (int s = 0; s < (V * c.st2) / 4; ++s) {
             const int col = 4 * s + kk;
@@ -407,6 +427,7 @@ __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_backward_kernel(
             }
         }
         c3_wave_sync();
+        C3_EV();  // 3 done
         // ---- 4. second convolution's input gradient (gather with the transposed weights), through the first activation:
         //         d(pooled)[v][q] -> written over a1[v][q] (each lane reads its block of a1 before it overwrites it) ---------------
         for (int T = 0; T < c.nPt; ++T) {
@@ -441,6 +462,7 @@ __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_backward_kernel(
             }
         }
         c3_wave_sync();
+        C3_EV();  // 4 done
         // ---- 5. first convolution's weight gradient from the pooled gradient, split by the pool's argmax:
         //         dW1_k[co][ci] += sum_(v,q) [arg = 0] dP one_hot[2 q + k] + [arg = 1] dP one_hot[2 q + 1 + k] -----------------------
         for (int s = 0; s < (V * c.P1 + 3) / 4; ++s) {
@@ -476,8 +498,71 @@ __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_backward_kernel(
                 }
         }
         c3_wave_sync();
+        C3_EV();  // 5 done
     }
-    // ---- the register-resident gradients reach global memory once per wave -----------------------------------------------
+    // ---- the register-resident gradients leave the kernel once per workgroup ----------------------------------------------
+    // Every wave holds the same C3_NACC accumulator tiles.  Global float atomics from here would be 64 * NW * gridDim.x adds to
+    // EACH address, all issued within the same few microseconds: they serialise in the L2 (measured: 260 of the kernel's 505 us
+    // were this epilogue).  With a workspace the waves of a workgroup sum their tiles through LDS and store ONE raw row per
+    // workgroup ([tile][lane] f4 + the bias sums); pmt_cnn3_fold_kernel maps the rows to theta offsets and adds them up.
+    if (ws != nullptr) {
+        constexpr int NACC = C3_NACC(K1, K2, L2);
+        __syncthreads();  // every wave is done with its LDS region (and with the weights)
+        f4* red = reinterpret_cast<f4*>(lds);                   // [NW][NACC][64]
+        float* redb = lds + NW * NACC * 256;                    // [NW][C3_NBIAS]
+        f4* mine = red + wave * NACC * 64 + lane;
+#pragma unroll
+        for (int tap = 0; tap < K1; ++tap)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) mine[(tap * 2 + mt) * 64] = gw1[tap][mt];
+#pragma unroll
+        for (int tap = 0; tap < K2; ++tap)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) mine[(K1 * 2 + (tap * 2 + mt) * 2 + kt) * 64] = gw2[tap][mt][kt];
+#pragma unroll
+        for (int p = 0; p < L2; ++p)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) mine[(K1 * 2 + K2 * 4 + p * 2 + t) * 64] = gwl[p][t];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float s1 = gb1[t][j], s2 = gb2[t][j];
+                s1 += dpp_mov<0xB1>(s1); s1 += dpp_mov<0x4E>(s1); s1 += dpp_mov<0x124>(s1); s1 += dpp_mov<0x128>(s1);
+                s2 += dpp_mov<0xB1>(s2); s2 += dpp_mov<0x4E>(s2); s2 += dpp_mov<0x124>(s2); s2 += dpp_mov<0x128>(s2);
+                if (r == 0) {
+                    redb[wave * C3_NBIAS + 16 * t + 4 * j + g] = s1;
+                    redb[wave * C3_NBIAS + 32 + 16 * t + 4 * j + g] = s2;
+                }
+            }
+        {
+            const float tot = group_sum(gbl);
+            if (g == 0) redb[wave * C3_NBIAS + 64 + m] = tot;
+        }
+        __syncthreads();
+        float* row = ws + (size_t)blockIdx.x * ws_stride;
+        for (int a = wave; a < NACC; a += NW) {
+            f4 sum = red[a * 64 + lane];
+#pragma unroll
+            for (int w2 = 1; w2 < NW; ++w2) sum = sum + red[(w2 * NACC + a) * 64 + lane];
+            reinterpret_cast<f4*>(row)[a * 64 + lane] = sum;
+        }
+        if ((int)threadIdx.x < C3_NBIAS) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < NW; ++w2) sum += redb[w2 * C3_NBIAS + threadIdx.x];
+            row[NACC * 256 + threadIdx.x] = sum;
+        }
+        if (C3_TRACE && tracing) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            C3_EV();  // gradients out
+            if (lane == 0) tr[127] = (unsigned long long)tr_n;
+        }
+        return;
+    }
+    // no workspace: global float atomics straight from the registers.
     // C layout: acc[j] of lane (g, col) is row rho = 4 g + j; rows are in position order (channel 16 t + c3_row(rho)), columns too.
 #pragma unroll
     for (int tap = 0; tap < K1; ++tap)
@@ -524,6 +609,53 @@ __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_backward_kernel(
         const float tot = group_sum(gbl);  // over the k-slots: lanes (m, *) hold d(bias)[o = m]
         if (g == 0 && m < c.O) atomicAdd(&gtheta[c.bl + m], tot);
     }
+    if (C3_TRACE && tracing) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        C3_EV();  // gradients out
+        if (lane == 0) tr[127] = (unsigned long long)tr_n;
+    }
+}
+
+// ---- fold: the workgroups' raw rows -> theta offsets ------------------------------------------------------------------------
+// element i < NACC * 256 of a row is accumulator tile a = i / 256, lane (i / 4) % 64, register j = i % 4 (the C layout: row 4 g + j,
+// column r); the C3_NBIAS entries behind them are d(bias1)[32], d(bias2)[32], d(linear bias)[16] by channel.
+#define C3_FOLD_SLICES 8
+__global__ __launch_bounds__(256) void pmt_cnn3_fold_kernel(C3Cfg c, const float* __restrict__ ws, int rows, int ws_stride, float* __restrict__ gtheta) {
+    const int nacc = C3_NACC(c.K1, c.K2, c.L2);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nacc * 256 + C3_NBIAS) return;
+    int off = -1;
+    if (i < nacc * 256) {
+        const int j = i & 3, lane = (i >> 2) & 63, a = i >> 8, g = lane >> 4, r = lane & 15;
+        if (a < c.K1 * 2) {
+            const int tap = a >> 1, mt = a & 1, co = 16 * mt + c3_row(4 * g + j), ci = r;
+            if (co < c.C1 && ci < 10) off = c.w1 + (co * 10 + ci) * c.K1 + tap;
+        } else if (a < c.K1 * 2 + c.K2 * 4) {
+            const int idx = a - c.K1 * 2, tap = idx >> 2, mt = (idx >> 1) & 1, kt = idx & 1;
+            const int co = 16 * mt + c3_row(4 * g + j), ci = 16 * kt + c3_row(r);
+            if (co < c.C2 && ci < c.C1) off = c.w2 + (co * c.C1 + ci) * c.K2 + tap;
+        } else {
+            const int idx = a - c.K1 * 2 - c.K2 * 4, p = idx >> 1, t = idx & 1;
+            const int o = 4 * g + j, ch = 16 * t + c3_row(r);
+            if (o < c.O && ch < c.C2) off = c.wl + o * c.F + ch * c.L2 + p;
+        }
+    } else {
+        const int e = i - nacc * 256;
+        if (e < 32) off = e < c.C1 ? c.b1 + e : -1;
+        else if (e < 64) off = e - 32 < c.C2 ? c.b2 + e - 32 : -1;
+        else off = e - 64 < c.O ? c.bl + e - 64 : -1;
+    }
+    if (off < 0) return;
+    float sum = 0.f;
+    const float* p = ws + i;
+    int row = blockIdx.y;
+    for (; row + 3 * C3_FOLD_SLICES < rows; row += 4 * C3_FOLD_SLICES) {  // four loads in flight
+        const float v0 = p[(size_t)row * ws_stride], v1 = p[(size_t)(row + C3_FOLD_SLICES) * ws_stride];
+        const float v2 = p[(size_t)(row + 2 * C3_FOLD_SLICES) * ws_stride], v3 = p[(size_t)(row + 3 * C3_FOLD_SLICES) * ws_stride];
+        sum += (v0 + v1) + (v2 + v3);
+    }
+    for (; row < rows; row += C3_FOLD_SLICES) sum += p[(size_t)row * ws_stride];
+    atomicAdd(gtheta + off, sum);  // (C3_FOLD_SLICES adds per address)
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
@@ -606,14 +738,37 @@ extern "C" int pmt_cnn3_try_forward(const PmtModel* model_host, const float* the
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }
 
+// floats of one workgroup's row of raw weight-gradient sums (16-byte multiple)
+static int cnn3_ws_stride(const C3Cfg* c) { return C3_NACC(c->K1, c->K2, c->L2) * 256 + ((C3_NBIAS + 3) & ~3); }
+// the workgroup's LDS has to hold its waves' accumulator tiles at the end of the kernel
+static bool cnn3_ws_fits(const C3Cfg* c) {
+    return cnn3_lds_bytes(c, true, C3_BWD_NW) >= (size_t)C3_BWD_NW * (C3_NACC(c->K1, c->K2, c->L2) * 256 + C3_NBIAS) * sizeof(float);
+}
+
+// floats of workspace with which pmt_cnn3_try_backward avoids gradient atomics (one row per workgroup it can launch); 0 = not used
+extern "C" size_t pmt_cnn3_workspace_floats(const PmtModel* m) {
+    C3Cfg f, b;
+    if (!m || !cnn3_covers(m, &f, &b) || !cnn3_ws_fits(&b)) return 0;
+    return (size_t)cnn3_grid(1 << 30, C3_BWD_V, C3_BWD_NW) * cnn3_ws_stride(&b);
+}
+
 extern "C" int pmt_cnn3_try_backward(const PmtModel* model_host, const float* theta, const int64_t* haplotypes, int64_t hap_stride, int32_t n,
-                                     const float* d_out, int64_t d_out_stride, const float* stash, float* grad_theta, void* stream) {
+                                     const float* d_out, int64_t d_out_stride, const float* stash, float* grad_theta, float* workspace,
+                                     size_t workspace_floats, void* stream) {
     C3Cfg cf, c;
     if (!stash || !cnn3_covers(model_host, &cf, &c)) return 1;
     const size_t lds = cnn3_lds_bytes(&c, true, C3_BWD_NW);
     auto kernel = pmt_cnn3_backward_kernel<C3_BWD_V, C3_BWD_NW, 3, 3, 7>;  // (cnn3_config admits exactly the instances compiled here)
     if (!cnn3_allow_lds(reinterpret_cast<const void*>(kernel), lds, 1)) return PMT_E_LAUNCH;
-    hipLaunchKernelGGL(kernel, dim3(cnn3_grid(n, C3_BWD_V, C3_BWD_NW)), dim3(64 * C3_BWD_NW), lds, reinterpret_cast<hipStream_t>(stream), c, theta,
-                       (const long long*)haplotypes, (long long)hap_stride, n, d_out, (long long)d_out_stride, stash, grad_theta);
+    const int grid = cnn3_grid(n, C3_BWD_V, C3_BWD_NW), stride = cnn3_ws_stride(&c);
+    const bool rows = workspace != nullptr && cnn3_ws_fits(&c) && workspace_floats >= (size_t)grid * stride;  // else: global atomics
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * C3_BWD_NW), lds, reinterpret_cast<hipStream_t>(stream), c, theta,
+                       (const long long*)haplotypes, (long long)hap_stride, n, d_out, (long long)d_out_stride, stash, grad_theta,
+                       rows ? workspace : nullptr, stride);
+    if (rows) {
+        const int elems = C3_NACC(c.K1, c.K2, c.L2) * 256 + C3_NBIAS;
+        hipLaunchKernelGGL(pmt_cnn3_fold_kernel, dim3((elems + 255) / 256, C3_FOLD_SLICES), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), c,
+                           workspace, grid, stride, grad_theta);
+    }
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }

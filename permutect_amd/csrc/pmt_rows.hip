@@ -85,6 +85,9 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_forward_kernel(const 
     }
 }
 
+#ifndef PMT_ROWS_DBG
+#define PMT_ROWS_DBG 0  // development: BwdCtx.dbg knock-out bits for the row kernels (wrong results; timing only)
+#endif
 struct RowsBwdShared {
     float aux[PMT_WAVES][PMT_AUX_CAP];
     int aux_dst[PMT_AUX_CAP];
@@ -95,8 +98,13 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_backward_kernel(
     const PmtModel* __restrict__ M, int which, const float* __restrict__ theta, const float* __restrict__ packed,
     const float* __restrict__ in, long long in_stride, int n_rows, const float* __restrict__ d_out, long long d_out_stride,
     const float* __restrict__ stash, float* __restrict__ gtheta, float* __restrict__ d_in, long long d_in_stride,
-    float d_in_scale) {
+    float d_in_scale, float* __restrict__ replicas, int rep_lo, int rep_span, int rep_count) {
     __shared__ __attribute__((aligned(16))) RowsBwdShared sh;
+    // Every workgroup adds its weight-gradient blocks to the SAME addresses at the same point of the same program: with
+    // hundreds of workgroups the L2 serialises those float atomics (78 of 164 us at 65 536 rows).  With `replicas` workgroup b
+    // adds into copy b % rep_count of the MLP's span [rep_lo, rep_lo + rep_span) of the gradient buffer instead
+    // (pmt_rows_fold_kernel sums the copies).
+    if (replicas != nullptr) gtheta = replicas + (size_t)(blockIdx.x % rep_count) * rep_span - rep_lo;
     const PmtMlp& mlp = M->row_mlp[which];
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, r = lane & 15, wave = uniform((int)(tid >> 6));
     const int tile0 = (blockIdx.x * PMT_WAVES + wave) * PMT_RT;
@@ -112,7 +120,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_backward_kernel(
     //  makes hipcc 7.2's SimplifyCFG crash while folding grad_ptr(), so theta / gtheta stand in)
     const int wg_tiles = min(PMT_GROUP_TILES, ((n_rows + 15) >> 4) - (int)blockIdx.x * PMT_GROUP_TILES);
     BwdCtx c{M, theta, theta, packed, gtheta, gtheta, &sh.stage[0], &sh.aux[0][0], &sh.aux_dst[0], g, present,
-             wave * PMT_RT, wg_tiles, wg_tiles, 0, 0, nullptr};
+             wave * PMT_RT, wg_tiles, wg_tiles, 0, PMT_ROWS_DBG, nullptr};
     // d(out) -> registers (zero for padding rows: they then contribute nothing to any weight gradient)
     f4 dy[PMT_RT][PMT_NT];
 #pragma unroll
@@ -177,6 +185,65 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_backward_kernel(
     }
 }
 
+// gradient replicas -> grad_theta[lo, lo + span); leaves the replicas zero for the next launch
+#define ROWS_FOLD_SLICES 4
+#define ROWS_REPLICAS 256
+__global__ __launch_bounds__(256) void pmt_rows_fold_kernel(float* __restrict__ replicas, int used, int span, float* __restrict__ dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= span) return;
+    float sum = 0.f;
+    int r = blockIdx.y;
+    for (; r + 3 * ROWS_FOLD_SLICES < used; r += 4 * ROWS_FOLD_SLICES) {  // four loads in flight
+        float* p0 = replicas + (size_t)r * span + i;
+        float* p1 = p0 + (size_t)ROWS_FOLD_SLICES * span;
+        float* p2 = p1 + (size_t)ROWS_FOLD_SLICES * span;
+        float* p3 = p2 + (size_t)ROWS_FOLD_SLICES * span;
+        const float v0 = *p0, v1 = *p1, v2 = *p2, v3 = *p3;
+        *p0 = 0.f; *p1 = 0.f; *p2 = 0.f; *p3 = 0.f;
+        sum += (v0 + v1) + (v2 + v3);
+    }
+    for (; r < used; r += ROWS_FOLD_SLICES) {
+        float* p = replicas + (size_t)r * span + i;
+        sum += *p;
+        *p = 0.f;
+    }
+    if (sum != 0.f) atomicAdd(dst + i, sum);
+}
+
+// [lo, hi) of theta that holds every parameter of a row MLP (its leaves are direct: offsets into theta)
+static bool rows_param_span(const PmtModel* m, int which, int* lo, int* hi) {
+    const PmtMlp* mlp = &m->row_mlp[which];
+    int a = INT32_MAX, b = -1;
+    for (int op = 0; op < mlp->n_ops; ++op) {
+        const PmtOp* o = &mlp->ops[op];
+        const int nl = o->kind == PMT_OP_SKIP ? o->n_layers : 1;
+        if (o->kind == PMT_OP_SKIP) {
+            if (o->alpha_src < 0) return false;
+            a = o->alpha_src < a ? o->alpha_src : a;
+            b = o->alpha_src + 1 > b ? o->alpha_src + 1 : b;
+        }
+        for (int l = 0; l < nl; ++l) {
+            const PmtLinear* L = &m->lin[o->lin[l]];
+            if (L->w_src < 0 || L->b_src < -1) return false;
+            a = L->w_src < a ? L->w_src : a;
+            b = L->w_src + L->in_dim * L->out_dim > b ? L->w_src + L->in_dim * L->out_dim : b;
+            if (L->b_src >= 0) {
+                a = L->b_src < a ? L->b_src : a;
+                b = L->b_src + L->out_dim > b ? L->b_src + L->out_dim : b;
+            }
+        }
+    }
+    if (b <= a || b - a > (1 << 16)) return false;  // (scattered leaves: replicas of the whole range would not pay)
+    *lo = a; *hi = b;
+    return true;
+}
+
+extern "C" size_t pmt_rows_workspace_floats(const PmtModel* m, int which) {
+    int lo, hi;
+    if (!m || which < 0 || which > 2 || m->row_mlp[which].n_ops < 1 || !rows_param_span(m, which, &lo, &hi)) return 0;
+    return (size_t)ROWS_REPLICAS * (size_t)(hi - lo);
+}
+
 static int rows_check(const PmtModel* m, int which, int n_rows) {
     if (!m || which < 0 || which > 2 || n_rows < 0) return PMT_E_INVALID;
     if (m->row_mlp[which].n_ops < 1) return PMT_E_INVALID;
@@ -211,15 +278,23 @@ extern "C" int pmt_rows_forward(const PmtModel* model_host, const PmtModel* mode
 extern "C" int pmt_rows_backward(const PmtModel* model_host, const PmtModel* model_dev, int which, const float* theta,
                                  const float* packed, const float* in, int64_t in_stride, int32_t n_rows, const float* d_out,
                                  int64_t d_out_stride, const float* stash, float* grad_theta, float* d_in,
-                                 int64_t d_in_stride, float d_in_scale, void* stream) {
+                                 int64_t d_in_stride, float d_in_scale, float* workspace, size_t workspace_floats, void* stream) {
     const int rc = rows_check(model_host, which, n_rows);
     if (rc) return rc;
     if (!model_dev || !theta || !packed || !in || !d_out || !stash || !grad_theta) return PMT_E_INVALID;
     if (model_host->row_mlp[which].in_dim > PMT_MAX_WIDTH && d_in) return PMT_E_UNSUPPORTED;
     if (n_rows == 0) return PMT_OK;
     const int grid = (n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    // gradient replicas pay once several workgroups collide on an address
+    int lo = 0, hi = 0;
+    const bool rep = workspace != nullptr && grid >= 8 && rows_param_span(model_host, which, &lo, &hi) &&
+                     workspace_floats >= (size_t)ROWS_REPLICAS * (size_t)(hi - lo);
+    const int used = grid < ROWS_REPLICAS ? grid : ROWS_REPLICAS;
     hipLaunchKernelGGL(pmt_rows_backward_kernel, dim3(grid), dim3(PMT_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
                        model_dev, which, theta, packed, in, (long long)in_stride, n_rows, d_out, (long long)d_out_stride, stash,
-                       grad_theta, d_in, (long long)d_in_stride, d_in_scale);
+                       grad_theta, d_in, (long long)d_in_stride, d_in_scale, rep ? workspace : nullptr, lo, hi - lo, used);
+    if (rep)
+        hipLaunchKernelGGL(pmt_rows_fold_kernel, dim3((hi - lo + 255) / 256, ROWS_FOLD_SLICES), dim3(256), 0,
+                           reinterpret_cast<hipStream_t>(stream), workspace, used, hi - lo, grad_theta + lo);
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }

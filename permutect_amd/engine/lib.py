@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_HERE, "libpermutect_amd.so")
 
 # ---- limits (must match the header) -------------------------------------------------------------------------------
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_WIDTH, MAX_HALF_FFN, MAX_CLUSTERS = 64, 16, 16
 MAX_ROW_INPUT = 128
 ROWS_INFO, ROWS_ALT_COUNT, ROWS_SOURCE = 0, 1, 2
@@ -151,7 +151,7 @@ class PmtLossInputGrads(C.Structure):
 
 EXPORTS = ["pmt_abi_version", "pmt_struct_bytes", "pmt_model_check", "pmt_plan_groups", "pmt_stash_bytes", "pmt_pack_params",
            "pmt_scan_counts", "pmt_forward", "pmt_backward", "pmt_clip_adamw",
-           "pmt_rows_stash_bytes", "pmt_rows_forward", "pmt_rows_backward", "pmt_cnn_forward", "pmt_cnn_backward", "pmt_cnn_stash_floats",
+           "pmt_rows_stash_bytes", "pmt_rows_forward", "pmt_rows_backward", "pmt_rows_workspace_floats", "pmt_cnn_forward", "pmt_cnn_backward", "pmt_cnn_stash_floats", "pmt_cnn_workspace_floats",
            "pmt_phi_forward", "pmt_phi_backward", "pmt_build_read_index", "pmt_losses_forward", "pmt_losses_backward",
            "pmt_downsample_counts", "pmt_downsample_index", "pmt_record_losses",
            "pmt_plan_groups_split", "pmt_layered_scratch_floats", "pmt_forward_layered",
@@ -191,13 +191,17 @@ def load() -> C.CDLL:
     lib.pmt_backward.argtypes = [P(PmtModel), vp, vp, vp, vp, P(PmtBatch), P(PmtOutputs), P(PmtOutputGrads), vp, vp, vp, vp, vp, i32, vp]
     lib.pmt_clip_adamw.argtypes = [vp, vp, vp, vp, i64, P(PmtAdamW), vp, vp, vp]
     lib.pmt_cnn_forward.argtypes = [P(PmtModel), vp, vp, vp, vp, i64, i32, vp, i64, vp, vp]
-    lib.pmt_cnn_backward.argtypes = [P(PmtModel), vp, vp, vp, vp, i64, i32, vp, i64, vp, vp, vp]
+    lib.pmt_cnn_backward.argtypes = [P(PmtModel), vp, vp, vp, vp, i64, i32, vp, i64, vp, vp, vp, C.c_size_t, vp]
+    lib.pmt_cnn_workspace_floats.argtypes = [P(PmtModel)]
+    lib.pmt_cnn_workspace_floats.restype = C.c_size_t
     lib.pmt_cnn_stash_floats.argtypes = [P(PmtModel)]
     lib.pmt_cnn_stash_floats.restype = C.c_size_t
     lib.pmt_rows_stash_bytes.argtypes = [P(PmtModel), i32, i32]
     lib.pmt_rows_stash_bytes.restype = C.c_size_t
     lib.pmt_rows_forward.argtypes = [P(PmtModel), vp, i32, vp, vp, vp, i64, i32, vp, i64, vp, vp]
-    lib.pmt_rows_backward.argtypes = [P(PmtModel), vp, i32, vp, vp, vp, i64, i32, vp, i64, vp, vp, vp, i64, C.c_float, vp]
+    lib.pmt_rows_backward.argtypes = [P(PmtModel), vp, i32, vp, vp, vp, i64, i32, vp, i64, vp, vp, vp, i64, C.c_float, vp, C.c_size_t, vp]
+    lib.pmt_rows_workspace_floats.argtypes = [P(PmtModel), i32]
+    lib.pmt_rows_workspace_floats.restype = C.c_size_t
     lib.pmt_build_read_index.argtypes = [vp, vp, vp, i32, vp, vp]
     lib.pmt_record_losses.argtypes = [P(PmtRecordArgs), vp, vp]
     lib.pmt_plan_groups_split.argtypes = [vp, vp, i32, vp, vp, i32, P(i32)]
@@ -220,7 +224,8 @@ def load() -> C.CDLL:
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("pmt_abi_version", "pmt_stash_bytes", "pmt_rows_stash_bytes", "pmt_layered_scratch_floats",
-                        "pmt_layered_backward_scratch_floats"):
+                        "pmt_layered_backward_scratch_floats", "pmt_cnn_stash_floats", "pmt_cnn_workspace_floats",
+                        "pmt_rows_workspace_floats"):
             fn.restype = i32
     lib.pmt_struct_bytes.argtypes = [i32]
     if lib.pmt_abi_version() != ABI_VERSION:

@@ -35,6 +35,8 @@ class ReadSetEngine:
         self.space = ParamSpace(model, device)
         self.plan = EnginePlan(model, self.space, device)
         self.trigger = torch.zeros(1, dtype=torch.float32, device=device, requires_grad=True)  # see RowsMlpFunction
+        self._cnn_ws = None
+        self._rows_ws = None
         self.timers = None  # bench.py sets {'pmt_forward': [], 'pmt_backward': []} to collect (start, end) HIP events
         self.grad_hook = None  # data parallel: BucketedGradAllReduce, told when the early gradient bucket is final
 
@@ -56,6 +58,24 @@ class ReadSetEngine:
         d = self.plan
         L.check(self.lib.pmt_pack_params(C.byref(d.desc), d.desc_dev.data_ptr(), self.space.theta.data_ptr(),
                                          phi.data_ptr(), d.packed.data_ptr(), _stream()), "pmt_pack_params")
+
+    def cnn_workspace(self) -> Optional[Tensor]:
+        """private rows for the haplotype CNN's weight-gradient sums (pmt_cnn_backward: workspace); PMT_CNN_WORKSPACE=0: atomics"""
+        if self._cnn_ws is None:
+            n = self.lib.pmt_cnn_workspace_floats(C.byref(self.plan.desc)) if os.environ.get("PMT_CNN_WORKSPACE", "1") != "0" else 0
+            self._cnn_ws = torch.empty(n, dtype=torch.float32, device=self.device) if n > 0 else False
+        return self._cnn_ws if self._cnn_ws is not False else None
+
+    def rows_workspace(self) -> Optional[Tensor]:
+        """zeroed gradient replicas shared by the three row MLPs' backward (pmt_rows_backward: workspace; every call leaves them
+        zero); PMT_ROWS_WORKSPACE=0: every workgroup adds to the gradient buffer itself"""
+        if self._rows_ws is None:
+            n = 0
+            if os.environ.get("PMT_ROWS_WORKSPACE", "1") != "0":
+                n = max(self.lib.pmt_rows_workspace_floats(C.byref(self.plan.desc), w) if self.plan.desc.row_mlp[w].n_ops > 0 else 0
+                        for w in range(3))
+            self._rows_ws = torch.zeros(n, dtype=torch.float32, device=self.device) if n > 0 else False
+        return self._rows_ws if self._rows_ws is not False else None
 
     # ---- batch views --------------------------------------------------------------------------------------------------
     def offsets(self, batch) -> Tuple[Tensor, Tensor]:
@@ -287,9 +307,11 @@ class HaplotypeCnnFunction(torch.autograd.Function):
         eng.space.bind_grads()
         if d_out.dtype != torch.float32 or d_out.stride(-1) != 1:
             d_out = d_out.float().contiguous()
+        ws = eng.cnn_workspace()
         L.check(eng.lib.pmt_cnn_backward(C.byref(d), eng.plan.desc_dev.data_ptr(), eng.space.theta.data_ptr(),
                                          eng.plan.packed.data_ptr(), hap.data_ptr(), hap.stride(0), hap.shape[0], d_out.data_ptr(), d_out.stride(0),
-                                         _ptr(ctx.stash), eng.space.gtheta.data_ptr(), _stream()), "pmt_cnn_backward")
+                                         _ptr(ctx.stash), eng.space.gtheta.data_ptr(), _ptr(ws), 0 if ws is None else ws.numel(), _stream()),
+                "pmt_cnn_backward")
         ctx.stash = None
         return None, None, None  # (the trigger only makes autograd call this node; it needs no gradient of its own)
 
@@ -337,8 +359,10 @@ class RowsMlpFunction(torch.autograd.Function):
         n = x.shape[0]
         d_in = torch.empty_like(x) if ctx.x_needs_grad else None
         scale = 1.0 if ctx.alpha is None else -float(ctx.alpha)
+        ws = eng.rows_workspace()
         L.check(eng.lib.pmt_rows_backward(C.byref(d), eng.plan.desc_dev.data_ptr(), ctx.which, eng.space.theta.data_ptr(),
                                           eng.plan.packed.data_ptr(), x.data_ptr(), x.stride(0), n, d_out.data_ptr(),
                                           d_out.stride(0), stash.data_ptr(), eng.space.gtheta.data_ptr(), _ptr(d_in),
-                                          d_in.stride(0) if d_in is not None else 0, scale, _stream()), "pmt_rows_backward")
+                                          d_in.stride(0) if d_in is not None else 0, scale, _ptr(ws), 0 if ws is None else ws.numel(),
+                                          _stream()), "pmt_rows_backward")
         return None, None, d_in, None, None

@@ -179,6 +179,48 @@ def test_private_partial_sums_match_the_atomic_path_at_65536_read_sets(monkeypat
     assert rel <= 2e-6 and rel_few <= 2e-6, (rel, rel_few)
 
 
+def test_cnn_and_row_kernel_workspaces_match_the_atomic_paths(monkeypatch):
+    """pmt_cnn_backward and pmt_rows_backward with their workspaces (private rows per workgroup + fold; gradient replicas + fold:
+    the defaults) against the same kernels adding with global float atomics (PMT_CNN_WORKSPACE=0, PMT_ROWS_WORKSPACE=0), at
+    16 384 variants (64 row-kernel workgroups, 256 CNN workgroups): same gradients up to summation order, replicas left zero."""
+    nb = 16384
+    _, sd, _ = load_case("p0_b16")
+    ints, floats, packed = synth(nb, seed=17)
+
+    def grads(workspaces):
+        for var in ("PMT_CNN_WORKSPACE", "PMT_ROWS_WORKSPACE"):
+            if workspaces:
+                monkeypatch.delenv(var, raising=False)
+            else:
+                monkeypatch.setenv(var, "0")
+        model, dev = build("p0_b16", sd)
+        model.train(True)
+        batch = Batch.from_arrays(ints, floats, packed).copy_to(dev)
+        opt = FusedClipAdamW(model, lr=1e-3, weight_decay=0.01)
+        for _ in range(2):  # (twice: the second pass starts from replicas the first one must have left zero)
+            out = model.compute_batch_output(batch)
+            losses = model.compute_batch_losses(out, batch)
+            opt.zero_grad()
+            losses.total_loss.backward()
+        torch.cuda.synchronize()
+        eng = model.engine()
+        names = [n for n, _ in model.named_parameters()]
+        return eng, names, [p.grad.detach().cpu().numpy().ravel() for _, p in model.named_parameters()]
+
+    eng, names, g_ws = grads(True)
+    assert eng.cnn_workspace() is not None and eng.rows_workspace() is not None
+    assert float(eng.rows_workspace().abs().max()) == 0.0
+    eng0, _, g_at = grads(False)
+    assert eng0.cnn_workspace() is None and eng0.rows_workspace() is None
+    worst = 0.0
+    for n, a, b in zip(names, g_ws, g_at):
+        if n.startswith(("haplotypes_cnn", "info_embedding", "alt_count_predictor")):
+            scale = max(float(np.linalg.norm(b)), 1e-12)
+            worst = max(worst, float(np.linalg.norm(a - b)) / scale)
+    record(test="workspaces_vs_atomics_16384", worst_tensor_rel_l2=worst)
+    assert worst <= 5e-6, worst
+
+
 def batch_groups(ints):
     from permutect_amd.engine import lib as L
     reads = int(ints[:, 0].astype(np.int64).sum() + ints[:, 1].astype(np.int64).sum())
