@@ -338,7 +338,9 @@ __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_backward_kernel(
     const int m = r, kk = g;  // names of the same lane coordinates when the lane feeds an A / B operand: row (or column) m, k-slot kk
     const C3Wave w = c3_wave_region<V>(c, lds + ((c3_weight_floats(c, true) + 3) & ~3) + wave * c.per_wave);
     const int nbatches = (n + V - 1) / V;
-    const float inv_st2 = 1.0f / (float)c.st2, inv_p1 = 1.0f / (float)c.P1;
+    // the geometry behind the second convolution follows from the template parameters (cnn3_config checks the model against it):
+    // compile-time trip counts let the compiler unroll the contraction loops and issue their LDS reads ahead of the matrix core
+    constexpr int P1 = L2 + K2 - 1, ST2 = L2 <= 4 ? 4 : 8, N2T = (V * ST2) / 16, NPT = (V * P1 + 15) / 16;
     // register-resident weight gradients over every variant this wave sees.  C layout: acc[j] of lane (g, col) = row 4 g + j.
     f4 gw1[K1][2], gw2[K2][2][2], gwl[L2][2];  // rows = out channels (position order) | linear outputs; cols below
     f4 gb1[2] = {c3_zero(), c3_zero()}, gb2[2] = {c3_zero(), c3_zero()};  // per-lane partial sums over this lane's columns
@@ -374,26 +376,26 @@ __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_backward_kernel(
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const f4 d = c3_mfma4(*reinterpret_cast<const f4*>(W.wltf + ((p * 2 + t) * 64 + lane) * 4), bo, c3_zero());
-                    if (r < V) *reinterpret_cast<f4*>(w.x + (v * c.st2 + p) * 32 + 16 * t + 4 * g) = d;  // rows = channels 16 t + 4 j + g
+                    if (r < V) *reinterpret_cast<f4*>(w.x + (v * ST2 + p) * 32 + 16 * t + 4 * g) = d;  // rows = channels 16 t + 4 j + g
                 }
         }
         c3_wave_sync();
         C3_EV();  // 1 done
         // ---- 2. through the second activation: dY2 = d(a2) * act2'(a2), zero on padding columns; back to LDS for the
         //         transposed reads; linear weight gradient ------------------------------------------------------------------
-        for (int T = 0; T < c.n2t; ++T) {
+        for (int T = 0; T < N2T; ++T) {
             const int col = 16 * T + r;
-            int v = (int)((float)col * inv_st2 + 1e-3f);
-            const int p = col - v * c.st2;
-            const bool valid = v < V && p < c.L2;
+            int v = col / ST2;
+            const int p = col - v * ST2;
+            const bool valid = v < V && p < L2;
             v = min(v, V - 1);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                float* px = w.x + (v * c.st2 + p) * 32 + 16 * t + 4 * g;
+                float* px = w.x + (v * ST2 + p) * 32 + 16 * t + 4 * g;
                 const f4 y = *reinterpret_cast<const f4*>(w.a2(v, p) + 16 * t + 4 * g);
                 f4 d = *reinterpret_cast<const f4*>(px) * c3_act_grad4(c.act2, y);
                 if (!valid) d = c3_zero();
-                if (v < V && col < V * c.st2) *reinterpret_cast<f4*>(px) = d;
+                if (v < V && col < V * ST2) *reinterpret_cast<f4*>(px) = d;
                 gb2[t] = gb2[t] + d;
             }
         }
@@ -412,13 +414,14 @@ __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_backward_kernel(
         c3_wave_sync();
         C3_EV();  // 2 done
         // ---- 3. second convolution's weight gradient: dW2_k[co][ci] += sum_cols dY2[co][col] a1[ci][col + k] ----------------
-        for (int s = 0; s < (V * c.st2) / 4; ++s) {
+#pragma unroll
+        for (int s = 0; s < (V * ST2) / 4; ++s) {
             const int col = 4 * s + kk;
-            const int v = (int)((float)col * inv_st2 + 1e-3f), p = col - v * c.st2;
+            const int v = col / ST2, p = col - v * ST2;
             const float a0 = w.x[col * 32 + m], a1v = w.x[col * 32 + 16 + m];  // rows = element m of channel block 0 / 1
 #pragma unroll
             for (int tap = 0; tap < K2; ++tap) {
-                const float* src = w.a1(v, min(p + tap, c.P1 - 1)) + m;  // (padding columns: dY2 is zero there)
+                const float* src = w.a1(v, min(p + tap, P1 - 1)) + m;  // (padding columns: dY2 is zero there)
                 const float b0 = src[0], b1 = src[16];
                 gw2[tap][0][0] = mfma16(a0, b0, gw2[tap][0][0]);
                 gw2[tap][0][1] = mfma16(a0, b1, gw2[tap][0][1]);
@@ -430,18 +433,19 @@ __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_backward_kernel(
         C3_EV();  // 3 done
         // ---- 4. second convolution's input gradient (gather with the transposed weights), through the first activation:
         //         d(pooled)[v][q] -> written over a1[v][q] (each lane reads its block of a1 before it overwrites it) ---------------
-        for (int T = 0; T < c.nPt; ++T) {
+#pragma unroll
+        for (int T = 0; T < NPT; ++T) {
             const int idx = 16 * T + r;  // flat (variant, pooled position)
-            int v = (int)((float)idx * inv_p1 + 1e-3f);
-            const int q = idx - v * c.P1;
+            int v = idx / P1;
+            const int q = idx - v * P1;
             const bool valid = v < V;
             v = min(v, V - 1);
             f4 acc[2] = {c3_zero(), c3_zero()};
 #pragma unroll
             for (int tap = 0; tap < K2; ++tap) {
                 const int p = q - tap;
-                const bool ok = valid && p >= 0 && p < c.L2;
-                const float* src = w.x + (v * c.st2 + (ok ? p : 0)) * 32 + 4 * g;
+                const bool ok = valid && p >= 0 && p < L2;
+                const float* src = w.x + (v * ST2 + (ok ? p : 0)) * 32 + 4 * g;
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt) {
                     f4 b = *reinterpret_cast<const f4*>(src + 16 * kt);
@@ -465,11 +469,12 @@ __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_backward_kernel(
         C3_EV();  // 4 done
         // ---- 5. first convolution's weight gradient from the pooled gradient, split by the pool's argmax:
         //         dW1_k[co][ci] += sum_(v,q) [arg = 0] dP one_hot[2 q + k] + [arg = 1] dP one_hot[2 q + 1 + k] -----------------------
-        for (int s = 0; s < (V * c.P1 + 3) / 4; ++s) {
+#pragma unroll
+        for (int s = 0; s < (V * P1 + 3) / 4; ++s) {
             const int idx = 4 * s + kk;
-            const bool valid = idx < V * c.P1;
+            const bool valid = idx < V * P1;
             const int ii = valid ? idx : 0;
-            const int v = (int)((float)ii * inv_p1 + 1e-3f), q = ii - v * c.P1;
+            const int v = ii / P1, q = ii - v * P1;
             const unsigned word = *w.argb(v, q);
             float a[2][2];  // [argmax][channel block]
 #pragma unroll

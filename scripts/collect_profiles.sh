@@ -9,7 +9,7 @@ root=$(pwd)
 out=$root/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $out/${tag}_kt --output-format csv -- python3 $root/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-extras > $out/${tag}_kt.log 2>&1
+rocprofv3 --kernel-trace --stats -d $out/${tag}_kt --output-format csv -- python3 $root/bench.py --steps 60 --warmup 20 --no-cpu-baseline --no-extras > $out/${tag}_kt.log 2>&1
 echo "kernel trace done" >> $out/${tag}_progress.log
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY -d $out/${tag}_pmc_a --output-format csv -- python3 $root/scripts/one_step.py 65536 3 > $out/${tag}_pmc_a.log 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT -d $out/${tag}_pmc_b --output-format csv -- python3 $root/scripts/one_step.py 65536 3 > $out/${tag}_pmc_b.log 2>&1
