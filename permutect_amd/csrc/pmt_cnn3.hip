@@ -30,8 +30,10 @@
 
 // V variants per wave and batch, NW waves per workgroup: the forward runs <4, 8> (two waves per SIMD hide its LDS latencies), the
 // backward <8, 4> (its register-resident weight gradients want the whole register file of a SIMD: measured 485 vs 633 us).
+#ifndef C3_FWD_V
 #define C3_FWD_V 4
 #define C3_FWD_NW 8
+#endif
 #define C3_BWD_V 8
 #define C3_BWD_NW 4
 #define C3_MAXK 7
@@ -210,24 +212,45 @@ DEV f4 c3_one_hot(const C3Cfg& c, const C3Wave& w, int v, int pos, int g) {
 }
 
 // ================================================ forward ===========================================================
-template <int V, int NW>
+// Development: -DC3_TRACE=1 makes wave 0 of workgroup 0 log the cycle counter at every phase boundary over the stash rows of its
+// own first batch (backward: dead once loaded; forward: from the second batch on, over what it stored for the first;
+// scripts/cnn3_trace.py reads them back).  Timing only.
+#ifndef C3_TRACE
+#define C3_TRACE 0
+#endif
+#define C3_EV()                                                                                                      \
+    do {                                                                                                             \
+        if (C3_TRACE && tracing) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0 && tr_n < 120) tr[tr_n] = t_; ++tr_n; } \
+    } while (0)
+// K1 / K2 / L2 (kernel sizes, second convolution's output length) are compile-time: the weight gradients are register arrays
+// indexed by tap / position, and a run-time index would push them to scratch memory.
+// K1 / K2 / L2 compile-time as in the backward: the tap loops unroll and their LDS reads are issued ahead of the matrix core
+template <int V, int NW, int K1, int K2, int L2>
 __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_forward_kernel(
     C3Cfg c, const float* __restrict__ theta, const long long* __restrict__ hap, long long hap_stride, int n, float* __restrict__ out,
     long long out_stride, float* __restrict__ stash) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const unsigned long long t_begin = C3_TRACE ? __builtin_readcyclecounter() : 0ull;
     const C3Weights W = c3_build_weights(c, theta, lds, false);
+    const unsigned long long t_weights = C3_TRACE ? __builtin_readcyclecounter() : 0ull;
     const int lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15, wave = uniform((int)(threadIdx.x >> 6));
+    bool tracing = false;  // (switched on behind the first batch)
+    unsigned long long* tr = reinterpret_cast<unsigned long long*>(stash);
+    int tr_n = 2;
     const C3Wave w = c3_wave_region<V>(c, lds + ((c3_weight_floats(c, false) + 3) & ~3) + wave * c.per_wave);
     const int nbatches = (n + V - 1) / V;
-    const float inv_st1 = 1.0f / (float)c.st1, inv_st2 = 1.0f / (float)c.st2;
+    const float inv_st1 = 1.0f / (float)c.st1;
+    constexpr int P1 = L2 + K2 - 1, ST2 = L2 <= 4 ? 4 : 8, N2T = (V * ST2 + 15) / 16;
     const f4 b1v[2] = {*reinterpret_cast<const f4*>(W.b1p + 4 * g), *reinterpret_cast<const f4*>(W.b1p + 16 + 4 * g)};
     const f4 b2v[2] = {*reinterpret_cast<const f4*>(W.b2p + 4 * g), *reinterpret_cast<const f4*>(W.b2p + 16 + 4 * g)};
     const f4 blv = *reinterpret_cast<const f4*>(W.blp + 4 * g);
     for (int batch = blockIdx.x * NW + wave; batch < nbatches; batch += gridDim.x * NW) {
         const long long v0 = (long long)batch * V;
         const int nv = (int)min((long long)V, (long long)n - v0);
+        C3_EV();  // batch begins
         c3_load_haplotypes<V>(c, w, hap, hap_stride, v0, nv);
         c3_wave_sync();
+        C3_EV();  // haplotypes in LDS
         // ---- conv1 (+ bias) -> max-pool over column pairs -> activation -> a1 ------------------------------------------
         for (int T = 0; T < c.n1t; ++T) {
             const int col = 16 * T + r;
@@ -236,7 +259,8 @@ __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_forward_kernel(
             const bool in_range = v < V;
             v = min(v, V - 1);
             f4 acc[2] = {b1v[0], b1v[1]};
-            for (int tap = 0; tap < c.K1; ++tap) {
+#pragma unroll
+            for (int tap = 0; tap < K1; ++tap) {
                 const f4 b = c3_one_hot(c, w, v, min(p + tap, c.S - 1), g);
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
@@ -246,7 +270,7 @@ __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_forward_kernel(
                 }
             }
             const int q = p >> 1;
-            const bool store = in_range && !(p & 1) && q < c.P1;  // (p + 1 < L1 follows from q < P1 = L1 / 2)
+            const bool store = in_range && !(p & 1) && q < P1;  // (p + 1 < L1 follows from q < P1 = L1 / 2)
             unsigned bits = 0;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
@@ -263,16 +287,19 @@ __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_forward_kernel(
             if (store) reinterpret_cast<unsigned char*>(w.argb(v, q))[g] = (unsigned char)bits;
         }
         c3_wave_sync();
+        C3_EV();  // conv1 done
         // ---- conv2 (+ bias) -> activation -> a2 --------------------------------------------------------------------------
-        for (int T = 0; T < c.n2t; ++T) {
+#pragma unroll
+        for (int T = 0; T < N2T; ++T) {
             const int col = 16 * T + r;
-            int v = (int)((float)col * inv_st2 + 1e-3f);
-            const int p = col - v * c.st2;
-            const bool valid = v < V && p < c.L2;
+            int v = col / ST2;
+            const int p = col - v * ST2;
+            const bool valid = v < V && p < L2;
             v = min(v, V - 1);
             f4 acc[2] = {b2v[0], b2v[1]};
-            for (int tap = 0; tap < c.K2; ++tap) {
-                const float* src = w.a1(v, min(p + tap, c.P1 - 1)) + 4 * g;
+#pragma unroll
+            for (int tap = 0; tap < K2; ++tap) {
+                const float* src = w.a1(v, min(p + tap, P1 - 1)) + 4 * g;
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt) {
                     const f4 b = *reinterpret_cast<const f4*>(src + 16 * kt);
@@ -281,17 +308,19 @@ __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_forward_kernel(
                         acc[mt] = c3_mfma4(*reinterpret_cast<const f4*>(W.w2f + (((tap * 2 + mt) * 2 + kt) * 64 + lane) * 4), b, acc[mt]);
                 }
             }
-            if (v < V && p < c.st2 && col < V * c.st2) {  // (padding columns hold zeros: they travel with the record)
+            if (v < V && p < ST2 && col < V * ST2) {  // (padding columns hold zeros: they travel with the record)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) *reinterpret_cast<f4*>(w.a2(v, p) + 16 * mt + 4 * g) = valid ? c3_act4(c.act2, acc[mt]) : c3_zero();
             }
         }
         c3_wave_sync();
+        C3_EV();  // conv2 done
         // ---- flatten + linear: a column per variant ------------------------------------------------------------------------
         {
             const int v = min(r, V - 1);
             f4 acc = blv;
-            for (int p = 0; p < c.L2; ++p)
+#pragma unroll
+            for (int p = 0; p < L2; ++p)
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
                     acc = c3_mfma4(*reinterpret_cast<const f4*>(W.wlf + ((p * 2 + t) * 64 + lane) * 4),
@@ -302,27 +331,24 @@ __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_forward_kernel(
                     if (4 * j + g < c.O) out[(size_t)(v0 + r) * out_stride + 4 * j + g] = acc[j];
             }
         }
+        C3_EV();  // linear done
         // ---- stash for the backward: the records as they lie in LDS ----------------------------------------------------------
         if (stash) {
             c3_wave_sync();
             c3_store_records(w, stash + (size_t)v0 * c.stash_per, nv);
         }
         c3_wave_sync();
+        if (C3_TRACE && stash != nullptr && blockIdx.x == 0 && wave == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!tracing && lane == 0) { tr[0] = t_begin; tr[1] = t_weights; }
+            tracing = true;
+            C3_EV();  // records stored
+            if (lane == 0) tr[127] = (unsigned long long)tr_n;
+        }
     }
 }
 
 // ================================================ backward ==========================================================
-// Development: -DC3_TRACE=1 makes wave 0 of workgroup 0 log the cycle counter at every phase boundary over the stash rows of its
-// own first batch (dead once loaded; scripts/cnn3_trace.py reads them back).  Timing only.
-#ifndef C3_TRACE
-#define C3_TRACE 0
-#endif
-#define C3_EV()                                                                                                      \
-    do {                                                                                                             \
-        if (C3_TRACE && tracing) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0 && tr_n < 120) tr[tr_n] = t_; ++tr_n; } \
-    } while (0)
-// K1 / K2 / L2 (kernel sizes, second convolution's output length) are compile-time: the weight gradients are register arrays
-// indexed by tap / position, and a run-time index would push them to scratch memory.
 template <int V, int NW, int K1, int K2, int L2>
 __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_backward_kernel(
     C3Cfg c, const float* __restrict__ theta, const long long* __restrict__ hap, long long hap_stride, int n, const float* __restrict__ d_out,
@@ -736,7 +762,7 @@ extern "C" int pmt_cnn3_try_forward(const PmtModel* model_host, const float* the
     C3Cfg c, cb;
     if (!cnn3_covers(model_host, &c, &cb)) return 1;
     const size_t lds = cnn3_lds_bytes(&c, false, C3_FWD_NW);
-    auto kernel = pmt_cnn3_forward_kernel<C3_FWD_V, C3_FWD_NW>;
+    auto kernel = pmt_cnn3_forward_kernel<C3_FWD_V, C3_FWD_NW, 3, 3, 7>;  // (cnn3_config admits exactly this instance)
     if (!cnn3_allow_lds(reinterpret_cast<const void*>(kernel), lds, 0)) return PMT_E_LAUNCH;
     hipLaunchKernelGGL(kernel, dim3(cnn3_grid(n, C3_FWD_V, C3_FWD_NW)), dim3(64 * C3_FWD_NW), lds, reinterpret_cast<hipStream_t>(stream), c, theta,
                        (const long long*)haplotypes, (long long)hap_stride, n, out, (long long)out_stride, stash);
@@ -766,7 +792,8 @@ extern "C" int pmt_cnn3_try_backward(const PmtModel* model_host, const float* th
     auto kernel = pmt_cnn3_backward_kernel<C3_BWD_V, C3_BWD_NW, 3, 3, 7>;  // (cnn3_config admits exactly the instances compiled here)
     if (!cnn3_allow_lds(reinterpret_cast<const void*>(kernel), lds, 1)) return PMT_E_LAUNCH;
     const int grid = cnn3_grid(n, C3_BWD_V, C3_BWD_NW), stride = cnn3_ws_stride(&c);
-    const bool rows = workspace != nullptr && cnn3_ws_fits(&c) && workspace_floats >= (size_t)grid * stride;  // else: global atomics
+    // (a few workgroups: their atomics do not queue, and the fold would be one more launch on a latency-bound step)
+    const bool rows = workspace != nullptr && grid >= 8 && cnn3_ws_fits(&c) && workspace_floats >= (size_t)grid * stride;  // else: global atomics
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * C3_BWD_NW), lds, reinterpret_cast<hipStream_t>(stream), c, theta,
                        (const long long*)haplotypes, (long long)hap_stride, n, d_out, (long long)d_out_stride, stash, grad_theta,
                        rows ? workspace : nullptr, stride);

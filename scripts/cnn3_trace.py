@@ -27,6 +27,23 @@ for it in range(3):
     out.backward(torch.ones_like(out))
     s1.record()
     torch.cuda.synchronize()
+def show(tr, names_cycle, last):
+    n = int(tr[127])
+    names = ["weights built"] + names_cycle * 64
+    prev = t0 = tr[0]
+    for i in range(1, min(n, 120)):
+        label = names[i - 1] if (i < n - 1 or last is None) else last
+        print(f"{i:3d} {label:18s} +{tr[i] - prev:8d}  at {tr[i] - t0:9d}")
+        prev = tr[i]
+
+
+# forward (training: the log lies over the stash rows of the wave's first batch)
+out = HaplotypeCnnFunction.apply(eng, hap, eng.trigger)
+torch.cuda.synchronize()
+trf = out.grad_fn.stash[:256].view(torch.int64).cpu().numpy()
+print(f"forward: {int(trf[127])} events (the first batch is not logged)")
+show(trf, ["records stored", "batch begins", "haplotypes", "conv1 + pool", "conv2", "linear"], None)
+del out
 tr = stash[:256].view(torch.int64).cpu().numpy()
 n = int(tr[127])
 print(f"backward {s0.elapsed_time(s1):.3f} ms; {n} events")
