@@ -449,11 +449,21 @@ DEV float* grad_ptr(int src, float* gtheta, float* gphi) { return src >= 0 ? gth
 DEV int stash_num_slots(const PmtModel* M) { return (M->read_mlp.n_ops - 1) + (M->num_blocks + 1) + (M->reducer.n_ops - 1) + M->num_blocks; }
 #define PMT_SLOT_FLOATS (PMT_NT * 256)
 
+#ifndef PMT_STASH_NT
+#define PMT_STASH_NT 1
+#endif
+#ifndef PMT_STASH_EXPERIMENT
+#define PMT_STASH_EXPERIMENT 0
+#endif
 template <int NT>
 DEV void stash_store(float* __restrict__ base, const f4 (&v)[NT]) {
+    if (PMT_STASH_EXPERIMENT == 1) return;  // development knock-out (timing only): no stash stores at all
     f4* p = reinterpret_cast<f4*>(base) + (pmt_tid() & 63);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) __builtin_nontemporal_store(v[t], p + t * 64);  // written once, read by the backward long after
+    for (int t = 0; t < NT; ++t) {
+        if (PMT_STASH_NT) __builtin_nontemporal_store(v[t], p + t * 64);  // written once, read by the backward long after
+        else p[t * 64] = v[t];
+    }
 }
 template <int NT>
 DEV void stash_load(const float* __restrict__ base, f4 (&v)[NT]) {

@@ -197,6 +197,11 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
     tr.ev(4);
     // ---- L gated ref/alt blocks; this wave's tiles all use the weights of its side ------------------------------
     for (int l = (LAYERED && lay.slice > 0) ? lay.slice - 1 : 0; l < L; ++l) {
+        // the lane coordinates are re-derived from an opaque thread id in every block: per-lane addresses computed from them
+        // would otherwise be hoisted out of the loop and, at 128 registers, spilled -- and a spill reload is a vector memory
+        // load that queues behind the stash stores (vmcnt retires in order)
+        // (pmt_forward_train.hip only, where pmt_tid() is opaque: the filter instance has the registers, and hoisting serves it better)
+        const int tid = pmt_tid(), lane = tid & 63, g = lane >> 4;
         const PmtBlock& B = M->blocks[l];
         const bool first_half = !LAYERED || l == lay.slice;        // LayerNorm, proj1, SELU, per-set sums of z2
         f4 z[PMT_RT][2];
@@ -204,7 +209,6 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
         const PmtLinear& P1r = M->lin[uniform(B.proj1[0])];
         const int baseA = uniform(P1r.w_frag);
         const float* stA = packed + baseA;
-        const f4 rho = load_pvec(stA + (uniform(B.ref_reg_pvec) - baseA), 0, g);
         f4 sw[1], sb[1];
         sw[0] = load_pvec(stA + (uniform(B.sgu_norm_w_pvec) - baseA), 0, g);
         sb[0] = load_pvec(stA + (uniform(B.sgu_norm_b_pvec) - baseA), 0, g);
@@ -299,6 +303,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
             const float w = uniform(phi[uniform(B.reg_weight_phi)]) + 0.25f;
             const float alpha = uniform(theta[uniform(B.alpha_src[side])]), beta = uniform(theta[uniform(B.beta_src[side])]);
             const float gamma = uniform(theta[uniform(B.gamma_src)]);
+            const f4 rho = load_pvec(stA + (uniform(B.ref_reg_pvec) - baseA), 0, g);  // (loaded here, not at the top of the block: four registers less across its first half)
             f4 u[PMT_RT][1];
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) {
@@ -536,6 +541,26 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
     }
 }
 
+// ---- translation units ---------------------------------------------------------------------------------------------------
+// pmt_forward_train.hip includes this file with PMT_FORWARD_TRAIN_TU (and PMT_OPAQUE_TID 1) defined and compiles ONE instance,
+// the training forward of the production shape; everything else -- the other instances, the layered path, the C entry points --
+// is compiled here.
+typedef int (*PmtForwardLaunch)(int groups, void* stream, const PmtModel* model_dev, const float* theta, const float* phi,
+                                const float* packed, const PmtBatch* batch, const PmtOutputs* out, float* stash, float* zsum_stash,
+                                float* rstd_stash);
+#ifdef PMT_FORWARD_TRAIN_TU
+extern "C" int pmt_forward_launch_train_p0x(int groups, void* stream, const PmtModel* model_dev, const float* theta, const float* phi,
+                                            const float* packed, const PmtBatch* batch, const PmtOutputs* out, float* stash,
+                                            float* zsum_stash, float* rstd_stash) {
+    hipLaunchKernelGGL((pmt_forward_kernel<true, ShapeP0X>), dim3(groups), dim3(PMT_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
+                       model_dev, theta, phi, packed, *batch, *out, stash, zsum_stash, rstd_stash, PmtLayeredArgs{});
+    return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
+}
+#else
+extern "C" int pmt_forward_launch_train_p0x(int groups, void* stream, const PmtModel* model_dev, const float* theta, const float* phi,
+                                            const float* packed, const PmtBatch* batch, const PmtOutputs* out, float* stash,
+                                            float* zsum_stash, float* rstd_stash);
+
 // per-set outputs from the global sums of a layered forward (same arithmetic as the finalisation above)
 __global__ __launch_bounds__(256) void pmt_finalize_kernel(const PmtModel* __restrict__ M, const float* __restrict__ phi, PmtBatch bt,
                                                            PmtOutputs out, const float* __restrict__ fsum_g, const float* __restrict__ hsum_g) {
@@ -639,9 +664,12 @@ extern "C" int pmt_forward(const PmtModel* model_host, const PmtModel* model_dev
     }
     auto kernel = stash ? (p0 ? pmt_forward_kernel<true, ShapeP0> : pmt_forward_kernel<true, ShapeAny>)
                         : (p0 ? pmt_forward_kernel<false, ShapeP0> : pmt_forward_kernel<false, ShapeAny>);
-    if (shape == 2) kernel = stash ? pmt_forward_kernel<true, ShapeP0X> : pmt_forward_kernel<false, ShapeP0X>;
+    if (shape == 2 && stash)  // its own translation unit (pmt_forward_train.hip)
+        return pmt_forward_launch_train_p0x(batch->num_groups, stream, model_dev, theta, phi, packed, batch, out, stash, zsum_stash, rstd_stash);
+    if (shape == 2) kernel = pmt_forward_kernel<false, ShapeP0X>;
     if (shape == 3) kernel = stash ? pmt_forward_kernel<true, ShapeP0XB> : pmt_forward_kernel<false, ShapeP0XB>;  // plain bf16 products
     hipLaunchKernelGGL(kernel, dim3(batch->num_groups), dim3(PMT_THREADS), 0, s, model_dev, theta, phi, packed, *batch, *out,
                        stash, zsum_stash, rstd_stash, PmtLayeredArgs{});
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }
+#endif  // PMT_FORWARD_TRAIN_TU
