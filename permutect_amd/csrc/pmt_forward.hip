@@ -202,6 +202,12 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
         // load that queues behind the stash stores (vmcnt retires in order)
         // (pmt_forward_train.hip only, where pmt_tid() is opaque: the filter instance has the registers, and hoisting serves it better)
         const int tid = pmt_tid(), lane = tid & 63, g = lane >> 4;
+        TileMeta tmb[PMT_RT];  // and the tiles' set ids pass through an opaque copy: what is derived from them (LDS offsets, segment keys) is not hoisted either
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt) {
+            tmb[rt] = tm[rt];
+            if (PMT_OPAQUE_TID) asm volatile("" : "+v"(tmb[rt].set));
+        }
         const PmtBlock& B = M->blocks[l];
         const bool first_half = !LAYERED || l == lay.slice;        // LayerNorm, proj1, SELU, per-set sums of z2
         f4 z[PMT_RT][2];
@@ -253,11 +259,11 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
             layernorm_tile<1>(zo, zh, rstd, zin, h, sw, sb, g);
             z[rt][1] = zo[0];
             {   // per-set sums of z2: segmented reduce over the tile's reads, one LDS add per set and value
-                const SegPlan sp = seg_plan(tm[rt].valid ? tm[rt].set : -1);
-                float* dst = &sh.zsum[buf][tm[rt].set][side][4 * g];
+                const SegPlan sp = seg_plan(tmb[rt].valid ? tmb[rt].set : -1);
+                float* dst = &sh.zsum[buf][tmb[rt].set][side][4 * g];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float s = seg_sum(tm[rt].valid ? z[rt][1][j] : 0.f, sp);
+                    const float s = seg_sum(tmb[rt].valid ? z[rt][1][j] : 0.f, sp);
                     if (sp.last && feat_of(0, j, g) < h) atomicAdd(dst + j, s);
                 }
             }
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
             f4 u[PMT_RT][1];
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) {
-                const int set = tm[rt].set;
+                const int set = tmb[rt].set;
                 const float n_ref = (float)(sh.off[0][set + 1] - sh.off[0][set]);
                 const float n_alt = (float)(sh.off[1][set + 1] - sh.off[1][set]);
                 const f4 s_ref = *reinterpret_cast<const f4*>(&sh.zsum[buf][set][0][4 * g]);
