@@ -179,11 +179,13 @@ def test_private_partial_sums_match_the_atomic_path_at_65536_read_sets(monkeypat
     assert rel <= 2e-6 and rel_few <= 2e-6, (rel, rel_few)
 
 
-def test_cnn_and_row_kernel_workspaces_match_the_atomic_paths(monkeypatch):
+@pytest.mark.parametrize("nb", [16384, 66001])
+def test_cnn_and_row_kernel_workspaces_match_the_atomic_paths(monkeypatch, nb):
     """pmt_cnn_backward and pmt_rows_backward with their workspaces (private rows per workgroup + fold; gradient replicas + fold:
     the defaults) against the same kernels adding with global float atomics (PMT_CNN_WORKSPACE=0, PMT_ROWS_WORKSPACE=0), at
-    16 384 variants (64 row-kernel workgroups, 256 CNN workgroups): same gradients up to summation order, replicas left zero."""
-    nb = 16384
+    16 384 variants (64 row-kernel workgroups, 256 CNN workgroups) and at 66 001 (258 row-kernel workgroups: two pairs share a
+    replica; a last CNN batch of one variant; a last row tile of one row): same gradients up to summation order, replicas left
+    zero."""
     _, sd, _ = load_case("p0_b16")
     ints, floats, packed = synth(nb, seed=17)
 
@@ -217,7 +219,7 @@ def test_cnn_and_row_kernel_workspaces_match_the_atomic_paths(monkeypatch):
         if n.startswith(("haplotypes_cnn", "info_embedding", "alt_count_predictor")):
             scale = max(float(np.linalg.norm(b)), 1e-12)
             worst = max(worst, float(np.linalg.norm(a - b)) / scale)
-    record(test="workspaces_vs_atomics_16384", worst_tensor_rel_l2=worst)
+    record(test=f"workspaces_vs_atomics_{nb}", worst_tensor_rel_l2=worst)
     assert worst <= 5e-6, worst
 
 
