@@ -205,8 +205,8 @@ DEV void c3_store_records(const C3Wave& w, float* __restrict__ dst, int nv) {
 }
 // one-hot B operand of the first convolution for (variant v, input position pos): channel ci = 4 j + g is base (ci >> 1) of the
 // ref (ci even) / alt (ci odd) haplotype (reference data/batch.py:115-130)
-DEV f4 c3_one_hot(const C3Cfg& c, const C3Wave& w, int v, int pos, int g) {
-    const int base = w.hap[v * 2 * c.S + (g & 1) * c.S + pos];
+DEV f4 c3_one_hot(int S, const C3Wave& w, int v, int pos, int g) {
+    const int base = w.hap[v * 2 * S + (g & 1) * S + pos];
     const int b0 = g >> 1;
     return f4{base == b0 ? 1.f : 0.f, base == b0 + 2 ? 1.f : 0.f, (g < 2 && base == b0 + 4) ? 1.f : 0.f, 0.f};
 }
@@ -224,8 +224,10 @@ DEV f4 c3_one_hot(const C3Cfg& c, const C3Wave& w, int v, int pos, int g) {
     } while (0)
 // K1 / K2 / L2 (kernel sizes, second convolution's output length) are compile-time: the weight gradients are register arrays
 // indexed by tap / position, and a run-time index would push them to scratch memory.
-// K1 / K2 / L2 compile-time as in the backward: the tap loops unroll and their LDS reads are issued ahead of the matrix core
-template <int V, int NW, int K1, int K2, int L2>
+// K1 / K2 / L2 compile-time as in the backward: the tap loops unroll and their LDS reads are issued ahead of the matrix core.
+// S1: the sequence length if known at compile time (0 = c.S): then the first convolution's tile loop unrolls too and its column ->
+// (variant, position) split is integer arithmetic on constants.
+template <int V, int NW, int K1, int K2, int L2, int S1>
 __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_forward_kernel(
     C3Cfg c, const float* __restrict__ theta, const long long* __restrict__ hap, long long hap_stride, int n, float* __restrict__ out,
     long long out_stride, float* __restrict__ stash) {
@@ -239,8 +241,9 @@ __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_forward_kernel(
     int tr_n = 2;
     const C3Wave w = c3_wave_region<V>(c, lds + ((c3_weight_floats(c, false) + 3) & ~3) + wave * c.per_wave);
     const int nbatches = (n + V - 1) / V;
-    const float inv_st1 = 1.0f / (float)c.st1;
     constexpr int P1 = L2 + K2 - 1, ST2 = L2 <= 4 ? 4 : 8, N2T = (V * ST2 + 15) / 16;
+    const int S = S1 ? S1 : c.S, st1 = S1 ? ((S1 - K1 + 2) & ~1) : c.st1, n1t = S1 ? (V * st1 + 15) / 16 : c.n1t;  // (cnn3_config: st1 = (L1 + 1) & ~1)
+    const float inv_st1 = 1.0f / (float)st1;
     const f4 b1v[2] = {*reinterpret_cast<const f4*>(W.b1p + 4 * g), *reinterpret_cast<const f4*>(W.b1p + 16 + 4 * g)};
     const f4 b2v[2] = {*reinterpret_cast<const f4*>(W.b2p + 4 * g), *reinterpret_cast<const f4*>(W.b2p + 16 + 4 * g)};
     const f4 blv = *reinterpret_cast<const f4*>(W.blp + 4 * g);
@@ -252,16 +255,17 @@ __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_forward_kernel(
         c3_wave_sync();
         C3_EV();  // haplotypes in LDS
         // ---- conv1 (+ bias) -> max-pool over column pairs -> activation -> a1 ------------------------------------------
-        for (int T = 0; T < c.n1t; ++T) {
+#pragma unroll
+        for (int T = 0; T < n1t; ++T) {
             const int col = 16 * T + r;
-            int v = (int)((float)col * inv_st1 + 1e-3f);
-            int p = col - v * c.st1;
+            int v = S1 ? col / st1 : (int)((float)col * inv_st1 + 1e-3f);
+            int p = col - v * st1;
             const bool in_range = v < V;
             v = min(v, V - 1);
             f4 acc[2] = {b1v[0], b1v[1]};
 #pragma unroll
             for (int tap = 0; tap < K1; ++tap) {
-                const f4 b = c3_one_hot(c, w, v, min(p + tap, c.S - 1), g);
+                const f4 b = c3_one_hot(S, w, v, min(p + tap, S - 1), g);
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
                     const f4 a = *reinterpret_cast<const f4*>(W.w1f + ((tap * 2 + mt) * 64 + lane) * 4);
@@ -762,7 +766,8 @@ extern "C" int pmt_cnn3_try_forward(const PmtModel* model_host, const float* the
     C3Cfg c, cb;
     if (!cnn3_covers(model_host, &c, &cb)) return 1;
     const size_t lds = cnn3_lds_bytes(&c, false, C3_FWD_NW);
-    auto kernel = pmt_cnn3_forward_kernel<C3_FWD_V, C3_FWD_NW, 3, 3, 7>;  // (cnn3_config admits exactly this instance)
+    auto kernel = c.S == 21 ? pmt_cnn3_forward_kernel<C3_FWD_V, C3_FWD_NW, 3, 3, 7, 21>   // the reference's 20 + 1 bases of context
+                            : pmt_cnn3_forward_kernel<C3_FWD_V, C3_FWD_NW, 3, 3, 7, 0>;  // (cnn3_config admits exactly these instances)
     if (!cnn3_allow_lds(reinterpret_cast<const void*>(kernel), lds, 0)) return PMT_E_LAUNCH;
     hipLaunchKernelGGL(kernel, dim3(cnn3_grid(n, C3_FWD_V, C3_FWD_NW)), dim3(64 * C3_FWD_NW), lds, reinterpret_cast<hipStream_t>(stream), c, theta,
                        (const long long*)haplotypes, (long long)hap_stride, n, out, (long long)out_stride, stash);
