@@ -551,21 +551,25 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
 // pmt_forward_train.hip includes this file with PMT_FORWARD_TRAIN_TU (and PMT_OPAQUE_TID 1) defined and compiles ONE instance,
 // the training forward of the production shape; everything else -- the other instances, the layered path, the C entry points --
 // is compiled here.
-typedef int (*PmtForwardLaunch)(int groups, void* stream, const PmtModel* model_dev, const float* theta, const float* phi,
-                                const float* packed, const PmtBatch* batch, const PmtOutputs* out, float* stash, float* zsum_stash,
-                                float* rstd_stash);
 #ifdef PMT_FORWARD_TRAIN_TU
 extern "C" int pmt_forward_launch_train_p0x(int groups, void* stream, const PmtModel* model_dev, const float* theta, const float* phi,
                                             const float* packed, const PmtBatch* batch, const PmtOutputs* out, float* stash,
-                                            float* zsum_stash, float* rstd_stash) {
-    hipLaunchKernelGGL((pmt_forward_kernel<true, ShapeP0X>), dim3(groups), dim3(PMT_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
-                       model_dev, theta, phi, packed, *batch, *out, stash, zsum_stash, rstd_stash, PmtLayeredArgs{});
+                                            float* zsum_stash, float* rstd_stash, const PmtLayeredArgs* lay) {
+    if (lay != nullptr && stash == nullptr)  // one launch of the layered filter forward (it parks activations between launches: stores, too)
+        hipLaunchKernelGGL((pmt_forward_kernel<false, ShapeP0X, true>), dim3(groups), dim3(PMT_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
+                           model_dev, theta, phi, packed, *batch, *out, stash, zsum_stash, rstd_stash, *lay);
+    else if (lay != nullptr)  // one launch of the layered training forward
+        hipLaunchKernelGGL((pmt_forward_kernel<true, ShapeP0X, true>), dim3(groups), dim3(PMT_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
+                           model_dev, theta, phi, packed, *batch, *out, stash, zsum_stash, rstd_stash, *lay);
+    else
+        hipLaunchKernelGGL((pmt_forward_kernel<true, ShapeP0X>), dim3(groups), dim3(PMT_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
+                           model_dev, theta, phi, packed, *batch, *out, stash, zsum_stash, rstd_stash, PmtLayeredArgs{});
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }
 #else
 extern "C" int pmt_forward_launch_train_p0x(int groups, void* stream, const PmtModel* model_dev, const float* theta, const float* phi,
                                             const float* packed, const PmtBatch* batch, const PmtOutputs* out, float* stash,
-                                            float* zsum_stash, float* rstd_stash);
+                                            float* zsum_stash, float* rstd_stash, const PmtLayeredArgs* lay);
 
 // per-set outputs from the global sums of a layered forward (same arithmetic as the finalisation above)
 __global__ __launch_bounds__(256) void pmt_finalize_kernel(const PmtModel* __restrict__ M, const float* __restrict__ phi, PmtBatch bt,
@@ -634,9 +638,14 @@ extern "C" int pmt_forward_layered(const PmtModel* model_host, const PmtModel* m
     if (hipMemsetAsync(lay.fsum_g, 0, B * (2 * PMT_MAX_WIDTH + PMT_MAX_CLUSTERS + 2) * sizeof(float), s) != hipSuccess) return PMT_E_LAUNCH;
     auto kernel = stash ? (p0 ? pmt_forward_kernel<true, ShapeP0, true> : pmt_forward_kernel<true, ShapeAny, true>)
                         : (p0 ? pmt_forward_kernel<false, ShapeP0, true> : pmt_forward_kernel<false, ShapeAny, true>);
-    if (shape >= 2) kernel = stash ? pmt_forward_kernel<true, ShapeP0X, true> : pmt_forward_kernel<false, ShapeP0X, true>;  // (layered: no plain-bf16 instance)
     for (int slice = 0; slice <= L; ++slice) {
         lay.slice = slice;
+        if (shape >= 2) {  // the layered instances of the production shape: pmt_forward_train.hip  (layered: no plain-bf16 instance)
+            const int rct = pmt_forward_launch_train_p0x(batch->num_groups, stream, model_dev, theta, phi, packed, batch, out, stash, zsum_stash,
+                                                         rstd_stash, &lay);
+            if (rct != PMT_OK) return rct;
+            continue;
+        }
         hipLaunchKernelGGL(kernel, dim3(batch->num_groups), dim3(PMT_THREADS), 0, s, model_dev, theta, phi, packed, *batch, *out, stash,
                            zsum_stash, rstd_stash, lay);
     }
@@ -671,7 +680,7 @@ extern "C" int pmt_forward(const PmtModel* model_host, const PmtModel* model_dev
     auto kernel = stash ? (p0 ? pmt_forward_kernel<true, ShapeP0> : pmt_forward_kernel<true, ShapeAny>)
                         : (p0 ? pmt_forward_kernel<false, ShapeP0> : pmt_forward_kernel<false, ShapeAny>);
     if (shape == 2 && stash)  // its own translation unit (pmt_forward_train.hip)
-        return pmt_forward_launch_train_p0x(batch->num_groups, stream, model_dev, theta, phi, packed, batch, out, stash, zsum_stash, rstd_stash);
+        return pmt_forward_launch_train_p0x(batch->num_groups, stream, model_dev, theta, phi, packed, batch, out, stash, zsum_stash, rstd_stash, nullptr);
     if (shape == 2) kernel = pmt_forward_kernel<false, ShapeP0X>;
     if (shape == 3) kernel = stash ? pmt_forward_kernel<true, ShapeP0XB> : pmt_forward_kernel<false, ShapeP0XB>;  // plain bf16 products
     hipLaunchKernelGGL(kernel, dim3(batch->num_groups), dim3(PMT_THREADS), 0, s, model_dev, theta, phi, packed, *batch, *out,

@@ -1,4 +1,4 @@
-// The training forward of the production shape, pmt_forward_kernel<true, ShapeP0X>, in its own translation unit so that it can be
+// The training forward of the production shape, pmt_forward_kernel<true, ShapeP0X> (and its layered twin), in its own translation unit so that it can be
 // compiled with an OPAQUE thread id (pmt_device.hpp: pmt_tid()).  At 128 registers per lane (four waves per SIMD) the compiler
 // otherwise hoists every per-lane address derived from the thread id out of the block loop and spills it; a spill reload is a
 // vector-memory load, and vmcnt retires in order: each reload then waits for the stash stores issued before it.  With the lane
