@@ -215,9 +215,6 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
         const PmtLinear& P1r = M->lin[uniform(B.proj1[0])];
         const int baseA = uniform(P1r.w_frag);
         const float* stA = packed + baseA;
-        f4 sw[1], sb[1];
-        sw[0] = load_pvec(stA + (uniform(B.sgu_norm_w_pvec) - baseA), 0, g);
-        sb[0] = load_pvec(stA + (uniform(B.sgu_norm_b_pvec) - baseA), 0, g);
         const int buf = l % 3;
         if (first_half) {
             f4 lw[NTD], lb[NTD];
@@ -247,6 +244,9 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
             if constexpr (S::BF16) linear_acc_bf16<NTD, 2, false, S::BF16>(z, n, packed + uniform(M->lin[uniform(B.proj1[side])].wb_frag));
             else linear_acc<NTD, 2, false, EX, S::DIM_D>(z, n, stA + side * frag_floats_dev(P1r), D, 16 + h);
         // SELU, LayerNorm(h) on z2, per-set sums (reference gated_mlp.py:228-239)
+        f4 sw[1], sb[1];  // (loaded here, behind the first projection: eight registers less across it)
+        sw[0] = load_pvec(stA + (uniform(B.sgu_norm_w_pvec) - baseA), 0, g);
+        sb[0] = load_pvec(stA + (uniform(B.sgu_norm_b_pvec) - baseA), 0, g);
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt) {
             z[rt][0] = selu4(z[rt][0]);
