@@ -41,6 +41,7 @@ extern "C" {
 #define PMT_MAX_CLUSTERS 16
 #define PMT_MAX_OPS 8           /* top-level ops per MLP program */
 #define PMT_MAX_ROW_INPUT 128    /* widest input of a per-variant row MLP (info vector) */
+#define PMT_MAX_CNN_TAPS 192     /* widest im2col column of a haplotype-CNN convolution: in_channels * kernel_size (64 x 3; 32 x 5) */
 #define PMT_ROWS_INFO 0
 #define PMT_ROWS_ALT_COUNT 1
 #define PMT_ROWS_SOURCE 2

@@ -42,6 +42,12 @@ NUM_PACKED_BYTES = 7  # data/datum.py:35
 LABEL_ARTIFACT, LABEL_VARIANT, LABEL_UNLABELED = 0, 1, 2  # utils/enums.py:36-39
 
 
+# The reference computes in fp32 on every device (data/datum.py:37-38).  The tests may set torch.float64 (with a state_dict cast to
+# double) to measure how far the fp32 restatement itself is from the exact result: a yardstick for the parity margins, never a
+# parity target.
+COMPUTE_DTYPE = torch.float32
+
+
 @dataclass
 class Config:
     read_layers: List[int]
@@ -74,7 +80,7 @@ def one_hot_haplotypes(haplotypes_bh: Tensor) -> Tensor:
     """[B, H] ints in 0..4 -> [B, 10, H/2] float; channel order refA, altA, refC, altC, ... (data/batch.py:115-130)."""
     b, h = haplotypes_bh.shape
     oh = F.one_hot(haplotypes_bh.long(), num_classes=5)  # [B, H, 5]
-    return oh.permute(0, 2, 1).reshape(b, 10, h // 2).to(torch.float32)
+    return oh.permute(0, 2, 1).reshape(b, 10, h // 2).to(COMPUTE_DTYPE)
 
 
 def downsampled_read_indices(keep_ref_mask: Tensor, keep_alt_mask: Tensor) -> Tensor:
@@ -249,8 +255,8 @@ def calculate_features(sd: SD, cfg: Config, reads_re: Tensor, nref: Tensor, nalt
                        haplotypes_bh: Tensor):
     """architecture/artifact_model.py:239-265 -> (final_ref_re, final_alt_re, ref_seq_embeddings_be)."""
     total_ref = int(nref.sum())
-    read_emb = mlp(sd, "read_embedding", [cfg.num_read_features] + cfg.read_layers, reads_re.to(torch.float32))
-    info_emb = mlp(sd, "info_embedding", [cfg.num_info_features] + cfg.info_layers, info_be.to(torch.float32))
+    read_emb = mlp(sd, "read_embedding", [cfg.num_read_features] + cfg.read_layers, reads_re.to(COMPUTE_DTYPE))
+    info_emb = mlp(sd, "info_embedding", [cfg.num_info_features] + cfg.info_layers, info_be.to(COMPUTE_DTYPE))
     hap_emb = cnn(sd, "haplotypes_cnn", cfg.cnn_layers, one_hot_haplotypes(haplotypes_bh))
     info_seq = torch.hstack((info_emb, hap_emb))
     x = torch.hstack((read_emb, torch.vstack((expand(info_seq, nref), expand(info_seq, nalt)))))

@@ -3,7 +3,7 @@
 //
 // A workgroup takes VPB variants, builds their one-hot input straight from the int64 haplotype rows, and walks the layer
 // list with every activation resident in LDS.  Convolutions run on the matrix cores as implicit GEMMs: a column is one
-// (variant, output position) pair, its im2col vector (in_ch * kernel taps, <= 128) is gathered from LDS directly into
+// (variant, output position) pair, its im2col vector (in_ch * kernel taps, <= PMT_MAX_CNN_TAPS) is gathered from LDS directly into
 // the B-operand register layout of pmt_device.hpp, and the convolution weight [out_ch][in_ch * kernel] is an ordinary
 // packed PmtLinear -- so the forward is linear_acc, the weight gradient is wgrad_exchange and the input gradient is
 // linear_acc with the transposed fragments followed by a col2im scatter-add in LDS.  Pooling, activations and the final
@@ -15,14 +15,14 @@
 #define PMT_OWN_WAVE_SHAPE
 #define PMT_WAVES 4
 #define PMT_RT 2
-#define PMT_STAGE_PLANES 24  // 12 planes per tile (4 of dy + 8 of im2col): 2 tiles per exchange pass; leaves LDS for the activations
+#define PMT_STAGE_PLANES 32  // 16 planes per tile (4 of dy + 12 of im2col): 2 tiles per exchange pass; leaves LDS for the activations
 #include <stdlib.h>
 #include <string.h>
 
 #include "pmt_device.hpp"
 #include "pmt_bwd_device.hpp"
 
-#define CNN_NTIN (PMT_MAX_ROW_INPUT / 16)
+#define CNN_NTIN (PMT_MAX_CNN_TAPS / 16)
 #define LEAKY_SLOPE 0.01f
 
 // a / b for 0 <= a < 2^22 without the ~35-instruction integer division sequence (inv_b = 1.0f / b)
@@ -58,7 +58,7 @@ DEV void build_one_hot(float* __restrict__ dst, int dst_stride, const long long*
 // per-layer tap table: for im2col feature f = ci * kernel + k :  tap[f] = (ci * in_len) | ((k * dilation - padding + 64) << 16)
 DEV void build_taps(int* __restrict__ tap, const PmtCnnLayer& L) {
     const int K = L.in_ch * L.kernel;
-    for (int f = threadIdx.x; f < PMT_MAX_ROW_INPUT; f += PMT_THREADS) {
+    for (int f = threadIdx.x; f < PMT_MAX_CNN_TAPS; f += PMT_THREADS) {
         int v = -1;
         if (f < K) {
             const int ci = f / L.kernel, k = f - ci * L.kernel;
@@ -180,7 +180,7 @@ DEV void small_layer_forward(const PmtCnnLayer& L, const float* __restrict__ the
 }
 
 struct CnnFwdShared {
-    int tap[PMT_MAX_ROW_INPUT];
+    int tap[PMT_MAX_CNN_TAPS];
 };
 
 extern "C" __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn_forward_kernel(
@@ -223,7 +223,7 @@ extern "C" __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn_forward_ker
 }
 
 struct CnnBwdShared {
-    int tap[PMT_MAX_ROW_INPUT];
+    int tap[PMT_MAX_CNN_TAPS];
     float aux[PMT_WAVES][PMT_AUX_CAP];
     int aux_dst[PMT_AUX_CAP];
     f4 stage[PMT_STAGE_PLANES * 64];
@@ -413,7 +413,7 @@ static int cnn_check(const PmtModel* m) {
             if (L->lin < 0 || L->lin >= m->n_linear) return PMT_E_INVALID;
             const PmtLinear* w = &m->lin[L->lin];
             if (w->in_dim != L->in_ch * L->kernel || w->out_dim != L->out_ch || w->b_pvec < 0) return PMT_E_INVALID;
-            if (w->in_dim > PMT_MAX_ROW_INPUT || w->out_dim > PMT_MAX_WIDTH) return PMT_E_UNSUPPORTED;
+            if (w->in_dim > PMT_MAX_CNN_TAPS || w->out_dim > PMT_MAX_WIDTH) return PMT_E_UNSUPPORTED;
             if (L->in_ch * L->in_len >= 65536 || L->kernel * L->dilation >= 64 || L->padding >= 64) return PMT_E_UNSUPPORTED;
         }
     }
@@ -439,6 +439,7 @@ extern "C" int pmt_cnn_forward(const PmtModel* model_host, const PmtModel* model
     {   // the batched-column kernels where they cover the model (with `stash`: in the layout their backward reads)
         const int rc3 = pmt_cnn3_try_forward(model_host, theta, haplotypes, hap_stride, n, out, out_stride, stash, stream);
         if (rc3 <= 0) return rc3;
+        if (model_host->force_cnn == 3) return PMT_E_UNSUPPORTED;  // a kernel family asked for by name never falls back silently
     }
     if (stash) {  // a training forward that keeps its layer outputs: the wave-per-variant kernel writes them in the backward's layout
         const int rc2 = pmt_cnn2_try_forward(model_host, model_dev, theta, packed, haplotypes, hap_stride, n, out, out_stride, stash, stream);
@@ -450,6 +451,7 @@ extern "C" int pmt_cnn_forward(const PmtModel* model_host, const PmtModel* model
     if (model_host->force_cnn == 2) {
         const int rc2 = pmt_cnn2_try_forward(model_host, model_dev, theta, packed, haplotypes, hap_stride, n, out, out_stride, nullptr, stream);
         if (rc2 <= 0) return rc2;
+        return PMT_E_UNSUPPORTED;  // PMT_CNN=wave on a stack the wave-per-variant kernels do not cover
     }
     const size_t per = 2 * (size_t)model_host->cnn.max_act;
     const int vpb = pick_vpb(per, sizeof(CnnFwdShared), 2);
@@ -478,12 +480,13 @@ extern "C" int pmt_cnn_backward(const PmtModel* model_host, const PmtModel* mode
                                                   workspace_floats, stream);
         if (rc3 <= 0) return rc3;
         if (stash && pmt_cnn3_stash_floats(model_host) > 0) return PMT_E_INVALID;  // (the stash is in pmt_cnn3's layout)
+        if (model_host->force_cnn == 3) return PMT_E_UNSUPPORTED;
     }
     {
         const int rc2 = pmt_cnn2_try_backward(model_host, model_dev, theta, packed, haplotypes, hap_stride, n, d_out, d_out_stride,
                                               stash, grad_theta, stream);
         if (rc2 <= 0) return rc2;
-        if (stash) return PMT_E_UNSUPPORTED;
+        if (stash || model_host->force_cnn == 2) return PMT_E_UNSUPPORTED;
     }
     const size_t per = (size_t)model_host->cnn.sum_act + 2 * (size_t)model_host->cnn.max_act;
     const int vpb = pick_vpb(per, sizeof(CnnBwdShared), 2);

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libpermutect_amd.so")
 ABI_VERSION = 5
 MAX_WIDTH, MAX_HALF_FFN, MAX_CLUSTERS = 64, 16, 16
 MAX_ROW_INPUT = 128
+MAX_CNN_TAPS = 192
 ROWS_INFO, ROWS_ALT_COUNT, ROWS_SOURCE = 0, 1, 2
 MAX_OPS, MAX_SKIP_LAYERS, MAX_BLOCKS, MAX_LINEAR = 8, 4, 16, 96
 GROUP_WAVES = 8  # PMT_GROUP_WAVES of the built library (include/permutect_amd.h; 4 was measured: DESIGN section 4)

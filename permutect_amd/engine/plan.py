@@ -325,7 +325,7 @@ class EnginePlan:
                 c.kernel, c.stride, c.padding, c.dilation = layer.kernel_size[0], layer.stride[0], layer.padding[0], layer.dilation[0]
                 c.w_src, c.b_src = self.space.offset_of(layer.weight), self.space.offset_of(layer.bias)
                 # the weight [out][in][k] is contiguous = an [out][in*k] matrix: packed like any linear (implicit GEMM)
-                c.lin = self._add_raw_linear(ch * c.kernel, layer.out_channels, c.w_src, c.b_src, True, max_in=L.MAX_ROW_INPUT)
+                c.lin = self._add_raw_linear(ch * c.kernel, layer.out_channels, c.w_src, c.b_src, True, max_in=L.MAX_CNN_TAPS)
                 ch, length = layer.out_channels, M._conv_len(length, kernel_size=c.kernel, stride=c.stride, padding=c.padding, dilation=c.dilation)
             elif isinstance(layer, nn.MaxPool1d):
                 if layer.padding != 0 or layer.dilation != 1 or layer.ceil_mode:

@@ -74,6 +74,30 @@ P0_CNN = [
     "flatten",
     "linear/out_features=10",
 ]
+# the 4-convolution stack of the shipped v0.4.0 checkpoint (10 -> 32 (k3) -> 32 (k3) -> 32 (k5) -> 32 (k5) -> linear 10)
+P0_CNN_LEGACY = [
+    "convolution/kernel_size=3/out_channels=32", "leaky_relu",
+    "convolution/kernel_size=3/out_channels=32", "leaky_relu",
+    "convolution/kernel_size=5/out_channels=32", "leaky_relu",
+    "convolution/kernel_size=5/out_channels=32", "leaky_relu",
+    "flatten",
+    "linear/out_features=10",
+]
+# the stack of the reference's docstring (dna_sequence_convolution.py:36-42: dilation, selu) followed by a strided and a padded
+# convolution.  The reference tracks lengths WITHOUT the padding (its conv_output_length takes `pad`, the layer string says
+# `padding`): a padded convolution only builds a runnable reference model where both lengths agree, as in the last one here
+# (2 -> 1 either way).
+T0_CNN_OPTIONS = [
+    "convolution/kernel_size=3/out_channels=64",
+    "pool/kernel_size=2",
+    "leaky_relu",
+    "convolution/kernel_size=3/dilation=2/out_channels=5",
+    "selu",
+    "convolution/kernel_size=3/stride=2/out_channels=8", "leaky_relu",
+    "convolution/kernel_size=2/stride=3/padding=1/out_channels=6", "leaky_relu",
+    "flatten",
+    "linear/out_features=10",
+]
 T0_CNN = [
     "convolution/kernel_size=3/out_channels=64",
     "pool/kernel_size=2",

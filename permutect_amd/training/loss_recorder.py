@@ -102,21 +102,61 @@ def evaluate(model, loader, num_sources: int = 1, balancer=None) -> LossRecorder
     return rec
 
 
-class EvaluationCounts:
-    """What an evaluation pass leaves behind: per epoch type (TRAIN / VALID) and label, the weighted numbers of variants
-    called artifact / not artifact (logit > 0) and the weighted sum of logits -- on the device, read once at the end.  The
-    reference feeds the same (batch, logits, weights) triples to its EvaluationMetrics for plots (metrics/*: out of scope)."""
+MIN_LOGIT, MAX_LOGIT, LOGIT_BIN_SKIP = -10, 10, 1  # reference data/count_binning.py:14-26 (logit 0 is a bin boundary)
+NUM_LOGIT_BINS = (MAX_LOGIT - MIN_LOGIT) // LOGIT_BIN_SKIP + 1
 
-    def __init__(self, device):
-        self.counts = torch.zeros(2, len(Label), 2, dtype=torch.float32, device=device)      # [epoch type][label][called artifact]
-        self.logit_sums = torch.zeros(2, len(Label), dtype=torch.float32, device=device)
+
+def logit_bin_indices(logits: torch.Tensor) -> torch.Tensor:
+    """reference data/count_binning.py:40-45"""
+    return torch.div(torch.clamp(logits, min=MIN_LOGIT, max=MAX_LOGIT) - MIN_LOGIT, LOGIT_BIN_SKIP, rounding_mode="floor").long()
+
+
+class EvaluationCounts:
+    """What an evaluation pass leaves behind, on the device, read once at the end.
+
+    `hist[epoch type]` is the reference's `EvaluationMetrics.accuracy_metrics_by_epoch_type[...]` (metrics/evaluation_metrics.py:
+    49-66 -> AccuracyMetrics, metrics/loss_metrics.py:226-243): the weights of the LABELED variants tallied over (source, label,
+    variant type, ref-count bin, alt-count bin, logit bin); its plots are out of scope, the tensor is what they are drawn from
+    (pinned by tests/golden/evaluation_metrics.npz).  `stats[epoch type][label]` = (weight called not artifact, weight called
+    artifact (logit > 0), weighted sum of logits) over ALL variants, for the log line.  Both live in ONE flat buffer so that data
+    parallel ranks join them with one collective (`all_reduce`)."""
+
+    def __init__(self, device, num_sources: int = 1):
+        self.num_sources = num_sources
+        self.shape = (num_sources, len(Label), len(Variation), NUM_REF_COUNT_BINS, NUM_ALT_COUNT_BINS, NUM_LOGIT_BINS)
+        self._nhist = 1
+        for d in self.shape:
+            self._nhist *= d
+        self.flat = torch.zeros(2 * self._nhist + 2 * len(Label) * 3, dtype=torch.float32, device=device)
         self.batches = 0
 
+    @property
+    def hist(self) -> torch.Tensor:       # [epoch type][S][L][V][R][A][G]
+        return self.flat[: 2 * self._nhist].view(2, *self.shape)
+
+    @property
+    def stats(self) -> torch.Tensor:      # [epoch type][label][not artifact | artifact | logit sum]
+        return self.flat[2 * self._nhist:].view(2, len(Label), 3)
+
+    @property
+    def counts(self) -> torch.Tensor:     # [epoch type][label][called artifact]
+        return self.stats[:, :, :2]
+
+    @property
+    def logit_sums(self) -> torch.Tensor:
+        return self.stats[:, :, 2]
+
     def record_batch(self, epoch_index: int, batch, logits: torch.Tensor, weights: torch.Tensor):
+        from permutect_amd.training.downsampler import flattened_slvra_index
         labels = batch.get(Data.LABEL).long()
+        weights, logits = weights.float(), logits.float()
         called = (logits > 0).long()
-        self.counts[epoch_index].view(-1).index_add_(0, labels * 2 + called, weights.float())
-        self.logit_sums[epoch_index].index_add_(0, labels, (weights * logits).float())
+        st = self.flat[2 * self._nhist:].view(2, -1)[epoch_index]
+        st.index_add_(0, labels * 3 + called, weights)
+        st.index_add_(0, labels * 3 + 2, weights * logits)
+        # reference evaluation_metrics.py:58-66: unlabeled data are not tallied (weight x is_labeled)
+        idx = flattened_slvra_index(batch) * NUM_LOGIT_BINS + logit_bin_indices(logits)
+        self.flat[: 2 * self._nhist].view(2, -1)[epoch_index].index_add_(0, idx, weights * (labels != int(Label.UNLABELED)).float())
         self.batches += 1
 
     def accuracy(self, epoch_index: int) -> float:
@@ -125,6 +165,11 @@ class EvaluationCounts:
         right = c[int(Label.ARTIFACT), 1] + c[int(Label.VARIANT), 0]
         total = c[int(Label.ARTIFACT)].sum() + c[int(Label.VARIANT)].sum()
         return float((right / total.clamp_min(1e-12)).item())
+
+    def all_reduce(self, dist):
+        """every tally of the pass, summed over the data-parallel ranks in one collective"""
+        self.flat = self.flat.clone()  # (filled under inference_mode: not updatable in place outside it)
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
 
 
 @torch.inference_mode()
@@ -136,7 +181,7 @@ def collect_evaluation_data(model, balancer, downsampler, train_loader, valid_lo
     the fused filter kernel; nothing returns to the host inside the loop."""
     was_training = model.training
     model.train(False)
-    ev = EvaluationCounts(model._device)
+    ev = EvaluationCounts(model._device, num_sources=getattr(balancer, "num_sources", None) or getattr(downsampler, "num_sources", 1))
     step = seed * 7_368_787
     for epoch_index, loader in enumerate((train_loader, valid_loader)):
         if loader is None:

@@ -167,7 +167,8 @@ def train_artifact_model(model, train_dataset: ReadsDataset, valid_dataset: Opti
                             opt.zero_grad()
                             losses.total_loss.backward()
                             opt.step(pre_reduce=reduce_grads)
-            check_for_nan(model)  # reference model_training.py:168, after every epoch
+            if epoch_type == Epoch.TRAIN:
+                check_for_nan(model)  # reference model_training.py:168 (a validation epoch leaves the training step's gradients as they were)
             if dist is not None:
                 recorder.all_reduce(dist)
             mean_loss = recorder.mean_loss(PRIMARY)  # the epoch's one host sync
@@ -184,8 +185,7 @@ def train_artifact_model(model, train_dataset: ReadsDataset, valid_dataset: Opti
                                                 rank=rank, world_size=world),
                     seed=seed * 1000 + epoch, fix_alt_gather=fix_alt_gather)
                 if dist is not None:
-                    ev.counts = ev.counts.clone()  # (made under inference_mode: not updatable in place out here)
-                    dist.all_reduce(ev.counts, op=dist.ReduceOp.SUM)
+                    ev.all_reduce(dist)  # every tally (histogram, call counts, logit sums) in one collective
                 log(f"epoch {epoch} evaluation: accuracy train {ev.accuracy(0):.4f}, valid {ev.accuracy(1):.4f}")
                 evaluations.append((epoch, ev.accuracy(0), ev.accuracy(1)))
             if epoch_type == Epoch.TRAIN:

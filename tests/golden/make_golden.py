@@ -42,17 +42,17 @@ from permutect.data.datum import Data, Datum  # noqa: E402
 from permutect.misc_utils import backpropagate  # noqa: E402
 from permutect.parameters import ModelParameters  # noqa: E402
 
-from permutect_amd.parameters import P0_CNN, T0_CNN  # noqa: E402  (plain lists of layer strings)
+from permutect_amd.parameters import P0_CNN, P0_CNN_LEGACY, T0_CNN, T0_CNN_OPTIONS  # noqa: E402  (plain lists of layer strings)
 
 CPU = torch.device("cpu")
 
 
-def make_model(kind, seed, perturb=0.05, num_sources=1):
+def make_model(kind, seed, perturb=0.05, num_sources=1, cnn=None):
     torch.manual_seed(seed)
     if kind == "T0":
-        p = ModelParameters([10, 10, 10], 20, 2, [10, 10], [20, 20, 20], 4, [10, 10, 10], list(T0_CNN), 0.0, 0.3, False)
+        p = ModelParameters([10, 10, 10], 20, 2, [10, 10], [20, 20, 20], 4, [10, 10, 10], list(cnn or T0_CNN), 0.0, 0.3, False)
     else:
-        p = ModelParameters([30, -2, -2, -2], 20, 6, [20, -2, -2, -2], [-2, -2, 10], 4, [10, 10], list(P0_CNN), 0.0, 0.3, False)
+        p = ModelParameters([30, -2, -2, -2], 20, 6, [20, -2, -2, -2], [-2, -2, 10], 4, [10, 10], list(cnn or P0_CNN), 0.0, 0.3, False)
     m = ArtifactModel(p, 61, 71, 42, device=CPU)
     if num_sources > 1:
         m.reset_source_predictor(num_sources)
@@ -338,6 +338,92 @@ def make_posterior_rows_fixture():
     print("posterior rows fixture written")
 
 
+def make_cnn_fixtures():
+    """p0_cnn_legacy.npz / t0_cnn_options.npz: haplotype-CNN stacks beyond the two of the other fixtures -- the four-convolution
+    stack of the shipped v0.4.0 checkpoint (kernel sizes 3, 3, 5, 5: im2col columns up to 160 wide) and the reference docstring's
+    stack (dilation, selu; a 192-wide im2col column) extended by a strided and a padded convolution -- forward, losses, every
+    gradient and the post-step parameters, like the other training fixtures.  Own random streams."""
+    rng = np.random.default_rng(31)
+    counts = [(int(rng.integers(0, 11)), int(rng.integers(1, 16))) for _ in range(20)]
+    run_case("p0_cnn_legacy", make_model("P0", 31, cnn=P0_CNN_LEGACY), make_data(rng, counts))
+    counts = [(int(rng.integers(0, 11)), int(rng.integers(1, 16))) for _ in range(20)]
+    run_case("t0_cnn_options", make_model("T0", 32, cnn=T0_CNN_OPTIONS), make_data(rng, counts))
+
+
+def make_metrics_fixtures():
+    """loss_metrics.npz: the reference's LossRecorder.record (training/loss_recorder.py:14-22 -> metrics/loss_metrics.py:50-54) over
+    three seeded batches with non-unit weights and two sources: the three (totals, counts) histograms it leaves.
+    evaluation_metrics.npz: the reference's collect_evaluation_data (training/model_training.py:204-228) on tiny_dataset.tar with a
+    seeded P0 model, a fresh reference Balancer and a downsampler stub whose fractions are all 1 (every read kept -- with the
+    reference's un-offset alt gather): the AccuracyMetrics tensors [source, label, variant type, ref bin, alt bin, logit bin] of
+    the TRAIN and VALID loaders, and the balancer's state afterwards."""
+    from types import SimpleNamespace
+    from permutect.data.memory_mapped_data import MemoryMappedData
+    from permutect.training.balancer import Balancer
+    from permutect.training.loss_recorder import LossRecorder
+    from permutect.training.model_training import collect_evaluation_data
+    from permutect.utils.enums import Epoch
+    rng = np.random.default_rng(41)
+    rec = LossRecorder(device=CPU, num_sources=2)
+    nb, per = 3, 200
+    int_array = np.zeros((nb * per, 16 + 42), dtype=np.int16)
+    vec = {k: [] for k in ("weights", "source_weights", "supervised", "unsupervised", "alt_count", "source")}
+    for k in range(nb):
+        data = []
+        for i in range(per):
+            d = Datum(np.zeros(16 + 42, dtype=np.int16), np.zeros(6 + 71, dtype=np.float16), np.zeros((1, 12), dtype=np.uint8), compressed=True)
+            d.set(Data.REF_COUNT, int(rng.integers(0, 40))); d.set(Data.ALT_COUNT, int(rng.integers(1, 30)))
+            d.set(Data.LABEL, int(rng.integers(0, 3))); d.set(Data.VARIANT_TYPE, int(rng.integers(0, 5))); d.set(Data.SOURCE, int(rng.integers(0, 2)))
+            int_array[k * per + i] = d.get_int_array()
+            data.append(d)
+        batch = Batch(data)
+        v = {name: torch.from_numpy((scale * rng.random(per)).astype(np.float32))
+             for name, scale in (("weights", 2.0), ("source_weights", 3.0), ("supervised", 5.0), ("unsupervised", 4.0), ("alt_count", 1.0), ("source", 2.0))}
+        rec.record(SimpleNamespace(weights=v["weights"], source_weights=v["source_weights"]),
+                   SimpleNamespace(supervised_losses_b=v["supervised"], unsupervised_losses_b=v["unsupervised"],
+                                   alt_count_losses_b=v["alt_count"], source_prediction_losses_b=v["source"]), batch)
+        for name in vec:
+            vec[name].append(v[name].numpy())
+    out = {"int_array": int_array, "batch": np.int64(per)}
+    out.update({name: np.concatenate(vs) for name, vs in vec.items()})
+    for name, m in (("primary", rec.primary_metrics), ("count", rec.count_metrics), ("source_m", rec.source_metrics)):
+        out[name + "_totals"] = np.asarray(m.totals_slvra.detach().numpy())
+        out[name + "_counts"] = np.asarray(m.counts_slvra.detach().numpy())
+    out["primary_marginal_by_label"] = np.asarray(rec.primary_metrics.put_on_cpu().get_marginal(__import__("permutect.data.batch", fromlist=["BatchProperty"]).BatchProperty.LABEL).numpy())
+    np.savez_compressed(os.path.join(HERE, "loss_metrics.npz"), **out)
+    print("loss metrics fixture written; primary totals sum", float(out["primary_totals"].sum()))
+
+    back = MemoryMappedData.load_from_tarfile(os.path.join(HERE, "tiny_dataset.tar"))
+    datums = list(back.generate())
+    model = make_model("P0", 51)
+    model.eval()
+    splits = {"train": [list(range(0, 14)), list(range(14, 30))], "valid": [list(range(30, 41))]}
+
+    class AllReadsKept:
+        def calculate_downsampling_fractions(self, batch):
+            return torch.ones(batch.size()), torch.ones(batch.size())
+
+    balancer = Balancer(num_sources=2, device=CPU)
+    random.seed(3)
+    em, _ = collect_evaluation_data(model, 2, balancer, AllReadsKept(), [Batch([datums[i] for i in ids]) for ids in splits["train"]],
+                                    [Batch([datums[i] for i in ids]) for ids in splits["valid"]], report_worst=False)
+    ev = {"sd/" + k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+    ev["train_batches"] = np.array([len(x) for x in splits["train"]]); ev["valid_batches"] = np.array([len(x) for x in splits["valid"]])
+    ev["train_ids"] = np.concatenate(splits["train"]); ev["valid_ids"] = np.concatenate(splits["valid"])
+    ev["accuracy_train"] = em.accuracy_metrics_by_epoch_type[Epoch.TRAIN].detach().numpy()
+    ev["accuracy_valid"] = em.accuracy_metrics_by_epoch_type[Epoch.VALID].detach().numpy()
+    ev["balancer_counts_slvra"] = balancer.counts_slvra.detach().numpy()
+    ev["balancer_weights_slvra"] = balancer.weights_slvra.detach().numpy()
+    # the logits behind the tallies (first pass over every batch, balancer untouched), so that a test can tell a bin flip from an error
+    with torch.inference_mode():
+        ev["first_pass_logits"] = np.concatenate([
+            model.compute_batch_output(DownsampledBatch(Batch([datums[i] for i in ids]), torch.ones(len(ids)), torch.ones(len(ids))), None).logits_b.numpy()
+            for ids in splits["train"] + splits["valid"]])
+    np.savez_compressed(os.path.join(HERE, "evaluation_metrics.npz"), **ev)
+    print("evaluation metrics fixture written; train total", float(ev["accuracy_train"].sum()), "valid total", float(ev["accuracy_valid"].sum()),
+          "shape", ev["accuracy_train"].shape)
+
+
 def make_dropout_eval_fixture():
     """p0_dropout_eval.npz: a P0-shaped model built with dropout_p = 0.25 (nn.Dropout modules inside every MLP: the
     state_dict keys shift, reference architecture/mlp.py:57-58) in EVAL mode, as filter_variants runs it: state_dict,
@@ -369,6 +455,10 @@ def make_dropout_eval_fixture():
 if __name__ == "__main__":
     if "--dropout-only" in sys.argv:
         make_dropout_eval_fixture()
+    elif "--cnn-only" in sys.argv:
+        make_cnn_fixtures()
+    elif "--metrics-only" in sys.argv:
+        make_metrics_fixtures()
     elif "--downsampler-only" in sys.argv:
         make_downsampler_fit_fixture()
     elif "--posterior-only" in sys.argv:
@@ -384,3 +474,5 @@ if __name__ == "__main__":
         make_downsampler_fit_fixture()
         make_posterior_rows_fixture()
         make_dropout_eval_fixture()
+        make_cnn_fixtures()
+        make_metrics_fixtures()

@@ -4,12 +4,12 @@ import pytest
 import torch
 
 from oracle import artifact_oracle as O
-from tests.helpers import CASES, config_for, load_case, GOLDEN
+from tests.helpers import CASES, CNN_CASES, config_for, load_case, GOLDEN
 
 FWD_TOL = dict(rtol=2e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + CNN_CASES)
 def test_forward_and_losses_match_reference(name):
     z, sd, b = load_case(name)
     cfg = config_for(name)
@@ -32,7 +32,7 @@ def test_forward_and_losses_match_reference(name):
     assert np.abs(out["logits_b"].numpy() - z["out/logits_b"]).max() < 1e-4
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + CNN_CASES)
 def test_gradients_and_adamw_step_match_reference(name):
     z, sd, b = load_case(name)
     cfg = config_for(name)

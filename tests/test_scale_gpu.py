@@ -1,6 +1,7 @@
 """Parity at the reference's inference batch size (parameters.py:236-242: 8 192 read sets = 427 workgroups, two rounds of
-the backward kernel, ~107 K reads): forward, losses and EVERY parameter gradient against the oracle's autograd on the same
-seeded inputs, in all three kernel instances.  At this size every weight-gradient element is the sum of ~430 float atomics
+the backward kernel, ~107 K reads) and at bench.py's launch size (65 536 read sets = 3 414 workgroups): forward, losses and EVERY
+parameter gradient against the oracle's autograd on the same seeded inputs, in all three kernel instances; a filter sweep over
+2^20 read sets.  At this size every weight-gradient element is the sum of ~430 float atomics
 from as many workgroups; the tolerances are the same as at 16 read sets (tests/test_train_gpu.py).  The measured errors go
 to gpurun_out/parity_errors.jsonl (DESIGN.md section 2 quotes them)."""
 import json
@@ -52,8 +53,28 @@ def synth(nb, seed):
     return ints[order], floats[order], packed[rows]
 
 
-def test_forward_and_every_gradient_at_8192_read_sets(kernel_shape):
-    nb = 8192
+_ORACLE_CACHE = {}
+
+
+def oracle_train_step(nb, seed, sd, cfg, ints, floats, packed):
+    """the oracle's outputs, losses and gradients for one seeded batch, computed once for the three kernel instances"""
+    if (nb, seed) not in _ORACLE_CACHE:
+        i64 = torch.from_numpy(ints.astype(np.int64))
+        ob = dict(reads_re=torch.from_numpy(O.decode_packed_reads(packed).astype(np.float32)), nref=i64[:, O.REF_COUNT],
+                  nalt=i64[:, O.ALT_COUNT], labels=i64[:, O.LABEL], sources=i64[:, O.SOURCE],
+                  info_be=torch.from_numpy(floats[:, O.INFO_START:].astype(np.float32)), haplotypes_bh=i64[:, O.HAPLOTYPES_START:])
+        ref_out, ref_losses, ref_grads = O.train_step_grads(sd, cfg, ob)
+        _ORACLE_CACHE.clear()  # (one batch at a time: a 65 536-set batch is 200 MB of decoded reads)
+        _ORACLE_CACHE[(nb, seed)] = ({k: v.detach().numpy() for k, v in ref_out.items()}, {k: v.detach().numpy() for k, v in ref_losses.items()},
+                                     {k: v.numpy() for k, v in ref_grads.items()})
+    return _ORACLE_CACHE[(nb, seed)]
+
+
+@pytest.mark.parametrize("nb", [8192, 65536])
+def test_forward_and_every_gradient_at_scale(kernel_shape, nb):
+    """nb = 8192: the reference's inference batch.  nb = 65 536: ONE launch of bench.py's headline workload in bench.py's
+    packing (3 414 groups: 13-14 per persistent workgroup of the backward) -- every capped logit, every summed log-likelihood,
+    the features and EVERY parameter gradient of the launch that is timed, against the oracle."""
     _, sd, _ = load_case("p0_b16")
     cfg = config_for("p0_b16")
     ints, floats, packed = synth(nb, seed=11)
@@ -68,43 +89,118 @@ def test_forward_and_every_gradient_at_8192_read_sets(kernel_shape):
     losses.total_loss.backward()
     torch.cuda.synchronize()
 
-    i64 = torch.from_numpy(ints.astype(np.int64))
-    ob = dict(reads_re=torch.from_numpy(O.decode_packed_reads(packed).astype(np.float32)), nref=i64[:, O.REF_COUNT],
-              nalt=i64[:, O.ALT_COUNT], labels=i64[:, O.LABEL], sources=i64[:, O.SOURCE],
-              info_be=torch.from_numpy(floats[:, O.INFO_START:].astype(np.float32)), haplotypes_bh=i64[:, O.HAPLOTYPES_START:])
-    ref_out, ref_losses, ref_grads = O.train_step_grads(sd, cfg, ob)
+    ref_out, ref_losses, ref_grads = oracle_train_step(nb, 11, sd, cfg, ints, floats, packed)
 
     # ---- forward: the north-star bound on the capped logit, per element; log-likelihood sums to a few ulp of THEIR OWN size --
-    logit_err = np.abs(out.logits_b.detach().cpu().numpy() - ref_out["logits_b"].detach().numpy())
-    lk, ref_lk = out.logits_bk.detach().cpu().numpy(), ref_out["logits_bk"].detach().numpy()
+    logit_err = np.abs(out.logits_b.detach().cpu().numpy() - ref_out["logits_b"])
+    lk, ref_lk = out.logits_bk.detach().cpu().numpy(), ref_out["logits_bk"]
     lk_err = np.abs(lk - ref_lk)
     lk_tol = 2e-5 + 8 * np.spacing(np.abs(ref_lk).astype(np.float32))
-    feat_err = np.abs(out.features_be.detach().cpu().numpy() - ref_out["features_be"].detach().numpy()).max()
-    assert logit_err.max() <= 1e-4, logit_err.max()
-    assert np.all(lk_err <= lk_tol), (lk_err / lk_tol).max()
-    assert feat_err <= 2e-5 * max(1.0, float(np.abs(ref_out["features_be"].detach().numpy()).max()))
-    ref_total = ref_losses["total_losses_b"].detach().numpy()
+    feat_ref, ref_feat_ref = ref_out["features_be"], ref_out["ref_features_be"]
+    feat_err = np.abs(out.features_be.detach().cpu().numpy() - feat_ref).max()
+    ref_feat_err = np.abs(out.ref_features_be.detach().cpu().numpy() - ref_feat_ref).max()
+    ref_total = ref_losses["total_losses_b"]
     loss_err = np.abs(losses.total_losses_b.detach().cpu().numpy() - ref_total).max()
-    assert loss_err <= 1e-4 + 1e-5 * np.abs(ref_total).max()
 
     # ---- every parameter gradient ----------------------------------------------------------------------------------------
     names = [n for n, _ in model.named_parameters()]
     assert set(names) == set(ref_grads)
-    gref = np.concatenate([ref_grads[n].numpy().ravel() for n in names])
+    gref = np.concatenate([ref_grads[n].ravel() for n in names])
     gour = np.concatenate([p.grad.detach().cpu().numpy().ravel() for _, p in model.named_parameters()])
-    assert np.all(np.isfinite(gour))
     gscale = np.abs(gref).max()
     worst, worst_name = 0.0, ""
     for n, p in model.named_parameters():
-        ref = ref_grads[n].numpy()
+        ref = ref_grads[n]
         rel = np.abs(p.grad.detach().cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-3 * gscale)
         if rel > worst:
             worst, worst_name = float(rel), n
     rel_l2 = float(np.linalg.norm(gour - gref) / np.linalg.norm(gref))
-    record(test="scale_8192", instance=kernel_shape, max_logit_err=float(logit_err.max()), max_lk_err_over_tol=float((lk_err / lk_tol).max()),
-           max_feature_err=float(feat_err), max_loss_err=float(loss_err), grad_rel_l2=rel_l2, worst_tensor=worst_name, worst_tensor_rel=worst)
+    record(test=f"scale_{nb}", instance=kernel_shape, groups=int(batch.plan().num_groups), max_logit_err=float(logit_err.max()),
+           p9999_logit_err=float(np.quantile(logit_err, 0.9999)), logit_errs_over_1e4=int((logit_err > 1e-4).sum()),
+           max_lk_err_over_tol=float((lk_err / lk_tol).max()), max_feature_err=float(feat_err), max_ref_feature_err=float(ref_feat_err),
+           max_loss_err=float(loss_err), grad_rel_l2=rel_l2, worst_tensor=worst_name, worst_tensor_rel=worst)
+    assert logit_err.max() <= 1e-4, logit_err.max()
+    assert np.all(lk_err <= lk_tol), (lk_err / lk_tol).max()
+    assert feat_err <= 2e-5 * max(1.0, float(np.abs(feat_ref).max()))
+    assert ref_feat_err <= 2e-5 * max(1.0, float(np.abs(ref_feat_ref).max()))
+    assert loss_err <= 1e-4 + 1e-5 * np.abs(ref_total).max()
+    assert np.all(np.isfinite(gour))
     assert worst <= 5e-4, (worst_name, worst)
     assert rel_l2 <= 1e-4, rel_l2
+
+
+def _oracle_forward(sd, cfg, ints, floats, packed, dtype=torch.float32):
+    """the oracle's forward in `dtype` (fp64: the yardstick that says how far fp32 arithmetic itself is from the exact result)"""
+    i64 = torch.from_numpy(ints.astype(np.int64))
+    old = O.COMPUTE_DTYPE
+    O.COMPUTE_DTYPE = dtype
+    try:
+        with torch.inference_mode():
+            sdd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
+            return O.compute_batch_output(sdd, cfg, torch.from_numpy(O.decode_packed_reads(packed).astype(np.float32)), i64[:, O.REF_COUNT],
+                                          i64[:, O.ALT_COUNT], torch.from_numpy(floats[:, O.INFO_START:].astype(np.float32)), i64[:, O.HAPLOTYPES_START:])
+    finally:
+        O.COMPUTE_DTYPE = old
+
+
+def test_filter_sweep_over_a_million_read_sets_stays_inside_the_contract():
+    """BASELINE configs[2] at scale: 16 filter launches of 65 536 WGS-shaped read sets (1 048 576 variants, ~13.6 M reads), every
+    capped logit against the oracle; the maximum, the 99.99th percentile and the count above 1e-4 go to
+    gpurun_out/parity_errors.jsonl (profiles/r03_parity_errors.jsonl).
+
+    What is asserted.  The contract (BASELINE.json north_star) is "within 1e-4 fp32" of the reference CPU path, and the
+    reference CPU path is itself fp32 arithmetic in ATen's summation order: a summed log-likelihood of 15 reads at |L| ~ 300 carries
+    a few ulp (3e-5 each) of its own rounding.  Measured on the first sweep (round 3): ONE of 1 048 576 variants differed by 1.15e-4,
+    53 by more than 5e-5.  So every variant that differs from the fp32 oracle by more than 5e-5 is recomputed by the same oracle in
+    fp64, and the test asserts: (a) at most 4 variants per million differ from the fp32 oracle by more than 1e-4, none by more than
+    2e-4; (b) for EVERY such candidate the HIP result is within 1e-4 of the fp64 result -- the excess over the contract is the
+    fp32 reference's own distance from the exact value, not the kernel's; (c) over the candidates the kernel is not further from
+    fp64 than the fp32 oracle is (ratio of the two worst distances <= 1.5)."""
+    nb, launches = 65536, 16
+    _, sd, _ = load_case("p0_b16")
+    cfg = config_for("p0_b16")
+    model, dev = build("p0_b16", sd)
+    model.eval()
+    errs, lk_over = [], 0.0
+    cand = {"ints": [], "floats": [], "ref_rows": [], "alt_rows": [], "gpu": [], "o32": []}
+    for i in range(launches):
+        ints, floats, packed = synth(nb, seed=1000 + i)
+        batch = Batch.from_arrays(ints, floats, packed).copy_to(dev)
+        with torch.inference_mode():
+            out = model.compute_batch_output(batch)
+        ref = _oracle_forward(sd, cfg, ints, floats, packed)
+        gpu_logits, ref_logits = out.logits_b.cpu().numpy(), ref["logits_b"].numpy()
+        err = np.abs(gpu_logits - ref_logits)
+        errs.append(err)
+        ref_lk = ref["logits_bk"].numpy()
+        lk_over = max(lk_over, float((np.abs(out.logits_bk.cpu().numpy() - ref_lk) / (2e-5 + 8 * np.spacing(np.abs(ref_lk).astype(np.float32)))).max()))
+        nref, nalt = ints[:, 0].astype(np.int64), ints[:, 1].astype(np.int64)
+        ro, ao = np.concatenate([[0], np.cumsum(nref)]), int(nref.sum()) + np.concatenate([[0], np.cumsum(nalt)])
+        for v in np.nonzero(err > 5e-5)[0]:
+            cand["ints"].append(ints[v]); cand["floats"].append(floats[v])
+            cand["ref_rows"].append(packed[ro[v]:ro[v + 1]]); cand["alt_rows"].append(packed[ao[v]:ao[v + 1]])
+            cand["gpu"].append(gpu_logits[v]); cand["o32"].append(ref_logits[v])
+        del batch, out, ref
+    err = np.concatenate(errs)
+    rec = dict(test="filter_sweep_1M", instance="auto", read_sets=int(err.size), launches=launches, max_logit_err=float(err.max()),
+               p9999_logit_err=float(np.quantile(err, 0.9999)), p99_logit_err=float(np.quantile(err, 0.99)), median_logit_err=float(np.median(err)),
+               logit_errs_over_1e4=int((err > 1e-4).sum()), logit_errs_over_5e5=int((err > 5e-5).sum()), max_lk_err_over_tol=lk_over)
+    gpu_vs_64 = o32_vs_64 = 0.0
+    if cand["gpu"]:
+        c_ints, c_floats = np.stack(cand["ints"]), np.stack(cand["floats"])
+        c_packed = np.concatenate(cand["ref_rows"] + cand["alt_rows"])
+        ref64 = _oracle_forward(sd, cfg, c_ints, c_floats, c_packed, dtype=torch.float64)["logits_b"].numpy()
+        again32 = _oracle_forward(sd, cfg, c_ints, c_floats, c_packed)["logits_b"].numpy()
+        gpu, o32 = np.array(cand["gpu"], dtype=np.float64), np.array(cand["o32"], dtype=np.float64)
+        assert np.abs(again32 - o32).max() <= 2e-5  # (a variant's result does not depend on its batch beyond the summation order)
+        gpu_vs_64, o32_vs_64 = float(np.abs(gpu - ref64).max()), float(np.abs(o32 - ref64).max())
+        rec.update(candidates=len(gpu), max_hip_vs_fp64=gpu_vs_64, max_fp32_oracle_vs_fp64=o32_vs_64,
+                   mean_hip_vs_fp64=float(np.abs(gpu - ref64).mean()), mean_fp32_oracle_vs_fp64=float(np.abs(o32 - ref64).mean()))
+    record(**rec)
+    assert err.size == nb * launches and np.all(np.isfinite(err))
+    assert int((err > 1e-4).sum()) <= 4 * launches * nb // 1_000_000 and err.max() <= 2e-4, (float(err.max()), int((err > 1e-4).sum()))
+    assert gpu_vs_64 <= 1e-4, gpu_vs_64
+    assert gpu_vs_64 <= 1.5 * max(o32_vs_64, 2e-5), (gpu_vs_64, o32_vs_64)
 
 
 def test_plain_bf16_mode_is_a_labelled_approximation(monkeypatch):

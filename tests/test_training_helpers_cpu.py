@@ -112,3 +112,34 @@ def test_dataset_totals_by_bin():
     want = torch.bincount(flattened_slvra_index(batch), minlength=tot.numel()).float().view(tot.shape)
     assert torch.equal(tot, want)
     assert torch.equal(tot.sum(dim=(0, 2, 3, 4)), ds.totals_by_label())
+
+
+def test_evaluation_tally_matches_reference_given_the_reference_logits():
+    """EvaluationCounts.record_batch (the reference's EvaluationMetrics.record_batch -> AccuracyMetrics over source, label, variant
+    type, ref bin, alt bin, LOGIT bin) fed the logits the reference itself computed (evaluation_metrics.npz: first_pass_logits;
+    every read kept, unit balancer weights, so each of the three passes tallies the same triples): the tensors must be the
+    reference's, bin for bin.  The GPU test (tests/test_metrics_gpu.py) runs the model as well."""
+    from permutect_amd.data.memory_mapped_data import MemoryMappedData
+    from permutect_amd.data.reads_dataset import ReadsDataset
+    from permutect_amd.training.loss_recorder import EvaluationCounts, NUM_LOGIT_BINS, logit_bin_indices
+    here = os.path.dirname(GOLDEN)
+    z = np.load(os.path.join(here, "evaluation_metrics.npz"))
+    assert np.all(z["balancer_weights_slvra"] == 1.0)  # (41 variants never reach the balancer's recompute threshold)
+    dataset = ReadsDataset(MemoryMappedData.load_from_tarfile(os.path.join(here, "tiny_dataset.tar")))
+    ev = EvaluationCounts(torch.device("cpu"), num_sources=2)
+    logits = torch.from_numpy(z["first_pass_logits"])
+    at = 0
+    for e, (ids_key, sizes_key) in enumerate((("train_ids", "train_batches"), ("valid_ids", "valid_batches"))):
+        ids, k = z[ids_key], 0
+        for n in z[sizes_key]:
+            batch = dataset.host_batch(ids[k:k + int(n)])
+            for _ in range(3):
+                ev.record_batch(e, batch, logits[at:at + int(n)], torch.ones(int(n)))
+            k += int(n)
+            at += int(n)
+    np.testing.assert_allclose(ev.hist[0].numpy(), z["accuracy_train"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(ev.hist[1].numpy(), z["accuracy_valid"], rtol=0, atol=1e-6)
+    assert ev.hist.shape[-1] == NUM_LOGIT_BINS == 21
+    assert logit_bin_indices(torch.tensor([-25.0, -10.0, -0.5, 0.0, 0.999, 9.99, 10.0, 30.0])).tolist() == [0, 0, 9, 10, 10, 19, 20, 20]
+    # the call counts of the log line: labeled + unlabeled, three passes
+    assert abs(float(ev.counts[0].sum()) - 3 * len(z["train_ids"])) < 1e-4 and abs(float(ev.counts[1].sum()) - 3 * len(z["valid_ids"])) < 1e-4
