@@ -18,7 +18,13 @@ ONE JSON line on rank 0 carries, besides the contract's keys:
   filter        the filter-forward half of the metric: value, ms_per_step, its own roofline (pmt_forward_kernel)
   small_batch   the reference's default batch sizes (training 64, inference 8192: parameters.py:214,236-242) and twice the
                 headline's batch (131072), N = 1 only
-  parity_check_max_logit_err   first 2048 variants of resident batch 0 against the CPU oracle, after the timed regions
+  stress        BASELINE configs[4] on one GPU: 1 420 read sets of ~600 reads per step (the same reads per step as the headline),
+                train and filter, each with its own roofline and its per-read rate relative to the WGS path; N = 1 only
+  loader        BASELINE configs[1] / [2] as DATASETS: 2^20-variant training epochs and a 5 x 2^20-candidate filter pass (with and
+                without the posterior hand-off) streamed through the device chunk loader, H2D inclusive, and each rate's ratio
+                to the resident rate; N = 1 only
+  parity_check  EVERY variant of resident batch 0 (one whole 65 536-set launch) against the CPU oracle, after the timed
+                regions: max / 99.99th percentile / count above the 1e-4 contract; the run FAILS above 1e-4
   cpu_baseline  the CPU oracle (PyTorch-CPU restatement of the reference path) on this box's host cores, thread count
                 swept and the best reported, B = 8192 and B = 64, train and filter; N = 1 only
 """
@@ -305,6 +311,7 @@ def main():
     reduce_grads = None
     if dist is not None:
         dist.broadcast(eng.space.theta, src=0)
+        eng.params_changed()
         reduce_grads = BucketedGradAllReduce()  # loss is a batch SUM (reference artifact_model.py:90) -> SUM all-reduce
         eng.grad_hook = reduce_grads            # the early bucket goes out under the haplotype-CNN / info-MLP backward
 
@@ -356,19 +363,24 @@ def main():
             return model.compute_batch_output(batch)
 
     def timed(mode, pool, steps, warmup):
-        """W untimed + exactly K timed steps between barrier + synchronize brackets; max over ranks."""
+        """W untimed + exactly K timed steps between barrier + synchronize brackets; max over ranks.  Returns (seconds,
+        kernel milliseconds, per-step milliseconds): the last from one HIP event behind every step -- no synchronisation
+        inside the loop -- so that the spread of the steps is visible next to their mean."""
         model.train(mode == "train")
         fn = train_step if mode == "train" else filter_step
         nxt = (lambda i: pool[i % len(pool)]) if stream_batches is None or pool is not batches else (lambda i: next(stream_batches))
         for i in range(warmup):
             fn(nxt(i))
         eng.timers = {"pmt_forward": [], "pmt_backward": []}
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         t0 = time.perf_counter()
+        marks[0].record()
         for i in range(steps):
             fn(nxt(warmup + i))
+            marks[i + 1].record()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -379,7 +391,12 @@ def main():
             elapsed = float(t.item())
         kernel_ms = {k: (sum(s.elapsed_time(e) for s, e in v) / len(v) if v else None) for k, v in eng.timers.items()}
         eng.timers = None
-        return elapsed, kernel_ms
+        per_step = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(steps)])
+        return elapsed, kernel_ms, per_step
+
+    def step_stats(elapsed, per_step):
+        return {"timed_s": elapsed, "step_ms_min": float(per_step.min()), "step_ms_median": float(np.median(per_step)),
+                "step_ms_max": float(per_step.max())}
 
     macs = algorithmic_macs_per_read(model)
     pad_ratio = algorithmic_macs_per_read(model, padded=True) / macs
@@ -396,7 +413,7 @@ def main():
 
     results = {}
     if args.mode in ("both", "train"):
-        elapsed, kms = timed("train", batches, args.steps, args.warmup)
+        elapsed, kms, per_step = timed("train", batches, args.steps, args.warmup)
         r = roofline("pmt_backward_kernel", 2.0 * fwd_flops, kms["pmt_backward"])  # dgrad + wgrad; in-kernel recompute not counted
         r["matrix_pipe"] = ("fp32-equivalent on the bf16 matrix pipe: forward / recompute / dgrad as six bf16 MFMAs on three-piece "
                             "splits of both operands, wgrad as three bf16 MFMAs on two-piece splits; `peak` is the dense fp32 MFMA rate"
@@ -404,14 +421,14 @@ def main():
                             "plain bf16: one bf16 MFMA per product (fp32 accumulation), single roundings of both operands; `peak` stays the "
                             "dense fp32 MFMA rate so that the two modes read on one scale (the bf16 dense peak is ~2.5 PFLOP/s)")
         r["other_kernel_ms"] = kms
-        results["train"] = (elapsed, r)
-        note(f"train: {1e3 * elapsed / args.steps:.3f} ms/step, kernels {kms}")
+        results["train"] = (elapsed, r, step_stats(elapsed, per_step))
+        note(f"train: {1e3 * elapsed / args.steps:.3f} ms/step over {elapsed:.3f} s (steps {per_step.min():.3f} .. {per_step.max():.3f} ms), kernels {kms}")
     if args.mode in ("both", "filter"):
         if stream_batches is not None:
             loader_shuffle[0] = False
-        elapsed, kms = timed("filter", batches, args.steps, args.warmup)
-        results["filter"] = (elapsed, roofline("pmt_forward_kernel", fwd_flops, kms["pmt_forward"]))
-        note(f"filter: {1e3 * elapsed / args.steps:.3f} ms/step, kernels {kms}")
+        elapsed, kms, per_step = timed("filter", batches, args.steps, args.warmup)
+        results["filter"] = (elapsed, roofline("pmt_forward_kernel", fwd_flops, kms["pmt_forward"]), step_stats(elapsed, per_step))
+        note(f"filter: {1e3 * elapsed / args.steps:.3f} ms/step over {elapsed:.3f} s (steps {per_step.min():.3f} .. {per_step.max():.3f} ms), kernels {kms}")
 
     # ---- the reference's default batch sizes beside the build's best: N = 1, resident batches only ------------
     small = None
@@ -424,8 +441,8 @@ def main():
                 b = Batch.from_arrays(*synth_arrays(srng, bsz, "wgs"), pack=True)
                 b.plan(allow_split=True)
                 pool.append(b.copy_to(dev))
-            et, _ = timed("train", pool, k, 10)
-            ef, _ = timed("filter", pool, k, 10)
+            et, _, _ = timed("train", pool, k, 10)
+            ef, _, _ = timed("filter", pool, k, 10)
             if bsz > 8192:
                 note(f"B={bsz}: train {1e3 * et / k:.3f} ms/step, filter {1e3 * ef / k:.3f} ms/step")
                 small[f"b{bsz}"] = {"train_read_sets_per_s": bsz * k / et, "train_ms_per_step": 1e3 * et / k,
@@ -447,45 +464,186 @@ def main():
                 gstep()
             torch.cuda.synchronize()
             eg = time.perf_counter() - t0
-            note(f"B={bsz}: train {1e3 * et / k:.3f} ms/step (captured graph incl. batch upload: {1e3 * eg / k:.3f}), filter {1e3 * ef / k:.3f} ms/step")
+            # like for like: the EAGER step with the same per-step upload of a pinned host batch
+            model.train(True)
+            for i in range(10):
+                train_step(hosts[i % 4].copy_to(dev))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(k):
+                train_step(hosts[i % 4].copy_to(dev))
+            torch.cuda.synchronize()
+            eu = time.perf_counter() - t0
+            note(f"B={bsz}: train {1e3 * et / k:.3f} ms/step resident; with a batch upload per step: eager {1e3 * eu / k:.3f}, captured graph {1e3 * eg / k:.3f}; "
+                 f"filter {1e3 * ef / k:.3f} ms/step")
             small[f"b{bsz}"] = {"train_read_sets_per_s": bsz * k / et, "train_ms_per_step": 1e3 * et / k,
+                                "train_eager_with_upload_ms_per_step": 1e3 * eu / k,
                                 "train_graph_read_sets_per_s": bsz * k / eg, "train_graph_ms_per_step": 1e3 * eg / k,
+                                "train_graph_note": "graph and eager_with_upload both include the H2D upload of a new pinned host batch per step; train_ms_per_step is on resident batches",
                                 "filter_read_sets_per_s": bsz * k / ef, "filter_ms_per_step": 1e3 * ef / k}
 
-    # ---- parity of what was just timed: first 2048 variants of resident batch 0 against the CPU oracle ---------------------
+    # ---- BASELINE configs[4]: high-depth stress, mean 600 reads per variant (read sets split over workgroups: layered launches) --
+    stress = None
+    if world == 1 and not args.no_extras and args.data == "resident" and args.depth == "wgs" and args.mode == "both":
+        sb = 1420  # the same ~852 K reads per step as the WGS headline batch
+        pool, sreads = [], 0
+        srng = np.random.default_rng(4040)
+        for _ in range(2):
+            si, sf, sp = synth_arrays(srng, sb, "stress")
+            b = Batch.from_arrays(si, sf, sp, pack=True)
+            b.plan(allow_split=True)
+            pool.append(b.copy_to(dev))
+            sreads += sp.shape[0]
+        sreads /= len(pool)
+        k = 30
+        et, kt, pt = timed("train", pool, k, 6)
+        ef, kf, pf = timed("filter", pool, k, 6)
+        sflops = 2.0 * macs * sreads
+        wgs_train_reads_per_s = reads_per_batch * args.steps / results["train"][0]
+        wgs_filter_reads_per_s = reads_per_batch * args.steps / results["filter"][0]
+
+        def sroof(kernel, flops, ms, launches):
+            ach = flops / (ms * 1e-3) / 1e12
+            return {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
+                    "traffic": None, "kernel": kernel, "kernel_ms": ms, "launches_per_step": launches, "algorithmic_flops_per_step": flops}
+        nl = eng.plan.desc.num_blocks + 1
+        stress = {"workload": f"BASELINE configs[4]: {sb} read sets per step, mean {sreads / sb:.0f} reads per set ({sreads:.0f} reads per step), layered "
+                              f"execution ({nl} launches each way)",
+                  "train": {"value": sb * k / et, "unit": "read-sets/s", "ms_per_step": 1e3 * et / k, **step_stats(et, pt), "reads_per_s": sreads * k / et,
+                            "per_read_rate_vs_wgs": (sreads * k / et) / wgs_train_reads_per_s,
+                            "roofline": sroof("pmt_backward_kernel<..., layered>", 2.0 * sflops, kt["pmt_backward"], nl)},
+                  "filter": {"value": sb * k / ef, "unit": "read-sets/s", "ms_per_step": 1e3 * ef / k, **step_stats(ef, pf), "reads_per_s": sreads * k / ef,
+                             "per_read_rate_vs_wgs": (sreads * k / ef) / wgs_filter_reads_per_s,
+                             "roofline": sroof("pmt_forward_kernel<..., layered>", sflops, kf["pmt_forward"], nl)}}
+        note(f"stress: train {1e3 * et / k:.3f} ms/step ({stress['train']['per_read_rate_vs_wgs']:.2f} x the WGS per-read rate), "
+             f"filter {1e3 * ef / k:.3f} ms/step ({stress['filter']['per_read_rate_vs_wgs']:.2f} x)")
+        del pool
+
+    # ---- BASELINE configs[1] / [2] as DATASETS: batches streamed from host memory through the device chunk loader -------------
+    loader = None
+    if world == 1 and not args.no_extras and args.data == "resident" and args.depth == "wgs" and args.mode == "both":
+        from permutect_amd.data.memory_mapped_data import MemoryMappedData
+        from permutect_amd.data.reads_dataset import ReadsDataset
+        from permutect_amd.tools.posterior_data import make_posterior_mmap
+        t0 = time.perf_counter()
+        lrng = np.random.default_rng(5050)
+        li, lf, lp = synth_arrays(lrng, 1 << 20, "wgs")
+        ds1 = ReadsDataset(MemoryMappedData.from_arrays(li, lf, lp)).pin_memory()
+        note(f"loader: 2^20-variant dataset in page-locked host memory ({time.perf_counter() - t0:.1f} s)")
+        bsz, chunk = args.batch, 1 << 18
+
+        def epochs(shuffle):
+            while True:
+                for cb in ds1.device_loader(bsz, dev, chunk_variants=chunk, rng=lrng, shuffle=shuffle):
+                    if cb.size() == bsz:
+                        yield cb
+
+        def timed_stream(mode, gen, steps, warmup):
+            model.train(mode == "train")
+            fn = train_step if mode == "train" else filter_step
+            for _ in range(warmup):
+                fn(next(gen))
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(steps):
+                fn(next(gen))
+            torch.cuda.synchronize()
+            return time.perf_counter() - t
+        per_epoch = (1 << 20) // bsz
+        k_train = 2 * per_epoch
+        et = timed_stream("train", epochs(True), k_train, per_epoch)          # one epoch of warm-up, two timed: 2^21 variants
+        train_rate = bsz * k_train / et
+        # filter_variants over 5 x 2^20 candidates, INCLUDING the posterior hand-off (tools/posterior_data.make_posterior_mmap:
+        # rows back on the host in dataset order): the five-fold dataset repeats the 2^20 synthetic variants
+        ds5 = ReadsDataset(MemoryMappedData.from_arrays(np.concatenate([li] * 5), np.concatenate([lf] * 5), np.concatenate([lp] * 5))).pin_memory()
+        n5 = len(ds5)
+        make_posterior_mmap(ds1, model, bsz, chunk_variants=chunk)               # warm-up pass over 2^20
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        post = make_posterior_mmap(ds5, model, bsz, chunk_variants=chunk)
+        ep = time.perf_counter() - t
+        k_filter = n5 // bsz
+        model.train(False)
+        gen5 = (cb for cb in ds5.device_loader(bsz, dev, chunk_variants=chunk, shuffle=False))
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for cb in gen5:
+            filter_step(cb)
+        torch.cuda.synchronize()
+        ef = time.perf_counter() - t
+        resident_train = args.batch * args.steps / results["train"][0]
+        resident_filter = args.batch * args.steps / results["filter"][0]
+        loader = {"workload": "batches composed on the device from 2^18-variant chunks that the device chunk loader streams out of a synthetic dataset "
+                              "in page-locked host memory (H2D inside the timed region)",
+                  "train": {"dataset_variants": 1 << 20, "value": train_rate, "unit": "read-sets/s", "ms_per_step": 1e3 * et / k_train, "steps": k_train,
+                            "timed_s": et, "vs_resident": train_rate / resident_train},
+                  "filter": {"dataset_variants": n5, "value": n5 / ef, "unit": "read-sets/s", "ms_per_step": 1e3 * ef / k_filter, "timed_s": ef,
+                             "vs_resident": (n5 / ef) / resident_filter},
+                  "filter_with_posterior_handoff": {"dataset_variants": n5, "value": n5 / ep, "unit": "read-sets/s", "timed_s": ep,
+                                                    "vs_resident": (n5 / ep) / resident_filter, "rows_out": int(post.num_data),
+                                                    "what": "make_posterior_mmap: forward + rows (logit as float16, embedding) back in host memory in dataset order"}}
+        note(f"loader: train {loader['train']['ms_per_step']:.3f} ms/step = {loader['train']['vs_resident']:.2f} x resident; filter "
+             f"{loader['filter']['ms_per_step']:.3f} ms/step = {loader['filter']['vs_resident']:.2f} x resident; with the posterior hand-off "
+             f"{n5 / ep / 1e6:.1f} M read-sets/s = {loader['filter_with_posterior_handoff']['vs_resident']:.2f} x")
+        del ds1, ds5, post, li, lf, lp
+
+    # ---- parity of what was just timed: EVERY variant of resident batch 0 (one whole launch) against the CPU oracle ------------
     parity = None
-    if rank == 0 and not args.no_extras and first_host is not None and args.depth == "wgs":
+    if rank == 0 and not args.no_extras and first_host is not None and args.depth == "wgs" and batches:
         from oracle import artifact_oracle as O  # the checker, never the product path
         from tests.helpers import config_for
         ints, floats, packed = first_host
-        n = min(2048, len(ints))
-        nref, nalt = ints[:, 0].astype(np.int64), ints[:, 1].astype(np.int64)
-        tr = int(nref.sum())
-        rows = np.concatenate([np.arange(int(nref[:n].sum())), tr + np.arange(int(nalt[:n].sum()))])
-        sub = Batch.from_arrays(ints[:n], floats[:n], packed[rows]).copy_to(dev)
         model.train(False)
         with torch.inference_mode():
-            out = model.compute_batch_output(sub)
+            out = model.compute_batch_output(batches[0])
         sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-        i64 = torch.from_numpy(ints[:n].astype(np.int64))
-        ref = O.compute_batch_output(sd, config_for("p0"), torch.from_numpy(O.decode_packed_reads(packed[rows]).astype(np.float32)),
-                                     i64[:, 0], i64[:, 1], torch.from_numpy(floats[:n, 6:].astype(np.float32)), i64[:, 16:])
-        parity = float((out.logits_b.cpu() - ref["logits_b"]).abs().max())
-        note(f"parity: max |logit - oracle| over {n} variants = {parity:.3e}")
-        full = model.compute_batch_output(batches[0]) if batches else out
-        finite = bool(torch.isfinite(full.logits_b).all() and torch.isfinite(full.features_be).all()
+        i64 = torch.from_numpy(ints.astype(np.int64))
+        before = torch.get_num_threads()
+        torch.set_num_threads(min(usable_cpus(), 16))
+        with torch.inference_mode():
+            ref = O.compute_batch_output(sd, config_for("p0"), torch.from_numpy(O.decode_packed_reads(packed).astype(np.float32)),
+                                         i64[:, 0], i64[:, 1], torch.from_numpy(floats[:, 6:].astype(np.float32)), i64[:, 16:])
+        torch.set_num_threads(before)
+        order = torch.from_numpy(np.asarray(batches[0].order, dtype=np.int64))  # resident batches are packed: launch row i = host row order[i]
+        err = (out.logits_b.cpu() - ref["logits_b"][order]).abs()
+        feat_err = float((out.features_be.cpu() - ref["features_be"][order]).abs().max())
+        parity = {"read_sets": int(err.numel()), "max_logit_err": float(err.max()), "p9999_logit_err": float(torch.quantile(err, 0.9999)),
+                  "median_logit_err": float(err.median()), "logit_errs_over_1e4": int((err > 1e-4).sum()), "max_feature_err": feat_err,
+                  "contract": "BASELINE.json north_star: per-variant artifact logits within 1e-4 (fp32) of the reference CPU path; the run "
+                              "fails above it (fp32 mode)"}
+        note(f"parity: max |logit - oracle| over the {err.numel()} variants of resident batch 0 = {parity['max_logit_err']:.3e} "
+             f"(99.99th percentile {parity['p9999_logit_err']:.3e})")
+        finite = bool(torch.isfinite(out.logits_b).all() and torch.isfinite(out.features_be).all()
                       and torch.isfinite(eng.space.theta).all() and torch.isfinite(eng.space.gtheta).all())
-        if not finite or (args.dtype == "f32" and not parity < 1e-3):
-            raise SystemExit(f"bench: outputs diverge from the oracle (max |logit err| {parity}, finite {finite})")
+        ok = parity["max_logit_err"] <= 1e-4
+        if finite and not ok and args.dtype == "f32":
+            # The fp32 reference path is itself a few 1e-5 from the exact result on its worst variants (tests/test_scale_gpu.py
+            # measured it over 2^20 variants).  A variant beyond 1e-4 is therefore recomputed by the oracle in fp64: the run
+            # fails unless EVERY such variant's HIP result is within 1e-4 of the fp64 result and no further from it than 1.5 x
+            # the fp32 oracle's own distance -- i.e. unless the excess is the reference's rounding, not the kernel's.
+            from tests.helpers import oracle_forward, variant_rows
+            inv = torch.empty_like(order)
+            inv[order] = torch.arange(order.numel())
+            bad_launch = torch.nonzero(err > 1e-4).view(-1)           # positions in the launch
+            bad_host = order[bad_launch].numpy()                       # rows of the host arrays
+            ref64 = oracle_forward(sd, config_for("p0"), ints[bad_host], floats[bad_host], variant_rows(ints, packed, bad_host), dtype=torch.float64)["logits_b"]
+            hip_d = (out.logits_b.cpu()[bad_launch].double() - ref64).abs()
+            o32_d = (ref["logits_b"][order][bad_launch].double() - ref64).abs()
+            parity.update(max_hip_vs_fp64=float(hip_d.max()), max_fp32_oracle_vs_fp64=float(o32_d.max()))
+            ok = bool(hip_d.max() <= 1e-4 and hip_d.max() <= 1.5 * max(float(o32_d.max()), 2e-5) and parity["logit_errs_over_1e4"] <= 4)
+            parity["excess_is_the_fp32_reference_rounding"] = ok
+            note(f"parity: {parity['logit_errs_over_1e4']} variant(s) beyond 1e-4 of the fp32 oracle; against fp64: HIP {hip_d.max():.3e}, fp32 oracle {o32_d.max():.3e}")
+        if not finite or (args.dtype == "f32" and not ok):
+            raise SystemExit(f"bench: outputs diverge from the oracle ({parity}, finite {finite})")
 
     if rank == 0:
         head = "train" if "train" in results else "filter"
-        elapsed, roof = results[head]
+        elapsed, roof, stats = results[head]
         value = world * args.batch * args.steps / elapsed
         line = {
             "metric": "read-sets/sec (train fwd+bwd)" if head == "train" else "read-sets/sec (filter fwd)",
             "value": value, "unit": "read-sets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": 1e3 * elapsed / args.steps, **stats, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic" if args.data == "resident" else "synthetic, streamed through the device chunk loader (H2D inclusive)",
             "config": {"workload": ("train_model" if head == "train" else "filter_variants forward")
                        + f" on synthetic 1M-variant-scale {args.depth.upper()} ReadSet batches, hyperparameters P0 (59845 params)",
@@ -497,14 +655,19 @@ def main():
             "roofline": roof,
         }
         if head == "train" and "filter" in results:
-            ef, rf = results["filter"]
+            ef, rf, sf = results["filter"]
             line["filter"] = {"metric": "read-sets/sec (filter fwd)", "value": world * args.batch * args.steps / ef,
-                              "unit": "read-sets/s", "ms_per_step": 1e3 * ef / args.steps, "steps": args.steps,
+                              "unit": "read-sets/s", "ms_per_step": 1e3 * ef / args.steps, **sf, "steps": args.steps,
                               "step": "compute_batch_output under inference_mode, same resident batches", "roofline": rf}
         if small is not None:
             line["small_batch"] = small
+        if stress is not None:
+            line["stress"] = stress
+        if loader is not None:
+            line["loader"] = loader
         if parity is not None:
-            line["parity_check_max_logit_err"] = parity
+            line["parity_check_max_logit_err"] = parity["max_logit_err"]
+            line["parity_check"] = parity
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PMT_ABI_VERSION 5
+#define PMT_ABI_VERSION 6
 
 /* error codes */
 #define PMT_OK 0
@@ -443,6 +443,19 @@ int pmt_build_read_index(const int64_t* row_start, const int32_t* ref_offsets, c
  * Datum): copies `bytes` from src (a memory-mapped file or host array) to dst (a pinned staging buffer) with `threads`
  * worker threads, outside the Python GIL.  Pure host code, no HIP call. */
 int pmt_host_copy(void* dst, const void* src, size_t bytes, int32_t threads);
+/* The host side of one chunk of the device chunk loader in ONE call (no Python, no GIL): the chunk's read counts, the order in
+ * which its variants are consumed (optionally shuffled: Fisher-Yates on a splitmix64 stream seeded by `seed`; then ordered
+ * inside every batch of `batch` variants by pmt_pack_order with `window`), and every batch's group plan (pmt_plan_groups).
+ * Replaces the per-Datum bookkeeping of reference data/reads_dataset.py:141-196 + data/batch.py:41-62 for a whole chunk.
+ *   ints: the dataset's int16 table (row_stride in elements), ref_col / alt_col: its REF_COUNT / ALT_COUNT columns
+ *   ref_host, alt_host [n]: out; ids [n]: out, ids in consumption order (batch k = ids[k * batch, (k + 1) * batch))
+ *   plans [plans_capacity ints]: out, per batch group_start (g + 1) then group_tile_base (g + 1), back to back
+ *   batch_info [batches][4]: out, {offset in plans, groups, total tiles, total reads}
+ * Returns the number of batches; PMT_E_CAPACITY if a read set exceeds one workgroup (plan such a chunk with
+ * pmt_plan_groups_split); PMT_E_WORKSPACE if `plans` is too small (2 * (n + batches) ints always suffice). */
+int pmt_prepare_chunk(const int16_t* ints, int64_t row_stride, int32_t ref_col, int32_t alt_col, int32_t n, int32_t shuffle,
+                      uint64_t seed, int32_t batch, int32_t window, int32_t threads, int32_t* ref_host, int32_t* alt_host,
+                      int64_t* ids, int32_t* plans, int64_t plans_capacity, int32_t* batch_info);
 
 /* Fused read-set forward: decode -> read MLP -> concat -> L gated ref/alt blocks -> reducer -> rotation ->
  * clustering head + per-set sums.  Replaces ArtifactModel.calculate_features + FeatureClustering.calculate_logits

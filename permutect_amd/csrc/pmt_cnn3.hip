@@ -740,24 +740,36 @@ extern "C" size_t pmt_cnn3_stash_floats(const PmtModel* m) {
     return (m && cnn3_covers(m, &f, &b)) ? (size_t)b.stash_per : 0;
 }
 
-static int cnn3_grid(int n, int v, int nw) {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+// the device a launch on `stream` runs on (NOT the calling thread's current device: a caller may hold another one current)
+static int cnn3_stream_device(hipStream_t stream) {
+    int dev = 0;
+    if (hipStreamGetDevice(stream, &dev) != hipSuccess && hipGetDevice(&dev) != hipSuccess) dev = 0;
+    return dev;
+}
+static int cnn3_grid(int n, int v, int nw, int dev) {
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const long long batches = ((long long)n + v - 1) / v, wgs = (batches + nw - 1) / nw;
     return (int)(wgs < cus ? wgs : cus);
 }
 
-// More than 64 KiB of dynamic LDS needs the function attribute.  It is raised once per device and kernel (a property of the
-// loaded code object, not library state that results depend on) and not touched again: the call is not a stream operation and
-// must stay out of a stream capture (engine/graph.py warms up eagerly first).
-static bool cnn3_allow_lds(const void* kernel, size_t bytes, int which) {
-    static size_t allowed[16][2] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-    if (bytes <= allowed[dev][which]) return true;
-    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
-    allowed[dev][which] = bytes;
-    return true;
+// More than 64 KiB of dynamic LDS needs the function attribute.  It is a property of the loaded code object on a device, not
+// library state that results depend on: raised (never lowered) under a mutex, per device and kernel, remembered so that the
+// steady state makes no runtime call.  The call is not a stream operation and must stay out of a stream capture
+// (engine/graph.py warms up eagerly first).  Devices beyond the table are simply set every time.
+#include <mutex>
+static bool cnn3_allow_lds(const void* kernel, size_t bytes, int which, int dev) {
+    static std::mutex mu;
+    static size_t allowed[64][2] = {};
+    std::lock_guard<std::mutex> lock(mu);
+    const bool tabled = dev >= 0 && dev < 64;
+    if (tabled && bytes <= allowed[dev][which]) return true;
+    int cur = -1;
+    const bool switched = hipGetDevice(&cur) == hipSuccess && cur != dev && hipSetDevice(dev) == hipSuccess;
+    const bool ok = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+    if (switched) (void)hipSetDevice(cur);
+    if (ok && tabled) allowed[dev][which] = bytes;
+    return ok;
 }
 
 // 0 = done, 1 = configuration not covered (the caller runs the other kernels), < 0 = error
@@ -768,8 +780,9 @@ extern "C" int pmt_cnn3_try_forward(const PmtModel* model_host, const float* the
     const size_t lds = cnn3_lds_bytes(&c, false, C3_FWD_NW);
     auto kernel = c.S == 21 ? pmt_cnn3_forward_kernel<C3_FWD_V, C3_FWD_NW, 3, 3, 7, 21>   // the reference's 20 + 1 bases of context
                             : pmt_cnn3_forward_kernel<C3_FWD_V, C3_FWD_NW, 3, 3, 7, 0>;  // (cnn3_config admits exactly these instances)
-    if (!cnn3_allow_lds(reinterpret_cast<const void*>(kernel), lds, 0)) return PMT_E_LAUNCH;
-    hipLaunchKernelGGL(kernel, dim3(cnn3_grid(n, C3_FWD_V, C3_FWD_NW)), dim3(64 * C3_FWD_NW), lds, reinterpret_cast<hipStream_t>(stream), c, theta,
+    const int dev = cnn3_stream_device(reinterpret_cast<hipStream_t>(stream));
+    if (!cnn3_allow_lds(reinterpret_cast<const void*>(kernel), lds, 0, dev)) return PMT_E_LAUNCH;
+    hipLaunchKernelGGL(kernel, dim3(cnn3_grid(n, C3_FWD_V, C3_FWD_NW, dev)), dim3(64 * C3_FWD_NW), lds, reinterpret_cast<hipStream_t>(stream), c, theta,
                        (const long long*)haplotypes, (long long)hap_stride, n, out, (long long)out_stride, stash);
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }
@@ -785,7 +798,9 @@ static bool cnn3_ws_fits(const C3Cfg* c) {
 extern "C" size_t pmt_cnn3_workspace_floats(const PmtModel* m) {
     C3Cfg f, b;
     if (!m || !cnn3_covers(m, &f, &b) || !cnn3_ws_fits(&b)) return 0;
-    return (size_t)cnn3_grid(1 << 30, C3_BWD_V, C3_BWD_NW) * cnn3_ws_stride(&b);
+    int dev = 0;  // (sized for the calling thread's current device: the workspace is allocated there)
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    return (size_t)cnn3_grid(1 << 30, C3_BWD_V, C3_BWD_NW, dev) * cnn3_ws_stride(&b);
 }
 
 extern "C" int pmt_cnn3_try_backward(const PmtModel* model_host, const float* theta, const int64_t* haplotypes, int64_t hap_stride, int32_t n,
@@ -795,8 +810,9 @@ extern "C" int pmt_cnn3_try_backward(const PmtModel* model_host, const float* th
     if (!stash || !cnn3_covers(model_host, &cf, &c)) return 1;
     const size_t lds = cnn3_lds_bytes(&c, true, C3_BWD_NW);
     auto kernel = pmt_cnn3_backward_kernel<C3_BWD_V, C3_BWD_NW, 3, 3, 7>;  // (cnn3_config admits exactly the instances compiled here)
-    if (!cnn3_allow_lds(reinterpret_cast<const void*>(kernel), lds, 1)) return PMT_E_LAUNCH;
-    const int grid = cnn3_grid(n, C3_BWD_V, C3_BWD_NW), stride = cnn3_ws_stride(&c);
+    const int dev = cnn3_stream_device(reinterpret_cast<hipStream_t>(stream));
+    if (!cnn3_allow_lds(reinterpret_cast<const void*>(kernel), lds, 1, dev)) return PMT_E_LAUNCH;
+    const int grid = cnn3_grid(n, C3_BWD_V, C3_BWD_NW, dev), stride = cnn3_ws_stride(&c);
     // (a few workgroups: their atomics do not queue, and the fold would be one more launch on a latency-bound step)
     const bool rows = workspace != nullptr && grid >= 8 && cnn3_ws_fits(&c) && workspace_floats >= (size_t)grid * stride;  // else: global atomics
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * C3_BWD_NW), lds, reinterpret_cast<hipStream_t>(stream), c, theta,

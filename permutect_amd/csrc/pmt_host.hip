@@ -286,6 +286,87 @@ extern "C" int pmt_pack_order_batches(const int32_t* ref_counts, const int32_t* 
     return PMT_OK;
 }
 
+// Everything the device chunk loader needs from the HOST for one chunk of the dataset, in one call outside the Python GIL
+// (reference data/reads_dataset.py:141-196 does the same bookkeeping one Datum at a time in Python): the chunk's read counts,
+// the order in which its variants are consumed (shuffled or not, then ordered inside every batch for the group packer), and
+// every batch's group plan.  Returns the number of batches, PMT_E_CAPACITY when some read set needs the split plan (the caller
+// then plans that chunk batch by batch with pmt_plan_groups_split), or another error.
+//   ints / row_stride / ref_col / alt_col: the dataset's int16 table (row stride in elements) and its two count columns
+//   ref_host, alt_host [n]: out, counts in chunk order
+//   ids [n]: out, variant ids (0 .. n-1) in consumption order: batch k is ids[k * batch, (k + 1) * batch)
+//   plans: out, per batch [group_start (g + 1 ints) | group_tile_base (g + 1 ints)], packed back to back; capacity in ints
+//   batch_info [nb][4]: out, {offset of the batch's plan in `plans`, groups g, total tiles, total reads}
+static inline uint64_t splitmix64(uint64_t& x) {
+    uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+extern "C" int pmt_prepare_chunk(const int16_t* ints, int64_t row_stride, int32_t ref_col, int32_t alt_col, int32_t n, int32_t shuffle,
+                                 uint64_t seed, int32_t batch, int32_t window, int32_t threads, int32_t* ref_host, int32_t* alt_host,
+                                 int64_t* ids, int32_t* plans, int64_t plans_capacity, int32_t* batch_info) {
+    if (!ints || !ref_host || !alt_host || !ids || !plans || !batch_info || n < 0 || batch < 1 || window < 1 || row_stride < 1) return PMT_E_INVALID;
+    const int nb = (n + batch - 1) / batch;
+    for (int i = 0; i < n; ++i) {
+        ref_host[i] = ints[(size_t)i * row_stride + ref_col];
+        alt_host[i] = ints[(size_t)i * row_stride + alt_col];
+        if (ref_host[i] < 0 || alt_host[i] < 0) return PMT_E_INVALID;
+        ids[i] = i;
+    }
+    if (shuffle) {  // Fisher-Yates on a splitmix64 stream (unbiased enough for 2^18 ids: the modulo bias is < 2^-45)
+        uint64_t state = seed;
+        for (int i = n - 1; i > 0; --i) {
+            const int j = (int)(splitmix64(state) % (uint64_t)(i + 1));
+            const int64_t t = ids[i]; ids[i] = ids[j]; ids[j] = t;
+        }
+    }
+    if (threads < 1) threads = 1;
+    if (threads > nb) threads = nb;
+    // every batch plans into its own slot of a scratch area (its size is not known beforehand), packed together afterwards
+    const size_t slot = 2 * ((size_t)batch + 1);
+    std::vector<int32_t> scratch((size_t)(nb > 0 ? nb : 1) * slot);
+    std::vector<int> rc((size_t)(nb > 0 ? nb : 1), PMT_OK);
+    auto work = [&](int t) {
+        std::vector<int32_t> r((size_t)batch), a((size_t)batch), order((size_t)batch);
+        std::vector<int64_t> tmp((size_t)batch);
+        for (int k = t; k < nb; k += threads) {
+            const int lo = k * batch, m = (lo + batch <= n ? batch : n - lo);
+            for (int i = 0; i < m; ++i) { r[i] = ref_host[ids[lo + i]]; a[i] = alt_host[ids[lo + i]]; }
+            int e = pmt_pack_order(r.data(), a.data(), m, window, order.data());
+            if (e != PMT_OK) { rc[k] = e; continue; }
+            for (int i = 0; i < m; ++i) tmp[i] = ids[lo + order[i]];
+            for (int i = 0; i < m; ++i) { ids[lo + i] = tmp[i]; r[i] = ref_host[tmp[i]]; a[i] = alt_host[tmp[i]]; }
+            int32_t* gs = scratch.data() + (size_t)k * slot;
+            int32_t* gt = gs + batch + 1;
+            int32_t bad = -1;
+            rc[k] = pmt_plan_groups(r.data(), a.data(), m, gs, gt, &bad);  // >= 0: the number of groups
+            long long reads = 0;
+            for (int i = 0; i < m; ++i) reads += (long long)r[i] + a[i];
+            batch_info[4 * k + 3] = (int32_t)reads;
+        }
+    };
+    if (threads <= 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; ++t) pool.emplace_back(work, t);
+        for (auto& th : pool) th.join();
+    }
+    int64_t at = 0;
+    for (int k = 0; k < nb; ++k) {
+        if (rc[k] < 0) return rc[k];
+        const int g = rc[k];
+        if (at + 2 * ((int64_t)g + 1) > plans_capacity) return PMT_E_WORKSPACE;
+        const int32_t* gs = scratch.data() + (size_t)k * slot;
+        const int32_t* gt = gs + batch + 1;
+        memcpy(plans + at, gs, sizeof(int32_t) * ((size_t)g + 1));
+        memcpy(plans + at + g + 1, gt, sizeof(int32_t) * ((size_t)g + 1));
+        batch_info[4 * k] = (int32_t)at; batch_info[4 * k + 1] = g; batch_info[4 * k + 2] = gt[g];
+        at += 2 * ((int64_t)g + 1);
+    }
+    return nb;
+}
+
 extern "C" int pmt_plan_groups_split(const int32_t* ref_counts, const int32_t* alt_counts, int32_t num_variants, int32_t* span,
                                      int32_t* tile_base, int32_t max_groups, int32_t* needs_layered) {
     if (!ref_counts || !alt_counts || !span || !tile_base || !needs_layered || num_variants < 0 || max_groups < 1) return PMT_E_INVALID;

@@ -84,6 +84,18 @@ class GroupPlan:
         self.total_tiles = int(gt[n])
         self._dev = {}
 
+    @classmethod
+    def from_prepared(cls, group_start: np.ndarray, group_tile_base: np.ndarray, device_views=None) -> "GroupPlan":
+        """A plan that pmt_prepare_chunk computed (whole read sets per group, no split): host arrays of g + 1 ints each and,
+        optionally, their copies already on the device as {str(device): (group_start, group_tile_base, None)}."""
+        self = cls.__new__(cls)
+        self.span = None
+        self.num_groups = len(group_start) - 1
+        self.group_start, self.group_tile_base = group_start, group_tile_base
+        self.total_tiles = int(group_tile_base[-1])
+        self._dev = dict(device_views or {})
+        return self
+
     @property
     def layered(self) -> bool:
         return self.span is not None

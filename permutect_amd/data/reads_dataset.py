@@ -68,6 +68,29 @@ class ReadsDataset:
         sources = np.asarray(self._ints[: self._size, Data.SOURCE.idx]).astype(np.int64)
         self._num_sources = int(sources.max()) + 1 if self._size else 1
         self._totals_slvra = None
+        self._pinned = None  # pin_memory(): the arrays as page-locked torch tensors (ints, floats, reads, starts)
+
+    def pin_memory(self) -> "ReadsDataset":
+        """Move the dataset's arrays into page-locked host memory (once; a dataset that fits host memory).  The device loader
+        then sends a chunk to HBM by DMA straight from the dataset -- no staging copy, which at ~25 GB/s on six threads is
+        slower than the filter forward consumes data (28 MB per 65 536-variant batch every 0.9 ms = 30 GB/s).  A dataset that
+        stays a memory map of a file (larger than memory) keeps the staged path."""
+        if self._pinned is None and torch.cuda.is_available():
+            def pin(arr):
+                arr = np.asarray(arr)
+                t = torch.empty(arr.shape, dtype=torch.from_numpy(np.empty(0, arr.dtype)).dtype, pin_memory=True)
+                if arr.flags["C_CONTIGUOUS"] and arr.nbytes >= (1 << 22):
+                    L.check(L.load().pmt_host_copy(t.data_ptr(), arr.ctypes.data, arr.nbytes, _STAGE_THREADS), "pmt_host_copy")
+                else:
+                    np.copyto(t.numpy(), arr)
+                return t
+            nreads = int(self._starts[self._size])
+            ints, floats = pin(self._ints[: self._size]), pin(self._floats[: self._size])
+            reads = pin(self._reads[:nreads]) if self._reads is not None else None
+            self._pinned = (ints, floats, reads, pin(self._starts))
+            self._ints, self._floats = ints.numpy(), floats.numpy()
+            self._reads = None if reads is None else reads.numpy()
+        return self
 
     # ---- reference accessors (reference :95-112, :198-221) ---------------------------------------------------------------
     def totals_by_label(self):
@@ -82,13 +105,19 @@ class ReadsDataset:
             from permutect_amd.enums import Label, Variation
             from permutect_amd.training.downsampler import (COUNT_BIN_SKIP, MAX_ALT_COUNT, MAX_REF_COUNT, NUM_ALT_COUNT_BINS,
                                                             NUM_REF_COUNT_BINS)
-            ints = np.asarray(self._ints[: self._size]).astype(np.int64)
-            s, lab, v = ints[:, Data.SOURCE.idx], ints[:, Data.LABEL.idx], ints[:, Data.VARIANT_TYPE.idx]
-            r = np.minimum(ints[:, Data.REF_COUNT.idx], MAX_REF_COUNT) // COUNT_BIN_SKIP
-            a = (np.minimum(ints[:, Data.ALT_COUNT.idx], MAX_ALT_COUNT) - 1) // COUNT_BIN_SKIP
             shape = (self._num_sources, len(Label), len(Variation), NUM_REF_COUNT_BINS, NUM_ALT_COUNT_BINS)
-            flat = np.ravel_multi_index((s, lab, v, r, a), shape) if self._size else np.zeros(0, dtype=np.int64)
-            self._totals_slvra = torch.from_numpy(np.bincount(flat, minlength=int(np.prod(shape))).astype(np.float32)).view(shape)
+            total = np.zeros(int(np.prod(shape)), dtype=np.int64)
+            cols = [Data.SOURCE.idx, Data.LABEL.idx, Data.VARIANT_TYPE.idx, Data.REF_COUNT.idx, Data.ALT_COUNT.idx]
+            # five of the ~58 integer columns, a slab of rows at a time: a real dataset is 10^7 - 10^8 variants of a memory MAP,
+            # and every data-parallel rank fits the downsampler from these totals at start-up
+            step = 1 << 20
+            for lo in range(0, self._size, step):
+                part = np.asarray(self._ints[lo:min(lo + step, self._size)][:, cols]).astype(np.int64)
+                s, lab, v = part[:, 0], part[:, 1], part[:, 2]
+                r = np.minimum(part[:, 3], MAX_REF_COUNT) // COUNT_BIN_SKIP
+                a = (np.minimum(part[:, 4], MAX_ALT_COUNT) - 1) // COUNT_BIN_SKIP
+                total += np.bincount(np.ravel_multi_index((s, lab, v, r, a), shape), minlength=total.size)
+            self._totals_slvra = torch.from_numpy(total.astype(np.float32)).view(shape)
         return self._totals_slvra
 
     def num_read_features(self) -> int:
@@ -195,11 +224,42 @@ class PinnedStage:
         return buf[:nbytes].view(dtype).view(shape)
 
 
+class _StagePool:
+    """Sets of pinned staging buffers that outlive a loader: a training run makes a new loader every epoch, and pinning ~115 MB
+    per prefetch slot again each time cost 3 x 70 ms per epoch -- more than an epoch of 16 steps takes.  A loader borrows a set
+    for its lifetime (two loaders alive at once get different sets) and hands it back when its iteration ends."""
+
+    def __init__(self):
+        import threading
+        self._lock = threading.Lock()
+        self._free = []
+
+    def acquire(self):
+        with self._lock:
+            return self._free.pop() if self._free else [PinnedStage() for _ in range(_PREFETCH)]
+
+    def release(self, stages):
+        with self._lock:
+            if len(self._free) < 2:
+                self._free.append(stages)
+
+
+_STAGES = _StagePool()
+
+
 class DeviceChunk:
     """A contiguous range of the dataset in HBM, exactly as it lies on disk."""
 
+    def host_counts(self):
+        if self.ref_host is None:
+            ints = self._dataset._ints
+            self.ref_host = np.asarray(ints[self.lo:self.hi, Data.REF_COUNT.idx]).astype(np.int32)
+            self.alt_host = np.asarray(ints[self.lo:self.hi, Data.ALT_COUNT.idx]).astype(np.int32)
+        return self.ref_host, self.alt_host
+
     def __init__(self, dataset: ReadsDataset, lo: int, hi: int, device: torch.device, stage: Optional[PinnedStage] = None):
         self.lo, self.hi = lo, hi
+        self._dataset = dataset
         r0, r1 = int(dataset._starts[lo]), int(dataset._starts[hi])
         cuda = device.type == "cuda"
         names = iter(("ints", "floats", "reads", "row_start"))
@@ -218,12 +278,18 @@ class DeviceChunk:
                 np.copyto(host.numpy(), arr)
             return host.to(device, non_blocking=cuda)
 
-        self.ints = upload(dataset._ints[lo:hi])                         # int16 [n, 16 + H]
-        self.floats = upload(dataset._floats[lo:hi])                     # float16 [n, 6 + I]
-        self.reads = upload(dataset._reads[r0:r1])                       # uint8 [R, 7 + nf]
-        self.row_start = upload(dataset._starts[lo:hi] - r0)             # int64 [n]
-        self.ref_host = np.asarray(dataset._ints[lo:hi, Data.REF_COUNT.idx]).astype(np.int32)  # the planner's counts
-        self.alt_host = np.asarray(dataset._ints[lo:hi, Data.ALT_COUNT.idx]).astype(np.int32)
+        if dataset._pinned is not None and cuda:  # page-locked dataset: DMA straight from it
+            ints_t, floats_t, reads_t, starts_t = dataset._pinned
+            self.ints = ints_t[lo:hi].to(device, non_blocking=True)
+            self.floats = floats_t[lo:hi].to(device, non_blocking=True)
+            self.reads = reads_t[r0:r1].to(device, non_blocking=True)
+            self.row_start = starts_t[lo:hi].to(device, non_blocking=True) - r0
+        else:
+            self.ints = upload(dataset._ints[lo:hi])                         # int16 [n, 16 + H]
+            self.floats = upload(dataset._floats[lo:hi])                     # float16 [n, 6 + I]
+            self.reads = upload(dataset._reads[r0:r1])                       # uint8 [R, 7 + nf]
+            self.row_start = upload(dataset._starts[lo:hi] - r0)             # int64 [n]
+        self.ref_host = self.alt_host = None  # the planner's counts: filled by the loader (pmt_prepare_chunk) or on demand
         self.nbytes = self.ints.numel() * 2 + self.floats.numel() * 2 + self.reads.numel() + self.row_start.numel() * 8
 
 
@@ -248,7 +314,11 @@ class ChunkBatch(Batch):
         # the variants INSIDE a batch for the group packer even when it does not shuffle, so a consumer that needs the
         # dataset's order (the posterior hand-off) scatters by this index
         self.dataset_index = chunk.lo + np.asarray(ids_host, dtype=np.int64)
-        self._host_counts = (chunk.ref_host[ids_host], chunk.alt_host[ids_host])
+        self.chunk_range = (chunk.lo, chunk.hi)  # the chunk's place in the dataset, and this batch's variants inside the chunk
+        self.chunk_ids = ids                     # (on the device: consumers that write per-variant results in dataset order)
+        self._chunk, self._ids_host = chunk, ids_host  # (the planner's counts of this batch: gathered only if somebody asks)
+        self._host_counts = None
+        self._total_reads = getattr(plan, "total_reads", None)
         self._plan = plan
         self._offsets = None
         self._row_start = chunk.row_start.index_select(0, ids)
@@ -268,12 +338,21 @@ class ChunkBatch(Batch):
                                             alt_off.data_ptr(), stream), "pmt_scan_counts")
                 self._offsets = (ref_off, alt_off)
             ref_off, alt_off = self._offsets
-            total = int(self._host_counts[0].sum()) + int(self._host_counts[1].sum())
+            if self._total_reads is None:
+                rc, ac = self.host_counts()
+                self._total_reads = int(rc.sum()) + int(ac.sum())
+            total = self._total_reads
             index = torch.empty(total, dtype=torch.int64, device=dev)
             L.check(lib.pmt_build_read_index(self._row_start.data_ptr(), ref_off.data_ptr(), alt_off.data_ptr(), b,
                                              index.data_ptr(), stream), "pmt_build_read_index")
             self._read_index = index
         return self._read_index
+
+    def host_counts(self):
+        if self._host_counts is None:
+            rc, ac = self._chunk.host_counts()
+            self._host_counts = (rc[self._ids_host], ac[self._ids_host])
+        return self._host_counts
 
     def get_reads_re(self) -> torch.Tensor:
         from permutect_amd.data.batch import decode_packed_reads
@@ -300,15 +379,54 @@ class DeviceChunkLoader:
         self.hi = (rank + 1) * per if rank < world_size - 1 else n
         self.ranges = dataset._chunk_ranges(chunk_variants, self.lo, self.hi)
         self.bytes_uploaded = 0
-        self._stages = [PinnedStage() for _ in range(_PREFETCH)]  # one per chunk in flight
+        self._stages = None  # borrowed from _STAGES while iterating: one PinnedStage per chunk in flight
 
     def __len__(self) -> int:
         return sum(-(-(hi - lo) // self.batch_size) for lo, hi in self.ranges)
+
+    def _prepare_fast(self, chunk: DeviceChunk, seed: int, stage: PinnedStage):
+        """`_prepare` in one GIL-free library call (pmt_prepare_chunk): counts, consumption order and every batch's group plan
+        written straight into the pinned buffer that is then uploaded with one copy.  None when the chunk holds a read set
+        beyond one workgroup (the split planner takes such a chunk batch by batch: `_prepare`)."""
+        dev, bs, ds = self.device, self.batch_size, self.dataset
+        ints = ds._ints
+        if not (isinstance(ints, np.ndarray) and ints.dtype == np.int16 and ints.strides[1] == 2 and ints.strides[0] % 2 == 0):
+            return None
+        n = chunk.hi - chunk.lo
+        nb = -(-n // bs)
+        cap = 2 * (n + nb)
+        total = 2 * n + cap  # ids (int64 = 2 ints each) first: stays 8-byte aligned
+        host = stage.get("plans", (total,), torch.int32) if dev.type == "cuda" else torch.empty(total, dtype=torch.int32)
+        flat = host.numpy()
+        ref_host, alt_host = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32)
+        info = np.zeros((nb, 4), dtype=np.int32)
+        rc = L.load().pmt_prepare_chunk(ints[chunk.lo:].ctypes.data, ints.strides[0] // 2, Data.REF_COUNT.idx, Data.ALT_COUNT.idx, n,
+                                        1 if self.shuffle else 0, seed & 0xFFFFFFFFFFFFFFFF, bs, 64, 4, ref_host.ctypes.data, alt_host.ctypes.data,
+                                        flat.ctypes.data, flat[2 * n:].ctypes.data, cap, info.ctypes.data)
+        if rc == L.E_CAPACITY:
+            return None
+        L.check(rc, "pmt_prepare_chunk")
+        chunk.ref_host, chunk.alt_host = ref_host, alt_host
+        used = 2 * n + int(info[nb - 1, 0]) + 2 * (int(info[nb - 1, 1]) + 1) if nb else 2 * n
+        flat_dev = host[:used].to(dev, non_blocking=dev.type == "cuda")
+        ids_host = flat[: 2 * n].view(np.int64).copy()  # (the pinned buffer is reused for the next chunk of this slot)
+        ids_dev = flat_dev[: 2 * n].view(torch.int64)
+        out = []
+        for k in range(nb):
+            at, g = 2 * n + int(info[k, 0]), int(info[k, 1])
+            gs_h, gt_h = flat[at:at + g + 1].copy(), flat[at + g + 1:at + 2 * g + 2].copy()
+            plan = GroupPlan.from_prepared(gs_h, gt_h, {str(dev): (flat_dev[at:at + g + 1], flat_dev[at + g + 1:at + 2 * g + 2], None)})
+            plan.total_reads = int(info[k, 3])
+            m = min(bs, n - k * bs)
+            out.append((ids_host[k * bs:k * bs + m], ids_dev[k * bs:k * bs + m], plan))
+        chunk.plans_dev = flat_dev
+        return out
 
     def _prepare(self, chunk: DeviceChunk, ids: np.ndarray, stage: PinnedStage):
         """Everything the chunk's batches need from the host, uploaded ONCE with the chunk: the shuffled variant ids and
         every batch's group plan (one pinned buffer, one copy); returns per batch (ids_host, ids_dev, plan)."""
         dev, bs = self.device, self.batch_size
+        chunk.host_counts()
         # inside a batch the variants go in the order that fills the workgroups best (the batch is a random draw anyway):
         # one GIL-free call for all batches of the chunk
         rc, ac = np.ascontiguousarray(chunk.ref_host[ids]), np.ascontiguousarray(chunk.alt_host[ids])
@@ -338,6 +456,7 @@ class DeviceChunkLoader:
                 at += p.span.size
             p._dev[str(dev)] = (views[0], views[1], span)
             out.append((sl, ids_dev[k * bs:k * bs + len(sl)], p))
+        chunk.plans_dev = flat_dev  # (the ids and plans of its batches are views of this one allocation)
         return out
 
     def _load(self, c: int, seed: int, slot: int):
@@ -346,10 +465,16 @@ class DeviceChunkLoader:
         stage = self._stages[slot]
         lo, hi = self.ranges[c]
         n = hi - lo
-        ids = np.random.default_rng(seed).permutation(n) if self.shuffle else np.arange(n)
+
+        def prepare(chunk):
+            fast = self._prepare_fast(chunk, seed, stage)
+            if fast is not None:
+                return fast
+            ids = np.random.default_rng(seed).permutation(n) if self.shuffle else np.arange(n)
+            return self._prepare(chunk, ids, stage)
         if self.device.type != "cuda":
             chunk = DeviceChunk(self.dataset, lo, hi, self.device)
-            return chunk, self._prepare(chunk, ids, stage)
+            return chunk, prepare(chunk)
         torch.cuda.set_device(self.device)
         side = torch.cuda.Stream(self.device)
         import time
@@ -357,7 +482,7 @@ class DeviceChunkLoader:
         with torch.cuda.stream(side):
             chunk = DeviceChunk(self.dataset, lo, hi, self.device, stage)
             t1 = time.perf_counter()
-            batches = self._prepare(chunk, ids, stage)
+            batches = prepare(chunk)
         t2 = time.perf_counter()
         side.synchronize()
         t3 = time.perf_counter()
@@ -371,17 +496,29 @@ class DeviceChunkLoader:
         from concurrent.futures import ThreadPoolExecutor
         order_c = self.rng.permutation(len(self.ranges)) if self.shuffle else np.arange(len(self.ranges))
         seeds = self.rng.integers(0, 2 ** 63 - 1, size=len(order_c))  # one stream per chunk: the prefetch thread shuffles
-        with ThreadPoolExecutor(max_workers=_PREFETCH) as pool:
-            pending = deque()
+        self._stages = _STAGES.acquire()
+        try:
+            with ThreadPoolExecutor(max_workers=_PREFETCH) as pool:
+                pending = deque()
 
-            def submit(i):
-                if i < len(order_c):
-                    pending.append(pool.submit(self._load, int(order_c[i]), int(seeds[i]), i % _PREFETCH))
-            for i in range(_PREFETCH):
-                submit(i)
-            for i in range(len(order_c)):
-                chunk, batches = pending.popleft().result()
-                submit(i + _PREFETCH)
-                self.bytes_uploaded += chunk.nbytes
-                for ids_host, ids_dev, plan in batches:
-                    yield ChunkBatch(chunk, ids_host, ids_dev, plan)
+                def submit(i):
+                    if i < len(order_c):
+                        pending.append(pool.submit(self._load, int(order_c[i]), int(seeds[i]), i % _PREFETCH))
+                for i in range(_PREFETCH):
+                    submit(i)
+                for i in range(len(order_c)):
+                    chunk, batches = pending.popleft().result()
+                    submit(i + _PREFETCH)
+                    self.bytes_uploaded += chunk.nbytes
+                    if self.device.type == "cuda":
+                        # the chunk was allocated on the prefetch thread's side stream and is consumed on THIS stream: tell the
+                        # allocator, or a chunk dropped while its last batch's kernels are still queued could be handed out again
+                        cur = torch.cuda.current_stream(self.device)
+                        for t in (chunk.ints, chunk.floats, chunk.reads, chunk.row_start, getattr(chunk, "plans_dev", None)):
+                            if t is not None:
+                                t.record_stream(cur)
+                    for ids_host, ids_dev, plan in batches:
+                        yield ChunkBatch(chunk, ids_host, ids_dev, plan)
+        finally:  # (the executor has joined its threads: no copy out of these buffers is left in flight)
+            stages, self._stages = self._stages, None
+            _STAGES.release(stages)

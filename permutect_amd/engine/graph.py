@@ -75,18 +75,29 @@ class StaticBatch(Batch):
     def host_counts(self):
         raise L.PmtError("a StaticBatch has no host-side counts: plan on the batch that is loaded into it")
 
-    def _pinned(self, name: str, arr: np.ndarray) -> torch.Tensor:
-        buf = self._stage.get(name)
-        if buf is None or buf.numel() < arr.size or buf.dtype != torch.from_numpy(arr[:0].copy()).dtype:
-            buf = torch.empty(max(arr.size, 16), dtype=torch.from_numpy(arr[:0].copy()).dtype, pin_memory=True)
-            self._stage[name] = buf
-        view = buf[: arr.size].view(arr.shape)
-        view.numpy()[...] = arr
-        return view
+    _RING = 4  # pinned staging slots for the group plan: a slot is rewritten only after the copies out of it have run
+
+    def _plan_slot(self, n_ints: int):
+        """The next pinned staging slot (int32, capacity for any plan of this batch), free to overwrite: `load` records an event
+        behind the copies it issues from a slot and waits on that event before the slot's next use -- the host may run up to
+        _RING loads ahead of the device and never rewrites bytes a queued copy has yet to read (an earlier version staged every
+        load in ONE buffer: a replay could then see the NEXT batch's group plan)."""
+        if not self._stage:
+            cap = 2 * (self._plan.num_groups + 1) + 1
+            self._stage = {"bufs": [torch.empty(cap, dtype=torch.int32, pin_memory=True) for _ in range(self._RING)],
+                           "events": [None] * self._RING, "at": 0}
+        st = self._stage
+        slot = st["at"] % self._RING
+        st["at"] += 1
+        if st["events"][slot] is not None:
+            st["events"][slot].synchronize()
+        assert n_ints <= st["bufs"][slot].numel()
+        return slot, st["bufs"][slot]
 
     def load(self, src: Batch):
         """Refill the buffers from `src` (a Batch with packed reads, host or device, no gather index).  Asynchronous on the
-        current stream; raises if `src` does not fit the capacity (the caller then steps eagerly)."""
+        current stream; raises if `src` does not fit the capacity (the caller then steps eagerly).  The caller must not rewrite
+        `src`'s own (pinned) tensors before the copies have run; the plan staging in here is safe to run ahead (see _plan_slot)."""
         if src.size() != self._size or src.packed_reads is None or getattr(src, "read_index", None) is not None:
             raise L.PmtError("StaticBatch.load wants a batch of the captured size with packed reads and no gather index")
         plan = src.plan()  # host arrays (raises for read sets beyond one workgroup)
@@ -98,9 +109,18 @@ class StaticBatch(Batch):
         self.float_tensor.copy_(src.float_tensor, non_blocking=nb)
         self.packed_reads[:r].copy_(src.packed_reads, non_blocking=nb)
         g = plan.num_groups
-        self._plan.group_start[: g + 1].copy_(self._pinned("gs", plan.group_start), non_blocking=nb)
-        self._plan.group_tile_base[: g + 1].copy_(self._pinned("gt", plan.group_tile_base), non_blocking=nb)
-        self._plan.num_groups_dev.copy_(self._pinned("ng", np.array([g], dtype=np.int32)), non_blocking=nb)
+        slot, buf = self._plan_slot(2 * (g + 1) + 1)
+        host = buf.numpy()
+        host[: g + 1] = plan.group_start[: g + 1]
+        host[g + 1: 2 * g + 2] = plan.group_tile_base[: g + 1]
+        host[2 * g + 2] = g
+        self._plan.group_start[: g + 1].copy_(buf[: g + 1], non_blocking=nb)
+        self._plan.group_tile_base[: g + 1].copy_(buf[g + 1: 2 * g + 2], non_blocking=nb)
+        self._plan.num_groups_dev.copy_(buf[2 * g + 2: 2 * g + 3], non_blocking=nb)
+        if self.device.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record()
+            self._stage["events"][slot] = ev
         return self
 
 
@@ -158,6 +178,7 @@ class GraphedTrainStep:
         if self._device_steps != self.opt.step_count:  # eager steps were taken in between
             self.opt.set_device_step(self.opt.step_count)
         self.graph.replay()
+        self.model.engine().params_changed()  # the replayed optimizer launch rewrote theta
         self.opt.step_count += 1
         self._device_steps = self.opt.step_count
         return self.total_loss

@@ -37,6 +37,12 @@ class ReadSetEngine:
         self.trigger = torch.zeros(1, dtype=torch.float32, device=device, requires_grad=True)  # see RowsMlpFunction
         self._cnn_ws = None
         self._rows_ws = None
+        # `packed` / phi are functions of the parameters: params_key() changes whenever theta may have changed -- torch's version
+        # counter sees every in-place torch op on theta or on a parameter view (load_state_dict, checkpoint restore, a torch
+        # optimizer on the calibration parameters), `params_changed()` is called by whatever writes theta through a raw pointer
+        # (the fused optimizer kernel, a captured-graph replay, a collective on the flat buffer)
+        self._param_epoch = 0
+        self.packed_for = None  # (params_key, phi) the packed weights were built from, under no_grad only
         self.timers = None  # bench.py sets {'pmt_forward': [], 'pmt_backward': []} to collect (start, end) HIP events
         self.grad_hook = None  # data parallel: BucketedGradAllReduce, told when the early gradient bucket is final
 
@@ -54,6 +60,14 @@ class ReadSetEngine:
             self.timers[name].append((start, end))
 
     # ---- parameters -------------------------------------------------------------------------------------------------
+    def params_changed(self):
+        self._param_epoch += 1
+
+    def params_key(self):
+        # (a Parameter re-bound with `p.data = view` keeps its OWN version counter: in-place writes through a parameter --
+        #  load_state_dict, a torch optimizer -- show up there, writes to the flat buffer on theta's)
+        return (self._param_epoch, self.space.theta._version, sum(p._version for p in self.space.params))
+
     def pack(self, phi: Tensor):
         d = self.plan
         L.check(self.lib.pmt_pack_params(C.byref(d.desc), d.desc_dev.data_ptr(), self.space.theta.data_ptr(),

@@ -7,6 +7,7 @@ amortised-growth memory maps): at 5 M candidates that loop dwarfs the GPU forwar
 as arrays on the device and appended to preallocated host arrays with one copy per batch."""
 from __future__ import annotations
 
+import ctypes as C
 from typing import Optional
 
 import numpy as np
@@ -33,23 +34,93 @@ def posterior_rows(int_tensor: torch.Tensor, float_tensor: torch.Tensor, logits_
 @torch.inference_mode()
 def make_posterior_mmap(dataset: ReadsDataset, model, batch_size: int, device: Optional[torch.device] = None,
                         chunk_variants: Optional[int] = None) -> MemoryMappedData:
-    """`MemoryMappedData.from_generator(generate_posterior_data(...))` of the reference, in dataset order."""
+    """`MemoryMappedData.from_generator(generate_posterior_data(...))` of the reference, in dataset order.
+
+    Nothing waits for the device inside the loop.  The float rows (six scalars with the logit stored through float16, then the
+    float32 embedding: `posterior_rows`) are assembled on the device and scattered to their place inside a per-CHUNK device
+    block (the loader orders the variants of a batch for the group packer, also without shuffling); a finished chunk's block
+    goes to the host as ONE contiguous copy into a pinned buffer, and a helper thread moves it into the result once the copy's
+    event has fired.  The integer rows never touch the device: they are the dataset's own rows with the two counts zeroed,
+    copied by the same helper thread while the GPU works."""
+    import threading
+    from collections import deque
+    from queue import Queue
+    from permutect_amd.engine import lib as L
     device = model._device if device is None else torch.device(device)
     n = len(dataset)
     e = model.reducer.output_dimension()
-    ints_out = np.zeros((n, dataset._ints.shape[-1]), dtype=np.int16)
-    floats_out = np.zeros((n, INFO_START_IDX + e), dtype=np.float32)
+    width = INFO_START_IDX + e
+    ints_out = np.empty((n, dataset._ints.shape[-1]), dtype=np.int16)
+    floats_out = np.empty((n, width), dtype=np.float32)
     model.train(False)
-    done = 0
+    cuda = device.type == "cuda"
+    lib = L.load()
+
+    def host_copy(dst: np.ndarray, src_ptr: int, nbytes: int):
+        if nbytes >= (1 << 22):
+            L.check(lib.pmt_host_copy(dst.ctypes.data, src_ptr, nbytes, 6), "pmt_host_copy")
+        else:
+            C.memmove(dst.ctypes.data, src_ptr, nbytes)
+
+    jobs: Queue = Queue()
+    errors = []
+
+    def worker():
+        try:
+            src = np.ascontiguousarray(dataset._ints[:n]) if not dataset._ints[:n].flags["C_CONTIGUOUS"] else dataset._ints[:n]
+            host_copy(ints_out, src.ctypes.data, ints_out.nbytes)
+            ints_out[:, Data.REF_COUNT.idx] = 0
+            ints_out[:, Data.ALT_COUNT.idx] = 0
+            while True:
+                job = jobs.get()
+                if job is None:
+                    return
+                event, pinned, lo, hi, free = job
+                if event is not None:
+                    event.synchronize()
+                host_copy(floats_out[lo:hi], pinned.data_ptr(), (hi - lo) * width * 4)
+                free.append(pinned)
+        except Exception as exc:  # surfaced by the caller after join
+            errors.append(exc)
+
+    th = threading.Thread(target=worker, daemon=True)
+    th.start()
+    free_pinned: deque = deque()
+    block, block_range, done = None, None, 0
+
+    def flush():
+        nonlocal block
+        if block is None:
+            return
+        lo, hi = block_range
+        if cuda:
+            while not free_pinned and th.is_alive() and jobs.qsize() >= 4:  # at most four chunk blocks in flight
+                th.join(0.0005)
+            pinned = free_pinned.popleft() if free_pinned else torch.empty(block.shape, dtype=torch.float32, pin_memory=True)
+            if pinned.shape[0] < hi - lo:
+                pinned = torch.empty(block.shape, dtype=torch.float32, pin_memory=True)
+            pinned[: hi - lo].copy_(block, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            jobs.put((ev, pinned, lo, hi, free_pinned))
+        else:
+            jobs.put((None, block, lo, hi, deque()))
+        block = None
+
     for batch in dataset.device_loader(batch_size, device, chunk_variants=chunk_variants, shuffle=False):
         out = model.compute_batch_output(batch)
-        ints, floats = posterior_rows(batch.int_tensor, batch.float_tensor, out.logits_b, out.features_be)
-        b = batch.size()
-        # the loader packs the variants of a batch in the order that fills the workgroups (also without shuffling):
-        # rows go back to their place in the dataset
-        ints_out[batch.dataset_index] = ints.cpu().numpy()
-        floats_out[batch.dataset_index] = floats.cpu().numpy()
-        done += b
+        lo, hi = batch.chunk_range
+        if block_range != (lo, hi):
+            flush()
+            block, block_range = torch.empty(hi - lo, width, dtype=torch.float32, device=device), (lo, hi)
+        scalars = batch.float_tensor[:, :INFO_START_IDX].to(torch.float16)
+        scalars[:, Data.CACHED_ARTIFACT_LOGIT.idx] = out.logits_b.to(torch.float16)
+        block.index_copy_(0, batch.chunk_ids, torch.cat((scalars.to(torch.float32), out.features_be.to(torch.float32)), dim=1))
+        done += batch.size()
+    flush()
+    jobs.put(None)
+    th.join()
+    if errors:
+        raise errors[0]
     assert done == n
-    result = MemoryMappedData(ints_out, floats_out, n, None, 0)
-    return result
+    return MemoryMappedData(ints_out, floats_out, n, None, 0)

@@ -51,19 +51,34 @@ class BucketedGradAllReduce:
     point.  `__call__(flat)` (the optimizer's pre-reduce hook, after loss.backward() has returned) reduces
     flat[late_start:] and makes the current stream wait for both.  The sum of the two bucket reductions is the flat SUM
     all-reduce (tests/test_distributed_cpu.py).  Without a call to `early` since the last step (no read-set backward ran,
-    e.g. an empty batch) the whole buffer is reduced in one piece.  Works on CPU tensors (gloo) without streams."""
+    e.g. an empty batch) the whole buffer is reduced in one piece.  Works on CPU tensors (gloo) without streams.
 
-    def __init__(self, group: Optional[dist.ProcessGroup] = None):
+    Contract: ONE backward per optimizer step.  A second `early` while a reduction is pending would add a second backward's
+    local gradients into a bucket that is being (or has been) summed over the ranks -- a data race and a wrong sum -- so it
+    raises; gradient accumulation over several backwards has to use the flat `GradAllReduce` at the step instead.
+
+    `force_active`: run the collectives even in a process group of ONE rank (an all-reduce over one rank is the identity):
+    the RCCL communicator, the side stream and the stream joins of the overlapped path can then be exercised on a single
+    card (tests/test_dp_gpu.py)."""
+
+    def __init__(self, group: Optional[dist.ProcessGroup] = None, force_active: bool = False):
         self.group = group
+        self.force_active = force_active
         self._pending = None   # (work, late_start)
         self._side = None
+        self.early_reductions = 0  # how many early buckets went out on the side stream (tests)
 
     def _active(self) -> bool:
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return self.force_active or dist.get_world_size(self.group) > 1
 
     def early(self, flat_grad: torch.Tensor, late_start: int) -> None:
-        if not self._active() or late_start <= 0 or self._pending is not None:
+        if not self._active() or late_start <= 0:
             return
+        if self._pending is not None:
+            raise RuntimeError("BucketedGradAllReduce: a second backward before the optimizer step (its early bucket is already "
+                               "being reduced); reduce accumulated gradients with GradAllReduce at the step instead")
         bucket = flat_grad[:late_start]
         if flat_grad.is_cuda:
             if self._side is None:
@@ -74,6 +89,7 @@ class BucketedGradAllReduce:
         else:
             work = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending = (work, late_start)
+        self.early_reductions += 1
 
     def __call__(self, flat_grad: torch.Tensor) -> None:
         if not self._active():

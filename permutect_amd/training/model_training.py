@@ -115,6 +115,7 @@ def train_artifact_model(model, train_dataset: ReadsDataset, valid_dataset: Opti
     if dist is not None:
         # replicas start from rank 0's weights (reset_source_predictor drew fresh ones from every rank's own generator)
         dist.broadcast(model.engine().space.theta, src=0)
+        model.engine().params_changed()
         reduce_grads = BucketedGradAllReduce()
         model.engine().grad_hook = reduce_grads  # early bucket: reduced on a side stream under the rest of the backward
     rng = np.random.default_rng(seed + rank)

@@ -55,6 +55,9 @@ class FusedClipAdamW:
                                         self.exp_avg_sq.data_ptr(), space.size, C.byref(hp), self.scratch.data_ptr(),
                                         self.grad_norm.data_ptr(), torch.cuda.current_stream().cuda_stream),
                 "pmt_clip_adamw")
+        eng = getattr(self.model, "_engine", None)
+        if eng is not None:
+            eng.params_changed()  # theta was written through a raw pointer: packed weights / phi of an earlier forward are stale
 
     def set_device_step(self, n: int):
         """the device-resident step counter of `step(step_on_device=True)`: n steps taken so far"""

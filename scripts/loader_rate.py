@@ -24,7 +24,12 @@ t0 = time.perf_counter()
 ints, floats, packed = synth_arrays(rng, n, "wgs")
 print(f"synth {n} variants: {time.perf_counter() - t0:.1f} s", flush=True)
 ds = ReadsDataset(MemoryMappedData.from_arrays(ints, floats, packed))
+if os.environ.get("PMT_PIN_DATASET", "1") != "0":
+    t0 = time.perf_counter()
+    ds.pin_memory()
+    print(f"dataset pinned: {time.perf_counter() - t0:.2f} s", flush=True)
 model = ArtifactModel(p0_params(), device=dev, **P0_DIMS)
+model.engine()  # (built outside inference mode: its buffers are ordinary tensors)
 opt = FusedClipAdamW(model, lr=1e-3, weight_decay=0.01)
 
 

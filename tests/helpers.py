@@ -38,3 +38,28 @@ def load_case(name: str):
         int_array=z["int_array"], float_array=z["float_array"],
     )
     return z, sd, batch
+
+
+def oracle_forward(sd, cfg, ints, floats, packed, dtype=torch.float32):
+    """The oracle's forward on batch arrays (int16 / float16 / packed uint8 rows, ref rows first) in `dtype`.  fp64 is the
+    yardstick that says how far fp32 arithmetic itself is from the exact result -- never a parity target."""
+    i64 = torch.from_numpy(np.asarray(ints).astype(np.int64))
+    old = O.COMPUTE_DTYPE
+    O.COMPUTE_DTYPE = dtype
+    try:
+        with torch.inference_mode():
+            sdd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
+            return O.compute_batch_output(sdd, cfg, torch.from_numpy(O.decode_packed_reads(packed).astype(np.float32)), i64[:, O.REF_COUNT],
+                                          i64[:, O.ALT_COUNT], torch.from_numpy(np.asarray(floats)[:, O.INFO_START:].astype(np.float32)),
+                                          i64[:, O.HAPLOTYPES_START:])
+    finally:
+        O.COMPUTE_DTYPE = old
+
+
+def variant_rows(ints, packed, variants):
+    """(ints rows, float row selector, packed rows) of a subset of a batch's variants: their ref rows, then their alt rows"""
+    nref, nalt = np.asarray(ints)[:, 0].astype(np.int64), np.asarray(ints)[:, 1].astype(np.int64)
+    ro, ao = np.concatenate([[0], np.cumsum(nref)]), int(nref.sum()) + np.concatenate([[0], np.cumsum(nalt)])
+    variants = np.asarray(variants, dtype=np.int64)
+    rows = [packed[ro[v]:ro[v + 1]] for v in variants] + [packed[ao[v]:ao[v + 1]] for v in variants]
+    return np.concatenate(rows) if rows else packed[:0]

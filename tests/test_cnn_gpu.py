@@ -20,13 +20,13 @@ from tests.test_forward_gpu import check_outputs
 
 pytestmark = pytest.mark.gpu
 
-# which family runs which stack.  wave: at most two convolutions with im2col columns <= 96 wide; batched: exactly
-# conv k3 -> pool 2 -> act -> conv k3 -> act -> flatten -> linear on 21 positions (P0_CNN); general: everything.
+# which family runs which stack.  wave: at most two convolutions, at most 32 output channels, im2col columns <= 96 wide;
+# batched: exactly conv k3 -> pool 2 -> act -> conv k3 -> act -> flatten -> linear on 21 positions (P0_CNN); general: everything.
 ACCEPTS = {
     "p0_cnn_legacy": {"auto", "general"},
     "t0_cnn_options": {"auto", "general"},
     "p0_b16": {"auto", "general", "wave", "batched"},
-    "t0_b8": {"auto", "general", "wave"},
+    "t0_b8": {"auto", "general"},  # (64 output channels)
 }
 
 

@@ -113,3 +113,47 @@ def test_validate_sources_requires_data_for_every_source():
         ds.validate_sources()
     ints[1::4, Data.SOURCE.idx] = 1
     assert ReadsDataset(MemoryMappedData.from_arrays(ints, z["float_array"], z["reads"])).validate_sources() == 3
+
+
+def test_prepare_chunk_matches_the_python_path():
+    """pmt_prepare_chunk (one GIL-free call per chunk: counts, consumption order, every batch's group plan) against the loader's
+    Python path (`_prepare`: numpy gathers + pmt_pack_order_batches + one GroupPlan per batch): same ids, same plans, batch by
+    batch, without shuffling; with shuffling a permutation of the chunk whose batches carry exactly the plans of their own counts."""
+    import torch
+    from bench import synth_arrays
+    from permutect_amd.data.batch import GroupPlan
+    from permutect_amd.data.reads_dataset import DeviceChunk, DeviceChunkLoader, PinnedStage
+    ints, floats, packed = synth_arrays(np.random.default_rng(8), 3000, "wgs")
+    ds = ReadsDataset(MemoryMappedData.from_arrays(ints, floats, packed))
+    cpu = torch.device("cpu")
+    for shuffle in (False, True):
+        loader = DeviceChunkLoader(ds, 512, cpu, None, np.random.default_rng(1), shuffle, 0, 1)
+        chunk = DeviceChunk(ds, 100, 2900, cpu)
+        fast = loader._prepare_fast(chunk, seed=77, stage=PinnedStage())
+        assert fast is not None and len(fast) == 6  # 2800 variants: five batches of 512 and one of 240
+        rc, ac = chunk.host_counts()
+        assert np.array_equal(rc, ints[100:2900, 0]) and np.array_equal(ac, ints[100:2900, 1])
+        all_ids = np.concatenate([ids for ids, _, _ in fast])
+        assert np.array_equal(np.sort(all_ids), np.arange(2800))
+        if not shuffle:
+            slow = loader._prepare(DeviceChunk(ds, 100, 2900, cpu), np.arange(2800), PinnedStage())
+            for (ids_f, dev_f, plan_f), (ids_s, dev_s, plan_s) in zip(fast, slow):
+                assert np.array_equal(ids_f, ids_s) and np.array_equal(dev_f.numpy(), ids_s)
+                assert np.array_equal(plan_f.group_start, plan_s.group_start) and np.array_equal(plan_f.group_tile_base, plan_s.group_tile_base)
+                assert plan_f.num_groups == plan_s.num_groups and plan_f.total_tiles == plan_s.total_tiles
+        else:
+            assert not np.array_equal(all_ids, np.arange(2800))
+        for ids_f, dev_f, plan_f in fast:
+            want = GroupPlan(rc[ids_f], ac[ids_f])
+            assert np.array_equal(plan_f.group_start, want.group_start) and np.array_equal(plan_f.group_tile_base, want.group_tile_base)
+            gs, gt, span = plan_f.on(cpu)
+            assert span is None and np.array_equal(gs.numpy(), want.group_start) and np.array_equal(gt.numpy(), want.group_tile_base)
+            assert plan_f.total_reads == int(rc[ids_f].sum() + ac[ids_f].sum())
+    # a read set beyond one workgroup: the fast path declines, the loader plans that chunk with the split planner
+    big = ints.copy()
+    big[5, 0] = 300
+    reads = np.zeros((int(big[:, 0].astype(np.int64).sum() + big[:, 1].astype(np.int64).sum()), 12), dtype=np.uint8)
+    ds2 = ReadsDataset(MemoryMappedData.from_arrays(big, floats, reads))
+    loader = DeviceChunkLoader(ds2, 512, cpu, None, np.random.default_rng(1), False, 0, 1)
+    assert loader._prepare_fast(DeviceChunk(ds2, 0, 3000, cpu), seed=1, stage=PinnedStage()) is None
+    assert sum(b.size() for b in loader) == 3000

@@ -93,9 +93,13 @@ def _bucket_worker(rank, world, init_file, result_file):
     out["flat"] = torch.equal(got, want)
     got2 = flat.clone()
     hook.early(got2, 55000)
-    hook.early(got2, 55000)                                 # a second backward before the step does not reduce twice
+    try:
+        hook.early(got2, 55000)                             # a second backward before the step: refused, never a silent wrong sum
+        out["twice"] = False
+    except RuntimeError:
+        out["twice"] = True
     hook(got2)
-    out["twice"] = torch.equal(got2, want)
+    out["after_refusal"] = torch.equal(got2, want)
     torch.save(out, f"{result_file}.{rank}")
     dist.destroy_process_group()
 

@@ -1,6 +1,6 @@
 """GPU parity: the fused HIP forward (through the C ABI) against the reference's outputs (golden fixtures) and the
-CPU oracle on the same inputs.  Tolerances: capped logits 1e-4 abs (the north-star contract), everything else 2e-5
-relative to the tensor's scale; deep sets (|log-likelihood| ~ 1e3) get 4 ulp of their magnitude."""
+CPU oracle on the same inputs.  Tolerances: capped logits 1e-4 abs (the north-star contract; sets whose summed log-likelihoods
+exceed 256 -- deep sets -- get 2 ulp of that sum where it is larger), everything else 2e-5 relative to the tensor's scale."""
 import numpy as np
 import pytest
 import torch
@@ -18,7 +18,8 @@ pytestmark = pytest.mark.gpu
 def kernel_shape(request, monkeypatch):
     """Every case runs three times: with the kernel instance the library picks for the model (for the P0 fixtures ShapeP0X,
     which has the production widths compiled in), with the tile-exact instance (PMT_SHAPE=tile: ShapeP0, widths read at run
-    time) and with the generic instance (PMT_SHAPE=any); the library reads the variable at every launch."""
+    time) and with the generic instance (PMT_SHAPE=any); the variable is read ONCE, when the model is lowered (engine/plan.py:
+    PmtModel.force_shape / force_cnn), which is why the fixture sets it before `build`."""
     if request.param == "tile":
         monkeypatch.setenv("PMT_SHAPE", "tile")
         monkeypatch.setenv("PMT_CNN_STASH", "0")  # and the haplotype-CNN backward that recomputes its forward
@@ -37,7 +38,7 @@ def build(name, sd):
     return model, dev
 
 
-def _record(name, logit_err, logit_over_tol, lk_over_tol):
+def _record(name, logit_err, logit_over_tol, lk_over_tol, big_sets_err_in_ulp=None):
     """measured errors per fixture, for DESIGN.md section 2 (gpurun_out/parity_errors.jsonl)"""
     import json
     import os
@@ -46,33 +47,41 @@ def _record(name, logit_err, logit_over_tol, lk_over_tol):
         os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
         with open(os.path.join(root, "gpurun_out", "parity_errors.jsonl"), "a") as f:
             f.write(json.dumps({"test": "forward_fixture", "case": name, "instance": os.environ.get("PMT_SHAPE", "auto"),
-                                "max_logit_err": logit_err, "max_logit_err_over_tol": logit_over_tol, "max_lk_err_over_tol": lk_over_tol}) + "\n")
+                                "max_logit_err": logit_err, "max_logit_err_over_tol": logit_over_tol, "max_lk_err_over_tol": lk_over_tol,
+                                "sets_with_sums_over_256_max_err_in_ulp_of_the_sum": big_sets_err_in_ulp}) + "\n")
     except OSError:
         pass
 
 
 def check_outputs(out, z, name, lk_ulps=8):
-    lk = out.logits_bk.cpu().numpy()
+    lk = out.logits_bk.detach().cpu().numpy()
     ref_lk = z["out/logits_bk"]
     mag = np.abs(ref_lk).max(axis=1)
-    tol_b = 1e-4 + 4 * np.spacing(mag.astype(np.float32))  # fp32 resolution of the summed log-likelihoods
-    logit_err = np.abs(out.logits_b.cpu().numpy() - z["out/logits_b"])
-    assert np.all(logit_err <= tol_b), name
+    # The contract, flat: 1e-4 on the capped logit wherever the summed log-likelihoods stay below 256 (every WGS-shaped set).  A
+    # set whose sums are larger (the 100 - 700-read sets of the deep / stress cases: |L| ~ 1e3 .. 1e4, one fp32 ulp = 6e-5 .. 1e-3)
+    # cannot be defined more finely than the ulp of the sums its logit is a difference of -- by the reference either: there the
+    # bound is 2 ulp of the larger sum (round 2 allowed 1e-4 + 4 ulp; measured: <= 0.6 ulp, recorded below).
+    ulp = np.spacing(mag.astype(np.float32))
+    tol_b = np.where(mag < 256.0, 1e-4, np.maximum(1e-4, 2 * ulp))
+    logit_err = np.abs(out.logits_b.detach().cpu().numpy() - z["out/logits_b"])
+    assert np.all(logit_err <= tol_b), (name, float((logit_err / tol_b).max()))
     # every summed log-likelihood on ITS OWN scale: 2e-5 + 8 ulp of that element (a cluster's 5.0 next to another's 2000.0 is
     # held to 2e-5, not to 2e-5 of the batch maximum)
     # (sums over several hundred reads carry ~sqrt(N) ulp of rounding in ANY summation order, the oracle's included: the
     #  tests with 300-700-read sets pass lk_ulps = 16)
     lk_tol = 2e-5 + lk_ulps * np.spacing(np.abs(ref_lk).astype(np.float32))
     assert np.all(np.abs(lk - ref_lk) <= lk_tol), (name, float((np.abs(lk - ref_lk) / lk_tol).max()))
-    _record(name, float(logit_err.max()), float((logit_err / tol_b).max()), float((np.abs(lk - ref_lk) / lk_tol).max()))
+    big = mag >= 256.0
+    _record(name, float(logit_err.max()), float((logit_err / tol_b).max()), float((np.abs(lk - ref_lk) / lk_tol).max()),
+            float((logit_err[big] / ulp[big]).max()) if big.any() else None)
     for k, t in (("features_be", out.features_be), ("ref_features_be", out.ref_features_be),
                  ("artifact_probs_b", out.artifact_probs_b)):
         ref = z["out/" + k]
-        np.testing.assert_allclose(t.cpu().numpy(), ref, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(ref).max())), err_msg=k)
+        np.testing.assert_allclose(t.detach().cpu().numpy(), ref, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(ref).max())), err_msg=k)
     ref = z["out/outlier_binary_logits"]
     # a difference of two summed log-likelihoods (each good to a few ulp of ITS magnitude; the per-set sums are float atomics,
     # so their rounding varies from run to run): 8 ulp of the larger one
-    np.testing.assert_allclose(out.outlier_binary_logits.cpu().numpy(), ref, rtol=2e-5, atol=1e-4 + 8 * np.spacing(mag.astype(np.float32)).max())
+    np.testing.assert_allclose(out.outlier_binary_logits.detach().cpu().numpy(), ref, rtol=2e-5, atol=1e-4 + 8 * np.spacing(mag.astype(np.float32)).max())
 
 
 def test_eval_forward_of_a_dropout_model_matches_reference():
@@ -246,3 +255,46 @@ def test_packed_order_gives_the_same_outputs_per_variant():
     assert torch.allclose(a.logits_b[o], c.logits_b, rtol=1e-5, atol=1e-5)
     assert torch.allclose(a.features_be[o], c.features_be, rtol=1e-5, atol=1e-5)
     assert torch.allclose(a.logits_bk[o], c.logits_bk, rtol=1e-5, atol=2e-4)
+
+
+def test_cached_packed_weights_follow_every_way_the_parameters_change():
+    """Under no_grad the forward reuses the packed weights / parametrizations while the parameters stand still (filter_variants:
+    two launches off every step).  Every way they can move must invalidate that: an optimizer step (the fused kernel writes the
+    flat buffer through a raw pointer), load_state_dict (in-place writes through the Parameters), a direct write to a Parameter."""
+    from permutect_amd.training.optimizer import FusedClipAdamW
+    z, sd, b = load_case("p0_b16")
+    z2, sd2, _ = load_case("p0_saturated")
+    model, dev = build("p0_b16", sd)
+    batch = Batch.from_arrays(b["int_array"], b["float_array"], b["packed_reads"]).copy_to(dev)
+    model.eval()
+
+    def logits():
+        with torch.inference_mode():
+            return model.compute_batch_output(batch).logits_b.clone()
+    first = logits()
+    key = model.engine().params_key()
+    assert torch.equal(logits(), first) and model.engine().params_key() == key and model.engine().packed_for is not None
+    model.load_state_dict(sd2)                         # other weights, same architecture
+    other = logits()
+    assert not torch.allclose(other, first)
+    fresh, _ = build("p0_saturated", sd2)
+    fresh.eval()
+    with torch.inference_mode():
+        assert torch.allclose(fresh.compute_batch_output(batch).logits_b, other, atol=1e-5)
+    model.load_state_dict(sd)
+    assert torch.allclose(logits(), first, atol=1e-6)
+    with torch.no_grad():                               # a direct in-place write to one Parameter
+        model.pre_clustering_transform.translation_e.add_(0.5)
+    moved = logits()
+    assert not torch.allclose(moved, first)
+    model.train(True)                                   # an optimizer step
+    opt = FusedClipAdamW(model, lr=1e-2, weight_decay=0.0)
+    opt.zero_grad()
+    out = model.compute_batch_output(batch)
+    model.compute_batch_losses(out, batch).total_loss.backward()
+    opt.step()
+    model.eval()
+    stepped = logits()
+    assert not torch.allclose(stepped, moved)
+    model.engine().packed_for = None                    # what an uncached forward gives for the same parameters
+    assert torch.equal(logits(), stepped)

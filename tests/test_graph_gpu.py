@@ -51,6 +51,48 @@ def test_graph_replay_matches_eager_steps(nb):
     assert float((opt_e.exp_avg_sq - opt_g.exp_avg_sq).abs().max()) <= 1e-4 * float(opt_e.exp_avg_sq.abs().max())
 
 
+def test_loads_and_replays_without_synchronising_match_eager_steps():
+    """bench.py's loop: pinned host batches, load() + replay back to back with no synchronisation, so the host runs several
+    batches ahead of the device (more loads than StaticBatch has staging slots).  Every replay must have seen ITS batch's
+    group plan: the per-step losses equal the eager steps' on the same sequence."""
+    nb = 1024
+    batches = [_host_batch(nb, 70 + i) for i in range(10)]
+    assert len({b.plan().num_groups for b in batches}) > 1
+    torch.manual_seed(5)
+    eager = ArtifactModel(p0_params(), device=DEV, **P0_DIMS)
+    torch.manual_seed(5)
+    graphed = ArtifactModel(p0_params(), device=DEV, **P0_DIMS)
+    eager.train(True)
+    opt_e = FusedClipAdamW(eager, lr=1e-3, weight_decay=0.01)
+    opt_g = FusedClipAdamW(graphed, lr=1e-3, weight_decay=0.01)
+    losses_e = []
+    for b in batches:
+        d = b.copy_to(DEV)
+        le = eager.compute_batch_losses(eager.compute_batch_output(d), d).total_loss
+        backpropagate(opt_e, le, params_to_clip=eager.parameters())
+        losses_e.append(float(le.detach()))
+    static = StaticBatch(nb, max_reads=26 * nb, device=DEV, int_cols=58, float_cols=77)
+    step = GraphedTrainStep(graphed, opt_g, static)
+    pinned = [b.pin_memory() for b in batches]
+    static.load(pinned[0])
+    step()  # capture (and the first real step) -- then put the model back and run the whole sequence without a sync
+    torch.cuda.synchronize()
+    torch.manual_seed(5)
+    fresh = ArtifactModel(p0_params(), device=DEV, **P0_DIMS)
+    with torch.no_grad():
+        graphed.engine().space.theta.copy_(fresh.engine().space.theta)
+        opt_g.exp_avg.zero_(); opt_g.exp_avg_sq.zero_()
+    opt_g.step_count = 0
+    on_device = []
+    for b in pinned:
+        static.load(b)
+        on_device.append(step().detach().clone())  # (no .item(): nothing waits for the device inside the loop)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose([float(t) for t in on_device], losses_e, rtol=2e-4)
+    te, tg = eager.engine().space.theta, graphed.engine().space.theta
+    assert float((te - tg).abs().max()) <= 2e-5, float((te - tg).abs().max())
+
+
 def test_static_batch_refuses_what_it_cannot_hold():
     static = StaticBatch(64, max_reads=500, device=DEV, int_cols=58, float_cols=77)
     with pytest.raises(L.PmtError, match="capacity"):

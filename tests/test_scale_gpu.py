@@ -14,7 +14,7 @@ import torch
 from oracle import artifact_oracle as O
 from permutect_amd.data.batch import Batch, pack_order
 from permutect_amd.training.optimizer import FusedClipAdamW
-from tests.helpers import config_for, load_case
+from tests.helpers import config_for, load_case, oracle_forward as _oracle_forward
 from tests.test_forward_gpu import build
 
 pytestmark = pytest.mark.gpu
@@ -129,20 +129,6 @@ def test_forward_and_every_gradient_at_scale(kernel_shape, nb):
     assert rel_l2 <= 1e-4, rel_l2
 
 
-def _oracle_forward(sd, cfg, ints, floats, packed, dtype=torch.float32):
-    """the oracle's forward in `dtype` (fp64: the yardstick that says how far fp32 arithmetic itself is from the exact result)"""
-    i64 = torch.from_numpy(ints.astype(np.int64))
-    old = O.COMPUTE_DTYPE
-    O.COMPUTE_DTYPE = dtype
-    try:
-        with torch.inference_mode():
-            sdd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
-            return O.compute_batch_output(sdd, cfg, torch.from_numpy(O.decode_packed_reads(packed).astype(np.float32)), i64[:, O.REF_COUNT],
-                                          i64[:, O.ALT_COUNT], torch.from_numpy(floats[:, O.INFO_START:].astype(np.float32)), i64[:, O.HAPLOTYPES_START:])
-    finally:
-        O.COMPUTE_DTYPE = old
-
-
 def test_filter_sweep_over_a_million_read_sets_stays_inside_the_contract():
     """BASELINE configs[2] at scale: 16 filter launches of 65 536 WGS-shaped read sets (1 048 576 variants, ~13.6 M reads), every
     capped logit against the oracle; the maximum, the 99.99th percentile and the count above 1e-4 go to
@@ -152,7 +138,8 @@ def test_filter_sweep_over_a_million_read_sets_stays_inside_the_contract():
     reference CPU path is itself fp32 arithmetic in ATen's summation order: a summed log-likelihood of 15 reads at |L| ~ 300 carries
     a few ulp (3e-5 each) of its own rounding.  Measured on the first sweep (round 3): ONE of 1 048 576 variants differed by 1.15e-4,
     53 by more than 5e-5.  So every variant that differs from the fp32 oracle by more than 5e-5 is recomputed by the same oracle in
-    fp64, and the test asserts: (a) at most 4 variants per million differ from the fp32 oracle by more than 1e-4, none by more than
+    fp64 (and once more in fp32, in the small batch of candidates: the fp32 oracle's own result for a variant moved by up to 4.9e-5
+    with the batch it was computed in), and the test asserts: (a) at most 4 variants per million differ from the fp32 oracle by more than 1e-4, none by more than
     2e-4; (b) for EVERY such candidate the HIP result is within 1e-4 of the fp64 result -- the excess over the contract is the
     fp32 reference's own distance from the exact value, not the kernel's; (c) over the candidates the kernel is not further from
     fp64 than the fp32 oracle is (ratio of the two worst distances <= 1.5)."""
@@ -192,7 +179,9 @@ def test_filter_sweep_over_a_million_read_sets_stays_inside_the_contract():
         ref64 = _oracle_forward(sd, cfg, c_ints, c_floats, c_packed, dtype=torch.float64)["logits_b"].numpy()
         again32 = _oracle_forward(sd, cfg, c_ints, c_floats, c_packed)["logits_b"].numpy()
         gpu, o32 = np.array(cand["gpu"], dtype=np.float64), np.array(cand["o32"], dtype=np.float64)
-        assert np.abs(again32 - o32).max() <= 2e-5  # (a variant's result does not depend on its batch beyond the summation order)
+        # the fp32 oracle's OWN answer for the same variant moves with the batch it is computed in (ATen picks its GEMM blocking and
+        # summation order by size): measured 4.9e-5 between the 65 536-set batch and the batch of candidates -- half the contract
+        rec["fp32_oracle_batch_dependence"] = float(np.abs(again32 - o32).max())
         gpu_vs_64, o32_vs_64 = float(np.abs(gpu - ref64).max()), float(np.abs(o32 - ref64).max())
         rec.update(candidates=len(gpu), max_hip_vs_fp64=gpu_vs_64, max_fp32_oracle_vs_fp64=o32_vs_64,
                    mean_hip_vs_fp64=float(np.abs(gpu - ref64).mean()), mean_fp32_oracle_vs_fp64=float(np.abs(o32 - ref64).mean()))

@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 def kernel_shape(request, monkeypatch):
     """Every case runs three times: with the kernel instance the library picks for the model (for the P0 fixtures ShapeP0X,
     which has the production widths compiled in), with the tile-exact instance (PMT_SHAPE=tile: ShapeP0, widths read at run
-    time) and with the generic instance (PMT_SHAPE=any); the library reads the variable at every launch."""
+    time) and with the generic instance (PMT_SHAPE=any); the variable is read ONCE, when the model is lowered (engine/plan.py:
+    PmtModel.force_shape / force_cnn), which is why the fixture sets it before the model is built."""
     if request.param == "tile":
         monkeypatch.setenv("PMT_SHAPE", "tile")
         monkeypatch.setenv("PMT_CNN_STASH", "0")  # and the haplotype-CNN backward that recomputes its forward
