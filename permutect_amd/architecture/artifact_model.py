@@ -116,7 +116,10 @@ class ArtifactModel(nn.Module):
     def engine(self) -> ReadSetEngine:
         """Flattens the parameters into one buffer and lowers the model to the device descriptor (once)."""
         if self._engine is None:
-            self._engine = ReadSetEngine(self, self._device)
+            # (built as ordinary tensors also when the first forward happens under torch.inference_mode: the flat buffers are
+            #  written in place by later training steps, and their version counters key the packed-weight cache)
+            with torch.inference_mode(False):
+                self._engine = ReadSetEngine(self, self._device)
         return self._engine
 
     def _invalidate_engine(self):
@@ -172,13 +175,13 @@ class ArtifactModel(nn.Module):
         # weights -> parametrizations (phi) -> MFMA fragment order (packed).  While the parameters do not change -- every forward
         # of filter_variants and of an evaluation pass -- both are reused: two launches and their gaps off every step.
         key = eng.params_key()
-        if not torch.is_grad_enabled() and eng.packed_for is not None and eng.packed_for[0] == key:
+        if key is not None and not torch.is_grad_enabled() and eng.packed_for is not None and eng.packed_for[0] == key:
             phi = eng.packed_for[1]
         else:
             prog = eng.plan.phi_program(self)
             phi = eng.plan.materialize_phi(self) if prog is None else PhiFunction.apply(eng, prog, eng.trigger)
             eng.pack(phi.detach().contiguous())  # once per forward when training, before any kernel uses the weights
-            eng.packed_for = (key, phi.detach()) if not torch.is_grad_enabled() else None
+            eng.packed_for = (key, phi.detach()) if (key is not None and not torch.is_grad_enabled()) else None
         variant_embed = self.variant_embedding(batch)
         outs = ReadSetFunction.apply(eng, batch, phi, variant_embed)
         return outs, variant_embed

@@ -26,6 +26,9 @@
 #ifndef PMT_BWD_XH4_AT_P3
 #define PMT_BWD_XH4_AT_P3 0  // (measured: 2.94 -> 3.04 ms: the in-order memory counter makes the phase's small loads wait for it)
 #endif
+#ifndef PMT_BWD_PRIO
+#define PMT_BWD_PRIO 0
+#endif
 #ifndef PMT_BWD_FRAG_AHEAD
 #define PMT_BWD_FRAG_AHEAD 3
 #endif
@@ -309,6 +312,9 @@ DEV void backward_group(
                 }
             }
             if (side == 1) {
+                // (wave-uniform reciprocals, once per cluster: every division below was an IEEE sequence of ~10 instructions)
+                const float inv_s2 = fast_rcp(1.4142135623730951f * sg), inv_tau = fast_rcp(tau), inv_tau2 = inv_tau * inv_tau;
+                const float var = sg * sg, inv_lam = fast_rcp(lam), inv_2var = fast_rcp(1.4142135623730951f * var);
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt) {
                     const int set = tm[rt].set;
@@ -320,9 +326,9 @@ DEV void backward_group(
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
                                 if (t < nte && feat_of(t, j, g) < E) {
-                                    const float av = a[rt][t][j], sv = sig[t][j], inv2 = 1.f / (sv * sv);
+                                    const float av = a[rt][t][j], inv_sv = fast_rcp(sig[t][j]), inv2 = inv_sv * inv_sv;
                                     da[rt][t][j] += -(g0 + 0.25f * g1) * av * inv2;
-                                    dsig[t][j] += g0 * (-1.f / sv + av * av * inv2 / sv) + g1 * (-1.f / sv + 0.25f * av * av * inv2 / sv);
+                                    dsig[t][j] += g0 * (-inv_sv + av * av * inv2 * inv_sv) + g1 * (-inv_sv + 0.25f * av * av * inv2 * inv_sv);
                                 }
                         continue;
                     }
@@ -342,11 +348,10 @@ DEV void backward_group(
                         }
                     o2 = group_sum(o2);
                     eu = group_sum(eu);
-                    const float var = sg * sg;
-                    const float zz = (mu + lam * var - p) / (1.4142135623730951f * sg);
+                    const float zz = (mu + lam * var - p) * inv_s2;
                     const float Lp = dlogerfc_dev(zz);
-                    const float demg_dp = -Lp / (1.4142135623730951f * sg) - lam;
-                    const float c_o = -G / (2.f * tau * tau);  // d(loss)/d(o2)
+                    const float demg_dp = -Lp * inv_s2 - lam;
+                    const float c_o = -0.5f * G * inv_tau2;  // d(loss)/d(o2)
 #pragma unroll
                     for (int t = 0; t < NTE; ++t)
 #pragma unroll
@@ -357,10 +362,10 @@ DEV void backward_group(
                                 dvk[t][j] += c_o * (-2.f * eu * a[rt][t][j] - 2.f * p * ee) + G * demg_dp * a[rt][t][j];
                             }
                     if (g == 0) {  // scalar parameter gradients: once per read
-                        d_tau += G * (-(float)(E - 1) / tau + o2 / (tau * tau * tau));
-                        d_mu += G * (Lp / (1.4142135623730951f * sg) + lam);
-                        d_lam += G * (1.f / lam + Lp * sg * 0.7071067811865476f + mu + lam * var - p);
-                        d_sg += G * (Lp * (-(mu - p) / (1.4142135623730951f * var) + lam * 0.7071067811865476f) + lam * lam * sg);
+                        d_tau += G * (-(float)(E - 1) * inv_tau + o2 * inv_tau2 * inv_tau);
+                        d_mu += G * (Lp * inv_s2 + lam);
+                        d_lam += G * (inv_lam + Lp * sg * 0.7071067811865476f + mu + lam * var - p);
+                        d_sg += G * (Lp * (-(mu - p) * inv_2var + lam * 0.7071067811865476f) + lam * lam * sg);
                     }
                 }
             }
@@ -535,9 +540,11 @@ DEV void backward_group(
                     d_alpha += dg * z2v[j];
                     d_beta += dg * (side == 0 ? m_ref[j] : m_alt[j]);
                     if (side == 1) d_gamma += dg * m_ref[j];
-                    const float sg = seg_sum(dg, sp);
-                    if (sp.last && feat_of(0, j, g) < h) atomicAdd(&sh.gsum[set][side][4 * g + j], sg);
                 }
+                const f4 sg4 = seg_sum4(dgate[rt], sp);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (sp.last && feat_of(0, j, g) < h) atomicAdd(&sh.gsum[set][side][4 * g + j], sg4[j]);
             }
             prof_add(c, 9, t_ph);
             trace_ev(c, 19);
@@ -703,17 +710,24 @@ DEV void backward_group(
         const int set = tm[rt].set;
         const SegPlan sp = seg_plan(tm[rt].valid ? set : -1);
 #pragma unroll
-        for (int t = 0; t < NTD; ++t)
+        for (int t = 0; t < NTD; ++t) {
+            if (16 * t + 15 < Er) continue;  // (no lane group holds a variant-embedding feature in this tile of registers)
+            f4 part;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (16 * t + 4 * j + 3 < Er) continue;  // (no lane group holds a variant-embedding feature in this register)
                 const int f = feat_of(t, j, g);
-                const float s = seg_sum((tm[rt].valid && f >= Er && f < D) ? dy[rt][t][j] : 0.f, sp);
+                part[j] = (tm[rt].valid && f >= Er && f < D) ? dy[rt][t][j] : 0.f;
+            }
+            const f4 s4 = seg_sum4(part, sp);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int f = feat_of(t, j, g);
                 if (f >= Er) {
-                    if (sp.last && f < D) atomicAdd(&sh.dv()[set][f - Er], s);
+                    if (sp.last && f < D) atomicAdd(&sh.dv()[set][f - Er], s4[j]);
                     dy[rt][t][j] = 0.f;
                 }
             }
+        }
     }
     lds_barrier();
     for (int i = tid; i < gg.nsets * Ev; i += PMT_THREADS) {  // (written out now: the read MLP's exchanges reuse the LDS)
@@ -782,6 +796,11 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
     __shared__ __attribute__((aligned(16))) BwdShared sh;
     const int ngroups = bt.num_groups_dev != nullptr ? uniform(bt.num_groups_dev[0]) : bt.num_groups;  // (device count: graph replay)
     float* priv = partials != nullptr ? partials + (size_t)blockIdx.x * (size_t)emit_len - emit_base : nullptr;
+#if PMT_BWD_PRIO
+    // the second-dispatched half of the workgroup loses every arbitration for its SIMD's issue slots to the older half
+    // (MI355X_MICROARCH.md, two waves per SIMD, item 4): one static priority for it, set once
+    if (threadIdx.x >= PMT_THREADS / 2) __builtin_amdgcn_s_setprio(1);
+#endif
 #ifdef PMT_X_NOLOOP
     const int grp = blockIdx.x;
     if (grp < ngroups) {

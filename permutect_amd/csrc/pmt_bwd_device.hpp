@@ -144,16 +144,18 @@ DEV f4 selu_bwd4(f4 d, f4 s) {  // d * selu'(a) through the output s = selu(a); 
     return d * gr;
 }
 
-// d/dz of the reference's logerfc (exponentially_modified_gaussian.py:30-55)
+// d/dz of the reference's logerfc (exponentially_modified_gaussian.py:30-55).  Divisions are v_rcp_f32 multiplies (1 ulp: this
+// feeds gradients, whose tolerance is four orders of magnitude wider); an IEEE division is ~10 instructions and the asymptotic
+// branch alone had eight of them, evaluated by every lane whenever one read of the wave is beyond z = 5.
 DEV float dlogerfc_dev(float z) {
     if (z > 5.f) {
-        const float z2 = z * z, z3 = z2 * z, z4 = z2 * z2, z5 = z4 * z, z6 = z4 * z2, z7 = z6 * z;
-        const float q = -1.f / (2.f * z2) + 3.f / (4.f * z4) - 15.f / (8.f * z6);
-        const float dq = 1.f / z3 - 3.f / z5 + 45.f / (4.f * z7);
-        return -2.f * z - 1.f / z + dq / (1.f + q);
+        const float r = fast_rcp(z), r2 = r * r, r3 = r2 * r, r4 = r2 * r2, r5 = r4 * r, r6 = r4 * r2, r7 = r6 * r;
+        const float q = -0.5f * r2 + 0.75f * r4 - 1.875f * r6;
+        const float dq = r3 - 3.f * r5 + 11.25f * r7;
+        return -2.f * z - r + dq * fast_rcp(1.f + q);
     }
     const float e = erfcf(z);
-    return e > 1.0e-12f ? -1.1283791670955126f * expf(-z * z) / e : 0.f;
+    return e > 1.0e-12f ? -1.1283791670955126f * expf(-z * z) * fast_rcp(e) : 0.f;
 }
 
 // Weight gradients contract over READS, and the reads of a workgroup are spread over its waves.  Summing per-wave
@@ -530,8 +532,43 @@ DEV float sub_f32(float a, float b) {
 DEV char* lds_ptr(unsigned byte_address) {  // an LDS address back as a pointer (address space 3 -> generic)
     return (char*)((__attribute__((address_space(3))) char*)(size_t)byte_address);
 }
+#ifndef PMT_STAGE_BLOCK
+#define PMT_STAGE_BLOCK 1
+#endif
+// Two pairs as ONE instruction block: the same six operations per pair, but interleaved two deep (every result is consumed two
+// instructions later) and without the wait state the compiler puts behind every separate
+// inline-asm instruction whose result the next one reads (`s_nop 0`, twice per pair: a fifth of the staging's issue slots).
+DEV void split_pairs_block(float a0, float a1, float b0, float b1, unsigned& h0, unsigned& h1, unsigned& m0, unsigned& m1) {
+    unsigned t0, t1;
+    asm("v_cvt_pk_bf16_f32 %[h0], %[a0], %[b0]\n\t"
+        "v_cvt_pk_bf16_f32 %[h1], %[a1], %[b1]\n\t"
+        "v_lshlrev_b32 %[m0], 16, %[h0]\n\t"
+        "v_lshlrev_b32 %[m1], 16, %[h1]\n\t"
+        "v_and_b32 %[t0], 0xffff0000, %[h0]\n\t"
+        "v_and_b32 %[t1], 0xffff0000, %[h1]\n\t"
+        "v_sub_f32 %[m0], %[a0], %[m0]\n\t"
+        "v_sub_f32 %[m1], %[a1], %[m1]\n\t"
+        "v_sub_f32 %[t0], %[b0], %[t0]\n\t"
+        "v_sub_f32 %[t1], %[b1], %[t1]\n\t"
+        "v_cvt_pk_bf16_f32 %[m0], %[m0], %[t0]\n\t"
+        "v_cvt_pk_bf16_f32 %[m1], %[m1], %[t1]"
+        : [h0] "=&v"(h0), [h1] "=&v"(h1), [m0] "=&v"(m0), [m1] "=&v"(m1), [t0] "=&v"(t0), [t1] "=&v"(t1)
+        : [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1));
+}
 template <int PIECES = 3>
 DEV void stage_pair_bf16(char* const (&pj)[4], int off, f4 v0, f4 v1) {
+    if constexpr (PIECES != 1 && PMT_STAGE_BLOCK) {
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+            unsigned h0, h1, m0, m1;
+            split_pairs_block(v0[j], v0[j + 1], v1[j], v1[j + 1], h0, h1, m0, m1);
+            *reinterpret_cast<unsigned*>(pj[j] + off) = h0;
+            *reinterpret_cast<unsigned*>(pj[j] + off + 1024) = m0;
+            *reinterpret_cast<unsigned*>(pj[j + 1] + off) = h1;
+            *reinterpret_cast<unsigned*>(pj[j + 1] + off + 1024) = m1;
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         char* p = pj[j] + off;

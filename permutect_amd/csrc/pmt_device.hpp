@@ -99,9 +99,13 @@ template <int CTRL>
 DEV int dpp_mov_int(int v, int absent) {  // `absent`: what lanes without a source lane read
     return __builtin_amdgcn_update_dpp(absent, v, CTRL, 0xF, 0xF, false);
 }
+#ifndef PMT_SEG_FMAC
+#define PMT_SEG_FMAC 1
+#endif
 struct SegPlan {
     bool t1, t2, t4, t8;  // lane r - d holds the same set
     bool last;            // the run ends in this lane
+    float m1, m2, m4, m8; // the same as multipliers (1.0 / 0.0): a scan step is ONE v_fmac_f32 with a DPP-shifted operand
 };
 DEV SegPlan seg_plan(int key) {  // key: the read's set, < 0 for lanes without a read
     SegPlan p;
@@ -114,6 +118,7 @@ DEV SegPlan seg_plan(int key) {  // key: the read's set, < 0 for lanes without a
     p.t4 = ok && k4 == key;
     p.t8 = ok && k8 == key;
     p.last = ok && kn != key;
+    p.m1 = p.t1 ? 1.f : 0.f; p.m2 = p.t2 ? 1.f : 0.f; p.m4 = p.t4 ? 1.f : 0.f; p.m8 = p.t8 ? 1.f : 0.f;
     return p;
 }
 template <int CTRL>
@@ -124,7 +129,19 @@ DEV float dpp_mov_all(float v) {
     asm volatile("" : "+v"(t));
     return t;
 }
-DEV float seg_sum(float v, const SegPlan& p) {  // v must be 0 in lanes without a read
+DEV float seg_sum(float v, const SegPlan& p) {  // v must be 0 (and finite everywhere) in lanes without a read
+    if (PMT_SEG_FMAC) {
+        // v += m_d * (v of lane r - d), d = 1, 2, 4, 8: four fused multiply-adds whose first operand comes through the DPP
+        // row shift (lanes without a source lane keep their value; their multiplier is 0 anyway).  Was per step: a move, the
+        // DPP move, a select on a scalar-register mask and an add, with two wait states in between -- six issue slots, and
+        // four scalar register pairs per plan.  s_nop 1 = the two wait states between a VALU write and a DPP read of it.
+        asm("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\tv_fmac_f32_dpp %0, %0, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\tv_fmac_f32_dpp %0, %0, %3 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\tv_fmac_f32_dpp %0, %0, %4 row_shr:8 row_mask:0xf bank_mask:0xf"
+            : "+v"(v) : "v"(p.m1), "v"(p.m2), "v"(p.m4), "v"(p.m8));
+        return v;
+    }
     float t = dpp_mov_all<0x111>(v);
     v += p.t1 ? t : 0.f;
     t = dpp_mov_all<0x112>(v);
@@ -134,6 +151,20 @@ DEV float seg_sum(float v, const SegPlan& p) {  // v must be 0 in lanes without 
     t = dpp_mov_all<0x118>(v);
     v += p.t8 ? t : 0.f;
     return v;
+}
+// four independent values at once: the steps of the four scans interleave, so no wait state is needed between them
+DEV f4 seg_sum4(f4 v, const SegPlan& p) {
+    if (!PMT_SEG_FMAC) return f4{seg_sum(v[0], p), seg_sum(v[1], p), seg_sum(v[2], p), seg_sum(v[3], p)};
+    float a = v[0], b = v[1], c = v[2], d = v[3];
+#define PMT_SEG_STEP(M, SH)                                                            \
+    "v_fmac_f32_dpp %0, %0, %" #M " row_shr:" #SH " row_mask:0xf bank_mask:0xf\n\t"  \
+    "v_fmac_f32_dpp %1, %1, %" #M " row_shr:" #SH " row_mask:0xf bank_mask:0xf\n\t"  \
+    "v_fmac_f32_dpp %2, %2, %" #M " row_shr:" #SH " row_mask:0xf bank_mask:0xf\n\t"  \
+    "v_fmac_f32_dpp %3, %3, %" #M " row_shr:" #SH " row_mask:0xf bank_mask:0xf\n\t"
+    asm("s_nop 1\n\t" PMT_SEG_STEP(4, 1) PMT_SEG_STEP(5, 2) PMT_SEG_STEP(6, 4) PMT_SEG_STEP(7, 8) "s_nop 0"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(p.m1), "v"(p.m2), "v"(p.m4), "v"(p.m8));
+#undef PMT_SEG_STEP
+    return f4{a, b, c, d};
 }
 
 // sum over the 4 lane groups (lanes r, r+16, r+32, r+48): completes a per-read reduction over features
@@ -163,7 +194,24 @@ DEV float selu1(float x) {
 // 4.5 instead of 7 VALU slots per element; SELU is a third of the non-matrix instructions of the MLP layers.  Same
 // formula and roundings as selu1 except that alpha*scale*(e - 1) is one fused multiply-add (e * c - c).
 typedef float f2 __attribute__((ext_vector_type(2)));
+#ifndef PMT_SELU_MINMAX
+#define PMT_SELU_MINMAX 0
+#endif
 DEV f4 selu4(f4 v) {
+    if (PMT_SELU_MINMAX) {
+        // branch-free form: scale * max(x, 0) + min(c e^x - c, 0), c = alpha * scale -- bit for bit the two-branch result (for
+        // x > 0 the second term is 0 and the fma rounds scale * x once; for x <= 0 the first is 0), without the compare /
+        // select pair per element and the wait state between them
+        constexpr float c = PMT_SELU_ALPHA * PMT_SELU_SCALE;
+        f4 r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float e = __builtin_amdgcn_exp2f(v[i] * 1.4426950408889634f);
+            const float neg = fminf(__builtin_fmaf(e, c, -c), 0.f);
+            r[i] = __builtin_fmaf(PMT_SELU_SCALE, fmaxf(v[i], 0.f), neg);
+        }
+        return r;
+    }
     const f2 lo = f2{v[0], v[1]}, hi = f2{v[2], v[3]};
     const f2 tl = lo * 1.4426950408889634f, th = hi * 1.4426950408889634f;
     const f2 el = f2{__builtin_amdgcn_exp2f(tl[0]), __builtin_amdgcn_exp2f(tl[1])};

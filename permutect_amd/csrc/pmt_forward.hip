@@ -261,11 +261,10 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
             {   // per-set sums of z2: segmented reduce over the tile's reads, one LDS add per set and value
                 const SegPlan sp = seg_plan(tmb[rt].valid ? tmb[rt].set : -1);
                 float* dst = &sh.zsum[buf][tmb[rt].set][side][4 * g];
+                const f4 s4 = seg_sum4(tmb[rt].valid ? z[rt][1] : f4{0.f, 0.f, 0.f, 0.f}, sp);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float s = seg_sum(tmb[rt].valid ? z[rt][1][j] : 0.f, sp);
-                    if (sp.last && feat_of(0, j, g) < h) atomicAdd(dst + j, s);
-                }
+                for (int j = 0; j < 4; ++j)
+                    if (sp.last && feat_of(0, j, g) < h) atomicAdd(dst + j, s4[j]);
             }
         }
         }
@@ -420,12 +419,12 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
             const SegPlan sp = seg_plan(tm[rt].valid ? set : -1);
 #pragma unroll
             for (int t = 0; t < NTE; ++t)
+                if (t < nte) {
+                    const f4 s4 = seg_sum4(tm[rt].valid ? a[rt][t] : f4{0.f, 0.f, 0.f, 0.f}, sp);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (t < nte && 16 * t + 4 * j < E) {  // (any lane group holds a feature of this register)
-                        const float s = seg_sum(tm[rt].valid ? a[rt][t][j] : 0.f, sp);
-                        if (sp.last && feat_of(t, j, g) < E) atomicAdd(&sh.fsum[set][side][16 * t + 4 * g + j], s);
-                    }
+                    for (int j = 0; j < 4; ++j)
+                        if (16 * t + 4 * j < E && sp.last && feat_of(t, j, g) < E) atomicAdd(&sh.fsum[set][side][16 * t + 4 * g + j], s4[j]);
+                }
             if (side != 1) continue;
             // nonartifact / outlier diagonal Gaussians
             float q0 = 0.f, q1 = 0.f;

@@ -307,55 +307,76 @@ extern "C" int pmt_prepare_chunk(const int16_t* ints, int64_t row_stride, int32_
                                  int64_t* ids, int32_t* plans, int64_t plans_capacity, int32_t* batch_info) {
     if (!ints || !ref_host || !alt_host || !ids || !plans || !batch_info || n < 0 || batch < 1 || window < 1 || row_stride < 1) return PMT_E_INVALID;
     const int nb = (n + batch - 1) / batch;
-    for (int i = 0; i < n; ++i) {
-        ref_host[i] = ints[(size_t)i * row_stride + ref_col];
-        alt_host[i] = ints[(size_t)i * row_stride + alt_col];
-        if (ref_host[i] < 0 || alt_host[i] < 0) return PMT_E_INVALID;
-        ids[i] = i;
-    }
-    if (shuffle) {  // Fisher-Yates on a splitmix64 stream (unbiased enough for 2^18 ids: the modulo bias is < 2^-45)
-        uint64_t state = seed;
-        for (int i = n - 1; i > 0; --i) {
-            const int j = (int)(splitmix64(state) % (uint64_t)(i + 1));
-            const int64_t t = ids[i]; ids[i] = ids[j]; ids[j] = t;
-        }
-    }
     if (threads < 1) threads = 1;
-    if (threads > nb) threads = nb;
+    auto run = [&](int jobs, auto&& body) {  // body(job) for job in [0, jobs) on up to `threads` host threads
+        const int nt = threads < jobs ? threads : jobs;
+        if (nt <= 1) {
+            for (int j = 0; j < jobs; ++j) body(j);
+            return;
+        }
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nt; ++t)
+            pool.emplace_back([&, t] { for (int j = t; j < jobs; j += nt) body(j); });
+        for (auto& th : pool) th.join();
+    };
+    // the counts: two int16 per 100-byte row (a cache line per variant), gathered by all threads; the shuffle meanwhile
+    std::thread shuffler([&] {
+        for (int i = 0; i < n; ++i) ids[i] = i;
+        if (shuffle) {  // Fisher-Yates on a splitmix64 stream; j = floor(u * (i + 1) / 2^64): unbiased to 2^-45 for i < 2^19
+            uint64_t state = seed;
+            for (int i = n - 1; i > 0; --i) {
+                const int j = (int)(((unsigned __int128)splitmix64(state) * (uint64_t)(i + 1)) >> 64);
+                const int64_t t = ids[i]; ids[i] = ids[j]; ids[j] = t;
+            }
+        }
+    });
+    const int slices = threads * 4;
+    run(slices, [&](int sl) {
+        const int lo = (int)((long long)n * sl / slices), hi = (int)((long long)n * (sl + 1) / slices);
+        for (int i = lo; i < hi; ++i) {
+            ref_host[i] = ints[(size_t)i * row_stride + ref_col];
+            alt_host[i] = ints[(size_t)i * row_stride + alt_col];
+        }
+    });
+    shuffler.join();
+    for (int i = 0; i < n; ++i)
+        if (ref_host[i] < 0 || alt_host[i] < 0) return PMT_E_INVALID;
+    // Packing order inside every batch (pmt_pack_order is sequential: ~60 ns per variant).  A large batch is ordered in two
+    // halves on two threads -- the only cost is one more partly filled group where the halves meet.
+    const int parts = batch >= 16384 ? 2 : 1;
+    std::vector<int> rc((size_t)(nb > 0 ? nb : 1) * parts, PMT_OK);
+    run(nb * parts, [&](int job) {
+        const int k = job / parts, part = job % parts;
+        const int blo = k * batch, m = (blo + batch <= n ? batch : n - blo);
+        const int lo = blo + (int)((long long)m * part / parts), cnt = blo + (int)((long long)m * (part + 1) / parts) - lo;
+        std::vector<int32_t> r((size_t)cnt), a((size_t)cnt), order((size_t)cnt);
+        std::vector<int64_t> tmp((size_t)cnt);
+        for (int i = 0; i < cnt; ++i) { r[i] = ref_host[ids[lo + i]]; a[i] = alt_host[ids[lo + i]]; }
+        const int e = pmt_pack_order(r.data(), a.data(), cnt, window, order.data());
+        if (e != PMT_OK) { rc[job] = e; return; }
+        for (int i = 0; i < cnt; ++i) tmp[i] = ids[lo + order[i]];
+        for (int i = 0; i < cnt; ++i) ids[lo + i] = tmp[i];
+    });
+    for (size_t j = 0; j < rc.size(); ++j)
+        if (rc[j] != PMT_OK) return rc[j];
     // every batch plans into its own slot of a scratch area (its size is not known beforehand), packed together afterwards
     const size_t slot = 2 * ((size_t)batch + 1);
     std::vector<int32_t> scratch((size_t)(nb > 0 ? nb : 1) * slot);
-    std::vector<int> rc((size_t)(nb > 0 ? nb : 1), PMT_OK);
-    auto work = [&](int t) {
-        std::vector<int32_t> r((size_t)batch), a((size_t)batch), order((size_t)batch);
-        std::vector<int64_t> tmp((size_t)batch);
-        for (int k = t; k < nb; k += threads) {
-            const int lo = k * batch, m = (lo + batch <= n ? batch : n - lo);
-            for (int i = 0; i < m; ++i) { r[i] = ref_host[ids[lo + i]]; a[i] = alt_host[ids[lo + i]]; }
-            int e = pmt_pack_order(r.data(), a.data(), m, window, order.data());
-            if (e != PMT_OK) { rc[k] = e; continue; }
-            for (int i = 0; i < m; ++i) tmp[i] = ids[lo + order[i]];
-            for (int i = 0; i < m; ++i) { ids[lo + i] = tmp[i]; r[i] = ref_host[tmp[i]]; a[i] = alt_host[tmp[i]]; }
-            int32_t* gs = scratch.data() + (size_t)k * slot;
-            int32_t* gt = gs + batch + 1;
-            int32_t bad = -1;
-            rc[k] = pmt_plan_groups(r.data(), a.data(), m, gs, gt, &bad);  // >= 0: the number of groups
-            long long reads = 0;
-            for (int i = 0; i < m; ++i) reads += (long long)r[i] + a[i];
-            batch_info[4 * k + 3] = (int32_t)reads;
-        }
-    };
-    if (threads <= 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < threads; ++t) pool.emplace_back(work, t);
-        for (auto& th : pool) th.join();
-    }
+    std::vector<int> groups((size_t)(nb > 0 ? nb : 1), 0);
+    run(nb, [&](int k) {
+        const int lo = k * batch, m = (lo + batch <= n ? batch : n - lo);
+        std::vector<int32_t> r((size_t)m), a((size_t)m);
+        long long reads = 0;
+        for (int i = 0; i < m; ++i) { r[i] = ref_host[ids[lo + i]]; a[i] = alt_host[ids[lo + i]]; reads += (long long)r[i] + a[i]; }
+        int32_t* gs = scratch.data() + (size_t)k * slot;
+        int32_t bad = -1;
+        groups[k] = pmt_plan_groups(r.data(), a.data(), m, gs, gs + batch + 1, &bad);  // >= 0: the number of groups
+        batch_info[4 * k + 3] = (int32_t)reads;
+    });
     int64_t at = 0;
     for (int k = 0; k < nb; ++k) {
-        if (rc[k] < 0) return rc[k];
-        const int g = rc[k];
+        if (groups[k] < 0) return groups[k];
+        const int g = groups[k];
         if (at + 2 * ((int64_t)g + 1) > plans_capacity) return PMT_E_WORKSPACE;
         const int32_t* gs = scratch.data() + (size_t)k * slot;
         const int32_t* gt = gs + batch + 1;

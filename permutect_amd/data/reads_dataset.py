@@ -401,7 +401,7 @@ class DeviceChunkLoader:
         ref_host, alt_host = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32)
         info = np.zeros((nb, 4), dtype=np.int32)
         rc = L.load().pmt_prepare_chunk(ints[chunk.lo:].ctypes.data, ints.strides[0] // 2, Data.REF_COUNT.idx, Data.ALT_COUNT.idx, n,
-                                        1 if self.shuffle else 0, seed & 0xFFFFFFFFFFFFFFFF, bs, 64, 4, ref_host.ctypes.data, alt_host.ctypes.data,
+                                        1 if self.shuffle else 0, seed & 0xFFFFFFFFFFFFFFFF, bs, 64, 8, ref_host.ctypes.data, alt_host.ctypes.data,
                                         flat.ctypes.data, flat[2 * n:].ctypes.data, cap, info.ctypes.data)
         if rc == L.E_CAPACITY:
             return None

@@ -66,7 +66,10 @@ class ReadSetEngine:
     def params_key(self):
         # (a Parameter re-bound with `p.data = view` keeps its OWN version counter: in-place writes through a parameter --
         #  load_state_dict, a torch optimizer -- show up there, writes to the flat buffer on theta's)
-        return (self._param_epoch, self.space.theta._version, sum(p._version for p in self.space.params))
+        try:
+            return (self._param_epoch, self.space.theta._version, sum(p._version for p in self.space.params))
+        except RuntimeError:  # inference tensors (a model built under torch.inference_mode) carry no version counter:
+            return None        # nothing can be proved unchanged, so nothing is reused
 
     def pack(self, phi: Tensor):
         d = self.plan

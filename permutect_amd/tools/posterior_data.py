@@ -65,12 +65,17 @@ def make_posterior_mmap(dataset: ReadsDataset, model, batch_size: int, device: O
     jobs: Queue = Queue()
     errors = []
 
-    def worker():
+    def ints_worker():  # the integer rows: the dataset's own, counts zeroed (never on the device)
         try:
             src = np.ascontiguousarray(dataset._ints[:n]) if not dataset._ints[:n].flags["C_CONTIGUOUS"] else dataset._ints[:n]
             host_copy(ints_out, src.ctypes.data, ints_out.nbytes)
             ints_out[:, Data.REF_COUNT.idx] = 0
             ints_out[:, Data.ALT_COUNT.idx] = 0
+        except Exception as exc:
+            errors.append(exc)
+
+    def worker():       # the float rows: chunk blocks as their device-to-host copies complete
+        try:
             while True:
                 job = jobs.get()
                 if job is None:
@@ -85,6 +90,8 @@ def make_posterior_mmap(dataset: ReadsDataset, model, batch_size: int, device: O
 
     th = threading.Thread(target=worker, daemon=True)
     th.start()
+    th_ints = threading.Thread(target=ints_worker, daemon=True)
+    th_ints.start()
     free_pinned: deque = deque()
     block, block_range, done = None, None, 0
 
@@ -120,6 +127,7 @@ def make_posterior_mmap(dataset: ReadsDataset, model, batch_size: int, device: O
     flush()
     jobs.put(None)
     th.join()
+    th_ints.join()
     if errors:
         raise errors[0]
     assert done == n

@@ -146,7 +146,11 @@ def test_train_artifact_model_loop_end_to_end():
     assert [h[:2] for h in hist] == [(1, "TRAIN"), (1, "VALID"), (2, "TRAIN"), (2, "VALID"), (3, "TRAIN"), (3, "VALID")]
     assert all(np.isfinite(h[2]) and h[2] > 0 for h in hist)
     # one line per epoch half plus the evaluation pass after every validation epoch (3 downsamplings of train + valid)
-    assert len(logs) == 9 and len(evals) == 3 and all(0.0 <= a <= 1.0 and 0.0 <= b <= 1.0 for _, a, b in evals)
+    # (33 training variants: an epoch's mean loss can double from noise alone, and the loop then rolls back to its best checkpoint
+    #  and says so -- the reference's behaviour, training/checkpoint.py:27-32; such lines are allowed, not counted)
+    regular = [ln for ln in logs if "restored the best checkpoint" not in ln]
+    assert len(regular) == 9 and len(logs) - len(regular) <= 2, logs
+    assert len(evals) == 3 and all(0.0 <= a <= 1.0 and 0.0 <= b <= 1.0 for _, a, b in evals)
     # the model still produces finite outputs after training
     with torch.no_grad():
         out = model.compute_batch_output(valid.host_batch(np.arange(len(valid))).copy_to(dev))
