@@ -506,15 +506,18 @@ def main():
             ach = flops / (ms * 1e-3) / 1e12
             return {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
                     "traffic": None, "kernel": kernel, "kernel_ms": ms, "launches_per_step": launches, "algorithmic_flops_per_step": flops}
-        nl = eng.plan.desc.num_blocks + 1
-        stress = {"workload": f"BASELINE configs[4]: {sb} read sets per step, mean {sreads / sb:.0f} reads per set ({sreads:.0f} reads per step), layered "
-                              f"execution ({nl} launches each way)",
+        nl = 1 if eng.join_layered else eng.plan.desc.num_blocks + 1
+        how = ("read sets split over workgroups and JOINED inside one launch each way (per-set sums through HBM + arrival counters, activations in registers)"
+               if eng.join_layered else f"layered execution ({nl} launches each way, activations parked in HBM in between)")
+        torch.cuda.synchronize()
+        eng.check_join_fault()  # (a joined launch that gave up waiting would have produced wrong numbers: fail loudly)
+        stress = {"workload": f"BASELINE configs[4]: {sb} read sets per step, mean {sreads / sb:.0f} reads per set ({sreads:.0f} reads per step); {how}",
                   "train": {"value": sb * k / et, "unit": "read-sets/s", "ms_per_step": 1e3 * et / k, **step_stats(et, pt), "reads_per_s": sreads * k / et,
                             "per_read_rate_vs_wgs": (sreads * k / et) / wgs_train_reads_per_s,
-                            "roofline": sroof("pmt_backward_kernel<..., layered>", 2.0 * sflops, kt["pmt_backward"], nl)},
+                            "roofline": sroof("pmt_backward_kernel<ShapeP0X, split read sets>", 2.0 * sflops, kt["pmt_backward"], nl)},
                   "filter": {"value": sb * k / ef, "unit": "read-sets/s", "ms_per_step": 1e3 * ef / k, **step_stats(ef, pf), "reads_per_s": sreads * k / ef,
                              "per_read_rate_vs_wgs": (sreads * k / ef) / wgs_filter_reads_per_s,
-                             "roofline": sroof("pmt_forward_kernel<..., layered>", sflops, kf["pmt_forward"], nl)}}
+                             "roofline": sroof("pmt_forward_kernel<false, ShapeP0X, split read sets>", sflops, kf["pmt_forward"], nl)}}
         note(f"stress: train {1e3 * et / k:.3f} ms/step ({stress['train']['per_read_rate_vs_wgs']:.2f} x the WGS per-read rate), "
              f"filter {1e3 * ef / k:.3f} ms/step ({stress['filter']['per_read_rate_vs_wgs']:.2f} x)")
         del pool

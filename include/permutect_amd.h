@@ -214,6 +214,11 @@ typedef struct PmtBatch {
                                        capacity the launch is sized for: workgroups beyond it return at once.  Lets one
                                        captured HIP graph (fixed grids) serve batches with different group plans;
                                        pmt_forward / pmt_backward only */
+    const int32_t* set_groups;      /* device, optional [B] (with group_span): how many groups cover each variant, i.e. the
+                                       number of g with span[g].v0 <= b < span[g].v1.  With it pmt_forward_layered /
+                                       pmt_backward_layered run ONE launch each way in which the groups of a split read set
+                                       join their per-set sums through HBM (arrival counters) while the activations stay in
+                                       registers; NULL = num_blocks + 1 launches with the activations parked in between */
 } PmtBatch;
 
 typedef struct PmtOutputs {
@@ -443,6 +448,11 @@ int pmt_build_read_index(const int64_t* row_start, const int32_t* ref_offsets, c
  * Datum): copies `bytes` from src (a memory-mapped file or host array) to dst (a pinned staging buffer) with `threads`
  * worker threads, outside the Python GIL.  Pure host code, no HIP call. */
 int pmt_host_copy(void* dst, const void* src, size_t bytes, int32_t threads);
+/* The same for `rows` rows of `row_bytes` bytes with bytes [zero_offset, zero_offset + zero_bytes) of every row cleared in the
+ * same pass: the integer rows of the posterior hand-off (reference tools/filter_variants.py:305-308: the datum's own integer
+ * array with REF_COUNT and ALT_COUNT set to zero). */
+int pmt_host_copy_rows(void* dst, const void* src, int64_t rows, int64_t row_bytes, int64_t zero_offset, int64_t zero_bytes,
+                       int32_t threads);
 /* The host side of one chunk of the device chunk loader in ONE call (no Python, no GIL): the chunk's read counts, the order in
  * which its variants are consumed (optionally shuffled: Fisher-Yates on a splitmix64 stream seeded by `seed`; then ordered
  * inside every batch of `batch` variants by pmt_pack_order with `window`), and every batch's group plan (pmt_plan_groups).

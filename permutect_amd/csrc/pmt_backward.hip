@@ -48,6 +48,7 @@ struct BwdShared {
     // blocks' last exchange and the read MLP's first).
     f4 stage[PMT_STAGE_PLANES * 64];
     float pf_sink[64];                                          // where stash_prefetch's LDS-DMA drops its dwords (never read)
+    int ticket;                                                 // joined execution: the group this workgroup drew (pmt_join_ticket)
     typedef float DFeat[2][PMT_MAX_WIDTH];                      // d(loss)/d(set mean) / (n + 1e-4), position order
     typedef float DVar[PMT_MAX_WIDTH];                          // per-set sum of d(x_0) (variant-embedding part)
     static constexpr int ALIAS_F4 = (PMT_STAGE_PLANES * 1024 - (int)sizeof(DFeat) * PMT_GROUP_MAX_SETS) / 16;
@@ -93,6 +94,7 @@ struct PmtBwdLayered {
     float* dy_scratch;  // [total_tiles][PMT_SLOT_FLOATS] running gradient
     float* park;        // [total_tiles][6][256]: z1, z2 (after SELU), z2hat, d(gate), d(u), rstd of LayerNorm(h)
     float* gsum_g;      // [B][L][32] per-set sums of d(gate)
+    PmtJoin join;       // join.on: ONE launch; the groups of a split read set join their d(gate) sums through HBM (pmt_device.hpp)
 };
 
 // One group (blockIdx.x of the one-group-per-workgroup launch; `grp` of the persistent one).  priv: this workgroup's private
@@ -432,9 +434,10 @@ DEV void backward_group(
             if (mask_all & (1u << rt)) stash_load<NTD>(stash_tile[rt] + (slot_x0 + l) * PMT_SLOT_FLOATS, xh[rt]);
         }
     };
+    const bool joined = LAYERED && lay.join.on != 0;
     const int l_first = (c.dbg & 4) ? -1 : ((LAYERED && lay.slice > 0) ? L - lay.slice : L - 1);
     for (int l = l_first; l >= 0; --l) {
-        const bool first_half = !LAYERED || l == L - 1 - lay.slice;  // phases 1-2 (up to the per-set sums of d(gate))
+        const bool first_half = !LAYERED || joined || l == L - 1 - lay.slice;  // phases 1-2 (up to the per-set sums of d(gate))
         // Register discipline (this loop body used to spill thousands of VGPRs): nothing of width D except the running
         // gradient dy stays live across phases.  xhat_l = the normalised x_l (stashed by the forward together with one
         // rstd per read) is re-read from the stash (L2/HBM, 4 KB per tile) each of the three times it is needed; z2 / gate
@@ -558,7 +561,17 @@ DEV void backward_group(
             float* pk[PMT_RT];
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) pk[rt] = lay.park + (tile_global + rt) * (6 * 256);
-            if (first_half) {  // end of this launch: join the global sums, park the per-read state and the running gradient
+            if (joined) {  // publish this group's part of the block's d(gate) sums, wait for the other groups of its split sets
+                lds_barrier();
+                pmt_join_sets(lay.join, &sh.gsum[0][0][0], lay.gsum_g + ((size_t)gg.v0 * L + l) * 32, L * 32,
+                              lay.join.arrivals + (size_t)gg.v0 * L + l, L, bt.set_groups + gg.v0, gg.nsets);
+                lds_barrier();
+                aux_push_scalar(c, uniform(B.alpha_src[0]), side == 0 ? d_alpha : 0.f);
+                aux_push_scalar(c, uniform(B.alpha_src[1]), side == 1 ? d_alpha : 0.f);
+                aux_push_scalar(c, uniform(B.beta_src[0]), side == 0 ? d_beta : 0.f);
+                aux_push_scalar(c, uniform(B.beta_src[1]), side == 1 ? d_beta : 0.f);
+                aux_push_scalar(c, uniform(B.gamma_src), d_gamma);
+            } else if (first_half) {  // end of this launch: join the global sums, park the per-read state and the running gradient
                 for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS) {
                     const float v = (&sh.gsum[0][0][0])[i];
                     if (v != 0.f) atomicAdd(&lay.gsum_g[((size_t)(gg.v0 + (i >> 5)) * L + l) * 32 + (i & 31)], v);
@@ -577,7 +590,7 @@ DEV void backward_group(
                     }
                 aux_flush(c);
                 return;
-            }
+            } else {
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) {
                 f4 st[6];
@@ -589,6 +602,7 @@ DEV void backward_group(
             for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS)
                 (&sh.gsum[0][0][0])[i] = lay.gsum_g[((size_t)(gg.v0 + (i >> 5)) * L + l) * 32 + (i & 31)];
             lds_barrier();
+            }
         }
         prof_add(c, 10, t_ph);
         trace_ev(c, 20);
@@ -801,6 +815,17 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
     // (MI355X_MICROARCH.md, two waves per SIMD, item 4): one static priority for it, set once
     if (threadIdx.x >= PMT_THREADS / 2) __builtin_amdgcn_s_setprio(1);
 #endif
+    if (LAYERED && lay.join.on) {
+        // joined execution: groups go out by ticket, so the groups that have started always form a prefix and a group never waits
+        // for one that nobody will run (pmt_device.hpp: PmtJoin)
+        for (;;) {
+            const int grp = pmt_join_ticket(lay.join, &sh.ticket);
+            if (grp >= ngroups) break;
+            backward_group<S, LAYERED>(M, theta, phi, packed, bt, out, dout, stash, zsum_stash, rstd_stash, gtheta, gphi, gvar, lay, grp, sh, priv);
+            lds_barrier();
+        }
+        return;
+    }
 #ifdef PMT_X_NOLOOP
     const int grp = blockIdx.x;
     if (grp < ngroups) {
@@ -889,7 +914,8 @@ extern "C" int pmt_backward(const PmtModel* model_host, const PmtModel* model_de
 extern "C" size_t pmt_layered_backward_scratch_floats(const PmtModel* m, int64_t total_tiles, int32_t num_variants) {
     if (!m) return 0;
     const size_t nb = (size_t)(m->num_blocks > 0 ? m->num_blocks : 1);
-    return (size_t)total_tiles * (PMT_SLOT_FLOATS + 6 * 256) + (size_t)num_variants * nb * 32;
+    // parked state (layered launches only) | per-set d(gate) sums | joined execution: arrival counters [B][L], ticket, fault word
+    return (size_t)total_tiles * (PMT_SLOT_FLOATS + 6 * 256) + (size_t)num_variants * nb * 32 + (size_t)num_variants * nb + 8;
 }
 
 extern "C" int pmt_backward_layered(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* phi,
@@ -918,7 +944,13 @@ extern "C" int pmt_backward_layered(const PmtModel* model_host, const PmtModel* 
     const bool part = use_partials(model_host, shape, grad_partials, num_partials);
     const int grid = part && num_partials < batch->num_groups ? num_partials : batch->num_groups;
     auto kernel = shape >= 2 ? pmt_backward_kernel<ShapeP0X, true> : shape == 1 ? pmt_backward_kernel<ShapeP0, true> : pmt_backward_kernel<ShapeAny, true>;
-    for (int slice = 0; slice <= L; ++slice) {
+    int* join_words = reinterpret_cast<int*>(lay.gsum_g + B * nb * 32);
+    lay.join = PmtJoin{0, join_words + B * nb, join_words, join_words + B * nb + 1};
+    if (batch->set_groups != nullptr && L > 0) {  // ONE launch: the groups of a split read set join their sums through HBM
+        lay.join.on = 1;
+        if (hipMemsetAsync(join_words, 0, (B * nb + 8) * sizeof(int), s) != hipSuccess) return PMT_E_LAUNCH;
+    }
+    for (int slice = 0; slice <= (lay.join.on ? 0 : L); ++slice) {
         lay.slice = slice;
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(PMT_THREADS), 0, s, model_dev, theta, phi, packed, *batch, *out, *dout,
                            stash, zsum_stash, rstd_stash, grad_theta, grad_phi, grad_variant_embed, lay,

@@ -638,6 +638,67 @@ DEV TileMeta tile_meta(const GroupGeom& gg, int rt, const int* s_off) {
     return tm;
 }
 
+// ---- read sets that span several workgroups, joined INSIDE one launch ---------------------------------------------------
+// A read set beyond one workgroup's capacity is split over consecutive groups (pmt_plan_groups_split).  Its per-set sums (the
+// gated blocks' z2 sums in the forward, their d(gate) sums in the backward: reference gated_mlp.py:236-239, sets/
+// ragged_sets.py:144-158) then need every group's part.  The layered launches exchange them through kernel boundaries (L + 1
+// launches each way, every activation parked in HBM in between); here the groups of ONE launch exchange them through HBM while
+// their activations stay in registers:
+//   publish: every group adds its partial sums to the set's global row with device-scope float atomics (they execute at the
+//            memory side: nothing to write back), waits until they are acknowledged (vmcnt(0) in every wave, then the workgroup
+//            barrier), and only then adds 1 to the set's arrival counter;
+//   wait:    one lane per set polls the counter (relaxed device-scope loads, s_sleep in between) until all PmtBatch.set_groups[set]
+//            groups have arrived; the complete sums are then read back with returning atomics (adds of 0: memory-side reads, no
+//            stale cache line on any XCD).
+// Progress: groups are handed out by a device-side TICKET (pmt_join_ticket), so the groups that have started always form a
+// prefix 0 .. T-1; a group waits only for groups within a few indices of its own, which have started (or start as soon as any
+// lower group finishes), provided a few dozen workgroups can be resident at once.  Every wait is bounded: after ~0.2 s it gives
+// up, raises the fault word and carries on with whatever arrived (wrong numbers, no hang); the host checks the word.
+struct PmtJoin {
+    int on;          // 0: not joined
+    int* ticket;     // device, [1]: the next group to hand out (zero at launch)
+    int* arrivals;   // device, [B][L]: groups that have published (variant, block) (zero at launch)
+    int* fault;      // device, [1]: set to 1 when a wait gave up
+};
+DEV int pmt_join_ticket(const PmtJoin& j, int* lds_slot) {
+    if (pmt_tid() == 0) *lds_slot = __hip_atomic_fetch_add(j.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int t = uniform(*lds_slot);
+    __syncthreads();
+    return t;
+}
+// lds: the group's partial sums [nsets][32]; glob / arrivals: the rows / counters of the group's FIRST set for this block, one
+// set apart by set_stride floats / arr_stride ints; expected: PmtBatch.set_groups + v0.  On return `lds` holds the COMPLETE sums
+// of every set (the caller's next LDS barrier publishes them to the workgroup).
+DEV void pmt_join_sets(const PmtJoin& j, float* lds, float* glob, int set_stride, int* arrivals, int arr_stride, const int* expected, int nsets) {
+    const int tid = pmt_tid();
+    for (int i = tid; i < nsets * 32; i += PMT_THREADS) {
+        const float v = lds[i];
+        if (v != 0.f) atomicAdd(&glob[(size_t)(i >> 5) * set_stride + (i & 31)], v);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's atomics have been acknowledged ...
+    __syncthreads();                                  // ... and every other wave's
+    if (tid < nsets) {
+        int* a = arrivals + (size_t)tid * arr_stride;
+        const int need = expected[tid];
+        __hip_atomic_fetch_add(a, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (need > 1) {
+            int spins = 0;
+            while (__hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1 << 17)) {  // ~0.2 s of polls: a legitimate wait is over within a group's run time (~0.2 ms)
+                    __hip_atomic_store(j.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < nsets * 32; i += PMT_THREADS)
+        if (expected[i >> 5] > 1)
+            lds[i] = __hip_atomic_fetch_add(&glob[(size_t)(i >> 5) * set_stride + (i & 31)], 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 extern "C" int pmt_stash_slots(const PmtModel* m);  // host helper (pmt_host.hip)
 extern "C" int pmt_shape_id(const PmtModel* m);     // host: 2 = ShapeP0X (exact widths), 1 = ShapeP0 (exact tiles), 0 = ShapeAny
 

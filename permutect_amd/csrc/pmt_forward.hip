@@ -12,6 +12,7 @@ struct FwdShared {  // (the float tables first: their rows are read and cleared 
     float fsum[PMT_GROUP_MAX_SETS][2][PMT_MAX_WIDTH];
     float hsum[PMT_GROUP_MAX_SETS][PMT_MAX_CLUSTERS + 2];
     int off[2][PMT_GROUP_MAX_SETS + 1];
+    int ticket;  // joined execution: the group this workgroup drew (pmt_join_ticket)
 };
 
 // ---- input decode ------------------------------------------------------------------------------------------------
@@ -41,6 +42,8 @@ DEV float logerfc_dev(float z) {
 
 // Layered execution (pmt_forward_layered): launch `slice` finishes block slice - 1 and starts block slice; per-set sums
 // live in HBM (zsum_g / fsum_g / hsum_g, float atomics), activations rest in x_scratch / z_scratch between launches.
+// JOINED execution (join.on, when the batch carries PmtBatch.set_groups): the same per-set sums in HBM, but ONE launch: a group
+// publishes its part of a block's z2 sums, waits for the other groups of its split sets and carries on -- nothing is parked.
 struct PmtLayeredArgs {
     int slice;
     float* x_scratch;   // [total_tiles][PMT_SLOT_FLOATS]
@@ -48,6 +51,7 @@ struct PmtLayeredArgs {
     float* zsum_g;      // [B][L][32] (the training stash's per-set z2 sums have the same layout and ARE this buffer)
     float* fsum_g;      // [B][2][PMT_MAX_WIDTH]
     float* hsum_g;      // [B][PMT_MAX_CLUSTERS + 2]
+    PmtJoin join;       // join.on: ONE launch, all blocks, the groups of a split read set join their sums through HBM (pmt_device.hpp)
 };
 
 // development: per-wave event log of ONE workgroup (PmtBatch.debug_flags[2] = workgroup + 1; scripts/fwd_trace.py); compiled in
@@ -82,14 +86,18 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
     __shared__ __attribute__((aligned(16))) FwdShared sh;
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
     if (bt.num_groups_dev != nullptr && (int)blockIdx.x >= uniform(bt.num_groups_dev[0])) return;  // grid sized for a capacity (graph replay)
-    const GroupGeom gg = group_geometry(bt, blockIdx.x);
+    const bool joined = LAYERED && lay.join.on != 0;
+    // joined: groups go out by ticket, in the order the workgroups actually start (dispatch order is not promised): the started
+    // groups are always a prefix, which is what makes waiting for a neighbouring group safe
+    const int grp = joined ? pmt_join_ticket(lay.join, &sh.ticket) : (int)blockIdx.x;
+    const GroupGeom gg = group_geometry(bt, grp);
     const int side = gg.side;
 
     const int D = S::DIM_D ? S::DIM_D : uniform(M->d_model), E = S::DIM_E ? S::DIM_E : uniform(M->feature_dim), K = uniform(M->num_clusters);
     const int Er = S::DIM_R ? S::DIM_R : uniform(M->read_embed_dim), Ev = uniform(M->variant_embed_dim);
     const int h = S::DIM_H ? S::DIM_H : (uniform(M->d_ffn) >> 1), L = uniform(M->num_blocks), F = S::DIM_F ? S::DIM_F : uniform(M->num_read_features);
     FwdTrace tr;
-    if (PMT_FWD_TRACE && bt.debug_flags && uniform(bt.debug_flags[2]) == (int)blockIdx.x + 1) tr.buf = bt.debug_flags + 64 + (tid >> 6) * 512;
+    if (PMT_FWD_TRACE && bt.debug_flags && uniform(bt.debug_flags[2]) == grp + 1) tr.buf = bt.debug_flags + 64 + (tid >> 6) * 512;
     tr.ev(1);
 
     // ---- group setup: local offsets, zero the per-set accumulators -------------------------------------------
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
         if (tm[rt].present) mask_all |= 1u << rt;
         stash_tile[rt] = nullptr;
         if (TRAIN)
-            stash_tile[rt] = stash + (size_t)(bt.group_tile_base[blockIdx.x] + gg.tile_begin + rt) * (size_t)(stash_num_slots(M) * PMT_SLOT_FLOATS);
+            stash_tile[rt] = stash + (size_t)(bt.group_tile_base[grp] + gg.tile_begin + rt) * (size_t)(stash_num_slots(M) * PMT_SLOT_FLOATS);
     }
 
     int slot = 0;
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
 
     // ---- decode the packed read rows straight into the B-operand layout, then the read MLP -------------------------
     f4 x[PMT_RT][NTD];
-    const size_t tile_global = (size_t)(bt.group_tile_base[blockIdx.x] + gg.tile_begin);
+    const size_t tile_global = (size_t)(bt.group_tile_base[grp] + gg.tile_begin);
     if (LAYERED && lay.slice > 0) {  // resume: activations of the previous launch
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt) {
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
             if (PMT_OPAQUE_TID) asm volatile("" : "+v"(tmb[rt].set));
         }
         const PmtBlock& B = M->blocks[l];
-        const bool first_half = !LAYERED || l == lay.slice;        // LayerNorm, proj1, SELU, per-set sums of z2
+        const bool first_half = !LAYERED || joined || l == lay.slice;  // LayerNorm, proj1, SELU, per-set sums of z2
         f4 z[PMT_RT][2];
         // packed region A of this block: [W1_ref | W1_alt | b1_ref | b1_alt | LN(D) w,b | LN(h) w,b | rho]
         const PmtLinear& P1r = M->lin[uniform(B.proj1[0])];
@@ -233,7 +241,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
                 if (TRAIN && (mask_all & (1u << rt))) {
                     stash_store<NTD>(stash_tile[rt] + slot * PMT_SLOT_FLOATS, xhat);
                     if (g == 0)
-                        rstd_stash[((size_t)(bt.group_tile_base[blockIdx.x] + gg.tile_begin + rt) * L + l) * 16 + (lane & 15)] = rstd;
+                        rstd_stash[((size_t)(bt.group_tile_base[grp] + gg.tile_begin + rt) * L + l) * 16 + (lane & 15)] = rstd;
                 }
             }
             if (TRAIN) ++slot;
@@ -269,7 +277,11 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
         }
         }
         if constexpr (LAYERED) {
-            if (first_half) {  // end of this launch: the group's partial sums join the global ones; park x and z
+            if (joined) {  // publish this group's part of the block's sums, wait for the other groups of its split sets, read the totals
+                lds_barrier();
+                pmt_join_sets(lay.join, &sh.zsum[buf][0][0][0], lay.zsum_g + ((size_t)gg.v0 * L + l) * 32, L * 32,
+                              lay.join.arrivals + (size_t)gg.v0 * L + l, L, bt.set_groups + gg.v0, gg.nsets);
+            } else if (first_half) {  // end of this launch: the group's partial sums join the global ones; park x and z
                 lds_barrier();
                 for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS) {
                     const float v = (&sh.zsum[buf][0][0][0])[i];
@@ -282,7 +294,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
                         stash_store<2>(lay.z_scratch + (tile_global + rt) * 512, z[rt]);
                     }
                 return;
-            }
+            } else {
             // second half of block l = slice - 1: z from the previous launch, the COMPLETE per-set sums from HBM
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) {
@@ -291,6 +303,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
             }
             for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS)
                 (&sh.zsum[buf][0][0][0])[i] = lay.zsum_g[((size_t)(gg.v0 + (i >> 5)) * L + l) * 32 + (i & 31)];
+            }
         }
         tr.ev(10);
         lds_barrier();
@@ -602,7 +615,9 @@ __global__ __launch_bounds__(256) void pmt_finalize_kernel(const PmtModel* __res
 extern "C" size_t pmt_layered_scratch_floats(const PmtModel* m, int64_t total_tiles, int32_t num_variants) {
     if (!m) return 0;
     const size_t nb = (size_t)(m->num_blocks > 0 ? m->num_blocks : 1);
-    return (size_t)total_tiles * (PMT_SLOT_FLOATS + 512) + (size_t)num_variants * (nb * 32 + 2 * PMT_MAX_WIDTH + PMT_MAX_CLUSTERS + 2);
+    // parked activations (layered launches only) | per-set sums | joined execution: arrival counters [B][L], ticket, fault word
+    return (size_t)total_tiles * (PMT_SLOT_FLOATS + 512) + (size_t)num_variants * (nb * 32 + 2 * PMT_MAX_WIDTH + PMT_MAX_CLUSTERS + 2) +
+           (size_t)num_variants * nb + 8;
 }
 
 extern "C" int pmt_forward_layered(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* phi,
@@ -637,7 +652,14 @@ extern "C" int pmt_forward_layered(const PmtModel* model_host, const PmtModel* m
     if (hipMemsetAsync(lay.fsum_g, 0, B * (2 * PMT_MAX_WIDTH + PMT_MAX_CLUSTERS + 2) * sizeof(float), s) != hipSuccess) return PMT_E_LAUNCH;
     auto kernel = stash ? (p0 ? pmt_forward_kernel<true, ShapeP0, true> : pmt_forward_kernel<true, ShapeAny, true>)
                         : (p0 ? pmt_forward_kernel<false, ShapeP0, true> : pmt_forward_kernel<false, ShapeAny, true>);
-    for (int slice = 0; slice <= L; ++slice) {
+    // joined execution: one launch in which the groups of a split read set exchange their per-set sums through HBM
+    int* join_words = reinterpret_cast<int*>(lay.hsum_g + B * (PMT_MAX_CLUSTERS + 2));
+    lay.join = PmtJoin{0, join_words + B * nb, join_words, join_words + B * nb + 1};
+    if (batch->set_groups != nullptr && L > 0) {
+        lay.join.on = 1;
+        if (hipMemsetAsync(join_words, 0, (B * nb + 8) * sizeof(int), s) != hipSuccess) return PMT_E_LAUNCH;
+    }
+    for (int slice = 0; slice <= (lay.join.on ? 0 : L); ++slice) {
         lay.slice = slice;
         if (shape >= 2) {  // the layered instances of the production shape: pmt_forward_train.hip  (layered: no plain-bf16 instance)
             const int rct = pmt_forward_launch_train_p0x(batch->num_groups, stream, model_dev, theta, phi, packed, batch, out, stash, zsum_stash,

@@ -77,6 +77,12 @@ class GroupPlan:
             L.check(n, "pmt_plan_groups_split")
             self.span = span[:n].copy()
             gs = np.zeros(n + 1, dtype=np.int32)  # unused by the layered kernels
+            # how many groups cover each variant (PmtBatch.set_groups): what the groups of a split read set wait for when they join
+            # their per-set sums inside ONE launch
+            cover = np.zeros(b + 1, dtype=np.int64)
+            np.add.at(cover, self.span[:, 0], 1)
+            np.add.at(cover, self.span[:, 1], -1)
+            self.set_groups = np.cumsum(cover)[:b].astype(np.int32)
         L.check(n, "pmt_plan_groups")
         self.num_groups = n
         self.group_start = gs[: n + 1].copy()
@@ -99,6 +105,30 @@ class GroupPlan:
     @property
     def layered(self) -> bool:
         return self.span is not None
+
+    set_groups = None  # int32 [B] for a split plan (span is not None)
+
+    def use_span(self, span: np.ndarray, group_tile_base: np.ndarray, num_variants: int):
+        """Replace the plan by explicit group spans ([G, 6]: v0, v1, ref_begin, ref_end, alt_begin, alt_end) -- tests cut read
+        sets into groups of their own choosing -- keeping everything derived from them consistent."""
+        self.span = np.ascontiguousarray(span, dtype=np.int32)
+        self.num_groups = len(self.span)
+        self.group_tile_base = np.ascontiguousarray(group_tile_base, dtype=np.int32)
+        self.total_tiles = int(self.group_tile_base[-1])
+        self.group_start = np.zeros(self.num_groups + 1, dtype=np.int32)
+        cover = np.zeros(num_variants + 1, dtype=np.int64)
+        np.add.at(cover, self.span[:, 0], 1)
+        np.add.at(cover, self.span[:, 1], -1)
+        self.set_groups = np.cumsum(cover)[:num_variants].astype(np.int32)
+        self._dev = {}
+
+    def set_groups_on(self, device: torch.device):
+        if self.set_groups is None:
+            return None
+        key = "sets:" + str(device)
+        if key not in self._dev:
+            self._dev[key] = torch.from_numpy(self.set_groups).to(device)
+        return self._dev[key]
 
     def on(self, device: torch.device):
         key = str(device)

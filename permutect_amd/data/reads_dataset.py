@@ -497,6 +497,35 @@ class DeviceChunkLoader:
         order_c = self.rng.permutation(len(self.ranges)) if self.shuffle else np.arange(len(self.ranges))
         seeds = self.rng.integers(0, 2 ** 63 - 1, size=len(order_c))  # one stream per chunk: the prefetch thread shuffles
         self._stages = _STAGES.acquire()
+        # Compose one batch AHEAD on a side stream: the dozen small gather / scan launches of batch i + 1 (~0.1 ms of device time)
+        # then run beside the read-set kernels of batch i instead of in front of its own.  And while batches are being drawn, the
+        # interpreter hands the GIL over every 0.5 ms instead of every 5: the prefetch threads run short stretches of Python between
+        # their GIL-free library calls, and the consumer's ~40 launches per step must not queue behind them for milliseconds.
+        import sys
+        cuda = self.device.type == "cuda"
+        compose = torch.cuda.Stream(self.device) if cuda else None
+        old_interval = sys.getswitchinterval()
+        sys.setswitchinterval(min(old_interval, 5e-4))
+
+        def composed(chunk, ids_host, ids_dev, plan):
+            if not cuda:
+                return ChunkBatch(chunk, ids_host, ids_dev, plan), None
+            cur = torch.cuda.current_stream(self.device)
+            compose.wait_stream(cur)  # (nothing of the consumer's stream may be overtaken by a reuse of freed memory)
+            with torch.cuda.stream(compose):
+                cb = ChunkBatch(chunk, ids_host, ids_dev, plan)
+                cb.read_index()
+                ev = torch.cuda.Event()
+                ev.record(compose)
+            for t in (cb.int_tensor, cb.float_tensor, cb._row_start, cb._read_index, *cb._offsets):
+                t.record_stream(cur)  # allocated on the side stream, consumed on the caller's
+            return cb, ev
+
+        def ready(item):
+            cb, ev = item
+            if ev is not None:
+                torch.cuda.current_stream(self.device).wait_event(ev)
+            return cb
         try:
             with ThreadPoolExecutor(max_workers=_PREFETCH) as pool:
                 pending = deque()
@@ -506,19 +535,27 @@ class DeviceChunkLoader:
                         pending.append(pool.submit(self._load, int(order_c[i]), int(seeds[i]), i % _PREFETCH))
                 for i in range(_PREFETCH):
                     submit(i)
+                ahead = None
                 for i in range(len(order_c)):
                     chunk, batches = pending.popleft().result()
                     submit(i + _PREFETCH)
                     self.bytes_uploaded += chunk.nbytes
-                    if self.device.type == "cuda":
+                    if cuda:
                         # the chunk was allocated on the prefetch thread's side stream and is consumed on THIS stream: tell the
                         # allocator, or a chunk dropped while its last batch's kernels are still queued could be handed out again
                         cur = torch.cuda.current_stream(self.device)
                         for t in (chunk.ints, chunk.floats, chunk.reads, chunk.row_start, getattr(chunk, "plans_dev", None)):
                             if t is not None:
                                 t.record_stream(cur)
+                                t.record_stream(compose)
                     for ids_host, ids_dev, plan in batches:
-                        yield ChunkBatch(chunk, ids_host, ids_dev, plan)
+                        nxt = composed(chunk, ids_host, ids_dev, plan)
+                        if ahead is not None:
+                            yield ready(ahead)
+                        ahead = nxt
+                if ahead is not None:
+                    yield ready(ahead)
         finally:  # (the executor has joined its threads: no copy out of these buffers is left in flight)
+            sys.setswitchinterval(old_interval)
             stages, self._stages = self._stages, None
             _STAGES.release(stages)

@@ -90,7 +90,7 @@ class PmtBatch(C.Structure):
     _fields_ = [("num_variants", i32), ("num_groups", i32), ("read_format", i32), ("read_row_bytes", i32),
                 ("reads", vp), ("read_index", vp), ("ref_offsets", vp), ("alt_offsets", vp), ("variant_embed", vp),
                 ("group_start", vp), ("group_tile_base", vp), ("total_tiles", i64), ("debug_flags", vp), ("group_span", vp),
-                ("num_groups_dev", vp)]
+                ("num_groups_dev", vp), ("set_groups", vp)]
 
 
 class PmtOutputs(C.Structure):
@@ -156,7 +156,7 @@ EXPORTS = ["pmt_abi_version", "pmt_struct_bytes", "pmt_model_check", "pmt_plan_g
            "pmt_phi_forward", "pmt_phi_backward", "pmt_build_read_index", "pmt_losses_forward", "pmt_losses_backward",
            "pmt_downsample_counts", "pmt_downsample_index", "pmt_record_losses",
            "pmt_plan_groups_split", "pmt_layered_scratch_floats", "pmt_forward_layered",
-           "pmt_layered_backward_scratch_floats", "pmt_backward_layered", "pmt_host_copy", "pmt_pack_order", "pmt_pack_order_batches", "pmt_prepare_chunk"]
+           "pmt_layered_backward_scratch_floats", "pmt_backward_layered", "pmt_host_copy", "pmt_pack_order", "pmt_pack_order_batches", "pmt_prepare_chunk", "pmt_host_copy_rows"]
 
 _lib = None
 
@@ -210,6 +210,7 @@ def load() -> C.CDLL:
     lib.pmt_layered_scratch_floats.restype = C.c_size_t
     lib.pmt_forward_layered.argtypes = [P(PmtModel), vp, vp, vp, vp, P(PmtBatch), P(PmtOutputs), vp, vp, vp]
     lib.pmt_host_copy.argtypes = [vp, vp, C.c_size_t, i32]
+    lib.pmt_host_copy_rows.argtypes = [vp, vp, i64, i64, i64, i64, i32]
     lib.pmt_pack_order.argtypes = [vp, vp, i32, i32, vp]
     lib.pmt_pack_order_batches.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     lib.pmt_prepare_chunk.argtypes = [vp, i64, i32, i32, i32, i32, C.c_uint64, i32, i32, i32, vp, vp, vp, vp, i64, vp]

@@ -41,6 +41,8 @@ class ReadSetEngine:
         # counter sees every in-place torch op on theta or on a parameter view (load_state_dict, checkpoint restore, a torch
         # optimizer on the calibration parameters), `params_changed()` is called by whatever writes theta through a raw pointer
         # (the fused optimizer kernel, a captured-graph replay, a collective on the flat buffer)
+        self.join_layered = os.environ.get("PMT_LAYERED_JOIN", "1") != "0"
+        self.join_fault_words = []  # views of the fault words of the joined launches issued so far (check_join_fault)
         self._param_epoch = 0
         self.packed_for = None  # (params_key, phi) the packed weights were built from, under no_grad only
         self.timers = None  # bench.py sets {'pmt_forward': [], 'pmt_backward': []} to collect (start, end) HIP events
@@ -58,6 +60,12 @@ class ReadSetEngine:
             end = torch.cuda.Event(enable_timing=True)
             end.record()
             self.timers[name].append((start, end))
+
+    def check_join_fault(self):
+        """Synchronises and raises if a joined launch gave up waiting for another workgroup (its results are then wrong)."""
+        words, self.join_fault_words = self.join_fault_words, []
+        if words and bool(torch.stack([w.reshape(()) for w in words]).any().item()):
+            raise L.PmtError("a joined layered launch timed out waiting for the other workgroups of a split read set")
 
     # ---- parameters -------------------------------------------------------------------------------------------------
     def params_changed(self):
@@ -124,7 +132,11 @@ class ReadSetEngine:
         bv.debug_flags = self.plan.debug_flags.data_ptr()
         bv.group_span = _ptr(span)
         bv.num_groups_dev = _ptr(getattr(plan, "num_groups_dev", None))  # (engine/graph.py: a plan sized for a capacity)
-        keep = (gs, gt, span, ref_off, alt_off, reads, index, variant_embed)
+        # split read sets: with the number of groups per variant the layered entry points run ONE joined launch each way
+        # (PMT_LAYERED_JOIN=0: num_blocks + 1 launches with the activations parked in between; the parity tests run both)
+        sets = plan.set_groups_on(self.device) if (getattr(plan, "set_groups", None) is not None and self.join_layered) else None
+        bv.set_groups = _ptr(sets)
+        keep = (gs, gt, span, ref_off, alt_off, reads, index, variant_embed, sets)
         return bv, keep, plan
 
     # ---- passes -----------------------------------------------------------------------------------------------------
@@ -152,6 +164,8 @@ class ReadSetEngine:
             L.check(self.lib.pmt_forward_layered(C.byref(d), self.plan.desc_dev.data_ptr(), self.space.theta.data_ptr(),
                                                  phi.data_ptr(), self.plan.packed.data_ptr(), C.byref(bv), C.byref(out),
                                                  _ptr(stash), scratch.data_ptr(), _stream()), "pmt_forward_layered")
+            if bv.set_groups:
+                self.join_fault_words = self.join_fault_words[-7:] + [scratch.view(torch.int32)[-7]]
         else:
             L.check(self.lib.pmt_forward(C.byref(d), self.plan.desc_dev.data_ptr(), self.space.theta.data_ptr(),
                                          phi.data_ptr(), self.plan.packed.data_ptr(), C.byref(bv), C.byref(out),
@@ -178,6 +192,8 @@ class ReadSetEngine:
                                                   self.space.gtheta.data_ptr(), gphi.data_ptr(), gvar.data_ptr(),
                                                   self.plan.grad_partials.data_ptr(), self.plan.partial_rows, _stream()),
                     "pmt_backward_layered")
+            if bv.set_groups:
+                self.join_fault_words = self.join_fault_words[-7:] + [scratch.view(torch.int32)[-7]]
         else:
             L.check(self.lib.pmt_backward(C.byref(d), self.plan.desc_dev.data_ptr(), self.space.theta.data_ptr(),
                                           phi.data_ptr(), self.plan.packed.data_ptr(), C.byref(bv), C.byref(out),

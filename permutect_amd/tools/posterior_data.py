@@ -68,9 +68,9 @@ def make_posterior_mmap(dataset: ReadsDataset, model, batch_size: int, device: O
     def ints_worker():  # the integer rows: the dataset's own, counts zeroed (never on the device)
         try:
             src = np.ascontiguousarray(dataset._ints[:n]) if not dataset._ints[:n].flags["C_CONTIGUOUS"] else dataset._ints[:n]
-            host_copy(ints_out, src.ctypes.data, ints_out.nbytes)
-            ints_out[:, Data.REF_COUNT.idx] = 0
-            ints_out[:, Data.ALT_COUNT.idx] = 0
+            assert Data.ALT_COUNT.idx == Data.REF_COUNT.idx + 1
+            L.check(lib.pmt_host_copy_rows(ints_out.ctypes.data, src.ctypes.data, n, ints_out.shape[1] * 2, Data.REF_COUNT.idx * 2, 4, 8),
+                    "pmt_host_copy_rows")  # one pass: the rows and the two zeroed counts
         except Exception as exc:
             errors.append(exc)
 

@@ -228,7 +228,8 @@ def test_layered_forward_equals_the_single_launch_forward():
         gs, counts = plan.group_start, forced.host_counts()
         ro = np.concatenate([[0], np.cumsum(counts[0])])
         ao = np.concatenate([[0], np.cumsum(counts[1])])
-        plan.span = np.array([[gs[g], gs[g + 1], ro[gs[g]], ro[gs[g + 1]], ao[gs[g]], ao[gs[g + 1]]] for g in range(plan.num_groups)], dtype=np.int32)
+        plan.use_span(np.array([[gs[g], gs[g + 1], ro[gs[g]], ro[gs[g + 1]], ao[gs[g]], ao[gs[g + 1]]] for g in range(plan.num_groups)], dtype=np.int32),
+                      plan.group_tile_base, len(counts[0]))
     forced._plan = plan
     with torch.no_grad():
         c = model.compute_batch_output(forced)

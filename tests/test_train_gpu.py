@@ -249,11 +249,8 @@ def test_layered_backward_on_forced_splits_matches_reference():
             tiles += (r1 - r + 15) // 16 + (a1 - a + 15) // 16
             r, a = r1, a1
     tile_base.append(tiles)
-    plan.span = np.array(spans, dtype=np.int32)
-    plan.num_groups, plan.total_tiles = len(spans), tiles
-    plan.group_tile_base = np.array(tile_base, dtype=np.int32)
-    plan.group_start = np.zeros(len(spans) + 1, dtype=np.int32)
-    assert plan.num_groups > 2 * len(nref)
+    plan.use_span(np.array(spans, dtype=np.int32), np.array(tile_base, dtype=np.int32), len(nref))
+    assert plan.num_groups > 2 * len(nref) and plan.set_groups.max() > 2
     batch._plan = plan
     out = model.compute_batch_output(batch)
     losses = model.compute_batch_losses(out, batch)
