@@ -447,6 +447,15 @@ int pmt_build_read_index(const int64_t* row_start, const int32_t* ref_offsets, c
 /* Host-side staging copy for the dataset loader (reference data/reads_dataset.py:141-196 reads the memory map Datum by
  * Datum): copies `bytes` from src (a memory-mapped file or host array) to dst (a pinned staging buffer) with `threads`
  * worker threads, outside the Python GIL.  Pure host code, no HIP call. */
+/* One batch composed on the device from a chunk of the dataset resident in HBM as it lies on disk (int16 / float16 per-variant
+ * tables, CSR row starts): the batch's variants are rows ids[0 .. num_variants) of the chunk.  Writes the Batch's tables in the
+ * reference's dtypes (data/batch.py:47-49: int64 [B][int_cols], float32 [B][float_cols]), the variants' first read rows, the
+ * exclusive scans of the two count columns ([B + 1] each) and the gather index of the reads (all ref rows, then all alt rows;
+ * sized by the caller: the batch's total reads).  Everything device memory; asynchronous on `stream`. */
+int pmt_compose_batch(const int16_t* chunk_ints, int32_t int_cols, const void* chunk_floats_f16, int32_t float_cols,
+                      const int64_t* chunk_row_start, const int64_t* ids, int32_t num_variants, int32_t ref_col, int32_t alt_col,
+                      int64_t* int_tensor, float* float_tensor, int64_t* row_start, int32_t* ref_offsets, int32_t* alt_offsets,
+                      int64_t* read_index, void* stream);
 int pmt_host_copy(void* dst, const void* src, size_t bytes, int32_t threads);
 /* The same for `rows` rows of `row_bytes` bytes with bytes [zero_offset, zero_offset + zero_bytes) of every row cleared in the
  * same pass: the integer rows of the posterior hand-off (reference tools/filter_variants.py:305-308: the datum's own integer

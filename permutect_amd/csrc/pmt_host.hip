@@ -738,6 +738,44 @@ extern "C" int pmt_build_read_index(const int64_t* row_start, const int32_t* ref
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }
 
+// One batch composed from a chunk of the dataset that is resident in HBM as it lies on disk (reference data/batch.py:41-62 does
+// this collate on the host, Datum by Datum): the batch's variants are rows `ids` of the chunk.  ONE call = the per-variant
+// tables in the Batch's dtypes (int16 -> int64, float16 -> float32: reference data/batch.py:47-49), the rows' read offsets, the
+// exclusive scans of the counts and the gather index of the reads (ref rows of all variants, then alt rows).
+__global__ __launch_bounds__(256) void pmt_gather_rows_kernel(const short* __restrict__ ints, int int_cols, const _Float16* __restrict__ floats,
+                                                              int float_cols, const long long* __restrict__ row_start,
+                                                              const long long* __restrict__ ids, int n, long long* __restrict__ ints_out,
+                                                              float* __restrict__ floats_out, long long* __restrict__ row_start_out) {
+    // a 64-lane slice per variant row: coalesced along the columns
+    const int rows_per_block = 256 / 64, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * rows_per_block + (threadIdx.x >> 6);
+    if (b >= n) return;
+    const long long src = ids[b];
+    const short* ip = ints + (size_t)src * int_cols;
+    for (int c = lane; c < int_cols; c += 64) ints_out[(size_t)b * int_cols + c] = (long long)ip[c];
+    const _Float16* fp = floats + (size_t)src * float_cols;
+    for (int c = lane; c < float_cols; c += 64) floats_out[(size_t)b * float_cols + c] = (float)fp[c];
+    if (lane == 0) row_start_out[b] = row_start[src];
+}
+
+extern "C" int pmt_compose_batch(const int16_t* chunk_ints, int32_t int_cols, const void* chunk_floats_f16, int32_t float_cols,
+                                 const int64_t* chunk_row_start, const int64_t* ids, int32_t num_variants, int32_t ref_col, int32_t alt_col,
+                                 int64_t* int_tensor, float* float_tensor, int64_t* row_start, int32_t* ref_offsets, int32_t* alt_offsets,
+                                 int64_t* read_index, void* stream) {
+    if (!chunk_ints || !chunk_floats_f16 || !chunk_row_start || !ids || !int_tensor || !float_tensor || !row_start || !ref_offsets ||
+        !alt_offsets || !read_index || num_variants < 0 || int_cols < 2 || float_cols < 1 || ref_col < 0 || alt_col < 0 || ref_col >= int_cols ||
+        alt_col >= int_cols)
+        return PMT_E_INVALID;
+    if (num_variants == 0) return pmt_scan_counts(int_tensor, int_tensor, 8, int_cols, 0, ref_offsets, alt_offsets, stream);
+    hipLaunchKernelGGL(pmt_gather_rows_kernel, dim3((num_variants + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       (const short*)chunk_ints, int_cols, (const _Float16*)chunk_floats_f16, float_cols, (const long long*)chunk_row_start,
+                       (const long long*)ids, num_variants, (long long*)int_tensor, float_tensor, (long long*)row_start);
+    if (hipGetLastError() != hipSuccess) return PMT_E_LAUNCH;
+    int rc = pmt_scan_counts(int_tensor + ref_col, int_tensor + alt_col, 8, int_cols, num_variants, ref_offsets, alt_offsets, stream);
+    if (rc != PMT_OK) return rc;
+    return pmt_build_read_index(row_start, ref_offsets, alt_offsets, num_variants, read_index, stream);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // fused clip_grad_norm_(max_norm) + AdamW over one flat buffer (reference misc_utils.py:128-129)
 // ---------------------------------------------------------------------------------------------------------------------

