@@ -4,7 +4,7 @@
 # kernel-trace statistics of the default bench workload, SQ counters and HBM traffic (separate --pmc passes) of
 # scripts/one_step.py at the same batch; summaries land in gpurun_out/<tag>_* (copy the ones to keep into profiles/).
 set -e
-tag=${1:-r02}
+tag=${1:-r03}
 root=$(pwd)
 out=$root/gpurun_out
 mkdir -p $out
