@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PMT_ABI_VERSION 6
+#define PMT_ABI_VERSION 7
 
 /* error codes */
 #define PMT_OK 0
@@ -92,7 +92,8 @@ typedef struct PmtOp {
 } PmtOp;
 
 typedef struct PmtMlp {
-    int32_t n_ops, in_dim, out_dim, reserved;
+    int32_t n_ops, in_dim, out_dim;
+    int32_t dropout;            /* 1: the reference built this MLP with dropout_p (an nn.Dropout behind every Linear) */
     PmtOp ops[PMT_MAX_OPS];
 } PmtMlp;
 
@@ -187,6 +188,9 @@ typedef struct PmtModel {
     int32_t cnn_debug;          /* development switches of pmt_cnn2_backward (0 in production)                           */
     int32_t emit_base;          /* packed: the linears' emit tables lie back to back in [emit_base, emit_base + emit_len) */
     int32_t emit_len;           /*   (floats); a row of pmt_backward's `grad_partials` mirrors exactly this region        */
+    float dropout_p;            /* reference parameters.py:26 / mlp.py:57-58: nn.Dropout(p) behind every Linear of the MLPs flagged
+                                   PmtMlp.dropout.  Applied only to a batch that brings a dropout_seed (train mode); such a batch
+                                   runs the generic kernel instances */
 } PmtModel;
 
 /* Inputs of one forward / backward pass.  Reads are ordered as the reference's Batch orders them: all ref reads
@@ -219,6 +223,8 @@ typedef struct PmtBatch {
                                        pmt_backward_layered run ONE launch each way in which the groups of a split read set
                                        join their per-set sums through HBM (arrival counters) while the activations stay in
                                        registers; NULL = num_blocks + 1 launches with the activations parked in between */
+    uint64_t dropout_seed;          /* 0 = no dropout (eval mode, or dropout_p = 0).  Otherwise the seed of THIS step's masks
+                                       (pmt_dropout_mask): the forward and the backward of one step get the same value */
 } PmtBatch;
 
 typedef struct PmtOutputs {
@@ -495,6 +501,11 @@ int pmt_backward(const PmtModel* model_host, const PmtModel* model_dev, const fl
                  const float* stash, float* grad_theta, float* grad_phi, float* grad_variant_embed, float* grad_partials,
                  int32_t num_partials, void* stream);
 
+/* The dropout mask of one linear's output as the kernels generate it (host computation, no GPU; pmt_dropout.hpp): out[r][f] =
+ * 1 / (1 - p) where element (row0 + r, f) of the output of linear `lin` (index into PmtModel.lin) is kept under `seed`, else 0.
+ * For the parity tests: the oracle applies exactly these masks (reference mlp.py:57-58 draws its own from torch's generator). */
+int pmt_dropout_mask(uint64_t seed, float p, int32_t lin, int64_t row0, int64_t rows, int32_t width, float* out);
+
 /* Row-wise MLP over N independent rows -- the per-variant branches: `which` = PMT_ROWS_INFO (info_embedding,
  * reference artifact_model.py:244), PMT_ROWS_ALT_COUNT (alt_count_predictor, :180-183, :276-279) or PMT_ROWS_SOURCE
  * (source_predictor, :267-274).  in: [n_rows] rows of in_dim floats with the given row stride (floats); out likewise, so a
@@ -503,8 +514,9 @@ int pmt_backward(const PmtModel* model_host, const PmtModel* model_dev, const fl
 size_t pmt_rows_stash_bytes(const PmtModel* model, int which, int32_t n_rows);
 int pmt_rows_forward(const PmtModel* model_host, const PmtModel* model_dev, int which, const float* theta,
                      const float* packed, const float* in, int64_t in_stride, int32_t n_rows, float* out,
-                     int64_t out_stride, float* stash, void* stream);
-/* Backward of pmt_rows_forward: accumulates parameter gradients into grad_theta and, if d_in != NULL, writes
+                     int64_t out_stride, float* stash, uint64_t dropout_seed, void* stream);
+/* (dropout_seed: as PmtBatch.dropout_seed; row r of the masks is row r of `in`.)
+ * Backward of pmt_rows_forward: accumulates parameter gradients into grad_theta and, if d_in != NULL, writes
  * d_in = d_in_scale * dL/d(in)  (d_in_scale = -alpha implements the reference's gradient reversal,
  * gradient_reversal/functional.py:18-22).
  * `workspace` (optional, device, >= pmt_rows_workspace_floats(model, which) floats, ALL ZERO at the first use; every call
@@ -514,7 +526,7 @@ int pmt_rows_forward(const PmtModel* model_host, const PmtModel* model_dev, int 
 int pmt_rows_backward(const PmtModel* model_host, const PmtModel* model_dev, int which, const float* theta,
                       const float* packed, const float* in, int64_t in_stride, int32_t n_rows, const float* d_out,
                       int64_t d_out_stride, const float* stash, float* grad_theta, float* d_in, int64_t d_in_stride,
-                      float d_in_scale, float* workspace, size_t workspace_floats, void* stream);
+                      float d_in_scale, float* workspace, size_t workspace_floats, uint64_t dropout_seed, void* stream);
 size_t pmt_rows_workspace_floats(const PmtModel* model_host, int which);
 
 /* Haplotype CNN: haplotypes = device int64 [n][H] rows (values 0..4: A, C, G, T, indel; ref half then alt half,

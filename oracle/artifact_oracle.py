@@ -19,7 +19,7 @@ from __future__ import annotations
 
 import math
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Tuple
+from typing import Callable, Dict, List, Optional, Tuple
 
 import numpy as np
 import torch
@@ -62,6 +62,11 @@ class Config:
     haplotypes_length: int
     alt_count_layers: List[int] = field(default_factory=lambda: [30, -1, -1, -1, 1])  # artifact_model.py:180-183
     num_sources: int = 1
+    # the model was built with dropout_p > 0 (architecture/mlp.py:57-58: an nn.Dropout behind every Linear of read_embedding,
+    # info_embedding, reducer and source_predictor, artifact_model.py:145-206): a callable (key of the Linear, e.g.
+    # "reducer._model.0"; its output y; row0 = 0, the batch row of y[0]) -> the multiplier tensor of train mode (0 or
+    # 1 / (1 - p) per element), or None for eval mode.  Being set at all shifts the Sequential indices by the Dropout modules, as in the reference's state_dict.
+    dropout: Optional[Callable] = None
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -91,8 +96,10 @@ def downsampled_read_indices(keep_ref_mask: Tensor, keep_alt_mask: Tensor) -> Te
 # ----------------------------------------------------------------------------------------------------------------
 # building blocks
 # ----------------------------------------------------------------------------------------------------------------
-def mlp(sd: SD, prefix: str, layer_sizes: List[int], x: Tensor, prepend_activation: bool = False) -> Tensor:
-    """architecture/mlp.py:32-67 (Sequential index bookkeeping included, it defines the key names)."""
+def mlp(sd: SD, prefix: str, layer_sizes: List[int], x: Tensor, prepend_activation: bool = False,
+        dropout: Optional[Callable] = None) -> Tensor:
+    """architecture/mlp.py:32-67 (Sequential index bookkeeping included, it defines the key names).  dropout: see
+    Config.dropout (mlp.py:57-58: Linear, Dropout, then the activation)."""
     idx = 0
     if prepend_activation:
         x = F.selu(x)
@@ -102,17 +109,29 @@ def mlp(sd: SD, prefix: str, layer_sizes: List[int], x: Tensor, prepend_activati
     for k, out in enumerate(layer_sizes[1:]):
         if out < 0:  # DenseSkipBlock, mlp.py:15-22
             p = f"{prefix}._model.{idx}"
-            inner = mlp(sd, p + ".mlp", (-out + 1) * [width], x, prepend_activation=True)
+            inner = mlp(sd, p + ".mlp", (-out + 1) * [width], x, prepend_activation=True, dropout=dropout)
             x = x + sd[p + ".alpha"] * inner
             idx += 1
             continue
         x = F.linear(x, sd[f"{prefix}._model.{idx}.weight"], sd[f"{prefix}._model.{idx}.bias"])
+        if dropout is not None:
+            mask = dropout(f"{prefix}._model.{idx}", x)
+            x = x if mask is None else x * mask
+            idx += 1
         idx += 1
         if k < last:
             x = F.selu(x)
             idx += 1
         width = out
     return x
+
+
+def _rows_from(dropout: Optional[Callable], row0: int) -> Optional[Callable]:
+    """The reducer runs on the ref reads and on the alt reads separately (artifact_model.py:262-263); a mask provider keyed by
+    the read's row in the batch is told where the block starts."""
+    if dropout is None:
+        return None
+    return lambda key, y: dropout(key, y, row0)
 
 
 def mlp_output_dim(layer_sizes: List[int]) -> int:
@@ -255,8 +274,9 @@ def calculate_features(sd: SD, cfg: Config, reads_re: Tensor, nref: Tensor, nalt
                        haplotypes_bh: Tensor):
     """architecture/artifact_model.py:239-265 -> (final_ref_re, final_alt_re, ref_seq_embeddings_be)."""
     total_ref = int(nref.sum())
-    read_emb = mlp(sd, "read_embedding", [cfg.num_read_features] + cfg.read_layers, reads_re.to(COMPUTE_DTYPE))
-    info_emb = mlp(sd, "info_embedding", [cfg.num_info_features] + cfg.info_layers, info_be.to(COMPUTE_DTYPE))
+    read_emb = mlp(sd, "read_embedding", [cfg.num_read_features] + cfg.read_layers, reads_re.to(COMPUTE_DTYPE),
+                   dropout=cfg.dropout)
+    info_emb = mlp(sd, "info_embedding", [cfg.num_info_features] + cfg.info_layers, info_be.to(COMPUTE_DTYPE), dropout=cfg.dropout)
     hap_emb = cnn(sd, "haplotypes_cnn", cfg.cnn_layers, one_hot_haplotypes(haplotypes_bh))
     info_seq = torch.hstack((info_emb, hap_emb))
     x = torch.hstack((read_emb, torch.vstack((expand(info_seq, nref), expand(info_seq, nalt)))))
@@ -266,8 +286,8 @@ def calculate_features(sd: SD, cfg: Config, reads_re: Tensor, nref: Tensor, nalt
     red_sizes = [ref.shape[-1]] + cfg.aggregation_layers
     q = rotation_matrix(sd, "pre_clustering_transform.rotation_ee")
     t = sd["pre_clustering_transform.translation_e"]
-    final = lambda r: F.linear(mlp(sd, "reducer", red_sizes, r) + t[None, :], q)  # euclidean_transformation.py:19-20
-    return final(ref), final(alt), hap_emb
+    final = lambda r, row0: F.linear(mlp(sd, "reducer", red_sizes, r, dropout=_rows_from(cfg.dropout, row0)) + t[None, :], q)  # euclidean_transformation.py:19-20
+    return final(ref, 0), final(alt, total_ref), hap_emb
 
 
 def compute_batch_output(sd: SD, cfg: Config, reads_re, nref, nalt, info_be, haplotypes_bh) -> Dict[str, Tensor]:
@@ -311,7 +331,7 @@ def compute_batch_losses(sd: SD, cfg: Config, out: Dict[str, Tensor], labels_enu
     if cfg.num_sources > 1:
         hidden = [-1, -1]
         src_logits = mlp(sd, "source_predictor.wrapped_module", [e] + hidden + [cfg.num_sources],
-                         revgrad(feats, source_adv_strength))
+                         revgrad(feats, source_adv_strength), dropout=cfg.dropout)
         probs = torch.softmax(src_logits, dim=-1)
         source = torch.sum(torch.square(probs - F.one_hot(sources_b.long(), cfg.num_sources)), dim=-1)
     else:

@@ -163,11 +163,9 @@ class ArtifactModel(nn.Module):
         return torch.hstack((info, hap))
 
     def _encode(self, batch: Batch):
-        if self.training and self._params.dropout_p > 0:
-            # reference mlp.py:57-58: nn.Dropout draws a mask in train mode.  The kernels have no dropout: refuse, never skip it.
-            raise NotImplementedError("permutect_amd trains with dropout_p = 0 only; a model with dropout_p > 0 runs in eval "
-                                      "mode (model.eval(): filter_variants, evaluation), where dropout is the identity")
         eng = self.engine()
+        # reference mlp.py:57-58: nn.Dropout draws new masks on every forward in train mode and is the identity in eval mode
+        eng.draw_dropout_seed(self.training)
         if batch.size() == 0:  # nothing to launch
             d, dev = eng.plan.desc, self._device
             z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)  # noqa: E731

@@ -86,8 +86,8 @@ class MLP(nn.Module):
             # kernels (its training statistics span the whole batch in the middle of the fused read-set pass).
             raise NotImplementedError("permutect_amd supports batch_normalize=False only")
         # dropout_p > 0 (reference mlp.py:57-58; default 0): the nn.Dropout modules are kept in the Sequential so that the
-        # state_dict keys of a reference checkpoint line up; the kernels run them as the identity, which is what they are
-        # in eval mode (filter_variants).  TRAINING with dropout is refused loudly (ArtifactModel._encode).
+        # state_dict keys of a reference checkpoint line up; the engine lowers them to a flag of the MLP (engine/plan.py) and the
+        # kernels mask every Linear's output in train mode (pmt_dropout.hpp) and run the identity in eval mode.
         self.dropout_p = float(dropout_p)
         layers: List[nn.Module] = [nn.SELU()] if prepend_activation else []
         self._input_dim = layer_sizes[0]

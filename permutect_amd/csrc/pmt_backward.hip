@@ -34,6 +34,7 @@
 #endif
 #define PMT_FRAG_AHEAD PMT_BWD_FRAG_AHEAD  // weight fragments three MFMA groups ahead (2 waves per SIMD do not hide an L2 round trip): 0 -> 1: 3.59 -> 3.52 ms; 1 -> 3: 3.31 -> 3.27 ms
 #include "pmt_device.hpp"
+#include "pmt_mlp_device.hpp"
 #include "pmt_bwd_device.hpp"
 
 struct BwdShared {
@@ -193,6 +194,13 @@ DEV void backward_group(
     const int slot_last_in = n_red_ops > 1 ? slot_red + (n_red_ops - 2) : slot_x0 + L;  // input of the last reducer op
     const PmtOp& red_last = M->reducer.ops[n_red_ops - 1];
 
+    PmtDrop drop;  // (generic instances only: the masks of the step's seed, regenerated -- pmt_dropout.hpp)
+    if constexpr (!EX) {
+        drop = drop_setup(M, bt.dropout_seed, uniform(M->reducer.dropout));
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt) drop.row[rt] = tm[rt].row;
+        c.drop = &drop;
+    }
     // ---- recompute the tail of the forward: last reducer op, translation, rotation -> a ----------------------------
     f4 dy[PMT_RT][NTD];  // running gradient (d_model wide)
     if (LAYERED && lay.slice > 0) {
@@ -219,40 +227,10 @@ DEV void backward_group(
 #pragma unroll
                         for (int t = 0; t < NTE; ++t) e[rt][t] = selu4(e[rt][t]);
                 }
-            } else {  // forward of the last reducer op only, whatever its kind
-                f4 y[PMT_RT][NTD];
-                if (uniform(red_last.kind) == PMT_OP_LINEAR) {
-                    const PmtLinear& Lr = M->lin[uniform(red_last.lin[0])];
-                    init_bias<NTD>(y, uniform(Lr.b_pvec) >= 0 ? packed + uniform(Lr.b_pvec) : nullptr, uniform(Lr.out_dim), g);
-                    linear_acc<NTD, NTD, false>(y, r, packed + uniform(Lr.w_frag), uniform(Lr.in_dim), uniform(Lr.out_dim));
-                    const bool act = uniform(red_last.selu_after) != 0;
-#pragma unroll
-                    for (int rt = 0; rt < PMT_RT; ++rt)
-#pragma unroll
-                        for (int t = 0; t < NTD; ++t) r[rt][t] = act ? selu4(y[rt][t]) : y[rt][t];
-                } else {
-                    const int nl = uniform(red_last.n_layers);
-                    const PmtLinear& L1 = M->lin[uniform(red_last.lin[0])];
-                    const PmtLinear& L2 = M->lin[uniform(red_last.lin[nl - 1])];
-                    const int width = uniform(L1.in_dim);
-                    const float alpha = uniform(theta[uniform(red_last.alpha_src)]);
-                    if (nl == 2) {
-                        init_bias<NTD>(y, packed + uniform(L1.b_pvec), width, g);
-                        linear_acc<NTD, NTD, true>(y, r, packed + uniform(L1.w_frag), width, width);
-                    } else {
-#pragma unroll
-                        for (int rt = 0; rt < PMT_RT; ++rt)
-#pragma unroll
-                            for (int t = 0; t < NTD; ++t) y[rt][t] = r[rt][t];
-                    }
-#pragma unroll
-                    for (int t = 0; t < NTD; ++t) {
-                        const f4 b = alpha * load_pvec(packed + uniform(L2.b_pvec), t, g);
-#pragma unroll
-                        for (int rt = 0; rt < PMT_RT; ++rt) r[rt][t] = r[rt][t] + b;
-                    }
-                    linear_acc<NTD, NTD, true>(r, y, packed + uniform(L2.w_frag), width, width, alpha);
-                }
+            } else {  // forward of the last reducer op only, whatever its kind (with this step's dropout masks, if any)
+                float* const no_stash[PMT_RT] = {};
+                int no_slot = 0;
+                run_mlp<false, NTD, false>(M, M->reducer, r, theta, g, 0u, no_stash, no_slot, 0, packed, n_red_ops - 1, n_red_ops, &drop);
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
@@ -784,6 +762,7 @@ DEV void backward_group(
         decode_reads(xf);
         linear_op_backward<NTF, NTR, true, S::DIM_F, S::DIM_R, BFB>(c, M->read_mlp.ops[0], dr, xf, dxf, false);
     } else {
+        drop.on = drop_setup(M, bt.dropout_seed, uniform(M->read_mlp.dropout)).on;
         mlp_backward<NTD, false>(c, M->read_mlp, dy, false,
                                  [&](int op, f4 (&x)[PMT_RT][NTD]) {
                                      if (op > 0) load_slot_tiles<NTD>(stash_tile, mask_all, op - 1, x); else decode_reads(x);
@@ -899,7 +878,7 @@ extern "C" int pmt_backward(const PmtModel* model_host, const PmtModel* model_de
         return PMT_E_INVALID;
     const float* zsum_stash = stash + (size_t)batch->total_tiles * (size_t)pmt_stash_slots(model_host) * PMT_SLOT_FLOATS;
     const float* rstd_stash = zsum_stash + (size_t)batch->num_variants * (size_t)(model_host->num_blocks > 0 ? model_host->num_blocks : 1) * 32;
-    const int shape = pmt_shape_id(model_host);
+    const int shape = pmt_shape_for(model_host, batch);
     const bool part = use_partials(model_host, shape, grad_partials, num_partials);
     const int grid = part && num_partials < batch->num_groups ? num_partials : batch->num_groups;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -940,7 +919,7 @@ extern "C" int pmt_backward_layered(const PmtModel* model_host, const PmtModel* 
     lay.park = lay.dy_scratch + (size_t)batch->total_tiles * PMT_SLOT_FLOATS;
     lay.gsum_g = lay.park + (size_t)batch->total_tiles * 6 * 256;
     if (hipMemsetAsync(lay.gsum_g, 0, B * nb * 32 * sizeof(float), s) != hipSuccess) return PMT_E_LAUNCH;
-    const int shape = pmt_shape_id(model_host);
+    const int shape = pmt_shape_for(model_host, batch);
     const bool part = use_partials(model_host, shape, grad_partials, num_partials);
     const int grid = part && num_partials < batch->num_groups ? num_partials : batch->num_groups;
     auto kernel = shape >= 2 ? pmt_backward_kernel<ShapeP0X, true> : shape == 1 ? pmt_backward_kernel<ShapeP0, true> : pmt_backward_kernel<ShapeAny, true>;

@@ -191,6 +191,7 @@ struct BwdCtx {
     int rbase;      // ... when it LOADS its MFMA operand (16 bytes)
     float* pf_sink; // LDS, 64 floats: where stash_prefetch drops its dwords
     float* priv = nullptr; // this workgroup's private row of weight-gradient partial sums, biased by -emit_base (pmt_backward.hip); nullptr = global atomics
+    const PmtDrop* drop = nullptr;  // dropout of the MLP being differentiated (generic instances; nullptr / on = 0: none)
     int* trace = nullptr;  // development: this wave's event log (PmtBatch.debug_flags[2] selects ONE workgroup; scripts/bwd_trace.py)
     int trace_n = 0;
 };
@@ -792,6 +793,7 @@ template <int NT, bool EXACT, int W = 0, int BF = 0, typename LoadInput>
 DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool need_input_grad, LoadInput load_input,
                       int op_begin, int op_end) {
     const PmtModel* M = c.M;
+    const bool dropping = !EXACT && c.drop != nullptr && c.drop->on != 0;
     for (int op = op_end - 1; op >= op_begin; --op) {
         const PmtOp& o = mlp.ops[op];
         f4 x[PMT_RT][NT];
@@ -805,11 +807,13 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
                 init_bias<NT>(y, uniform(L.b_pvec) >= 0 ? c.packed + uniform(L.b_pvec) : nullptr, out_dim, c.g);
                 if constexpr (BF) linear_acc_bf16<NT, NT, false, BF>(y, x, c.packed + uniform(L.wb_frag));
                 else linear_acc<NT, NT, false, EXACT, W>(y, x, c.packed + uniform(L.w_frag), in_dim, out_dim);
+                if (dropping) drop_apply<NT>(*c.drop, uniform(o.lin[0]), y, c.g);  // s = selu(mask * (Wx + b))
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
                     for (int t = 0; t < NT; ++t) dy[rt][t] = selu_bwd4(dy[rt][t], selu4(y[rt][t]));
             }
+            if (dropping) drop_apply<NT>(*c.drop, uniform(o.lin[0]), dy, c.g);  // d(Wx + b) = mask * d(masked)
             linear_wgrad<NT, NT, BF>(c, L, dy, x);
             if (op > op_begin || need_input_grad) {
                 f4 dx[PMT_RT][NT];
@@ -836,6 +840,7 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
                 if (c.dbg & 4096) {}  // knock-out (wrong results): the most that stashing s1 could save
                 else if constexpr (BF) linear_acc_bf16<NT, NT, true, BF>(s1, x, c.packed + uniform(L1.wb_frag));
                 else linear_acc<NT, NT, true, EXACT, W>(s1, x, c.packed + uniform(L1.w_frag), width, width);
+                if (dropping) drop_apply<NT>(*c.drop, uniform(o.lin[0]), s1, c.g);
             }
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
@@ -843,12 +848,15 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
                 for (int t = 0; t < NT; ++t) s1[rt][t] = selu4(nl == 2 ? s1[rt][t] : x[rt][t]);
             // last layer: d(f) = alpha * dy
             trace_ev(c, 220);
-            linear_wgrad<NT, NT, BF>(c, L2, dy, s1, alpha);
             f4 d1[PMT_RT][NT];
-            init_bias<NT>(d1, nullptr, width, c.g);
-            if constexpr (BF) linear_acc_bf16<NT, NT, false, BF>(d1, dy, c.packed + uniform(L2.wtb_frag));
-            else linear_acc<NT, NT, false, EXACT, W>(d1, dy, c.packed + uniform(L2.wt_frag), width, width);
-            {   // d(alpha) = sum dy . f with f = W2 s1 + b2, i.e. sum (W2^T dy) . s1 + sum dy . b2: the first factor is d1 as it
+            // dyl: the gradient w.r.t. the last Linear's own output (per unit of alpha) -- dy itself, or with dropout mask2 * dy
+            // (a copy: dy is still needed whole for the residual path)
+            auto last_layer = [&](const f4 (&dyl)[PMT_RT][NT]) {
+                linear_wgrad<NT, NT, BF>(c, L2, dyl, s1, alpha);
+                init_bias<NT>(d1, nullptr, width, c.g);
+                if constexpr (BF) linear_acc_bf16<NT, NT, false, BF>(d1, dyl, c.packed + uniform(L2.wtb_frag));
+                else linear_acc<NT, NT, false, EXACT, W>(d1, dyl, c.packed + uniform(L2.wt_frag), width, width);
+                // d(alpha) = sum dy . f with f = W2 s1 + b2, i.e. sum (W2^T dy) . s1 + sum dy . b2: the first factor is d1 as it
                 // stands here, so the forward product f is never formed (it was a quarter of this op's matrix work)
                 float da = 0.f;
 #pragma unroll
@@ -856,16 +864,28 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
                     const f4 b2 = load_pvec(c.packed + uniform(L2.b_pvec), t, c.g);
 #pragma unroll
                     for (int rt = 0; rt < PMT_RT; ++rt) {
-                        const f4 p = d1[rt][t] * s1[rt][t] + dy[rt][t] * b2;
+                        const f4 p = d1[rt][t] * s1[rt][t] + dyl[rt][t] * b2;
                         da += (p[0] + p[1]) + (p[2] + p[3]);
                     }
                 }
                 aux_push_scalar(c, uniform(o.alpha_src), da);
+            };
+            if (dropping) {
+                f4 dm[PMT_RT][NT];
+#pragma unroll
+                for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) dm[rt][t] = dy[rt][t];
+                drop_apply<NT>(*c.drop, uniform(o.lin[nl - 1]), dm, c.g);
+                last_layer(dm);
+            } else {
+                last_layer(dy);
             }
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) d1[rt][t] = alpha * selu_bwd4(d1[rt][t], s1[rt][t]);  // d(h1) (n=2) or d(x) part (n=1)
+            if (dropping && nl == 2) drop_apply<NT>(*c.drop, uniform(o.lin[0]), d1, c.g);  // d(L1's own output)
             __builtin_amdgcn_sched_barrier(0);
             trace_ev(c, 221);
             if (nl == 2) {

@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include "permutect_amd.h"
+#include "pmt_dropout.hpp"
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -699,8 +700,43 @@ DEV void pmt_join_sets(const PmtJoin& j, float* lds, float* glob, int set_stride
             lds[i] = __hip_atomic_fetch_add(&glob[(size_t)(i >> 5) * set_stride + (i & 31)], 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- dropout in training (pmt_dropout.hpp: the mask is a function of (seed, linear, row, feature)) --------------------------
+// Only the generic instances (ShapeAny read-set kernels, the row kernels) carry it; the host selects them when the model has
+// dropout_p > 0 AND the batch brings a seed (train mode).  row[rt]: the batch row of this lane's read (or variant) in tile rt.
+struct PmtDrop {
+    unsigned on, s0, s1, thresh;
+    float scale;     // 1 / (1 - p)
+    int row[PMT_RT];
+};
+DEV PmtDrop drop_setup(const PmtModel* __restrict__ M, unsigned long long seed, int mlp_flag) {
+    PmtDrop d;
+    const float p = uniform(M->dropout_p);
+    d.on = (seed != 0ull && p > 0.f && mlp_flag != 0) ? 1u : 0u;
+    d.s0 = (unsigned)seed; d.s1 = (unsigned)(seed >> 32);
+    d.thresh = pmt_drop_threshold(p);
+    d.scale = 1.0f / (1.0f - p);
+#pragma unroll
+    for (int rt = 0; rt < PMT_RT; ++rt) d.row[rt] = 0;
+    return d;
+}
+template <int NT>
+DEV void drop_apply(const PmtDrop& d, int lin, f4 (&y)[PMT_RT][NT], int g) {
+#pragma unroll
+    for (int rt = 0; rt < PMT_RT; ++rt) {
+        const unsigned key = pmt_drop_row_key(d.s0, d.s1, lin, d.row[rt]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[rt][t][j] = pmt_drop_keep(key, feat_of(t, j, g), d.thresh) ? y[rt][t][j] * d.scale : 0.f;
+    }
+}
+
 extern "C" int pmt_stash_slots(const PmtModel* m);  // host helper (pmt_host.hip)
 extern "C" int pmt_shape_id(const PmtModel* m);     // host: 2 = ShapeP0X (exact widths), 1 = ShapeP0 (exact tiles), 0 = ShapeAny
+// a batch that brings a dropout seed to a model with dropout_p > 0 runs the generic instances: only they carry the masks
+static inline int pmt_shape_for(const PmtModel* m, const PmtBatch* b) {
+    return (m->dropout_p > 0.f && b->dropout_seed != 0) ? 0 : pmt_shape_id(m);
+}
 
 DEV int frag_floats_dev(const PmtLinear& L) {
     const int h = uniform(L.out_split);

@@ -178,7 +178,10 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
 #pragma unroll
                 for (int t = 0; t < NTD; ++t) x[rt][t] = t < NTR ? xr[rt][t < NTR ? t : 0] : f4{0.f, 0.f, 0.f, 0.f};
         } else {
-            run_mlp<TRAIN, NTD, false>(M, M->read_mlp, xf, theta, g, mask_all, stash_tile, slot, 1, packed, 0, n_read_ops);
+            PmtDrop drop = drop_setup(M, bt.dropout_seed, uniform(M->read_mlp.dropout));
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt) drop.row[rt] = tm[rt].row;
+            run_mlp<TRAIN, NTD, false>(M, M->read_mlp, xf, theta, g, mask_all, stash_tile, slot, 1, packed, 0, n_read_ops, &drop);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
@@ -375,7 +378,10 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
         }
         run_linear_op<NTD, NTE, true, S::DIM_D, S::DIM_E, S::BF16>(M, M->reducer.ops[n_red_ops - 1], e, x, g, packed);
     } else {
-        run_mlp<TRAIN, NTD, false>(M, M->reducer, x, theta, g, mask_all, stash_tile, slot, 1, packed, 0, n_red_ops);
+        PmtDrop drop = drop_setup(M, bt.dropout_seed, uniform(M->reducer.dropout));
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt) drop.row[rt] = tm[rt].row;
+        run_mlp<TRAIN, NTD, false>(M, M->reducer, x, theta, g, mask_all, stash_tile, slot, 1, packed, 0, n_red_ops, &drop);
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
@@ -631,7 +637,7 @@ extern "C" int pmt_forward_layered(const PmtModel* model_host, const PmtModel* m
         !batch->group_tile_base || batch->total_tiles <= 0 || !out->logits_b || !out->logits_bk || !out->features_be || !out->ref_features_be)
         return PMT_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int shape = pmt_shape_id(model_host);
+    const int shape = pmt_shape_for(model_host, batch);
     const bool p0 = shape == 1;
     const int L = model_host->num_blocks;
     const size_t nb = (size_t)(L > 0 ? L : 1), B = (size_t)batch->num_variants;
@@ -688,7 +694,7 @@ extern "C" int pmt_forward(const PmtModel* model_host, const PmtModel* model_dev
         return PMT_E_INVALID;
     if (batch->group_span) return PMT_E_UNSUPPORTED;  // split read sets: pmt_forward_layered
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int shape = pmt_shape_id(model_host);  // pmt_device.hpp: 2 ShapeP0X, 1 ShapeP0, 0 ShapeAny
+    const int shape = pmt_shape_for(model_host, batch);  // pmt_device.hpp: 2 ShapeP0X, 1 ShapeP0, 0 ShapeAny
     const bool p0 = shape == 1;
     float* zsum_stash = nullptr;
     float* rstd_stash = nullptr;

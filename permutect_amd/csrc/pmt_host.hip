@@ -133,6 +133,7 @@ extern "C" int pmt_model_check(const PmtModel* m) {
     if (m->num_blocks < 0 || m->num_blocks > PMT_MAX_BLOCKS) return PMT_E_UNSUPPORTED;
     if (m->feature_dim < 2 || m->feature_dim > PMT_MAX_WIDTH) return PMT_E_UNSUPPORTED;
     if (m->num_clusters < 1 || m->num_clusters > PMT_MAX_CLUSTERS) return PMT_E_UNSUPPORTED;
+    if (!(m->dropout_p >= 0.f && m->dropout_p < 1.f)) return PMT_E_INVALID;
     if (m->read_mlp.in_dim != m->num_read_features || m->read_mlp.out_dim != m->read_embed_dim) return PMT_E_INVALID;
     if (m->reducer.in_dim != m->d_model || m->reducer.out_dim != m->feature_dim) return PMT_E_INVALID;
     int rc = check_mlp(m, &m->read_mlp);
@@ -868,6 +869,18 @@ extern "C" int pmt_host_copy(void* dst, const void* src, size_t bytes, int32_t t
         if (hi == bytes) break;
     }
     for (auto& t : pool) t.join();
+    return PMT_OK;
+}
+
+// The dropout masks as the kernels generate them (pmt_dropout.hpp), for the parity tests.
+extern "C" int pmt_dropout_mask(uint64_t seed, float p, int32_t lin, int64_t row0, int64_t rows, int32_t width, float* out) {
+    if (!out || rows < 0 || width < 0 || !(p >= 0.f && p < 1.f) || lin < 0) return PMT_E_INVALID;
+    const unsigned thresh = pmt_drop_threshold(p);
+    const float scale = 1.0f / (1.0f - p);
+    for (int64_t r = 0; r < rows; ++r) {
+        const unsigned key = pmt_drop_row_key((unsigned)seed, (unsigned)(seed >> 32), lin, (int)(row0 + r));
+        for (int f = 0; f < width; ++f) out[r * width + f] = (seed == 0 || pmt_drop_keep(key, f, thresh)) ? (seed == 0 ? 1.0f : scale) : 0.f;
+    }
     return PMT_OK;
 }
 

@@ -28,10 +28,13 @@ DEV void run_linear_op(const PmtModel* __restrict__ M, const PmtOp& o, f4 (&y)[P
 // Runs ops [op_begin, op_end) on x in place; every op in the range maps NT tiles to NT tiles.  With TRAIN the INPUT of
 // every op with index >= first_stashed_op is written to consecutive stash slots starting at `slot` (tiles in
 // store_mask only).
+// drop (generic instances only, nullptr = none): dropout behind every Linear (reference mlp.py:57-58), BEFORE the SELU that
+// follows it; inside a skip block both Linears are followed by one, so f(x) itself is masked before alpha scales it.
 template <bool TRAIN, int NT, bool EXACT, int W = 0, int BF = 0>
 DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_RT][NT], const float* __restrict__ theta,
                  int g, unsigned store_mask, float* const (&stash_tile)[PMT_RT], int& slot, int first_stashed_op,
-                 const float* __restrict__ packed, int op_begin, int op_end) {
+                 const float* __restrict__ packed, int op_begin, int op_end, const PmtDrop* drop = nullptr) {
+    const bool dropping = !EXACT && drop != nullptr && drop->on != 0;
     for (int op = op_begin; op < op_end; ++op) {
         const PmtOp& o = mlp.ops[op];
         if (TRAIN && op >= first_stashed_op) {
@@ -42,11 +45,49 @@ DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_
         }
         f4 y[PMT_RT][NT];
         if (uniform(o.kind) == PMT_OP_LINEAR) {
+            if (dropping) {
+                const PmtLinear& L = M->lin[uniform(o.lin[0])];
+                const int b_pvec = uniform(L.b_pvec);
+                init_bias<NT>(y, b_pvec >= 0 ? packed + b_pvec : nullptr, uniform(L.out_dim), g);
+                linear_acc<NT, NT, false, false>(y, x, packed + uniform(L.w_frag), uniform(L.in_dim), uniform(L.out_dim));
+                drop_apply<NT>(*drop, uniform(o.lin[0]), y, g);
+                const bool act = uniform(o.selu_after) != 0;
+#pragma unroll
+                for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) x[rt][t] = act ? selu4(y[rt][t]) : y[rt][t];
+                continue;
+            }
             run_linear_op<NT, NT, EXACT, W, W, BF>(M, o, y, x, g, packed);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) x[rt][t] = y[rt][t];
+        } else if (dropping) {
+            // x + alpha * D2(L2(selu(D1(L1(selu(x))))))   (n = 2)   or   x + alpha * D1(L1(selu(x)))   (n = 1)
+            const int nl = uniform(o.n_layers);
+            const int width = uniform(M->lin[uniform(o.lin[0])].in_dim);
+            const float alpha = uniform(theta[uniform(o.alpha_src)]);
+            f4 f[PMT_RT][NT];
+            if (nl == 2) {
+                const PmtLinear& L1 = M->lin[uniform(o.lin[0])];
+                init_bias<NT>(y, packed + uniform(L1.b_pvec), width, g);
+                linear_acc<NT, NT, true, false>(y, x, packed + uniform(L1.w_frag), width, width);
+                drop_apply<NT>(*drop, uniform(o.lin[0]), y, g);
+            } else {
+#pragma unroll
+                for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) y[rt][t] = x[rt][t];
+            }
+            const PmtLinear& L2 = M->lin[uniform(o.lin[nl - 1])];
+            init_bias<NT>(f, packed + uniform(L2.b_pvec), width, g);
+            linear_acc<NT, NT, true, false>(f, y, packed + uniform(L2.w_frag), width, width);
+            drop_apply<NT>(*drop, uniform(o.lin[nl - 1]), f, g);
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) x[rt][t] = x[rt][t] + alpha * f[rt][t];
         } else {
             // x + alpha * f(x) with one or two (SELU, Linear) layers.  Only two register arrays are live: the last
             // layer accumulates straight into x, with alpha folded into its B operand and bias.

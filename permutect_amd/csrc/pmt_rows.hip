@@ -37,7 +37,8 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_forward_kernel(const 
                                                                            const float* __restrict__ packed,
                                                                            const float* __restrict__ in, long long in_stride,
                                                                            int n_rows, float* __restrict__ out,
-                                                                           long long out_stride, float* __restrict__ stash) {
+                                                                           long long out_stride, float* __restrict__ stash,
+                                                                           unsigned long long dropout_seed) {
     const PmtMlp& mlp = M->row_mlp[which];
     const int lane = threadIdx.x & 63, g = lane >> 4, wave = uniform((int)(threadIdx.x >> 6));
     const int tile0 = (blockIdx.x * PMT_WAVES + wave) * PMT_RT;
@@ -49,6 +50,9 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_forward_kernel(const 
         if ((tile0 + rt) * 16 < n_rows) present |= 1u << rt;
         stash_tile[rt] = TRAIN ? stash + (size_t)(tile0 + rt) * (size_t)((n_ops - 1) * PMT_SLOT_FLOATS) : nullptr;
     }
+    PmtDrop drop = drop_setup(M, dropout_seed, uniform(mlp.dropout));
+#pragma unroll
+    for (int rt = 0; rt < PMT_RT; ++rt) drop.row[rt] = (tile0 + rt) * 16 + (lane & 15);
     f4 x[PMT_RT][PMT_NT];
     int slot = 0, op_begin = 0;
     if (in_dim > PMT_MAX_WIDTH) {  // wide first linear (checked on the host: op 0 is LINEAR)
@@ -59,6 +63,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_forward_kernel(const 
         const int b_pvec = uniform(L.b_pvec);
         init_bias<PMT_NT>(x, b_pvec >= 0 ? packed + b_pvec : nullptr, uniform(L.out_dim), g);
         linear_acc<ROWS_NTIN, PMT_NT, false>(x, xin, packed + uniform(L.w_frag), in_dim, uniform(L.out_dim));
+        if (drop.on) drop_apply<PMT_NT>(drop, uniform(o.lin[0]), x, g);
         if (uniform(o.selu_after) != 0) {
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
@@ -69,7 +74,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_forward_kernel(const 
     } else {
         load_rows<PMT_NT>(x, in, in_stride, n_rows, in_dim, tile0, g);
     }
-    run_mlp<TRAIN, PMT_NT, false>(M, mlp, x, theta, g, present, stash_tile, slot, 1, packed, op_begin, uniform(mlp.n_ops));
+    run_mlp<TRAIN, PMT_NT, false>(M, mlp, x, theta, g, present, stash_tile, slot, 1, packed, op_begin, uniform(mlp.n_ops), &drop);
     const int r = lane & 15;
 #pragma unroll
     for (int rt = 0; rt < PMT_RT; ++rt) {
@@ -98,7 +103,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_backward_kernel(
     const PmtModel* __restrict__ M, int which, const float* __restrict__ theta, const float* __restrict__ packed,
     const float* __restrict__ in, long long in_stride, int n_rows, const float* __restrict__ d_out, long long d_out_stride,
     const float* __restrict__ stash, float* __restrict__ gtheta, float* __restrict__ d_in, long long d_in_stride,
-    float d_in_scale, float* __restrict__ replicas, int rep_lo, int rep_span, int rep_count) {
+    float d_in_scale, float* __restrict__ replicas, int rep_lo, int rep_span, int rep_count, unsigned long long dropout_seed) {
     __shared__ __attribute__((aligned(16))) RowsBwdShared sh;
     // Every workgroup adds its weight-gradient blocks to the SAME addresses at the same point of the same program: with
     // hundreds of workgroups the L2 serialises those float atomics (78 of 164 us at 65 536 rows).  With `replicas` workgroup b
@@ -121,6 +126,10 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_backward_kernel(
     const int wg_tiles = min(PMT_GROUP_TILES, ((n_rows + 15) >> 4) - (int)blockIdx.x * PMT_GROUP_TILES);
     BwdCtx c{M, theta, theta, packed, gtheta, gtheta, &sh.stage[0], &sh.aux[0][0], &sh.aux_dst[0], g, present,
              wave * PMT_RT, wg_tiles, wg_tiles, 0, PMT_ROWS_DBG, nullptr};
+    PmtDrop drop = drop_setup(M, dropout_seed, uniform(mlp.dropout));
+#pragma unroll
+    for (int rt = 0; rt < PMT_RT; ++rt) drop.row[rt] = (tile0 + rt) * 16 + r;
+    c.drop = &drop;
     // d(out) -> registers (zero for padding rows: they then contribute nothing to any weight gradient)
     f4 dy[PMT_RT][PMT_NT];
 #pragma unroll
@@ -161,11 +170,13 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_backward_kernel(
             const int b_pvec = uniform(L.b_pvec);
             init_bias<PMT_NT>(y, b_pvec >= 0 ? packed + b_pvec : nullptr, uniform(L.out_dim), g);
             linear_acc<ROWS_NTIN, PMT_NT, false>(y, xin, packed + uniform(L.w_frag), in_dim, uniform(L.out_dim));
+            if (drop.on) drop_apply<PMT_NT>(drop, uniform(o.lin[0]), y, g);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
                 for (int t = 0; t < PMT_NT; ++t) dy[rt][t] = selu_bwd4(dy[rt][t], selu4(y[rt][t]));
         }
+        if (drop.on) drop_apply<PMT_NT>(drop, uniform(o.lin[0]), dy, g);
         linear_wgrad<PMT_NT, ROWS_NTIN>(c, L, dy, xin);
     }
     aux_flush(c);  // skip-block alphas
@@ -259,7 +270,7 @@ extern "C" size_t pmt_rows_stash_bytes(const PmtModel* m, int which, int32_t n_r
 
 extern "C" int pmt_rows_forward(const PmtModel* model_host, const PmtModel* model_dev, int which, const float* theta,
                                 const float* packed, const float* in, int64_t in_stride, int32_t n_rows, float* out,
-                                int64_t out_stride, float* stash, void* stream) {
+                                int64_t out_stride, float* stash, uint64_t dropout_seed, void* stream) {
     const int rc = rows_check(model_host, which, n_rows);
     if (rc) return rc;
     if (!model_dev || !theta || !packed || !in || !out) return PMT_E_INVALID;
@@ -268,17 +279,18 @@ extern "C" int pmt_rows_forward(const PmtModel* model_host, const PmtModel* mode
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (stash)
         hipLaunchKernelGGL(pmt_rows_forward_kernel<true>, dim3(grid), dim3(PMT_THREADS), 0, s, model_dev, which, theta, packed, in,
-                           (long long)in_stride, n_rows, out, (long long)out_stride, stash);
+                           (long long)in_stride, n_rows, out, (long long)out_stride, stash, (unsigned long long)dropout_seed);
     else
         hipLaunchKernelGGL(pmt_rows_forward_kernel<false>, dim3(grid), dim3(PMT_THREADS), 0, s, model_dev, which, theta, packed,
-                           in, (long long)in_stride, n_rows, out, (long long)out_stride, (float*)nullptr);
+                           in, (long long)in_stride, n_rows, out, (long long)out_stride, (float*)nullptr, (unsigned long long)dropout_seed);
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }
 
 extern "C" int pmt_rows_backward(const PmtModel* model_host, const PmtModel* model_dev, int which, const float* theta,
                                  const float* packed, const float* in, int64_t in_stride, int32_t n_rows, const float* d_out,
                                  int64_t d_out_stride, const float* stash, float* grad_theta, float* d_in,
-                                 int64_t d_in_stride, float d_in_scale, float* workspace, size_t workspace_floats, void* stream) {
+                                 int64_t d_in_stride, float d_in_scale, float* workspace, size_t workspace_floats, uint64_t dropout_seed,
+                                 void* stream) {
     const int rc = rows_check(model_host, which, n_rows);
     if (rc) return rc;
     if (!model_dev || !theta || !packed || !in || !d_out || !stash || !grad_theta) return PMT_E_INVALID;
@@ -292,7 +304,8 @@ extern "C" int pmt_rows_backward(const PmtModel* model_host, const PmtModel* mod
     const int used = grid < ROWS_REPLICAS ? grid : ROWS_REPLICAS;
     hipLaunchKernelGGL(pmt_rows_backward_kernel, dim3(grid), dim3(PMT_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
                        model_dev, which, theta, packed, in, (long long)in_stride, n_rows, d_out, (long long)d_out_stride, stash,
-                       grad_theta, d_in, (long long)d_in_stride, d_in_scale, rep ? workspace : nullptr, lo, hi - lo, used);
+                       grad_theta, d_in, (long long)d_in_stride, d_in_scale, rep ? workspace : nullptr, lo, hi - lo, used,
+                       (unsigned long long)dropout_seed);
     if (rep)
         hipLaunchKernelGGL(pmt_rows_fold_kernel, dim3((hi - lo + 255) / 256, ROWS_FOLD_SLICES), dim3(256), 0,
                            reinterpret_cast<hipStream_t>(stream), workspace, used, hi - lo, grad_theta + lo);

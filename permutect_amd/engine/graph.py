@@ -130,6 +130,9 @@ class GraphedTrainStep:
 
     def __init__(self, model, optimizer, batch: StaticBatch, warmup: int = 2):
         self.model, self.opt, self.batch = model, optimizer, batch
+        if model.engine().plan.desc.dropout_p > 0:
+            # the step's dropout seed is a launch argument: a captured graph would replay ONE mask for ever
+            raise NotImplementedError("a model with dropout_p > 0 trains eagerly (a new seed per step); GraphedTrainStep would freeze the masks")
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self._lr = None
         self._warmup = warmup

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_HERE, "libpermutect_amd.so")
 
 # ---- limits (must match the header) -------------------------------------------------------------------------------
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_WIDTH, MAX_HALF_FFN, MAX_CLUSTERS = 64, 16, 16
 MAX_ROW_INPUT = 128
 MAX_CNN_TAPS = 192
@@ -44,7 +44,7 @@ class PmtOp(C.Structure):
 
 
 class PmtMlp(C.Structure):
-    _fields_ = [("n_ops", i32), ("in_dim", i32), ("out_dim", i32), ("reserved", i32), ("ops", PmtOp * MAX_OPS)]
+    _fields_ = [("n_ops", i32), ("in_dim", i32), ("out_dim", i32), ("dropout", i32), ("ops", PmtOp * MAX_OPS)]
 
 
 class PmtBlock(C.Structure):
@@ -83,14 +83,15 @@ class PmtModel(C.Structure):
                 ("translation_src", i32), ("translation_pvec", i32), ("rotation_lin", i32),
                 ("read_mlp", PmtMlp), ("reducer", PmtMlp), ("row_mlp", PmtMlp * 3), ("blocks", PmtBlock * MAX_BLOCKS), ("head", PmtHead), ("cnn", PmtCnn),
                 ("lin", PmtLinear * MAX_LINEAR),
-                ("force_shape", i32), ("force_cnn", i32), ("cnn_debug", i32), ("emit_base", i32), ("emit_len", i32)]
+                ("force_shape", i32), ("force_cnn", i32), ("cnn_debug", i32), ("emit_base", i32), ("emit_len", i32),
+                ("dropout_p", C.c_float)]
 
 
 class PmtBatch(C.Structure):
     _fields_ = [("num_variants", i32), ("num_groups", i32), ("read_format", i32), ("read_row_bytes", i32),
                 ("reads", vp), ("read_index", vp), ("ref_offsets", vp), ("alt_offsets", vp), ("variant_embed", vp),
                 ("group_start", vp), ("group_tile_base", vp), ("total_tiles", i64), ("debug_flags", vp), ("group_span", vp),
-                ("num_groups_dev", vp), ("set_groups", vp)]
+                ("num_groups_dev", vp), ("set_groups", vp), ("dropout_seed", C.c_uint64)]
 
 
 class PmtOutputs(C.Structure):
@@ -152,7 +153,7 @@ class PmtLossInputGrads(C.Structure):
 
 EXPORTS = ["pmt_abi_version", "pmt_struct_bytes", "pmt_model_check", "pmt_plan_groups", "pmt_stash_bytes", "pmt_pack_params",
            "pmt_scan_counts", "pmt_forward", "pmt_backward", "pmt_clip_adamw",
-           "pmt_rows_stash_bytes", "pmt_rows_forward", "pmt_rows_backward", "pmt_rows_workspace_floats", "pmt_cnn_forward", "pmt_cnn_backward", "pmt_cnn_stash_floats", "pmt_cnn_workspace_floats",
+           "pmt_dropout_mask", "pmt_rows_stash_bytes", "pmt_rows_forward", "pmt_rows_backward", "pmt_rows_workspace_floats", "pmt_cnn_forward", "pmt_cnn_backward", "pmt_cnn_stash_floats", "pmt_cnn_workspace_floats",
            "pmt_phi_forward", "pmt_phi_backward", "pmt_build_read_index", "pmt_losses_forward", "pmt_losses_backward",
            "pmt_downsample_counts", "pmt_downsample_index", "pmt_record_losses",
            "pmt_plan_groups_split", "pmt_layered_scratch_floats", "pmt_forward_layered",
@@ -199,8 +200,9 @@ def load() -> C.CDLL:
     lib.pmt_cnn_stash_floats.restype = C.c_size_t
     lib.pmt_rows_stash_bytes.argtypes = [P(PmtModel), i32, i32]
     lib.pmt_rows_stash_bytes.restype = C.c_size_t
-    lib.pmt_rows_forward.argtypes = [P(PmtModel), vp, i32, vp, vp, vp, i64, i32, vp, i64, vp, vp]
-    lib.pmt_rows_backward.argtypes = [P(PmtModel), vp, i32, vp, vp, vp, i64, i32, vp, i64, vp, vp, vp, i64, C.c_float, vp, C.c_size_t, vp]
+    lib.pmt_rows_forward.argtypes = [P(PmtModel), vp, i32, vp, vp, vp, i64, i32, vp, i64, vp, C.c_uint64, vp]
+    lib.pmt_rows_backward.argtypes = [P(PmtModel), vp, i32, vp, vp, vp, i64, i32, vp, i64, vp, vp, vp, i64, C.c_float, vp, C.c_size_t, C.c_uint64, vp]
+    lib.pmt_dropout_mask.argtypes = [C.c_uint64, C.c_float, i32, i64, i64, i32, vp]
     lib.pmt_rows_workspace_floats.argtypes = [P(PmtModel), i32]
     lib.pmt_rows_workspace_floats.restype = C.c_size_t
     lib.pmt_build_read_index.argtypes = [vp, vp, vp, i32, vp, vp]

@@ -189,6 +189,7 @@ class EnginePlan:
         d.force_shape = {"tile": 1, "any": 2, "bf16": 3}.get(os.environ.get("PMT_SHAPE", ""), 0)
         d.force_cnn = {"general": 1, "wave": 2, "batched": 3}.get(os.environ.get("PMT_CNN", ""), 0)
         d.cnn_debug = int(os.environ.get("PMT_CNN_DBG", "0"))
+        d.dropout_p = max((float(getattr(m, "dropout_p", 0.0)) for m in model.modules() if isinstance(m, M.MLP)), default=0.0)
 
         lib = L.load()
         L.check(lib.pmt_model_check(C.byref(d)), "pmt_model_check")
@@ -271,7 +272,9 @@ class EnginePlan:
                                     layer.bias is not None, out_split, max_in=max_in)
 
     def _lower_mlp(self, dst: L.PmtMlp, mlp: M.MLP, max_in: int = L.MAX_WIDTH):
-        # (nn.Dropout: identity in eval mode, the only mode the engine runs a model with dropout_p > 0 in)
+        # nn.Dropout (reference mlp.py:57-58: one behind every Linear when dropout_p > 0) becomes a flag of the MLP: the kernels
+        # mask every Linear's output of a flagged MLP when the batch brings a seed (train mode), and ignore it otherwise (eval)
+        dst.dropout = int(any(isinstance(c, nn.Dropout) for c in mlp._model.modules()))
         children = [c for c in mlp._model.children() if not isinstance(c, nn.Dropout)]
         ops = []
         i = 0

@@ -42,6 +42,7 @@ class ReadSetEngine:
         # optimizer on the calibration parameters), `params_changed()` is called by whatever writes theta through a raw pointer
         # (the fused optimizer kernel, a captured-graph replay, a collective on the flat buffer)
         self.join_layered = os.environ.get("PMT_LAYERED_JOIN", "1") != "0"
+        self.dropout_seed = 0  # this step's dropout masks (draw_dropout_seed; 0 = none)
         self.join_fault_words = []  # views of the fault words of the joined launches issued so far (check_join_fault)
         self._param_epoch = 0
         self.packed_for = None  # (params_key, phi) the packed weights were built from, under no_grad only
@@ -114,7 +115,14 @@ class ReadSetEngine:
             batch._offsets = (ref_off, alt_off)
         return batch._offsets
 
-    def batch_view(self, batch, variant_embed: Tensor, allow_split: bool = True):
+    def draw_dropout_seed(self, training: bool) -> int:
+        """The seed of this step's dropout masks (0 = none: eval mode or dropout_p = 0).  Drawn from torch's CPU generator, so
+        torch.manual_seed replays a training run mask for mask; every MLP of the step uses it (the masks differ by linear
+        and row, pmt_dropout.hpp), the forward keeps it for its backward."""
+        self.dropout_seed = int(torch.randint(1, 2 ** 62, (1,)).item()) if (training and self.plan.desc.dropout_p > 0) else 0
+        return self.dropout_seed
+
+    def batch_view(self, batch, variant_embed: Tensor, allow_split: bool = True, dropout_seed: int = 0):
         plan = batch.plan(allow_split=allow_split)
         gs, gt, span = plan.on(self.device)
         ref_off, alt_off = self.offsets(batch)
@@ -136,18 +144,19 @@ class ReadSetEngine:
         # (PMT_LAYERED_JOIN=0: num_blocks + 1 launches with the activations parked in between; the parity tests run both)
         sets = plan.set_groups_on(self.device) if (getattr(plan, "set_groups", None) is not None and self.join_layered) else None
         bv.set_groups = _ptr(sets)
+        bv.dropout_seed = dropout_seed
         keep = (gs, gt, span, ref_off, alt_off, reads, index, variant_embed, sets)
         return bv, keep, plan
 
     # ---- passes -----------------------------------------------------------------------------------------------------
-    def forward(self, batch, phi: Tensor, variant_embed: Tensor, train: bool):
+    def forward(self, batch, phi: Tensor, variant_embed: Tensor, train: bool, dropout_seed: int = 0):
         d = self.plan.desc
         b, k, e = batch.size(), d.num_clusters, d.feature_dim
         variant_embed = variant_embed.contiguous().float()
         assert variant_embed.shape == (b, d.variant_embed_dim), (variant_embed.shape, d.variant_embed_dim)
         phi = phi.contiguous()
         # read sets of any size: beyond one workgroup they are split over several groups (layered execution)
-        bv, keep, plan = self.batch_view(batch, variant_embed)
+        bv, keep, plan = self.batch_view(batch, variant_embed, dropout_seed=dropout_seed)
         dev = self.device
         logits_b = torch.empty(b, dtype=torch.float32, device=dev)
         logits_bk = torch.empty(b, k + 2, dtype=torch.float32, device=dev)
@@ -173,9 +182,9 @@ class ReadSetEngine:
         self._event_stop("pmt_forward", ev)
         return (logits_b, logits_bk, feats, ref_feats), stash, variant_embed, phi
 
-    def backward(self, batch, phi: Tensor, variant_embed: Tensor, stash: Tensor, outs, grads):
+    def backward(self, batch, phi: Tensor, variant_embed: Tensor, stash: Tensor, outs, grads, dropout_seed: int = 0):
         d = self.plan.desc
-        bv, keep, plan = self.batch_view(batch, variant_embed)
+        bv, keep, plan = self.batch_view(batch, variant_embed, dropout_seed=dropout_seed)
         g = [None if t is None else t.contiguous().float() for t in grads]
         dout = L.PmtOutputGrads(_ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]))
         out = L.PmtOutputs(*[t.data_ptr() for t in outs])
@@ -291,7 +300,8 @@ class ReadSetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, engine: ReadSetEngine, batch, phi: Tensor, variant_embed: Tensor):
         train = bool(ctx.needs_input_grad[2] or ctx.needs_input_grad[3])  # False under no_grad / inference_mode
-        outs, stash, ve, ph = engine.forward(batch, phi.detach(), variant_embed.detach(), train)
+        ctx.dropout_seed = engine.dropout_seed  # (set by the model at the start of the step; 0 in eval mode)
+        outs, stash, ve, ph = engine.forward(batch, phi.detach(), variant_embed.detach(), train, ctx.dropout_seed)
         ctx.engine, ctx.batch, ctx.train = engine, batch, train
         ctx.set_materialize_grads(False)  # outputs the loss does not use (ref_features_be) arrive as None = a null pointer
         if train:
@@ -304,7 +314,8 @@ class ReadSetFunction(torch.autograd.Function):
             return None, None, None, None
         phi, ve, stash, *outs = ctx.saved_tensors
         ctx.engine.space.bind_grads()
-        gphi, gvar = ctx.engine.backward(ctx.batch, phi, ve, stash, outs, (d_logits_b, d_logits_bk, d_feats, d_ref_feats))
+        gphi, gvar = ctx.engine.backward(ctx.batch, phi, ve, stash, outs, (d_logits_b, d_logits_bk, d_feats, d_ref_feats),
+                                         ctx.dropout_seed)
         return None, None, gphi, gvar
 
 
@@ -373,7 +384,8 @@ class RowsMlpFunction(torch.autograd.Function):
             stash = torch.empty(lib.pmt_rows_stash_bytes(C.byref(d), which, n) // 4, dtype=torch.float32, device=engine.device)
         L.check(lib.pmt_rows_forward(C.byref(d), engine.plan.desc_dev.data_ptr(), which, engine.space.theta.data_ptr(),
                                      engine.plan.packed.data_ptr(), x.data_ptr(), x.stride(0), n, out.data_ptr(),
-                                     out.stride(0), _ptr(stash), _stream()), "pmt_rows_forward")
+                                     out.stride(0), _ptr(stash), engine.dropout_seed, _stream()), "pmt_rows_forward")
+        ctx.dropout_seed = engine.dropout_seed
         ctx.engine, ctx.which, ctx.train, ctx.alpha = engine, which, train, reverse_alpha
         ctx.x_needs_grad = bool(ctx.needs_input_grad[2])
         if train:
@@ -397,5 +409,5 @@ class RowsMlpFunction(torch.autograd.Function):
                                           eng.plan.packed.data_ptr(), x.data_ptr(), x.stride(0), n, d_out.data_ptr(),
                                           d_out.stride(0), stash.data_ptr(), eng.space.gtheta.data_ptr(), _ptr(d_in),
                                           d_in.stride(0) if d_in is not None else 0, scale, _ptr(ws), 0 if ws is None else ws.numel(),
-                                          _stream()), "pmt_rows_backward")
+                                          ctx.dropout_seed, _stream()), "pmt_rows_backward")
         return None, None, d_in, None, None
