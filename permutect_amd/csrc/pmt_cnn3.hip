@@ -55,7 +55,7 @@ DEV void c3_wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 DEV int c3_row(int m) { return 4 * (m & 3) + (m >> 2); }  // A-fragment row m / block element e -> channel within the 16-block
-DEV float c3_act(int kind, float x) { return kind == PMT_CNN_LEAKY_RELU ? (x > 0.f ? x : 0.01f * x) : selu1(x); }
+DEV float c3_act(int kind, float x) { return kind == PMT_CNN_LEAKY_RELU ? fmaxf(x, 0.01f * x) : selu1(x); }  // (max: x for x > 0, 0.01 x below)
 DEV float c3_act_grad(int kind, float y) { return kind == PMT_CNN_LEAKY_RELU ? (y > 0.f ? 1.f : 0.01f) : selu_grad_from_out(y); }
 DEV f4 c3_act4(int kind, f4 v) { return f4{c3_act(kind, v[0]), c3_act(kind, v[1]), c3_act(kind, v[2]), c3_act(kind, v[3])}; }
 DEV f4 c3_act_grad4(int kind, f4 y) { return f4{c3_act_grad(kind, y[0]), c3_act_grad(kind, y[1]), c3_act_grad(kind, y[2]), c3_act_grad(kind, y[3])}; }
@@ -349,6 +349,246 @@ __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_forward_kernel(
             C3_EV();  // records stored
             if (lane == 0) tr[127] = (unsigned long long)tr_n;
         }
+    }
+}
+
+// ================================================ forward on the bf16 matrix pipe ======================================
+// The same forward with every product as bf16 MFMAs on three-piece splits (pmt_device.hpp: an fp32 value IS hi + mid + lo in
+// bf16; six v_mfma_f32_16x16x32_bf16 reproduce the fp32 product to a bit or two in 96 cycles per 32-deep block where eight
+// v_mfma_f32_16x16x4_f32 take 256).  What changes against the kernel above:
+//   * conv1's B operand is exact in ONE piece (a one-hot), and all of its K1 * 10 <= 32 taps x channels are one k block: 3 MFMAs
+//     per 16 x 16 tile instead of 18.  The one-hot lies in LDS as bf16 [position][channel] per variant, so the operand of
+//     column (v, p) -- k = tap * 10 + channel -- is the 64 contiguous bytes behind position p: four ds_read_b32, no compares;
+//   * activations rest in LDS as bf16 pieces [column][piece][32 channels in record order]: a k block of conv2 / the linear is
+//     one ds_read_b128 per piece; the producer splits its 4 channels per 16-block and stores 8 bytes per piece;
+//   * conv1's and conv2's weights live in registers (96) for the whole kernel, the linear's in LDS; they are split once per
+//     workgroup into a staging area that the waves' regions then reuse;
+//   * a training forward writes its records (fp32 a1, a2, pool argmax: the backward's format) straight from registers.
+// Selected for K1 * 10 <= 32 (PmtModel.cnn_debug bit 8 keeps the fp32 kernel above: A/B runs, and the parity tests run both).
+#define C3B_OH_PAD 16
+DEV int c3_chan_of_elem(int e) { return 16 * (e >> 4) + 4 * (e & 3) + ((e & 15) >> 2); }  // record element -> channel
+typedef unsigned c3_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned c3_u2 __attribute__((ext_vector_type(2)));
+// the A fragment of lane `ln` (row m = ln & 15, k = 8 (ln >> 4) + i) in three pieces: dst[piece * 64 + ln]
+template <typename F>
+DEV void c3b_build_frag(bf8* __restrict__ dst, int ln, F value) {
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) split_pair<3>(value(2 * q), value(2 * q + 1), h[q], m[q], l[q]);
+    dst[ln] = __builtin_bit_cast(bf8, c3_u4{h[0], h[1], h[2], h[3]});
+    dst[64 + ln] = __builtin_bit_cast(bf8, c3_u4{m[0], m[1], m[2], m[3]});
+    dst[128 + ln] = __builtin_bit_cast(bf8, c3_u4{l[0], l[1], l[2], l[3]});
+}
+// acc += A B with both operands in three pieces (smallest terms first)
+DEV f4 c3b_mfma6(const bf8 (&a)[3], const bf8 (&b)[3], f4 acc) {
+    acc = mfma_bf16(a[2], b[0], acc);
+    acc = mfma_bf16(a[0], b[2], acc);
+    acc = mfma_bf16(a[1], b[1], acc);
+    acc = mfma_bf16(a[1], b[0], acc);
+    acc = mfma_bf16(a[0], b[1], acc);
+    return mfma_bf16(a[0], b[0], acc);
+}
+// four activations of one 16-block -> 8 bytes per piece at dst + piece * 64
+DEV void c3b_store_pieces(unsigned char* dst, f4 v) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    split_pair<3>(v[0], v[1], h0, m0, l0);
+    split_pair<3>(v[2], v[3], h1, m1, l1);
+    *reinterpret_cast<c3_u2*>(dst) = c3_u2{h0, h1};
+    *reinterpret_cast<c3_u2*>(dst + 64) = c3_u2{m0, m1};
+    *reinterpret_cast<c3_u2*>(dst + 128) = c3_u2{l0, l1};
+}
+__host__ __device__ inline size_t c3b_wave_bytes(int V, int S, int P1, int ST2) {
+    return (size_t)((V * (S * 10 + C3B_OH_PAD) * 2 + 15) & ~15) + (size_t)V * P1 * 192 + (size_t)V * ST2 * 192;
+}
+
+// A1 / A2: the two activations at compile time (0 = read the configuration: both kinds are then evaluated per element);
+// TRAIN: write the backward's records.
+template <int V, int NW, int K1, int K2, int L2, int S1, int A1, int A2, bool TRAIN>
+__global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_forward_bf_kernel(
+    C3Cfg c, const float* __restrict__ theta, const long long* __restrict__ hap, long long hap_stride, int n, float* __restrict__ out,
+    long long out_stride, float* __restrict__ stash) {
+    static_assert(K1 * 10 <= 32, "conv1's taps x channels are one k block");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int P1 = L2 + K2 - 1, ST2 = L2 <= 4 ? 4 : 8, N2T = (V * ST2 + 15) / 16;
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, r = lane & 15, wave = uniform((int)(tid >> 6));
+    const int S = S1 ? S1 : c.S, st1 = S1 ? ((S1 - K1 + 2) & ~1) : c.st1, n1t = S1 ? (V * st1 + 15) / 16 : c.n1t;
+    const float inv_st1 = 1.0f / (float)st1;
+    const int OHS = S * 10 + C3B_OH_PAD;  // bf16 elements of one variant's one-hot array
+    // ---- LDS: [linear weights: L2 x 3 pieces x 1 KiB][biases: 80 floats][staging of conv1 / conv2 weights | the waves' regions]
+    unsigned char* base = reinterpret_cast<unsigned char*>(lds);
+    bf8* wlb = reinterpret_cast<bf8*>(base);
+    float* bp = reinterpret_cast<float*>(base + L2 * 3072);
+    unsigned char* dyn = base + L2 * 3072 + 320;
+    bf8* w1s = reinterpret_cast<bf8*>(dyn);
+    bf8* w2s = w1s + 2 * 192;
+    for (int e = tid; e < 2 * 64; e += 64 * NW) {
+        const int ln = e & 63, mt = e >> 6, co = 16 * mt + c3_row(ln & 15), kg = ln >> 4;
+        c3b_build_frag(w1s + mt * 192, ln, [&](int i) {
+            const int k = 8 * kg + i, tap = k / 10, ci = k - 10 * tap;
+            return (k < 10 * K1 && co < c.C1) ? theta[c.w1 + (co * 10 + ci) * K1 + tap] : 0.f;
+        });
+    }
+    for (int e = tid; e < K2 * 2 * 64; e += 64 * NW) {
+        const int ln = e & 63, tm = e >> 6, tap = tm >> 1, mt = tm & 1, co = 16 * mt + c3_row(ln & 15), kg = ln >> 4;
+        c3b_build_frag(w2s + tm * 192, ln, [&](int i) {
+            const int ci = c3_chan_of_elem(8 * kg + i);
+            return (co < c.C2 && ci < c.C1) ? theta[c.w2 + (co * c.C1 + ci) * K2 + tap] : 0.f;
+        });
+    }
+    for (int e = tid; e < L2 * 64; e += 64 * NW) {
+        const int ln = e & 63, p = e >> 6, o = c3_row(ln & 15), kg = ln >> 4;
+        c3b_build_frag(wlb + p * 192, ln, [&](int i) {
+            const int ch = c3_chan_of_elem(8 * kg + i);
+            return (o < c.O && ch < c.C2) ? theta[c.wl + o * c.F + ch * L2 + p] : 0.f;
+        });
+    }
+    for (int i = tid; i < 80; i += 64 * NW) {
+        const int e = i & 15, f = 16 * ((i >> 4) & 1) + c3_row(e);
+        float v = 0.f;
+        if (i < 32) v = f < c.C1 ? theta[c.b1 + f] : 0.f;
+        else if (i < 64) v = f < c.C2 ? theta[c.b2 + f] : 0.f;
+        else v = c3_row(e) < c.O ? theta[c.bl + c3_row(e)] : 0.f;
+        bp[i] = v;
+    }
+    __syncthreads();
+    bf8 w1r[2][3], w2r[K2][2][3];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) w1r[mt][pc] = w1s[(mt * 3 + pc) * 64 + lane];
+#pragma unroll
+    for (int tap = 0; tap < K2; ++tap)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) w2r[tap][mt][pc] = w2s[((tap * 2 + mt) * 3 + pc) * 64 + lane];
+    const f4 b1v[2] = {*reinterpret_cast<const f4*>(bp + 4 * g), *reinterpret_cast<const f4*>(bp + 16 + 4 * g)};
+    const f4 b2v[2] = {*reinterpret_cast<const f4*>(bp + 32 + 4 * g), *reinterpret_cast<const f4*>(bp + 48 + 4 * g)};
+    const f4 blv = *reinterpret_cast<const f4*>(bp + 64 + 4 * g);
+    __syncthreads();  // the staging area is dead: the waves' regions take its place
+    unsigned char* oh = dyn + (size_t)wave * c3b_wave_bytes(V, S, P1, ST2);
+    unsigned char* a1b = oh + ((V * OHS * 2 + 15) & ~15);
+    unsigned char* a2b = a1b + V * P1 * 192;
+    for (int i = lane; i < (V * OHS) / 2; i += 64) reinterpret_cast<unsigned*>(oh)[i] = 0u;  // (the pads stay zero for good)
+    c3_wave_sync();
+    const int nbatches = (n + V - 1) / V, n2s = 2 * S;
+    const int rec_a2 = P1 * 32, rec_arg = P1 * 32 + ST2 * 32;
+    // the haplotypes of a batch are requested one batch ahead: their HBM latency passes under the previous batch's arithmetic
+    long long bnext[C3_HAP_LOADS];
+    auto request = [&](int batch) {
+        const long long v0 = (long long)batch * V;
+#pragma unroll
+        for (int k = 0; k < C3_HAP_LOADS; ++k) {
+            const int i = lane + 64 * k, v = i / n2s, e = i - v * n2s;
+            bnext[k] = 255;
+            if (batch < nbatches && i < V * n2s && v0 + v < n) bnext[k] = hap[(size_t)(v0 + v) * hap_stride + e];
+        }
+    };
+    request(blockIdx.x * NW + wave);
+    for (int batch = blockIdx.x * NW + wave; batch < nbatches; batch += gridDim.x * NW) {
+        const long long v0 = (long long)batch * V;
+        const int nv = (int)min((long long)V, (long long)n - v0);
+        // ---- haplotypes -> one-hot, bf16 [position][channel = 2 base + (0 ref | 1 alt)] (reference data/batch.py:115-130) ----
+        {
+            long long b[C3_HAP_LOADS];
+#pragma unroll
+            for (int k = 0; k < C3_HAP_LOADS; ++k) b[k] = bnext[k];
+            request(batch + gridDim.x * NW);
+#pragma unroll
+            for (int k = 0; k < C3_HAP_LOADS; ++k) {
+                const int i = lane + 64 * k, v = i / n2s, e = i - v * n2s, hs = e >= S ? 1 : 0, pos = e - hs * S;
+                if (i < V * n2s) {
+                    unsigned short* dst = reinterpret_cast<unsigned short*>(oh) + v * OHS + pos * 10 + hs;
+#pragma unroll
+                    for (int bs = 0; bs < 5; ++bs) dst[2 * bs] = b[k] == bs ? (unsigned short)0x3F80 : (unsigned short)0;
+                }
+            }
+        }
+        c3_wave_sync();
+        float* rec0 = TRAIN ? stash + (size_t)v0 * c.stash_per : nullptr;
+        // ---- conv1 (+ bias) -> max-pool over column pairs -> activation -> a1 (bf16 pieces; fp32 record when training) --------
+#pragma unroll
+        for (int T = 0; T < n1t; ++T) {
+            const int col = 16 * T + r;
+            int v = S1 ? col / st1 : (int)((float)col * inv_st1 + 1e-3f);
+            const int p = col - v * st1;
+            const bool in_range = v < V;
+            v = min(v, V - 1);
+            const unsigned* src = reinterpret_cast<const unsigned*>(oh + 2 * (v * OHS + p * 10 + 8 * g));
+            const bf8 b = __builtin_bit_cast(bf8, c3_u4{src[0], src[1], src[2], src[3]});
+            f4 acc[2] = {b1v[0], b1v[1]};
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                acc[mt] = mfma_bf16(w1r[mt][2], b, acc[mt]);
+                acc[mt] = mfma_bf16(w1r[mt][1], b, acc[mt]);
+                acc[mt] = mfma_bf16(w1r[mt][0], b, acc[mt]);
+            }
+            const int q = p >> 1;
+            const bool store = in_range && !(p & 1) && q < P1;  // (p + 1 < L1 follows from q < P1 = L1 / 2)
+            unsigned bits = 0;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const f4 nxt = c3_dpp4<0x101>(acc[mt]);  // row_shl:1 -- the column to the right (position p + 1 of the same variant)
+                f4 m;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool second = nxt[j] > acc[mt][j];  // the first maximum wins, like ATen's max_pool1d
+                    m[j] = second ? nxt[j] : acc[mt][j];
+                    if (TRAIN) bits |= second ? 1u << (4 * mt + j) : 0u;
+                }
+                m = c3_act4(A1 ? A1 : c.act1, m);
+                if (store) {
+                    c3b_store_pieces(a1b + (v * P1 + q) * 192 + (16 * mt + 4 * g) * 2, m);
+                    if (TRAIN && v < nv) *reinterpret_cast<f4*>(rec0 + (size_t)v * c.stash_per + q * 32 + 16 * mt + 4 * g) = m;
+                }
+            }
+            if (TRAIN && store && v < nv) reinterpret_cast<unsigned char*>(rec0 + (size_t)v * c.stash_per + rec_arg + q)[g] = (unsigned char)bits;
+        }
+        c3_wave_sync();
+        // ---- conv2 (+ bias) -> activation -> a2 -----------------------------------------------------------------------------
+#pragma unroll
+        for (int T = 0; T < N2T; ++T) {
+            const int col = 16 * T + r;
+            int v = col / ST2;
+            const int p = col - v * ST2;
+            const bool valid = v < V && p < L2;
+            const bool in_range = v < V;
+            v = min(v, V - 1);
+            f4 acc[2] = {b2v[0], b2v[1]};
+#pragma unroll
+            for (int tap = 0; tap < K2; ++tap) {
+                const unsigned char* src = a1b + (v * P1 + min(p + tap, P1 - 1)) * 192 + 16 * g;
+                const bf8 b[3] = {*reinterpret_cast<const bf8*>(src), *reinterpret_cast<const bf8*>(src + 64), *reinterpret_cast<const bf8*>(src + 128)};
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc[mt] = c3b_mfma6(w2r[tap][mt], b, acc[mt]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const f4 a = valid ? c3_act4(A2 ? A2 : c.act2, acc[mt]) : c3_zero();
+                if (valid) c3b_store_pieces(a2b + (v * ST2 + p) * 192 + (16 * mt + 4 * g) * 2, a);
+                // (the record's padding columns hold zeros, as the backward expects)
+                if (TRAIN && in_range && v < nv) *reinterpret_cast<f4*>(rec0 + (size_t)v * c.stash_per + rec_a2 + p * 32 + 16 * mt + 4 * g) = a;
+            }
+        }
+        c3_wave_sync();
+        // ---- flatten + linear: a column per variant --------------------------------------------------------------------------
+        {
+            const int v = min(r, V - 1);
+            f4 acc = blv;
+#pragma unroll
+            for (int p = 0; p < L2; ++p) {
+                const unsigned char* src = a2b + (v * ST2 + p) * 192 + 16 * g;
+                const bf8 b[3] = {*reinterpret_cast<const bf8*>(src), *reinterpret_cast<const bf8*>(src + 64), *reinterpret_cast<const bf8*>(src + 128)};
+                const bf8 a[3] = {wlb[(p * 3 + 0) * 64 + lane], wlb[(p * 3 + 1) * 64 + lane], wlb[(p * 3 + 2) * 64 + lane]};
+                acc = c3b_mfma6(a, b, acc);
+            }
+            if (r < nv) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (4 * j + g < c.O) out[(size_t)(v0 + r) * out_stride + 4 * j + g] = acc[j];
+            }
+        }
+        c3_wave_sync();
     }
 }
 
@@ -760,7 +1000,7 @@ static int cnn3_grid(int n, int v, int nw, int dev) {
 #include <mutex>
 static bool cnn3_allow_lds(const void* kernel, size_t bytes, int which, int dev) {
     static std::mutex mu;
-    static size_t allowed[64][2] = {};
+    static size_t allowed[64][3] = {};
     std::lock_guard<std::mutex> lock(mu);
     const bool tabled = dev >= 0 && dev < 64;
     if (tabled && bytes <= allowed[dev][which]) return true;
@@ -777,11 +1017,21 @@ extern "C" int pmt_cnn3_try_forward(const PmtModel* model_host, const float* the
                                     float* out, int64_t out_stride, float* stash, void* stream) {
     C3Cfg c, cb;
     if (!cnn3_covers(model_host, &c, &cb)) return 1;
-    const size_t lds = cnn3_lds_bytes(&c, false, C3_FWD_NW);
+    const bool bf = (model_host->cnn_debug & 256) == 0;  // the bf16-pipe forward (bit 8: the fp32-MFMA kernel, for A/B runs and the parity tests)
+    size_t lds = cnn3_lds_bytes(&c, false, C3_FWD_NW);
     auto kernel = c.S == 21 ? pmt_cnn3_forward_kernel<C3_FWD_V, C3_FWD_NW, 3, 3, 7, 21>   // the reference's 20 + 1 bases of context
                             : pmt_cnn3_forward_kernel<C3_FWD_V, C3_FWD_NW, 3, 3, 7, 0>;  // (cnn3_config admits exactly these instances)
+    if (bf) {
+        const bool leaky = c.act1 == PMT_CNN_LEAKY_RELU && c.act2 == PMT_CNN_LEAKY_RELU, s21 = c.S == 21;  // the production stack's instance
+        if (leaky && s21) kernel = stash ? pmt_cnn3_forward_bf_kernel<C3_FWD_V, C3_FWD_NW, 3, 3, 7, 21, PMT_CNN_LEAKY_RELU, PMT_CNN_LEAKY_RELU, true>
+                                         : pmt_cnn3_forward_bf_kernel<C3_FWD_V, C3_FWD_NW, 3, 3, 7, 21, PMT_CNN_LEAKY_RELU, PMT_CNN_LEAKY_RELU, false>;
+        else kernel = stash ? pmt_cnn3_forward_bf_kernel<C3_FWD_V, C3_FWD_NW, 3, 3, 7, 0, 0, 0, true> : pmt_cnn3_forward_bf_kernel<C3_FWD_V, C3_FWD_NW, 3, 3, 7, 0, 0, 0, false>;
+        const size_t regions = (size_t)C3_FWD_NW * c3b_wave_bytes(C3_FWD_V, c.S, c.P1, c.st2), staging = (size_t)(2 + 2 * c.K2) * 3072;
+        lds = (size_t)c.L2 * 3072 + 320 + (regions > staging ? regions : staging);
+        if (lds > 160 * 1024 || C3_FWD_V * 2 * c.S > 64 * C3_HAP_LOADS) return 1;
+    }
     const int dev = cnn3_stream_device(reinterpret_cast<hipStream_t>(stream));
-    if (!cnn3_allow_lds(reinterpret_cast<const void*>(kernel), lds, 0, dev)) return PMT_E_LAUNCH;
+    if (!cnn3_allow_lds(reinterpret_cast<const void*>(kernel), lds, bf ? 2 : 0, dev)) return PMT_E_LAUNCH;
     hipLaunchKernelGGL(kernel, dim3(cnn3_grid(n, C3_FWD_V, C3_FWD_NW, dev)), dim3(64 * C3_FWD_NW), lds, reinterpret_cast<hipStream_t>(stream), c, theta,
                        (const long long*)haplotypes, (long long)hap_stride, n, out, (long long)out_stride, stash);
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;

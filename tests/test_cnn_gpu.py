@@ -25,13 +25,16 @@ pytestmark = pytest.mark.gpu
 ACCEPTS = {
     "p0_cnn_legacy": {"auto", "general"},
     "t0_cnn_options": {"auto", "general"},
-    "p0_b16": {"auto", "general", "wave", "batched"},
+    "p0_b16": {"auto", "general", "wave", "batched", "batched_fp32"},
     "t0_b8": {"auto", "general"},  # (64 output channels)
 }
 
 
 def build_cnn(name, sd, family, monkeypatch):
-    if family != "auto":
+    if family == "batched_fp32":  # the batched family's forward on the fp32 matrix pipe (default: bf16 pieces, pmt_cnn3.hip)
+        monkeypatch.setenv("PMT_CNN", "batched")
+        monkeypatch.setenv("PMT_CNN_DBG", "256")
+    elif family != "auto":
         monkeypatch.setenv("PMT_CNN", family)
     params = t0_params() if name.startswith("t0") else p0_params()
     if name in CNN_STACKS:
@@ -41,7 +44,7 @@ def build_cnn(name, sd, family, monkeypatch):
     return model
 
 
-@pytest.mark.parametrize("family", ["auto", "general", "wave", "batched"])
+@pytest.mark.parametrize("family", ["auto", "general", "wave", "batched", "batched_fp32"])
 @pytest.mark.parametrize("name", CNN_CASES + ["p0_b16", "t0_b8"])
 def test_every_family_matches_the_reference_or_refuses(name, family, monkeypatch):
     z, sd, b = load_case(name)

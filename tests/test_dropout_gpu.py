@@ -211,7 +211,7 @@ def test_keep_rate_seen_through_the_kernels():
     np.testing.assert_allclose(y, expect, rtol=1e-6)
 
 
-def test_training_loop_with_dropout_runs_end_to_end():
+def test_training_loop_with_dropout_runs_end_to_end(monkeypatch):
     """train_artifact_model (reference model_training.py:49-201) with --dropout_p 0.25: train epochs draw masks (DownsampledBatch
     parents included), validation / evaluation epochs run in eval mode; the losses stay finite and the model learns something"""
     import os
@@ -229,9 +229,13 @@ def test_training_loop_with_dropout_runs_end_to_end():
     params.dropout_p = P
     model = ArtifactModel(params, device=dev, **P0_DIMS)
     seeds = []
-    eng = model.engine()
-    draw = eng.draw_dropout_seed
-    eng.draw_dropout_seed = lambda training: seeds.append(draw(training)) or seeds[-1]
+    from permutect_amd.engine.runtime import ReadSetEngine
+    draw = ReadSetEngine.draw_dropout_seed  # (patched on the class: the loop rebuilds the engine when it resets the source predictor)
+
+    def recording(self, training):
+        seeds.append(draw(self, training))
+        return seeds[-1]
+    monkeypatch.setattr(ReadSetEngine, "draw_dropout_seed", recording)
     hist = train_artifact_model(model, train, valid, TrainingParameters(batch_size=16, num_epochs=2, num_calibration_epochs=1, learning_rate=1e-3),
                                 chunk_variants=24, seed=1, log=lambda s: None)
     assert [h[:2] for h in hist] == [(1, "TRAIN"), (1, "VALID"), (2, "TRAIN"), (2, "VALID"), (3, "TRAIN"), (3, "VALID")]
