@@ -532,9 +532,13 @@ __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_forward_bf_kernel(
                 f4 m;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const bool second = nxt[j] > acc[mt][j];  // the first maximum wins, like ATen's max_pool1d
-                    m[j] = second ? nxt[j] : acc[mt][j];
-                    if (TRAIN) bits |= second ? 1u << (4 * mt + j) : 0u;
+                    if constexpr (TRAIN) {
+                        const bool second = nxt[j] > acc[mt][j];  // the first maximum wins, like ATen's max_pool1d
+                        m[j] = second ? nxt[j] : acc[mt][j];
+                        bits |= second ? 1u << (4 * mt + j) : 0u;
+                    } else {
+                        m[j] = fmaxf(acc[mt][j], nxt[j]);  // (the value alone: no argmax to keep)
+                    }
                 }
                 m = c3_act4(A1 ? A1 : c.act1, m);
                 if (store) {

@@ -34,7 +34,8 @@ class ReadSetEngine:
         self.device = device
         self.space = ParamSpace(model, device)
         self.plan = EnginePlan(model, self.space, device)
-        self.trigger = torch.zeros(1, dtype=torch.float32, device=device, requires_grad=True)  # see RowsMlpFunction
+        self._trigger = torch.zeros(1, dtype=torch.float32, device=device, requires_grad=True)  # see RowsMlpFunction
+        self._no_trigger = torch.zeros(1, dtype=torch.float32, device=device)
         self._cnn_ws = None
         self._rows_ws = None
         # `packed` / phi are functions of the parameters: params_key() changes whenever theta may have changed -- torch's version
@@ -114,6 +115,14 @@ class ReadSetEngine:
                                              alt_off.data_ptr(), _stream()), "pmt_scan_counts")
             batch._offsets = (ref_off, alt_off)
         return batch._offsets
+
+    @property
+    def trigger(self) -> Tensor:
+        """The 1-element leaf that makes autograd call the backward of the engine's Functions (their parameters live in the flat
+        buffer, not among their inputs).  A Function's `ctx.needs_input_grad` reports its inputs' requires_grad flags WHATEVER
+        the grad mode, so under no_grad / inference_mode a tensor without grad is handed out instead: the forward kernels then
+        keep nothing for a backward that cannot follow (the haplotype CNN's records alone are 145 MB per 65 536 variants)."""
+        return self._trigger if torch.is_grad_enabled() else self._no_trigger
 
     def draw_dropout_seed(self, training: bool) -> int:
         """The seed of this step's dropout masks (0 = none: eval mode or dropout_p = 0).  Drawn from torch's CPU generator, so
@@ -299,7 +308,7 @@ class ReadSetFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, engine: ReadSetEngine, batch, phi: Tensor, variant_embed: Tensor):
-        train = bool(ctx.needs_input_grad[2] or ctx.needs_input_grad[3])  # False under no_grad / inference_mode
+        train = bool(ctx.needs_input_grad[2] or ctx.needs_input_grad[3])  # (phi / variant_embed carry no grad under no_grad)
         ctx.dropout_seed = engine.dropout_seed  # (set by the model at the start of the step; 0 in eval mode)
         outs, stash, ve, ph = engine.forward(batch, phi.detach(), variant_embed.detach(), train, ctx.dropout_seed)
         ctx.engine, ctx.batch, ctx.train = engine, batch, train
@@ -331,7 +340,7 @@ class HaplotypeCnnFunction(torch.autograd.Function):
         assert hap.stride(-1) == 1 and hap.shape[1] == 2 * d.cnn.seq_len
         n = hap.shape[0]
         out = torch.empty(n, d.cnn.out_dim, dtype=torch.float32, device=engine.device)
-        train = bool(ctx.needs_input_grad[2])
+        train = bool(ctx.needs_input_grad[2])  # (callers pass engine.mode_trigger(): no grad under no_grad / inference_mode)
         # (PMT_CNN_STASH=0: let the backward recompute the layer outputs instead; the parity tests cover both)
         per = engine.lib.pmt_cnn_stash_floats(C.byref(d)) if train and os.environ.get("PMT_CNN_STASH", "1") != "0" else 0
         stash = torch.empty(n * per, dtype=torch.float32, device=engine.device) if per > 0 and n > 0 else None
