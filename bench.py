@@ -522,6 +522,38 @@ def main():
              f"filter {1e3 * ef / k:.3f} ms/step ({stress['filter']['per_read_rate_vs_wgs']:.2f} x)")
         del pool
 
+    # ---- the same training step with the reference's --dropout_p (mlp.py:57-58): the masks are generated in the kernels, such a
+    #      step runs the generic instances ("Dropout") ---------------------------------------------------------
+    dropout = None
+    if world == 1 and not args.no_extras and args.data == "resident" and args.depth == "wgs" and args.mode == "both":
+        dparams = p0_params()
+        dparams.dropout_p = 0.25
+        dmodel = ArtifactModel(dparams, device=dev, **P0_DIMS)
+        dopt = FusedClipAdamW(dmodel, lr=1e-3, weight_decay=0.01)
+        dmodel.train(True)
+
+        def dstep(batch):
+            dopt.zero_grad()
+            out = dmodel.compute_batch_output(batch)
+            dmodel.compute_batch_losses(out, batch).total_loss.backward()
+            dopt.step()
+        for i in range(4):
+            dstep(batches[i % len(batches)])
+        k = 20
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        torch.cuda.synchronize()
+        marks[0].record()
+        for i in range(k):
+            dstep(batches[i % len(batches)])
+        marks[1].record()
+        torch.cuda.synchronize()
+        dms = marks[0].elapsed_time(marks[1]) / k
+        dropout = {"workload": "the headline training step with dropout_p = 0.25 (a new mask seed per step; generic kernel instances)",
+                   "ms_per_step": dms, "value": args.batch / (dms * 1e-3), "unit": "read-sets/s", "steps": k,
+                   "vs_no_dropout": (results["train"][0] / args.steps * 1e3) / dms}
+        note(f"dropout_p = 0.25: train {dms:.3f} ms/step ({dropout['vs_no_dropout']:.2f} x the rate without dropout)")
+        del dmodel, dopt
+
     # ---- BASELINE configs[1] / [2] as DATASETS: batches streamed from host memory through the device chunk loader -------------
     loader = None
     if world == 1 and not args.no_extras and args.data == "resident" and args.depth == "wgs" and args.mode == "both":
@@ -668,6 +700,8 @@ def main():
             line["stress"] = stress
         if loader is not None:
             line["loader"] = loader
+        if dropout is not None:
+            line["dropout"] = dropout
         if parity is not None:
             line["parity_check_max_logit_err"] = parity["max_logit_err"]
             line["parity_check"] = parity

@@ -7,6 +7,9 @@
 #include "pmt_mlp_device.hpp"
 #include "pmt_bwd_device.hpp"
 
+#ifndef PMT_ROWS_TRACE
+#define PMT_ROWS_TRACE 0  // development: cycle stamps of one wave of the forward into its first output row (timing only)
+#endif
 #define ROWS_NTIN (PMT_MAX_ROW_INPUT / 16)
 #define ROWS_PER_BLOCK (PMT_WAVES * PMT_RT * 16)
 
@@ -31,14 +34,36 @@ DEV void load_rows(f4 (&x)[PMT_RT][NTIN], const float* __restrict__ in, long lon
     }
 }
 
-template <bool TRAIN>
+// WLDS: the MLP's weight fragments ([span_lo, span_lo + span_len) of `packed`: every linear of a row MLP lies in one run) are
+// copied into LDS once per workgroup and every layer reads them from there.  A workgroup walks ONE chain of ~8 small layers over
+// its 256 rows; with the fragments in global memory every layer started with an L2 round trip that nothing could hide (33 us for
+// 0.5 GFLOP over 65 536 rows).
+// NT: tiles of 16 features the activations take (2 when every layer behind the input is at most 32 wide: half the registers, half the
+// element-wise work of the 64-wide generic layout).
+template <bool TRAIN, bool WLDS, int NT>
 __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_forward_kernel(const PmtModel* __restrict__ M, int which,
                                                                            const float* __restrict__ theta,
-                                                                           const float* __restrict__ packed,
+                                                                           const float* __restrict__ packed_g,
                                                                            const float* __restrict__ in, long long in_stride,
                                                                            int n_rows, float* __restrict__ out,
                                                                            long long out_stride, float* __restrict__ stash,
-                                                                           unsigned long long dropout_seed) {
+                                                                           unsigned long long dropout_seed, int span_lo, int span_len) {
+    extern __shared__ __attribute__((aligned(16))) float rows_lds[];
+#if PMT_ROWS_TRACE
+    unsigned long long tr[8];
+    tr[0] = __builtin_readcyclecounter();
+#define ROWS_EV(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tr[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ROWS_EV(k) do {} while (0)
+#endif
+    const float* packed = packed_g;
+    if constexpr (WLDS) {
+        const f4* __restrict__ src = reinterpret_cast<const f4*>(packed_g + span_lo);
+        for (int i = threadIdx.x; i < span_len / 4; i += PMT_THREADS) reinterpret_cast<f4*>(rows_lds)[i] = src[i];
+        __syncthreads();
+        packed = rows_lds - span_lo;
+    }
+    ROWS_EV(1);
     const PmtMlp& mlp = M->row_mlp[which];
     const int lane = threadIdx.x & 63, g = lane >> 4, wave = uniform((int)(threadIdx.x >> 6));
     const int tile0 = (blockIdx.x * PMT_WAVES + wave) * PMT_RT;
@@ -53,28 +78,31 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_forward_kernel(const 
     PmtDrop drop = drop_setup(M, dropout_seed, uniform(mlp.dropout));
 #pragma unroll
     for (int rt = 0; rt < PMT_RT; ++rt) drop.row[rt] = (tile0 + rt) * 16 + (lane & 15);
-    f4 x[PMT_RT][PMT_NT];
+    f4 x[PMT_RT][NT];
     int slot = 0, op_begin = 0;
     if (in_dim > PMT_MAX_WIDTH) {  // wide first linear (checked on the host: op 0 is LINEAR)
         f4 xin[PMT_RT][ROWS_NTIN];
         load_rows<ROWS_NTIN>(xin, in, in_stride, n_rows, in_dim, tile0, g);
+        ROWS_EV(2);
         const PmtOp& o = mlp.ops[0];
         const PmtLinear& L = M->lin[uniform(o.lin[0])];
         const int b_pvec = uniform(L.b_pvec);
-        init_bias<PMT_NT>(x, b_pvec >= 0 ? packed + b_pvec : nullptr, uniform(L.out_dim), g);
-        linear_acc<ROWS_NTIN, PMT_NT, false>(x, xin, packed + uniform(L.w_frag), in_dim, uniform(L.out_dim));
-        if (drop.on) drop_apply<PMT_NT>(drop, uniform(o.lin[0]), x, g);
+        init_bias<NT>(x, b_pvec >= 0 ? packed + b_pvec : nullptr, uniform(L.out_dim), g);
+        linear_acc<ROWS_NTIN, NT, false>(x, xin, packed + uniform(L.w_frag), in_dim, uniform(L.out_dim));
+        if (drop.on) drop_apply<NT>(drop, uniform(o.lin[0]), x, g);
         if (uniform(o.selu_after) != 0) {
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
-                for (int t = 0; t < PMT_NT; ++t) x[rt][t] = selu4(x[rt][t]);
+                for (int t = 0; t < NT; ++t) x[rt][t] = selu4(x[rt][t]);
         }
         op_begin = 1;
     } else {
-        load_rows<PMT_NT>(x, in, in_stride, n_rows, in_dim, tile0, g);
+        load_rows<NT>(x, in, in_stride, n_rows, in_dim, tile0, g);
     }
-    run_mlp<TRAIN, PMT_NT, false>(M, mlp, x, theta, g, present, stash_tile, slot, 1, packed, op_begin, uniform(mlp.n_ops), &drop);
+    ROWS_EV(3);
+    run_mlp<TRAIN, NT, false>(M, mlp, x, theta, g, present, stash_tile, slot, 1, packed, op_begin, uniform(mlp.n_ops), &drop);
+    ROWS_EV(4);
     const int r = lane & 15;
 #pragma unroll
     for (int rt = 0; rt < PMT_RT; ++rt) {
@@ -82,12 +110,17 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_forward_kernel(const 
         if (row < n_rows) {
             float* p = out + (size_t)row * out_stride;
 #pragma unroll
-            for (int t = 0; t < PMT_NT; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (feat_of(t, j, g) < out_dim) p[feat_of(t, j, g)] = x[rt][t][j];
         }
     }
+#if PMT_ROWS_TRACE
+    ROWS_EV(5);
+    if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0)
+        for (int k = 1; k < 6; ++k) out[(size_t)(tile0 * 16) * out_stride + k - 1] = (float)(tr[k] - tr[0]);
+#endif
 }
 
 #ifndef PMT_ROWS_DBG
@@ -99,6 +132,7 @@ struct RowsBwdShared {
     f4 stage[PMT_STAGE_PLANES * 64];
 };
 
+template <int NT>
 __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_backward_kernel(
     const PmtModel* __restrict__ M, int which, const float* __restrict__ theta, const float* __restrict__ packed,
     const float* __restrict__ in, long long in_stride, int n_rows, const float* __restrict__ d_out, long long d_out_stride,
@@ -131,53 +165,53 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_backward_kernel(
     for (int rt = 0; rt < PMT_RT; ++rt) drop.row[rt] = (tile0 + rt) * 16 + r;
     c.drop = &drop;
     // d(out) -> registers (zero for padding rows: they then contribute nothing to any weight gradient)
-    f4 dy[PMT_RT][PMT_NT];
+    f4 dy[PMT_RT][NT];
 #pragma unroll
     for (int rt = 0; rt < PMT_RT; ++rt) {
         const int row = (tile0 + rt) * 16 + r;
         const float* p = d_out + (size_t)row * d_out_stride;
 #pragma unroll
-        for (int t = 0; t < PMT_NT; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int f = feat_of(t, j, g);
                 dy[rt][t][j] = (row < n_rows && f < out_dim) ? p[f] : 0.f;
             }
     }
-    auto load_input = [&](int op, f4 (&x)[PMT_RT][PMT_NT]) {
+    auto load_input = [&](int op, f4 (&x)[PMT_RT][NT]) {
         if (op == 0) {
-            load_rows<PMT_NT>(x, in, in_stride, n_rows, in_dim, tile0, g);
+            load_rows<NT>(x, in, in_stride, n_rows, in_dim, tile0, g);
         } else {
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) {
 #pragma unroll
-                for (int t = 0; t < PMT_NT; ++t) x[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
-                if (present & (1u << rt)) stash_load<PMT_NT>(stash_tile[rt] + (op - 1) * PMT_SLOT_FLOATS, x[rt]);
+                for (int t = 0; t < NT; ++t) x[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
+                if (present & (1u << rt)) stash_load<NT>(stash_tile[rt] + (op - 1) * PMT_SLOT_FLOATS, x[rt]);
             }
         }
     };
     const bool wide = in_dim > PMT_MAX_WIDTH;
     const bool want_d_in = d_in != nullptr;
     const int first_op = wide ? 1 : 0;
-    mlp_backward<PMT_NT, false>(c, mlp, dy, want_d_in || wide, load_input, first_op, n_ops);
+    mlp_backward<NT, false>(c, mlp, dy, want_d_in || wide, load_input, first_op, n_ops);
     if (wide) {  // op 0 is a LINEAR with up to 128 inputs: weight gradient only (its input needs no gradient)
         const PmtOp& o = mlp.ops[0];
         const PmtLinear& L = M->lin[uniform(o.lin[0])];
         f4 xin[PMT_RT][ROWS_NTIN];
         load_rows<ROWS_NTIN>(xin, in, in_stride, n_rows, in_dim, tile0, g);
         if (uniform(o.selu_after) != 0) {
-            f4 y[PMT_RT][PMT_NT];
+            f4 y[PMT_RT][NT];
             const int b_pvec = uniform(L.b_pvec);
-            init_bias<PMT_NT>(y, b_pvec >= 0 ? packed + b_pvec : nullptr, uniform(L.out_dim), g);
-            linear_acc<ROWS_NTIN, PMT_NT, false>(y, xin, packed + uniform(L.w_frag), in_dim, uniform(L.out_dim));
-            if (drop.on) drop_apply<PMT_NT>(drop, uniform(o.lin[0]), y, g);
+            init_bias<NT>(y, b_pvec >= 0 ? packed + b_pvec : nullptr, uniform(L.out_dim), g);
+            linear_acc<ROWS_NTIN, NT, false>(y, xin, packed + uniform(L.w_frag), in_dim, uniform(L.out_dim));
+            if (drop.on) drop_apply<NT>(drop, uniform(o.lin[0]), y, g);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
-                for (int t = 0; t < PMT_NT; ++t) dy[rt][t] = selu_bwd4(dy[rt][t], selu4(y[rt][t]));
+                for (int t = 0; t < NT; ++t) dy[rt][t] = selu_bwd4(dy[rt][t], selu4(y[rt][t]));
         }
-        if (drop.on) drop_apply<PMT_NT>(drop, uniform(o.lin[0]), dy, g);
-        linear_wgrad<PMT_NT, ROWS_NTIN>(c, L, dy, xin);
+        if (drop.on) drop_apply<NT>(drop, uniform(o.lin[0]), dy, g);
+        linear_wgrad<NT, ROWS_NTIN>(c, L, dy, xin);
     }
     aux_flush(c);  // skip-block alphas
     if (!wide && want_d_in) {
@@ -187,7 +221,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_rows_backward_kernel(
             if (row < n_rows) {
                 float* p = d_in + (size_t)row * d_in_stride;
 #pragma unroll
-                for (int t = 0; t < PMT_NT; ++t)
+                for (int t = 0; t < NT; ++t)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         if (feat_of(t, j, g) < in_dim) p[feat_of(t, j, g)] = d_in_scale * dy[rt][t][j];
@@ -268,6 +302,60 @@ extern "C" size_t pmt_rows_stash_bytes(const PmtModel* m, int which, int32_t n_r
     return tiles * slots * PMT_SLOT_FLOATS * sizeof(float);
 }
 
+// more than 64 KiB of dynamic LDS needs the function attribute (raised once per device and kernel; see cnn3_allow_lds)
+#include <mutex>
+static bool rows_allow_lds(const void* kernel, size_t bytes, int which, hipStream_t stream) {
+    static std::mutex mu;
+    static size_t allowed[64][4] = {};
+    int dev = 0;
+    if (hipStreamGetDevice(stream, &dev) != hipSuccess && hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    const bool tabled = dev >= 0 && dev < 64;
+    if (tabled && bytes <= allowed[dev][which]) return true;
+    int cur = -1;
+    const bool switched = hipGetDevice(&cur) == hipSuccess && cur != dev && hipSetDevice(dev) == hipSuccess;
+    const bool ok = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+    if (switched) (void)hipSetDevice(cur);
+    if (ok && tabled) allowed[dev][which] = bytes;
+    return ok;
+}
+// [lo, lo + len) of `packed` that holds every fragment and bias of a row MLP (its linears are lowered one after the other)
+static bool rows_packed_span(const PmtModel* m, int which, int* lo, int* len) {
+    const PmtMlp* mlp = &m->row_mlp[which];
+    long long a = INT32_MAX, b = -1;
+    for (int op = 0; op < mlp->n_ops; ++op) {
+        const PmtOp* o = &mlp->ops[op];
+        const int nl = o->kind == PMT_OP_SKIP ? o->n_layers : 1;
+        for (int l = 0; l < nl; ++l) {
+            const PmtLinear* L = &m->lin[o->lin[l]];
+            const long long frag = (long long)((L->out_dim + 15) / 16) * ((L->in_dim + 15) / 16) * 256;
+            if (L->w_frag < 0 || L->wt_frag < 0) return false;
+            a = L->w_frag < a ? L->w_frag : a;
+            b = L->wt_frag + frag > b ? L->wt_frag + frag : b;
+            if (L->b_pvec >= 0 && (L->b_pvec < L->w_frag || L->b_pvec >= L->wt_frag)) return false;  // (the bias lies between the two)
+        }
+    }
+    if (b <= a || (a & 3) || ((b - a) & 3)) return false;
+    *lo = (int)a; *len = (int)(b - a);
+    return true;
+}
+#define ROWS_LDS_MAX_FLOATS (19 * 1024)  // 76 KiB: two workgroups per compute unit
+// 2 when every activation behind the input fits two tiles (the input itself may take the wide first-linear path), else PMT_NT
+static int rows_nt(const PmtModel* m, int which) {
+    const PmtMlp* mlp = &m->row_mlp[which];
+    if (mlp->out_dim > 32 || (mlp->in_dim > 32 && mlp->in_dim <= PMT_MAX_WIDTH)) return PMT_NT;
+    for (int op = 0; op < mlp->n_ops; ++op) {
+        const PmtOp* o = &mlp->ops[op];
+        const int nl = o->kind == PMT_OP_SKIP ? o->n_layers : 1;
+        for (int l = 0; l < nl; ++l) {
+            const PmtLinear* L = &m->lin[o->lin[l]];
+            const bool wide_first = op == 0 && l == 0 && mlp->in_dim > PMT_MAX_WIDTH;
+            if (L->out_dim > 32 || (L->in_dim > 32 && !wide_first)) return PMT_NT;
+        }
+    }
+    return 2;
+}
+
 extern "C" int pmt_rows_forward(const PmtModel* model_host, const PmtModel* model_dev, int which, const float* theta,
                                 const float* packed, const float* in, int64_t in_stride, int32_t n_rows, float* out,
                                 int64_t out_stride, float* stash, uint64_t dropout_seed, void* stream) {
@@ -277,12 +365,18 @@ extern "C" int pmt_rows_forward(const PmtModel* model_host, const PmtModel* mode
     if (n_rows == 0) return PMT_OK;
     const int grid = (n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (stash)
-        hipLaunchKernelGGL(pmt_rows_forward_kernel<true>, dim3(grid), dim3(PMT_THREADS), 0, s, model_dev, which, theta, packed, in,
-                           (long long)in_stride, n_rows, out, (long long)out_stride, stash, (unsigned long long)dropout_seed);
-    else
-        hipLaunchKernelGGL(pmt_rows_forward_kernel<false>, dim3(grid), dim3(PMT_THREADS), 0, s, model_dev, which, theta, packed,
-                           in, (long long)in_stride, n_rows, out, (long long)out_stride, (float*)nullptr, (unsigned long long)dropout_seed);
+    int lo = 0, len = 0;
+    const bool wlds = rows_packed_span(model_host, which, &lo, &len) && len <= ROWS_LDS_MAX_FLOATS;
+    const bool narrow = rows_nt(model_host, which) == 2;
+    auto kernel = stash ? (wlds ? pmt_rows_forward_kernel<true, true, PMT_NT> : pmt_rows_forward_kernel<true, false, PMT_NT>)
+                        : (wlds ? pmt_rows_forward_kernel<false, true, PMT_NT> : pmt_rows_forward_kernel<false, false, PMT_NT>);
+    if (narrow)
+        kernel = stash ? (wlds ? pmt_rows_forward_kernel<true, true, 2> : pmt_rows_forward_kernel<true, false, 2>)
+                       : (wlds ? pmt_rows_forward_kernel<false, true, 2> : pmt_rows_forward_kernel<false, false, 2>);
+    const size_t lds = wlds ? (size_t)len * sizeof(float) : 0;
+    if (lds > 64 * 1024 && !rows_allow_lds(reinterpret_cast<const void*>(kernel), lds, (stash ? 1 : 0) + (narrow ? 2 : 0), s)) return PMT_E_LAUNCH;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(PMT_THREADS), lds, s, model_dev, which, theta, packed, in, (long long)in_stride, n_rows, out,
+                       (long long)out_stride, stash, (unsigned long long)dropout_seed, lo, len);
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }
 
@@ -302,7 +396,8 @@ extern "C" int pmt_rows_backward(const PmtModel* model_host, const PmtModel* mod
     const bool rep = workspace != nullptr && grid >= 8 && rows_param_span(model_host, which, &lo, &hi) &&
                      workspace_floats >= (size_t)ROWS_REPLICAS * (size_t)(hi - lo);
     const int used = grid < ROWS_REPLICAS ? grid : ROWS_REPLICAS;
-    hipLaunchKernelGGL(pmt_rows_backward_kernel, dim3(grid), dim3(PMT_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
+    auto kernel = rows_nt(model_host, which) == 2 ? pmt_rows_backward_kernel<2> : pmt_rows_backward_kernel<PMT_NT>;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(PMT_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
                        model_dev, which, theta, packed, in, (long long)in_stride, n_rows, d_out, (long long)d_out_stride, stash,
                        grad_theta, d_in, (long long)d_in_stride, d_in_scale, rep ? workspace : nullptr, lo, hi - lo, used,
                        (unsigned long long)dropout_seed);
