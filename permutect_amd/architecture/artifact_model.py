@@ -19,7 +19,8 @@ from permutect_amd.architecture import modules as M
 from permutect_amd.data.batch import Batch
 from permutect_amd.data.datum import Data
 from permutect_amd.engine import lib as L
-from permutect_amd.engine.runtime import HaplotypeCnnFunction, LossesFunction, PhiFunction, ReadSetEngine, ReadSetFunction, RowsMlpFunction
+from permutect_amd.engine.runtime import (HaplotypeCnnFunction, LossesFunction, PhiFunction, ReadSetEngine, ReadSetFunction,  # noqa: F401
+                                          RowsMlpFunction, VariantEmbedFunction)
 from permutect_amd.enums import Epoch
 from permutect_amd.parameters import ModelParameters, install_pickle_alias
 
@@ -158,9 +159,7 @@ class ArtifactModel(nn.Module):
         """[B, E_info + E_hap]: the per-variant part of every read's input (reference artifact_model.py:244-246).
         The info MLP is a HIP row kernel (pmt_rows_forward); requires packed weights to be current (see _encode)."""
         eng = self.engine()
-        info = RowsMlpFunction.apply(eng, L.ROWS_INFO, batch.get_info_be(), eng.trigger, None)
-        hap = HaplotypeCnnFunction.apply(eng, batch.get_haplotypes_bs(), eng.trigger)
-        return torch.hstack((info, hap))
+        return VariantEmbedFunction.apply(eng, batch.get_info_be(), batch.get_haplotypes_bs(), eng.trigger)
 
     def _encode(self, batch: Batch):
         eng = self.engine()

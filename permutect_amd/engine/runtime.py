@@ -369,6 +369,66 @@ class HaplotypeCnnFunction(torch.autograd.Function):
         return None, None, None  # (the trigger only makes autograd call this node; it needs no gradient of its own)
 
 
+class VariantEmbedFunction(torch.autograd.Function):
+    """(info vectors [B, I], haplotypes int64 [B, H]) -> the per-variant embedding [B, E_info + E_hap] (reference
+    artifact_model.py:244-246: hstack of info_embedding(info) and haplotypes_cnn(one-hot)).  The info MLP (pmt_rows_forward) and the
+    haplotype CNN (pmt_cnn_forward) write their column blocks of ONE buffer (both entry points take an output stride), and their
+    backward kernels read the column blocks of its gradient in place: no concatenation launch either way."""
+
+    @staticmethod
+    def forward(ctx, engine: ReadSetEngine, info: Tensor, haplotypes: Tensor, trigger: Tensor):
+        lib, d = engine.lib, engine.plan.desc
+        mlp = d.row_mlp[L.ROWS_INFO]
+        n = info.shape[0]
+        x = info.detach()
+        if x.dtype != torch.float32 or x.stride(-1) != 1:
+            x = x.float().contiguous()
+        hap = haplotypes if haplotypes.dtype == torch.int64 else haplotypes.long()
+        assert x.shape[1] == mlp.in_dim and hap.stride(-1) == 1 and hap.shape[1] == 2 * d.cnn.seq_len
+        e_info, e_hap = mlp.out_dim, d.cnn.out_dim
+        ve = torch.empty(n, e_info + e_hap, dtype=torch.float32, device=engine.device)
+        train = bool(ctx.needs_input_grad[3])
+        rows_stash = cnn_stash = None
+        if train:
+            rows_stash = torch.empty(lib.pmt_rows_stash_bytes(C.byref(d), L.ROWS_INFO, n) // 4, dtype=torch.float32, device=engine.device)
+            per = lib.pmt_cnn_stash_floats(C.byref(d)) if os.environ.get("PMT_CNN_STASH", "1") != "0" else 0
+            cnn_stash = torch.empty(n * per, dtype=torch.float32, device=engine.device) if per > 0 and n > 0 else None
+        L.check(lib.pmt_rows_forward(C.byref(d), engine.plan.desc_dev.data_ptr(), L.ROWS_INFO, engine.space.theta.data_ptr(),
+                                     engine.plan.packed.data_ptr(), x.data_ptr(), x.stride(0), n, ve.data_ptr(), ve.stride(0),
+                                     _ptr(rows_stash), engine.dropout_seed, _stream()), "pmt_rows_forward")
+        L.check(lib.pmt_cnn_forward(C.byref(d), engine.plan.desc_dev.data_ptr(), engine.space.theta.data_ptr(),
+                                    engine.plan.packed.data_ptr(), hap.data_ptr(), hap.stride(0), n, ve.data_ptr() + 4 * e_info, ve.stride(0),
+                                    _ptr(cnn_stash), _stream()), "pmt_cnn_forward")
+        ctx.engine, ctx.train, ctx.dropout_seed, ctx.e_info = engine, train, engine.dropout_seed, e_info
+        ctx.hap, ctx.cnn_stash = hap, cnn_stash
+        if train:
+            ctx.save_for_backward(x, rows_stash)
+        return ve
+
+    @staticmethod
+    def backward(ctx, d_ve):
+        if not ctx.train:
+            return None, None, None, None
+        x, rows_stash = ctx.saved_tensors
+        eng, d, hap = ctx.engine, ctx.engine.plan.desc, ctx.hap
+        eng.space.bind_grads()
+        if d_ve.dtype != torch.float32 or d_ve.stride(-1) != 1:
+            d_ve = d_ve.float().contiguous()
+        n = x.shape[0]
+        ws = eng.rows_workspace()
+        L.check(eng.lib.pmt_rows_backward(C.byref(d), eng.plan.desc_dev.data_ptr(), L.ROWS_INFO, eng.space.theta.data_ptr(),
+                                          eng.plan.packed.data_ptr(), x.data_ptr(), x.stride(0), n, d_ve.data_ptr(), d_ve.stride(0),
+                                          rows_stash.data_ptr(), eng.space.gtheta.data_ptr(), None, 0, 1.0, _ptr(ws),
+                                          0 if ws is None else ws.numel(), ctx.dropout_seed, _stream()), "pmt_rows_backward")
+        cws = eng.cnn_workspace()
+        L.check(eng.lib.pmt_cnn_backward(C.byref(d), eng.plan.desc_dev.data_ptr(), eng.space.theta.data_ptr(),
+                                         eng.plan.packed.data_ptr(), hap.data_ptr(), hap.stride(0), n, d_ve.data_ptr() + 4 * ctx.e_info,
+                                         d_ve.stride(0), _ptr(ctx.cnn_stash), eng.space.gtheta.data_ptr(), _ptr(cws),
+                                         0 if cws is None else cws.numel(), _stream()), "pmt_cnn_backward")
+        ctx.cnn_stash = None
+        return None, None, None, None
+
+
 class RowsMlpFunction(torch.autograd.Function):
     """One of the per-variant row MLPs (pmt_rows_forward / pmt_rows_backward): info embedding, alt-count adversary,
     source adversary.  `x` is [N, in_dim] fp32 (any row stride); the result is [N, out_dim].  `trigger` is the engine's
