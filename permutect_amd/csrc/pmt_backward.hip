@@ -194,8 +194,8 @@ DEV void backward_group(
     const int slot_last_in = n_red_ops > 1 ? slot_red + (n_red_ops - 2) : slot_x0 + L;  // input of the last reducer op
     const PmtOp& red_last = M->reducer.ops[n_red_ops - 1];
 
-    PmtDrop drop;  // (generic instances only: the masks of the step's seed, regenerated -- pmt_dropout.hpp)
-    if constexpr (!EX) {
+    PmtDrop drop;  // (the instances that carry dropout: the masks of the step's seed, regenerated -- pmt_dropout.hpp)
+    if constexpr (S::DROP) {
         drop = drop_setup(M, bt.dropout_seed, uniform(M->reducer.dropout));
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt) drop.row[rt] = tm[rt].row;
@@ -221,6 +221,9 @@ DEV void backward_group(
                 init_bias<NTE>(e, uniform(Lr.b_pvec) >= 0 ? packed + uniform(Lr.b_pvec) : nullptr, E, g);
                 if constexpr (S::BF16) linear_acc_bf16<NTD, NTE, false, BFB>(e, r, packed + uniform(Lr.wb_frag));
                 else linear_acc<NTD, NTE, false, true, S::DIM_D>(e, r, packed + uniform(Lr.w_frag), D, E);
+                if constexpr (S::DROP) {
+                    if (drop.on != 0) drop_apply<NTE>(drop, uniform(red_last.lin[0]), e, g);
+                }
                 if (uniform(red_last.selu_after) != 0) {
 #pragma unroll
                     for (int rt = 0; rt < PMT_RT; ++rt)
@@ -381,7 +384,7 @@ DEV void backward_group(
         if constexpr (EX) {
             f4 r[PMT_RT][NTD];
             load_slot_tiles<NTD>(stash_tile, mask_all, slot_last_in, r);
-            linear_op_backward<NTD, NTE, true, S::DIM_D, S::DIM_E, BFB>(c, red_last, de, r, dy, true);
+            linear_op_backward<NTD, NTE, true, S::DIM_D, S::DIM_E, BFB, S::DROP>(c, red_last, de, r, dy, true);
         } else {
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
@@ -393,7 +396,7 @@ DEV void backward_group(
 
     // ---- reducer backward ---------------------------------------------------------------------------------------------
     if (!(LAYERED && lay.slice > 0))
-    mlp_backward<NTD, EX, S::DIM_D, BFB>(c, M->reducer, dy, true,
+    mlp_backward<NTD, EX, S::DIM_D, BFB, S::DROP>(c, M->reducer, dy, true,
                           [&](int op, f4 (&x)[PMT_RT][NTD]) { load_slot_tiles<NTD>(stash_tile, mask_all, op == 0 ? slot_x0 + L : slot_red + op - 1, x, c.pf_sink); },
                           0, EX ? n_red_ops - 1 : n_red_ops);
 
@@ -756,11 +759,12 @@ DEV void backward_group(
         for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
             for (int t = 0; t < NTR; ++t) dr[rt][t] = dy[rt][t < NTD ? t : 0];
-        mlp_backward<NTR, true, S::DIM_R, BFB>(c, M->read_mlp, dr, true,
+        if constexpr (S::DROP) drop.on = drop_setup(M, bt.dropout_seed, uniform(M->read_mlp.dropout)).on;
+        mlp_backward<NTR, true, S::DIM_R, BFB, S::DROP>(c, M->read_mlp, dr, true,
                                 [&](int op, f4 (&x)[PMT_RT][NTR]) { load_slot_tiles<NTR>(stash_tile, mask_all, op - 1, x, c.pf_sink); }, 1, n_read_ops);
         f4 xf[PMT_RT][NTF], dxf[PMT_RT][NTF];
         decode_reads(xf);
-        linear_op_backward<NTF, NTR, true, S::DIM_F, S::DIM_R, BFB>(c, M->read_mlp.ops[0], dr, xf, dxf, false);
+        linear_op_backward<NTF, NTR, true, S::DIM_F, S::DIM_R, BFB, S::DROP>(c, M->read_mlp.ops[0], dr, xf, dxf, false);
     } else {
         drop.on = drop_setup(M, bt.dropout_seed, uniform(M->read_mlp.dropout)).on;
         mlp_backward<NTD, false>(c, M->read_mlp, dy, false,
@@ -882,7 +886,8 @@ extern "C" int pmt_backward(const PmtModel* model_host, const PmtModel* model_de
     const bool part = use_partials(model_host, shape, grad_partials, num_partials);
     const int grid = part && num_partials < batch->num_groups ? num_partials : batch->num_groups;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    auto kernel = shape == 3 ? pmt_backward_kernel<ShapeP0XB> : shape == 2 ? pmt_backward_kernel<ShapeP0X> : shape == 1 ? pmt_backward_kernel<ShapeP0> : pmt_backward_kernel<ShapeAny>;
+    auto kernel = shape == 4 ? pmt_backward_kernel<ShapeP0XD> : shape == 3 ? pmt_backward_kernel<ShapeP0XB> : shape == 2 ? pmt_backward_kernel<ShapeP0X>
+                  : shape == 1 ? pmt_backward_kernel<ShapeP0> : pmt_backward_kernel<ShapeAny>;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(PMT_THREADS), 0, s, model_dev,
                        theta, phi, packed, *batch, *out, *dout, stash, zsum_stash, rstd_stash, grad_theta, grad_phi, grad_variant_embed,
                        PmtBwdLayered{}, part ? grad_partials : nullptr, model_host->emit_base, model_host->emit_len);
@@ -919,7 +924,7 @@ extern "C" int pmt_backward_layered(const PmtModel* model_host, const PmtModel* 
     lay.park = lay.dy_scratch + (size_t)batch->total_tiles * PMT_SLOT_FLOATS;
     lay.gsum_g = lay.park + (size_t)batch->total_tiles * 6 * 256;
     if (hipMemsetAsync(lay.gsum_g, 0, B * nb * 32 * sizeof(float), s) != hipSuccess) return PMT_E_LAUNCH;
-    const int shape = pmt_shape_for(model_host, batch);
+    const int shape = pmt_shape_for(model_host, batch, true);
     const bool part = use_partials(model_host, shape, grad_partials, num_partials);
     const int grid = part && num_partials < batch->num_groups ? num_partials : batch->num_groups;
     auto kernel = shape >= 2 ? pmt_backward_kernel<ShapeP0X, true> : shape == 1 ? pmt_backward_kernel<ShapeP0, true> : pmt_backward_kernel<ShapeAny, true>;

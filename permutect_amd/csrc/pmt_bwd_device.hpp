@@ -764,21 +764,24 @@ DEV void linear_wgrad(BwdCtx& c, const PmtLinear& L, const f4 (&dy)[PMT_RT][NTO]
 
 // Backward of one LINEAR op between register arrays of different tile counts (see run_linear_op): dy is the gradient
 // w.r.t. the op's output (modified: multiplied by the activation derivative), x its input; dx (if wanted) = W^T dy.
-template <int NTI, int NTO, bool EXACT, int WI = 0, int WO = 0, int BF = 0>
+template <int NTI, int NTO, bool EXACT, int WI = 0, int WO = 0, int BF = 0, bool DROP = false>
 DEV void linear_op_backward(BwdCtx& c, const PmtOp& o, f4 (&dy)[PMT_RT][NTO], const f4 (&x)[PMT_RT][NTI],
                             f4 (&dx)[PMT_RT][NTI], bool want_dx) {
     const PmtLinear& L = c.M->lin[uniform(o.lin[0])];
     const int in_dim = WI ? WI : uniform(L.in_dim), out_dim = WO ? WO : uniform(L.out_dim);
+    const bool dropping = DROP && c.drop != nullptr && c.drop->on != 0;
     if (uniform(o.selu_after) != 0) {  // recompute s = selu(Wx + b); dy <- dy * selu'(s)
         f4 y[PMT_RT][NTO];
         init_bias<NTO>(y, uniform(L.b_pvec) >= 0 ? c.packed + uniform(L.b_pvec) : nullptr, out_dim, c.g);
         if constexpr (BF) linear_acc_bf16<NTI, NTO, false, BF>(y, x, c.packed + uniform(L.wb_frag));
         else linear_acc<NTI, NTO, false, EXACT, WI>(y, x, c.packed + uniform(L.w_frag), in_dim, out_dim);
+        if (dropping) drop_apply<NTO>(*c.drop, uniform(o.lin[0]), y, c.g);
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
             for (int t = 0; t < NTO; ++t) dy[rt][t] = selu_bwd4(dy[rt][t], selu4(y[rt][t]));
     }
+    if (dropping) drop_apply<NTO>(*c.drop, uniform(o.lin[0]), dy, c.g);
     linear_wgrad<NTO, NTI, BF>(c, L, dy, x);
     if (want_dx) {
         init_bias<NTI>(dx, nullptr, in_dim, c.g);
@@ -789,11 +792,11 @@ DEV void linear_op_backward(BwdCtx& c, const PmtOp& o, f4 (&dy)[PMT_RT][NTO], co
 
 // backward of one MLP program.  dy (in/out): gradient w.r.t. the MLP output on entry, w.r.t. its input on exit
 // (not computed for op 0 when need_input_grad is false).  in_slot(op) gives the stash slot of op's input.
-template <int NT, bool EXACT, int W = 0, int BF = 0, typename LoadInput>
+template <int NT, bool EXACT, int W = 0, int BF = 0, bool DROP = !EXACT, typename LoadInput>
 DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool need_input_grad, LoadInput load_input,
                       int op_begin, int op_end) {
     const PmtModel* M = c.M;
-    const bool dropping = !EXACT && c.drop != nullptr && c.drop->on != 0;
+    const bool dropping = DROP && c.drop != nullptr && c.drop->on != 0;
     for (int op = op_end - 1; op >= op_begin; --op) {
         const PmtOp& o = mlp.ops[op];
         f4 x[PMT_RT][NT];

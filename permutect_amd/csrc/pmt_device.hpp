@@ -64,18 +64,21 @@ DEV int pmt_tid() {
 // XBF: 0 = exact-fp32 MFMAs; 3 = the layers' matrix products as SIX bf16 MFMAs on three-piece splits of both operands
 // (linear_acc_bf16: fp32-equivalent); 1 = ONE bf16 MFMA per product on single bf16 roundings of both operands -- the plain
 // bf16 mode BASELINE.json's training configuration names: no parity claim, measured and labelled as such (bench.py --dtype bf16).
-template <int F, int R, int D, int E, bool EXACT_, int XF = 0, int XR = 0, int XD = 0, int XH = 0, int XE = 0, int XBF = 0>
+// XDROP: the instance carries the dropout masks of a training step (pmt_dropout.hpp); the generic instances always do.
+template <int F, int R, int D, int E, bool EXACT_, int XF = 0, int XR = 0, int XD = 0, int XH = 0, int XE = 0, int XBF = 0, bool XDROP = false>
 struct Shape {
     static constexpr int NTF = F, NTR = R, NTD = D, NTE = E;
     static constexpr bool EXACT = EXACT_;
     static constexpr int DIM_F = XF, DIM_R = XR, DIM_D = XD, DIM_H = XH, DIM_E = XE;  // read features, read width, d_model, d_ffn / 2, feature_dim
     static constexpr int BF16 = XBF;  // pieces per operand (0: fp32 MFMA)
+    static constexpr bool DROP = XDROP || !EXACT_;
     static_assert(!XBF || EXACT_, "the bf16 path has no tile guards");
 };
 using ShapeAny = Shape<4, 4, 4, 4, false>;   // any supported model
 using ShapeP0 = Shape<4, 2, 4, 1, true>;     // F in 49..64, read widths 17..32, d_model / reducer widths 49..64, E <= 16
 using ShapeP0X = Shape<4, 2, 4, 1, true, 61, 30, 60, 10, 10, 3>;  // exactly the production hyperparameters (SURVEY: P0)
 using ShapeP0XB = Shape<4, 2, 4, 1, true, 61, 30, 60, 10, 10, 1>; // the same widths, plain bf16 products (not a parity mode)
+using ShapeP0XD = Shape<4, 2, 4, 1, true, 61, 30, 60, 10, 10, 3, true>;  // the production shape in a training step WITH dropout
 
 DEV float uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -733,9 +736,12 @@ DEV void drop_apply(const PmtDrop& d, int lin, f4 (&y)[PMT_RT][NT], int g) {
 
 extern "C" int pmt_stash_slots(const PmtModel* m);  // host helper (pmt_host.hip)
 extern "C" int pmt_shape_id(const PmtModel* m);     // host: 2 = ShapeP0X (exact widths), 1 = ShapeP0 (exact tiles), 0 = ShapeAny
-// a batch that brings a dropout seed to a model with dropout_p > 0 runs the generic instances: only they carry the masks
-static inline int pmt_shape_for(const PmtModel* m, const PmtBatch* b) {
-    return (m->dropout_p > 0.f && b->dropout_seed != 0) ? 0 : pmt_shape_id(m);
+// A batch that brings a dropout seed to a model with dropout_p > 0 runs an instance that carries the masks: 4 = ShapeP0XD (the
+// production shape, one-launch path only), else 0 = the generic instance.
+static inline int pmt_shape_for(const PmtModel* m, const PmtBatch* b, bool layered = false) {
+    const int shape = pmt_shape_id(m);
+    if (!(m->dropout_p > 0.f && b->dropout_seed != 0)) return shape;
+    return (shape == 2 && !layered) ? 4 : 0;
 }
 
 DEV int frag_floats_dev(const PmtLinear& L) {

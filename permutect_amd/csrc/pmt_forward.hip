@@ -170,9 +170,15 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
         tr.ev(5);
         if constexpr (EX) {
             f4 xr[PMT_RT][NTR];
-            run_linear_op<NTF, NTR, true, S::DIM_F, S::DIM_R, S::BF16>(M, M->read_mlp.ops[0], xr, xf, g, packed);
+            PmtDrop drop;  // (only the dropout instance, ShapeP0XD, touches it)
+            if constexpr (S::DROP) {
+                drop = drop_setup(M, bt.dropout_seed, uniform(M->read_mlp.dropout));
+#pragma unroll
+                for (int rt = 0; rt < PMT_RT; ++rt) drop.row[rt] = tm[rt].row;
+            }
+            run_linear_op<NTF, NTR, true, S::DIM_F, S::DIM_R, S::BF16, S::DROP>(M, M->read_mlp.ops[0], xr, xf, g, packed, &drop);
             tr.ev(6);
-            run_mlp<TRAIN, NTR, true, S::DIM_R, S::BF16>(M, M->read_mlp, xr, theta, g, mask_all, stash_tile, slot, 1, packed, 1, n_read_ops);
+            run_mlp<TRAIN, NTR, true, S::DIM_R, S::BF16, S::DROP>(M, M->read_mlp, xr, theta, g, mask_all, stash_tile, slot, 1, packed, 1, n_read_ops, &drop);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
 #pragma unroll
@@ -369,14 +375,20 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
     // ---- reducer MLP, then translation + rotation ----------------------------------------------------------------
     f4 e[PMT_RT][NTE];
     if constexpr (EX) {
-        run_mlp<TRAIN, NTD, true, S::DIM_D, S::BF16>(M, M->reducer, x, theta, g, mask_all, stash_tile, slot, 1, packed, 0, n_red_ops - 1);
+        PmtDrop drop;
+        if constexpr (S::DROP) {
+            drop = drop_setup(M, bt.dropout_seed, uniform(M->reducer.dropout));
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt) drop.row[rt] = tm[rt].row;
+        }
+        run_mlp<TRAIN, NTD, true, S::DIM_D, S::BF16, S::DROP>(M, M->reducer, x, theta, g, mask_all, stash_tile, slot, 1, packed, 0, n_red_ops - 1, &drop);
         if (TRAIN && n_red_ops > 1) {
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
                 if (mask_all & (1u << rt)) stash_store<NTD>(stash_tile[rt] + slot * PMT_SLOT_FLOATS, x[rt]);
             ++slot;
         }
-        run_linear_op<NTD, NTE, true, S::DIM_D, S::DIM_E, S::BF16>(M, M->reducer.ops[n_red_ops - 1], e, x, g, packed);
+        run_linear_op<NTD, NTE, true, S::DIM_D, S::DIM_E, S::BF16, S::DROP>(M, M->reducer.ops[n_red_ops - 1], e, x, g, packed, &drop);
     } else {
         PmtDrop drop = drop_setup(M, bt.dropout_seed, uniform(M->reducer.dropout));
 #pragma unroll
@@ -579,6 +591,9 @@ extern "C" int pmt_forward_launch_train_p0x(int groups, void* stream, const PmtM
     else if (lay != nullptr)  // one launch of the layered training forward
         hipLaunchKernelGGL((pmt_forward_kernel<true, ShapeP0X, true>), dim3(groups), dim3(PMT_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
                            model_dev, theta, phi, packed, *batch, *out, stash, zsum_stash, rstd_stash, *lay);
+    else if (batch->dropout_seed != 0)  // a training step with dropout (the caller checked the model's dropout_p): the instance with the masks
+        hipLaunchKernelGGL((pmt_forward_kernel<true, ShapeP0XD>), dim3(groups), dim3(PMT_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
+                           model_dev, theta, phi, packed, *batch, *out, stash, zsum_stash, rstd_stash, PmtLayeredArgs{});
     else
         hipLaunchKernelGGL((pmt_forward_kernel<true, ShapeP0X>), dim3(groups), dim3(PMT_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
                            model_dev, theta, phi, packed, *batch, *out, stash, zsum_stash, rstd_stash, PmtLayeredArgs{});
@@ -637,7 +652,7 @@ extern "C" int pmt_forward_layered(const PmtModel* model_host, const PmtModel* m
         !batch->group_tile_base || batch->total_tiles <= 0 || !out->logits_b || !out->logits_bk || !out->features_be || !out->ref_features_be)
         return PMT_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int shape = pmt_shape_for(model_host, batch);
+    const int shape = pmt_shape_for(model_host, batch, true);
     const bool p0 = shape == 1;
     const int L = model_host->num_blocks;
     const size_t nb = (size_t)(L > 0 ? L : 1), B = (size_t)batch->num_variants;
@@ -694,7 +709,8 @@ extern "C" int pmt_forward(const PmtModel* model_host, const PmtModel* model_dev
         return PMT_E_INVALID;
     if (batch->group_span) return PMT_E_UNSUPPORTED;  // split read sets: pmt_forward_layered
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int shape = pmt_shape_for(model_host, batch);  // pmt_device.hpp: 2 ShapeP0X, 1 ShapeP0, 0 ShapeAny
+    int shape = pmt_shape_for(model_host, batch);  // pmt_device.hpp: 2 ShapeP0X, 1 ShapeP0, 0 ShapeAny, 4 ShapeP0XD (dropout step)
+    if (shape == 4 && !stash) shape = 0;            // (train mode without a backward to follow: the generic instance)
     const bool p0 = shape == 1;
     float* zsum_stash = nullptr;
     float* rstd_stash = nullptr;
@@ -706,7 +722,7 @@ extern "C" int pmt_forward(const PmtModel* model_host, const PmtModel* model_dev
     }
     auto kernel = stash ? (p0 ? pmt_forward_kernel<true, ShapeP0> : pmt_forward_kernel<true, ShapeAny>)
                         : (p0 ? pmt_forward_kernel<false, ShapeP0> : pmt_forward_kernel<false, ShapeAny>);
-    if (shape == 2 && stash)  // its own translation unit (pmt_forward_train.hip)
+    if ((shape == 2 || shape == 4) && stash)  // its own translation unit (pmt_forward_train.hip); 4: with the step's dropout masks
         return pmt_forward_launch_train_p0x(batch->num_groups, stream, model_dev, theta, phi, packed, batch, out, stash, zsum_stash, rstd_stash, nullptr);
     if (shape == 2) kernel = pmt_forward_kernel<false, ShapeP0X>;
     if (shape == 3) kernel = stash ? pmt_forward_kernel<true, ShapeP0XB> : pmt_forward_kernel<false, ShapeP0XB>;  // plain bf16 products

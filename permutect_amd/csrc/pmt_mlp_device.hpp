@@ -6,9 +6,10 @@
 // reducer, the wide first op of a row MLP): y = act(W x + b).
 // WI / WO / W (compile time, 0 = read the descriptor): the widths, for the instances that have them compiled in.
 // BF: the matrix products on the bf16 pipe (linear_acc_bf16; exact instances, direct weight path only).
-template <int NTI, int NTO, bool EXACT, int WI = 0, int WO = 0, int BF = 0>
+// DROP (+ drop): dropout behind the Linear, before the SELU (reference mlp.py:57-58).
+template <int NTI, int NTO, bool EXACT, int WI = 0, int WO = 0, int BF = 0, bool DROP = false>
 DEV void run_linear_op(const PmtModel* __restrict__ M, const PmtOp& o, f4 (&y)[PMT_RT][NTO], const f4 (&x)[PMT_RT][NTI],
-                       int g, const float* __restrict__ packed) {
+                       int g, const float* __restrict__ packed, const PmtDrop* drop = nullptr) {
     const PmtLinear& L = M->lin[uniform(o.lin[0])];
     const int b_pvec = uniform(L.b_pvec), base = uniform(L.w_frag);
     const float* st = packed + base;  // [fragments | bias]
@@ -16,6 +17,9 @@ DEV void run_linear_op(const PmtModel* __restrict__ M, const PmtOp& o, f4 (&y)[P
     init_bias<NTO>(y, b_pvec >= 0 ? st + (b_pvec - base) : nullptr, out_dim, g);
     if constexpr (BF) linear_acc_bf16<NTI, NTO, false, BF>(y, x, packed + uniform(L.wb_frag));
     else linear_acc<NTI, NTO, false, EXACT, WI>(y, x, st, in_dim, out_dim);
+    if constexpr (DROP) {
+        if (drop != nullptr && drop->on != 0) drop_apply<NTO>(*drop, uniform(o.lin[0]), y, g);
+    }
     if (uniform(o.selu_after) != 0) {
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt)
@@ -30,11 +34,11 @@ DEV void run_linear_op(const PmtModel* __restrict__ M, const PmtOp& o, f4 (&y)[P
 // store_mask only).
 // drop (generic instances only, nullptr = none): dropout behind every Linear (reference mlp.py:57-58), BEFORE the SELU that
 // follows it; inside a skip block both Linears are followed by one, so f(x) itself is masked before alpha scales it.
-template <bool TRAIN, int NT, bool EXACT, int W = 0, int BF = 0>
+template <bool TRAIN, int NT, bool EXACT, int W = 0, int BF = 0, bool DROP = !EXACT>
 DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_RT][NT], const float* __restrict__ theta,
                  int g, unsigned store_mask, float* const (&stash_tile)[PMT_RT], int& slot, int first_stashed_op,
                  const float* __restrict__ packed, int op_begin, int op_end, const PmtDrop* drop = nullptr) {
-    const bool dropping = !EXACT && drop != nullptr && drop->on != 0;
+    const bool dropping = DROP && drop != nullptr && drop->on != 0;
     for (int op = op_begin; op < op_end; ++op) {
         const PmtOp& o = mlp.ops[op];
         if (TRAIN && op >= first_stashed_op) {
@@ -48,8 +52,9 @@ DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_
             if (dropping) {
                 const PmtLinear& L = M->lin[uniform(o.lin[0])];
                 const int b_pvec = uniform(L.b_pvec);
-                init_bias<NT>(y, b_pvec >= 0 ? packed + b_pvec : nullptr, uniform(L.out_dim), g);
-                linear_acc<NT, NT, false, false>(y, x, packed + uniform(L.w_frag), uniform(L.in_dim), uniform(L.out_dim));
+                init_bias<NT>(y, b_pvec >= 0 ? packed + b_pvec : nullptr, W ? W : uniform(L.out_dim), g);
+                if constexpr (BF) linear_acc_bf16<NT, NT, false, BF>(y, x, packed + uniform(L.wb_frag));
+                else linear_acc<NT, NT, false, EXACT, W>(y, x, packed + uniform(L.w_frag), W ? W : uniform(L.in_dim), W ? W : uniform(L.out_dim));
                 drop_apply<NT>(*drop, uniform(o.lin[0]), y, g);
                 const bool act = uniform(o.selu_after) != 0;
 #pragma unroll
@@ -66,13 +71,14 @@ DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_
         } else if (dropping) {
             // x + alpha * D2(L2(selu(D1(L1(selu(x))))))   (n = 2)   or   x + alpha * D1(L1(selu(x)))   (n = 1)
             const int nl = uniform(o.n_layers);
-            const int width = uniform(M->lin[uniform(o.lin[0])].in_dim);
+            const int width = W ? W : uniform(M->lin[uniform(o.lin[0])].in_dim);
             const float alpha = uniform(theta[uniform(o.alpha_src)]);
             f4 f[PMT_RT][NT];
             if (nl == 2) {
                 const PmtLinear& L1 = M->lin[uniform(o.lin[0])];
                 init_bias<NT>(y, packed + uniform(L1.b_pvec), width, g);
-                linear_acc<NT, NT, true, false>(y, x, packed + uniform(L1.w_frag), width, width);
+                if constexpr (BF) linear_acc_bf16<NT, NT, true, BF>(y, x, packed + uniform(L1.wb_frag));
+                else linear_acc<NT, NT, true, EXACT, W>(y, x, packed + uniform(L1.w_frag), width, width);
                 drop_apply<NT>(*drop, uniform(o.lin[0]), y, g);
             } else {
 #pragma unroll
@@ -82,7 +88,8 @@ DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_
             }
             const PmtLinear& L2 = M->lin[uniform(o.lin[nl - 1])];
             init_bias<NT>(f, packed + uniform(L2.b_pvec), width, g);
-            linear_acc<NT, NT, true, false>(f, y, packed + uniform(L2.w_frag), width, width);
+            if constexpr (BF) linear_acc_bf16<NT, NT, true, BF>(f, y, packed + uniform(L2.wb_frag));
+            else linear_acc<NT, NT, true, EXACT, W>(f, y, packed + uniform(L2.w_frag), width, width);
             drop_apply<NT>(*drop, uniform(o.lin[nl - 1]), f, g);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)

@@ -29,7 +29,7 @@ def means(d, counter):
 
 
 def short(name):
-    for key in ("pmt_backward_kernel", "pmt_forward_kernel<true", "pmt_forward_kernel<false", "pmt_cnn3_backward_kernel", "pmt_cnn3_forward_kernel"):
+    for key in ("pmt_backward_kernel", "pmt_forward_kernel<true", "pmt_forward_kernel<false", "pmt_cnn3_backward_kernel", "pmt_cnn3_forward_bf_kernel", "pmt_cnn3_forward_kernel", "pmt_rows_forward_kernel", "pmt_rows_backward_kernel"):
         if key in name:
             return {"pmt_forward_kernel<true": "pmt_forward_kernel<train>", "pmt_forward_kernel<false": "pmt_forward_kernel"}.get(key, key)
     return None
