@@ -67,6 +67,9 @@ class Config:
     # "reducer._model.0"; its output y; row0 = 0, the batch row of y[0]) -> the multiplier tensor of train mode (0 or
     # 1 / (1 - p) per element), or None for eval mode.  Being set at all shifts the Sequential indices by the Dropout modules, as in the reference's state_dict.
     dropout: Optional[Callable] = None
+    # the model was built with batch_normalize = True (architecture/mlp.py:52-53: an nn.BatchNorm1d in front of every Linear of the
+    # same four MLPs).  Only EVAL mode is restated (running statistics: what filter_variants runs); train-mode statistics span the batch.
+    batch_normalize: bool = False
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -97,7 +100,7 @@ def downsampled_read_indices(keep_ref_mask: Tensor, keep_alt_mask: Tensor) -> Te
 # building blocks
 # ----------------------------------------------------------------------------------------------------------------
 def mlp(sd: SD, prefix: str, layer_sizes: List[int], x: Tensor, prepend_activation: bool = False,
-        dropout: Optional[Callable] = None) -> Tensor:
+        dropout: Optional[Callable] = None, batch_normalize: bool = False) -> Tensor:
     """architecture/mlp.py:32-67 (Sequential index bookkeeping included, it defines the key names).  dropout: see
     Config.dropout (mlp.py:57-58: Linear, Dropout, then the activation)."""
     idx = 0
@@ -109,10 +112,14 @@ def mlp(sd: SD, prefix: str, layer_sizes: List[int], x: Tensor, prepend_activati
     for k, out in enumerate(layer_sizes[1:]):
         if out < 0:  # DenseSkipBlock, mlp.py:15-22
             p = f"{prefix}._model.{idx}"
-            inner = mlp(sd, p + ".mlp", (-out + 1) * [width], x, prepend_activation=True, dropout=dropout)
+            inner = mlp(sd, p + ".mlp", (-out + 1) * [width], x, prepend_activation=True, dropout=dropout, batch_normalize=batch_normalize)
             x = x + sd[p + ".alpha"] * inner
             idx += 1
             continue
+        if batch_normalize:  # eval mode (mlp.py:52-53; torch.nn.BatchNorm1d, eps = 1e-5)
+            bn = f"{prefix}._model.{idx}"
+            x = F.batch_norm(x, sd[bn + ".running_mean"], sd[bn + ".running_var"], sd[bn + ".weight"], sd[bn + ".bias"], False, 0.0, 1e-5)
+            idx += 1
         x = F.linear(x, sd[f"{prefix}._model.{idx}.weight"], sd[f"{prefix}._model.{idx}.bias"])
         if dropout is not None:
             mask = dropout(f"{prefix}._model.{idx}", x)
@@ -275,8 +282,9 @@ def calculate_features(sd: SD, cfg: Config, reads_re: Tensor, nref: Tensor, nalt
     """architecture/artifact_model.py:239-265 -> (final_ref_re, final_alt_re, ref_seq_embeddings_be)."""
     total_ref = int(nref.sum())
     read_emb = mlp(sd, "read_embedding", [cfg.num_read_features] + cfg.read_layers, reads_re.to(COMPUTE_DTYPE),
-                   dropout=cfg.dropout)
-    info_emb = mlp(sd, "info_embedding", [cfg.num_info_features] + cfg.info_layers, info_be.to(COMPUTE_DTYPE), dropout=cfg.dropout)
+                   dropout=cfg.dropout, batch_normalize=cfg.batch_normalize)
+    info_emb = mlp(sd, "info_embedding", [cfg.num_info_features] + cfg.info_layers, info_be.to(COMPUTE_DTYPE), dropout=cfg.dropout,
+                   batch_normalize=cfg.batch_normalize)
     hap_emb = cnn(sd, "haplotypes_cnn", cfg.cnn_layers, one_hot_haplotypes(haplotypes_bh))
     info_seq = torch.hstack((info_emb, hap_emb))
     x = torch.hstack((read_emb, torch.vstack((expand(info_seq, nref), expand(info_seq, nalt)))))
@@ -286,7 +294,8 @@ def calculate_features(sd: SD, cfg: Config, reads_re: Tensor, nref: Tensor, nalt
     red_sizes = [ref.shape[-1]] + cfg.aggregation_layers
     q = rotation_matrix(sd, "pre_clustering_transform.rotation_ee")
     t = sd["pre_clustering_transform.translation_e"]
-    final = lambda r, row0: F.linear(mlp(sd, "reducer", red_sizes, r, dropout=_rows_from(cfg.dropout, row0)) + t[None, :], q)  # euclidean_transformation.py:19-20
+    final = lambda r, row0: F.linear(mlp(sd, "reducer", red_sizes, r, dropout=_rows_from(cfg.dropout, row0),
+                                                  batch_normalize=cfg.batch_normalize) + t[None, :], q)  # euclidean_transformation.py:19-20
     return final(ref, 0), final(alt, total_ref), hap_emb
 
 
@@ -331,7 +340,7 @@ def compute_batch_losses(sd: SD, cfg: Config, out: Dict[str, Tensor], labels_enu
     if cfg.num_sources > 1:
         hidden = [-1, -1]
         src_logits = mlp(sd, "source_predictor.wrapped_module", [e] + hidden + [cfg.num_sources],
-                         revgrad(feats, source_adv_strength), dropout=cfg.dropout)
+                         revgrad(feats, source_adv_strength), dropout=cfg.dropout, batch_normalize=cfg.batch_normalize)
         probs = torch.softmax(src_logits, dim=-1)
         source = torch.sum(torch.square(probs - F.one_hot(sources_b.long(), cfg.num_sources)), dim=-1)
     else:

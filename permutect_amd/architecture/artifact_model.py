@@ -162,6 +162,11 @@ class ArtifactModel(nn.Module):
         return VariantEmbedFunction.apply(eng, batch.get_info_be(), batch.get_haplotypes_bs(), eng.trigger)
 
     def _encode(self, batch: Batch):
+        if self.training and self._params.batch_normalize:
+            # reference mlp.py:52-53: BatchNorm1d normalises with the statistics of the whole batch in train mode.  The kernels run its
+            # eval-mode form (running statistics folded into the Linear behind it, engine/plan.py): refuse, never train on the wrong map.
+            raise NotImplementedError("permutect_amd runs a batch_normalize model in eval mode only (model.eval(): filter_variants, "
+                                      "evaluation); training with BatchNorm statistics is not built")
         eng = self.engine()
         # reference mlp.py:57-58: nn.Dropout draws new masks on every forward in train mode and is the identity in eval mode
         eng.draw_dropout_seed(self.training)

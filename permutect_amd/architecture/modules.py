@@ -81,10 +81,12 @@ class MLP(nn.Module):
     def __init__(self, layer_sizes: List[int], batch_normalize: bool = False, dropout_p: float = 0,
                  prepend_activation: bool = False):
         super().__init__()
-        if batch_normalize:
-            # BatchNorm1d is off by default in the reference CLI (parameters.py:139-156) and is not part of the MI355X
-            # kernels (its training statistics span the whole batch in the middle of the fused read-set pass).
-            raise NotImplementedError("permutect_amd supports batch_normalize=False only")
+        # batch_normalize (reference mlp.py:52-53; off by default, parameters.py:139-156): an nn.BatchNorm1d in front of every Linear,
+        # kept as modules so that a reference checkpoint loads key for key.  EVAL mode (running statistics: what filter_variants and
+        # evaluation run) is an affine map per feature and is folded into the Linear behind it when the model is lowered
+        # (engine/plan.py); TRAINING with it is refused loudly (ArtifactModel._encode): batch statistics span every read of the
+        # batch in the middle of the fused read-set pass.
+        self.batch_normalize = bool(batch_normalize)
         # dropout_p > 0 (reference mlp.py:57-58; default 0): the nn.Dropout modules are kept in the Sequential so that the
         # state_dict keys of a reference checkpoint line up; the engine lowers them to a flag of the MLP (engine/plan.py) and the
         # kernels mask every Linear's output in train mode (pmt_dropout.hpp) and run the identity in eval mode.
@@ -97,6 +99,8 @@ class MLP(nn.Module):
             if out < 0:
                 layers.append(DenseSkipBlock(width, -out, batch_normalize, dropout_p))
                 continue
+            if batch_normalize:
+                layers.append(nn.BatchNorm1d(num_features=width))
             layers.append(nn.Linear(width, out))
             if dropout_p > 0:
                 layers.append(nn.Dropout(p=dropout_p))

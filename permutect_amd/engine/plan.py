@@ -15,7 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Dict, List
+from typing import Dict, List, Optional
 
 import torch
 from torch import nn
@@ -97,6 +97,7 @@ class EnginePlan:
         self._phi_off = 0
         self._phi_prog = None
         self.phi_layout: List[tuple] = []  # (name, offset, numel)
+        self.bn_folds: List[tuple] = []    # (BatchNorm1d, Linear) pairs folded into phi, in phi order (materialize_phi)
 
         read_mlp: M.MLP = model.read_embedding
         enc: M.GatedRefAltMLP = model.ref_alt_reads_encoder
@@ -266,7 +267,16 @@ class EnginePlan:
         lr.wt_frag = self._alloc_packed(nfl); la.wt_frag = self._alloc_packed(nfl)
         return ids[0], ids[1]
 
-    def _add_linear(self, layer: nn.Linear, out_split: int = 0, max_in: int = L.MAX_WIDTH) -> int:
+    def _add_linear(self, layer: nn.Linear, out_split: int = 0, max_in: int = L.MAX_WIDTH, bn: Optional[nn.BatchNorm1d] = None) -> int:
+        if bn is not None:
+            # eval-mode BatchNorm1d in front of the Linear (reference mlp.py:52-53) is an affine map per input feature,
+            # x -> s x + t with s = w / sqrt(running_var + eps), t = b - running_mean s: the Linear the kernels run is
+            # W' = W diag(s), b' = b + W t, materialised into phi by materialize_phi (bn_folds) like any parametrization
+            n = self._n_lin
+            w_phi = self._alloc_phi(f"bnfold.w.{n}", layer.out_features * layer.in_features)
+            b_phi = self._alloc_phi(f"bnfold.b.{n}", layer.out_features)
+            self.bn_folds.append((bn, layer))
+            return self._add_raw_linear(layer.in_features, layer.out_features, -(w_phi + 2), -(b_phi + 2), True, out_split, max_in=max_in)
         b_src = self.space.offset_of(layer.bias) if layer.bias is not None else -1
         return self._add_raw_linear(layer.in_features, layer.out_features, self.space.offset_of(layer.weight), b_src,
                                     layer.bias is not None, out_split, max_in=max_in)
@@ -275,7 +285,23 @@ class EnginePlan:
         # nn.Dropout (reference mlp.py:57-58: one behind every Linear when dropout_p > 0) becomes a flag of the MLP: the kernels
         # mask every Linear's output of a flagged MLP when the batch brings a seed (train mode), and ignore it otherwise (eval)
         dst.dropout = int(any(isinstance(c, nn.Dropout) for c in mlp._model.modules()))
-        children = [c for c in mlp._model.children() if not isinstance(c, nn.Dropout)]
+        def strip(seq):
+            """children without the Dropouts, and the BatchNorm1d (if any) in front of every Linear"""
+            kept, bn_of, pending = [], {}, None
+            for m in seq:
+                if isinstance(m, nn.Dropout):
+                    continue
+                if isinstance(m, nn.BatchNorm1d):
+                    pending = m
+                    continue
+                if pending is not None:
+                    if not isinstance(m, nn.Linear):
+                        raise L.PmtError("a BatchNorm1d that is not directly in front of a Linear")
+                    bn_of[m] = pending
+                    pending = None
+                kept.append(m)
+            return kept, bn_of
+        children, bn_of = strip(mlp._model.children())
         ops = []
         i = 0
         while i < len(children):
@@ -285,7 +311,8 @@ class EnginePlan:
                 ops.append(("lin", c, selu_after))
                 i += 2 if selu_after else 1
             elif isinstance(c, M.DenseSkipBlock):
-                inner = [m for m in c.mlp._model.children() if not isinstance(m, nn.Dropout)]  # (SELU, Linear) * n
+                inner, inner_bn = strip(c.mlp._model.children())  # (SELU, Linear) * n
+                bn_of.update(inner_bn)
                 lins = [m for m in inner if isinstance(m, nn.Linear)]
                 assert len(inner) == 2 * len(lins) and all(isinstance(m, nn.SELU) for m in inner[0::2])
                 ops.append(("skip", c, lins))
@@ -299,7 +326,7 @@ class EnginePlan:
             o = dst.ops[j]
             if op[0] == "lin":
                 o.kind, o.n_layers, o.selu_after, o.alpha_src = L.OP_LINEAR, 1, int(op[2]), -1
-                o.lin[0] = self._add_linear(op[1], max_in=max_in if j == 0 else L.MAX_WIDTH)
+                o.lin[0] = self._add_linear(op[1], max_in=max_in if j == 0 else L.MAX_WIDTH, bn=bn_of.get(op[1]))
             else:
                 blk, lins = op[1], op[2]
                 if len(lins) > 2:
@@ -307,7 +334,7 @@ class EnginePlan:
                 o.kind, o.n_layers, o.selu_after = L.OP_SKIP, len(lins), 0
                 o.alpha_src = self.space.offset_of(blk.alpha)
                 for t, lin in enumerate(lins):
-                    o.lin[t] = self._add_linear(lin)
+                    o.lin[t] = self._add_linear(lin, bn=bn_of.get(lin))
 
     def _lower_cnn(self, dst: L.PmtCnn, cnn: M.DNASequenceConvolution, seq_len: int):
         layers = list(cnn._model.children())
@@ -367,7 +394,7 @@ class EnginePlan:
         evaluation `materialize_phi` is then used instead.  Built once; the base-matrix pointer is refreshed per call."""
         tr, fc, space = model.pre_clustering_transform, model.feature_clustering, self.space
         e = self.desc.feature_dim
-        if e > L.MAX_ORTHO_DIM:
+        if e > L.MAX_ORTHO_DIM or self.bn_folds:  # (folded BatchNorm weights are materialised by torch: eval mode only)
             return None
         if self._phi_prog is None:
             offs = {name: off for name, off, _ in self.phi_layout}
@@ -406,14 +433,24 @@ class EnginePlan:
         return self._phi_prog
 
     def materialize_phi(self, model) -> torch.Tensor:
-        """Evaluate every parametrization with torch (autograd-tracked) in the order of phi_layout.  The product path
+        """Evaluate every parametrization with torch (autograd-tracked), laid out as phi_layout says.  The product path
         uses the device program above; this is the general path for configurations outside it and the test reference."""
         fc = model.feature_clustering
-        parts = [blk.sgu.reg_weight.reshape(1) for blk in model.ref_alt_reads_encoder.blocks]
-        parts += [model.pre_clustering_transform.rotation_ee.weight.reshape(-1),
-                  fc.nonartifact_stdev_e.reshape(-1), fc.artifact_directions_ke.reshape(-1),
-                  fc.artifact_stdev_k.reshape(-1), fc.log_cluster_weights_k.reshape(-1),
-                  fc.artifact_emg.sigma_k.reshape(-1), fc.artifact_emg.lambda_k.reshape(-1)]
+        vals = {f"reg_weight.{i}": blk.sgu.reg_weight for i, blk in enumerate(model.ref_alt_reads_encoder.blocks)}
+        vals.update({"rotation": model.pre_clustering_transform.rotation_ee.weight, "stdev_e": fc.nonartifact_stdev_e,
+                     "dirs_ke": fc.artifact_directions_ke, "art_stdev_k": fc.artifact_stdev_k, "log_w_k": fc.log_cluster_weights_k,
+                     "sigma_k": fc.artifact_emg.sigma_k, "lambda_k": fc.artifact_emg.lambda_k})
+        names = [n for n, _, _ in self.phi_layout if n.startswith("bnfold.w.")]
+        for name, (bn, lin) in zip(names, self.bn_folds):  # W' = W diag(s), b' = b + W t  (eval-mode BatchNorm1d folded into its Linear)
+            s = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+            t = bn.bias - bn.running_mean * s
+            vals[name] = lin.weight * s[None, :]
+            vals["bnfold.b." + name[len("bnfold.w."):]] = lin.bias + lin.weight @ t
+        parts, at = [], 0
+        for name, off, n in self.phi_layout:
+            assert off == at and vals[name].numel() == n, (name, off, at)
+            parts.append(vals[name].reshape(-1))
+            at += n
         phi = torch.cat(parts)
         if phi.numel() < self.desc.phi_size:
             phi = torch.cat([phi, phi.new_zeros(self.desc.phi_size - phi.numel())])

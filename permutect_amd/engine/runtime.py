@@ -77,7 +77,8 @@ class ReadSetEngine:
         # (a Parameter re-bound with `p.data = view` keeps its OWN version counter: in-place writes through a parameter --
         #  load_state_dict, a torch optimizer -- show up there, writes to the flat buffer on theta's)
         try:
-            return (self._param_epoch, self.space.theta._version, sum(p._version for p in self.space.params))
+            stats = sum(bn.running_mean._version + bn.running_var._version for bn, _ in self.plan.bn_folds)  # (folded into phi: buffers, not leaves)
+            return (self._param_epoch, self.space.theta._version, sum(p._version for p in self.space.params), stats)
         except RuntimeError:  # inference tensors (a model built under torch.inference_mode) carry no version counter:
             return None        # nothing can be proved unchanged, so nothing is reused
 

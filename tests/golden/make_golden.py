@@ -452,9 +452,44 @@ def make_dropout_eval_fixture():
     print("dropout eval fixture written;", len(m.state_dict()), "state_dict entries; logits", out["out/logits_b"][:4])
 
 
+def make_batchnorm_eval_fixture():
+    """p0_batchnorm_eval.npz: a P0-shaped model built with batch_normalize = True (an nn.BatchNorm1d in front of every Linear of the
+    MLPs, reference architecture/mlp.py:52-53) in EVAL mode, as filter_variants runs a checkpoint trained that way: running
+    statistics away from their initial (0, 1), state_dict, inputs and the forward outputs."""
+    torch.manual_seed(13)
+    p = ModelParameters([30, -2, -2, -2], 20, 6, [20, -2, -2, -2], [-2, -2, 10], 4, [10, 10], list(P0_CNN), 0.0, 0.3, True)
+    m = ArtifactModel(p, 61, 71, 42, device=CPU)
+    with torch.no_grad():
+        for q in m.parameters():
+            q.add_(0.05 * torch.randn_like(q))
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.normal_(0.0, 0.3)
+                mod.running_var.uniform_(0.5, 1.5)
+    m.eval()
+    rng = np.random.default_rng(13)
+    counts = [(int(rng.integers(0, 12)), int(rng.integers(1, 9))) for _ in range(24)]
+    data = make_data(rng, counts)
+    batch = Batch(data)
+    packed = np.vstack([d.get_ref_reads_re() for d in data] + [d.get_alt_reads_re() for d in data])
+    out = {"packed_reads": packed, "int_array": batch.int_tensor.numpy().astype(np.int16),
+           "float_array": batch.float_tensor.numpy().astype(np.float16)}
+    for k, v in m.state_dict().items():
+        out["sd/" + k] = v.detach().numpy().copy()
+    with torch.inference_mode():
+        output = m.compute_batch_output(batch, None)
+    for k in ("features_be", "ref_features_be", "logits_b", "logits_bk", "artifact_probs_b", "outlier_binary_logits"):
+        out["out/" + k] = getattr(output, k).detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "p0_batchnorm_eval.npz"), **out)
+    n_bn = sum(isinstance(mod, torch.nn.BatchNorm1d) for mod in m.modules())
+    print("batchnorm eval fixture written;", len(m.state_dict()), "state_dict entries,", n_bn, "BatchNorm1d modules; logits", out["out/logits_b"][:4])
+
+
 if __name__ == "__main__":
     if "--dropout-only" in sys.argv:
         make_dropout_eval_fixture()
+    elif "--batchnorm-only" in sys.argv:
+        make_batchnorm_eval_fixture()
     elif "--cnn-only" in sys.argv:
         make_cnn_fixtures()
     elif "--metrics-only" in sys.argv:
@@ -474,5 +509,6 @@ if __name__ == "__main__":
         make_downsampler_fit_fixture()
         make_posterior_rows_fixture()
         make_dropout_eval_fixture()
+        make_batchnorm_eval_fixture()
         make_cnn_fixtures()
         make_metrics_fixtures()

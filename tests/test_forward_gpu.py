@@ -104,6 +104,34 @@ def test_eval_forward_of_a_dropout_model_matches_reference():
     assert model.engine().dropout_seed != 0 and float((tr.logits_b - out.logits_b).abs().max()) > 1e-3
 
 
+def test_eval_forward_of_a_batchnorm_model_matches_reference():
+    """A reference model built with batch_normalize = True (an nn.BatchNorm1d in front of every Linear of the MLPs, reference
+    architecture/mlp.py:52-53; tests/golden/p0_batchnorm_eval.npz, running statistics away from (0, 1)), run in eval mode as
+    filter_variants runs a checkpoint trained that way: the engine folds every BatchNorm into the Linear behind it (engine/plan.py).
+    Training with batch statistics is refused."""
+    z, sd, b = load_case("p0_batchnorm_eval")
+    params = p0_params()
+    params.batch_normalize = True
+    model = ArtifactModel(params, device=torch.device("cuda"), **P0_DIMS)
+    model.load_state_dict(sd)
+    model.eval()
+    batch = Batch.from_arrays(b["int_array"], b["float_array"], b["packed_reads"]).copy_to(torch.device("cuda"))
+    with torch.inference_mode():
+        out = model.compute_batch_output(batch)
+        again = model.compute_batch_output(batch)  # (the folded weights are cached while the parameters stand still)
+    check_outputs(out, z, "p0_batchnorm_eval")
+    assert torch.equal(out.logits_b, again.logits_b) or float((out.logits_b - again.logits_b).abs().max()) < 1e-5
+    # new running statistics are new weights: the cache must notice a load_state_dict
+    sd2 = {k: (v * 1.5 if k.endswith("running_var") else v) for k, v in sd.items()}
+    model.load_state_dict(sd2)
+    with torch.inference_mode():
+        moved = model.compute_batch_output(batch)
+    assert float((moved.logits_b - out.logits_b).abs().max()) > 1e-3
+    model.train(True)
+    with pytest.raises(NotImplementedError, match="batch_normalize"):
+        model.compute_batch_output(batch)
+
+
 @pytest.mark.parametrize("name", CASES)
 @pytest.mark.parametrize("fmt", ["packed", "f16", "f32"])
 def test_forward_matches_reference(name, fmt):

@@ -7,12 +7,13 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import artifact_oracle as O
 from permutect_amd.architecture.artifact_model import ArtifactModel, load_model
 from permutect_amd.data.batch import Batch, DownsampledBatch, decode_packed_reads
 from permutect_amd.data.datum import Data, Datum
 from permutect_amd.engine import lib as L
 from permutect_amd.parameters import P0_DIMS, p0_params, t0_params
-from tests.helpers import GOLDEN, load_case
+from tests.helpers import GOLDEN, config_for, load_case
 
 CPU = torch.device("cpu")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -40,9 +41,36 @@ def test_dropout_model_keeps_the_reference_state_dict_layout():
     assert list(model.state_dict().keys()) == list(sd.keys())
     assert list(sd.keys()) != list(ArtifactModel(p0_params(), device=CPU, **P0_DIMS).state_dict().keys())  # (the indices do shift)
     model.load_state_dict(sd)  # strict
+
+
+def test_batchnorm_model_keeps_the_reference_state_dict_layout_and_trains_nowhere():
+    """reference architecture/mlp.py:52-53: with batch_normalize an nn.BatchNorm1d sits in front of every Linear of the four MLPs
+    (p0_batchnorm_eval.npz: a reference model built that way, running statistics away from (0, 1)).  The modules exist so that
+    the checkpoint loads key for key; eval mode is folded into the Linears (tests/test_forward_gpu.py runs it), training with
+    batch statistics is refused."""
+    z, sd, b = load_case("p0_batchnorm_eval")
+    params = p0_params()
     params.batch_normalize = True
+    model = ArtifactModel(params, device=CPU, **P0_DIMS)
+    assert list(model.state_dict().keys()) == list(sd.keys())
+    for k in sd:
+        assert tuple(model.state_dict()[k].shape) == tuple(sd[k].shape), k
+    model.load_state_dict(sd)  # strict
+    assert sum(isinstance(m, torch.nn.BatchNorm1d) for m in model.modules()) == 20
+    model.train(True)
     with pytest.raises(NotImplementedError, match="batch_normalize"):
-        ArtifactModel(params, device=CPU, **P0_DIMS)
+        model.compute_batch_output(Batch.from_arrays(b["int_array"], b["float_array"], b["packed_reads"]))
+
+
+def test_oracle_eval_mode_of_a_batchnorm_model_matches_the_reference_outputs():
+    z, sd, b = load_case("p0_batchnorm_eval")
+    cfg = config_for("p0_batchnorm_eval")
+    cfg.batch_normalize = True
+    with torch.no_grad():
+        out = O.compute_batch_output(sd, cfg, b["reads_re"], b["nref"], b["nalt"], b["info_be"], b["haplotypes_bh"])
+    for k in ("logits_b", "features_be", "ref_features_be"):
+        ref = z["out/" + k]
+        np.testing.assert_allclose(out[k].numpy(), ref, rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(ref).max())), err_msg=k)
 
 
 def test_p0_parameter_count():
