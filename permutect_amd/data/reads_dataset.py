@@ -16,7 +16,6 @@ batches do not straddle chunks (the reference's DataLoader lets the last batch o
 """
 from __future__ import annotations
 
-import ctypes as C
 import os
 from typing import Iterator, List, Optional
 
@@ -545,7 +544,7 @@ class DeviceChunkLoader:
         cuda = self.device.type == "cuda"
         compose = torch.cuda.Stream(self.device) if cuda else None
         old_interval = sys.getswitchinterval()
-        sys.setswitchinterval(min(old_interval, 5e-4))
+        sys.setswitchinterval(min(old_interval, float(os.environ.get("PMT_LOADER_SWITCH_INTERVAL", "5e-4"))))
 
         def composed(chunk, ids_host, ids_dev, plan, ready_made=None):
             if not cuda:

@@ -17,10 +17,8 @@ parallel reduction.  A learning-rate change re-captures.
 """
 from __future__ import annotations
 
-import ctypes as C
 from typing import Optional
 
-import numpy as np
 import torch
 
 from permutect_amd.data.batch import Batch

@@ -22,7 +22,7 @@ from permutect_amd.training.balancer import Balancer
 from permutect_amd.training.distributed import BucketedGradAllReduce, rank0_decides
 from permutect_amd.training.downsampler import Downsampler
 from permutect_amd.training.loss_recorder import PRIMARY, LossRecorder, collect_evaluation_data
-from permutect_amd.training.optimizer import FusedClipAdamW, backpropagate
+from permutect_amd.training.optimizer import FusedClipAdamW, backpropagate  # noqa: F401  (backpropagate: re-exported, reference misc_utils.py:125)
 
 
 class PlateauScheduler:

@@ -4,7 +4,6 @@ Launched by torch.distributed.run; writes each rank's parameters and history for
 import os
 import sys
 
-import numpy as np
 import torch
 import torch.distributed as dist
 
