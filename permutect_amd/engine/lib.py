@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_HERE, "libpermutect_amd.so")
+LIB_PATH = os.environ.get("PMT_LIB", os.path.join(_HERE, "libpermutect_amd.so"))  # (PMT_LIB: development builds for A/B runs)
 
 # ---- limits (must match the header) -------------------------------------------------------------------------------
 ABI_VERSION = 7
