@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PMT_ABI_VERSION 7
+#define PMT_ABI_VERSION 8
 
 /* error codes */
 #define PMT_OK 0
@@ -462,6 +462,12 @@ int pmt_compose_batch(const int16_t* chunk_ints, int32_t int_cols, const void* c
                       const int64_t* chunk_row_start, const int64_t* ids, int32_t num_variants, int32_t ref_col, int32_t alt_col,
                       int64_t* int_tensor, float* float_tensor, int64_t* row_start, int32_t* ref_offsets, int32_t* alt_offsets,
                       int64_t* read_index, void* stream);
+/* pmt_compose_batch with the scans of the counts supplied (device copies of pmt_prepare_chunk's `offsets` rows): one launch. */
+int pmt_compose_batch_planned(const int16_t* chunk_ints, int32_t int_cols, const void* chunk_floats_f16, int32_t float_cols,
+                              const int64_t* chunk_row_start, const int64_t* ids, int32_t num_variants,
+                              const int32_t* ref_offsets, const int32_t* alt_offsets, int64_t* int_tensor, float* float_tensor,
+                              int64_t* row_start, int64_t* read_index, void* stream);
+
 int pmt_host_copy(void* dst, const void* src, size_t bytes, int32_t threads);
 /* The same for `rows` rows of `row_bytes` bytes with bytes [zero_offset, zero_offset + zero_bytes) of every row cleared in the
  * same pass: the integer rows of the posterior hand-off (reference tools/filter_variants.py:305-308: the datum's own integer
@@ -480,7 +486,9 @@ int pmt_host_copy_rows(void* dst, const void* src, int64_t rows, int64_t row_byt
  * pmt_plan_groups_split); PMT_E_WORKSPACE if `plans` is too small (2 * (n + batches) ints always suffice). */
 int pmt_prepare_chunk(const int16_t* ints, int64_t row_stride, int32_t ref_col, int32_t alt_col, int32_t n, int32_t shuffle,
                       uint64_t seed, int32_t batch, int32_t window, int32_t threads, int32_t* ref_host, int32_t* alt_host,
-                      int64_t* ids, int32_t* plans, int64_t plans_capacity, int32_t* batch_info);
+                      int64_t* ids, int32_t* plans, int64_t plans_capacity, int32_t* batch_info, int32_t* offsets);
+/* (offsets: optional, host, [batches][2][batch + 1]: per batch the exclusive scans of its ref counts and of its alt counts in its
+ *  consumption order -- what pmt_compose_batch_planned takes, so that composing a batch on the device is one launch) */
 
 /* Fused read-set forward: decode -> read MLP -> concat -> L gated ref/alt blocks -> reducer -> rotation ->
  * clustering head + per-set sums.  Replaces ArtifactModel.calculate_features + FeatureClustering.calculate_logits

@@ -305,7 +305,7 @@ static inline uint64_t splitmix64(uint64_t& x) {
 }
 extern "C" int pmt_prepare_chunk(const int16_t* ints, int64_t row_stride, int32_t ref_col, int32_t alt_col, int32_t n, int32_t shuffle,
                                  uint64_t seed, int32_t batch, int32_t window, int32_t threads, int32_t* ref_host, int32_t* alt_host,
-                                 int64_t* ids, int32_t* plans, int64_t plans_capacity, int32_t* batch_info) {
+                                 int64_t* ids, int32_t* plans, int64_t plans_capacity, int32_t* batch_info, int32_t* offsets) {
     if (!ints || !ref_host || !alt_host || !ids || !plans || !batch_info || n < 0 || batch < 1 || window < 1 || row_stride < 1) return PMT_E_INVALID;
     const int nb = (n + batch - 1) / batch;
     if (threads < 1) threads = 1;
@@ -373,6 +373,13 @@ extern "C" int pmt_prepare_chunk(const int16_t* ints, int64_t row_stride, int32_
         int32_t bad = -1;
         groups[k] = pmt_plan_groups(r.data(), a.data(), m, gs, gs + batch + 1, &bad);  // >= 0: the number of groups
         batch_info[4 * k + 3] = (int32_t)reads;
+        if (offsets != nullptr) {  // the exclusive scans of the batch's counts, in its consumption order (pmt_compose_batch_planned)
+            int32_t* ro = offsets + (size_t)k * 2 * ((size_t)batch + 1);
+            int32_t* ao = ro + batch + 1;
+            int32_t rs = 0, as = 0;
+            for (int i = 0; i < m; ++i) { ro[i] = rs; ao[i] = as; rs += r[i]; as += a[i]; }
+            ro[m] = rs; ao[m] = as;
+        }
     });
     int64_t at = 0;
     for (int k = 0; k < nb; ++k) {
@@ -757,6 +764,47 @@ __global__ __launch_bounds__(256) void pmt_gather_rows_kernel(const short* __res
     const _Float16* fp = floats + (size_t)src * float_cols;
     for (int c = lane; c < float_cols; c += 64) floats_out[(size_t)b * float_cols + c] = (float)fp[c];
     if (lane == 0) row_start_out[b] = row_start[src];
+}
+
+// The same with the exclusive scans of the counts already known (pmt_prepare_chunk computes them on the host, beside the group
+// plan): ONE launch per batch -- a 64-lane slice per variant gathers its two table rows AND writes its entries of the read index --
+// where pmt_compose_batch needs five (gather, three for the scans, one workgroup per variant for the index).  Composition runs
+// beside the consumer's read-set kernels, which leave it only the slots their retiring workgroups free: every launch less counts.
+__global__ __launch_bounds__(256) void pmt_compose_planned_kernel(const short* __restrict__ ints, int int_cols, const _Float16* __restrict__ floats,
+                                                                  int float_cols, const long long* __restrict__ row_start,
+                                                                  const long long* __restrict__ ids, int n, const int* __restrict__ ref_off,
+                                                                  const int* __restrict__ alt_off, long long* __restrict__ ints_out,
+                                                                  float* __restrict__ floats_out, long long* __restrict__ row_start_out,
+                                                                  long long* __restrict__ index) {
+    const int rows_per_block = 256 / 64, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * rows_per_block + (threadIdx.x >> 6);
+    if (b >= n) return;
+    const long long src = ids[b];
+    const long long start = row_start[src];
+    const int r0 = ref_off[b], nr = ref_off[b + 1] - r0, a0 = alt_off[b], na = alt_off[b + 1] - a0;
+    const long long total_ref = ref_off[n];
+    const short* ip = ints + (size_t)src * int_cols;
+    for (int c = lane; c < int_cols; c += 64) ints_out[(size_t)b * int_cols + c] = (long long)ip[c];
+    const _Float16* fp = floats + (size_t)src * float_cols;
+    for (int c = lane; c < float_cols; c += 64) floats_out[(size_t)b * float_cols + c] = (float)fp[c];
+    for (int i = lane; i < nr; i += 64) index[r0 + i] = start + i;
+    for (int i = lane; i < na; i += 64) index[total_ref + a0 + i] = start + nr + i;
+    if (lane == 0) row_start_out[b] = start;
+}
+
+extern "C" int pmt_compose_batch_planned(const int16_t* chunk_ints, int32_t int_cols, const void* chunk_floats_f16, int32_t float_cols,
+                                         const int64_t* chunk_row_start, const int64_t* ids, int32_t num_variants,
+                                         const int32_t* ref_offsets, const int32_t* alt_offsets, int64_t* int_tensor, float* float_tensor,
+                                         int64_t* row_start, int64_t* read_index, void* stream) {
+    if (!chunk_ints || !chunk_floats_f16 || !chunk_row_start || !ids || !int_tensor || !float_tensor || !row_start || !ref_offsets ||
+        !alt_offsets || !read_index || num_variants < 0 || int_cols < 2 || float_cols < 1)
+        return PMT_E_INVALID;
+    if (num_variants == 0) return PMT_OK;
+    hipLaunchKernelGGL(pmt_compose_planned_kernel, dim3((num_variants + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       (const short*)chunk_ints, int_cols, (const _Float16*)chunk_floats_f16, float_cols, (const long long*)chunk_row_start,
+                       (const long long*)ids, num_variants, ref_offsets, alt_offsets, (long long*)int_tensor, float_tensor, (long long*)row_start,
+                       (long long*)read_index);
+    return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }
 
 extern "C" int pmt_compose_batch(const int16_t* chunk_ints, int32_t int_cols, const void* chunk_floats_f16, int32_t float_cols,

@@ -279,6 +279,8 @@ class DeviceChunk:
 
         if dataset._pinned is not None and cuda:  # page-locked dataset: DMA straight from it
             ints_t, floats_t, reads_t, starts_t = dataset._pinned
+            # (the read rows on a second stream -- two copy engines on one chunk -- was measured: no change, 1.00 - 1.07 ms per filter
+            #  batch either way; the copies are not what a second engine would speed up)
             self.ints = ints_t[lo:hi].to(device, non_blocking=True)
             self.floats = floats_t[lo:hi].to(device, non_blocking=True)
             self.reads = reads_t[r0:r1].to(device, non_blocking=True)
@@ -333,13 +335,22 @@ class ChunkBatch(Batch):
             self._read_index = None
 
     @staticmethod
-    def compose_on_device(chunk: DeviceChunk, ids_dev: torch.Tensor, total_reads: int):
+    def compose_on_device(chunk: DeviceChunk, ids_dev: torch.Tensor, total_reads: int, offsets=None):
         """The batch's device tensors in ONE library call (pmt_compose_batch: gather + convert, count scans, read index) on the
-        current stream; no host synchronisation, and the GIL is released for the duration of the call."""
+        current stream; no host synchronisation, and the GIL is released for the duration of the call.  With the scans of the
+        counts already on the device (`offsets`, from pmt_prepare_chunk) the call is ONE launch (pmt_compose_batch_planned)."""
         dev, n = chunk.ints.device, ids_dev.numel()
         ints = torch.empty(n, chunk.ints.shape[1], dtype=torch.long, device=dev)
         floats = torch.empty(n, chunk.floats.shape[1], dtype=torch.float32, device=dev)
         row_start = torch.empty(n, dtype=torch.long, device=dev)
+        if offsets is not None:
+            ref_off, alt_off = offsets
+            index = torch.empty(total_reads, dtype=torch.int64, device=dev)
+            L.check(L.load().pmt_compose_batch_planned(chunk.ints.data_ptr(), chunk.ints.shape[1], chunk.floats.data_ptr(), chunk.floats.shape[1],
+                                                       chunk.row_start.data_ptr(), ids_dev.data_ptr(), n, ref_off.data_ptr(), alt_off.data_ptr(),
+                                                       ints.data_ptr(), floats.data_ptr(), row_start.data_ptr(), index.data_ptr(),
+                                                       torch.cuda.current_stream(dev).cuda_stream), "pmt_compose_batch_planned")
+            return ints, floats, row_start, ref_off, alt_off, index
         ref_off = torch.empty(n + 1, dtype=torch.int32, device=dev)
         alt_off = torch.empty(n + 1, dtype=torch.int32, device=dev)
         index = torch.empty(total_reads, dtype=torch.int64, device=dev)
@@ -410,6 +421,7 @@ class DeviceChunkLoader:
             self.ranges = [(first_lo, first_lo + batch_size), (first_lo + batch_size, first_hi)] + self.ranges[1:]
         self.bytes_uploaded = 0
         self._stages = None  # borrowed from _STAGES while iterating: one PinnedStage per chunk in flight
+        self._slot_events = [None] * _PREFETCH  # per staging slot: the event behind the last chunk enqueued out of it
 
     def __len__(self) -> int:
         return sum(-(-(hi - lo) // self.batch_size) for lo, hi in self.ranges)
@@ -430,15 +442,18 @@ class DeviceChunkLoader:
         flat = host.numpy()
         ref_host, alt_host = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32)
         info = np.zeros((nb, 4), dtype=np.int32)
+        # per batch the exclusive scans of its counts (ref | alt, bs + 1 each): composing a batch on the device is then ONE launch
+        offs = (stage.get("offsets", (nb, 2, bs + 1), torch.int32) if dev.type == "cuda" else torch.empty((nb, 2, bs + 1), dtype=torch.int32))
         rc = L.load().pmt_prepare_chunk(ints[chunk.lo:].ctypes.data, ints.strides[0] // 2, Data.REF_COUNT.idx, Data.ALT_COUNT.idx, n,
                                         1 if self.shuffle else 0, seed & 0xFFFFFFFFFFFFFFFF, bs, 64, 8, ref_host.ctypes.data, alt_host.ctypes.data,
-                                        flat.ctypes.data, flat[2 * n:].ctypes.data, cap, info.ctypes.data)
+                                        flat.ctypes.data, flat[2 * n:].ctypes.data, cap, info.ctypes.data, offs.data_ptr())
         if rc == L.E_CAPACITY:
             return None
         L.check(rc, "pmt_prepare_chunk")
         chunk.ref_host, chunk.alt_host = ref_host, alt_host
         used = 2 * n + int(info[nb - 1, 0]) + 2 * (int(info[nb - 1, 1]) + 1) if nb else 2 * n
         flat_dev = host[:used].to(dev, non_blocking=dev.type == "cuda")
+        offs_dev = offs.to(dev, non_blocking=dev.type == "cuda")
         ids_host = flat[: 2 * n].view(np.int64).copy()  # (the pinned buffer is reused for the next chunk of this slot)
         ids_dev = flat_dev[: 2 * n].view(torch.int64)
         out = []
@@ -448,8 +463,10 @@ class DeviceChunkLoader:
             plan = GroupPlan.from_prepared(gs_h, gt_h, {str(dev): (flat_dev[at:at + g + 1], flat_dev[at + g + 1:at + 2 * g + 2], None)})
             plan.total_reads = int(info[k, 3])
             m = min(bs, n - k * bs)
+            plan.offsets_dev = (offs_dev[k, 0, :m + 1], offs_dev[k, 1, :m + 1])
             out.append((ids_host[k * bs:k * bs + m], ids_dev[k * bs:k * bs + m], plan))
         chunk.plans_dev = flat_dev
+        chunk.offsets_dev = offs_dev
         return out
 
     def _prepare(self, chunk: DeviceChunk, ids: np.ndarray, stage: PinnedStage):
@@ -490,9 +507,15 @@ class DeviceChunkLoader:
         return out
 
     def _load(self, c: int, seed: int, slot: int):
-        """Runs on a prefetch thread: stage and upload chunk c and its batches' ids / plans on a side stream, return when
-        they are resident.  `slot` names the staging buffers (free again once the chunk that used them last was returned)."""
+        """Runs on a prefetch thread: stage chunk c, ENQUEUE its upload, its batches' ids / plans and their composition on a side
+        stream, and return the event behind them -- the consumer's stream waits for that event on the device, its thread never
+        does (it used to block until the chunk was resident and then needed 0.1 - 0.35 ms to wake up and launch while the GPU idled
+        at every chunk boundary).  `slot` names the pinned staging buffers: before they are written again, this thread waits for
+        the event of the chunk that used them last."""
         stage = self._stages[slot]
+        last = self._slot_events[slot]
+        if last is not None:
+            last.synchronize()  # (the copies out of this slot's buffers have left)
         lo, hi = self.ranges[c]
         n = hi - lo
 
@@ -504,7 +527,7 @@ class DeviceChunkLoader:
             return self._prepare(chunk, ids, stage)
         if self.device.type != "cuda":
             chunk = DeviceChunk(self.dataset, lo, hi, self.device)
-            return chunk, prepare(chunk)
+            return chunk, prepare(chunk), None
         torch.cuda.set_device(self.device)
         # (a HIGH-priority stream for the chunk's copies and composition kernels was measured SLOWER: 1.09 - 1.12 against 1.01 - 1.05 ms
         #  per filter batch -- its kernels then displace the consumer's read-set kernels instead of filling their tails)
@@ -522,14 +545,15 @@ class DeviceChunkLoader:
                 if total is None:
                     rc, ac = chunk.host_counts()
                     total = int(rc[ids_host].sum()) + int(ac[ids_host].sum())
-                composed.append(ChunkBatch.compose_on_device(chunk, ids_dev, total))
+                composed.append(ChunkBatch.compose_on_device(chunk, ids_dev, total, getattr(plan, "offsets_dev", None)))
             batches = [b + (c,) for b, c in zip(batches, composed)]
+            done = torch.cuda.Event()
+            done.record(side)
+        self._slot_events[slot] = done
         t2 = time.perf_counter()
-        side.synchronize()
-        t3 = time.perf_counter()
         if os.environ.get("PMT_LOADER_TIMING"):
-            print(f"[loader] chunk {c}: stage+enqueue {1e3 * (t1 - t0):.1f} ms, prepare {1e3 * (t2 - t1):.1f} ms, wait {1e3 * (t3 - t2):.1f} ms", flush=True)
-        return chunk, batches
+            print(f"[loader] chunk {c}: stage+enqueue {1e3 * (t1 - t0):.1f} ms, prepare + compose enqueued {1e3 * (t2 - t1):.1f} ms", flush=True)
+        return chunk, batches, done
 
     def __iter__(self) -> Iterator[ChunkBatch]:
         """One chunk is trained on while the next ones are read, staged and uploaded by background threads."""
@@ -583,14 +607,17 @@ class DeviceChunkLoader:
                     submit(i)
                 ahead = None
                 for i in range(len(order_c)):
-                    chunk, batches = pending.popleft().result()
+                    chunk, batches, done = pending.popleft().result()
                     submit(i + _PREFETCH)
                     self.bytes_uploaded += chunk.nbytes
                     if cuda:
+                        torch.cuda.current_stream(self.device).wait_event(done)  # the chunk and its composed batches, on the device
+                        compose.wait_event(done)
                         # the chunk was allocated on the prefetch thread's side stream and is consumed on THIS stream: tell the
                         # allocator, or a chunk dropped while its last batch's kernels are still queued could be handed out again
                         cur = torch.cuda.current_stream(self.device)
-                        for t in (chunk.ints, chunk.floats, chunk.reads, chunk.row_start, getattr(chunk, "plans_dev", None)):
+                        for t in (chunk.ints, chunk.floats, chunk.reads, chunk.row_start, getattr(chunk, "plans_dev", None),
+                                  getattr(chunk, "offsets_dev", None)):
                             if t is not None:
                                 t.record_stream(cur)
                                 t.record_stream(compose)
@@ -601,7 +628,11 @@ class DeviceChunkLoader:
                         ahead = nxt
                 if ahead is not None:
                     yield ready(ahead)
-        finally:  # (the executor has joined its threads: no copy out of these buffers is left in flight)
+        finally:  # (the executor has joined its threads; wait for the copies they enqueued out of the staging buffers)
+            for ev in self._slot_events:
+                if ev is not None:
+                    ev.synchronize()
+            self._slot_events = [None] * _PREFETCH
             sys.setswitchinterval(old_interval)
             stages, self._stages = self._stages, None
             _STAGES.release(stages)

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("PMT_LIB", os.path.join(_HERE, "libpermutect_amd.so"))  # (PMT_LIB: development builds for A/B runs)
 
 # ---- limits (must match the header) -------------------------------------------------------------------------------
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_WIDTH, MAX_HALF_FFN, MAX_CLUSTERS = 64, 16, 16
 MAX_ROW_INPUT = 128
 MAX_CNN_TAPS = 192
@@ -157,7 +157,7 @@ EXPORTS = ["pmt_abi_version", "pmt_struct_bytes", "pmt_model_check", "pmt_plan_g
            "pmt_phi_forward", "pmt_phi_backward", "pmt_build_read_index", "pmt_losses_forward", "pmt_losses_backward",
            "pmt_downsample_counts", "pmt_downsample_index", "pmt_record_losses",
            "pmt_plan_groups_split", "pmt_layered_scratch_floats", "pmt_forward_layered",
-           "pmt_layered_backward_scratch_floats", "pmt_backward_layered", "pmt_host_copy", "pmt_pack_order", "pmt_pack_order_batches", "pmt_prepare_chunk", "pmt_host_copy_rows", "pmt_compose_batch"]
+           "pmt_layered_backward_scratch_floats", "pmt_backward_layered", "pmt_host_copy", "pmt_pack_order", "pmt_pack_order_batches", "pmt_prepare_chunk", "pmt_host_copy_rows", "pmt_compose_batch", "pmt_compose_batch_planned"]
 
 _lib = None
 
@@ -214,9 +214,10 @@ def load() -> C.CDLL:
     lib.pmt_host_copy.argtypes = [vp, vp, C.c_size_t, i32]
     lib.pmt_host_copy_rows.argtypes = [vp, vp, i64, i64, i64, i64, i32]
     lib.pmt_compose_batch.argtypes = [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.pmt_compose_batch_planned.argtypes = [vp, i32, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
     lib.pmt_pack_order.argtypes = [vp, vp, i32, i32, vp]
     lib.pmt_pack_order_batches.argtypes = [vp, vp, i32, i32, i32, i32, vp]
-    lib.pmt_prepare_chunk.argtypes = [vp, i64, i32, i32, i32, i32, C.c_uint64, i32, i32, i32, vp, vp, vp, vp, i64, vp]
+    lib.pmt_prepare_chunk.argtypes = [vp, i64, i32, i32, i32, i32, C.c_uint64, i32, i32, i32, vp, vp, vp, vp, i64, vp, vp]
     lib.pmt_layered_backward_scratch_floats.argtypes = [P(PmtModel), i64, i32]
     lib.pmt_layered_backward_scratch_floats.restype = C.c_size_t
     lib.pmt_backward_layered.argtypes = [P(PmtModel), vp, vp, vp, vp, P(PmtBatch), P(PmtOutputs), P(PmtOutputGrads), vp, vp, vp,
