@@ -110,17 +110,26 @@ class Downsampler(nn.Module):
             p.requires_grad_(True)
         optimizer = torch.optim.AdamW([p for p in self.parameters() if p.requires_grad])
         counts_slvra = counts_slvra.to(device=params[0].device, dtype=params[0].dtype)
-        for _ in range(steps):
-            expected = self.calculate_expected_downsampled_counts(counts_slvra)
-            total = torch.sum(expected, dim=(-2, -1), keepdim=True)
-            # a (source, label, variant type) cell without any data: the reference divides 0 / 0 there and every weight turns
-            # NaN; here such a cell contributes nothing (its weights only see the weight decay).  Cells with data are
-            # independent terms of the loss, so wherever the reference's result is finite this is the same fit.
-            normalized = expected / torch.where(total > 0, total, torch.ones_like(total))
-            loss = torch.sum(torch.sum(torch.square(normalized), dim=(-2, -1)))
-            optimizer.zero_grad(set_to_none=True)
-            loss.backward()
-            optimizer.step()
+        # 10 000 steps over tensors of a few thousand elements: on a many-core host torch's default intra-op pool (one thread per
+        # hardware thread, 256 on the MI355X hosts, of which a job may own 16) turns every small op into a thread rendezvous --
+        # 12 ms per step there against 1.5 ms with a handful of threads (two minutes of every training run's start-up)
+        threads = torch.get_num_threads()
+        if params[0].device.type == "cpu":
+            torch.set_num_threads(min(threads, 4))
+        try:
+            for _ in range(steps):
+                expected = self.calculate_expected_downsampled_counts(counts_slvra)
+                total = torch.sum(expected, dim=(-2, -1), keepdim=True)
+                # a (source, label, variant type) cell without any data: the reference divides 0 / 0 there and every weight turns
+                # NaN; here such a cell contributes nothing (its weights only see the weight decay).  Cells with data are
+                # independent terms of the loss, so wherever the reference's result is finite this is the same fit.
+                normalized = expected / torch.where(total > 0, total, torch.ones_like(total))
+                loss = torch.sum(torch.sum(torch.square(normalized), dim=(-2, -1)))
+                optimizer.zero_grad(set_to_none=True)
+                loss.backward()
+                optimizer.step()
+        finally:
+            torch.set_num_threads(threads)
         for p in params:
             p.requires_grad_(False)
 
