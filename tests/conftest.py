@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the oracle is PyTorch on the CPU: on a many-core host its default intra-op pool (one thread per hardware thread: 256 on the
+    # MI355X hosts, where a job owns 16) is oversubscribed several times over and every small op becomes a thread rendezvous
+    import torch
+    torch.set_num_threads(min(torch.get_num_threads(), 16))
 
 
 @pytest.fixture(scope="session")
