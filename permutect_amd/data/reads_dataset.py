@@ -534,8 +534,11 @@ class DeviceChunkLoader:
         side = torch.cuda.Stream(self.device)
         import time
         t0 = time.perf_counter()
+        # (every chunk's upload on ONE stream shared by the prefetch threads -- scripts/h2d_rate.py shows copies from several streams
+        #  sharing the link badly beside a busy GPU -- was measured: no change, 1.01 - 1.08 ms per filter batch either way)
         with torch.cuda.stream(side):
             chunk = DeviceChunk(self.dataset, lo, hi, self.device, stage)
+        with torch.cuda.stream(side):
             t1 = time.perf_counter()
             batches = prepare(chunk)
             # ... and every batch of the chunk composed right here, on this thread's stream, behind the upload
