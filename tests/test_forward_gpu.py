@@ -67,8 +67,9 @@ def check_outputs(out, z, name, lk_ulps=8):
     assert np.all(logit_err <= tol_b), (name, float((logit_err / tol_b).max()))
     # every summed log-likelihood on ITS OWN scale: 2e-5 + 8 ulp of that element (a cluster's 5.0 next to another's 2000.0 is
     # held to 2e-5, not to 2e-5 of the batch maximum)
-    # (sums over several hundred reads carry ~sqrt(N) ulp of rounding in ANY summation order, the oracle's included: the
-    #  tests with 300-700-read sets pass lk_ulps = 16)
+    # (sums over several hundred reads carry ~sqrt(N) ulp of rounding in ANY summation order, the oracle's included, and the
+    #  kernels' per-set sums are float atomics whose order changes from run to run: the tests with 300 - 700-read sets pass
+    #  lk_ulps = 32 -- sqrt(600) = 24; measured over a dozen runs: up to 14 ulp -- the 110-read fixture 16)
     lk_tol = 2e-5 + lk_ulps * np.spacing(np.abs(ref_lk).astype(np.float32))
     assert np.all(np.abs(lk - ref_lk) <= lk_tol), (name, float((np.abs(lk - ref_lk) / lk_tol).max()))
     big = mag >= 256.0
@@ -243,7 +244,7 @@ def test_read_sets_beyond_one_workgroup_run_layered_and_match_oracle():
                                      torch.from_numpy(nref), torch.from_numpy(nalt),
                                      torch.from_numpy(floats[:, 6:].astype(np.float32)), torch.from_numpy(ints[:, 16:].astype(np.int64)))
     z = {"out/" + k: v.numpy() for k, v in ref.items()}
-    check_outputs(out, z, "p0_deep", lk_ulps=16)
+    check_outputs(out, z, "p0_deep", lk_ulps=32)
 
 
 def test_layered_forward_equals_the_single_launch_forward():

@@ -64,7 +64,7 @@ def test_joined_training_step_matches_oracle_and_the_layered_launches():
               nalt=i64[:, O.ALT_COUNT], labels=i64[:, O.LABEL], sources=i64[:, O.SOURCE],
               info_be=torch.from_numpy(floats[:, O.INFO_START:].astype(np.float32)), haplotypes_bh=i64[:, O.HAPLOTYPES_START:])
     ref_out, ref_losses, ref_grads = O.train_step_grads(sd, cfg, ob)
-    check_outputs(out_j, {"out/" + k: v.detach().numpy() for k, v in ref_out.items()}, "p0_deep", lk_ulps=16)
+    check_outputs(out_j, {"out/" + k: v.detach().numpy() for k, v in ref_out.items()}, "p0_deep", lk_ulps=32)
     ref_total = ref_losses["total_losses_b"].detach().numpy()
     np.testing.assert_allclose(losses_j.total_losses_b.detach().cpu().numpy(), ref_total, rtol=1e-4, atol=1e-4 + 1e-5 * np.abs(ref_total).max())
     gref = np.concatenate([ref_grads[n].numpy().ravel() for n in g_j])
@@ -103,7 +103,7 @@ def test_more_groups_than_resident_workgroups():
     with torch.inference_mode():
         out = joined.compute_batch_output(batch)
     joined.engine().check_join_fault()
-    check_outputs(out, {"out/" + k: v.numpy() for k, v in ref.items()}, "p0_deep", lk_ulps=16)
+    check_outputs(out, {"out/" + k: v.numpy() for k, v in ref.items()}, "p0_deep", lk_ulps=32)
 
 
 def test_joined_path_on_forced_small_groups_matches_reference():
@@ -132,7 +132,7 @@ def test_joined_path_on_forced_small_groups_matches_reference():
     assert plan.set_groups.max() >= 3
     batch._plan = plan
     out, losses, grads = _train_step(model, batch)
-    check_outputs(out, z, "p0_deep", lk_ulps=16)
+    check_outputs(out, z, "p0_deep", lk_ulps=32)
     gref = np.concatenate([z["grad/" + n].ravel() for n in grads])
     gour = np.concatenate([g.ravel() for g in grads.values()])
     assert np.linalg.norm(gour - gref) <= 1e-4 * np.linalg.norm(gref)
