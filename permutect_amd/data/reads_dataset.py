@@ -206,6 +206,45 @@ _PREFETCH = 3  # chunks being loaded while one is consumed: one loader thread (~
                # 114 MB chunk) cannot keep up with the filter forward (~6 ms per chunk of 262 144 variants)
 
 
+class _UploadQueue:
+    """Every host-to-device copy of the loader goes through ONE stream, one copy at a time.  Beside a busy GPU a single stream moves
+    ~50 GB/s from page-locked memory, but copies in flight on several streams at once share the link at 12 - 23 GB/s
+    (scripts/h2d_rate.py) -- and three prefetch threads, each with its own stream and seven copies per chunk, made exactly that
+    traffic: the chunk uploads of a filter pass ran at 26 GB/s and set its pace.  `copy` enqueues on the shared stream and makes
+    the CALLER's current stream wait for the copy (and the allocator know that stream)."""
+
+    def __init__(self):
+        import threading
+        self._lock = threading.Lock()
+        self._streams = {}
+
+    def copy(self, host: torch.Tensor, device: torch.device) -> torch.Tensor:
+        if device.type != "cuda":
+            return host.to(device)
+        cur = torch.cuda.current_stream(device)
+        with self._lock:
+            up = self._streams.get(device)
+            if up is None:
+                up = self._streams[device] = torch.cuda.Stream(device)
+            with torch.cuda.stream(up):
+                out = host.to(device, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(up)
+        cur.wait_event(ev)
+        out.record_stream(cur)
+        return out
+
+
+_UPLOADS = _UploadQueue()
+_ONE_UPLOAD_STREAM = os.environ.get("PMT_LOADER_ONE_UPLOAD_STREAM", "1") != "0"
+
+
+def _h2d(host: torch.Tensor, device: torch.device) -> torch.Tensor:
+    if _ONE_UPLOAD_STREAM:
+        return _UPLOADS.copy(host, device)
+    return host.to(device, non_blocking=device.type == "cuda")
+
+
 class PinnedStage:
     """Pinned staging buffers that live as long as their loader (pinning ~100 MB costs 10 - 70 ms, a chunk upload ~2 ms).
     One buffer per array name, grown with 12 % slack when a chunk needs more.  The user must have finished (synchronised)
@@ -275,16 +314,16 @@ class DeviceChunk:
                 L.check(L.load().pmt_host_copy(host.data_ptr(), arr.ctypes.data, arr.nbytes, _STAGE_THREADS), "pmt_host_copy")
             else:
                 np.copyto(host.numpy(), arr)
-            return host.to(device, non_blocking=cuda)
+            return _h2d(host, device)
 
         if dataset._pinned is not None and cuda:  # page-locked dataset: DMA straight from it
             ints_t, floats_t, reads_t, starts_t = dataset._pinned
             # (the read rows on a second stream -- two copy engines on one chunk -- was measured: no change, 1.00 - 1.07 ms per filter
             #  batch either way; the copies are not what a second engine would speed up)
-            self.ints = ints_t[lo:hi].to(device, non_blocking=True)
-            self.floats = floats_t[lo:hi].to(device, non_blocking=True)
-            self.reads = reads_t[r0:r1].to(device, non_blocking=True)
-            self.row_start = starts_t[lo:hi].to(device, non_blocking=True) - r0
+            self.ints = _h2d(ints_t[lo:hi], device)
+            self.floats = _h2d(floats_t[lo:hi], device)
+            self.reads = _h2d(reads_t[r0:r1], device)
+            self.row_start = _h2d(starts_t[lo:hi], device) - r0
         else:
             self.ints = upload(dataset._ints[lo:hi])                         # int16 [n, 16 + H]
             self.floats = upload(dataset._floats[lo:hi])                     # float16 [n, 6 + I]
@@ -422,6 +461,7 @@ class DeviceChunkLoader:
         self.bytes_uploaded = 0
         self._stages = None  # borrowed from _STAGES while iterating: one PinnedStage per chunk in flight
         self._slot_events = [None] * _PREFETCH  # per staging slot: the event behind the last chunk enqueued out of it
+        self._compose_on_consumer = os.environ.get("PMT_LOADER_COMPOSE", "consumer") != "prefetch"
 
     def __len__(self) -> int:
         return sum(-(-(hi - lo) // self.batch_size) for lo, hi in self.ranges)
@@ -452,8 +492,8 @@ class DeviceChunkLoader:
         L.check(rc, "pmt_prepare_chunk")
         chunk.ref_host, chunk.alt_host = ref_host, alt_host
         used = 2 * n + int(info[nb - 1, 0]) + 2 * (int(info[nb - 1, 1]) + 1) if nb else 2 * n
-        flat_dev = host[:used].to(dev, non_blocking=dev.type == "cuda")
-        offs_dev = offs.to(dev, non_blocking=dev.type == "cuda")
+        flat_dev = _h2d(host[:used], dev)
+        offs_dev = _h2d(offs, dev)
         ids_host = flat[: 2 * n].view(np.int64).copy()  # (the pinned buffer is reused for the next chunk of this slot)
         ids_dev = flat_dev[: 2 * n].view(torch.int64)
         out = []
@@ -488,7 +528,7 @@ class DeviceChunkLoader:
         flat = np.concatenate([ids.astype(np.int64).view(np.int32)] + parts)  # ids first: stays 8-byte aligned
         host = stage.get("plans", flat.shape, torch.int32) if dev.type == "cuda" else torch.empty(flat.shape, dtype=torch.int32)
         host.numpy()[...] = flat
-        flat_dev = host.to(dev, non_blocking=dev.type == "cuda")
+        flat_dev = _h2d(host, dev)
         ids_dev = flat_dev[: 2 * len(ids)].view(torch.int64)
         at = 2 * len(ids)
         out = []
@@ -544,6 +584,9 @@ class DeviceChunkLoader:
             # ... and every batch of the chunk composed right here, on this thread's stream, behind the upload
             composed = []
             for ids_host, ids_dev, plan in batches:
+                if self._compose_on_consumer and getattr(plan, "offsets_dev", None) is not None and getattr(plan, "total_reads", None) is not None:
+                    composed.append(None)  # one launch on the consumer's own stream, in front of the batch's kernels (__iter__)
+                    continue
                 total = getattr(plan, "total_reads", None)
                 if total is None:
                     rc, ac = chunk.host_counts()
@@ -583,6 +626,12 @@ class DeviceChunkLoader:
                 for t in ready_made:
                     t.record_stream(cur)
                 return ChunkBatch(chunk, ids_host, ids_dev, plan, composed=ready_made), None
+            if self._compose_on_consumer and getattr(plan, "offsets_dev", None) is not None and getattr(plan, "total_reads", None) is not None:
+                # ONE launch (pmt_compose_batch_planned) on the consumer's stream: 0.04 ms in front of the batch's own kernels.  Beside
+                # them, on another stream, the same launch cost the read-set forward 0.07 ms: its 3 400 workgroups run in 6.7 rounds
+                # of 512, and workgroups of another kernel that take slots in between push it into one more partial round
+                made = ChunkBatch.compose_on_device(chunk, ids_dev, plan.total_reads, plan.offsets_dev)
+                return ChunkBatch(chunk, ids_host, ids_dev, plan, composed=made), None
             cur = torch.cuda.current_stream(self.device)
             compose.wait_stream(cur)  # (nothing of the consumer's stream may be overtaken by a reuse of freed memory)
             with torch.cuda.stream(compose):
