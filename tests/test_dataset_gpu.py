@@ -38,6 +38,32 @@ def test_device_composed_batch_equals_host_batch():
     assert torch.allclose(a.logits_b, b.logits_b, rtol=1e-5, atol=1e-5) and torch.allclose(a.features_be, b.features_be, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("mode", ["consumer", "prefetch"])
+def test_loader_batches_equal_host_batches_in_every_composition_mode(mode, monkeypatch):
+    """Every batch the device chunk loader hands out -- composed in ONE launch from host-side count scans (pmt_compose_batch_planned),
+    on the consumer's stream (default) or by the prefetch thread -- holds exactly the rows, tables, offsets and gather index of the
+    same variants collated on the host; and the unplanned composition (pmt_compose_batch: scans on the device) gives the same."""
+    monkeypatch.setenv("PMT_LOADER_COMPOSE", mode)
+    dev = torch.device("cuda:0")
+    ds = _dataset()
+    seen = 0
+    for cb in ds.device_loader(batch_size=16, device=dev, chunk_variants=24, rng=np.random.default_rng(9), shuffle=True):
+        hb = ds.host_batch(cb.dataset_index).copy_to(dev)
+        np.testing.assert_array_equal(cb._chunk.reads[cb.read_index()].cpu().numpy(), hb.packed_reads.cpu().numpy())
+        np.testing.assert_array_equal(cb.int_tensor.cpu().numpy(), hb.int_tensor.cpu().numpy())
+        np.testing.assert_allclose(cb.float_tensor.cpu().numpy(), hb.float_tensor.cpu().numpy(), rtol=0, atol=0)
+        nref, nalt = hb.host_counts()
+        ref_off, alt_off = cb._offsets
+        np.testing.assert_array_equal(ref_off.cpu().numpy(), np.concatenate([[0], np.cumsum(nref)]))
+        np.testing.assert_array_equal(alt_off.cpu().numpy(), np.concatenate([[0], np.cumsum(nalt)]))
+        # the same batch composed with the scans made on the device
+        plain = ChunkBatch.compose_on_device(cb._chunk, cb.chunk_ids, int(nref.sum() + nalt.sum()))
+        for a, b in zip(plain, (cb.int_tensor, cb.float_tensor, cb._row_start, ref_off, alt_off, cb.read_index())):
+            assert torch.equal(a, b)
+        seen += cb.size()
+    assert seen == len(ds)
+
+
 def test_device_loader_and_downsampling_compose():
     dev = torch.device("cuda:0")
     ds = _dataset()
