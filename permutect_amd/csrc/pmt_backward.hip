@@ -368,7 +368,7 @@ DEV void backward_group(
         linear_wgrad<NTE, NTE, BFB>(c, R, da, e);
         f4 de[PMT_RT][NTE];
         init_bias<NTE>(de, nullptr, E, g);
-        if constexpr (S::BF16) linear_acc_bf16<NTE, NTE, false, BFB>(de, da, packed + uniform(R.wtb_frag));
+        if constexpr (S::BF16) linear_acc_bf16<NTE, NTE, false, PMT_DG(BFB)>(de, da, packed + uniform(R.wtb_frag));
         else linear_acc<NTE, NTE, false, EX, S::DIM_E>(de, da, packed + uniform(R.wt_frag), E, E);
         f4 dt[NTE];
 #pragma unroll
@@ -464,7 +464,7 @@ DEV void backward_group(
                 const f4 b0 = load_pvec(packed + uniform(P1.b_pvec), 0, g), b1 = load_pvec(packed + uniform(P1.b_pvec), 1, g);
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt) { z[rt][0] = b0; z[rt][1] = b1; }
-                if constexpr (S::BF16) linear_acc_bf16<NTD, 2, false, BFB>(z, n, packed + uniform(P1.wb_frag));
+                if constexpr (S::BF16) linear_acc_bf16<NTD, 2, false, PMT_RC(BFB)>(z, n, packed + uniform(P1.wb_frag));
                 else linear_acc<NTD, 2, false, EX, S::DIM_D>(z, n, packed + uniform(P1.w_frag), D, 16 + h);
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt) {
@@ -501,7 +501,7 @@ DEV void backward_group(
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt) du[rt][0] = f4{0.f, 0.f, 0.f, 0.f};
         if (first_half) {
-            if constexpr (S::BF16) linear_acc_bf16<NTD, 1, false, BFB>(du, dy, packed + uniform(P2.wtb_frag));
+            if constexpr (S::BF16) linear_acc_bf16<NTD, 1, false, PMT_DG(BFB)>(du, dy, packed + uniform(P2.wtb_frag));
             else linear_acc<NTD, 1, false, EX, S::DIM_D>(du, dy, packed + uniform(P2.wt_frag), D, h);
         }
         if (first_half) {
@@ -672,7 +672,7 @@ DEV void backward_group(
         {
             f4 dn[PMT_RT][NTD];
             init_bias<NTD>(dn, nullptr, D, g);
-            if constexpr (S::BF16) linear_acc_bf16<2, NTD, false, BFB>(dn, dz, packed + uniform(P1.wtb_frag));
+            if constexpr (S::BF16) linear_acc_bf16<2, NTD, false, PMT_DG(BFB)>(dn, dz, packed + uniform(P1.wtb_frag));
             else linear_acc<2, NTD, false, EX, 0, S::DIM_H>(dn, dz, packed + uniform(P1.wt_frag), 16 + h, D);
             f4 lw[NTD], dlw[NTD], dlb[NTD];
 #pragma unroll

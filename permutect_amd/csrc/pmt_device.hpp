@@ -367,6 +367,9 @@ DEV void split_kblock(const f4 (&in)[PMT_RT][NTI], int kb, float in_scale, bf8 (
         if constexpr (PIECES >= 3) bl[rt] = __builtin_bit_cast(bf8, l);
     }
 }
+#ifndef PMT_TWO_PIECE_MFMAS
+#define PMT_TWO_PIECE_MFMAS 3  // MFMAs of a product with two-piece activations: 5 (all but a_hi b_lo) or 3 (first order only)
+#endif
 #ifndef PMT_FRAG_AHEAD
 #define PMT_FRAG_AHEAD 0  // the forward (4 waves per SIMD hide the latency; no registers to spare): 1.15 ms -> 1.18 with 1
 #endif
@@ -406,17 +409,20 @@ DEV void linear_acc_bf16(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], co
                 const bf8 am = q[step % (AH + 1)][NP > 1 ? 1 : 0], al = q[step % (AH + 1)][NP > 2 ? 2 : 0];
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt) {  // smallest terms first
+                    // (two-piece activations drop the a_hi b_lo term, 2^-16 of the product: with PMT_TWO_PIECE_MFMAS = 3 the two
+                    //  other terms of that order, a_lo b_hi and a_mid b_mid, go as well -- three MFMAs, the same error order)
+                    constexpr bool SECOND_ORDER = PIECES == 3 || PMT_TWO_PIECE_MFMAS != 3;
                     if (half_block) {
-                        acc[rt][mt] = mfma_bf16_k16(al, bh[rt], acc[rt][mt]);
+                        if constexpr (SECOND_ORDER) acc[rt][mt] = mfma_bf16_k16(al, bh[rt], acc[rt][mt]);
                         if constexpr (PIECES == 3) acc[rt][mt] = mfma_bf16_k16(ah, bl[rt], acc[rt][mt]);
-                        acc[rt][mt] = mfma_bf16_k16(am, bm[rt], acc[rt][mt]);
+                        if constexpr (SECOND_ORDER) acc[rt][mt] = mfma_bf16_k16(am, bm[rt], acc[rt][mt]);
                         acc[rt][mt] = mfma_bf16_k16(am, bh[rt], acc[rt][mt]);
                         acc[rt][mt] = mfma_bf16_k16(ah, bm[rt], acc[rt][mt]);
                         acc[rt][mt] = mfma_bf16_k16(ah, bh[rt], acc[rt][mt]);
                     } else {
-                        acc[rt][mt] = mfma_bf16(al, bh[rt], acc[rt][mt]);
+                        if constexpr (SECOND_ORDER) acc[rt][mt] = mfma_bf16(al, bh[rt], acc[rt][mt]);
                         if constexpr (PIECES == 3) acc[rt][mt] = mfma_bf16(ah, bl[rt], acc[rt][mt]);
-                        acc[rt][mt] = mfma_bf16(am, bm[rt], acc[rt][mt]);
+                        if constexpr (SECOND_ORDER) acc[rt][mt] = mfma_bf16(am, bm[rt], acc[rt][mt]);
                         acc[rt][mt] = mfma_bf16(am, bh[rt], acc[rt][mt]);
                         acc[rt][mt] = mfma_bf16(ah, bm[rt], acc[rt][mt]);
                         acc[rt][mt] = mfma_bf16(ah, bh[rt], acc[rt][mt]);

@@ -312,3 +312,51 @@ def batch_groups(ints):
     from permutect_amd.engine import lib as L
     reads = int(ints[:, 0].astype(np.int64).sum() + ints[:, 1].astype(np.int64).sum())
     return reads // (L.GROUP_TILES * L.TILE)  # a lower bound on the number of groups
+
+
+def test_gradients_against_an_fp64_evaluation_stay_inside_the_reference_fp32_error():
+    """The backward's input-gradient and recomputation products run on two bf16 pieces per operand (16 significant bits; the forward
+    and the reference-facing logits keep three: pmt_bwd_device.hpp, PMT_DGRAD_PIECES / PMT_RECOMPUTE_PIECES).  The yardstick is an
+    fp64 evaluation of the same training step: the HIP gradients must be no farther from it than the reference's OWN fp32 arithmetic
+    (the oracle in float32) is, with room to spare against the 1e-4 contract.  Measured at 8 192 read sets: HIP 7.3e-6 (1.1e-6 with
+    six-MFMA products), fp32 oracle 8.6e-6."""
+    from bench import synth_arrays
+    from permutect_amd.architecture.artifact_model import ArtifactModel
+    from permutect_amd.parameters import P0_DIMS, p0_params
+    nb = 4096
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    model = ArtifactModel(p0_params(), device=dev, **P0_DIMS)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    ints, floats, packed = synth_arrays(np.random.default_rng(1), nb, "wgs")
+    batch = Batch.from_arrays(ints, floats, packed).copy_to(dev)
+    model.train(True)
+    out = model.compute_batch_output(batch)
+    losses = model.compute_batch_losses(out, batch)
+    opt = FusedClipAdamW(model, lr=1e-3, weight_decay=0.01)
+    opt.zero_grad()
+    losses.total_loss.backward()
+    torch.cuda.synchronize()
+    names = [n for n, _ in model.named_parameters()]
+    ours = np.concatenate([p.grad.detach().cpu().numpy().ravel().astype(np.float64) for _, p in model.named_parameters()])
+    i64 = torch.from_numpy(ints.astype(np.int64))
+    ob = dict(reads_re=torch.from_numpy(O.decode_packed_reads(packed).astype(np.float32)), nref=i64[:, O.REF_COUNT], nalt=i64[:, O.ALT_COUNT],
+              labels=i64[:, O.LABEL], sources=i64[:, O.SOURCE], info_be=torch.from_numpy(floats[:, O.INFO_START:].astype(np.float32)),
+              haplotypes_bh=i64[:, O.HAPLOTYPES_START:])
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    cfg = config_for("p0")
+    grads = {}
+    try:
+        for dt in (torch.float32, torch.float64):
+            O.COMPUTE_DTYPE = dt
+            _, _, g = O.train_step_grads({k: (v.to(dt) if v.is_floating_point() else v) for k, v in sd.items()}, cfg, ob)
+            grads[dt] = np.concatenate([g[n].numpy().ravel().astype(np.float64) for n in names])
+    finally:
+        O.COMPUTE_DTYPE = torch.float32
+    ref = grads[torch.float64]
+    hip = float(np.linalg.norm(ours - ref) / np.linalg.norm(ref))
+    fp32 = float(np.linalg.norm(grads[torch.float32] - ref) / np.linalg.norm(ref))
+    record(test="grad_vs_fp64_4096", hip_vs_fp64=hip, fp32_oracle_vs_fp64=fp32)
+    assert hip <= 2e-5 and hip <= 1.5 * fp32, (hip, fp32)
