@@ -417,8 +417,8 @@ def main():
         r = roofline("pmt_backward_kernel", 2.0 * fwd_flops, kms["pmt_backward"])  # dgrad + wgrad; in-kernel recompute not counted
         r["matrix_pipe"] = ("fp32 accumulation on the bf16 matrix pipe.  Forward (both kernels): fp32-equivalent, six bf16 MFMAs on "
                             "three-piece splits of both operands.  Backward: dgrad, recompute and wgrad as three bf16 MFMAs on two-piece "
-                            "splits (16 significant bits per operand): gradients 7e-6 from an fp64 evaluation, the reference's own fp32 "
-                            "arithmetic 9e-6 (tests/test_scale_gpu.py); `peak` is the dense fp32 MFMA rate"
+                            "splits (16 significant bits per operand): gradients 7 - 8e-6 from an fp64 evaluation, the reference's own fp32 "
+                            "arithmetic 7 - 9e-6 (tests/test_scale_gpu.py); `peak` is the dense fp32 MFMA rate"
                             if args.dtype == "f32" else
                             "plain bf16: one bf16 MFMA per product (fp32 accumulation), single roundings of both operands; `peak` stays the "
                             "dense fp32 MFMA rate so that the two modes read on one scale (the bf16 dense peak is ~2.5 PFLOP/s)")

@@ -7,8 +7,8 @@
 // SELU, the inner layer of a skip block).  The forward keeps every product fp32-equivalent (three bf16 pieces per operand, six
 // MFMAs); in the backward the GRADIENT contract is 1e-4 relative, and the reference's own fp32 arithmetic sits 8.6e-6 from an fp64
 // evaluation of the same step.  Two pieces per operand (16 significant bits) and the three first-order MFMAs put the HIP gradients
-// at 7.3e-6 from fp64 -- still inside the reference's own error -- where the six-MFMA form gives 1.1e-6, for 5.8 % of the kernel
-// (scripts/grad_vs_fp64.py).  The weight gradients have contracted two-piece operands since round 2.
+// at 7.3e-6 from fp64 -- the size of the reference's own error (7.9e-6 against 7.0e-6 at 4 096 read sets) -- where the six-MFMA
+// form gives 1.1e-6, for 5.8 % of the kernel (scripts/grad_vs_fp64.py, tests/test_scale_gpu.py).  The weight gradients have contracted two-piece operands since round 2.
 // -DPMT_DGRAD_PIECES=3 -DPMT_RECOMPUTE_PIECES=3 restores the six-MFMA form; PMT_TWO_PIECE_MFMAS=5 keeps the second-order terms.
 #ifndef PMT_DGRAD_PIECES
 #define PMT_DGRAD_PIECES 2
