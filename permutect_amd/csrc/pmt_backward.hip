@@ -2,13 +2,15 @@
 // kernel walks the network in reverse; inside each layer group it RECOMPUTES the forward from the stashed layer-group
 // input (pmt_forward<TRAIN> wrote those), so only ~0.7 K floats per read cross HBM between the two passes.
 //
-//   dgrad  dx = W^T dy      : MFMA with the transposed A fragments (wt_frag, or their bf16 pieces wtb_frag in the
-//                             exact-width instance); dy is already the B operand.
+//   dgrad  dx = W^T dy      : MFMA with the transposed A fragments (wt_frag; in the exact-width instances their bf16 pieces
+//                             wtb_frag: two pieces of dy against two of W, three MFMAs -- pmt_bwd_device.hpp, PMT_DGRAD_PIECES);
+//                             dy is already the B operand.
 //   wgrad  dW += dy x^T     : contraction over READS.  Both operands are written transposed into an LDS stage (reads move
-//                             from the lane axis to the MFMA k axis purely by the store addressing) and exchanged; each
-//                             wave then owns distinct 16x16 blocks of dW, contracts them over all reads of the workgroup
-//                             with v_mfma_f32_16x16x4_f32 and adds them with global float atomics into the flat gradient
-//                             buffer (pmt_bwd_device.hpp: wgrad_exchange).  No LDS atomics.
+//                             from the lane axis to the MFMA k axis purely by the store addressing) as two bf16 pieces each and
+//                             exchanged; each wave then owns distinct 16x16 blocks of dW, contracts them over all reads of the
+//                             workgroup (three bf16 MFMAs per 32 reads; fp32 MFMAs in the generic instances) and adds them to
+//                             its workgroup's PRIVATE row of partial sums, which pmt_grad_fold_kernel folds into the flat
+//                             gradient buffer (without the workspace: global float atomics).  No LDS atomics.
 //   set-coupled terms       : per-set sums of d(gate) go through LDS exactly like the forward's z2 sums.
 //
 // Replaces autograd over reference artifact_model.py:239-297 (misc_utils.py:127 `loss.backward()`).
@@ -17,8 +19,8 @@
 #define PMT_WAVES PMT_GROUP_WAVES
 #define PMT_RT 2
 #ifndef PMT_BWD_PIECES
-#define PMT_BWD_PIECES 3  // (2 was measured again on the final build: 2.83 -> 2.71 ms, gradient rel. L2 unchanged at 2.2e-5, one tensor's worst
-                          //  element 9e-5 -> 2.4e-4 of its scale; the parity headline keeps the fp32-equivalent three)
+#define PMT_BWD_PIECES 3  // pieces of the products that keep the forward's precision (the head's recomputation); the input-gradient and
+                          // recomputation products of the layers take PMT_DGRAD_PIECES / PMT_RECOMPUTE_PIECES (pmt_bwd_device.hpp)
 #endif
 #define PMT_STAGE_PLANES (16 * PMT_GROUP_WAVES)  // every wave's operands of a 4 + 4 tile linear at once (8 waves x 8 planes x (hi + mid))
 #include "permutect_amd.h"
@@ -108,8 +110,8 @@ DEV void backward_group(
     float* __restrict__ gvar, const PmtBwdLayered& lay, const int grp, BwdShared& sh, float* __restrict__ priv) {
     constexpr int NTF = S::NTF, NTR = S::NTR, NTD = S::NTD, NTE = S::NTE;
     constexpr bool EX = S::EXACT;
-    // Pieces of the activations / gradients in the backward's products (PMT_BWD_PIECES): three, like the forward.  Two (hi + mid,
-    // five MFMAs and a shorter split) measured 1.4 % faster with a visibly larger error on single tensors, and stays off.
+    // Pieces of the activations / gradients in the backward's products: BFB (three, like the forward) where PMT_DG / PMT_RC do not
+    // apply; the layers' input-gradient and recomputation products run on two (pmt_bwd_device.hpp, with the fp64 yardstick).
     constexpr int BFB = S::BF16 == 3 ? PMT_BWD_PIECES : S::BF16;
     static_assert(EX || (NTF == NTD && NTR == NTD && NTE == NTD), "the generic shape keeps one array width");
     const int tid = pmt_tid(), lane = tid & 63, g = lane >> 4, wave = uniform((int)(tid >> 6));
