@@ -466,7 +466,7 @@ DEV void backward_group(
                 const f4 b0 = load_pvec(packed + uniform(P1.b_pvec), 0, g), b1 = load_pvec(packed + uniform(P1.b_pvec), 1, g);
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt) { z[rt][0] = b0; z[rt][1] = b1; }
-                if constexpr (S::BF16) linear_acc_bf16<NTD, 2, false, PMT_RC(BFB)>(z, n, packed + uniform(P1.wb_frag));
+                if constexpr (S::BF16) linear_acc_bf16<NTD, 2, false, BFB>(z, n, packed + uniform(P1.wb_frag));  // (the gate multiplies by this: three pieces)
                 else linear_acc<NTD, 2, false, EX, S::DIM_D>(z, n, packed + uniform(P1.w_frag), D, 16 + h);
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt) {

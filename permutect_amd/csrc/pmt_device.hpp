@@ -500,7 +500,11 @@ DEV float* grad_ptr(int src, float* gtheta, float* gphi) { return src >= 0 ? gth
 // ---- stash layout (floats per 16-read tile) ---------------------------------------------------------------------
 // slots: [read-MLP op boundaries 1..n-1][x_0 .. x_L][reducer op boundaries 1..n-1], each slot NT*256 floats
 #ifndef PMT_STASH_Z
-#define PMT_STASH_Z 1  // the blocks' z in the stash (0: the backward recomputes it)
+#define PMT_STASH_Z 1  // 1: the blocks' z in the stash; 0: the backward recomputes it.  Measured again in round 3, when the training forward had
+                       // turned out to be bound by its stash WRITES (3.0 GB per 65 536-set launch at ~3.5 TB/s) and the layers'
+                       // recomputation had dropped to three MFMAs per product: without z (22 % of the stash) the forward gains 40 us,
+                       // but the gate multiplies by z, and recomputed on two bf16 pieces it puts the gradients 5e-5 from fp64 (7e-6
+                       // with z stashed); recomputed on three pieces the backward pays 70 us.  z stays in the stash.
 #endif
 // stash slots per tile: the inputs of the read MLP's ops 1.., xhat_0 .. xhat_{L-1} and x_L, the inputs of the reducer's ops 1..,
 // then every block's z (after SELU; half a slot used)
