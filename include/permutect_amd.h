@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PMT_ABI_VERSION 8
+#define PMT_ABI_VERSION 9
 
 /* error codes */
 #define PMT_OK 0
@@ -73,6 +73,10 @@ typedef struct PmtLinear {
     int32_t wb_frag;     /* packed: W as THREE bf16 pieces (hi + mid + lo = the fp32 value) in the operand order of
                             v_mfma_f32_16x16x32_bf16: [k block of 32][out tile][piece][lane][8 bf16]; -1 = none */
     int32_t wtb_frag;    /* the same for W^T                                                                   */
+    int32_t wh_frag;     /* packed: W as TWO f16 pieces in the operand order of v_mfma_f32_16x16x32_f16:
+                            [out tile][k block of 32][piece][lane][8 f16], piece 0 = f16(w), piece 1 = f16(2^12 (w - piece 0)):
+                            the low piece is stored scaled so that it keeps its 11 bits whatever the weight's size
+                            (pmt_device.hpp: linear_acc_f16); -1 = none                                        */
     int32_t emit_tab;    /* packed (read as int32): where the weight-gradient blocks of this linear go.  For every 16 x 16
                             block (out tile ot, in tile it) of dW in the matrix core's C layout, [(ot * nkt + it)][lane][4]
                             element offsets into the buffer w_src names (theta, or phi when w_src <= -2), -1 = padding;
@@ -182,7 +186,9 @@ typedef struct PmtModel {
      * 0 everywhere = the library's own choice; the other values exist so that the parity tests can run every instance. */
     int32_t force_shape;        /* read-set kernels: 0 auto, 1 at most the tile-exact instance, 2 the generic instance,
                                    3 plain bf16 products where the exact-width instance applies (NOT a parity mode:
-                                   one bf16 MFMA per product instead of the fp32-equivalent six; bench.py --dtype bf16) */
+                                   one bf16 MFMA per product instead of the fp32-equivalent ones; bench.py --dtype bf16),
+                                   5 the exact-width FORWARD with its products as six bf16 MFMAs on three-piece splits (the
+                                   round-3 form; auto = three f16 MFMAs on two-piece splits, pmt_device.hpp: linear_acc_f16) */
     int32_t force_cnn;          /* haplotype CNN: 0 auto, 1 general (workgroup-per-chunk) kernels, 2 wave-per-variant
                                    kernels (pmt_cnn2), 3 batched-column kernels (pmt_cnn3)                               */
     int32_t cnn_debug;          /* development switches of pmt_cnn2_backward (0 in production)                           */
@@ -225,6 +231,11 @@ typedef struct PmtBatch {
                                        registers; NULL = num_blocks + 1 launches with the activations parked in between */
     uint64_t dropout_seed;          /* 0 = no dropout (eval mode, or dropout_p = 0).  Otherwise the seed of THIS step's masks
                                        (pmt_dropout_mask): the forward and the backward of one step get the same value */
+    int32_t* join_fault;            /* device, optional [1], caller-owned and never cleared by the library: a joined launch
+                                       (set_groups) whose bounded wait for another workgroup gave up stores 1 here -- its
+                                       numbers are then wrong.  One persistent word serves every launch of a run; the host
+                                       reads it where it synchronises anyway (end of an epoch / of a filtering pass).
+                                       NULL = the word inside the launch's own scratch (development) */
 } PmtBatch;
 
 typedef struct PmtOutputs {

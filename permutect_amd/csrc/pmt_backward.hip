@@ -931,7 +931,7 @@ extern "C" int pmt_backward_layered(const PmtModel* model_host, const PmtModel* 
     const int grid = part && num_partials < batch->num_groups ? num_partials : batch->num_groups;
     auto kernel = shape >= 2 ? pmt_backward_kernel<ShapeP0X, true> : shape == 1 ? pmt_backward_kernel<ShapeP0, true> : pmt_backward_kernel<ShapeAny, true>;
     int* join_words = reinterpret_cast<int*>(lay.gsum_g + B * nb * 32);
-    lay.join = PmtJoin{0, join_words + B * nb, join_words, join_words + B * nb + 1};
+    lay.join = PmtJoin{0, join_words + B * nb, join_words, batch->join_fault ? batch->join_fault : join_words + B * nb + 1};
     if (batch->set_groups != nullptr && L > 0) {  // ONE launch: the groups of a split read set join their sums through HBM
         lay.join.on = 1;
         if (hipMemsetAsync(join_words, 0, (B * nb + 8) * sizeof(int), s) != hipSuccess) return PMT_E_LAUNCH;

@@ -64,6 +64,7 @@ DEV int pmt_tid() {
 // XBF: 0 = exact-fp32 MFMAs; 3 = the layers' matrix products as SIX bf16 MFMAs on three-piece splits of both operands
 // (linear_acc_bf16: fp32-equivalent); 1 = ONE bf16 MFMA per product on single bf16 roundings of both operands -- the plain
 // bf16 mode BASELINE.json's training configuration names: no parity claim, measured and labelled as such (bench.py --dtype bf16).
+//      16 (PMT_F16X2) = three f16 MFMAs on two-piece splits with a scaled low piece (linear_acc_f16: fp32-equivalent).
 // XDROP: the instance carries the dropout masks of a training step (pmt_dropout.hpp); the generic instances always do.
 template <int F, int R, int D, int E, bool EXACT_, int XF = 0, int XR = 0, int XD = 0, int XH = 0, int XE = 0, int XBF = 0, bool XDROP = false>
 struct Shape {
@@ -79,6 +80,12 @@ using ShapeP0 = Shape<4, 2, 4, 1, true>;     // F in 49..64, read widths 17..32,
 using ShapeP0X = Shape<4, 2, 4, 1, true, 61, 30, 60, 10, 10, 3>;  // exactly the production hyperparameters (SURVEY: P0)
 using ShapeP0XB = Shape<4, 2, 4, 1, true, 61, 30, 60, 10, 10, 1>; // the same widths, plain bf16 products (not a parity mode)
 using ShapeP0XD = Shape<4, 2, 4, 1, true, 61, 30, 60, 10, 10, 3, true>;  // the production shape in a training step WITH dropout
+// The FORWARD instances of the production shape since round 4: the same widths with the products as THREE f16 MFMAs on two-piece
+// splits (XBF = 16 = PMT_F16X2, linear_acc_f16 below; fp32-equivalent like the six bf16 MFMAs).  The backward keeps its bf16
+// pieces (gradients need bf16's exponent range), so ShapeP0X / ShapeP0XD above remain its instances and, for the forward, the
+// round-3 form that PmtModel.force_shape = 5 asks for.
+using ShapeP0XH = Shape<4, 2, 4, 1, true, 61, 30, 60, 10, 10, 16>;
+using ShapeP0XHD = Shape<4, 2, 4, 1, true, 61, 30, 60, 10, 10, 16, true>;
 
 DEV float uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -431,6 +438,117 @@ DEV void linear_acc_bf16(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], co
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same product on the f16 matrix pipe with TWO pieces per operand: three MFMAs instead of six, five vector operations per
+// pair of activation values instead of nine, two KiB of weight fragments per (out tile, k block) instead of three.
+//   x = xh + 2^-12 xl',  xh = f16(x),  xl' = f16(2^12 (x - xh));   w = wh + 2^-12 wl' likewise (pmt_pack_params, wh_frag)
+// x - xh is exact in fp32 and at most 2^-11 |x| (round to nearest), so the scaled low piece is a normal f16 with its full 11
+// bits whenever xh is normal: the pair carries x to 2^-23 relative from |x| = 6e-5 to 65504, over the whole range the
+// hardware's f16 has -- unscaled, the low piece of any |x| < 1/4 would be a denormal (measured: an activation vector of size
+// 1e-3 lost half its digits, scripts/microbench/f16x2.hip).  Then
+//   w x = wh xh + 2^-12 (wh xl' + wl' xh) + 2^-24 wl' xl':
+// the first product accumulates straight into `acc`, the two first-order ones into an accumulator of their own per out tile
+// that joins `acc` with one fused multiply-add, the last term (at most 2^-22 |w x|, 2^-25 rms) is dropped.  Measured against
+// fp64 on 60-wide dot products: rms error 1.9e-8 of the sum of |terms| (three bf16 pieces / six MFMAs: 1.7e-8; sequential fp32
+// fused multiply-adds: 2.9e-8).  Range: the kernels run with MODE.FP16_OVFL set, so an activation beyond +-65504 saturates
+// (finite, wrong) instead of turning into inf - inf; no activation of a LayerNorm'ed network is near it, and the limit is
+// stated in DESIGN.md.  Loop order: out tile outermost -- the low-order accumulator is 2 x 4 registers, the pieces of the whole
+// input (NKB x 2 tiles x 2 pieces x 4 registers) are made once up front, after which the input registers are dead.
+// ---------------------------------------------------------------------------------------------------------------
+#define PMT_F16X2 16  // Shape::BF16 value of the instances whose forward products run this way
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+DEV f4 mfma_f16(h8 a, h8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+DEV f4 mfma_f16_k16(h8 a, h8 b, f4 c) {  // the 16-deep variant on elements 0..3 of both operands (one activation tile)
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(h4v{a[0], a[1], a[2], a[3]}, h4v{b[0], b[1], b[2], b[3]}, c, 0, 0, 0);
+}
+DEV void fp16_saturate_on() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }  // MODE.FP16_OVFL
+#ifndef PMT_F16_SPLIT_ASM
+#define PMT_F16_SPLIT_ASM 1
+#endif
+DEV void split_pair_f16(float a, float b, unsigned& h, unsigned& l, float k4096) {
+    if (PMT_F16_SPLIT_ASM) {
+        // v_cvt_pk_f16_f32 (round to nearest even); the residuals straight from the packed halves (v_fma_mix_f32 reads an f16
+        // half as an operand: x - h, exact); scaled and rounded by v_fma_mixlo / mixhi_f16 (fp32 product, one rounding)
+        float ra, rb;
+        asm("v_cvt_pk_f16_f32 %0, %3, %4\n\t"
+            "v_fma_mix_f32 %1, %0, -1.0, %3 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %2, %0, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+            : "=&v"(h), "=&v"(ra), "=&v"(rb) : "v"(a), "v"(b));
+        asm("v_fma_mixlo_f16 %0, %1, %3, 0\n\t"
+            "v_fma_mixhi_f16 %0, %2, %3, 0"
+            : "=&v"(l) : "v"(ra), "v"(rb), "v"(k4096));
+        return;
+    }
+    const h2v hh = {(_Float16)a, (_Float16)b};
+    const h2v ll = {(_Float16)((a - (float)hh[0]) * 4096.f), (_Float16)((b - (float)hh[1]) * 4096.f)};
+    h = __builtin_bit_cast(unsigned, hh);
+    l = __builtin_bit_cast(unsigned, ll);
+}
+template <int NTI, int NTO, bool SELU_IN>
+DEV void linear_acc_f16(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], const float* __restrict__ fragh, float in_scale = 1.0f) {
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    constexpr int NKB = (NTI + 1) / 2;
+    const h8* __restrict__ fp = reinterpret_cast<const h8*>(fragh) + (pmt_tid() & 63);
+    h8 xh[NKB][PMT_RT], xl[NKB][PMT_RT];
+    float k4096 = 4096.f;
+    asm volatile("" : "+v"(k4096));  // (one register for the whole kernel, not a literal per instruction)
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt) {
+            const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
+            f4 v0 = in[rt][2 * kb], v1 = (2 * kb + 1 < NTI) ? in[rt][(2 * kb + 1 < NTI) ? 2 * kb + 1 : 0] : zero;
+            if (SELU_IN) {
+                v0 = selu4(v0) * in_scale;
+                if (2 * kb + 1 < NTI) v1 = selu4(v1) * in_scale;
+            }
+            unsigned hh[4] = {0u, 0u, 0u, 0u}, ll[4] = {0u, 0u, 0u, 0u};
+            split_pair_f16(v0[0], v0[1], hh[0], ll[0], k4096);
+            split_pair_f16(v0[2], v0[3], hh[1], ll[1], k4096);
+            if (2 * kb + 1 < NTI) {
+                split_pair_f16(v1[0], v1[1], hh[2], ll[2], k4096);
+                split_pair_f16(v1[2], v1[3], hh[3], ll[3], k4096);
+            }
+            xh[kb][rt] = __builtin_bit_cast(h8, u4v{hh[0], hh[1], hh[2], hh[3]});
+            xl[kb][rt] = __builtin_bit_cast(h8, u4v{ll[0], ll[1], ll[2], ll[3]});
+        }
+#pragma unroll
+    for (int mt = 0; mt < NTO; ++mt) {
+        f4 lo[PMT_RT];
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt) lo[rt] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            const int step = mt * NKB + kb;
+            const h8 ah = fp[128 * step], al = fp[128 * step + 64];
+            const bool half_block = 2 * kb + 1 >= NTI;  // a last k block with one tile only: the 16-deep MFMA on the lower halves
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt) {
+                if (half_block) {
+                    lo[rt] = mfma_f16_k16(al, xh[kb][rt], lo[rt]);
+                    lo[rt] = mfma_f16_k16(ah, xl[kb][rt], lo[rt]);
+                    acc[rt][mt] = mfma_f16_k16(ah, xh[kb][rt], acc[rt][mt]);
+                } else {
+                    lo[rt] = mfma_f16(al, xh[kb][rt], lo[rt]);
+                    lo[rt] = mfma_f16(ah, xl[kb][rt], lo[rt]);
+                    acc[rt][mt] = mfma_f16(ah, xh[kb][rt], acc[rt][mt]);
+                }
+            }
+        }
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt) acc[rt][mt] = lo[rt] * (1.0f / 4096.f) + acc[rt][mt];
+    }
+}
+// the layers' products of an exact-width instance: BF = PMT_F16X2 two f16 pieces (wh_frag), else bf16 pieces (wb_frag)
+template <int NTI, int NTO, bool SELU_IN, int BF>
+DEV void linear_acc_mx(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], const float* __restrict__ packed, const PmtLinear& L,
+                       float in_scale = 1.0f) {
+    if constexpr (BF == PMT_F16X2) linear_acc_f16<NTI, NTO, SELU_IN>(acc, in, packed + uniform(L.wh_frag), in_scale);
+    else linear_acc_bf16<NTI, NTO, SELU_IN, BF>(acc, in, packed + uniform(L.wb_frag), in_scale);
 }
 
 // A wave's tiles are all on one side of the ref / alt boundary (group_geometry), so no per-tile masks exist.

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
     static_assert(EX || (NTF == NTD && NTR == NTD && NTE == NTD), "the generic shape keeps one array width");
     __shared__ __attribute__((aligned(16))) FwdShared sh;
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+    if constexpr (S::BF16 == PMT_F16X2) fp16_saturate_on();  // f16 operand pieces: beyond +-65504 saturate, never inf (linear_acc_f16)
     if (bt.num_groups_dev != nullptr && (int)blockIdx.x >= uniform(bt.num_groups_dev[0])) return;  // grid sized for a capacity (graph replay)
     const bool joined = LAYERED && lay.join.on != 0;
     // joined: groups go out by ticket, in the order the workgroups actually start (dispatch order is not promised): the started
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
             const f4 b0 = load_pvec(bp, 0, g), b1 = load_pvec(bp, 1, g);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) { z[rt][0] = b0; z[rt][1] = b1; }
-            if constexpr (S::BF16) linear_acc_bf16<NTD, 2, false, S::BF16>(z, n, packed + uniform(M->lin[uniform(B.proj1[side])].wb_frag));
+            if constexpr (S::BF16) linear_acc_mx<NTD, 2, false, S::BF16>(z, n, packed, M->lin[uniform(B.proj1[side])]);
             else linear_acc<NTD, 2, false, EX, S::DIM_D>(z, n, stA + side * frag_floats_dev(P1r), D, 16 + h);
         // SELU, LayerNorm(h) on z2, per-set sums (reference gated_mlp.py:228-239)
         f4 sw[1], sb[1];  // (loaded here, behind the first projection: eight registers less across it)
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt) x[rt][t] = x[rt][t] + b;
             }
-            if constexpr (S::BF16) linear_acc_bf16<1, NTD, false, S::BF16>(x, u, packed + uniform(M->lin[uniform(B.proj2[side])].wb_frag));
+            if constexpr (S::BF16) linear_acc_mx<1, NTD, false, S::BF16>(x, u, packed, M->lin[uniform(B.proj2[side])]);
             else linear_acc<1, NTD, false, EX, S::DIM_H>(x, u, p2_frags + side * frag_floats_dev(P2r), h, D);
         }
         tr.ev(12);
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
                 a[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        if constexpr (S::BF16) linear_acc_bf16<NTE, NTE, false, S::BF16>(a, e, packed + uniform(R.wb_frag));
+        if constexpr (S::BF16) linear_acc_mx<NTE, NTE, false, S::BF16>(a, e, packed, R);
         else linear_acc<NTE, NTE, false, EX, S::DIM_E>(a, e, stR, E, E);
     }
 
@@ -584,25 +585,29 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
 #ifdef PMT_FORWARD_TRAIN_TU
 extern "C" int pmt_forward_launch_train_p0x(int groups, void* stream, const PmtModel* model_dev, const float* theta, const float* phi,
                                             const float* packed, const PmtBatch* batch, const PmtOutputs* out, float* stash,
-                                            float* zsum_stash, float* rstd_stash, const PmtLayeredArgs* lay) {
-    if (lay != nullptr && stash == nullptr)  // one launch of the layered filter forward (it parks activations between launches: stores, too)
-        hipLaunchKernelGGL((pmt_forward_kernel<false, ShapeP0X, true>), dim3(groups), dim3(PMT_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
-                           model_dev, theta, phi, packed, *batch, *out, stash, zsum_stash, rstd_stash, *lay);
-    else if (lay != nullptr)  // one launch of the layered training forward
-        hipLaunchKernelGGL((pmt_forward_kernel<true, ShapeP0X, true>), dim3(groups), dim3(PMT_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
-                           model_dev, theta, phi, packed, *batch, *out, stash, zsum_stash, rstd_stash, *lay);
-    else if (batch->dropout_seed != 0)  // a training step with dropout (the caller checked the model's dropout_p): the instance with the masks
-        hipLaunchKernelGGL((pmt_forward_kernel<true, ShapeP0XD>), dim3(groups), dim3(PMT_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
-                           model_dev, theta, phi, packed, *batch, *out, stash, zsum_stash, rstd_stash, PmtLayeredArgs{});
-    else
-        hipLaunchKernelGGL((pmt_forward_kernel<true, ShapeP0X>), dim3(groups), dim3(PMT_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
-                           model_dev, theta, phi, packed, *batch, *out, stash, zsum_stash, rstd_stash, PmtLayeredArgs{});
+                                            float* zsum_stash, float* rstd_stash, const PmtLayeredArgs* lay, int bf16x3) {
+    const hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const PmtLayeredArgs none{};
+    // bf16x3 (PmtModel.force_shape = 5): the round-3 instances, six bf16 MFMAs per product; otherwise three f16 MFMAs
+#define PMT_LAUNCH_FWD(TRAIN, SHAPE, LAYERED, LAY) \
+    hipLaunchKernelGGL((pmt_forward_kernel<TRAIN, SHAPE, LAYERED>), dim3(groups), dim3(PMT_THREADS), 0, s, model_dev, theta, phi, packed, \
+                       *batch, *out, stash, zsum_stash, rstd_stash, LAY)
+    if (lay != nullptr && stash == nullptr) {  // one launch of the layered filter forward (it parks activations between launches: stores, too)
+        if (bf16x3) PMT_LAUNCH_FWD(false, ShapeP0X, true, *lay); else PMT_LAUNCH_FWD(false, ShapeP0XH, true, *lay);
+    } else if (lay != nullptr) {  // one launch of the layered training forward
+        if (bf16x3) PMT_LAUNCH_FWD(true, ShapeP0X, true, *lay); else PMT_LAUNCH_FWD(true, ShapeP0XH, true, *lay);
+    } else if (batch->dropout_seed != 0) {  // a training step with dropout (the caller checked the model's dropout_p): the instance with the masks
+        if (bf16x3) PMT_LAUNCH_FWD(true, ShapeP0XD, false, none); else PMT_LAUNCH_FWD(true, ShapeP0XHD, false, none);
+    } else {
+        if (bf16x3) PMT_LAUNCH_FWD(true, ShapeP0X, false, none); else PMT_LAUNCH_FWD(true, ShapeP0XH, false, none);
+    }
+#undef PMT_LAUNCH_FWD
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }
 #else
 extern "C" int pmt_forward_launch_train_p0x(int groups, void* stream, const PmtModel* model_dev, const float* theta, const float* phi,
                                             const float* packed, const PmtBatch* batch, const PmtOutputs* out, float* stash,
-                                            float* zsum_stash, float* rstd_stash, const PmtLayeredArgs* lay);
+                                            float* zsum_stash, float* rstd_stash, const PmtLayeredArgs* lay, int bf16x3);
 
 // per-set outputs from the global sums of a layered forward (same arithmetic as the finalisation above)
 __global__ __launch_bounds__(256) void pmt_finalize_kernel(const PmtModel* __restrict__ M, const float* __restrict__ phi, PmtBatch bt,
@@ -675,7 +680,7 @@ extern "C" int pmt_forward_layered(const PmtModel* model_host, const PmtModel* m
                         : (p0 ? pmt_forward_kernel<false, ShapeP0, true> : pmt_forward_kernel<false, ShapeAny, true>);
     // joined execution: one launch in which the groups of a split read set exchange their per-set sums through HBM
     int* join_words = reinterpret_cast<int*>(lay.hsum_g + B * (PMT_MAX_CLUSTERS + 2));
-    lay.join = PmtJoin{0, join_words + B * nb, join_words, join_words + B * nb + 1};
+    lay.join = PmtJoin{0, join_words + B * nb, join_words, batch->join_fault ? batch->join_fault : join_words + B * nb + 1};
     if (batch->set_groups != nullptr && L > 0) {
         lay.join.on = 1;
         if (hipMemsetAsync(join_words, 0, (B * nb + 8) * sizeof(int), s) != hipSuccess) return PMT_E_LAUNCH;
@@ -684,7 +689,7 @@ extern "C" int pmt_forward_layered(const PmtModel* model_host, const PmtModel* m
         lay.slice = slice;
         if (shape >= 2) {  // the layered instances of the production shape: pmt_forward_train.hip  (layered: no plain-bf16 instance)
             const int rct = pmt_forward_launch_train_p0x(batch->num_groups, stream, model_dev, theta, phi, packed, batch, out, stash, zsum_stash,
-                                                         rstd_stash, &lay);
+                                                         rstd_stash, &lay, model_host->force_shape == 5);
             if (rct != PMT_OK) return rct;
             continue;
         }
@@ -723,8 +728,9 @@ extern "C" int pmt_forward(const PmtModel* model_host, const PmtModel* model_dev
     auto kernel = stash ? (p0 ? pmt_forward_kernel<true, ShapeP0> : pmt_forward_kernel<true, ShapeAny>)
                         : (p0 ? pmt_forward_kernel<false, ShapeP0> : pmt_forward_kernel<false, ShapeAny>);
     if ((shape == 2 || shape == 4) && stash)  // its own translation unit (pmt_forward_train.hip); 4: with the step's dropout masks
-        return pmt_forward_launch_train_p0x(batch->num_groups, stream, model_dev, theta, phi, packed, batch, out, stash, zsum_stash, rstd_stash, nullptr);
-    if (shape == 2) kernel = pmt_forward_kernel<false, ShapeP0X>;
+        return pmt_forward_launch_train_p0x(batch->num_groups, stream, model_dev, theta, phi, packed, batch, out, stash, zsum_stash, rstd_stash, nullptr,
+                                            model_host->force_shape == 5);
+    if (shape == 2) kernel = model_host->force_shape == 5 ? pmt_forward_kernel<false, ShapeP0X> : pmt_forward_kernel<false, ShapeP0XH>;
     if (shape == 3) kernel = stash ? pmt_forward_kernel<true, ShapeP0XB> : pmt_forward_kernel<false, ShapeP0XB>;  // plain bf16 products
     hipLaunchKernelGGL(kernel, dim3(batch->num_groups), dim3(PMT_THREADS), 0, s, model_dev, theta, phi, packed, *batch, *out,
                        stash, zsum_stash, rstd_stash, PmtLayeredArgs{});

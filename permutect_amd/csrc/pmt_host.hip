@@ -63,7 +63,7 @@ static bool mlp_ops_have_tiles(const PmtModel* m, const PmtMlp* mlp, int first, 
     return true;
 }
 extern "C" int pmt_shape_id(const PmtModel* m) {
-    if (m->force_shape == 2) return 0;
+    if (m->force_shape == 2) return 0;  // (5 = auto for every kernel but the forward, whose launchers read it themselves)
     const PmtMlp* rm = &m->read_mlp;
     const PmtMlp* red = &m->reducer;
     if (rm->n_ops < 1 || red->n_ops < 1 || m->num_blocks < 0) return 0;
@@ -498,14 +498,15 @@ DEV int split_row(int v, int h) {
 }
 
 // one job per workgroup: (lin, 0) forward frags, (lin, 1) transposed frags, (lin, 2) bias, (lin, 3 / 4) the same two matrices
-// as bf16 pieces, (lin, 5) the weight-gradient emit table, then per-block vectors
+// as bf16 pieces, (lin, 5) the weight-gradient emit table, (lin, 6) the forward matrix as two f16 pieces, then per-block vectors
+#define PMT_PACK_KINDS 7
 __global__ void pmt_pack_kernel(const PmtModel* __restrict__ M, const float* __restrict__ theta,
                                 const float* __restrict__ phi, float* __restrict__ packed) {
     const int job = blockIdx.x;
-    const int n_lin_jobs = M->n_linear * 6;
+    const int n_lin_jobs = M->n_linear * PMT_PACK_KINDS;
     if (job < n_lin_jobs) {
-        const PmtLinear& L = M->lin[job / 6];
-        const int kind = job % 6;
+        const PmtLinear& L = M->lin[job / PMT_PACK_KINDS];
+        const int kind = job % PMT_PACK_KINDS;
         const int h = L.out_split;
         const int out_v = h > 0 ? 16 + h : L.out_dim;  // virtual output rows
         if (kind == 5) {
@@ -527,6 +528,37 @@ __global__ void pmt_pack_kernel(const PmtModel* __restrict__ M, const float* __r
             for (int i = threadIdx.x; i < nmt * 16; i += blockDim.x) {
                 const int p = i & 15, pf = 16 * (i >> 4) + 4 * (p & 3) + (p >> 2), o = pf < out_v ? split_row(pf, h) : -1;
                 btab[i] = (L.b_src >= 0 && o >= 0 && o < L.out_dim) ? L.b_src + o : -1;
+            }
+            return;
+        }
+        if (kind == 6) {
+            // PmtLinear.wh_frag: two f16 pieces per weight, (out tile, k block) order, the element order of the bf16 pieces
+            // below.  hi = f16(w), lo = f16(2^12 (w - hi)): w - hi is exact in fp32 and at most 2^-11 |w|, so the scaled low
+            // piece is a NORMAL f16 with all 11 bits wherever hi is normal (unscaled it would be a denormal for |w| < 1/4 --
+            // every weight of a 60-wide layer); linear_acc_f16 keeps the products of the low pieces in an accumulator of
+            // their own and scales it back.  |w| beyond the f16 range saturates at 65504 (no trained weight is near it).
+            if (L.wh_frag < 0) return;
+            const float* W = src_ptr(L.w_src, theta, phi);
+            const int nmt = (out_v + 15) >> 4, nkt = (L.in_dim + 15) >> 4, nkb = (nkt + 1) >> 1;
+            _Float16* dst = reinterpret_cast<_Float16*>(packed + L.wh_frag);
+            const int total = nkb * nmt * 512;
+            for (int i = threadIdx.x; i < total; i += blockDim.x) {
+                const int e = i & 7, lane = (i >> 3) & 63, blk = i >> 9;
+                const int kb = blk % nkb, mt = blk / nkb;
+                const int m = lane & 15, kg = lane >> 4;
+                const int mv = 16 * mt + 4 * (m & 3) + (m >> 2);
+                const int kv = 16 * (2 * kb + (e >> 2)) + 4 * (e & 3) + kg;
+                float val = 0.f;
+                if (mv < out_v && kv < L.in_dim && (2 * kb + (e >> 2)) < nkt) {
+                    const int orow = split_row(mv, h);
+                    if (orow >= 0 && orow < L.out_dim) val = W[(size_t)orow * L.in_dim + kv];
+                }
+                val = fminf(fmaxf(val, -65504.f), 65504.f);
+                const _Float16 hi = (_Float16)val;
+                const _Float16 lo = (_Float16)((val - (float)hi) * 4096.f);
+                const size_t base = (size_t)blk * 2 * 512 + lane * 8 + e;
+                dst[base] = hi;
+                dst[base + 512] = lo;
             }
             return;
         }
@@ -625,7 +657,7 @@ extern "C" int pmt_pack_params(const PmtModel* model_host, const PmtModel* model
     if (!model_host || !model_dev || !theta || !packed) return PMT_E_INVALID;
     const int rc = pmt_model_check(model_host);
     if (rc) return rc;
-    const int jobs = model_host->n_linear * 6 + model_host->num_blocks * 5 + 1;
+    const int jobs = model_host->n_linear * PMT_PACK_KINDS + model_host->num_blocks * 5 + 1;
     hipLaunchKernelGGL(pmt_pack_kernel, dim3(jobs), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), model_dev, theta,
                        phi, packed);
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;

@@ -15,7 +15,7 @@ DEV void run_linear_op(const PmtModel* __restrict__ M, const PmtOp& o, f4 (&y)[P
     const float* st = packed + base;  // [fragments | bias]
     const int in_dim = WI ? WI : uniform(L.in_dim), out_dim = WO ? WO : uniform(L.out_dim);
     init_bias<NTO>(y, b_pvec >= 0 ? st + (b_pvec - base) : nullptr, out_dim, g);
-    if constexpr (BF) linear_acc_bf16<NTI, NTO, false, BF>(y, x, packed + uniform(L.wb_frag));
+    if constexpr (BF) linear_acc_mx<NTI, NTO, false, BF>(y, x, packed, L);
     else linear_acc<NTI, NTO, false, EXACT, WI>(y, x, st, in_dim, out_dim);
     if constexpr (DROP) {
         if (drop != nullptr && drop->on != 0) drop_apply<NTO>(*drop, uniform(o.lin[0]), y, g);
@@ -53,7 +53,7 @@ DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_
                 const PmtLinear& L = M->lin[uniform(o.lin[0])];
                 const int b_pvec = uniform(L.b_pvec);
                 init_bias<NT>(y, b_pvec >= 0 ? packed + b_pvec : nullptr, W ? W : uniform(L.out_dim), g);
-                if constexpr (BF) linear_acc_bf16<NT, NT, false, BF>(y, x, packed + uniform(L.wb_frag));
+                if constexpr (BF) linear_acc_mx<NT, NT, false, BF>(y, x, packed, L);
                 else linear_acc<NT, NT, false, EXACT, W>(y, x, packed + uniform(L.w_frag), W ? W : uniform(L.in_dim), W ? W : uniform(L.out_dim));
                 drop_apply<NT>(*drop, uniform(o.lin[0]), y, g);
                 const bool act = uniform(o.selu_after) != 0;
@@ -77,7 +77,7 @@ DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_
             if (nl == 2) {
                 const PmtLinear& L1 = M->lin[uniform(o.lin[0])];
                 init_bias<NT>(y, packed + uniform(L1.b_pvec), width, g);
-                if constexpr (BF) linear_acc_bf16<NT, NT, true, BF>(y, x, packed + uniform(L1.wb_frag));
+                if constexpr (BF) linear_acc_mx<NT, NT, true, BF>(y, x, packed, L1);
                 else linear_acc<NT, NT, true, EXACT, W>(y, x, packed + uniform(L1.w_frag), width, width);
                 drop_apply<NT>(*drop, uniform(o.lin[0]), y, g);
             } else {
@@ -88,7 +88,7 @@ DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_
             }
             const PmtLinear& L2 = M->lin[uniform(o.lin[nl - 1])];
             init_bias<NT>(f, packed + uniform(L2.b_pvec), width, g);
-            if constexpr (BF) linear_acc_bf16<NT, NT, true, BF>(f, y, packed + uniform(L2.wb_frag));
+            if constexpr (BF) linear_acc_mx<NT, NT, true, BF>(f, y, packed, L2);
             else linear_acc<NT, NT, true, EXACT, W>(f, y, packed + uniform(L2.w_frag), width, width);
             drop_apply<NT>(*drop, uniform(o.lin[nl - 1]), f, g);
 #pragma unroll
@@ -109,7 +109,7 @@ DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_
                 const PmtLinear& L1 = M->lin[uniform(o.lin[0])];
                 const float* st1 = packed + uniform(L1.w_frag);
                 init_bias<NT>(y, st1 + (uniform(L1.b_pvec) - uniform(L1.w_frag)), width, g);
-                if constexpr (BF) linear_acc_bf16<NT, NT, true, BF>(y, x, packed + uniform(L1.wb_frag));
+                if constexpr (BF) linear_acc_mx<NT, NT, true, BF>(y, x, packed, L1);
                 else linear_acc<NT, NT, true, EXACT, W>(y, x, st1, width, width);
             }
             const PmtLinear& L2 = M->lin[uniform(o.lin[nl - 1])];
@@ -124,7 +124,7 @@ DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_
                     for (int rt = 0; rt < PMT_RT; ++rt) x[rt][t] = x[rt][t] + b;
                 }
             }
-            if constexpr (BF) linear_acc_bf16<NT, NT, true, BF>(x, y, packed + uniform(L2.wb_frag), alpha);
+            if constexpr (BF) linear_acc_mx<NT, NT, true, BF>(x, y, packed, L2, alpha);
             else linear_acc<NT, NT, true, EXACT, W>(x, y, st2, width, width, alpha);
         }
     }

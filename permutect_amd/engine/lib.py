@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("PMT_LIB", os.path.join(_HERE, "libpermutect_amd.so"))  # (PMT_LIB: development builds for A/B runs)
 
 # ---- limits (must match the header) -------------------------------------------------------------------------------
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_WIDTH, MAX_HALF_FFN, MAX_CLUSTERS = 64, 16, 16
 MAX_ROW_INPUT = 128
 MAX_CNN_TAPS = 192
@@ -35,7 +35,7 @@ i32, i64, vp = C.c_int32, C.c_int64, C.c_void_p
 
 class PmtLinear(C.Structure):
     _fields_ = [("in_dim", i32), ("out_dim", i32), ("w_frag", i32), ("wt_frag", i32), ("b_pvec", i32),
-                ("w_src", i32), ("b_src", i32), ("out_split", i32), ("wb_frag", i32), ("wtb_frag", i32), ("emit_tab", i32)]
+                ("w_src", i32), ("b_src", i32), ("out_split", i32), ("wb_frag", i32), ("wtb_frag", i32), ("wh_frag", i32), ("emit_tab", i32)]
 
 
 class PmtOp(C.Structure):
@@ -91,7 +91,7 @@ class PmtBatch(C.Structure):
     _fields_ = [("num_variants", i32), ("num_groups", i32), ("read_format", i32), ("read_row_bytes", i32),
                 ("reads", vp), ("read_index", vp), ("ref_offsets", vp), ("alt_offsets", vp), ("variant_embed", vp),
                 ("group_start", vp), ("group_tile_base", vp), ("total_tiles", i64), ("debug_flags", vp), ("group_span", vp),
-                ("num_groups_dev", vp), ("set_groups", vp), ("dropout_seed", C.c_uint64)]
+                ("num_groups_dev", vp), ("set_groups", vp), ("dropout_seed", C.c_uint64), ("join_fault", vp)]
 
 
 class PmtOutputs(C.Structure):

@@ -171,6 +171,8 @@ class EnginePlan:
             nmt, nkt = (out_v + 15) // 16, (lin.in_dim + 15) // 16
             lin.wb_frag = self._alloc_packed(nmt * ((nkt + 1) // 2) * 3 * 256 + 256)
             lin.wtb_frag = self._alloc_packed(nkt * ((nmt + 1) // 2) * 3 * 256 + 256)
+            # and as two f16 pieces (PmtLinear.wh_frag): the forward's operands (three MFMAs per product instead of six)
+            lin.wh_frag = self._alloc_packed(nmt * ((nkt + 1) // 2) * 2 * 256 + 256)
         # the emit tables (int32 destinations of the dW blocks and the bias rows) lie back to back: a row of the backward's
         # private partial sums mirrors this region entry for entry (pmt_backward: grad_partials)
         # (only the read-set backward emits through tables; the row kernels compute their few destinations)
@@ -187,7 +189,7 @@ class EnginePlan:
         d.theta_size, d.phi_size, d.packed_size = space.size, max(self._phi_off, 4), self._packed_off + 512  # slack: the kernels prefetch two fragments ahead
         # Which kernel instances run is part of the descriptor (the library itself reads no environment).  The parity tests
         # select the non-default instances through these variables, read HERE, once, when the model is lowered.
-        d.force_shape = {"tile": 1, "any": 2, "bf16": 3}.get(os.environ.get("PMT_SHAPE", ""), 0)
+        d.force_shape = {"tile": 1, "any": 2, "bf16": 3, "bf16x3": 5}.get(os.environ.get("PMT_SHAPE", ""), 0)
         d.force_cnn = {"general": 1, "wave": 2, "batched": 3}.get(os.environ.get("PMT_CNN", ""), 0)
         d.cnn_debug = int(os.environ.get("PMT_CNN_DBG", "0"))
         d.dropout_p = max((float(getattr(m, "dropout_p", 0.0)) for m in model.modules() if isinstance(m, M.MLP)), default=0.0)

@@ -14,12 +14,15 @@ from tests.helpers import CASES, config_for, load_case
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["auto", "tile", "any"], autouse=True)
+@pytest.fixture(params=["auto", "bf16x3", "tile", "any"], autouse=True)
 def kernel_shape(request, monkeypatch):
-    """Every case runs three times: with the kernel instance the library picks for the model (for the P0 fixtures ShapeP0X,
-    which has the production widths compiled in), with the tile-exact instance (PMT_SHAPE=tile: ShapeP0, widths read at run
+    """Every case runs four times: with the kernel instance the library picks for the model (for the P0 fixtures ShapeP0XH: the
+    production widths compiled in, products as three f16 MFMAs on two-piece splits), with the round-3 form of that instance
+    (PMT_SHAPE=bf16x3: six bf16 MFMAs on three-piece splits), with the tile-exact instance (PMT_SHAPE=tile: ShapeP0, widths read at run
     time) and with the generic instance (PMT_SHAPE=any); the variable is read ONCE, when the model is lowered (engine/plan.py:
     PmtModel.force_shape / force_cnn), which is why the fixture sets it before `build`."""
+    if request.param == "bf16x3":
+        monkeypatch.setenv("PMT_SHAPE", "bf16x3")
     if request.param == "tile":
         monkeypatch.setenv("PMT_SHAPE", "tile")
         monkeypatch.setenv("PMT_CNN_STASH", "0")  # and the haplotype-CNN backward that recomputes its forward
