@@ -696,6 +696,8 @@ def main():
             line["filter"] = {"metric": "read-sets/sec (filter fwd)", "value": world * args.batch * args.steps / ef,
                               "unit": "read-sets/s", "ms_per_step": 1e3 * ef / args.steps, **sf, "steps": args.steps,
                               "step": "compute_batch_output under inference_mode, same resident batches", "roofline": rf}
+        if reduce_grads is not None:  # what RCCL saw: the driver can check that N ranks took part and the overlap hook fired
+            line["collective"] = reduce_grads.describe()
         if small is not None:
             line["small_batch"] = small
         if stress is not None:

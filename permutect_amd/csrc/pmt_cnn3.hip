@@ -1052,9 +1052,16 @@ static bool cnn3_ws_fits(const C3Cfg* c) {
 extern "C" size_t pmt_cnn3_workspace_floats(const PmtModel* m) {
     C3Cfg f, b;
     if (!m || !cnn3_covers(m, &f, &b) || !cnn3_ws_fits(&b)) return 0;
-    int dev = 0;  // (sized for the calling thread's current device: the workspace is allocated there)
-    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    return (size_t)cnn3_grid(1 << 30, C3_BWD_V, C3_BWD_NW, dev) * cnn3_ws_stride(&b);
+    // One row per workgroup the backward can launch = per compute unit of the device it runs on.  The call has no stream to
+    // name that device and the calling thread's current device may be another one (a rank that holds a different card
+    // current), so the size covers the LARGEST device this process can see: right whichever card the stream belongs to.
+    int ndev = 0, grid = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) ndev = 1;
+    for (int dev = 0; dev < ndev; ++dev) {
+        const int gd = cnn3_grid(1 << 30, C3_BWD_V, C3_BWD_NW, dev);
+        grid = gd > grid ? gd : grid;
+    }
+    return (size_t)grid * cnn3_ws_stride(&b);
 }
 
 extern "C" int pmt_cnn3_try_backward(const PmtModel* model_host, const float* theta, const int64_t* haplotypes, int64_t hap_stride, int32_t n,

@@ -44,7 +44,10 @@ class ReadSetEngine:
         # (the fused optimizer kernel, a captured-graph replay, a collective on the flat buffer)
         self.join_layered = os.environ.get("PMT_LAYERED_JOIN", "1") != "0"
         self.dropout_seed = 0  # this step's dropout masks (draw_dropout_seed; 0 = none)
-        self.join_fault_words = []  # views of the fault words of the joined launches issued so far (check_join_fault)
+        # ONE persistent fault word for every joined launch of this engine (PmtBatch.join_fault): a launch whose bounded wait for
+        # another workgroup gave up stores 1 there and its numbers are wrong.  Read by check_join_fault() wherever the callers
+        # synchronise anyway: end of a training / evaluation epoch, end of a filtering pass, bench.py, the tests.
+        self.join_fault = torch.zeros(1, dtype=torch.int32, device=device)
         self._param_epoch = 0
         self.packed_for = None  # (params_key, phi) the packed weights were built from, under no_grad only
         self.timers = None  # bench.py sets {'pmt_forward': [], 'pmt_backward': []} to collect (start, end) HIP events
@@ -64,10 +67,12 @@ class ReadSetEngine:
             self.timers[name].append((start, end))
 
     def check_join_fault(self):
-        """Synchronises and raises if a joined launch gave up waiting for another workgroup (its results are then wrong)."""
-        words, self.join_fault_words = self.join_fault_words, []
-        if words and bool(torch.stack([w.reshape(()) for w in words]).any().item()):
-            raise L.PmtError("a joined layered launch timed out waiting for the other workgroups of a split read set")
+        """Synchronises and raises if ANY joined launch since the last check gave up waiting for another workgroup (its results,
+        and everything computed from them since, are wrong).  The word is cleared so that a caller may catch and carry on."""
+        if int(self.join_fault.item()) != 0:
+            self.join_fault.zero_()
+            raise L.PmtError("a joined layered launch timed out waiting for the other workgroups of a split read set: the logits / "
+                             "gradients computed since the last check are wrong (PMT_LAYERED_JOIN=0 runs the layered launches instead)")
 
     # ---- parameters -------------------------------------------------------------------------------------------------
     def params_changed(self):
@@ -155,6 +160,7 @@ class ReadSetEngine:
         sets = plan.set_groups_on(self.device) if (getattr(plan, "set_groups", None) is not None and self.join_layered) else None
         bv.set_groups = _ptr(sets)
         bv.dropout_seed = dropout_seed
+        bv.join_fault = self.join_fault.data_ptr()
         keep = (gs, gt, span, ref_off, alt_off, reads, index, variant_embed, sets)
         return bv, keep, plan
 
@@ -183,8 +189,6 @@ class ReadSetEngine:
             L.check(self.lib.pmt_forward_layered(C.byref(d), self.plan.desc_dev.data_ptr(), self.space.theta.data_ptr(),
                                                  phi.data_ptr(), self.plan.packed.data_ptr(), C.byref(bv), C.byref(out),
                                                  _ptr(stash), scratch.data_ptr(), _stream()), "pmt_forward_layered")
-            if bv.set_groups:
-                self.join_fault_words = self.join_fault_words[-7:] + [scratch.view(torch.int32)[-7]]
         else:
             L.check(self.lib.pmt_forward(C.byref(d), self.plan.desc_dev.data_ptr(), self.space.theta.data_ptr(),
                                          phi.data_ptr(), self.plan.packed.data_ptr(), C.byref(bv), C.byref(out),
@@ -211,8 +215,6 @@ class ReadSetEngine:
                                                   self.space.gtheta.data_ptr(), gphi.data_ptr(), gvar.data_ptr(),
                                                   self.plan.grad_partials.data_ptr(), self.plan.partial_rows, _stream()),
                     "pmt_backward_layered")
-            if bv.set_groups:
-                self.join_fault_words = self.join_fault_words[-7:] + [scratch.view(torch.int32)[-7]]
         else:
             L.check(self.lib.pmt_backward(C.byref(d), self.plan.desc_dev.data_ptr(), self.space.theta.data_ptr(),
                                           phi.data_ptr(), self.plan.packed.data_ptr(), C.byref(bv), C.byref(out),

@@ -147,4 +147,5 @@ def make_posterior_mmap(dataset: ReadsDataset, model, batch_size: int, device: O
     if errors:
         raise errors[0]
     assert done == n
+    model.engine().check_join_fault()  # (every float row is home: the device has finished; a timed-out join means wrong logits -> raise)
     return MemoryMappedData(ints_out, floats_out, n, None, 0)

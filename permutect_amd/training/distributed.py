@@ -66,12 +66,24 @@ class BucketedGradAllReduce:
         self.force_active = force_active
         self._pending = None   # (work, late_start)
         self._side = None
-        self.early_reductions = 0  # how many early buckets went out on the side stream (tests)
+        self.early_reductions = 0  # how many early buckets went out on the side stream (tests; bench.py's `collective` record)
+        self.steps = 0             # optimizer steps reduced through __call__
+        self.early_bytes = 0       # bytes of the LAST step's early / late bucket (what bench.py reports)
+        self.late_bytes = 0
 
     def _active(self) -> bool:
         if not (dist.is_available() and dist.is_initialized()):
             return False
         return self.force_active or dist.get_world_size(self.group) > 1
+
+    def describe(self) -> dict:
+        """What the collectives saw, for bench.py's N > 1 lines: the backend and world size as torch.distributed reports them,
+        the early buckets that went out per optimizer step, the bytes of the last step's two buckets."""
+        on = dist.is_available() and dist.is_initialized()
+        return {"backend": dist.get_backend(self.group) if on else None, "world_size": dist.get_world_size(self.group) if on else 1,
+                "steps_reduced": self.steps, "early_buckets_per_step": (self.early_reductions / self.steps) if self.steps else 0.0,
+                "early_bytes": self.early_bytes, "late_bytes": self.late_bytes, "op": "SUM",
+                "early_bucket_on_side_stream": self._side is not None}
 
     def early(self, flat_grad: torch.Tensor, late_start: int) -> None:
         if not self._active() or late_start <= 0:
@@ -90,15 +102,34 @@ class BucketedGradAllReduce:
             work = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending = (work, late_start)
         self.early_reductions += 1
+        self.early_bytes = bucket.numel() * bucket.element_size()
+
+    def reset(self) -> None:
+        """Drop a reduction left pending by a step that was abandoned between loss.backward() and optimizer.step() (an exception
+        caught by the caller, a gradient probe with the hook installed): waits for the early bucket's collective -- every rank
+        issued it, so it completes -- and forgets it, after which the next backward may issue a new one.  FusedClipAdamW.zero_grad
+        calls this, so an abandoned step cannot poison the hook for good.  NOTE the raise in `early` is rank-local: a rank that
+        raises there has left the other ranks inside their all-reduce; callers that catch it must tear the process group down (the
+        training loop does not catch it)."""
+        if self._pending is None:
+            return
+        work, _ = self._pending
+        self._pending = None
+        work.wait()
+        if self._side is not None:
+            torch.cuda.current_stream(self._side.device).wait_stream(self._side)
 
     def __call__(self, flat_grad: torch.Tensor) -> None:
         if not self._active():
             return
+        self.steps += 1
         if self._pending is None:
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            self.early_bytes, self.late_bytes = 0, flat_grad.numel() * flat_grad.element_size()
             return
         work, late_start = self._pending
         self._pending = None
+        self.late_bytes = (flat_grad.numel() - late_start) * flat_grad.element_size()
         if late_start < flat_grad.numel():
             dist.all_reduce(flat_grad[late_start:], op=dist.ReduceOp.SUM, group=self.group)
         work.wait()  # CUDA: the current stream waits for the side-stream reduction; CPU: blocks

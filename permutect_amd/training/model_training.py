@@ -173,6 +173,7 @@ def train_artifact_model(model, train_dataset: ReadsDataset, valid_dataset: Opti
             if dist is not None:
                 recorder.all_reduce(dist)
             mean_loss = recorder.mean_loss(PRIMARY)  # the epoch's one host sync
+            model.engine().check_join_fault()  # (a split read set whose workgroups did not meet in time: the epoch's numbers are wrong -> raise)
             history.append((epoch, epoch_type.name, mean_loss))
             log(f"epoch {epoch} {epoch_type.name}: mean semisupervised loss {mean_loss:.5f}, lr {opt.param_groups[0]['lr']:.2e}")
             if epoch_type == Epoch.VALID and evaluate_every_epoch:
@@ -187,6 +188,7 @@ def train_artifact_model(model, train_dataset: ReadsDataset, valid_dataset: Opti
                     seed=seed * 1000 + epoch, fix_alt_gather=fix_alt_gather)
                 if dist is not None:
                     ev.all_reduce(dist)  # every tally (histogram, call counts, logit sums) in one collective
+                model.engine().check_join_fault()
                 log(f"epoch {epoch} evaluation: accuracy train {ev.accuracy(0):.4f}, valid {ev.accuracy(1):.4f}")
                 evaluations.append((epoch, ev.accuracy(0), ev.accuracy(1)))
             if epoch_type == Epoch.TRAIN:

@@ -35,6 +35,9 @@ class FusedClipAdamW:
 
     def zero_grad(self, set_to_none: bool = True):
         space = self._bind()
+        hook = getattr(getattr(self.model, "_engine", None), "grad_hook", None)
+        if hook is not None and hasattr(hook, "reset"):
+            hook.reset()  # (a step abandoned between backward and step left its early bucket pending: training/distributed.py)
         space.gtheta.zero_()
         space.bind_grads()
 

@@ -16,11 +16,19 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def free_port() -> int:
+    """a port nobody listens on right now (fixed ports collide under parallel pytest runs or with a stale worker)"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def test_two_rank_training_keeps_replicas_identical():
     with tempfile.TemporaryDirectory() as d:
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-               "--master-port", "29631", os.path.join(ROOT, "tests", "dp_worker.py"), d]
+               "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dp_worker.py"), d]
         res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
         r0, r1 = (torch.load(os.path.join(d, f"rank{r}.pt"), weights_only=False) for r in range(2))
@@ -41,7 +49,7 @@ def test_rccl_overlapped_reduction_on_one_card():
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "rccl.pt")
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT="29647")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
         res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_worker.py"), out], cwd=ROOT, env=env,
                              capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
@@ -53,3 +61,34 @@ def test_rccl_overlapped_reduction_on_one_card():
     diff = float((r["plain"] - r["hooked"]).abs().max())
     assert diff <= max(4 * noise, 2e-7 * float(r["plain"].abs().max())), (diff, noise)
     np.testing.assert_allclose(r["hooked_losses"], r["plain_losses"], rtol=1e-5)
+
+
+def _bench_line(*flags, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]  # ONE JSON line, from rank 0
+    import json
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("extra", [(), ("--data", "loader", "--dataset-variants", "32768", "--chunk-variants", "16384"), ("--depth", "stress", "--batch", "128")],
+                         ids=["resident", "loader", "stress"])
+def test_bench_two_rank_path(extra):
+    """bench.py's own N > 1 path (the one the driver launches on the 8-GPU node) must not run for the first time there: two ranks
+    share this box's one card (--rehearse: gloo instead of RCCL, the numbers mean nothing), spawned the way `--gpus N` spawns them.
+    The line must say two ranks took part, count both ranks' read sets, and show that the overlap hook fired once per step."""
+    batch = "128" if "stress" in extra else "4096"
+    flags = ["--gpus", "2", "--rehearse", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
+    if "--batch" not in extra:
+        flags += ["--batch", batch]
+    line = _bench_line(*flags, *extra)
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["scaling"] == "weak"
+    assert line["steps"] == 3 and line["warmup"] == 1
+    per_rank = int(batch) * 3 / (line["ms_per_step"] * 3e-3)
+    assert abs(line["value"] - 2 * per_rank) <= 1e-6 * line["value"]  # whole-job rate = both ranks' read sets / max-over-ranks time
+    c = line["collective"]
+    assert c["world_size"] == 2 and c["backend"] == "gloo" and c["op"] == "SUM"
+    assert c["early_buckets_per_step"] == 1.0 and c["early_bytes"] > c["late_bytes"] > 0 and c["early_bucket_on_side_stream"]
+    assert "cpu_baseline" not in line and line["filter"]["value"] > 0

@@ -136,3 +136,35 @@ def test_joined_path_on_forced_small_groups_matches_reference():
     gref = np.concatenate([z["grad/" + n].ravel() for n in grads])
     gour = np.concatenate([g.ravel() for g in grads.values()])
     assert np.linalg.norm(gour - gref) <= 1e-4 * np.linalg.norm(gref)
+
+
+def test_a_join_that_gives_up_is_reported_through_the_persistent_fault_word():
+    """a wait that times out carries on with partial sums -- wrong numbers -- so it must not pass silently.  One variant
+    is told to expect ONE MORE group than covers it: its groups' bounded wait gives up (no hang), the kernels raise the engine's
+    persistent fault word (PmtBatch.join_fault), and the host raises at its next check -- also when other, healthy launches ran in
+    between (the old per-launch words kept only the last eight and were read by tests only).  The check clears the word."""
+    from permutect_amd.engine.lib import PmtError
+    _, sd, _ = load_case("p0_b16")
+    nref, nalt = _stress_counts(np.random.default_rng(8), 6, 6)
+    ints, floats, packed = _arrays(nref, nalt, seed=43)
+    model, dev = build("p0_b16", sd)
+    eng = model.engine()
+    good = Batch.from_arrays(ints, floats, packed).copy_to(dev)
+    bad = Batch.from_arrays(ints, floats, packed).copy_to(dev)
+    plan = bad.plan(allow_split=True)
+    assert plan.layered and plan.set_groups is not None
+    v = int(np.argmax(plan.set_groups))
+    plan.set_groups = plan.set_groups.copy()
+    plan.set_groups[v] += 1  # a group that will never arrive
+    model.eval()
+    with torch.inference_mode():
+        model.compute_batch_output(bad)
+        for _ in range(10):  # healthy launches afterwards must not hide it
+            model.compute_batch_output(good)
+    with pytest.raises(PmtError, match="timed out"):
+        eng.check_join_fault()
+    eng.check_join_fault()  # cleared: the next check passes
+    with torch.inference_mode():
+        out = model.compute_batch_output(good)
+    eng.check_join_fault()
+    assert torch.isfinite(out.logits_b).all()
