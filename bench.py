@@ -415,10 +415,12 @@ def main():
     if args.mode in ("both", "train"):
         elapsed, kms, per_step = timed("train", batches, args.steps, args.warmup)
         r = roofline("pmt_backward_kernel", 2.0 * fwd_flops, kms["pmt_backward"])  # dgrad + wgrad; in-kernel recompute not counted
-        r["matrix_pipe"] = ("fp32 accumulation on the bf16 matrix pipe.  Forward (both kernels): fp32-equivalent, six bf16 MFMAs on "
-                            "three-piece splits of both operands.  Backward: dgrad, recompute and wgrad as three bf16 MFMAs on two-piece "
-                            "splits (16 significant bits per operand): gradients 7 - 8e-6 from an fp64 evaluation, the reference's own fp32 "
-                            "arithmetic 7 - 9e-6 (tests/test_scale_gpu.py); `peak` is the dense fp32 MFMA rate"
+        r["matrix_pipe"] = ("fp32 accumulation on the 16-bit matrix pipes.  Forward (both kernels): fp32-equivalent, three f16 MFMAs on two-piece "
+                            "splits of both operands with the low piece scaled by 2^12 (23 significant bits per operand; six bf16 MFMAs on "
+                            "three-piece splits until round 3, PMT_SHAPE=bf16x3).  Backward: dgrad, recompute and wgrad as three bf16 MFMAs on "
+                            "two-piece splits (16 significant bits per operand, `bwd_operand_bits`): gradients 7 - 8e-6 from an fp64 evaluation, "
+                            "the reference's own fp32 arithmetic 7 - 9e-6 (tests/test_scale_gpu.py); over a 100-step trajectory no farther from "
+                            "fp64 than the fp32 reference or the six-MFMA build (tests/test_trajectory_gpu.py); `peak` is the dense fp32 MFMA rate"
                             if args.dtype == "f32" else
                             "plain bf16: one bf16 MFMA per product (fp32 accumulation), single roundings of both operands; `peak` stays the "
                             "dense fp32 MFMA rate so that the two modes read on one scale (the bf16 dense peak is ~2.5 PFLOP/s)")
@@ -624,6 +626,22 @@ def main():
              f"{n5 / ep / 1e6:.1f} M read-sets/s = {loader['filter_with_posterior_handoff']['vs_resident']:.2f} x")
         del ds1, ds5, post, li, lf, lp
 
+    # ---- the same training step on the build whose backward runs six-MFMA (fp32-equivalent) products: what the 16-bit operands buy ----
+    six = None
+    alt6 = os.path.join(ROOT, "permutect_amd", "libpermutect_amd_alt6.so")
+    if (world == 1 and rank == 0 and not args.no_extras and args.data == "resident" and args.depth == "wgs" and args.mode == "both"
+            and args.dtype == "f32" and os.path.exists(alt6) and "PMT_LIB" not in os.environ):
+        torch.cuda.synchronize()
+        res = subprocess.run([sys.executable, os.path.abspath(__file__), "--mode", "train", "--steps", "100", "--warmup", "20", "--no-extras",
+                              "--no-cpu-baseline", "--batch", str(args.batch)], env=dict(os.environ, PMT_LIB=alt6), stdout=subprocess.PIPE, text=True)
+        lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+        if res.returncode == 0 and lines:
+            a6 = json.loads(lines[0])
+            six = {"build": "libpermutect_amd_alt6.so: -DPMT_DGRAD_PIECES=3 -DPMT_RECOMPUTE_PIECES=3 (backward products fp32-equivalent)",
+                   "ms_per_step": a6["ms_per_step"], "backward_kernel_ms": a6["roofline"]["kernel_ms"],
+                   "vs_default_step": a6["ms_per_step"] / (1e3 * results["train"][0] / args.steps)}
+            note(f"six-MFMA backward build: {six['ms_per_step']:.3f} ms/step (kernel {six['backward_kernel_ms']:.3f} ms) = {six['vs_default_step']:.3f} x the default step")
+
     # ---- parity of what was just timed: EVERY variant of resident batch 0 (one whole launch) against the CPU oracle ------------
     parity = None
     if rank == 0 and not args.no_extras and first_host is not None and args.depth == "wgs" and batches:
@@ -681,7 +699,9 @@ def main():
             "metric": "read-sets/sec (train fwd+bwd)" if head == "train" else "read-sets/sec (filter fwd)",
             "value": value, "unit": "read-sets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, **stats, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic" if args.data == "resident" else "synthetic, streamed through the device chunk loader (H2D inclusive)",
+            "dtype": args.dtype if args.dtype != "f32" else "f32 (fp32 accumulate; fwd: 2 x f16 pieces per operand = 23 bits; bwd: 2 x bf16 pieces = 16 bits)",
+            "fwd_operand_bits": 23 if args.dtype == "f32" else 8, "bwd_operand_bits": 16 if args.dtype == "f32" else 8,
+            "data": "synthetic" if args.data == "resident" else "synthetic, streamed through the device chunk loader (H2D inclusive)",
             "config": {"workload": ("train_model" if head == "train" else "filter_variants forward")
                        + f" on synthetic 1M-variant-scale {args.depth.upper()} ReadSet batches, hyperparameters P0 (59845 params)",
                        "batch_read_sets_per_gpu": args.batch, "mean_reads_per_set": reads_per_batch / args.batch,
@@ -706,6 +726,8 @@ def main():
             line["loader"] = loader
         if dropout is not None:
             line["dropout"] = dropout
+        if six is not None:
+            line["six_mfma_backward"] = six
         if parity is not None:
             line["parity_check_max_logit_err"] = parity["max_logit_err"]
             line["parity_check"] = parity

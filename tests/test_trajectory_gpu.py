@@ -1,0 +1,118 @@
+"""A TRAJECTORY, not one step (reference training/model_training.py:151-165, misc_utils.py:125-129): 100
+optimizer steps of the HIP training path on a fixed sequence of seeded batches (B = 512, production hyperparameters, lr 1e-3, weight
+decay 0.01, no dropout, no downsampling) against the oracle stepped the same way -- `train_step_grads` + `clip_and_adamw` -- in
+fp32 (the reference's arithmetic) and in fp64 (the yardstick that says how far fp32 arithmetic itself drifts over 100 Adam steps).
+
+What can be asserted, and what cannot: an Adam trajectory amplifies rounding noise -- one step moves a parameter by ~lr = 1e-3
+whatever the size of its gradient, and an element whose gradient is near zero flips its normalised step from -lr to +lr on fp32
+noise.  Measured (gpurun_out/parity_errors.jsonl -> profiles/r04_parity_errors.jsonl): the fp32 ORACLE ITSELF ends 3.2e-3 (relative
+L2 of the parameter vector) from the fp64 oracle after 100 steps, its per-step loss up to 2.3 % off.  No fp32 implementation can be
+held to "1e-3 relative at every step" against another one; what is held:
+  * the first ten steps, before the amplification: every loss within 1e-3 relative of the fp32 oracle's;
+  * the whole trajectory: the HIP path is no farther from the fp64 trajectory than 1.5 x the fp32 oracle is -- the worst per-step
+    loss error and the final parameter vector both;
+  * and, when a build of the library with six-MFMA backward products lies next to the default one
+(`make -C permutect_amd/csrc alt6`: -DPMT_DGRAD_PIECES=3 -DPMT_RECOMPUTE_PIECES=3), that the default build is no farther from the
+oracle than 1.5 x that build.  Everything measured goes to gpurun_out/parity_errors.jsonl."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import artifact_oracle as O
+from tests.helpers import config_for
+from tests.trajectory_worker import BATCH, LR, NBATCH, STEPS, WD, initial_state_dict, make_batches
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ALT6 = os.path.join(ROOT, "permutect_amd", "libpermutect_amd_alt6.so")
+
+
+def oracle_trajectory(dtype):
+    cfg = config_for("p0")
+    sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in initial_state_dict().items()}
+    names = [k for k, v in sd.items() if v.is_floating_point() and not k.endswith(".base")]
+    m = [torch.zeros_like(sd[k]) for k in names]
+    v = [torch.zeros_like(sd[k]) for k in names]
+    batches = []
+    for ints, floats, packed in make_batches():
+        i64 = torch.from_numpy(ints.astype(np.int64))
+        batches.append(dict(reads_re=torch.from_numpy(O.decode_packed_reads(packed).astype(np.float32)).to(dtype), nref=i64[:, O.REF_COUNT],
+                            nalt=i64[:, O.ALT_COUNT], labels=i64[:, O.LABEL], sources=i64[:, O.SOURCE],
+                            info_be=torch.from_numpy(floats[:, O.INFO_START:].astype(np.float32)).to(dtype), haplotypes_bh=i64[:, O.HAPLOTYPES_START:]))
+    old = O.COMPUTE_DTYPE
+    O.COMPUTE_DTYPE = dtype
+    losses = []
+    try:
+        for step in range(STEPS):
+            _, ls, grads = O.train_step_grads(sd, cfg, batches[step % NBATCH])
+            losses.append(float(ls["total_loss"].detach()))
+            with torch.no_grad():
+                O.clip_and_adamw([sd[k] for k in names], [grads[k] for k in names], m, v, step + 1, LR, WD)
+    finally:
+        O.COMPUTE_DTYPE = old
+    return np.array(losses), {k: sd[k].double() for k in names}
+
+
+def hip_trajectory(lib=None):
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "traj.pt")
+        env = dict(os.environ, OMP_NUM_THREADS="4")
+        if lib is not None:
+            env["PMT_LIB"] = lib
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "trajectory_worker.py"), out], cwd=ROOT, env=env, capture_output=True,
+                             text=True, timeout=900)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+        r = torch.load(out, weights_only=False)
+    return r["losses"], {k: v.double() for k, v in r["params"].items()}
+
+
+def rel_l2(a, b, names):
+    fa = torch.cat([a[k].reshape(-1) for k in names])
+    fb = torch.cat([b[k].reshape(-1) for k in names])
+    return float((fa - fb).norm() / fb.norm())
+
+
+def test_hundred_step_trajectory_stays_with_the_oracle():
+    before = torch.get_num_threads()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    try:
+        l32, p32 = oracle_trajectory(torch.float32)
+        l64, p64 = oracle_trajectory(torch.float64)
+    finally:
+        torch.set_num_threads(before)
+    lh, ph = hip_trajectory()
+    names = list(p32)
+    assert set(names) == set(ph)
+    rec = {"test": "trajectory_100_steps", "batch": BATCH, "steps": STEPS, "lr": LR,
+           "max_rel_loss_err_hip_vs_fp32_oracle": float(np.max(np.abs(lh - l32) / np.abs(l32))),
+           "max_rel_loss_err_hip_vs_fp64_oracle": float(np.max(np.abs(lh - l64) / np.abs(l64))),
+           "max_rel_loss_err_fp32_oracle_vs_fp64_oracle": float(np.max(np.abs(l32 - l64) / np.abs(l64))),
+           "params_rel_l2_hip_vs_fp32_oracle": rel_l2(ph, p32, names), "params_rel_l2_hip_vs_fp64_oracle": rel_l2(ph, p64, names),
+           "params_rel_l2_fp32_oracle_vs_fp64_oracle": rel_l2(p32, p64, names),
+           "loss_first_last": [float(l32[0]), float(l32[-1])],
+           "rel_loss_err_hip_vs_fp32_oracle_at_steps_1_5_10_25_50_100": [float(abs(lh[i] - l32[i]) / abs(l32[i])) for i in (0, 4, 9, 24, 49, 99)],
+           "rel_loss_err_fp32_oracle_vs_fp64_at_steps_1_5_10_25_50_100": [float(abs(l32[i] - l64[i]) / abs(l64[i])) for i in (0, 4, 9, 24, 49, 99)],
+           "max_rel_loss_err_first_10_steps_hip_vs_fp32_oracle": float(np.max(np.abs(lh[:10] - l32[:10]) / np.abs(l32[:10])))}
+    if os.path.exists(ALT6):
+        la, pa = hip_trajectory(ALT6)
+        rec.update(alt6_max_rel_loss_err_vs_fp32_oracle=float(np.max(np.abs(la - l32) / np.abs(l32))),
+                   alt6_params_rel_l2_vs_fp32_oracle=rel_l2(pa, p32, names), alt6_params_rel_l2_vs_fp64_oracle=rel_l2(pa, p64, names),
+                   params_rel_l2_hip_vs_alt6=rel_l2(ph, pa, names))
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "parity_errors.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+    assert l32[-1] < 0.9 * l32[0], rec  # (the model is learning over these 100 steps: a trajectory worth comparing)
+    assert rec["max_rel_loss_err_first_10_steps_hip_vs_fp32_oracle"] <= 1e-3, rec
+    assert rec["max_rel_loss_err_hip_vs_fp64_oracle"] <= 1.5 * rec["max_rel_loss_err_fp32_oracle_vs_fp64_oracle"] + 1e-4, rec
+    assert rec["params_rel_l2_hip_vs_fp64_oracle"] <= 1.5 * rec["params_rel_l2_fp32_oracle_vs_fp64_oracle"] + 1e-5, rec
+    if "alt6_params_rel_l2_vs_fp64_oracle" in rec:
+        assert rec["params_rel_l2_hip_vs_fp64_oracle"] <= 1.5 * rec["alt6_params_rel_l2_vs_fp64_oracle"] + 1e-5, rec
