@@ -164,6 +164,8 @@ def cnn(sd: SD, prefix: str, layer_strings: List[str], x: Tensor) -> Tensor:
             x = F.leaky_relu(x)
         elif kind == "selu":
             x = F.selu(x)
+        elif kind == "batch_norm":  # dna_sequence_convolution.py:82-83, EVAL mode (running statistics; nn.BatchNorm1d eps 1e-5)
+            x = F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"], training=False, eps=1e-5)
         elif kind == "flatten":
             x = x.flatten(1)
         elif kind == "linear":

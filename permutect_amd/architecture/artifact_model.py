@@ -162,6 +162,10 @@ class ArtifactModel(nn.Module):
         return VariantEmbedFunction.apply(eng, batch.get_info_be(), batch.get_haplotypes_bs(), eng.trigger)
 
     def _encode(self, batch: Batch):
+        if self.training and any(isinstance(m, nn.BatchNorm1d) for m in self.haplotypes_cnn.modules()):
+            # the reference's `batch_norm` token of the haplotype CNN (dna_sequence_convolution.py:82-83): same story as below
+            raise NotImplementedError("permutect_amd runs a haplotype CNN with batch_norm tokens in eval mode only (model.eval() under "
+                                      "no_grad / inference_mode: filter_variants, evaluation); training with BatchNorm statistics is not built")
         if self.training and self._params.batch_normalize:
             # reference mlp.py:52-53: BatchNorm1d normalises with the statistics of the whole batch in train mode.  The kernels run its
             # eval-mode form (running statistics folded into the Linear behind it, engine/plan.py): refuse, never train on the wrong map.

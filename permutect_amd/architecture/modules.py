@@ -258,7 +258,7 @@ def _pool_len(n, kernel_size=1, stride=None, padding=0, dilation=1, **_):
 
 
 class DNASequenceConvolution(nn.Module):
-    """Layer-string grammar: `<type>[/key=int]...`, types convolution | pool | leaky_relu | selu | flatten | linear."""
+    """Layer-string grammar: `<type>[/key=int]...`, types convolution | pool | leaky_relu | selu | batch_norm | flatten | linear."""
 
     def __init__(self, layer_strings: List[str], sequence_length: int):
         super().__init__()
@@ -279,7 +279,10 @@ class DNASequenceConvolution(nn.Module):
             elif kind == "selu":
                 layers.append(nn.SELU())
             elif kind == "batch_norm":
-                raise NotImplementedError("batch_norm in the haplotype CNN is not supported by permutect_amd")
+                # reference dna_sequence_convolution.py:82-83.  The kernels have no such layer: in eval mode the engine folds its
+                # per-channel affine map into the convolution / linear next to it (engine/plan.py: _lower_cnn, cnn_bn_folds); training
+                # with batch statistics is refused (ArtifactModel.compute_batch_output)
+                layers.append(nn.BatchNorm1d(channels))
             elif kind == "flatten":
                 layers.append(nn.Flatten())
                 channels, length = channels * length, 1

@@ -98,6 +98,7 @@ class EnginePlan:
         self._phi_prog = None
         self.phi_layout: List[tuple] = []  # (name, offset, numel)
         self.bn_folds: List[tuple] = []    # (BatchNorm1d, Linear) pairs folded into phi, in phi order (materialize_phi)
+        self.cnn_bn_folds: List[tuple] = []  # haplotype CNN: (BatchNorm1d, Conv1d | Linear, "out" | "in", features per BN channel), stack order
 
         read_mlp: M.MLP = model.read_embedding
         enc: M.GatedRefAltMLP = model.ref_alt_reads_encoder
@@ -339,7 +340,7 @@ class EnginePlan:
                     o.lin[t] = self._add_linear(lin, bn=bn_of.get(lin))
 
     def _lower_cnn(self, dst: L.PmtCnn, cnn: M.DNASequenceConvolution, seq_len: int):
-        layers = list(cnn._model.children())
+        layers = self._strip_cnn_batchnorm(list(cnn._model.children()))
         if len(layers) > L.MAX_CNN_LAYERS:
             raise L.PmtError(f"haplotype CNN with {len(layers)} layers exceeds the kernel limit {L.MAX_CNN_LAYERS}")
         ch, length = M.INITIAL_NUM_CHANNELS, seq_len
@@ -388,6 +389,60 @@ class EnginePlan:
             max_act = max(max_act, ch * length)
         dst.n_layers, dst.seq_len, dst.out_dim = len(layers), seq_len, ch * length
         dst.max_act, dst.sum_act = max_act, off
+
+    def _strip_cnn_batchnorm(self, layers):
+        """The reference's `batch_norm` token (dna_sequence_convolution.py:82-83) in EVAL mode is x -> s x + t per channel, s = w /
+        sqrt(running_var + eps), t = b - running_mean s.  The kernels have no such layer; every BatchNorm1d is folded into a
+        neighbour (recorded in cnn_bn_folds, applied by folded_cnn_theta):
+          "out": directly behind a Conv1d / Linear -> that layer's output rows:   W' = diag(s) W,  b' = s b + t;
+          "in":  otherwise in front of (a Flatten and) an un-padded Conv1d / a Linear -> its input channels:  W' = W diag(s),
+                 b' = b + W t  (a zero-padded convolution would see t only inside the sequence: refused).
+        Returns the layer list without the BatchNorms.  Training with batch statistics is refused by ArtifactModel."""
+        kept = []
+        for i, layer in enumerate(layers):
+            if not isinstance(layer, nn.BatchNorm1d):
+                kept.append(layer)
+                continue
+            prev = layers[i - 1] if i > 0 else None
+            if isinstance(prev, (nn.Conv1d, nn.Linear)):
+                self.cnn_bn_folds.append((layer, prev, "out", 1))
+                continue
+            j = i + 1
+            while j < len(layers) and isinstance(layers[j], nn.Flatten):
+                j += 1
+            nxt = layers[j] if j < len(layers) else None
+            if isinstance(nxt, nn.Conv1d) and nxt.padding[0] == 0 and nxt.in_channels == layer.num_features:
+                self.cnn_bn_folds.append((layer, nxt, "in", 1))
+            elif isinstance(nxt, nn.Linear) and nxt.in_features % layer.num_features == 0:
+                self.cnn_bn_folds.append((layer, nxt, "in", nxt.in_features // layer.num_features))
+            else:
+                raise L.PmtError("a batch_norm token of the haplotype CNN that is neither directly behind a convolution / linear nor in "
+                                 "front of an un-padded convolution / a linear cannot be folded (permutect_amd runs it in eval mode only)")
+        return kept
+
+    def folded_cnn_theta(self, theta: torch.Tensor) -> torch.Tensor:
+        """A copy of the flat parameter buffer in which the haplotype CNN's convolutions / linear carry their folded BatchNorms
+        (eval mode; cnn_bn_folds in stack order, so an input-side fold of a layer precedes its output-side fold)."""
+        out = theta.detach().clone()
+        space = self.space
+        with torch.no_grad():
+            for bn, layer, side, per in self.cnn_bn_folds:
+                s = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                t = bn.bias - bn.running_mean * s
+                wo, bo = space.offset_of(layer.weight), space.offset_of(layer.bias)
+                w = out[wo:wo + layer.weight.numel()].view_as(layer.weight)
+                b = out[bo:bo + layer.bias.numel()]
+                if side == "out":
+                    b.mul_(s).add_(t)
+                    w.mul_(s.view(-1, *([1] * (w.dim() - 1))))
+                elif w.dim() == 3:  # Conv1d [out][in][k]
+                    b.add_((w * t.view(1, -1, 1)).sum(dim=(1, 2)))
+                    w.mul_(s.view(1, -1, 1))
+                else:               # Linear [out][in], `per` consecutive input features per BatchNorm channel (flatten: c * len + p)
+                    se, te = s.repeat_interleave(per), t.repeat_interleave(per)
+                    b.add_(w @ te)
+                    w.mul_(se.view(1, -1))
+        return out
 
     # ---- phi ------------------------------------------------------------------------------------------------------
     def phi_program(self, model):

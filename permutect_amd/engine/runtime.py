@@ -82,7 +82,8 @@ class ReadSetEngine:
         # (a Parameter re-bound with `p.data = view` keeps its OWN version counter: in-place writes through a parameter --
         #  load_state_dict, a torch optimizer -- show up there, writes to the flat buffer on theta's)
         try:
-            stats = sum(bn.running_mean._version + bn.running_var._version for bn, _ in self.plan.bn_folds)  # (folded into phi: buffers, not leaves)
+            stats = sum(bn.running_mean._version + bn.running_var._version  # (folded into phi / the CNN's weights: buffers, not leaves)
+                        for bn in [f[0] for f in self.plan.bn_folds] + [f[0] for f in self.plan.cnn_bn_folds])
             return (self._param_epoch, self.space.theta._version, sum(p._version for p in self.space.params), stats)
         except RuntimeError:  # inference tensors (a model built under torch.inference_mode) carry no version counter:
             return None        # nothing can be proved unchanged, so nothing is reused
@@ -91,6 +92,22 @@ class ReadSetEngine:
         d = self.plan
         L.check(self.lib.pmt_pack_params(C.byref(d.desc), d.desc_dev.data_ptr(), self.space.theta.data_ptr(),
                                          phi.data_ptr(), d.packed.data_ptr(), _stream()), "pmt_pack_params")
+
+    def cnn_params(self) -> Tuple[Tensor, Tensor]:
+        """(theta, packed) as the haplotype-CNN kernels read them.  A stack with `batch_norm` tokens (eval mode only) reads a COPY of
+        the flat buffer in which the BatchNorms are folded into their neighbouring convolutions / linear, and fragments packed from
+        that copy (plan.folded_cnn_theta); rebuilt when the parameters or the running statistics change."""
+        if not self.plan.cnn_bn_folds:
+            return self.space.theta, self.plan.packed
+        key = self.params_key()
+        if key is None or getattr(self, "_cnn_fold_key", None) != key:
+            theta_f = self.plan.folded_cnn_theta(self.space.theta)
+            packed_f = torch.zeros_like(self.plan.packed)
+            phi0 = torch.zeros(max(self.plan.desc.phi_size, 4), dtype=torch.float32, device=self.device)  # (the CNN's linears read theta only)
+            L.check(self.lib.pmt_pack_params(C.byref(self.plan.desc), self.plan.desc_dev.data_ptr(), theta_f.data_ptr(), phi0.data_ptr(),
+                                             packed_f.data_ptr(), _stream()), "pmt_pack_params")
+            self._cnn_fold, self._cnn_fold_key = (theta_f, packed_f), key
+        return self._cnn_fold
 
     def cnn_workspace(self) -> Optional[Tensor]:
         """private rows for the haplotype CNN's weight-gradient sums (pmt_cnn_backward: workspace); PMT_CNN_WORKSPACE=0: atomics"""
@@ -347,8 +364,12 @@ class HaplotypeCnnFunction(torch.autograd.Function):
         # (PMT_CNN_STASH=0: let the backward recompute the layer outputs instead; the parity tests cover both)
         per = engine.lib.pmt_cnn_stash_floats(C.byref(d)) if train and os.environ.get("PMT_CNN_STASH", "1") != "0" else 0
         stash = torch.empty(n * per, dtype=torch.float32, device=engine.device) if per > 0 and n > 0 else None
-        L.check(engine.lib.pmt_cnn_forward(C.byref(d), engine.plan.desc_dev.data_ptr(), engine.space.theta.data_ptr(),
-                                           engine.plan.packed.data_ptr(), hap.data_ptr(), hap.stride(0), n, out.data_ptr(), out.stride(0),
+        if train and engine.plan.cnn_bn_folds:
+            raise NotImplementedError("a haplotype CNN with batch_norm tokens runs under no_grad / inference_mode only (its BatchNorms are folded "
+                                      "into the neighbouring layers' weights); a backward through it is not built")
+        cnn_theta, cnn_packed = engine.cnn_params()
+        L.check(engine.lib.pmt_cnn_forward(C.byref(d), engine.plan.desc_dev.data_ptr(), cnn_theta.data_ptr(),
+                                           cnn_packed.data_ptr(), hap.data_ptr(), hap.stride(0), n, out.data_ptr(), out.stride(0),
                                            _ptr(stash), _stream()),
                 "pmt_cnn_forward")
         ctx.engine, ctx.train, ctx.stash = engine, train, stash
@@ -399,8 +420,12 @@ class VariantEmbedFunction(torch.autograd.Function):
         L.check(lib.pmt_rows_forward(C.byref(d), engine.plan.desc_dev.data_ptr(), L.ROWS_INFO, engine.space.theta.data_ptr(),
                                      engine.plan.packed.data_ptr(), x.data_ptr(), x.stride(0), n, ve.data_ptr(), ve.stride(0),
                                      _ptr(rows_stash), engine.dropout_seed, _stream()), "pmt_rows_forward")
-        L.check(lib.pmt_cnn_forward(C.byref(d), engine.plan.desc_dev.data_ptr(), engine.space.theta.data_ptr(),
-                                    engine.plan.packed.data_ptr(), hap.data_ptr(), hap.stride(0), n, ve.data_ptr() + 4 * e_info, ve.stride(0),
+        if train and engine.plan.cnn_bn_folds:
+            raise NotImplementedError("a haplotype CNN with batch_norm tokens runs under no_grad / inference_mode only (its BatchNorms are folded "
+                                      "into the neighbouring layers' weights); a backward through it is not built")
+        cnn_theta, cnn_packed = engine.cnn_params()
+        L.check(lib.pmt_cnn_forward(C.byref(d), engine.plan.desc_dev.data_ptr(), cnn_theta.data_ptr(),
+                                    cnn_packed.data_ptr(), hap.data_ptr(), hap.stride(0), n, ve.data_ptr() + 4 * e_info, ve.stride(0),
                                     _ptr(cnn_stash), _stream()), "pmt_cnn_forward")
         ctx.engine, ctx.train, ctx.dropout_seed, ctx.e_info = engine, train, engine.dropout_seed, e_info
         ctx.hap, ctx.cnn_stash = hap, cnn_stash

@@ -98,6 +98,21 @@ T0_CNN_OPTIONS = [
     "flatten",
     "linear/out_features=10",
 ]
+# the production stack with the reference's `batch_norm` token in its three foldable places: behind a convolution (folds into that
+# convolution's output rows), in front of an un-padded convolution (into its input channels) and between flatten and the linear
+# (per flattened feature, into the linear's columns): eval mode only (tests/golden/p0_cnn_batchnorm_eval.npz)
+P0_CNN_BATCHNORM = [
+    "convolution/kernel_size=3/out_channels=32",
+    "batch_norm",
+    "pool/kernel_size=2",
+    "leaky_relu",
+    "batch_norm",
+    "convolution/kernel_size=3/out_channels=32",
+    "leaky_relu",
+    "flatten",
+    "batch_norm",
+    "linear/out_features=10",
+]
 T0_CNN = [
     "convolution/kernel_size=3/out_channels=64",
     "pool/kernel_size=2",

@@ -42,7 +42,7 @@ from permutect.data.datum import Data, Datum  # noqa: E402
 from permutect.misc_utils import backpropagate  # noqa: E402
 from permutect.parameters import ModelParameters  # noqa: E402
 
-from permutect_amd.parameters import P0_CNN, P0_CNN_LEGACY, T0_CNN, T0_CNN_OPTIONS  # noqa: E402  (plain lists of layer strings)
+from permutect_amd.parameters import P0_CNN, P0_CNN_BATCHNORM, P0_CNN_LEGACY, T0_CNN, T0_CNN_OPTIONS  # noqa: E402  (plain lists of layer strings)
 
 CPU = torch.device("cpu")
 
@@ -485,8 +485,44 @@ def make_batchnorm_eval_fixture():
     print("batchnorm eval fixture written;", len(m.state_dict()), "state_dict entries,", n_bn, "BatchNorm1d modules; logits", out["out/logits_b"][:4])
 
 
+def make_cnn_batchnorm_eval_fixture():
+    """p0_cnn_batchnorm_eval.npz: the production stack with the reference's `batch_norm` token (dna_sequence_convolution.py:82-83)
+    behind the first convolution, in front of the second one and between flatten and the linear, in EVAL mode with running
+    statistics away from (0, 1): state_dict, inputs, the forward outputs and the haplotype embedding itself."""
+    torch.manual_seed(17)
+    p = ModelParameters([30, -2, -2, -2], 20, 6, [20, -2, -2, -2], [-2, -2, 10], 4, [10, 10], list(P0_CNN_BATCHNORM), 0.0, 0.3, False)
+    m = ArtifactModel(p, 61, 71, 42, device=CPU)
+    with torch.no_grad():
+        for q in m.parameters():
+            q.add_(0.05 * torch.randn_like(q))
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.normal_(0.0, 0.3)
+                mod.running_var.uniform_(0.5, 1.5)
+    m.eval()
+    rng = np.random.default_rng(17)
+    counts = [(int(rng.integers(0, 12)), int(rng.integers(1, 9))) for _ in range(24)]
+    data = make_data(rng, counts)
+    batch = Batch(data)
+    packed = np.vstack([d.get_ref_reads_re() for d in data] + [d.get_alt_reads_re() for d in data])
+    out = {"packed_reads": packed, "int_array": batch.int_tensor.numpy().astype(np.int16),
+           "float_array": batch.float_tensor.numpy().astype(np.float16)}
+    for k, v in m.state_dict().items():
+        out["sd/" + k] = v.detach().numpy().copy()
+    with torch.inference_mode():
+        output = m.compute_batch_output(batch, None)
+        out["out/ref_seq_embeddings_be"] = m.haplotypes_cnn(batch.get_one_hot_haplotypes_bcs().float()).numpy()
+    for k in ("features_be", "ref_features_be", "logits_b", "logits_bk", "artifact_probs_b", "outlier_binary_logits"):
+        out["out/" + k] = getattr(output, k).detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "p0_cnn_batchnorm_eval.npz"), **out)
+    n_bn = sum(isinstance(mod, torch.nn.BatchNorm1d) for mod in m.haplotypes_cnn.modules())
+    print("cnn batchnorm eval fixture written;", n_bn, "BatchNorm1d modules in the CNN; logits", out["out/logits_b"][:4])
+
+
 if __name__ == "__main__":
-    if "--dropout-only" in sys.argv:
+    if "--cnn-batchnorm-only" in sys.argv:
+        make_cnn_batchnorm_eval_fixture()
+    elif "--dropout-only" in sys.argv:
         make_dropout_eval_fixture()
     elif "--batchnorm-only" in sys.argv:
         make_batchnorm_eval_fixture()
@@ -512,3 +548,4 @@ if __name__ == "__main__":
         make_batchnorm_eval_fixture()
         make_cnn_fixtures()
         make_metrics_fixtures()
+        make_cnn_batchnorm_eval_fixture()

@@ -5,12 +5,12 @@ import numpy as np
 import torch
 
 from oracle import artifact_oracle as O
-from permutect_amd.parameters import P0_CNN, P0_CNN_LEGACY, T0_CNN, T0_CNN_OPTIONS
+from permutect_amd.parameters import P0_CNN, P0_CNN_BATCHNORM, P0_CNN_LEGACY, T0_CNN, T0_CNN_OPTIONS
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = ["t0_b8", "p0_b16", "p0_zero_ref", "p0_saturated", "p0_deep", "t0_two_sources"]
 CNN_CASES = ["p0_cnn_legacy", "t0_cnn_options"]  # haplotype-CNN stacks beyond the two of CASES (tests/golden/make_golden.py: make_cnn_fixtures)
-CNN_STACKS = {"p0_cnn_legacy": P0_CNN_LEGACY, "t0_cnn_options": T0_CNN_OPTIONS}
+CNN_STACKS = {"p0_cnn_legacy": P0_CNN_LEGACY, "t0_cnn_options": T0_CNN_OPTIONS, "p0_cnn_batchnorm_eval": P0_CNN_BATCHNORM}
 
 
 def config_for(name: str) -> O.Config:

@@ -118,3 +118,40 @@ def test_embeddings_of_every_fixture_match_the_reference_directly(name):
     with torch.no_grad():
         info_ref = O.mlp(sd, "info_embedding", [cfg.num_info_features] + cfg.info_layers, b["info_be"].to(torch.float32)).numpy()
     np.testing.assert_allclose(ve[:, :info_ref.shape[1]].cpu().numpy(), info_ref, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(info_ref).max())))
+
+
+@pytest.mark.parametrize("family", ["auto", "general", "wave", "batched"])
+def test_eval_forward_with_cnn_batch_norm_tokens_matches_reference(family, monkeypatch):
+    """The reference's `batch_norm` token (dna_sequence_convolution.py:82-83) in EVAL mode, as filter_variants runs a checkpoint
+    trained with it (tests/golden/p0_cnn_batchnorm_eval.npz: behind the first convolution, in front of the second, between flatten
+    and the linear; running statistics away from (0, 1)).  The engine folds the three BatchNorms into the neighbouring layers'
+    weights (engine/plan.py: folded_cnn_theta), so every kernel family runs the stack unchanged; state_dict keys as the
+    reference's; new running statistics are new weights; training is refused loudly."""
+    from permutect_amd.architecture.artifact_model import ArtifactModel
+    from permutect_amd.parameters import P0_CNN_BATCHNORM, P0_DIMS, p0_params
+    from tests.test_forward_gpu import check_outputs
+    if family != "auto":
+        monkeypatch.setenv("PMT_CNN", family)
+    z, sd, b = load_case("p0_cnn_batchnorm_eval")
+    params = p0_params()
+    params.ref_seq_layer_strings = list(P0_CNN_BATCHNORM)
+    dev = torch.device("cuda")
+    model = ArtifactModel(params, device=dev, **P0_DIMS)
+    assert set(model.state_dict().keys()) == set(sd.keys())
+    model.load_state_dict(sd)
+    model.eval()
+    batch = Batch.from_arrays(b["int_array"], b["float_array"], b["packed_reads"]).copy_to(dev)
+    with torch.inference_mode():
+        out = model.compute_batch_output(batch)
+        _, _, hap = model.calculate_features(batch)
+    ref_hap = z["out/ref_seq_embeddings_be"]
+    np.testing.assert_allclose(hap.cpu().numpy(), ref_hap, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(ref_hap).max())))
+    check_outputs(out, z, "p0_cnn_batchnorm_eval")
+    sd2 = {k: (v * 1.5 if (k.startswith("haplotypes_cnn") and k.endswith("running_var")) else v) for k, v in sd.items()}
+    model.load_state_dict(sd2)
+    with torch.inference_mode():
+        moved = model.compute_batch_output(batch)
+    assert float((moved.logits_b - out.logits_b).abs().max()) > 1e-4
+    model.train(True)
+    with pytest.raises(NotImplementedError, match="batch_norm"):
+        model.compute_batch_output(batch)

@@ -58,6 +58,19 @@ def test_gradients_and_adamw_step_match_reference(name):
         np.testing.assert_allclose(p.numpy(), z["after/" + n], rtol=1e-5, atol=2e-6, err_msg=n)
 
 
+def test_eval_forward_with_cnn_batch_norm_tokens_matches_reference():
+    """the reference's `batch_norm` token of the haplotype CNN in eval mode (tests/golden/p0_cnn_batchnorm_eval.npz: three of them,
+    running statistics away from (0, 1)): the oracle's forward and the haplotype embedding itself"""
+    z, sd, b = load_case("p0_cnn_batchnorm_eval")
+    cfg = config_for("p0_cnn_batchnorm_eval")
+    with torch.no_grad():
+        out = O.compute_batch_output(sd, cfg, b["reads_re"], b["nref"], b["nalt"], b["info_be"], b["haplotypes_bh"])
+    for k in ("features_be", "ref_features_be", "logits_b", "logits_bk", "outlier_binary_logits", "ref_seq_embeddings_be"):
+        ref = z["out/" + k]
+        np.testing.assert_allclose(out[k].numpy(), ref, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(ref).max())), err_msg=k)
+    assert np.abs(out["logits_b"].numpy() - z["out/logits_b"]).max() < 1e-4
+
+
 def test_decode_wrap_quirk():
     z = np.load(f"{GOLDEN}/quirk_decode.npz")
     dec = O.decode_packed_reads(z["packed_reads"])
