@@ -567,8 +567,11 @@ def main():
         t0 = time.perf_counter()
         lrng = np.random.default_rng(5050)
         li, lf, lp = synth_arrays(lrng, 1 << 20, "wgs")
-        ds1 = ReadsDataset(MemoryMappedData.from_arrays(li, lf, lp)).pin_memory()
-        note(f"loader: 2^20-variant dataset in page-locked host memory ({time.perf_counter() - t0:.1f} s)")
+        # the tools' own path: train_artifact_model / make_posterior_mmap page-lock a dataset that fits host memory (ReadsDataset.
+        # pin_memory_if_it_fits; PMT_PIN_DATASET=0 or a dataset beyond memory: staged copies), and so does this section
+        ds1 = ReadsDataset(MemoryMappedData.from_arrays(li, lf, lp))
+        pinned = ds1.pin_memory_if_it_fits()
+        note(f"loader: 2^20-variant dataset, page-locked: {pinned} ({time.perf_counter() - t0:.1f} s)")
         bsz, chunk = args.batch, 1 << 18
 
         def epochs(shuffle):
@@ -594,7 +597,8 @@ def main():
         train_rate = bsz * k_train / et
         # filter_variants over 5 x 2^20 candidates, INCLUDING the posterior hand-off (tools/posterior_data.make_posterior_mmap:
         # rows back on the host in dataset order): the five-fold dataset repeats the 2^20 synthetic variants
-        ds5 = ReadsDataset(MemoryMappedData.from_arrays(np.concatenate([li] * 5), np.concatenate([lf] * 5), np.concatenate([lp] * 5))).pin_memory()
+        ds5 = ReadsDataset(MemoryMappedData.from_arrays(np.concatenate([li] * 5), np.concatenate([lf] * 5), np.concatenate([lp] * 5)))
+        pinned = ds5.pin_memory_if_it_fits() and pinned
         n5 = len(ds5)
         make_posterior_mmap(ds1, model, bsz, chunk_variants=chunk)               # warm-up pass over 2^20
         k_filter = n5 // bsz
@@ -612,7 +616,8 @@ def main():
         resident_train = args.batch * args.steps / results["train"][0]
         resident_filter = args.batch * args.steps / results["filter"][0]
         loader = {"workload": "batches composed on the device from 2^18-variant chunks that the device chunk loader streams out of a synthetic dataset "
-                              "in page-locked host memory (H2D inside the timed region)",
+                              "in host memory (H2D inside the timed region); page-locked by ReadsDataset.pin_memory_if_it_fits exactly as "
+                              "train_artifact_model / make_posterior_mmap do it", "dataset_page_locked": bool(pinned),
                   "train": {"dataset_variants": 1 << 20, "value": train_rate, "unit": "read-sets/s", "ms_per_step": 1e3 * et / k_train, "steps": k_train,
                             "timed_s": et, "vs_resident": train_rate / resident_train},
                   "filter": {"dataset_variants": n5, "value": n5 / ef, "unit": "read-sets/s", "ms_per_step": 1e3 * ef / k_filter, "timed_s": ef,

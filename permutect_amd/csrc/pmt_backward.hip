@@ -527,7 +527,7 @@ DEV void backward_group(
                     d_beta += dg * (side == 0 ? m_ref[j] : m_alt[j]);
                     if (side == 1) d_gamma += dg * m_ref[j];
                 }
-                const f4 sg4 = seg_sum4(dgate[rt], sp);
+                const f4 sg4 = seg_sum4<!S::BF16>(dgate[rt], sp);  // (guarded in the fp32 instances only: pmt_device.hpp, seg_sum)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (sp.last && feat_of(0, j, g) < h) atomicAdd(&sh.gsum[set][side][4 * g + j], sg4[j]);
@@ -715,7 +715,7 @@ DEV void backward_group(
                 const int f = feat_of(t, j, g);
                 part[j] = (tm[rt].valid && f >= Er && f < D) ? dy[rt][t][j] : 0.f;
             }
-            const f4 s4 = seg_sum4(part, sp);
+            const f4 s4 = seg_sum4<!S::BF16>(part, sp);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int f = feat_of(t, j, g);

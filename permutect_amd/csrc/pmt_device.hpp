@@ -76,16 +76,37 @@ struct Shape {
     static_assert(!XBF || EXACT_, "the bf16 path has no tile guards");
 };
 using ShapeAny = Shape<4, 4, 4, 4, false>;   // any supported model
-using ShapeP0 = Shape<4, 2, 4, 1, true>;     // F in 49..64, read widths 17..32, d_model / reducer widths 49..64, E <= 16
-using ShapeP0X = Shape<4, 2, 4, 1, true, 61, 30, 60, 10, 10, 3>;  // exactly the production hyperparameters (SURVEY: P0)
-using ShapeP0XB = Shape<4, 2, 4, 1, true, 61, 30, 60, 10, 10, 1>; // the same widths, plain bf16 products (not a parity mode)
-using ShapeP0XD = Shape<4, 2, 4, 1, true, 61, 30, 60, 10, 10, 3, true>;  // the production shape in a training step WITH dropout
-// The FORWARD instances of the production shape since round 4: the same widths with the products as THREE f16 MFMAs on two-piece
+// The exact-width instances are compiled for ONE model shape per build of the library: the production hyperparameters (SURVEY:
+// P0) by default; `make SHAPE="ntf,ntr,ntd,nte,F,R,D,H,E" LIB=...` builds the same library around another shape (tile counts of
+// the read features / read widths / d_model / feature_dim, then the widths themselves: read features, read-MLP width, d_model,
+// d_ffn / 2, feature_dim).  permutect_amd/engine/instances.py builds and loads such a library for a model whose shape is not
+// the default's (T0: 4,1,2,2,61,10,30,10,20), so every model that meets the EXACT conditions runs exact-width kernels.
+#ifndef PMT_SH_NTF
+#define PMT_SH_NTF 4
+#define PMT_SH_NTR 2
+#define PMT_SH_NTD 4
+#define PMT_SH_NTE 1
+#define PMT_SH_F 61
+#define PMT_SH_R 30
+#define PMT_SH_D 60
+#define PMT_SH_H 10
+#define PMT_SH_E 10
+#endif
+#define PMT_SH_TILES PMT_SH_NTF, PMT_SH_NTR, PMT_SH_NTD, PMT_SH_NTE
+#define PMT_SH_DIMS PMT_SH_F, PMT_SH_R, PMT_SH_D, PMT_SH_H, PMT_SH_E
+static_assert(PMT_SH_F <= 16 * PMT_SH_NTF && PMT_SH_F > 16 * (PMT_SH_NTF - 1) && PMT_SH_R <= 16 * PMT_SH_NTR && PMT_SH_R > 16 * (PMT_SH_NTR - 1) &&
+              PMT_SH_D <= 16 * PMT_SH_NTD && PMT_SH_D > 16 * (PMT_SH_NTD - 1) && PMT_SH_E <= 16 * PMT_SH_NTE && PMT_SH_E > 16 * (PMT_SH_NTE - 1) &&
+              PMT_SH_H >= 1 && PMT_SH_H <= 16, "SHAPE: the widths must fill exactly the tile counts given");
+using ShapeP0 = Shape<PMT_SH_TILES, true>;     // the shape's TILE counts (P0: F in 49..64, read widths 17..32, d_model / reducer widths 49..64, E <= 16), widths at run time
+using ShapeP0X = Shape<PMT_SH_TILES, true, PMT_SH_DIMS, 3>;  // exactly the shape's widths (default: the production hyperparameters, SURVEY: P0)
+using ShapeP0XB = Shape<PMT_SH_TILES, true, PMT_SH_DIMS, 1>; // the same widths, plain bf16 products (not a parity mode)
+using ShapeP0XD = Shape<PMT_SH_TILES, true, PMT_SH_DIMS, 3, true>;  // the shape in a training step WITH dropout
+// The FORWARD instances of the shape since round 4: the same widths with the products as THREE f16 MFMAs on two-piece
 // splits (XBF = 16 = PMT_F16X2, linear_acc_f16 below; fp32-equivalent like the six bf16 MFMAs).  The backward keeps its bf16
 // pieces (gradients need bf16's exponent range), so ShapeP0X / ShapeP0XD above remain its instances and, for the forward, the
 // round-3 form that PmtModel.force_shape = 5 asks for.
-using ShapeP0XH = Shape<4, 2, 4, 1, true, 61, 30, 60, 10, 10, 16>;
-using ShapeP0XHD = Shape<4, 2, 4, 1, true, 61, 30, 60, 10, 10, 16, true>;
+using ShapeP0XH = Shape<PMT_SH_TILES, true, PMT_SH_DIMS, 16>;
+using ShapeP0XHD = Shape<PMT_SH_TILES, true, PMT_SH_DIMS, 16, true>;
 
 DEV float uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -140,8 +161,35 @@ DEV float dpp_mov_all(float v) {
     asm volatile("" : "+v"(t));
     return t;
 }
-DEV float seg_sum(float v, const SegPlan& p) {  // v must be 0 (and finite everywhere) in lanes without a read
-    if (PMT_SEG_FMAC) {
+// A step of the scan is v += m * (v of lane r - d) with m = 1.0 / 0.0: ONE v_fmac_f32 with a DPP-shifted operand.  0 * inf is NaN, so
+// a non-finite value in one read set would leak into the sets that share its row of 16 lanes, where the reference (and a select)
+// confines it to the offending set.  A GUARDed scan therefore first asks whether the WAVE holds a non-finite input at
+// all (one v_cmp_class per value, a scalar OR and a branch) and only then takes the select form below, six issue slots a step.
+// The guard costs the production forward 6 % (0.548 -> 0.582 ms: eight more spilled registers at its 128), and exactly that
+// instance cannot meet a non-finite activation unless its WEIGHTS are non-finite (every set is NaN then, nothing to confine): its
+// inputs are bytes, its matrix operands f16 pieces that saturate at +-65504 (MODE.FP16_OVFL clamps even an inf input), and
+// nothing between two LayerNorms can reach 3e38 from there.  So the f16 instances (and the backward that consumes their stash)
+// scan unguarded; every other instance -- fp32 or bf16 operands, where an inf input does propagate -- keeps the guard
+// (tests/test_forward_gpu.py: test_a_non_finite_read_set_does_not_leak_into_its_neighbours runs all of them).
+DEV bool seg_all_finite(float v) { return !__builtin_amdgcn_classf(v, 0x203); }  // not (signalling | quiet NaN | -inf | +inf)
+DEV bool wave_any(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
+DEV float seg_sum_select(float v, const SegPlan& p) {
+    float t = dpp_mov_all<0x111>(v);
+    v += p.t1 ? t : 0.f;
+    t = dpp_mov_all<0x112>(v);
+    v += p.t2 ? t : 0.f;
+    t = dpp_mov_all<0x114>(v);
+    v += p.t4 ? t : 0.f;
+    t = dpp_mov_all<0x118>(v);
+    v += p.t8 ? t : 0.f;
+    return v;
+}
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "the inline-asm DPP scans below hard-code gfx950's wave64 rows of 16 lanes and its VALU -> DPP wait states"
+#endif
+template <bool GUARD = true>
+DEV float seg_sum(float v, const SegPlan& p) {  // v must be 0 in lanes without a read
+    if (PMT_SEG_FMAC && (!GUARD || !wave_any(!seg_all_finite(v)))) {
         // v += m_d * (v of lane r - d), d = 1, 2, 4, 8: four fused multiply-adds whose first operand comes through the DPP
         // row shift (lanes without a source lane keep their value; their multiplier is 0 anyway).  Was per step: a move, the
         // DPP move, a select on a scalar-register mask and an add, with two wait states in between -- six issue slots, and
@@ -153,19 +201,13 @@ DEV float seg_sum(float v, const SegPlan& p) {  // v must be 0 (and finite every
             : "+v"(v) : "v"(p.m1), "v"(p.m2), "v"(p.m4), "v"(p.m8));
         return v;
     }
-    float t = dpp_mov_all<0x111>(v);
-    v += p.t1 ? t : 0.f;
-    t = dpp_mov_all<0x112>(v);
-    v += p.t2 ? t : 0.f;
-    t = dpp_mov_all<0x114>(v);
-    v += p.t4 ? t : 0.f;
-    t = dpp_mov_all<0x118>(v);
-    v += p.t8 ? t : 0.f;
-    return v;
+    return seg_sum_select(v, p);
 }
 // four independent values at once: the steps of the four scans interleave, so no wait state is needed between them
+template <bool GUARD = true>
 DEV f4 seg_sum4(f4 v, const SegPlan& p) {
-    if (!PMT_SEG_FMAC) return f4{seg_sum(v[0], p), seg_sum(v[1], p), seg_sum(v[2], p), seg_sum(v[3], p)};
+    const bool finite = !GUARD || (seg_all_finite(v[0]) && seg_all_finite(v[1]) && seg_all_finite(v[2]) && seg_all_finite(v[3]));
+    if (!PMT_SEG_FMAC || (GUARD && wave_any(!finite))) return f4{seg_sum_select(v[0], p), seg_sum_select(v[1], p), seg_sum_select(v[2], p), seg_sum_select(v[3], p)};
     float a = v[0], b = v[1], c = v[2], d = v[3];
 #define PMT_SEG_STEP(M, SH)                                                            \
     "v_fmac_f32_dpp %0, %0, %" #M " row_shr:" #SH " row_mask:0xf bank_mask:0xf\n\t"  \

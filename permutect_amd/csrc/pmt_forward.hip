@@ -82,6 +82,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
                                                                       float* __restrict__ rstd_stash, PmtLayeredArgs lay) {
     constexpr int NTF = S::NTF, NTR = S::NTR, NTD = S::NTD, NTE = S::NTE;
     constexpr bool EX = S::EXACT;
+    constexpr bool SEG_GUARD = S::BF16 != PMT_F16X2;  // (pmt_device.hpp, seg_sum: the f16 instances cannot meet a non-finite activation)
     static_assert(EX || (NTF == NTD && NTR == NTD && NTE == NTD), "the generic shape keeps one array width");
     __shared__ __attribute__((aligned(16))) FwdShared sh;
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
             {   // per-set sums of z2: segmented reduce over the tile's reads, one LDS add per set and value
                 const SegPlan sp = seg_plan(tmb[rt].valid ? tmb[rt].set : -1);
                 float* dst = &sh.zsum[buf][tmb[rt].set][side][4 * g];
-                const f4 s4 = seg_sum4(tmb[rt].valid ? z[rt][1] : f4{0.f, 0.f, 0.f, 0.f}, sp);
+                const f4 s4 = seg_sum4<SEG_GUARD>(tmb[rt].valid ? z[rt][1] : f4{0.f, 0.f, 0.f, 0.f}, sp);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (sp.last && feat_of(0, j, g) < h) atomicAdd(dst + j, s4[j]);
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
 #pragma unroll
             for (int t = 0; t < NTE; ++t)
                 if (t < nte) {
-                    const f4 s4 = seg_sum4(tm[rt].valid ? a[rt][t] : f4{0.f, 0.f, 0.f, 0.f}, sp);
+                    const f4 s4 = seg_sum4<SEG_GUARD>(tm[rt].valid ? a[rt][t] : f4{0.f, 0.f, 0.f, 0.f}, sp);
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         if (16 * t + 4 * j < E && sp.last && feat_of(t, j, g) < E) atomicAdd(&sh.fsum[set][side][16 * t + 4 * g + j], s4[j]);
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
             q0 = group_sum(q0);
             q1 = group_sum(q1);
             {
-                const float s0 = seg_sum(tm[rt].valid ? c0 - 0.5f * q0 : 0.f, sp), s1 = seg_sum(tm[rt].valid ? c1 - 0.5f * q1 : 0.f, sp);
+                const float s0 = seg_sum<SEG_GUARD>(tm[rt].valid ? c0 - 0.5f * q0 : 0.f, sp), s1 = seg_sum<SEG_GUARD>(tm[rt].valid ? c1 - 0.5f * q1 : 0.f, sp);
                 if (sp.last && g == 0) {
                     atomicAdd(&sh.hsum[set][0], s0);
                     atomicAdd(&sh.hsum[set][1], s1);
@@ -529,7 +530,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
                     const float par = logf(lam * 0.5f) + logerfc_dev(zz) + (lam * 0.5f) * (2.f * mu + lam * var - 2.f * p);
                     lk = orth + par;
                 }
-                const float s = seg_sum(lk, sp);  // (every lane of the row takes part in the scan)
+                const float s = seg_sum<SEG_GUARD>(lk, sp);  // (every lane of the row takes part in the scan)
                 if (sp.last && k < K) atomicAdd(&sh.hsum[set][2 + k], s);
               }
             }

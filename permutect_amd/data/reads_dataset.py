@@ -91,6 +91,30 @@ class ReadsDataset:
             self._reads = None if reads is None else reads.numpy()
         return self
 
+    def host_bytes(self) -> int:
+        nreads = int(self._starts[self._size])
+        per_read = self._reads.shape[1] * self._reads.itemsize if self._reads is not None else 0
+        return int(self._ints[: self._size].nbytes + self._floats[: self._size].nbytes + nreads * per_read + np.asarray(self._starts).nbytes)
+
+    def pin_memory_if_it_fits(self, max_fraction: float = 0.4) -> bool:
+        """What the tools call before they stream a dataset (train_artifact_model, make_posterior_mmap): page-lock it (pin_memory)
+        when it takes at most `max_fraction` of the host memory that is available right now; otherwise (or with
+        PMT_PIN_DATASET=0 in the environment) the dataset stays where it is -- a memory map of a file, typically -- and chunks go
+        through the staging copies.  Returns whether the dataset is page-locked."""
+        if self._pinned is not None:
+            return True
+        if os.environ.get("PMT_PIN_DATASET", "1") == "0" or not torch.cuda.is_available():
+            return False
+        try:
+            import psutil
+            available = psutil.virtual_memory().available
+        except Exception:  # noqa: BLE001 -- no way to tell: leave the dataset alone
+            return False
+        if self.host_bytes() > max_fraction * available:
+            return False
+        self.pin_memory()
+        return self._pinned is not None
+
     # ---- reference accessors (reference :95-112, :198-221) ---------------------------------------------------------------
     def totals_by_label(self):
         return self.totals_by_label_l

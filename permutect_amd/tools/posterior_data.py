@@ -50,6 +50,8 @@ def make_posterior_mmap(dataset: ReadsDataset, model, batch_size: int, device: O
     from queue import Queue
     from permutect_amd.engine import lib as L
     device = model._device if device is None else torch.device(device)
+    if device.type == "cuda":
+        dataset.pin_memory_if_it_fits()  # (chunks by DMA straight from the dataset when it fits host memory; else staged copies)
     n = len(dataset)
     e = model.reducer.output_dimension()
     width = INFO_START_IDX + e

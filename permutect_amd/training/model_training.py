@@ -99,6 +99,11 @@ def train_artifact_model(model, train_dataset: ReadsDataset, valid_dataset: Opti
     intended rows."""
     device = model._device
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
+    # datasets that fit host memory are page-locked once: their chunks then go to HBM by DMA straight from the dataset (a dataset
+    # that stays a memory map keeps the staged copies; PMT_PIN_DATASET=0 opts out).  bench.py's `loader` lines take the same path.
+    for ds in (train_dataset, valid_dataset):
+        if ds is not None and device.type == "cuda":
+            ds.pin_memory_if_it_fits()
     num_sources = train_dataset.validate_sources()  # (reference :63)
     balancer = Balancer(num_sources=num_sources, device=device)
     downsampler = Downsampler(num_sources=num_sources)

@@ -335,3 +335,34 @@ def test_cached_packed_weights_follow_every_way_the_parameters_change():
     assert not torch.allclose(stepped, moved)
     model.engine().packed_for = None                    # what an uncached forward gives for the same parameters
     assert torch.equal(logits(), stepped)
+
+
+def test_a_non_finite_read_set_does_not_leak_into_its_neighbours():
+    """the per-set sums are segmented scans whose step is a multiply-add with a 0 / 1 multiplier, and 0 * inf = NaN: a
+    non-finite activation in ONE read set must stay in that set, as it does in the reference (segment_reduce) -- the scans take
+    their select form whenever the wave holds a non-finite value (pmt_device.hpp: seg_sum; the f16 instances cannot meet one: their
+    operand pieces saturate).  One alt read of one variant carries an inf (float16 read format); every OTHER variant's outputs must
+    equal the clean run's in EVERY instance; the poisoned variant's logit is NaN where the operands carry the inf."""
+    z, sd, b = load_case("p0_b16")
+    model, dev = build("p0_b16", sd)
+    reads = np.array(z["reads_re_f16"], dtype=np.float16, copy=True)
+    nref, nalt = b["nref"].numpy(), b["nalt"].numpy()
+    clean = Batch.from_arrays(b["int_array"], b["float_array"], reads).copy_to(dev, torch.float16)
+    victim = int(np.argmax((nalt >= 2) & (nref >= 1) & (np.arange(len(nalt)) > 2)))  # a variant in the middle of a tile's lanes
+    row = int(nref.sum() + nalt[:victim].sum()) + 1  # its second alt read
+    poisoned = reads.copy()
+    poisoned[row, 57] = np.inf
+    dirty = Batch.from_arrays(b["int_array"], b["float_array"], poisoned).copy_to(dev, torch.float16)
+    with torch.no_grad():
+        good = model.compute_batch_output(clean)
+        bad = model.compute_batch_output(dirty)
+    others = np.arange(len(nalt)) != victim
+    import os
+    if os.environ.get("PMT_SHAPE", "") in ("bf16x3", "tile", "any"):  # fp32 / bf16 operands carry the inf into the set's sums
+        assert not torch.isfinite(bad.logits_b[victim])
+    else:  # the f16 instances saturate their matrix operands at +-65504 (MODE.FP16_OVFL): the set's logit is finite garbage
+        assert torch.isfinite(bad.logits_b[victim])
+    for k in ("logits_b", "logits_bk", "features_be", "ref_features_be"):
+        g, d = getattr(good, k).cpu().numpy()[others], getattr(bad, k).cpu().numpy()[others]
+        assert np.all(np.isfinite(d)), k
+        np.testing.assert_allclose(d, g, rtol=1e-6, atol=1e-6, err_msg=k)
