@@ -631,6 +631,50 @@ def main():
              f"{n5 / ep / 1e6:.1f} M read-sets/s = {loader['filter_with_posterior_handoff']['vs_resident']:.2f} x")
         del ds1, ds5, post, li, lf, lp
 
+    # ---- a model that is NOT the production shape: the reference's test configuration T0 on its own kernel instances (engine/
+    #      instances.py: the library built around its tile counts) against the generic instance every such model used to run ---------
+    shapes = None
+    if world == 1 and not args.no_extras and args.data == "resident" and args.depth == "wgs" and args.mode == "both" and args.dtype == "f32":
+        from permutect_amd.parameters import t0_params
+        shapes = {}
+        for label, env in (("instance", None), ("generic", "any")):
+            if env is None:
+                os.environ.pop("PMT_SHAPE", None)
+            else:
+                os.environ["PMT_SHAPE"] = env  # read once, when the model is lowered
+            torch.manual_seed(1)
+            tmodel = ArtifactModel(t0_params(), device=dev, **P0_DIMS)
+            topt = FusedClipAdamW(tmodel, lr=1e-3, weight_decay=0.01)
+            os.environ.pop("PMT_SHAPE", None)
+
+            def tstep(batch, train):
+                if not train:
+                    with torch.inference_mode():
+                        return tmodel.compute_batch_output(batch)
+                topt.zero_grad()
+                tmodel.compute_batch_losses(tmodel.compute_batch_output(batch), batch).total_loss.backward()
+                topt.step()
+            rec = {"pmt_shape_id": tmodel.engine().shape_id, "library_shape": list(__import__("permutect_amd.engine.lib", fromlist=["x"]).shape_of(tmodel.engine().lib))}
+            for mode in ("train", "filter"):
+                tmodel.train(mode == "train")
+                for i in range(4):
+                    tstep(batches[i % len(batches)], mode == "train")
+                k = 20
+                marks = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                torch.cuda.synchronize()
+                marks[0].record()
+                for i in range(k):
+                    tstep(batches[i % len(batches)], mode == "train")
+                marks[1].record()
+                torch.cuda.synchronize()
+                rec[f"{mode}_ms_per_step"] = marks[0].elapsed_time(marks[1]) / k
+            shapes[label] = rec
+            del tmodel, topt
+        shapes["workload"] = (f"the reference's test configuration T0 (read_layers [10,10,10], reducer [20,20,20], 2 gated blocks) on the headline's "
+                              f"{args.batch}-set batches: the library built around its tile counts against the generic instance")
+        note(f"T0 shape: train {shapes['instance']['train_ms_per_step']:.3f} ms/step on its instances vs {shapes['generic']['train_ms_per_step']:.3f} generic; "
+             f"filter {shapes['instance']['filter_ms_per_step']:.3f} vs {shapes['generic']['filter_ms_per_step']:.3f}")
+
     # ---- the same training step on the build whose backward runs six-MFMA (fp32-equivalent) products: what the 16-bit operands buy ----
     six = None
     alt6 = os.path.join(ROOT, "permutect_amd", "libpermutect_amd_alt6.so")
@@ -733,6 +777,8 @@ def main():
             line["dropout"] = dropout
         if six is not None:
             line["six_mfma_backward"] = six
+        if shapes is not None:
+            line["shapes"] = shapes
         if parity is not None:
             line["parity_check_max_logit_err"] = parity["max_logit_err"]
             line["parity_check"] = parity

@@ -267,6 +267,18 @@ typedef struct PmtAdamW {
 
 int pmt_abi_version(void);
 
+/* The shape the exact-width kernel instances of THIS build of the library are compiled for: tile counts (16 features each) of the
+ * read features, the read-MLP widths, d_model / the reducer's widths, feature_dim, then the widths themselves: read features,
+ * read-MLP width, d_model, d_ffn / 2, feature_dim.  The default build carries the production hyperparameters
+ * (4, 2, 4, 1; 61, 30, 60, 10, 10); `make -C permutect_amd/csrc instance SHAPE="..."` builds the library around another shape,
+ * and permutect_amd/engine/instances.py picks (or builds) the library whose TILE counts a model fills.  pmt_shape_id: which
+ * instance a model runs in this build -- 0 generic (fp32 MFMAs, any supported model), 1 the build's tiles with fp32 MFMAs (asked for
+ * through force_shape only), 6 the build's tiles on the 16-bit matrix pipes with the widths read at run time, 2 the build's widths
+ * compiled in, 3 the same with plain bf16 products.  Replaces nothing in the reference: its ATen kernels take any width
+ * (architecture/mlp.py:32-67, parameters.py:70-156). */
+int pmt_shape_info(int32_t* nine);
+int pmt_shape_id(const struct PmtModel* m);
+
 /* sizeof() of the ABI structs as compiled into the library, for binding self-checks:
  * 0 PmtModel, 1 PmtBatch, 2 PmtOutputs, 3 PmtOutputGrads, 4 PmtAdamW, 5 PmtLinear, 6 PmtOp, 7 PmtMlp, 8 PmtBlock, 9 PmtHead */
 int pmt_struct_bytes(int which);

@@ -860,7 +860,7 @@ __global__ __launch_bounds__(256) void pmt_grad_fold_kernel(const PmtModel* __re
 
 // persistent launch with private partial sums: only the bf16-exchange instances know them
 static bool use_partials(const PmtModel* m, int shape, const float* partials, int rows) {
-    return partials != nullptr && rows > 0 && m->emit_len > 0 && shape >= 2;
+    return partials != nullptr && rows > 0 && m->emit_len > 0 && shape >= 2;  // (2, 3, 4, 6: the instances with the bf16 exchange)
 }
 static int fold_partials(const PmtModel* model_host, const PmtModel* model_dev, const float* packed, float* partials, int rows,
                          float* grad_theta, float* grad_phi, hipStream_t s) {
@@ -889,7 +889,7 @@ extern "C" int pmt_backward(const PmtModel* model_host, const PmtModel* model_de
     const int grid = part && num_partials < batch->num_groups ? num_partials : batch->num_groups;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     auto kernel = shape == 4 ? pmt_backward_kernel<ShapeP0XD> : shape == 3 ? pmt_backward_kernel<ShapeP0XB> : shape == 2 ? pmt_backward_kernel<ShapeP0X>
-                  : shape == 1 ? pmt_backward_kernel<ShapeP0> : pmt_backward_kernel<ShapeAny>;
+                  : shape == 6 ? pmt_backward_kernel<ShapeP0T> : shape == 1 ? pmt_backward_kernel<ShapeP0> : pmt_backward_kernel<ShapeAny>;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(PMT_THREADS), 0, s, model_dev,
                        theta, phi, packed, *batch, *out, *dout, stash, zsum_stash, rstd_stash, grad_theta, grad_phi, grad_variant_embed,
                        PmtBwdLayered{}, part ? grad_partials : nullptr, model_host->emit_base, model_host->emit_len);
@@ -929,7 +929,7 @@ extern "C" int pmt_backward_layered(const PmtModel* model_host, const PmtModel* 
     const int shape = pmt_shape_for(model_host, batch, true);
     const bool part = use_partials(model_host, shape, grad_partials, num_partials);
     const int grid = part && num_partials < batch->num_groups ? num_partials : batch->num_groups;
-    auto kernel = shape >= 2 ? pmt_backward_kernel<ShapeP0X, true> : shape == 1 ? pmt_backward_kernel<ShapeP0, true> : pmt_backward_kernel<ShapeAny, true>;
+    auto kernel = (shape >= 2 && shape != 6) ? pmt_backward_kernel<ShapeP0X, true> : (shape == 1 || shape == 6) ? pmt_backward_kernel<ShapeP0, true> : pmt_backward_kernel<ShapeAny, true>;
     int* join_words = reinterpret_cast<int*>(lay.gsum_g + B * nb * 32);
     lay.join = PmtJoin{0, join_words + B * nb, join_words, batch->join_fault ? batch->join_fault : join_words + B * nb + 1};
     if (batch->set_groups != nullptr && L > 0) {  // ONE launch: the groups of a split read set join their sums through HBM

@@ -107,6 +107,12 @@ using ShapeP0XD = Shape<PMT_SH_TILES, true, PMT_SH_DIMS, 3, true>;  // the shape
 // round-3 form that PmtModel.force_shape = 5 asks for.
 using ShapeP0XH = Shape<PMT_SH_TILES, true, PMT_SH_DIMS, 16>;
 using ShapeP0XHD = Shape<PMT_SH_TILES, true, PMT_SH_DIMS, 16, true>;
+// A model that fills the shape's TILE counts but not its widths (other widths inside the same tiles, or layers of different widths
+// within one MLP -- the reference's test configuration T0: reducer 30 -> 20 -> 20 -> 20) still runs on the 16-bit matrix pipes:
+// the tile-exact instances with the widths read from the descriptor (pmt_shape_id: 6).  Padding positions hold zeros in the
+// packed weights and in every activation, so whole tiles are multiplied without guards.
+using ShapeP0T = Shape<PMT_SH_TILES, true, 0, 0, 0, 0, 0, 3>;    // backward (bf16 pieces)
+using ShapeP0TH = Shape<PMT_SH_TILES, true, 0, 0, 0, 0, 0, 16>;  // forward (f16 pieces)
 
 DEV float uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -905,11 +911,12 @@ DEV void drop_apply(const PmtDrop& d, int lin, f4 (&y)[PMT_RT][NT], int g) {
 }
 
 extern "C" int pmt_stash_slots(const PmtModel* m);  // host helper (pmt_host.hip)
-extern "C" int pmt_shape_id(const PmtModel* m);     // host: 2 = ShapeP0X (exact widths), 1 = ShapeP0 (exact tiles), 0 = ShapeAny
+extern "C" int pmt_shape_id(const PmtModel* m);     // host: 2 = ShapeP0X (exact widths), 6 = ShapeP0T (exact tiles, 16-bit pipes), 1 = ShapeP0 (exact tiles, fp32 MFMAs: asked for only), 0 = ShapeAny
 // A batch that brings a dropout seed to a model with dropout_p > 0 runs an instance that carries the masks: 4 = ShapeP0XD (the
 // production shape, one-launch path only), else 0 = the generic instance.
 static inline int pmt_shape_for(const PmtModel* m, const PmtBatch* b, bool layered = false) {
-    const int shape = pmt_shape_id(m);
+    int shape = pmt_shape_id(m);
+    if (shape == 6 && layered) shape = 1;  // (split read sets of a tile-exact model: the fp32 tile-exact instances)
     if (!(m->dropout_p > 0.f && b->dropout_seed != 0)) return shape;
     return (shape == 2 && !layered) ? 4 : 0;
 }

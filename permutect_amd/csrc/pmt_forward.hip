@@ -156,7 +156,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
                 const long long src = bt.read_index ? bt.read_index[tm[rt].row] : (long long)tm[rt].row;
                 rowp = reinterpret_cast<const unsigned char*>(bt.reads) + (size_t)src * (size_t)bt.read_row_bytes;
             }
-            if (NTF == 4 && S::DIM_F == 61 && fmt == PMT_READS_PACKED_U8 && bt.read_row_bytes == 12) {
+            if (NTF == 4 && (S::DIM_F == 61 || (S::DIM_F == 0 && EX && F == 61)) && fmt == PMT_READS_PACKED_U8 && bt.read_row_bytes == 12) {
 #pragma unroll
                 for (int t = 0; t < NTF; ++t) xf[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
                 if constexpr (NTF == 4) {
@@ -732,6 +732,7 @@ extern "C" int pmt_forward(const PmtModel* model_host, const PmtModel* model_dev
         return pmt_forward_launch_train_p0x(batch->num_groups, stream, model_dev, theta, phi, packed, batch, out, stash, zsum_stash, rstd_stash, nullptr,
                                             model_host->force_shape == 5);
     if (shape == 2) kernel = model_host->force_shape == 5 ? pmt_forward_kernel<false, ShapeP0X> : pmt_forward_kernel<false, ShapeP0XH>;
+    if (shape == 6) kernel = stash ? pmt_forward_kernel<true, ShapeP0TH> : pmt_forward_kernel<false, ShapeP0TH>;  // the shape's tiles, widths at run time
     if (shape == 3) kernel = stash ? pmt_forward_kernel<true, ShapeP0XB> : pmt_forward_kernel<false, ShapeP0XB>;  // plain bf16 products
     hipLaunchKernelGGL(kernel, dim3(batch->num_groups), dim3(PMT_THREADS), 0, s, model_dev, theta, phi, packed, *batch, *out,
                        stash, zsum_stash, rstd_stash, PmtLayeredArgs{});

@@ -33,12 +33,20 @@ extern "C" int pmt_struct_bytes(int which) {
 
 extern "C" int pmt_stash_slots(const PmtModel* m) { return (m->read_mlp.n_ops - 1) + (m->num_blocks + 1) + (m->reducer.n_ops - 1) + m->num_blocks; }
 
-// Which register-array shape the read-set kernels run with (pmt_device.hpp: Shape).  1 = ShapeP0, every layer fills
-// its tile arrays exactly: F and the first read linear 4 -> 2 tiles, the rest of the read MLP 2 tiles wide, d_model
-// and the reducer 4 tiles wide up to a last LINEAR 4 -> 1, feature_dim 1 tile.  Anything else runs the generic shape.
-// 2 = ShapeP0X: additionally every width equals the production hyperparameters' (61 read features, read width 30,
-// d_model 60, d_ffn 20, feature_dim 10), which that instance has compiled in.
-// PmtModel.force_shape = 2 / 1 forces the generic / the tile-exact instance (the parity tests cover all).
+// Which register-array shape the read-set kernels run with (pmt_device.hpp: Shape; the tile counts and widths of the exact
+// instances are the BUILD's shape, PMT_SH_*: the production hyperparameters by default).
+//   0 = ShapeAny: any supported model (fp32 MFMAs, every tile guarded);
+//   1 = ShapeP0: every layer fills the shape's tile arrays exactly -- read features and the first read linear NTF -> NTR tiles, the
+//       rest of the read MLP NTR wide, d_model and the reducer NTD wide up to a last LINEAR NTD -> NTE, feature_dim NTE -- fp32
+//       MFMAs, widths at run time (PmtModel.force_shape = 1 only);
+//   6 = ShapeP0T / ShapeP0TH: the same tile-exact models on the 16-bit matrix pipes, widths at run time;
+//   2 = ShapeP0X / ShapeP0XH: additionally every width equals the build's (compiled in); 3 = the same with plain bf16 products.
+// PmtModel.force_shape = 2 / 1 forces the generic / the fp32 tile-exact instance (the parity tests cover all).
+extern "C" int pmt_shape_info(int32_t* nine) {  // the build's shape: tile counts NTF, NTR, NTD, NTE, then widths F, R, D, H, E
+    const int32_t v[9] = {PMT_SH_NTF, PMT_SH_NTR, PMT_SH_NTD, PMT_SH_NTE, PMT_SH_F, PMT_SH_R, PMT_SH_D, PMT_SH_H, PMT_SH_E};
+    if (nine) memcpy(nine, v, sizeof(v));
+    return PMT_OK;
+}
 static int tiles_of(int dim) { return (dim + 15) / 16; }
 static bool mlp_ops_have_width(const PmtModel* m, const PmtMlp* mlp, int first, int last, int width) {
     for (int i = first; i < last; ++i) {
@@ -72,16 +80,18 @@ extern "C" int pmt_shape_id(const PmtModel* m) {
     if (first->kind != PMT_OP_LINEAR || last->kind != PMT_OP_LINEAR) return 0;
     const PmtLinear* Lf = &m->lin[first->lin[0]];
     const PmtLinear* Ll = &m->lin[last->lin[0]];
-    const bool ok = tiles_of(m->num_read_features) == 4 && tiles_of(Lf->in_dim) == 4 && tiles_of(Lf->out_dim) == 2 &&
-                    mlp_ops_have_tiles(m, rm, 1, rm->n_ops, 2) && tiles_of(m->read_embed_dim) == 2 &&
-                    tiles_of(m->d_model) == 4 && m->d_ffn >= 2 && mlp_ops_have_tiles(m, red, 0, red->n_ops - 1, 4) &&
-                    tiles_of(Ll->in_dim) == 4 && tiles_of(Ll->out_dim) == 1 && tiles_of(m->feature_dim) == 1;
+    const bool ok = tiles_of(m->num_read_features) == PMT_SH_NTF && tiles_of(Lf->in_dim) == PMT_SH_NTF && tiles_of(Lf->out_dim) == PMT_SH_NTR &&
+                    mlp_ops_have_tiles(m, rm, 1, rm->n_ops, PMT_SH_NTR) && tiles_of(m->read_embed_dim) == PMT_SH_NTR &&
+                    tiles_of(m->d_model) == PMT_SH_NTD && m->d_ffn >= 2 && mlp_ops_have_tiles(m, red, 0, red->n_ops - 1, PMT_SH_NTD) &&
+                    tiles_of(Ll->in_dim) == PMT_SH_NTD && tiles_of(Ll->out_dim) == PMT_SH_NTE && tiles_of(m->feature_dim) == PMT_SH_NTE;
     if (!ok) return 0;
     if (m->force_shape == 1) return 1;
-    const bool exact = m->num_read_features == 61 && Lf->in_dim == 61 && Lf->out_dim == 30 && mlp_ops_have_width(m, rm, 1, rm->n_ops, 30) &&
-                       m->read_embed_dim == 30 && m->d_model == 60 && m->d_ffn == 20 &&
-                       mlp_ops_have_width(m, red, 0, red->n_ops - 1, 60) && Ll->in_dim == 60 && Ll->out_dim == 10 && m->feature_dim == 10;
-    return exact ? (m->force_shape == 3 ? 3 : 2) : 1;  // 3: the exact widths with plain bf16 products (asked for explicitly only)
+    const bool exact = m->num_read_features == PMT_SH_F && Lf->in_dim == PMT_SH_F && Lf->out_dim == PMT_SH_R &&
+                       mlp_ops_have_width(m, rm, 1, rm->n_ops, PMT_SH_R) && m->read_embed_dim == PMT_SH_R && m->d_model == PMT_SH_D &&
+                       m->d_ffn == 2 * PMT_SH_H && mlp_ops_have_width(m, red, 0, red->n_ops - 1, PMT_SH_D) && Ll->in_dim == PMT_SH_D &&
+                       Ll->out_dim == PMT_SH_E && m->feature_dim == PMT_SH_E;
+    if (!exact) return 6;  // the shape's tiles, other widths: the 16-bit pipes with the widths read at run time
+    return m->force_shape == 3 ? 3 : 2;  // 3: the exact widths with plain bf16 products (asked for explicitly only)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

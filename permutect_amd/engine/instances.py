@@ -1,0 +1,113 @@
+"""Which build of libpermutect_amd.so runs a model's read-set kernels.
+
+The exact-width kernel instances are compiled for ONE model shape per build of the library (csrc/pmt_device.hpp: PMT_SH_*): the
+tile counts (16 features each) of the read features, the read-MLP widths, d_model / the reducer's widths and feature_dim, and the
+widths themselves.  The default build carries the production hyperparameters (4, 2, 4, 1; 61, 30, 60, 10, 10).  The reference
+accepts any layer list (architecture/mlp.py:32-67, parameters.py:70-156); so that another list does not drop to the generic instance
+(fp32 MFMAs with every tile guarded, ~2x slower), `library_for` picks -- or builds, once, with the hipcc of the ROCm installation --
+the library whose tile counts the model fills:
+
+  * the default library, when the model fills ITS tiles (pmt_shape_id != 0);
+  * a library under permutect_amd/instances/ with the model's tile counts (the widths compiled in when they are the model's, read at
+    run time otherwise: pmt_shape_id 2 or 6): `make -C permutect_amd/csrc instances` builds the table of known shapes ahead of time
+    (the reference's test configuration T0), `__graft_entry__.build()` calls it;
+  * a library built on the spot (`make instance SHAPE=...`, one to two minutes, kept for later runs) unless PMT_JIT=0 or there is no
+    hipcc -- then, and for a model that cannot fill any tile shape (a read MLP that does not start, or a reducer that does not end,
+    with a Linear; widths beyond 64), the default library's generic instance, with a warning that says so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import glob
+import os
+import shutil
+import subprocess
+import warnings
+from typing import Optional, Tuple
+
+from permutect_amd.engine import lib as L
+
+_HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INSTANCE_DIR = os.path.join(_HERE, "instances")
+CSRC = os.path.join(_HERE, "csrc")
+
+
+def _tiles(n: int) -> int:
+    return (n + 15) // 16
+
+
+def exact_shape_of(desc: L.PmtModel) -> Optional[Tuple[int, ...]]:
+    """(NTF, NTR, NTD, NTE, F, R, D, H, E) if SOME build of the library can run the model on tile-exact instances -- the conditions of
+    pmt_shape_id (pmt_host.hip) with the tile counts left open -- else None."""
+    rm, red = desc.read_mlp, desc.reducer
+    if rm.n_ops < 1 or red.n_ops < 1:
+        return None
+    first, last = rm.ops[0], red.ops[red.n_ops - 1]
+    if first.kind != L.OP_LINEAR or last.kind != L.OP_LINEAR:
+        return None
+    lf, ll = desc.lin[first.lin[0]], desc.lin[last.lin[0]]
+    ntf, ntr, ntd, nte = _tiles(desc.num_read_features), _tiles(lf.out_dim), _tiles(desc.d_model), _tiles(desc.feature_dim)
+
+    def ops_fill(mlp, lo, hi, nt):
+        for i in range(lo, hi):
+            o = mlp.ops[i]
+            for k in range(o.n_layers if o.kind == L.OP_SKIP else 1):
+                ln = desc.lin[o.lin[k]]
+                if _tiles(ln.in_dim) != nt or _tiles(ln.out_dim) != nt:
+                    return False
+        return True
+    ok = (_tiles(lf.in_dim) == ntf and ops_fill(rm, 1, rm.n_ops, ntr) and _tiles(desc.read_embed_dim) == ntr and desc.d_ffn >= 2
+          and ops_fill(red, 0, red.n_ops - 1, ntd) and _tiles(ll.in_dim) == ntd and _tiles(ll.out_dim) == nte)
+    if not ok or max(ntf, ntr, ntd, nte) > 4:
+        return None
+    return (ntf, ntr, ntd, nte, desc.num_read_features, lf.out_dim, desc.d_model, desc.d_ffn // 2, desc.feature_dim)
+
+
+def _tag(shape) -> str:
+    return "_".join(str(int(v)) for v in shape)
+
+
+def build_instance(shape, log=print) -> Optional[str]:
+    """`make instance SHAPE=...` (csrc/Makefile); returns the library's path, None when it cannot be built here"""
+    if os.environ.get("PMT_JIT", "1") == "0":
+        return None
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which("hipcc")) or not shutil.which("make"):
+        return None
+    log(f"permutect_amd: building the kernel instances for model shape {shape} (once; ~1-2 minutes) ...")
+    cmd = ["make", "-C", CSRC, f"-j{min(8, os.cpu_count() or 1)}", "instance", "SHAPE=" + " ".join(str(int(v)) for v in shape)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    path = os.path.join(INSTANCE_DIR, f"libpermutect_amd_{_tag(shape)}.so")
+    if res.returncode != 0 or not os.path.exists(path):
+        warnings.warn("permutect_amd: building the kernel instances failed:\n" + res.stderr[-2000:])
+        return None
+    return path
+
+
+def library_for(desc: L.PmtModel, log=print) -> C.CDLL:
+    default = L.load()
+    if "PMT_LIB" in os.environ:  # a development build named explicitly: use it as it is
+        return default
+    if default.pmt_shape_id(C.byref(desc)) != 0 or desc.force_shape == 2:
+        return default
+    shape = exact_shape_of(desc)
+    if shape is None:
+        warnings.warn("permutect_amd: this model cannot run on tile-exact kernel instances (the read MLP must start and the reducer end with a "
+                      "Linear, and each MLP keep one tile count); it runs the GENERIC instance (fp32 MFMAs, ~2x slower)")
+        return default
+    # a library with the model's tile counts: its widths first, then any other widths (pmt_shape_id 6: widths at run time)
+    exact = os.path.join(INSTANCE_DIR, f"libpermutect_amd_{_tag(shape)}.so")
+    candidates = ([exact] if os.path.exists(exact) else []) + sorted(glob.glob(os.path.join(INSTANCE_DIR, f"libpermutect_amd_{_tag(shape[:4])}_*.so")))
+    for path in candidates:
+        lib = L.load(path)
+        if lib.pmt_shape_id(C.byref(desc)) != 0:
+            return lib
+    path = build_instance(shape, log)
+    if path is not None:
+        lib = L.load(path)
+        if lib.pmt_shape_id(C.byref(desc)) != 0:
+            return lib
+    warnings.warn(f"permutect_amd: no kernel instances for model shape {shape} and none could be built here (hipcc / make missing, or "
+                  "PMT_JIT=0); the model runs the GENERIC instance (fp32 MFMAs, ~2x slower).  `make -C permutect_amd/csrc instance "
+                  f"SHAPE=\"{' '.join(str(v) for v in shape)}\"` builds them")
+    return default

@@ -151,7 +151,7 @@ class PmtLossInputGrads(C.Structure):
     _fields_ = [("d_logits_b", vp), ("d_logits_bk", vp), ("d_alt_count_raw", vp), ("d_source_logits", vp)]
 
 
-EXPORTS = ["pmt_abi_version", "pmt_struct_bytes", "pmt_model_check", "pmt_plan_groups", "pmt_stash_bytes", "pmt_pack_params",
+EXPORTS = ["pmt_abi_version", "pmt_shape_info", "pmt_shape_id", "pmt_struct_bytes", "pmt_model_check", "pmt_plan_groups", "pmt_stash_bytes", "pmt_pack_params",
            "pmt_scan_counts", "pmt_forward", "pmt_backward", "pmt_clip_adamw",
            "pmt_dropout_mask", "pmt_rows_stash_bytes", "pmt_rows_forward", "pmt_rows_backward", "pmt_rows_workspace_floats", "pmt_cnn_forward", "pmt_cnn_backward", "pmt_cnn_stash_floats", "pmt_cnn_workspace_floats",
            "pmt_phi_forward", "pmt_phi_backward", "pmt_build_read_index", "pmt_losses_forward", "pmt_losses_backward",
@@ -160,6 +160,7 @@ EXPORTS = ["pmt_abi_version", "pmt_struct_bytes", "pmt_model_check", "pmt_plan_g
            "pmt_layered_backward_scratch_floats", "pmt_backward_layered", "pmt_host_copy", "pmt_pack_order", "pmt_pack_order_batches", "pmt_prepare_chunk", "pmt_host_copy_rows", "pmt_compose_batch", "pmt_compose_batch_planned"]
 
 _lib = None
+_libs = {}  # path -> CDLL: the default library and the per-shape instance libraries (engine/instances.py)
 
 
 class PmtError(RuntimeError):
@@ -172,15 +173,19 @@ def check(rc: int, what: str) -> int:
     return rc
 
 
-def load() -> C.CDLL:
-    """Load libpermutect_amd.so (once).  Raises if it has not been built -- there is no CPU fallback."""
+def load(path: str = None) -> C.CDLL:
+    """Load libpermutect_amd.so (once), or the build of it at `path` (a per-shape instance library, engine/instances.py).  Raises if
+    it has not been built -- there is no CPU fallback."""
     global _lib
-    if _lib is not None:
+    if path is None and _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise PmtError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+    path = LIB_PATH if path is None else path
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise PmtError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                        f"or `make -C permutect_amd/csrc`.  permutect_amd has no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     P = C.POINTER
     lib.pmt_abi_version.restype = i32
     lib.pmt_model_check.argtypes = [P(PmtModel)]
@@ -242,5 +247,16 @@ def load() -> C.CDLL:
         if lib.pmt_struct_bytes(which) != C.sizeof(st):
             raise PmtError(f"ctypes layout of {st.__name__} ({C.sizeof(st)} B) does not match the library "
                            f"({lib.pmt_struct_bytes(which)} B)")
-    _lib = lib
+    lib.pmt_shape_info.argtypes = [P(i32)]
+    lib.pmt_shape_id.argtypes = [P(PmtModel)]
+    _libs[path] = lib
+    if path == LIB_PATH:
+        _lib = lib
     return lib
+
+
+def shape_of(lib: C.CDLL):
+    """(NTF, NTR, NTD, NTE, F, R, D, H, E): the shape a build's exact-width instances are compiled for (pmt_shape_info)"""
+    v = (i32 * 9)()
+    check(lib.pmt_shape_info(v), "pmt_shape_info")
+    return tuple(int(x) for x in v)

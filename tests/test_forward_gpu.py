@@ -366,3 +366,19 @@ def test_a_non_finite_read_set_does_not_leak_into_its_neighbours():
         g, d = getattr(good, k).cpu().numpy()[others], getattr(bad, k).cpu().numpy()[others]
         assert np.all(np.isfinite(d)), k
         np.testing.assert_allclose(d, g, rtol=1e-6, atol=1e-6, err_msg=k)
+
+
+def test_every_fixture_model_runs_exact_tile_instances(monkeypatch):
+    """a model whose layer list is not the production one must not drop to the generic instance.  The engine
+    picks the build of the library whose tile counts the model fills (engine/instances.py): the default library for P0 (widths
+    compiled in: pmt_shape_id 2), the T0 build under permutect_amd/instances/ for the reference's test configuration (its reducer
+    changes width inside one tile count, so the widths are read at run time: pmt_shape_id 6, still on the 16-bit matrix pipes)."""
+    from permutect_amd.engine import lib as L
+    monkeypatch.delenv("PMT_SHAPE", raising=False)
+    _, sd, _ = load_case("p0_b16")
+    p0, _ = build("p0_b16", sd)
+    assert p0.engine().shape_id == 2 and L.shape_of(p0.engine().lib) == (4, 2, 4, 1, 61, 30, 60, 10, 10)
+    _, sd, _ = load_case("t0_b8")
+    t0, _ = build("t0_b8", sd)
+    assert t0.engine().shape_id == 6 and L.shape_of(t0.engine().lib)[:4] == (4, 1, 2, 2)
+    assert t0.engine().lib is not p0.engine().lib

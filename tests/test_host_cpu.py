@@ -313,3 +313,42 @@ def test_split_planner_streams_rows_into_full_groups():
         assert plan.total_tiles == tiles
         if len(ref) == 200:  # 600-read sets: 38 tiles each used to take 3 groups (48 tile slots)
             assert plan.num_groups <= 1.08 * tiles / L.GROUP_TILES + 1, (plan.num_groups, tiles)
+
+
+def test_kernel_instances_are_chosen_by_the_models_tile_shape(monkeypatch):
+    """engine/instances.py: which build of the library runs a model.  Host logic only -- the descriptor is lowered
+    on the CPU and `pmt_shape_id` is a host function of every build: P0 fills the default library's shape with its widths compiled in
+    (2); the reference's test configuration T0 fills no tile of it (0 there) but has an exact shape of its own, for which the table's
+    prebuilt library answers 6 (its tiles, widths at run time); a model with the production TILES but other widths runs the default
+    library's tile-exact 16-bit instances (6) instead of the generic one; a read MLP that starts with a skip block has no exact shape."""
+    import ctypes as C
+    from permutect_amd.engine import instances as I
+    from permutect_amd.engine import lib as L
+    from permutect_amd.engine.plan import EnginePlan, ParamSpace
+    from permutect_amd.parameters import t0_params
+    monkeypatch.delenv("PMT_SHAPE", raising=False)
+    monkeypatch.delenv("PMT_LIB", raising=False)
+    monkeypatch.setenv("PMT_JIT", "0")  # (this test must not start a two-minute build)
+
+    def desc_of(params):
+        model = ArtifactModel(params, device=torch.device("cpu"), **P0_DIMS)
+        return EnginePlan(model, ParamSpace(model, torch.device("cpu")), torch.device("cpu")).desc
+    default = L.load()
+    assert L.shape_of(default) == (4, 2, 4, 1, 61, 30, 60, 10, 10)
+    p0 = desc_of(p0_params())
+    assert default.pmt_shape_id(C.byref(p0)) == 2 and I.exact_shape_of(p0) == (4, 2, 4, 1, 61, 30, 60, 10, 10)
+    assert I.library_for(p0) is default
+    t0 = desc_of(t0_params())
+    assert default.pmt_shape_id(C.byref(t0)) == 0 and I.exact_shape_of(t0) == (4, 1, 2, 2, 61, 10, 30, 10, 20)
+    t0_lib = os.path.join(I.INSTANCE_DIR, "libpermutect_amd_4_1_2_2_61_10_30_10_20.so")
+    if os.path.exists(t0_lib):  # built by __graft_entry__.build() (make instances)
+        lib = I.library_for(t0)
+        assert lib is not default and L.shape_of(lib)[:4] == (4, 1, 2, 2) and lib.pmt_shape_id(C.byref(t0)) == 6
+    other = p0_params()
+    other.read_layers, other.info_layers = [24, -2], [24, -1]  # D = 24 + 24 + 10 = 58: the production tiles, other widths
+    od = desc_of(other)
+    assert I.exact_shape_of(od)[:4] == (4, 2, 4, 1) and default.pmt_shape_id(C.byref(od)) == 6 and I.library_for(od) is default
+    odd = p0_params()
+    odd.read_layers = [-2, 30]  # (the read MLP starts with a skip block over the 61 read features: no tile-exact instance)
+    with pytest.warns(UserWarning, match="GENERIC"):
+        assert I.exact_shape_of(desc_of(odd)) is None and I.library_for(desc_of(odd)) is default
