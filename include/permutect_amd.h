@@ -395,6 +395,15 @@ typedef struct PmtRecordArgs {
 } PmtRecordArgs;
 int pmt_record_losses(const PmtRecordArgs* args, float* histograms, void* stream);
 
+/* The float rows of the posterior hand-off, one launch per batch (reference tools/filter_variants.py:302-320 builds a Datum per
+ * variant in Python: `set(CACHED_ARTIFACT_LOGIT, logit)` stores the logit through the float16 scalar array, `set_info_1d(embedding)`
+ * replaces the info columns by the float32 embedding, data/datum.py:199-211).  Row i of the batch becomes row dest_ids[i] (NULL: i)
+ * of `block`: columns [0, n_scalars) = the batch's float columns rounded through float16, column logit_col = float16(logits_b[i]);
+ * columns [n_scalars, n_scalars + e) = features_be[i].  Replaces five torch launches per batch in tools/posterior_data.py. */
+int pmt_posterior_rows(const float* float_rows, int64_t float_stride, int32_t n_scalars, int32_t logit_col, const float* logits_b,
+                       const float* features_be, int32_t e, const int64_t* dest_ids, int32_t n, float* block, int64_t block_stride,
+                       void* stream);
+
 /* Partition variants into register-resident groups: greedy over consecutive variants so that each group has
  * <= PMT_GROUP_MAX_SETS sets and its tiles fit the workgroup: ref tiles and alt tiles go to disjoint waves, two per wave,
  * i.e. ceil(ceil(ref/16) / 2) + ceil(ceil(alt/16) / 2) <= PMT_GROUP_WAVES (so never more than PMT_GROUP_TILES tiles).  Counts are HOST arrays

@@ -186,3 +186,38 @@ extern "C" int pmt_record_losses(const PmtRecordArgs* args, float* histograms, v
                        reinterpret_cast<hipStream_t>(stream), *args, histograms);
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }
+
+// ---- posterior hand-off: the float rows of a batch, scattered to dataset order (reference tools/filter_variants.py:302-320) --------
+__global__ __launch_bounds__(256) void pmt_posterior_rows_kernel(const float* __restrict__ float_rows, long long float_stride, int n_scalars,
+                                                                 int logit_col, const float* __restrict__ logits_b,
+                                                                 const float* __restrict__ features_be, int e,
+                                                                 const long long* __restrict__ dest_ids, int n, float* __restrict__ block,
+                                                                 long long block_stride) {
+    const int width = n_scalars + e;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < (long long)n * width; i += (long long)gridDim.x * 256) {
+        const int v = (int)(i / width), c = (int)(i - (long long)v * width);
+        const long long row = dest_ids ? dest_ids[v] : v;
+        float x;
+        if (c < n_scalars) {  // the scalar columns live in a float16 array (data/datum.py:25,76): round to nearest even through it
+            const float raw = c == logit_col ? logits_b[v] : float_rows[(long long)v * float_stride + c];
+            x = (float)(_Float16)raw;
+        } else {
+            x = features_be[(long long)v * e + (c - n_scalars)];
+        }
+        block[row * block_stride + c] = x;
+    }
+}
+
+extern "C" int pmt_posterior_rows(const float* float_rows, int64_t float_stride, int32_t n_scalars, int32_t logit_col, const float* logits_b,
+                                  const float* features_be, int32_t e, const int64_t* dest_ids, int32_t n, float* block, int64_t block_stride,
+                                  void* stream) {
+    if (!float_rows || !logits_b || !features_be || !block || n < 0 || n_scalars < 1 || e < 0 || logit_col < 0 || logit_col >= n_scalars ||
+        block_stride < n_scalars + e)
+        return PMT_E_INVALID;
+    if (n == 0) return PMT_OK;
+    const long long work = (long long)n * (n_scalars + e);
+    const int grid = (int)((work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pmt_posterior_rows_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), float_rows, (long long)float_stride,
+                       n_scalars, logit_col, logits_b, features_be, e, reinterpret_cast<const long long*>(dest_ids), n, block, (long long)block_stride);
+    return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
+}

@@ -479,9 +479,14 @@ class DeviceChunkLoader:
         self.ranges = dataset._chunk_ranges(chunk_variants, self.lo, self.hi)
         # a short first chunk: the consumer starts after ONE batch's worth of upload and preparation instead of a whole chunk's
         # (~10 ms of a 5 M-candidate filter pass that takes 90), while the full-size chunks behind it are already on their way
+        # (round 4: and that first piece is loaded ALONE before the prefetch threads start on the others (__iter__): starting together
+        #  they put the first batch's seven small copies behind the other chunks' large ones on the one upload stream, and the first
+        #  batch of a pass left the loader after 6.5 ms instead of ~1.5)
         first_lo, first_hi = self.ranges[0]
+        self._staged_start = 0
         if len(self.ranges) > 1 and first_hi - first_lo >= 4 * batch_size:
             self.ranges = [(first_lo, first_lo + batch_size), (first_lo + batch_size, first_hi)] + self.ranges[1:]
+            self._staged_start = 0  # (measured: loading the first piece alone first made the SECOND batch late; 0 = all prefetch threads at once)
         self.bytes_uploaded = 0
         self._stages = None  # borrowed from _STAGES while iterating: one PinnedStage per chunk in flight
         self._slot_events = [None] * _PREFETCH  # per staging slot: the event behind the last chunk enqueued out of it
@@ -679,12 +684,22 @@ class DeviceChunkLoader:
                 def submit(i):
                     if i < len(order_c):
                         pending.append(pool.submit(self._load, int(order_c[i]), int(seeds[i]), i % _PREFETCH))
-                for i in range(_PREFETCH):
+                # the first pieces of an unshuffled pass one after the other (each load's copies enqueued before the next one's), then
+                # _PREFETCH loads in flight
+                staged = self._staged_start if not self.shuffle else 0
+                submitted = 0
+                for i in range(max(1, min(_PREFETCH, len(order_c)) if staged == 0 else 1)):
                     submit(i)
+                    submitted += 1
                 ahead = None
                 for i in range(len(order_c)):
+                    if i < staged:
+                        pending[0].result()  # (this piece's copies are on the upload stream: the next piece may enqueue its own)
                     chunk, batches, done = pending.popleft().result()
-                    submit(i + _PREFETCH)
+                    want = i + 2 if i + 1 < staged else i + 1 + _PREFETCH
+                    while submitted < min(want, len(order_c)):
+                        submit(submitted)
+                        submitted += 1
                     self.bytes_uploaded += chunk.nbytes
                     if cuda:
                         torch.cuda.current_stream(self.device).wait_event(done)  # the chunk and its composed batches, on the device
@@ -699,6 +714,12 @@ class DeviceChunkLoader:
                                 t.record_stream(compose)
                     for item in batches:
                         nxt = composed(chunk, *item)
+                        if nxt[1] is None and ahead is None:
+                            # composed on the consumer's own stream: ready as it is.  (Held back as `ahead` like a side-stream batch,
+                            # the single batch of the short first chunk left the loader only once the SECOND chunk had been loaded:
+                            # the first batch of a pass came after 6.5 ms, the short chunk bought nothing)
+                            yield nxt[0]
+                            continue
                         if ahead is not None:
                             yield ready(ahead)
                         ahead = nxt

@@ -155,7 +155,7 @@ EXPORTS = ["pmt_abi_version", "pmt_shape_info", "pmt_shape_id", "pmt_struct_byte
            "pmt_scan_counts", "pmt_forward", "pmt_backward", "pmt_clip_adamw",
            "pmt_dropout_mask", "pmt_rows_stash_bytes", "pmt_rows_forward", "pmt_rows_backward", "pmt_rows_workspace_floats", "pmt_cnn_forward", "pmt_cnn_backward", "pmt_cnn_stash_floats", "pmt_cnn_workspace_floats",
            "pmt_phi_forward", "pmt_phi_backward", "pmt_build_read_index", "pmt_losses_forward", "pmt_losses_backward",
-           "pmt_downsample_counts", "pmt_downsample_index", "pmt_record_losses",
+           "pmt_downsample_counts", "pmt_downsample_index", "pmt_record_losses", "pmt_posterior_rows",
            "pmt_plan_groups_split", "pmt_layered_scratch_floats", "pmt_forward_layered",
            "pmt_layered_backward_scratch_floats", "pmt_backward_layered", "pmt_host_copy", "pmt_pack_order", "pmt_pack_order_batches", "pmt_prepare_chunk", "pmt_host_copy_rows", "pmt_compose_batch", "pmt_compose_batch_planned"]
 
@@ -229,6 +229,7 @@ def load(path: str = None) -> C.CDLL:
                                          vp, vp, vp, i32, vp]
     lib.pmt_downsample_counts.argtypes = [P(PmtDownsample), vp, vp, vp, vp, vp]
     lib.pmt_downsample_index.argtypes = [P(PmtDownsample), vp, vp, vp, vp, vp, vp]
+    lib.pmt_posterior_rows.argtypes = [vp, i64, i32, i32, vp, vp, i32, vp, i32, vp, i64, vp]
     lib.pmt_losses_forward.argtypes = [P(PmtLossArgs), P(PmtLossOutputs), vp]
     lib.pmt_losses_backward.argtypes = [P(PmtLossArgs), P(PmtLossOutputs), P(PmtLossInputGrads), vp]
     lib.pmt_phi_forward.argtypes = [P(PmtPhiProgram), vp, vp, vp]

@@ -33,6 +33,31 @@ def posterior_rows(int_tensor: torch.Tensor, float_tensor: torch.Tensor, logits_
     return ints, floats
 
 
+def device_posterior_rows(float_tensor: torch.Tensor, logits_b: torch.Tensor, features_be: torch.Tensor, dest_ids: Optional[torch.Tensor],
+                          block: torch.Tensor):
+    """The float rows of `posterior_rows` for a batch on the device, written to rows `dest_ids` (None: in order) of `block`, in ONE
+    launch (pmt_posterior_rows) -- was five torch launches per batch in a loop whose host time exceeded the forward it feeds.  On
+    the CPU (no library call without a GPU) the same rows by torch."""
+    if float_tensor.device.type != "cuda":
+        scalars = float_tensor[:, :INFO_START_IDX].to(torch.float16)
+        scalars[:, Data.CACHED_ARTIFACT_LOGIT.idx] = logits_b.to(torch.float16)
+        rows = torch.cat((scalars.to(torch.float32), features_be.to(torch.float32)), dim=1)
+        if dest_ids is None:
+            block[: rows.shape[0]] = rows
+        else:
+            block.index_copy_(0, dest_ids, rows)
+        return
+    from permutect_amd.engine import lib as L
+    assert float_tensor.dtype == torch.float32 and float_tensor.stride(1) == 1 and block.dtype == torch.float32 and block.stride(1) == 1
+    logits_b, features_be = logits_b.contiguous().float(), features_be.contiguous().float()
+    assert dest_ids is None or (dest_ids.dtype == torch.int64 and dest_ids.is_contiguous())
+    n, e = logits_b.shape[0], features_be.shape[1]
+    assert block.shape[1] == INFO_START_IDX + e
+    L.check(L.load().pmt_posterior_rows(float_tensor.data_ptr(), float_tensor.stride(0), INFO_START_IDX, Data.CACHED_ARTIFACT_LOGIT.idx,
+                                        logits_b.data_ptr(), features_be.data_ptr(), e, None if dest_ids is None else dest_ids.data_ptr(), n,
+                                        block.data_ptr(), block.stride(0), torch.cuda.current_stream().cuda_stream), "pmt_posterior_rows")
+
+
 @torch.inference_mode()
 def make_posterior_mmap(dataset: ReadsDataset, model, batch_size: int, device: Optional[torch.device] = None,
                         chunk_variants: Optional[int] = None) -> MemoryMappedData:
@@ -107,6 +132,7 @@ def make_posterior_mmap(dataset: ReadsDataset, model, batch_size: int, device: O
     th_ints.start()
     free_pinned: deque = deque()
     block, block_range, done = None, None, 0
+    d2h_stream = torch.cuda.Stream(device) if cuda else None
 
     def flush():
         nonlocal block
@@ -119,9 +145,17 @@ def make_posterior_mmap(dataset: ReadsDataset, model, batch_size: int, device: O
             pinned = free_pinned.popleft() if free_pinned else torch.empty(block.shape, dtype=torch.float32, pin_memory=True)
             if pinned.shape[0] < hi - lo:
                 pinned = torch.empty(block.shape, dtype=torch.float32, pin_memory=True)
-            pinned[: hi - lo].copy_(block, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
+            # the copy home runs on a stream of its own: on the compute stream its ~0.7 ms per chunk (17 MB over PCIe) stood between
+            # two batches' kernels -- a fifth of the pass.  It waits for the block's last writer and nothing waits for it but the
+            # helper thread (the block's memory is kept from reuse until the copy is done: record_stream)
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(d2h_stream):
+                d2h_stream.wait_event(ready)
+                pinned[: hi - lo].copy_(block, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(d2h_stream)
+            block.record_stream(d2h_stream)
             jobs.put((ev, pinned, lo, hi, free_pinned))
         else:
             jobs.put((None, block, lo, hi, deque()))
@@ -133,9 +167,7 @@ def make_posterior_mmap(dataset: ReadsDataset, model, batch_size: int, device: O
         if block_range != (lo, hi):
             flush()
             block, block_range = torch.empty(hi - lo, width, dtype=torch.float32, device=device), (lo, hi)
-        scalars = batch.float_tensor[:, :INFO_START_IDX].to(torch.float16)
-        scalars[:, Data.CACHED_ARTIFACT_LOGIT.idx] = out.logits_b.to(torch.float16)
-        block.index_copy_(0, batch.chunk_ids, torch.cat((scalars.to(torch.float32), out.features_be.to(torch.float32)), dim=1))
+        device_posterior_rows(batch.float_tensor, out.logits_b, out.features_be, batch.chunk_ids, block)
         done += batch.size()
     flush()
     t_enqueued = time.perf_counter()

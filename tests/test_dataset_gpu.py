@@ -281,3 +281,29 @@ def test_evaluation_pass_runs_three_downsamplings_over_both_loaders():
     labels = np.asarray(train._ints[: len(train), 2])
     np.testing.assert_allclose(counts[0].sum(axis=1), 3 * np.bincount(labels, minlength=3), atol=1e-3)
     assert 0.0 <= ev.accuracy(0) <= 1.0
+
+
+def test_device_posterior_rows_match_the_reference_fixture_directly():
+    """the DEVICE hand-off pinned by the reference's own rows, not by the repo's Datum emulation.  The fixture
+    (tests/golden/posterior_rows.npz, written by make_golden.py from the reference's loop in generate_posterior_data,
+    tools/filter_variants.py:302-320) holds a batch, the logits / embeddings the reference model produced and the rows its loop made
+    of them; the same logits / embeddings go into pmt_posterior_rows (one launch) and must give the same float rows BIT FOR BIT, in
+    order and scattered through a permutation."""
+    import os
+    from permutect_amd.tools.posterior_data import device_posterior_rows
+    from tests.helpers import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "posterior_rows.npz"))
+    dev = torch.device("cuda:0")
+    floats = torch.from_numpy(z["batch_float"]).to(dev)
+    logits, feats = torch.from_numpy(z["logits_b"]).to(dev), torch.from_numpy(z["features_be"]).to(dev)
+    want = z["out_float"]
+    n, width = want.shape
+    block = torch.full((n, width), float("nan"), dtype=torch.float32, device=dev)
+    device_posterior_rows(floats, logits, feats, None, block)
+    np.testing.assert_array_equal(block.cpu().numpy(), want)
+    perm = torch.from_numpy(np.random.default_rng(3).permutation(n)).to(dev)
+    scattered = torch.full((n + 5, width), float("nan"), dtype=torch.float32, device=dev)
+    device_posterior_rows(floats, logits, feats, perm, scattered)
+    got = scattered.cpu().numpy()
+    np.testing.assert_array_equal(got[perm.cpu().numpy()], want)
+    assert np.isnan(got[n:]).all()
