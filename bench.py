@@ -86,6 +86,26 @@ def kernels_sha():
     return h.hexdigest()[:16]
 
 
+def committed_parity_sweep():
+    """The 2^20-variant filter sweep of tests/test_scale_gpu.py as last committed under profiles/ (NOT measured by this run): how many
+    variants per million lie beyond 1e-4 of the fp32 oracle, and the fp64 yardstick for them."""
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_parity_errors.jsonl"))):
+        with open(path) as f:
+            for ln in f:
+                try:
+                    rec = json.loads(ln)
+                except ValueError:
+                    continue
+                if rec.get("test") == "filter_sweep_1M":
+                    best = {"source": os.path.relpath(path, ROOT) + " (tests/test_scale_gpu.py; a committed measurement, not this run)",
+                            "read_sets": rec.get("read_sets"), "logit_errs_over_1e4": rec.get("logit_errs_over_1e4"),
+                            "logit_errs_over_1e4_per_million": 1e6 * rec.get("logit_errs_over_1e4", 0) / max(1, rec.get("read_sets", 1)),
+                            "max_logit_err": rec.get("max_logit_err"), "max_hip_vs_fp64": rec.get("max_hip_vs_fp64"),
+                            "max_fp32_oracle_vs_fp64": rec.get("max_fp32_oracle_vs_fp64")}
+    return best
+
+
 def pmc_traffic(kernel, batch, depth):
     """HBM bytes per launch of `kernel` from a committed rocprofv3 --pmc measurement (profiles/*pmc_traffic*.json, written by
     scripts/pmc_traffic.py: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-byte-per-lane streaming reads on
@@ -263,6 +283,10 @@ def main():
                          "three-piece splits / exact fp32 MFMAs).  bf16: ONE bf16 MFMA per product on single roundings of both operands -- "
                          "BASELINE.json's 'bf16' training configuration, which the reference itself never computes in; a separate, labelled "
                          "line with its measured logit error, no parity claim")
+    ap.add_argument("--preroll", type=float, default=0.25, help="seconds of untimed steps before the counted warm-up of the headline loops (clock ramp)")
+    ap.add_argument("--strict-parity", action="store_true",
+                    help="fail on ANY variant beyond 1e-4 of the fp32 oracle; default: such a variant is recomputed in fp64 and the run fails "
+                         "unless the excess is the fp32 reference's own rounding (counted and reported in parity_check either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the small-batch points and the oracle parity check")
     ap.add_argument("--rehearse", action="store_true",
@@ -362,6 +386,9 @@ def main():
         with torch.inference_mode():
             return model.compute_batch_output(batch)
 
+    prerolled = {}
+    preroll_s = args.preroll
+
     def timed(mode, pool, steps, warmup):
         """W untimed + exactly K timed steps between barrier + synchronize brackets; max over ranks.  Returns (seconds,
         kernel milliseconds, per-step milliseconds): the last from one HIP event behind every step -- no synchronisation
@@ -369,6 +396,15 @@ def main():
         model.train(mode == "train")
         fn = train_step if mode == "train" else filter_step
         nxt = (lambda i: pool[i % len(pool)]) if stream_batches is None or pool is not batches else (lambda i: next(stream_batches))
+        # untimed pre-roll on top of the counted warm-up: the card's clocks need ~15 ms of work to come back after an idle stretch and a
+        # `--steps 20` run would sit inside that ramp; resident batches only (a streamed pass has its own fill)
+        t_pre = time.perf_counter()
+        if preroll_s > 0 and pool is batches and stream_batches is None:
+            while time.perf_counter() - t_pre < preroll_s:
+                for i in range(4):
+                    fn(nxt(i))
+                torch.cuda.synchronize()
+        prerolled[mode] = time.perf_counter() - t_pre
         for i in range(warmup):
             fn(nxt(i))
         eng.timers = {"pmt_forward": [], "pmt_backward": []}
@@ -729,7 +765,9 @@ def main():
         finite = bool(torch.isfinite(out.logits_b).all() and torch.isfinite(out.features_be).all()
                       and torch.isfinite(eng.space.theta).all() and torch.isfinite(eng.space.gtheta).all())
         ok = parity["max_logit_err"] <= 1e-4
-        if finite and not ok and args.dtype == "f32":
+        parity["variants_needing_fp64_adjudication"] = parity["logit_errs_over_1e4"]
+        parity["logit_errs_over_1e4_per_million"] = 1e6 * parity["logit_errs_over_1e4"] / max(1, parity["read_sets"])
+        if finite and not ok and args.dtype == "f32" and not args.strict_parity:
             # The fp32 reference path is itself a few 1e-5 from the exact result on its worst variants (tests/test_scale_gpu.py
             # measured it over 2^20 variants).  A variant beyond 1e-4 is therefore recomputed by the oracle in fp64: the run
             # fails unless EVERY such variant's HIP result is within 1e-4 of the fp64 result and no further from it than 1.5 x
@@ -756,7 +794,7 @@ def main():
         line = {
             "metric": "read-sets/sec (train fwd+bwd)" if head == "train" else "read-sets/sec (filter fwd)",
             "value": value, "unit": "read-sets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, **stats, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": 1e3 * elapsed / args.steps, **stats, "preroll_s": prerolled.get(head, 0.0), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype if args.dtype != "f32" else "f32 (fp32 accumulate; fwd: 2 x f16 pieces per operand = 23 bits; bwd: 2 x bf16 pieces = 16 bits)",
             "fwd_operand_bits": 23 if args.dtype == "f32" else 8, "bwd_operand_bits": 16 if args.dtype == "f32" else 8,
             "data": "synthetic" if args.data == "resident" else "synthetic, streamed through the device chunk loader (H2D inclusive)",
@@ -791,6 +829,9 @@ def main():
         if parity is not None:
             line["parity_check_max_logit_err"] = parity["max_logit_err"]
             line["parity_check"] = parity
+            sweep = committed_parity_sweep()
+            if sweep is not None:
+                line["parity_sweep"] = sweep
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -173,8 +173,7 @@ def train_artifact_model(model, train_dataset: ReadsDataset, valid_dataset: Opti
                             opt.zero_grad()
                             losses.total_loss.backward()
                             opt.step(pre_reduce=reduce_grads)
-            if epoch_type == Epoch.TRAIN:
-                check_for_nan(model)  # reference model_training.py:168 (a validation epoch leaves the training step's gradients as they were)
+            check_for_nan(model)  # reference model_training.py:168: after EVERY epoch, validation epochs included (whose gradients are the last training step's)
             if dist is not None:
                 recorder.all_reduce(dist)
             mean_loss = recorder.mean_loss(PRIMARY)  # the epoch's one host sync
