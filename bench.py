@@ -400,10 +400,16 @@ def main():
         # `--steps 20` run would sit inside that ramp; resident batches only (a streamed pass has its own fill)
         t_pre = time.perf_counter()
         if preroll_s > 0 and pool is batches and stream_batches is None:
-            while time.perf_counter() - t_pre < preroll_s:
+            go = True
+            while go:
                 for i in range(4):
                     fn(nxt(i))
                 torch.cuda.synchronize()
+                go = time.perf_counter() - t_pre < preroll_s
+                if dist is not None:  # every rank takes the SAME number of steps (each one is a collective): rank 0's clock decides
+                    flag = torch.tensor([1 if go else 0], device=dev, dtype=torch.int32)
+                    dist.broadcast(flag, src=0)
+                    go = bool(flag.item())
         prerolled[mode] = time.perf_counter() - t_pre
         for i in range(warmup):
             fn(nxt(i))

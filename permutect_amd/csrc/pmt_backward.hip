@@ -92,6 +92,9 @@ DEV void load_slot_tiles(const float* const (&stash_tile)[PMT_RT], unsigned mask
 // Layered execution (pmt_backward_layered; read sets split over several workgroups): launch `slice` finishes block
 // L - slice from the COMPLETE per-set sums of d(gate) and starts block L - slice - 1; the sums accumulate in HBM, the
 // running gradient and the half-finished block's per-read state rest in scratch between launches.
+#ifndef PMT_BWD_Z_F16
+#define PMT_BWD_Z_F16 1
+#endif
 struct PmtBwdLayered {
     int slice;
     float* dy_scratch;  // [total_tiles][PMT_SLOT_FLOATS] running gradient
@@ -466,7 +469,10 @@ DEV void backward_group(
                 const f4 b0 = load_pvec(packed + uniform(P1.b_pvec), 0, g), b1 = load_pvec(packed + uniform(P1.b_pvec), 1, g);
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt) { z[rt][0] = b0; z[rt][1] = b1; }
-                if constexpr (S::BF16) linear_acc_bf16<NTD, 2, false, BFB>(z, n, packed + uniform(P1.wb_frag));  // (the gate multiplies by this: three pieces)
+                // (the gate multiplies by this: fp32-equivalent products -- three f16 MFMAs on two-piece splits like the forward's, or
+                //  with PMT_BWD_Z_F16 = 0 the six bf16 MFMAs on three-piece splits of round 3)
+                if constexpr (S::BF16 && PMT_BWD_Z_F16) linear_acc_f16<NTD, 2, false>(z, n, packed + uniform(P1.wh_frag));
+                else if constexpr (S::BF16) linear_acc_bf16<NTD, 2, false, BFB>(z, n, packed + uniform(P1.wb_frag));
                 else linear_acc<NTD, 2, false, EX, S::DIM_D>(z, n, packed + uniform(P1.w_frag), D, 16 + h);
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt) {

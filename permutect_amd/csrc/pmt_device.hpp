@@ -256,6 +256,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef PMT_SELU_MINMAX
 #define PMT_SELU_MINMAX 0
 #endif
+#ifndef PMT_SELU_SCALAR
+#define PMT_SELU_SCALAR 0
+#endif
 DEV f4 selu4(f4 v) {
     if (PMT_SELU_MINMAX) {
         // branch-free form: scale * max(x, 0) + min(c e^x - c, 0), c = alpha * scale -- bit for bit the two-branch result (for
@@ -268,6 +271,21 @@ DEV f4 selu4(f4 v) {
             const float e = __builtin_amdgcn_exp2f(v[i] * 1.4426950408889634f);
             const float neg = fminf(__builtin_fmaf(e, c, -c), 0.f);
             r[i] = __builtin_fmaf(PMT_SELU_SCALE, fmaxf(v[i], 0.f), neg);
+        }
+        return r;
+    }
+    if (PMT_SELU_SCALAR) {  // the same arithmetic without the packed fp32 instructions (A/B switch)
+        f4 r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float t, e, n, p;
+            asm("v_mul_f32 %0, 0x3fb8aa3b, %1" : "=v"(t) : "v"(v[i]));
+            e = __builtin_amdgcn_exp2f(t);
+            constexpr float c = PMT_SELU_ALPHA * PMT_SELU_SCALE;
+            n = __builtin_fmaf(e, c, -c);
+            p = v[i] * PMT_SELU_SCALE;
+            asm volatile("" : "+v"(n), "+v"(p));
+            r[i] = v[i] > 0.f ? p : n;
         }
         return r;
     }
@@ -536,7 +554,12 @@ DEV void split_pair_f16(float a, float b, unsigned& h, unsigned& l, float k4096)
     h = __builtin_bit_cast(unsigned, hh);
     l = __builtin_bit_cast(unsigned, ll);
 }
-template <int NTI, int NTO, bool SELU_IN>
+#ifndef PMT_F16_AHEAD
+#define PMT_F16_AHEAD 0  // weight fragments of the next (out tile, k block) step requested one step ahead (8 more registers)
+#endif
+// X1: the input is exact in ONE f16 piece (packed read rows: bits and k / 32 quantiles; float16 read rows): no low piece is made and
+// the wh * xl' product is skipped -- two MFMAs per product.
+template <int NTI, int NTO, bool SELU_IN, bool X1 = false>
 DEV void linear_acc_f16(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], const float* __restrict__ fragh, float in_scale = 1.0f) {
     typedef unsigned u4v __attribute__((ext_vector_type(4)));
     constexpr int NKB = (NTI + 1) / 2;
@@ -555,15 +578,29 @@ DEV void linear_acc_f16(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], con
                 if (2 * kb + 1 < NTI) v1 = selu4(v1) * in_scale;
             }
             unsigned hh[4] = {0u, 0u, 0u, 0u}, ll[4] = {0u, 0u, 0u, 0u};
+            if constexpr (X1) {
+                const h2v p0 = {(_Float16)v0[0], (_Float16)v0[1]}, p1 = {(_Float16)v0[2], (_Float16)v0[3]};
+                hh[0] = __builtin_bit_cast(unsigned, p0);
+                hh[1] = __builtin_bit_cast(unsigned, p1);
+                if (2 * kb + 1 < NTI) {
+                    const h2v p2 = {(_Float16)v1[0], (_Float16)v1[1]}, p3 = {(_Float16)v1[2], (_Float16)v1[3]};
+                    hh[2] = __builtin_bit_cast(unsigned, p2);
+                    hh[3] = __builtin_bit_cast(unsigned, p3);
+                }
+            } else {
             split_pair_f16(v0[0], v0[1], hh[0], ll[0], k4096);
             split_pair_f16(v0[2], v0[3], hh[1], ll[1], k4096);
             if (2 * kb + 1 < NTI) {
                 split_pair_f16(v1[0], v1[1], hh[2], ll[2], k4096);
                 split_pair_f16(v1[2], v1[3], hh[3], ll[3], k4096);
             }
+            }
             xh[kb][rt] = __builtin_bit_cast(h8, u4v{hh[0], hh[1], hh[2], hh[3]});
             xl[kb][rt] = __builtin_bit_cast(h8, u4v{ll[0], ll[1], ll[2], ll[3]});
         }
+    constexpr int NSTEP = NTO * NKB;
+    h8 qh[2], ql[2];
+    if (PMT_F16_AHEAD) { qh[0] = fp[0]; ql[0] = fp[64]; }
 #pragma unroll
     for (int mt = 0; mt < NTO; ++mt) {
         f4 lo[PMT_RT];
@@ -572,17 +609,23 @@ DEV void linear_acc_f16(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], con
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
             const int step = mt * NKB + kb;
-            const h8 ah = fp[128 * step], al = fp[128 * step + 64];
+            h8 ah, al;
+            if (PMT_F16_AHEAD) {
+                ah = qh[step & 1]; al = ql[step & 1];
+                if (step + 1 < NSTEP) { qh[(step + 1) & 1] = fp[128 * (step + 1)]; ql[(step + 1) & 1] = fp[128 * (step + 1) + 64]; }
+            } else {
+                ah = fp[128 * step]; al = fp[128 * step + 64];
+            }
             const bool half_block = 2 * kb + 1 >= NTI;  // a last k block with one tile only: the 16-deep MFMA on the lower halves
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) {
                 if (half_block) {
                     lo[rt] = mfma_f16_k16(al, xh[kb][rt], lo[rt]);
-                    lo[rt] = mfma_f16_k16(ah, xl[kb][rt], lo[rt]);
+                    if constexpr (!X1) lo[rt] = mfma_f16_k16(ah, xl[kb][rt], lo[rt]);
                     acc[rt][mt] = mfma_f16_k16(ah, xh[kb][rt], acc[rt][mt]);
                 } else {
                     lo[rt] = mfma_f16(al, xh[kb][rt], lo[rt]);
-                    lo[rt] = mfma_f16(ah, xl[kb][rt], lo[rt]);
+                    if constexpr (!X1) lo[rt] = mfma_f16(ah, xl[kb][rt], lo[rt]);
                     acc[rt][mt] = mfma_f16(ah, xh[kb][rt], acc[rt][mt]);
                 }
             }
@@ -592,10 +635,10 @@ DEV void linear_acc_f16(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], con
     }
 }
 // the layers' products of an exact-width instance: BF = PMT_F16X2 two f16 pieces (wh_frag), else bf16 pieces (wb_frag)
-template <int NTI, int NTO, bool SELU_IN, int BF>
+template <int NTI, int NTO, bool SELU_IN, int BF, bool X1 = false>
 DEV void linear_acc_mx(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], const float* __restrict__ packed, const PmtLinear& L,
                        float in_scale = 1.0f) {
-    if constexpr (BF == PMT_F16X2) linear_acc_f16<NTI, NTO, SELU_IN>(acc, in, packed + uniform(L.wh_frag), in_scale);
+    if constexpr (BF == PMT_F16X2) linear_acc_f16<NTI, NTO, SELU_IN, X1>(acc, in, packed + uniform(L.wh_frag), in_scale);
     else linear_acc_bf16<NTI, NTO, SELU_IN, BF>(acc, in, packed + uniform(L.wb_frag), in_scale);
 }
 

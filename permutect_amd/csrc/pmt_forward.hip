@@ -7,6 +7,9 @@
 #include "pmt_device.hpp"
 #include "pmt_mlp_device.hpp"
 
+#ifndef PMT_F16_X1
+#define PMT_F16_X1 1  // the first read-MLP linear on one-piece inputs (0: two pieces like every other layer; A/B switch)
+#endif
 struct FwdShared {  // (the float tables first: their rows are read and cleared 16 bytes at a time)
     float zsum[3][PMT_GROUP_MAX_SETS][2][16];
     float fsum[PMT_GROUP_MAX_SETS][2][PMT_MAX_WIDTH];
@@ -178,7 +181,11 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt) drop.row[rt] = tm[rt].row;
             }
-            run_linear_op<NTF, NTR, true, S::DIM_F, S::DIM_R, S::BF16, S::DROP>(M, M->read_mlp.ops[0], xr, xf, g, packed, &drop);
+            // packed rows (bits, k / 32 quantiles) and float16 rows are exact in ONE f16 piece: no low piece, two MFMAs per product
+            if (PMT_F16_X1 && S::BF16 == PMT_F16X2 && fmt != PMT_READS_F32)
+                run_linear_op<NTF, NTR, true, S::DIM_F, S::DIM_R, S::BF16, S::DROP, true>(M, M->read_mlp.ops[0], xr, xf, g, packed, &drop);
+            else
+                run_linear_op<NTF, NTR, true, S::DIM_F, S::DIM_R, S::BF16, S::DROP>(M, M->read_mlp.ops[0], xr, xf, g, packed, &drop);
             tr.ev(6);
             run_mlp<TRAIN, NTR, true, S::DIM_R, S::BF16, S::DROP>(M, M->read_mlp, xr, theta, g, mask_all, stash_tile, slot, 1, packed, 1, n_read_ops, &drop);
 #pragma unroll

@@ -7,7 +7,8 @@
 // WI / WO / W (compile time, 0 = read the descriptor): the widths, for the instances that have them compiled in.
 // BF: the matrix products on the bf16 pipe (linear_acc_bf16; exact instances, direct weight path only).
 // DROP (+ drop): dropout behind the Linear, before the SELU (reference mlp.py:57-58).
-template <int NTI, int NTO, bool EXACT, int WI = 0, int WO = 0, int BF = 0, bool DROP = false>
+// X1 (f16 instances): the input is exact in one f16 piece (linear_acc_f16).
+template <int NTI, int NTO, bool EXACT, int WI = 0, int WO = 0, int BF = 0, bool DROP = false, bool X1 = false>
 DEV void run_linear_op(const PmtModel* __restrict__ M, const PmtOp& o, f4 (&y)[PMT_RT][NTO], const f4 (&x)[PMT_RT][NTI],
                        int g, const float* __restrict__ packed, const PmtDrop* drop = nullptr) {
     const PmtLinear& L = M->lin[uniform(o.lin[0])];
@@ -15,7 +16,7 @@ DEV void run_linear_op(const PmtModel* __restrict__ M, const PmtOp& o, f4 (&y)[P
     const float* st = packed + base;  // [fragments | bias]
     const int in_dim = WI ? WI : uniform(L.in_dim), out_dim = WO ? WO : uniform(L.out_dim);
     init_bias<NTO>(y, b_pvec >= 0 ? st + (b_pvec - base) : nullptr, out_dim, g);
-    if constexpr (BF) linear_acc_mx<NTI, NTO, false, BF>(y, x, packed, L);
+    if constexpr (BF) linear_acc_mx<NTI, NTO, false, BF, X1>(y, x, packed, L);
     else linear_acc<NTI, NTO, false, EXACT, WI>(y, x, st, in_dim, out_dim);
     if constexpr (DROP) {
         if (drop != nullptr && drop->on != 0) drop_apply<NTO>(*drop, uniform(o.lin[0]), y, g);

@@ -29,7 +29,7 @@ def test_two_rank_training_keeps_replicas_identical():
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dp_worker.py"), d]
-        res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
         r0, r1 = (torch.load(os.path.join(d, f"rank{r}.pt"), weights_only=False) for r in range(2))
     assert r0["hook"] == "BucketedGradAllReduce" and 0 < r0["late_start"] < r0["theta"].numel()
@@ -51,7 +51,7 @@ def test_rccl_overlapped_reduction_on_one_card():
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
         res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_worker.py"), out], cwd=ROOT, env=env,
-                             capture_output=True, text=True, timeout=600)
+                             capture_output=True, text=True, timeout=300)
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
         r = torch.load(out, weights_only=False)
     assert r["backend"] == "nccl" and r["early_reductions"] == 3 and r["side_stream"] and not r["pending"]
@@ -63,7 +63,7 @@ def test_rccl_overlapped_reduction_on_one_card():
     np.testing.assert_allclose(r["hooked_losses"], r["plain_losses"], rtol=1e-5)
 
 
-def _bench_line(*flags, timeout=900):
+def _bench_line(*flags, timeout=300):  # (well under the pool's 420 s silence limit: a hang must fail THIS test, not kill the run)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]

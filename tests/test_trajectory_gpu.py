@@ -66,7 +66,7 @@ def hip_trajectory(lib=None):
         if lib is not None:
             env["PMT_LIB"] = lib
         res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "trajectory_worker.py"), out], cwd=ROOT, env=env, capture_output=True,
-                             text=True, timeout=900)
+                             text=True, timeout=300)
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
         r = torch.load(out, weights_only=False)
     return r["losses"], {k: v.double() for k, v in r["params"].items()}
