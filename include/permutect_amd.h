@@ -27,6 +27,10 @@ extern "C" {
 
 #define PMT_ABI_VERSION 9
 
+/* bits of the fault word (PmtBatch.join_fault) */
+#define PMT_FAULT_JOIN 1
+#define PMT_FAULT_F16_RANGE 2
+
 /* error codes */
 #define PMT_OK 0
 #define PMT_E_INVALID (-1)      /* bad argument / descriptor out of supported range */
@@ -58,7 +62,7 @@ extern "C" {
 /* read-row formats accepted at the boundary (reference data/batch.py:41-62, data/datum.py:35) */
 #define PMT_READS_PACKED_U8 0   /* [R][7 + nf] uint8: 7 MSB-first bit-packed bytes, then nf quantile bytes */
 #define PMT_READS_F16 1         /* [R][F] float16 (Batch.reads_re as the reference collates it) */
-#define PMT_READS_F32 2         /* [R][F] float32 (Batch.copy_to(device, float32)) */
+#define PMT_READS_F32 2         /* [R][F] float32 (Batch.copy_to(device, float32)); values within +-65504 (the reference's are < 8) */
 
 /* One nn.Linear.  Weights are consumed in MFMA fragment order from the packed buffer. */
 typedef struct PmtLinear {
@@ -231,11 +235,13 @@ typedef struct PmtBatch {
                                        registers; NULL = num_blocks + 1 launches with the activations parked in between */
     uint64_t dropout_seed;          /* 0 = no dropout (eval mode, or dropout_p = 0).  Otherwise the seed of THIS step's masks
                                        (pmt_dropout_mask): the forward and the backward of one step get the same value */
-    int32_t* join_fault;            /* device, optional [1], caller-owned and never cleared by the library: a joined launch
-                                       (set_groups) whose bounded wait for another workgroup gave up stores 1 here -- its
-                                       numbers are then wrong.  One persistent word serves every launch of a run; the host
-                                       reads it where it synchronises anyway (end of an epoch / of a filtering pass).
-                                       NULL = the word inside the launch's own scratch (development) */
+    int32_t* join_fault;            /* device, optional [1], caller-owned and never cleared by the library: the launches' fault
+                                       word.  Bit 0 (PMT_FAULT_JOIN): a joined launch (set_groups) whose bounded wait for another
+                                       workgroup gave up -- its numbers are wrong.  Bit 1 (PMT_FAULT_F16_RANGE): a forward whose
+                                       residual stream or reducer output left the range of its f16 operand pieces (+-65504: they
+                                       saturate) -- the logits of that launch are wrong.  One persistent word serves every launch
+                                       of a run; the host reads it where it synchronises anyway (end of an epoch / of a filtering
+                                       pass) and raises.  NULL = join faults go to the launch's own scratch, range faults nowhere */
 } PmtBatch;
 
 typedef struct PmtOutputs {

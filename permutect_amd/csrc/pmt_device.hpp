@@ -524,6 +524,7 @@ DEV void linear_acc_bf16(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], co
 // input (NKB x 2 tiles x 2 pieces x 4 registers) are made once up front, after which the input registers are dead.
 // ---------------------------------------------------------------------------------------------------------------
 #define PMT_F16X2 16  // Shape::BF16 value of the instances whose forward products run this way
+#define PMT_F16_OPERAND_MAX 65504.0f
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
@@ -910,7 +911,7 @@ DEV void pmt_join_sets(const PmtJoin& j, float* lds, float* glob, int set_stride
             while (__hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
                 __builtin_amdgcn_s_sleep(2);
                 if (++spins > (1 << 17)) {  // ~0.2 s of polls: a legitimate wait is over within a group's run time (~0.2 ms)
-                    __hip_atomic_store(j.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_or(j.fault, PMT_FAULT_JOIN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
             }

@@ -34,6 +34,27 @@ DEV float read_feature(const unsigned char* __restrict__ row, int fmt, int f, in
     }
 }
 
+// an activation array about to become a pair of f16 operand pieces: any value beyond their range goes into the caller's fault word
+// (v_max3 over the registers, one compare, one ballot; NaN compares false: a non-finite stream shows in the outputs themselves)
+#ifndef PMT_F16_RANGE_CHECK
+#define PMT_F16_RANGE_CHECK 6  // bits: 1 float32 read rows (off: that branch in the prologue costs the filter instance 14 spilled registers
+                               // = 6 % of its time, and the reference's read rows are bits and (uint8 +- 128) / 32 < 8 in every format),
+                               // 2 the residual stream at the reducer, 4 the reducer's output (both free)
+#endif
+template <int NT, int WHICH>
+DEV void f16_range_check(const f4 (&v)[PMT_RT][NT], int* __restrict__ fault) {
+    if (!(PMT_F16_RANGE_CHECK & WHICH)) return;
+    float m = 0.f;
+#pragma unroll
+    for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(v[rt][t][0])), __builtin_fabsf(v[rt][t][1]));
+            m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(v[rt][t][2])), __builtin_fabsf(v[rt][t][3]));
+        }
+    if (fault != nullptr && wave_any(m > PMT_F16_OPERAND_MAX) && (pmt_tid() & 63) == 0) atomicOr(fault, PMT_FAULT_F16_RANGE);
+}
+
 // log erfc with the asymptotic branch for z > 5 (reference exponentially_modified_gaussian.py:30-55)
 DEV float logerfc_dev(float z) {
     const float zc = fmaxf(z, 2.f);
@@ -173,6 +194,9 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
                 for (int j = 0; j < 4; ++j) xf[rt][t][j] = rowp ? read_feature(rowp, fmt, feat_of(t, j, g), F) : 0.f;
         }
         tr.ev(5);
+        if constexpr (S::BF16 == PMT_F16X2) {  // read rows given as float32 can hold anything (packed rows are bytes, float16 rows in range)
+            if (fmt == PMT_READS_F32) f16_range_check<NTF, 1>(xf, bt.join_fault);
+        }
         if constexpr (EX) {
             f4 xr[PMT_RT][NTR];
             PmtDrop drop;  // (only the dropout instance, ShapeP0XD, touches it)
@@ -379,6 +403,11 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
             if (mask_all & (1u << rt)) stash_store<NTD>(stash_tile[rt] + slot * PMT_SLOT_FLOATS, x[rt]);
         ++slot;
     }
+    // The f16 operand pieces saturate at +-65504 (linear_acc_f16).  Inside the gated blocks every matrix operand is LayerNorm'ed or a
+    // SELU of one, and the read MLP's inputs are bytes; the ONE place an unnormalised activation of any size becomes a matrix
+    // operand is here, where the residual stream x_L enters the reducer (and, below, where the reducer's output enters the
+    // rotation).  A value beyond the range is reported in the caller's fault word (bit 1), never silently clipped.
+    if constexpr (S::BF16 == PMT_F16X2) f16_range_check<NTD, 2>(x, bt.join_fault);
 
     tr.ev(19);
     // ---- reducer MLP, then translation + rotation ----------------------------------------------------------------
@@ -421,6 +450,7 @@ __global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_ker
                 a[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
             }
         }
+        if constexpr (S::BF16 == PMT_F16X2) f16_range_check<NTE, 4>(e, bt.join_fault);
         if constexpr (S::BF16) linear_acc_mx<NTE, NTE, false, S::BF16>(a, e, packed, R);
         else linear_acc<NTE, NTE, false, EX, S::DIM_E>(a, e, stR, E, E);
     }

@@ -73,10 +73,17 @@ class ReadSetEngine:
     def check_join_fault(self):
         """Synchronises and raises if ANY joined launch since the last check gave up waiting for another workgroup (its results,
         and everything computed from them since, are wrong).  The word is cleared so that a caller may catch and carry on."""
-        if int(self.join_fault.item()) != 0:
+        word = int(self.join_fault.item())
+        if word != 0:
             self.join_fault.zero_()
-            raise L.PmtError("a joined layered launch timed out waiting for the other workgroups of a split read set: the logits / "
-                             "gradients computed since the last check are wrong (PMT_LAYERED_JOIN=0 runs the layered launches instead)")
+            what = []
+            if word & 1:
+                what.append("a joined layered launch timed out waiting for the other workgroups of a split read set "
+                            "(PMT_LAYERED_JOIN=0 runs the layered launches instead)")
+            if word & 2:
+                what.append("an activation left the range of the forward's f16 operand pieces (|x| > 65504 where the residual stream enters the "
+                            "reducer or its output the rotation): those operands saturate (PMT_SHAPE=bf16x3 runs the bf16-piece forward, which has no such limit)")
+            raise L.PmtError("; ".join(what) + ": the logits / gradients computed since the last check are wrong")
 
     # ---- parameters -------------------------------------------------------------------------------------------------
     def params_changed(self):

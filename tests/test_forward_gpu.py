@@ -382,3 +382,31 @@ def test_every_fixture_model_runs_exact_tile_instances(monkeypatch):
     t0, _ = build("t0_b8", sd)
     assert t0.engine().shape_id == 6 and L.shape_of(t0.engine().lib)[:4] == (4, 1, 2, 2)
     assert t0.engine().lib is not p0.engine().lib
+
+
+def test_an_activation_beyond_the_f16_operand_range_is_reported_not_clipped(monkeypatch):
+    """The forward's matrix operands are pairs of f16 pieces, which saturate at +-65504 (pmt_device.hpp: linear_acc_f16).  Nothing
+    between two LayerNorms can get there; the residual stream that enters the reducer can, in a model built to do it (a 1e5 bias on
+    the last block's output).  The reference computes such a model in fp32 without complaint; here the launch raises the engine's
+    fault word (PMT_FAULT_F16_RANGE) and the host raises at its next check -- never a silently clipped logit -- and the bf16-piece
+    forward (PMT_SHAPE=bf16x3, no such limit) still matches the oracle on it."""
+    import os
+    from permutect_amd.engine.lib import PmtError
+    if os.environ.get("PMT_SHAPE", "") in ("tile", "any"):
+        pytest.skip("fp32 instances have no operand range")
+    z, sd, b = load_case("p0_b16")
+    sd = {k: v.clone() for k, v in sd.items()}
+    sd["ref_alt_reads_encoder.blocks.5.proj2_alt.bias"][:10] += 1.0e5
+    model, dev = build("p0_b16", sd)
+    batch = Batch.from_arrays(b["int_array"], b["float_array"], b["packed_reads"]).copy_to(dev)
+    with torch.no_grad():
+        out = model.compute_batch_output(batch)
+    if os.environ.get("PMT_SHAPE", "") == "bf16x3":
+        model.engine().check_join_fault()  # nothing to report
+        with torch.no_grad():
+            ref = O.compute_batch_output(sd, config_for("p0_b16"), b["reads_re"], b["nref"], b["nalt"], b["info_be"], b["haplotypes_bh"])
+        assert torch.allclose(out.features_be.cpu(), ref["features_be"], rtol=1e-4, atol=1e-2)
+    else:
+        with pytest.raises(PmtError, match="range"):
+            model.engine().check_join_fault()
+        model.engine().check_join_fault()  # cleared
