@@ -410,3 +410,48 @@ def test_an_activation_beyond_the_f16_operand_range_is_reported_not_clipped(monk
         with pytest.raises(PmtError, match="range"):
             model.engine().check_join_fault()
         model.engine().check_join_fault()  # cleared
+
+
+def test_a_model_with_the_production_tiles_but_other_widths_matches_the_oracle(monkeypatch):
+    """pmt_shape_id 6 in the DEFAULT library: a model that fills the production tile counts (4, 2, 4, 1) with other widths -- read
+    width 24, info width 24 (d_model 58), d_ffn 24, feature_dim 12, three blocks -- runs the tile-exact instances on the 16-bit
+    matrix pipes with the widths read at run time (it ran the generic fp32 instance until round 4).  Forward, losses and every
+    gradient against the oracle (no reference fixture has these widths; the oracle is pinned by the ones that exist)."""
+    from permutect_amd.parameters import ModelParameters, P0_CNN
+    from permutect_amd.training.optimizer import FusedClipAdamW
+    if __import__("os").environ.get("PMT_SHAPE", "") != "":
+        pytest.skip("the library's own choice is what is tested")
+    params = ModelParameters([24, -2], 24, 3, [24, -1], [-1, 12], 4, [10, 10], list(P0_CNN), 0.0, 0.3)
+    cfg = O.Config([24, -2], [24, -1], [-1, 12], 24, 3, 4, list(P0_CNN), 61, 71, 42)
+    dev = torch.device("cuda")
+    torch.manual_seed(5)
+    model = ArtifactModel(params, device=dev, **P0_DIMS)
+    with torch.no_grad():
+        for q in model.parameters():
+            q.add_(0.05 * torch.randn_like(q))
+    assert model.engine().shape_id == 6
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    rng = np.random.default_rng(77)
+    nb = 200
+    nref, nalt = rng.integers(0, 11, nb), rng.integers(1, 16, nb)
+    ints, floats, packed = _arrays(nref, nalt, seed=78)
+    batch = Batch.from_arrays(ints, floats, packed).copy_to(dev)
+    model.train(True)
+    out = model.compute_batch_output(batch)
+    losses = model.compute_batch_losses(out, batch)
+    opt = FusedClipAdamW(model, lr=1e-3, weight_decay=0.01)
+    opt.zero_grad()
+    losses.total_loss.backward()
+    torch.cuda.synchronize()
+    i64 = torch.from_numpy(ints.astype(np.int64))
+    ob = dict(reads_re=torch.from_numpy(O.decode_packed_reads(packed).astype(np.float32)), nref=i64[:, O.REF_COUNT], nalt=i64[:, O.ALT_COUNT],
+              labels=i64[:, O.LABEL], sources=i64[:, O.SOURCE], info_be=torch.from_numpy(floats[:, O.INFO_START:].astype(np.float32)),
+              haplotypes_bh=i64[:, O.HAPLOTYPES_START:])
+    ref_out, ref_losses, ref_grads = O.train_step_grads(sd, cfg, ob)
+    check_outputs(out, {"out/" + k: v.detach().numpy() for k, v in ref_out.items()}, "p0_other_widths")
+    ref_total = ref_losses["total_losses_b"].detach().numpy()
+    np.testing.assert_allclose(losses.total_losses_b.detach().cpu().numpy(), ref_total, rtol=1e-4, atol=1e-4 + 1e-5 * np.abs(ref_total).max())
+    names = [n for n, _ in model.named_parameters()]
+    gref = np.concatenate([ref_grads[n].numpy().ravel() for n in names])
+    gour = np.concatenate([p.grad.detach().cpu().numpy().ravel() for _, p in model.named_parameters()])
+    assert np.all(np.isfinite(gour)) and np.linalg.norm(gour - gref) <= 1e-4 * np.linalg.norm(gref)
