@@ -494,22 +494,7 @@ def main():
                 small[f"b{bsz}"] = {"train_read_sets_per_s": bsz * k / et, "train_ms_per_step": 1e3 * et / k,
                                     "filter_read_sets_per_s": bsz * k / ef, "filter_ms_per_step": 1e3 * ef / k}
                 continue
-            # the same train step as ONE captured HIP graph (engine/graph.py); every replay is preceded by the upload of a new
-            # batch into the graph's static buffers, as a training loop would do it
-            from permutect_amd.engine.graph import GraphedTrainStep, StaticBatch
             hosts = [Batch.from_arrays(*synth_arrays(srng, bsz, "wgs"), pack=True).pin_memory() for _ in range(4)]
-            static = StaticBatch(bsz, max_reads=26 * bsz, device=dev, int_cols=58, float_cols=77)
-            gstep = GraphedTrainStep(model, opt, static)
-            for i in range(10):
-                static.load(hosts[i % 4])
-                gstep()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(k):
-                static.load(hosts[i % 4])
-                gstep()
-            torch.cuda.synchronize()
-            eg = time.perf_counter() - t0
             # like for like: the EAGER step with the same per-step upload of a pinned host batch
             model.train(True)
             for i in range(10):
@@ -520,12 +505,9 @@ def main():
                 train_step(hosts[i % 4].copy_to(dev))
             torch.cuda.synchronize()
             eu = time.perf_counter() - t0
-            note(f"B={bsz}: train {1e3 * et / k:.3f} ms/step resident; with a batch upload per step: eager {1e3 * eu / k:.3f}, captured graph {1e3 * eg / k:.3f}; "
-                 f"filter {1e3 * ef / k:.3f} ms/step")
+            note(f"B={bsz}: train {1e3 * et / k:.3f} ms/step resident, {1e3 * eu / k:.3f} with a batch upload per step; filter {1e3 * ef / k:.3f} ms/step")
             small[f"b{bsz}"] = {"train_read_sets_per_s": bsz * k / et, "train_ms_per_step": 1e3 * et / k,
-                                "train_eager_with_upload_ms_per_step": 1e3 * eu / k,
-                                "train_graph_read_sets_per_s": bsz * k / eg, "train_graph_ms_per_step": 1e3 * eg / k,
-                                "train_graph_note": "graph and eager_with_upload both include the H2D upload of a new pinned host batch per step; train_ms_per_step is on resident batches",
+                                "train_with_upload_ms_per_step": 1e3 * eu / k,
                                 "filter_read_sets_per_s": bsz * k / ef, "filter_ms_per_step": 1e3 * ef / k}
 
     # ---- BASELINE configs[4]: high-depth stress, mean 600 reads per variant (read sets split over workgroups: layered launches) --

@@ -1000,7 +1000,7 @@ static int cnn3_grid(int n, int v, int nw, int dev) {
 // More than 64 KiB of dynamic LDS needs the function attribute.  It is a property of the loaded code object on a device, not
 // library state that results depend on: raised (never lowered) under a mutex, per device and kernel, remembered so that the
 // steady state makes no runtime call.  The call is not a stream operation and must stay out of a stream capture
-// (engine/graph.py warms up eagerly first).  Devices beyond the table are simply set every time.
+// (tests/graph_capture.py warms up eagerly first).  Devices beyond the table are simply set every time.
 #include <mutex>
 static bool cnn3_allow_lds(const void* kernel, size_t bytes, int which, int dev) {
     static std::mutex mu;

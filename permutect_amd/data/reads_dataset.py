@@ -634,6 +634,9 @@ class DeviceChunkLoader:
         """One chunk is trained on while the next ones are read, staged and uploaded by background threads."""
         from collections import deque
         from concurrent.futures import ThreadPoolExecutor
+        import time as _time
+        _t_iter = _time.perf_counter()
+        _timing = bool(os.environ.get("PMT_LOADER_TIMING"))
         order_c = self.rng.permutation(len(self.ranges)) if self.shuffle else np.arange(len(self.ranges))
         seeds = self.rng.integers(0, 2 ** 63 - 1, size=len(order_c))  # one stream per chunk: the prefetch thread shuffles
         self._stages = _STAGES.acquire()
@@ -692,10 +695,14 @@ class DeviceChunkLoader:
                     submit(i)
                     submitted += 1
                 ahead = None
+                if _timing:
+                    print(f"[loader] iteration set up and first loads submitted after {1e3 * (_time.perf_counter() - _t_iter):.2f} ms", flush=True)
                 for i in range(len(order_c)):
                     if i < staged:
                         pending[0].result()  # (this piece's copies are on the upload stream: the next piece may enqueue its own)
                     chunk, batches, done = pending.popleft().result()
+                    if _timing and i < 3:
+                        print(f"[loader] chunk {i} ({len(batches)} batches) in hand after {1e3 * (_time.perf_counter() - _t_iter):.2f} ms", flush=True)
                     want = i + 2 if i + 1 < staged else i + 1 + _PREFETCH
                     while submitted < min(want, len(order_c)):
                         submit(submitted)

@@ -182,7 +182,7 @@ class ReadSetEngine:
         bv.total_tiles = plan.total_tiles
         bv.debug_flags = self.plan.debug_flags.data_ptr()
         bv.group_span = _ptr(span)
-        bv.num_groups_dev = _ptr(getattr(plan, "num_groups_dev", None))  # (engine/graph.py: a plan sized for a capacity)
+        bv.num_groups_dev = _ptr(getattr(plan, "num_groups_dev", None))  # (tests/graph_capture.py: a plan sized for a capacity)
         # split read sets: with the number of groups per variant the layered entry points run ONE joined launch each way
         # (PMT_LAYERED_JOIN=0: num_blocks + 1 launches with the activations parked in between; the parity tests run both)
         sets = plan.set_groups_on(self.device) if (getattr(plan, "set_groups", None) is not None and self.join_layered) else None

@@ -45,7 +45,7 @@ class FusedClipAdamW:
         """`pre_reduce(flat_grad)` (optional) runs before the clip: the data-parallel all-reduce hook.
         `step_on_device`: the step number (Adam's bias correction) is read from, and incremented in, device memory by the
         launch itself (PMT_STEP_ON_DEVICE) -- what a captured graph needs; the caller keeps `step_count` in step
-        (engine/graph.py)."""
+        (tests/graph_capture.py)."""
         space = self._bind()
         if pre_reduce is not None:
             pre_reduce(space.gtheta)

@@ -1,4 +1,12 @@
-"""A whole training step as ONE captured HIP graph, for the batch sizes where the host is the bottleneck.
+"""TEST INFRASTRUCTURE (moved out of the product package in round 4): a whole training step as ONE captured HIP graph.
+
+It proves a property of the C ABI -- every entry point of a training step is stream-ordered, allocates nothing and reads what varies
+from device memory, so the step can be captured and replayed (tests/test_graph_gpu.py) -- and it is kept for that.  As a PRODUCT path
+it earned nothing: at B = 64 / 8 192 a replay (0.68 / 1.09 ms with the batch upload) does not beat the eager step (0.54 - 0.71 /
+1.11 ms); a step's ~27 kernels are a dependent chain whose device time (0.46 / 0.83 ms) is the floor either way, and hipGraph's
+per-node launch cost is not below the stream's.  The original description:
+
+A whole training step as ONE captured HIP graph, for the batch sizes where the host is the bottleneck.
 
 At the reference's default training batch (64 read sets, parameters.py:214) a step is ~0.2 ms of kernels inside ~0.6-0.9 ms
 of Python, autograd and launch overhead (~45 launches).  `GraphedTrainStep` captures zero_grad -> forward -> losses ->

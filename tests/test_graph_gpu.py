@@ -1,4 +1,4 @@
-"""The captured-graph training step (engine/graph.py) against the eager step on the same sequence of batches: same kernels,
+"""The captured-graph training step (tests/graph_capture.py: test infrastructure that proves the C ABI capturable) against the eager step on the same sequence of batches: same kernels,
 so parameters agree to the order-dependence of the float atomics; the batch data, its group count and the optimizer's step
 number all reach the replay through device memory."""
 import numpy as np
@@ -8,7 +8,7 @@ import torch
 from permutect_amd.architecture.artifact_model import ArtifactModel
 from permutect_amd.data.batch import Batch
 from permutect_amd.engine import lib as L
-from permutect_amd.engine.graph import GraphedTrainStep, StaticBatch
+from tests.graph_capture import GraphedTrainStep, StaticBatch
 from permutect_amd.parameters import P0_DIMS, p0_params
 from permutect_amd.training.optimizer import FusedClipAdamW, backpropagate
 
