@@ -7,6 +7,9 @@
 #include "pmt_device.hpp"
 #include "pmt_mlp_device.hpp"
 
+#ifndef PMT_LAYERED_WIDE
+#define PMT_LAYERED_WIDE 0  // 1: the instances for split read sets at 256 registers / two waves per SIMD (A/B switch)
+#endif
 #ifndef PMT_F16_X1
 #define PMT_F16_X1 1  // the first read-MLP linear on one-piece inputs (0: two pieces like every other layer; A/B switch)
 #endif
@@ -97,7 +100,7 @@ struct FwdTrace {
 };
 
 template <bool TRAIN, typename S, bool LAYERED = false>
-__global__ __launch_bounds__(PMT_THREADS, S::EXACT ? 4 : 2) void pmt_forward_kernel(const PmtModel* __restrict__ M,
+__global__ __launch_bounds__(PMT_THREADS, (S::EXACT && !(LAYERED && PMT_LAYERED_WIDE)) ? 4 : 2) void pmt_forward_kernel(const PmtModel* __restrict__ M,
                                                                       const float* __restrict__ theta,
                                                                       const float* __restrict__ phi,
                                                                       const float* __restrict__ packed, PmtBatch bt,
