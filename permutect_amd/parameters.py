@@ -148,3 +148,47 @@ def t0_params() -> ModelParameters:
 
 
 P0_DIMS = dict(num_read_features=61, num_info_features=71, haplotypes_length=42)
+
+
+# ---- the reference's command-line flags (parameters.py:43-242): same names, same defaults --------------------------------------
+def parse_model_params(args) -> ModelParameters:
+    from permutect_amd import constants as c
+    return ModelParameters(getattr(args, c.READ_LAYERS_NAME), getattr(args, c.SELF_ATTENTION_HIDDEN_DIMENSION_NAME),
+                           getattr(args, c.NUM_SELF_ATTENTION_LAYERS_NAME), getattr(args, c.INFO_LAYERS_NAME),
+                           getattr(args, c.AGGREGATION_LAYERS_NAME), getattr(args, c.NUM_ARTIFACT_CLUSTERS_NAME),
+                           getattr(args, c.CALIBRATION_LAYERS_NAME), getattr(args, c.REF_SEQ_LAYER_STRINGS_NAME),
+                           getattr(args, c.DROPOUT_P_NAME), getattr(args, c.REWEIGHTING_RANGE_NAME), getattr(args, c.BATCH_NORMALIZE_NAME))
+
+
+def add_model_params_to_parser(parser) -> None:
+    from permutect_amd import constants as c
+    parser.add_argument("--" + c.PRETRAINED_ARTIFACT_MODEL_NAME, type=str, required=False, help="optional pretrained artifact model to start from")
+    parser.add_argument("--" + c.READ_LAYERS_NAME, nargs="+", type=int, required=True, help="read embedding layers; -d = a d-layer residual skip block")
+    parser.add_argument("--" + c.SELF_ATTENTION_HIDDEN_DIMENSION_NAME, type=int, required=True, help="hidden dimension (d_ffn) of the gated blocks")
+    parser.add_argument("--" + c.NUM_SELF_ATTENTION_LAYERS_NAME, type=int, required=True, help="number of gated ref / alt blocks")
+    parser.add_argument("--" + c.INFO_LAYERS_NAME, nargs="+", type=int, required=True, help="info embedding layers")
+    parser.add_argument("--" + c.AGGREGATION_LAYERS_NAME, nargs="+", type=int, required=True, help="reducer layers behind the gated blocks")
+    parser.add_argument("--" + c.NUM_ARTIFACT_CLUSTERS_NAME, type=int, default=4, required=False, help="artifact clusters of the generative head")
+    parser.add_argument("--" + c.CALIBRATION_LAYERS_NAME, nargs="+", type=int, required=True, help="calibration layers (kept in the checkpoint's hyperparameters)")
+    parser.add_argument("--" + c.REF_SEQ_LAYER_STRINGS_NAME, nargs="+", type=str, required=True, help="haplotype CNN layer strings, e.g. convolution/kernel_size=3/out_channels=64")
+    parser.add_argument("--" + c.DROPOUT_P_NAME, type=float, default=0.0, required=False, help="dropout probability")
+    parser.add_argument("--" + c.REWEIGHTING_RANGE_NAME, type=float, default=0.3, required=False, help="reweighting range")
+    parser.add_argument("--" + c.BATCH_NORMALIZE_NAME, action="store_true", help="BatchNorm1d in front of every Linear (runs in eval mode only here)")
+
+
+def parse_training_params(args) -> TrainingParameters:
+    from permutect_amd import constants as c
+    return TrainingParameters(getattr(args, c.BATCH_SIZE_NAME), getattr(args, c.NUM_EPOCHS_NAME), getattr(args, c.LEARNING_RATE_NAME),
+                              getattr(args, c.WEIGHT_DECAY_NAME), getattr(args, c.NUM_WORKERS_NAME), getattr(args, c.NUM_CALIBRATION_EPOCHS_NAME),
+                              getattr(args, c.INFERENCE_BATCH_SIZE_NAME))
+
+
+def add_training_params_to_parser(parser) -> None:
+    from permutect_amd import constants as c
+    parser.add_argument("--" + c.LEARNING_RATE_NAME, type=float, default=0.001, required=False, help="learning rate")
+    parser.add_argument("--" + c.WEIGHT_DECAY_NAME, type=float, default=0.0, required=False, help="weight decay")
+    parser.add_argument("--" + c.BATCH_SIZE_NAME, type=int, default=64, required=False, help="batch size")
+    parser.add_argument("--" + c.NUM_WORKERS_NAME, type=int, default=0, required=False, help="accepted for compatibility (the device chunk loader has its own prefetch threads)")
+    parser.add_argument("--" + c.NUM_EPOCHS_NAME, type=int, required=True, help="training epochs")
+    parser.add_argument("--" + c.NUM_CALIBRATION_EPOCHS_NAME, type=int, default=0, required=False, help="calibration-only epochs behind them")
+    parser.add_argument("--" + c.INFERENCE_BATCH_SIZE_NAME, type=int, default=8192, required=False, help="batch size of the evaluation passes")

@@ -307,3 +307,45 @@ def test_device_posterior_rows_match_the_reference_fixture_directly():
     got = scattered.cpu().numpy()
     np.testing.assert_array_equal(got[perm.cpu().numpy()], want)
     assert np.isnan(got[n:]).all()
+
+
+def test_train_artifact_model_tool_runs_the_references_own_tool_test():
+    """BASELINE configs[0] on a synthetic tar in the reference's format: `tools/train_artifact_model.main_without_parsing` with the
+    Namespace of the reference's tool test (test/tools/test_train_permutect_model.py:14-64: T0 hyperparameters, two epochs, batch 64)
+    -- same flag names through the same `parse_*_params` -- trains, saves a `.pt` in the reference's dictionary format, and the
+    saved model loads back and filters.  (The reference asserts only that much: events load, the model re-loads.)"""
+    import argparse
+    import os
+    import tempfile
+    from permutect_amd import constants
+    from permutect_amd.architecture.artifact_model import load_model
+    from permutect_amd.parameters import T0_CNN
+    from permutect_amd.tools import train_artifact_model as tool
+    from tests.helpers import GOLDEN
+    args = argparse.Namespace()
+    for name, value in ((constants.READ_LAYERS_NAME, [10, 10, 10]), (constants.SELF_ATTENTION_HIDDEN_DIMENSION_NAME, 20),
+                        (constants.NUM_SELF_ATTENTION_LAYERS_NAME, 2), (constants.INFO_LAYERS_NAME, [10, 10]),
+                        (constants.AGGREGATION_LAYERS_NAME, [20, 20, 20]), (constants.NUM_ARTIFACT_CLUSTERS_NAME, 4),
+                        (constants.CALIBRATION_LAYERS_NAME, [10, 10, 10]), (constants.REF_SEQ_LAYER_STRINGS_NAME, list(T0_CNN)),
+                        (constants.DROPOUT_P_NAME, 0.0), (constants.BATCH_NORMALIZE_NAME, False),
+                        (constants.TRAIN_TAR_NAME, os.path.join(GOLDEN, "tiny_dataset.tar")), (constants.PRETRAINED_ARTIFACT_MODEL_NAME, None),
+                        (constants.REWEIGHTING_RANGE_NAME, 0.3), (constants.BATCH_SIZE_NAME, 64), (constants.INFERENCE_BATCH_SIZE_NAME, 64),
+                        (constants.NUM_WORKERS_NAME, 2), (constants.NUM_EPOCHS_NAME, 2), (constants.NUM_CALIBRATION_EPOCHS_NAME, 0),
+                        (constants.LEARNING_RATE_NAME, 0.001), (constants.WEIGHT_DECAY_NAME, 0.01)):
+        setattr(args, name, value)
+    with tempfile.TemporaryDirectory() as d:
+        setattr(args, constants.OUTPUT_NAME, os.path.join(d, "model.pt"))
+        setattr(args, constants.TENSORBOARD_DIR_NAME, os.path.join(d, "tb"))
+        history = tool.main_without_parsing(args, log=lambda *_: None)
+        assert [h[:2] for h in history] == [(1, "TRAIN"), (1, "VALID"), (2, "TRAIN"), (2, "VALID")] and all(np.isfinite(h[2]) for h in history)
+        model, _, _ = load_model(getattr(args, constants.OUTPUT_NAME), device=torch.device("cuda:0"))
+    ds = _dataset()
+    model.eval()
+    with torch.inference_mode():
+        for cb in ds.device_loader(64, torch.device("cuda:0"), shuffle=False):
+            assert torch.isfinite(model.compute_batch_output(cb).logits_b).all()
+    # and the command line itself parses the reference's flags
+    ns = tool.parse_arguments(["--train_tar", "x.tar", "--output", "m.pt", "--read_layers", "30", "-2", "--self_attention_hidden_dimension", "20",
+                               "--num_self_attention_layers", "6", "--info_layers", "20", "-2", "--aggregation_layers", "-2", "10",
+                               "--calibration_layers", "10", "10", "--ref_seq_layer_strings", "flatten", "linear/out_features=10", "--num_epochs", "3"])
+    assert ns.read_layers == [30, -2] and ns.batch_size == 64 and ns.inference_batch_size == 8192 and ns.weight_decay == 0.0 and ns.num_epochs == 3
