@@ -399,7 +399,8 @@ def main():
         # untimed pre-roll on top of the counted warm-up: the card's clocks need ~15 ms of work to come back after an idle stretch and a
         # `--steps 20` run would sit inside that ramp; resident batches only (a streamed pass has its own fill)
         t_pre = time.perf_counter()
-        if preroll_s > 0 and pool is batches and stream_batches is None:
+        did_preroll = preroll_s > 0 and pool is batches and stream_batches is None
+        if did_preroll:
             go = True
             while go:
                 for i in range(4):
@@ -410,7 +411,8 @@ def main():
                     flag = torch.tensor([1 if go else 0], device=dev, dtype=torch.int32)
                     dist.broadcast(flag, src=0)
                     go = bool(flag.item())
-        prerolled[mode] = time.perf_counter() - t_pre
+        if did_preroll:
+            prerolled[mode] = time.perf_counter() - t_pre
         for i in range(warmup):
             fn(nxt(i))
         eng.timers = {"pmt_forward": [], "pmt_backward": []}
