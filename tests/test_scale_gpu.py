@@ -360,3 +360,69 @@ def test_gradients_against_an_fp64_evaluation_stay_inside_the_reference_fp32_err
     fp32 = float(np.linalg.norm(grads[torch.float32] - ref) / np.linalg.norm(ref))
     record(test="grad_vs_fp64_4096", hip_vs_fp64=hip, fp32_oracle_vs_fp64=fp32)
     assert hip <= 2e-5 and hip <= 1.5 * fp32, (hip, fp32)
+
+
+def test_domain_properties_at_the_benchmarked_size():
+    """Properties of the model that need no oracle, at bench.py's full launch size (65 536 read sets, production hyperparameters) --
+    what the reference's architecture promises by construction (DeepSets: gated_mlp.py:236-239, feature_clustering.py:111-113):
+      * permutation INVARIANCE within a read set: shuffling every variant's ref reads among themselves and its alt reads among
+        themselves changes no output beyond fp32 summation-order noise (the reads then sit in other lanes, tiles and sum orders;
+        measured 6e-5 on the worst of 65 536 logits -- the size of the fp32 reference's own batch dependence, 5e-5 -- bound: the
+        contract's 1e-4);
+      * permutation EQUIVARIANCE over variants: a batch with its variants (and their reads) in another order gives the same logits in
+        that order -- other groups, other workgroups, other neighbours in every tile;
+      * independence of read sets: the first 4 096 variants computed alone equal their logits inside the big batch;
+      * the gradient is additive over variants (loss = a batch sum, artifact_model.py:90): the gradient of the whole batch equals
+        the sum of the gradients of its two halves (1e-4 relative L2: float atomics in other orders)."""
+    from bench import synth_arrays
+    _, sd, _ = load_case("p0_b16")
+    model, dev = build("p0_b16", sd)
+    nb = 65536
+    ints, floats, packed = synth_arrays(np.random.default_rng(2025), nb, "wgs")
+    nref, nalt = ints[:, 0].astype(np.int64), ints[:, 1].astype(np.int64)
+    rs = np.concatenate([[0], np.cumsum(nref)])
+    as_ = int(nref.sum()) + np.concatenate([[0], np.cumsum(nalt)])
+    rng = np.random.default_rng(7)
+
+    def forward(i, f, p, pack=True):
+        b = Batch.from_arrays(i, f, p, pack=pack).copy_to(dev)
+        model.eval()
+        with torch.inference_mode():
+            out = model.compute_batch_output(b)
+        order = np.arange(len(i)) if b.order is None else np.asarray(b.order)
+        inv = np.empty_like(order)
+        inv[order] = np.arange(len(order))
+        return out.logits_b.cpu().numpy()[inv], out.features_be.cpu().numpy()[inv]  # in the order of the arrays given
+    base_logits, base_feats = forward(ints, floats, packed)
+    assert np.all(np.isfinite(base_logits))
+    # invariance within sets: a random permutation of every segment of rows (one argsort of (segment id, random key))
+    seg = np.concatenate([np.repeat(np.arange(nb), nref), nb + np.repeat(np.arange(nb), nalt)])
+    within = np.lexsort((rng.random(len(seg)), seg))
+    l2, f2 = forward(ints, floats, packed[within])
+    assert np.abs(l2 - base_logits).max() <= 1e-4 and np.abs(f2 - base_feats).max() <= 2e-5 * max(1.0, np.abs(base_feats).max())
+    # equivariance over variants
+    perm = rng.permutation(nb)
+    rows = np.concatenate([np.concatenate([np.arange(rs[v], rs[v + 1]) for v in perm]), np.concatenate([np.arange(as_[v], as_[v + 1]) for v in perm])])
+    l3, _ = forward(ints[perm], floats[perm], packed[rows], pack=False)
+    assert np.abs(l3 - base_logits[perm]).max() <= 1e-4
+    # independence of read sets
+    k = 4096
+    rows_k = np.concatenate([np.arange(rs[0], rs[k]), np.arange(as_[0], as_[k])])
+    l4, _ = forward(ints[:k], floats[:k], packed[rows_k])
+    assert np.abs(l4 - base_logits[:k]).max() <= 1e-4
+    # additivity of the gradient over variants
+    def grad_of(lo, hi):
+        r = np.concatenate([np.arange(rs[lo], rs[hi]), np.arange(as_[lo], as_[hi])])
+        b = Batch.from_arrays(ints[lo:hi], floats[lo:hi], packed[r], pack=True).copy_to(dev)
+        model.train(True)
+        opt = FusedClipAdamW(model, lr=1e-3, weight_decay=0.0)
+        opt.zero_grad()
+        model.compute_batch_losses(model.compute_batch_output(b), b).total_loss.backward()
+        torch.cuda.synchronize()
+        return model.engine().space.gtheta.detach().cpu().double().clone()
+    whole, first, second = grad_of(0, nb), grad_of(0, nb // 2), grad_of(nb // 2, nb)
+    rel = float((whole - (first + second)).norm() / whole.norm())
+    record(test="domain_properties_65536", invariance_within_sets=float(np.abs(l2 - base_logits).max()),
+           equivariance_over_variants=float(np.abs(l3 - base_logits[perm]).max()), independence_of_sets=float(np.abs(l4 - base_logits[:k]).max()),
+           gradient_additivity_rel_l2=rel)
+    assert torch.isfinite(whole).all() and rel <= 1e-4
