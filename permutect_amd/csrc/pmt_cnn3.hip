@@ -369,36 +369,67 @@ __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_forward_kernel(
 DEV int c3_chan_of_elem(int e) { return 16 * (e >> 4) + 4 * (e & 3) + ((e & 15) >> 2); }  // record element -> channel
 typedef unsigned c3_u4 __attribute__((ext_vector_type(4)));
 typedef unsigned c3_u2 __attribute__((ext_vector_type(2)));
-// the A fragment of lane `ln` (row m = ln & 15, k = 8 (ln >> 4) + i) in three pieces: dst[piece * 64 + ln]
-template <typename F>
-DEV void c3b_build_frag(bf8* __restrict__ dst, int ln, F value) {
-    unsigned h[4], m[4], l[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) split_pair<3>(value(2 * q), value(2 * q + 1), h[q], m[q], l[q]);
-    dst[ln] = __builtin_bit_cast(bf8, c3_u4{h[0], h[1], h[2], h[3]});
-    dst[64 + ln] = __builtin_bit_cast(bf8, c3_u4{m[0], m[1], m[2], m[3]});
-    dst[128 + ln] = __builtin_bit_cast(bf8, c3_u4{l[0], l[1], l[2], l[3]});
+// Round 4: the pieces are TWO f16 values per operand with the low one scaled by 2^12 (pmt_device.hpp, linear_acc_f16: fp32-equivalent
+// like three bf16 pieces) -- three MFMAs per product instead of six (conv1: two instead of three), five vector operations per
+// pair of activations instead of nine, 128 bytes of LDS per column instead of 192.  C3_F16 = 0 keeps the bf16 form (A/B runs).
+#ifndef C3_F16
+#define C3_F16 1
+#endif
+#if C3_F16
+typedef h8 c3p8;
+#define C3_NP 2
+#define C3_ONE ((unsigned short)0x3C00)  // 1.0 as f16
+DEV f4 c3p_mfma(c3p8 a, c3p8 b, f4 c) { return mfma_f16(a, b, c); }
+DEV void c3p_split(float a, float b, unsigned (&pc)[3]) {
+    float k = 4096.f;
+    asm volatile("" : "+v"(k));
+    split_pair_f16(a, b, pc[0], pc[1], k);
+    pc[2] = 0u;
 }
-// acc += A B with both operands in three pieces (smallest terms first)
-DEV f4 c3b_mfma6(const bf8 (&a)[3], const bf8 (&b)[3], f4 acc) {
+// acc += hi products, lo += the two first-order products (scaled by 2^12: the caller joins lo * 2^-12 once per accumulator)
+DEV void c3p_mma(const c3p8 (&a)[C3_NP], const c3p8 (&b)[C3_NP], f4& acc, f4& lo) {
+    lo = c3p_mfma(a[1], b[0], lo);
+    lo = c3p_mfma(a[0], b[1], lo);
+    acc = c3p_mfma(a[0], b[0], acc);
+}
+DEV f4 c3p_join(f4 acc, f4 lo) { return lo * (1.0f / 4096.f) + acc; }
+#else
+typedef bf8 c3p8;
+#define C3_NP 3
+#define C3_ONE ((unsigned short)0x3F80)  // 1.0 as bf16
+DEV f4 c3p_mfma(c3p8 a, c3p8 b, f4 c) { return mfma_bf16(a, b, c); }
+DEV void c3p_split(float a, float b, unsigned (&pc)[3]) { split_pair<3>(a, b, pc[0], pc[1], pc[2]); }
+// acc += A B with both operands in three pieces (smallest terms first); lo unused
+DEV void c3p_mma(const c3p8 (&a)[C3_NP], const c3p8 (&b)[C3_NP], f4& acc, f4& lo) {
     acc = mfma_bf16(a[2], b[0], acc);
     acc = mfma_bf16(a[0], b[2], acc);
     acc = mfma_bf16(a[1], b[1], acc);
     acc = mfma_bf16(a[1], b[0], acc);
     acc = mfma_bf16(a[0], b[1], acc);
-    return mfma_bf16(a[0], b[0], acc);
+    acc = mfma_bf16(a[0], b[0], acc);
+}
+DEV f4 c3p_join(f4 acc, f4 lo) { return acc; }
+#endif
+#define C3_COL_BYTES (64 * C3_NP)  // one column of activations in LDS: [piece][32 channels]
+// the A fragment of lane `ln` (row m = ln & 15, k = 8 (ln >> 4) + i) in C3_NP pieces: dst[piece * 64 + ln]
+template <typename F>
+DEV void c3b_build_frag(c3p8* __restrict__ dst, int ln, F value) {
+    unsigned pc[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c3p_split(value(2 * q), value(2 * q + 1), pc[q]);
+#pragma unroll
+    for (int k = 0; k < C3_NP; ++k) dst[64 * k + ln] = __builtin_bit_cast(c3p8, c3_u4{pc[0][k], pc[1][k], pc[2][k], pc[3][k]});
 }
 // four activations of one 16-block -> 8 bytes per piece at dst + piece * 64
 DEV void c3b_store_pieces(unsigned char* dst, f4 v) {
-    unsigned h0, m0, l0, h1, m1, l1;
-    split_pair<3>(v[0], v[1], h0, m0, l0);
-    split_pair<3>(v[2], v[3], h1, m1, l1);
-    *reinterpret_cast<c3_u2*>(dst) = c3_u2{h0, h1};
-    *reinterpret_cast<c3_u2*>(dst + 64) = c3_u2{m0, m1};
-    *reinterpret_cast<c3_u2*>(dst + 128) = c3_u2{l0, l1};
+    unsigned p0[3], p1[3];
+    c3p_split(v[0], v[1], p0);
+    c3p_split(v[2], v[3], p1);
+#pragma unroll
+    for (int k = 0; k < C3_NP; ++k) *reinterpret_cast<c3_u2*>(dst + 64 * k) = c3_u2{p0[k], p1[k]};
 }
 __host__ __device__ inline size_t c3b_wave_bytes(int V, int S, int P1, int ST2) {
-    return (size_t)((V * (S * 10 + C3B_OH_PAD) * 2 + 15) & ~15) + (size_t)V * P1 * 192 + (size_t)V * ST2 * 192;
+    return (size_t)((V * (S * 10 + C3B_OH_PAD) * 2 + 15) & ~15) + (size_t)V * P1 * C3_COL_BYTES + (size_t)V * ST2 * C3_COL_BYTES;
 }
 
 // A1 / A2: the two activations at compile time (0 = read the configuration: both kinds are then evaluated per element);
@@ -416,28 +447,29 @@ __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_forward_bf_kernel(
     const int OHS = S * 10 + C3B_OH_PAD;  // bf16 elements of one variant's one-hot array
     // ---- LDS: [linear weights: L2 x 3 pieces x 1 KiB][biases: 80 floats][staging of conv1 / conv2 weights | the waves' regions]
     unsigned char* base = reinterpret_cast<unsigned char*>(lds);
-    bf8* wlb = reinterpret_cast<bf8*>(base);
-    float* bp = reinterpret_cast<float*>(base + L2 * 3072);
-    unsigned char* dyn = base + L2 * 3072 + 320;
-    bf8* w1s = reinterpret_cast<bf8*>(dyn);
-    bf8* w2s = w1s + 2 * 192;
+    if (C3_F16) fp16_saturate_on();  // (f16 pieces beyond +-65504 saturate, never inf: pmt_device.hpp)
+    c3p8* wlb = reinterpret_cast<c3p8*>(base);
+    float* bp = reinterpret_cast<float*>(base + L2 * C3_NP * 1024);
+    unsigned char* dyn = base + L2 * C3_NP * 1024 + 320;
+    c3p8* w1s = reinterpret_cast<c3p8*>(dyn);
+    c3p8* w2s = w1s + 2 * 64 * C3_NP;
     for (int e = tid; e < 2 * 64; e += 64 * NW) {
         const int ln = e & 63, mt = e >> 6, co = 16 * mt + c3_row(ln & 15), kg = ln >> 4;
-        c3b_build_frag(w1s + mt * 192, ln, [&](int i) {
+        c3b_build_frag(w1s + mt * 64 * C3_NP, ln, [&](int i) {
             const int k = 8 * kg + i, tap = k / 10, ci = k - 10 * tap;
             return (k < 10 * K1 && co < c.C1) ? theta[c.w1 + (co * 10 + ci) * K1 + tap] : 0.f;
         });
     }
     for (int e = tid; e < K2 * 2 * 64; e += 64 * NW) {
         const int ln = e & 63, tm = e >> 6, tap = tm >> 1, mt = tm & 1, co = 16 * mt + c3_row(ln & 15), kg = ln >> 4;
-        c3b_build_frag(w2s + tm * 192, ln, [&](int i) {
+        c3b_build_frag(w2s + tm * 64 * C3_NP, ln, [&](int i) {
             const int ci = c3_chan_of_elem(8 * kg + i);
             return (co < c.C2 && ci < c.C1) ? theta[c.w2 + (co * c.C1 + ci) * K2 + tap] : 0.f;
         });
     }
     for (int e = tid; e < L2 * 64; e += 64 * NW) {
         const int ln = e & 63, p = e >> 6, o = c3_row(ln & 15), kg = ln >> 4;
-        c3b_build_frag(wlb + p * 192, ln, [&](int i) {
+        c3b_build_frag(wlb + p * 64 * C3_NP, ln, [&](int i) {
             const int ch = c3_chan_of_elem(8 * kg + i);
             return (o < c.O && ch < c.C2) ? theta[c.wl + o * c.F + ch * L2 + p] : 0.f;
         });
@@ -451,24 +483,24 @@ __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_forward_bf_kernel(
         bp[i] = v;
     }
     __syncthreads();
-    bf8 w1r[2][3], w2r[K2][2][3];
+    c3p8 w1r[2][C3_NP], w2r[K2][2][C3_NP];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) w1r[mt][pc] = w1s[(mt * 3 + pc) * 64 + lane];
+        for (int pc = 0; pc < C3_NP; ++pc) w1r[mt][pc] = w1s[(mt * C3_NP + pc) * 64 + lane];
 #pragma unroll
     for (int tap = 0; tap < K2; ++tap)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) w2r[tap][mt][pc] = w2s[((tap * 2 + mt) * 3 + pc) * 64 + lane];
+            for (int pc = 0; pc < C3_NP; ++pc) w2r[tap][mt][pc] = w2s[((tap * 2 + mt) * C3_NP + pc) * 64 + lane];
     const f4 b1v[2] = {*reinterpret_cast<const f4*>(bp + 4 * g), *reinterpret_cast<const f4*>(bp + 16 + 4 * g)};
     const f4 b2v[2] = {*reinterpret_cast<const f4*>(bp + 32 + 4 * g), *reinterpret_cast<const f4*>(bp + 48 + 4 * g)};
     const f4 blv = *reinterpret_cast<const f4*>(bp + 64 + 4 * g);
     __syncthreads();  // the staging area is dead: the waves' regions take its place
     unsigned char* oh = dyn + (size_t)wave * c3b_wave_bytes(V, S, P1, ST2);
     unsigned char* a1b = oh + ((V * OHS * 2 + 15) & ~15);
-    unsigned char* a2b = a1b + V * P1 * 192;
+    unsigned char* a2b = a1b + V * P1 * C3_COL_BYTES;
     for (int i = lane; i < (V * OHS) / 2; i += 64) reinterpret_cast<unsigned*>(oh)[i] = 0u;  // (the pads stay zero for good)
     c3_wave_sync();
     const int nbatches = (n + V - 1) / V, n2s = 2 * S;
@@ -500,7 +532,7 @@ __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_forward_bf_kernel(
                 if (i < V * n2s) {
                     unsigned short* dst = reinterpret_cast<unsigned short*>(oh) + v * OHS + pos * 10 + hs;
 #pragma unroll
-                    for (int bs = 0; bs < 5; ++bs) dst[2 * bs] = b[k] == bs ? (unsigned short)0x3F80 : (unsigned short)0;
+                    for (int bs = 0; bs < 5; ++bs) dst[2 * bs] = b[k] == bs ? C3_ONE : (unsigned short)0;
                 }
             }
         }
@@ -515,13 +547,18 @@ __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_forward_bf_kernel(
             const bool in_range = v < V;
             v = min(v, V - 1);
             const unsigned* src = reinterpret_cast<const unsigned*>(oh + 2 * (v * OHS + p * 10 + 8 * g));
-            const bf8 b = __builtin_bit_cast(bf8, c3_u4{src[0], src[1], src[2], src[3]});
+            const c3p8 b = __builtin_bit_cast(c3p8, c3_u4{src[0], src[1], src[2], src[3]});
             f4 acc[2] = {b1v[0], b1v[1]};
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+            for (int mt = 0; mt < 2; ++mt) {  // (the one-hot is exact in one piece: the weights' pieces against it)
+#if C3_F16
+                const f4 lo = c3p_mfma(w1r[mt][1], b, c3_zero());
+                acc[mt] = c3p_join(c3p_mfma(w1r[mt][0], b, acc[mt]), lo);
+#else
                 acc[mt] = mfma_bf16(w1r[mt][2], b, acc[mt]);
                 acc[mt] = mfma_bf16(w1r[mt][1], b, acc[mt]);
                 acc[mt] = mfma_bf16(w1r[mt][0], b, acc[mt]);
+#endif
             }
             const int q = p >> 1;
             const bool store = in_range && !(p & 1) && q < P1;  // (p + 1 < L1 follows from q < P1 = L1 / 2)
@@ -542,7 +579,7 @@ __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_forward_bf_kernel(
                 }
                 m = c3_act4(A1 ? A1 : c.act1, m);
                 if (store) {
-                    c3b_store_pieces(a1b + (v * P1 + q) * 192 + (16 * mt + 4 * g) * 2, m);
+                    c3b_store_pieces(a1b + (v * P1 + q) * C3_COL_BYTES + (16 * mt + 4 * g) * 2, m);
                     if (TRAIN && v < nv) *reinterpret_cast<f4*>(rec0 + (size_t)v * c.stash_per + q * 32 + 16 * mt + 4 * g) = m;
                 }
             }
@@ -558,18 +595,20 @@ __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_forward_bf_kernel(
             const bool valid = v < V && p < L2;
             const bool in_range = v < V;
             v = min(v, V - 1);
-            f4 acc[2] = {b2v[0], b2v[1]};
+            f4 acc[2] = {b2v[0], b2v[1]}, lo2[2] = {c3_zero(), c3_zero()};
 #pragma unroll
             for (int tap = 0; tap < K2; ++tap) {
-                const unsigned char* src = a1b + (v * P1 + min(p + tap, P1 - 1)) * 192 + 16 * g;
-                const bf8 b[3] = {*reinterpret_cast<const bf8*>(src), *reinterpret_cast<const bf8*>(src + 64), *reinterpret_cast<const bf8*>(src + 128)};
+                const unsigned char* src = a1b + (v * P1 + min(p + tap, P1 - 1)) * C3_COL_BYTES + 16 * g;
+                c3p8 b[C3_NP];
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) acc[mt] = c3b_mfma6(w2r[tap][mt], b, acc[mt]);
+                for (int k = 0; k < C3_NP; ++k) b[k] = *reinterpret_cast<const c3p8*>(src + 64 * k);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) c3p_mma(w2r[tap][mt], b, acc[mt], lo2[mt]);
             }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-                const f4 a = valid ? c3_act4(A2 ? A2 : c.act2, acc[mt]) : c3_zero();
-                if (valid) c3b_store_pieces(a2b + (v * ST2 + p) * 192 + (16 * mt + 4 * g) * 2, a);
+                const f4 a = valid ? c3_act4(A2 ? A2 : c.act2, c3p_join(acc[mt], lo2[mt])) : c3_zero();
+                if (valid) c3b_store_pieces(a2b + (v * ST2 + p) * C3_COL_BYTES + (16 * mt + 4 * g) * 2, a);
                 // (the record's padding columns hold zeros, as the backward expects)
                 if (TRAIN && in_range && v < nv) *reinterpret_cast<f4*>(rec0 + (size_t)v * c.stash_per + rec_a2 + p * 32 + 16 * mt + 4 * g) = a;
             }
@@ -578,14 +617,19 @@ __global__ __launch_bounds__(64 * NW, 1) void pmt_cnn3_forward_bf_kernel(
         // ---- flatten + linear: a column per variant --------------------------------------------------------------------------
         {
             const int v = min(r, V - 1);
-            f4 acc = blv;
+            f4 acc = blv, lol = c3_zero();
 #pragma unroll
             for (int p = 0; p < L2; ++p) {
-                const unsigned char* src = a2b + (v * ST2 + p) * 192 + 16 * g;
-                const bf8 b[3] = {*reinterpret_cast<const bf8*>(src), *reinterpret_cast<const bf8*>(src + 64), *reinterpret_cast<const bf8*>(src + 128)};
-                const bf8 a[3] = {wlb[(p * 3 + 0) * 64 + lane], wlb[(p * 3 + 1) * 64 + lane], wlb[(p * 3 + 2) * 64 + lane]};
-                acc = c3b_mfma6(a, b, acc);
+                const unsigned char* src = a2b + (v * ST2 + p) * C3_COL_BYTES + 16 * g;
+                c3p8 b[C3_NP], a[C3_NP];
+#pragma unroll
+                for (int k = 0; k < C3_NP; ++k) {
+                    b[k] = *reinterpret_cast<const c3p8*>(src + 64 * k);
+                    a[k] = wlb[(p * C3_NP + k) * 64 + lane];
+                }
+                c3p_mma(a, b, acc, lol);
             }
+            acc = c3p_join(acc, lol);
             if (r < nv) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -1030,8 +1074,8 @@ extern "C" int pmt_cnn3_try_forward(const PmtModel* model_host, const float* the
         if (leaky && s21) kernel = stash ? pmt_cnn3_forward_bf_kernel<C3_FWD_V, C3_FWD_NW, 3, 3, 7, 21, PMT_CNN_LEAKY_RELU, PMT_CNN_LEAKY_RELU, true>
                                          : pmt_cnn3_forward_bf_kernel<C3_FWD_V, C3_FWD_NW, 3, 3, 7, 21, PMT_CNN_LEAKY_RELU, PMT_CNN_LEAKY_RELU, false>;
         else kernel = stash ? pmt_cnn3_forward_bf_kernel<C3_FWD_V, C3_FWD_NW, 3, 3, 7, 0, 0, 0, true> : pmt_cnn3_forward_bf_kernel<C3_FWD_V, C3_FWD_NW, 3, 3, 7, 0, 0, 0, false>;
-        const size_t regions = (size_t)C3_FWD_NW * c3b_wave_bytes(C3_FWD_V, c.S, c.P1, c.st2), staging = (size_t)(2 + 2 * c.K2) * 3072;
-        lds = (size_t)c.L2 * 3072 + 320 + (regions > staging ? regions : staging);
+        const size_t regions = (size_t)C3_FWD_NW * c3b_wave_bytes(C3_FWD_V, c.S, c.P1, c.st2), staging = (size_t)(2 + 2 * c.K2) * C3_NP * 1024;
+        lds = (size_t)c.L2 * C3_NP * 1024 + 320 + (regions > staging ? regions : staging);
         if (lds > 160 * 1024 || C3_FWD_V * 2 * c.S > 64 * C3_HAP_LOADS) return 1;
     }
     const int dev = cnn3_stream_device(reinterpret_cast<hipStream_t>(stream));
