@@ -359,10 +359,10 @@ DEV void backward_group(
             }
             if (k >= 0) {  // every wave pushes (zeros from a ref wave): the slab layout is workgroup-uniform
                 aux_push_vec_x<NTE, EX>(c, enc_phi(uniform(M->head.dirs_ke_phi) + k * E), dvk, E);
-                aux_push_scalar(c, enc_phi(uniform(M->head.art_stdev_k_phi) + k), d_tau);
-                aux_push_scalar(c, uniform(M->head.mu_k_src) + k, d_mu);
-                aux_push_scalar(c, enc_phi(uniform(M->head.lambda_k_phi) + k), d_lam);
-                aux_push_scalar(c, enc_phi(uniform(M->head.sigma_k_phi) + k), d_sg);
+                const int enc4[4] = {enc_phi(uniform(M->head.art_stdev_k_phi) + k), uniform(M->head.mu_k_src) + k,
+                                     enc_phi(uniform(M->head.lambda_k_phi) + k), enc_phi(uniform(M->head.sigma_k_phi) + k)};
+                const float val4[4] = {d_tau, d_mu, d_lam, d_sg};
+                aux_push_scalars<4>(c, enc4, val4);
             }
         }
         aux_push_vec_x<NTE, EX>(c, enc_phi(uniform(M->head.stdev_e_phi)), dsig, E);
@@ -505,7 +505,15 @@ DEV void backward_group(
         // ---- phase 2: d(u) = W2^T dy, d(gate), per-set sums of d(gate), proj2 weight gradient ------------------------------
         f4 z2hat[PMT_RT], dgate[PMT_RT], du[PMT_RT][1];
         float rstd2[PMT_RT];
-        float d_alpha = 0.f, d_beta = 0.f, d_gamma = 0.f;
+        float d_alpha = 0.f, d_beta = 0.f, d_gamma = 0.f, d_reg_w = 0.f;
+        // the block's scalar gradients in ONE push (zeros from the waves of the other side: the slab layout is workgroup-uniform)
+        auto push_gate_scalars = [&](float extra, int extra_enc) {
+            const int enc8[8] = {uniform(B.alpha_src[0]), uniform(B.alpha_src[1]), uniform(B.beta_src[0]), uniform(B.beta_src[1]),
+                                 uniform(B.gamma_src), extra_enc, -1, -1};
+            const float val8[8] = {side == 0 ? d_alpha : 0.f, side == 1 ? d_alpha : 0.f, side == 0 ? d_beta : 0.f, side == 1 ? d_beta : 0.f,
+                                   d_gamma, extra, 0.f, 0.f};
+            aux_push_scalars<8>(c, enc8, val8);
+        };
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt) du[rt][0] = f4{0.f, 0.f, 0.f, 0.f};
         if (first_half) {
@@ -555,21 +563,13 @@ DEV void backward_group(
                 pmt_join_sets(lay.join, &sh.gsum[0][0][0], lay.gsum_g + ((size_t)gg.v0 * L + l) * 32, L * 32,
                               lay.join.arrivals + (size_t)gg.v0 * L + l, L, bt.set_groups + gg.v0, gg.nsets);
                 lds_barrier();
-                aux_push_scalar(c, uniform(B.alpha_src[0]), side == 0 ? d_alpha : 0.f);
-                aux_push_scalar(c, uniform(B.alpha_src[1]), side == 1 ? d_alpha : 0.f);
-                aux_push_scalar(c, uniform(B.beta_src[0]), side == 0 ? d_beta : 0.f);
-                aux_push_scalar(c, uniform(B.beta_src[1]), side == 1 ? d_beta : 0.f);
-                aux_push_scalar(c, uniform(B.gamma_src), d_gamma);
+                push_gate_scalars(0.f, -1);
             } else if (first_half) {  // end of this launch: join the global sums, park the per-read state and the running gradient
                 for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS) {
                     const float v = (&sh.gsum[0][0][0])[i];
                     if (v != 0.f) atomicAdd(&lay.gsum_g[((size_t)(gg.v0 + (i >> 5)) * L + l) * 32 + (i & 31)], v);
                 }
-                aux_push_scalar(c, uniform(B.alpha_src[0]), side == 0 ? d_alpha : 0.f);
-                aux_push_scalar(c, uniform(B.alpha_src[1]), side == 1 ? d_alpha : 0.f);
-                aux_push_scalar(c, uniform(B.beta_src[0]), side == 0 ? d_beta : 0.f);
-                aux_push_scalar(c, uniform(B.beta_src[1]), side == 1 ? d_beta : 0.f);
-                aux_push_scalar(c, uniform(B.gamma_src), d_gamma);
+                push_gate_scalars(0.f, -1);
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
                     if (mask_all & (1u << rt)) {
@@ -621,7 +621,8 @@ DEV void backward_group(
                 }
             }
             aux_push_row16(c, uniform(B.ref_reg_src), group_sum(a_rho), h);
-            aux_push_scalar(c, enc_phi(uniform(B.reg_weight_phi)), a_w);
+            if constexpr (LAYERED) aux_push_scalar(c, enc_phi(uniform(B.reg_weight_phi)), a_w);
+            else d_reg_w = a_w;  // (pushed with the block's other scalars, phase 3)
         }
         lds_barrier();
         for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS) (&sh.gsum[0][0][0])[i] = 0.f;
@@ -655,13 +656,7 @@ DEV void backward_group(
             }
             aux_push_vec_x<1, EX>(c, uniform(B.sgu_norm_w_src), dsw, h);
             aux_push_vec_x<1, EX>(c, uniform(B.sgu_norm_b_src), dsb, h);
-            if constexpr (!LAYERED) {  // (layered: pushed at the end of the launch that computed them)
-                aux_push_scalar(c, uniform(B.alpha_src[0]), side == 0 ? d_alpha : 0.f);
-                aux_push_scalar(c, uniform(B.alpha_src[1]), side == 1 ? d_alpha : 0.f);
-                aux_push_scalar(c, uniform(B.beta_src[0]), side == 0 ? d_beta : 0.f);
-                aux_push_scalar(c, uniform(B.beta_src[1]), side == 1 ? d_beta : 0.f);
-                aux_push_scalar(c, uniform(B.gamma_src), d_gamma);
-            }
+            if constexpr (!LAYERED) push_gate_scalars(d_reg_w, enc_phi(uniform(B.reg_weight_phi)));  // (layered: pushed at the end of the launch that computed them)
         }
         prof_add(c, 12, t_ph);
         trace_ev(c, 22);

@@ -245,6 +245,9 @@ DEV void aux_reduce(BwdCtx& c) {
             float s = 0.f;
 #pragma unroll
             for (int w = 0; w < PMT_WAVES; ++w) s += c.aux[w * PMT_AUX_CAP + i];
+#if defined(PMT_BWD_ABLATE) && PMT_BWD_ABLATE
+            if (c.dbg & 16384) continue;
+#endif
             atomicAdd(grad_ptr(d, c.gtheta, c.gphi), s);
         }
     }
@@ -368,6 +371,35 @@ DEV void aux_push_row16(BwdCtx& c, int enc, float v, int dim) {
         if (wave == 0) c.aux_dst[c.aux_n + lane] = f < dim ? enc_at(enc, f) : -1;
     }
     c.aux_n += 16;
+}
+// N scalar gradients at once (4 or 8; enc -1 = none): the halving butterfly of aux_push_vec_full over the 16 lanes of a row, then the
+// four rows -- N + 5 exchange-adds instead of 6 N (a scalar's wave_sum is six exchange steps; the head and the gated blocks push
+// ~60 scalars per group, 6 % of the kernel's vector instructions before this)
+template <int N>
+DEV void aux_push_scalars(BwdCtx& c, const int (&enc)[N], const float (&v)[N]) {
+    static_assert(N == 4 || N == 8, "4 or 8 scalars");
+    const int lane = pmt_tid() & 63, wave = pmt_tid() >> 6;
+    if (c.aux_n + N > PMT_AUX_CAP) aux_flush(c);
+    if (c.dbg & 16) return;
+    const float total = group_sum(row_halving_sum<N, 0>(v, lane));
+    constexpr int STEPS = N == 8 ? 3 : 2;
+    const int bits[4] = {(lane >> 2) & 1, (lane >> 3) & 1, (lane >> 1) & 1, lane & 1};
+    int idx = 0, spare = lane >> 4;  // (every row holds the totals: row 0 stores)
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        if (st < STEPS) idx = 2 * idx + bits[st];
+        else spare |= bits[st];
+    }
+    if (spare == 0) {
+        c.aux[wave * PMT_AUX_CAP + c.aux_n + idx] = total;
+        if (wave == 0) {
+            int d = enc[0];
+#pragma unroll
+            for (int k = 1; k < N; ++k) d = idx == k ? enc[k] : d;
+            c.aux_dst[c.aux_n + idx] = d;
+        }
+    }
+    c.aux_n += N;
 }
 DEV void aux_push_scalar(BwdCtx& c, int enc, float v) {
     if (c.aux_n + 1 > PMT_AUX_CAP) aux_flush(c);
@@ -600,6 +632,10 @@ DEV void stage_pair_bf16(char* const (&pj)[4], int off, f4 v0, f4 v1) {
 }
 
 #define PMT_BF_PLANE_BYTES 2048  // hi + mid piece of one (wave, plane)
+#ifndef PMT_BWD_ABLATE
+#define PMT_BWD_ABLATE 0  // development build (scripts/bwd_ablate.py): knock-outs of the exchange's parts through PmtBatch.debug_flags[1]
+#endif
+#define PMT_ABL(c, bit) (PMT_BWD_ABLATE && ((c).dbg & (bit)))
 template <int NTO, int NTI, int SIDES, int PIECES = 3>
 DEV void wgrad_exchange_bf(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, const f4 (&dy)[PMT_RT][NTO],
                            const f4 (&x)[PMT_RT][NTI], float scale) {
@@ -657,12 +693,12 @@ DEV void wgrad_exchange_bf(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, 
     for (int w0 = 0; w0 < PMT_WAVES; w0 += PW) {
         unsigned long long t1 = prof_now();
         trace_ev(c, 100);
-        if (c.dbg & 128) __syncthreads(); else lds_barrier();  // the stage (and the slabs) of the previous round have been consumed
+        if (PMT_ABL(c, 8192)) {} else if (c.dbg & 128) __syncthreads(); else lds_barrier();  // the stage (and the slabs) of the previous round have been consumed
         trace_ev(c, 101);
         prof_add(c, 17, t1);
         if (w0 == 0) aux_reduce(c);
         t1 = prof_now();
-        if (PW == PMT_WAVES || (wave >= w0 && wave < w0 + PW)) {
+        if (!PMT_ABL(c, 1024) && (PW == PMT_WAVES || (wave >= w0 && wave < w0 + PW))) {
             char* mine = stage + (wave - w0) * (P * PMT_BF_PLANE_BYTES);
             // (through an empty asm: computed ONCE per exchange; the compiler otherwise rebuilds each address at every store)
             unsigned a0 = (unsigned)(size_t)(mine + c.wbase), a1 = (unsigned)(size_t)(mine + (c.wbase ^ 16)),
@@ -677,11 +713,12 @@ DEV void wgrad_exchange_bf(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, 
         prof_add(c, 18, t1);
         t1 = prof_now();
         trace_ev(c, 102);
-        if (c.dbg & 128) __syncthreads(); else lds_barrier();
+        if (PMT_ABL(c, 8192)) {} else if (c.dbg & 128) __syncthreads(); else lds_barrier();
         trace_ev(c, 103);
         prof_add(c, 19, t1);
         const int whi_all = min(w0 + PW, PMT_WAVES);
         const char* rd = stage + c.rbase;
+        if (PMT_ABL(c, 512)) continue;
         if (SIDES == 1) {
             if (t_side[0] >= 0) {
 #pragma unroll

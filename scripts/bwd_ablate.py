@@ -16,8 +16,8 @@ model.train(True)
 ints, floats, packed = synth_arrays(np.random.default_rng(0), B, "wgs")
 batch = Batch.from_arrays(ints, floats, packed).copy_to(dev)
 eng = model.engine()
-MASKS = [] if os.environ.get("PMT_PROFILE_ONLY") else [(0, "full"), (2048, "no proj1 recompute"), (4096, "no skip-block s1 recompute"), (6144, "neither"), (0, "full")] if os.environ.get("PMT_RECOMPUTE") else None
-for mask, name in MASKS if MASKS is not None else [(0, "full"), (64, "no stash prefetch"), (256, "stash reads from L2 (wrong results)"), (256 + 64, "same, no prefetch"), (0, "full again"), (2, "no flush"), (1, "no wgrad"), (4, "no blocks"), (5, "no blocks, no wgrad"), (16, "no small-param atomics")]:
+MASKS = [(0, "full"), (16384, "small params: pushes only, no global atomics"), (16, "no small-param work"), (0, "full"), (16384, "small params: pushes only, no global atomics")] if os.environ.get("PMT_ABLATE_AUX") else [] if os.environ.get("PMT_PROFILE_ONLY") else [(0, "full"), (2048, "no proj1 recompute"), (4096, "no skip-block s1 recompute"), (6144, "neither"), (0, "full")] if os.environ.get("PMT_RECOMPUTE") else None
+for mask, name in MASKS if MASKS is not None else [(0, "full"), (64, "no stash prefetch"), (256, "stash reads from L2 (wrong results)"), (256 + 64, "same, no prefetch"), (0, "full again"), (2, "no flush"), (1, "no wgrad"), (4, "no blocks"), (5, "no blocks, no wgrad"), (16, "no small-param atomics")] + ([(512, "exchange: no MFMAs"), (1024, "exchange: no staging"), (1536, "exchange: neither"), (1536 + 2, "exchange: neither, no flush"), (16384, "small params: pushes only, no global atomics"), (0, "full")] if os.environ.get("PMT_ABLATE_EXCHANGE") else []):
     eng.plan.debug_flags[1] = mask
     ts = []
     for i in range(6):
