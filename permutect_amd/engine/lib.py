@@ -18,7 +18,8 @@ MAX_ROW_INPUT = 128
 MAX_CNN_TAPS = 192
 ROWS_INFO, ROWS_ALT_COUNT, ROWS_SOURCE = 0, 1, 2
 MAX_OPS, MAX_SKIP_LAYERS, MAX_BLOCKS, MAX_LINEAR = 8, 4, 16, 96
-GROUP_WAVES = 8  # PMT_GROUP_WAVES of the built library (include/permutect_amd.h; 4 was measured: DESIGN section 4)
+GROUP_WAVES = int(os.environ.get("PMT_GROUP_WAVES", 8))  # PMT_GROUP_WAVES of the built library (include/permutect_amd.h; the variable is for development builds
+# loaded through PMT_LIB: 4 was measured)
 GROUP_TILES, GROUP_MAX_SETS, TILE = 2 * GROUP_WAVES, 8 * GROUP_WAVES, 16
 READS_PACKED_U8, READS_F16, READS_F32 = 0, 1, 2
 OP_LINEAR, OP_SKIP = 0, 1
