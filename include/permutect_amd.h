@@ -40,7 +40,10 @@ extern "C" {
 #define PMT_E_WORKSPACE (-5)    /* workspace too small */
 
 /* compile-time limits of the kernels */
-#define PMT_MAX_WIDTH 64        /* widest activation (features) kept register-resident: 4 tiles of 16 */
+#ifndef PMT_MAX_WIDTH
+#define PMT_MAX_WIDTH 64        /* widest activation (features) kept register-resident: 4 tiles of 16.  The WIDE build of the
+                                   library (csrc/Makefile: `make wide`, -DPMT_MAX_WIDTH=128) keeps 8: pmt_limits() reports it */
+#endif
 #define PMT_MAX_HALF_FFN 16     /* d_ffn / 2 */
 #define PMT_MAX_CLUSTERS 16
 #define PMT_MAX_OPS 8           /* top-level ops per MLP program */
@@ -284,6 +287,11 @@ int pmt_abi_version(void);
  * (architecture/mlp.py:32-67, parameters.py:70-156). */
 int pmt_shape_info(int32_t* nine);
 int pmt_shape_id(const struct PmtModel* m);
+/* The compile-time limits of THIS build of the library: four[0] widest register-resident activation (PMT_MAX_WIDTH: 64; the wide
+ * build `libpermutect_amd_wide.so` -- csrc/Makefile `make wide`, generic instances only -- 128), [1] largest d_ffn / 2, [2] floats of
+ * one stash slot, [3] waves per workgroup of the read-set kernels.  permutect_amd/engine/instances.py loads the wide build for a
+ * model with a layer wider than the default build's limit (the reference takes any width: architecture/mlp.py:32-67). */
+int pmt_limits(int32_t* four);
 
 /* sizeof() of the ABI structs as compiled into the library, for binding self-checks:
  * 0 PmtModel, 1 PmtBatch, 2 PmtOutputs, 3 PmtOutputGrads, 4 PmtAdamW, 5 PmtLinear, 6 PmtOp, 7 PmtMlp, 8 PmtBlock, 9 PmtHead */

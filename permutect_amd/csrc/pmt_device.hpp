@@ -21,7 +21,7 @@
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-#define PMT_NT 4                 // feature tiles per activation (PMT_MAX_WIDTH / 16)
+#define PMT_NT (PMT_MAX_WIDTH / 16)  // feature tiles per activation: 4 (the wide build of the library: 8)
 #ifndef PMT_RT
 #define PMT_RT 2                 // read tiles per wave (a translation unit may choose its own wave shape)
 #endif
@@ -75,7 +75,7 @@ struct Shape {
     static constexpr bool DROP = XDROP || !EXACT_;
     static_assert(!XBF || EXACT_, "the bf16 path has no tile guards");
 };
-using ShapeAny = Shape<4, 4, 4, 4, false>;   // any supported model
+using ShapeAny = Shape<PMT_NT, PMT_NT, PMT_NT, PMT_NT, false>;   // any supported model
 // The exact-width instances are compiled for ONE model shape per build of the library: the production hyperparameters (SURVEY:
 // P0) by default; `make SHAPE="ntf,ntr,ntd,nte,F,R,D,H,E" LIB=...` builds the same library around another shape (tile counts of
 // the read features / read widths / d_model / feature_dim, then the widths themselves: read features, read-MLP width, d_model,
@@ -97,6 +97,13 @@ using ShapeAny = Shape<4, 4, 4, 4, false>;   // any supported model
 static_assert(PMT_SH_F <= 16 * PMT_SH_NTF && PMT_SH_F > 16 * (PMT_SH_NTF - 1) && PMT_SH_R <= 16 * PMT_SH_NTR && PMT_SH_R > 16 * (PMT_SH_NTR - 1) &&
               PMT_SH_D <= 16 * PMT_SH_NTD && PMT_SH_D > 16 * (PMT_SH_NTD - 1) && PMT_SH_E <= 16 * PMT_SH_NTE && PMT_SH_E > 16 * (PMT_SH_NTE - 1) &&
               PMT_SH_H >= 1 && PMT_SH_H <= 16, "SHAPE: the widths must fill exactly the tile counts given");
+#ifndef PMT_GENERIC_ONLY
+#define PMT_GENERIC_ONLY 0  // 1 (the WIDE build, csrc/Makefile): no exact instances -- every shape below is the generic one, pmt_shape_id is 0
+#endif
+#if PMT_GENERIC_ONLY
+using ShapeP0 = ShapeAny; using ShapeP0X = ShapeAny; using ShapeP0XB = ShapeAny; using ShapeP0XD = ShapeAny; using ShapeP0XH = ShapeAny;
+using ShapeP0XHD = ShapeAny; using ShapeP0T = ShapeAny; using ShapeP0TH = ShapeAny;
+#else
 using ShapeP0 = Shape<PMT_SH_TILES, true>;     // the shape's TILE counts (P0: F in 49..64, read widths 17..32, d_model / reducer widths 49..64, E <= 16), widths at run time
 using ShapeP0X = Shape<PMT_SH_TILES, true, PMT_SH_DIMS, 3>;  // exactly the shape's widths (default: the production hyperparameters, SURVEY: P0)
 using ShapeP0XB = Shape<PMT_SH_TILES, true, PMT_SH_DIMS, 1>; // the same widths, plain bf16 products (not a parity mode)
@@ -113,6 +120,7 @@ using ShapeP0XHD = Shape<PMT_SH_TILES, true, PMT_SH_DIMS, 16, true>;
 // packed weights and in every activation, so whole tiles are multiplied without guards.
 using ShapeP0T = Shape<PMT_SH_TILES, true, 0, 0, 0, 0, 0, 3>;    // backward (bf16 pieces)
 using ShapeP0TH = Shape<PMT_SH_TILES, true, 0, 0, 0, 0, 0, 16>;  // forward (f16 pieces)
+#endif
 
 DEV float uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }

@@ -627,6 +627,9 @@ __global__ __launch_bounds__(PMT_THREADS, (S::EXACT && !(LAYERED && PMT_LAYERED_
 extern "C" int pmt_forward_launch_train_p0x(int groups, void* stream, const PmtModel* model_dev, const float* theta, const float* phi,
                                             const float* packed, const PmtBatch* batch, const PmtOutputs* out, float* stash,
                                             float* zsum_stash, float* rstd_stash, const PmtLayeredArgs* lay, int bf16x3) {
+#if PMT_GENERIC_ONLY
+    return PMT_E_UNSUPPORTED;  // (never asked for: pmt_shape_id is 0 in this build)
+#else
     const hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const PmtLayeredArgs none{};
     // bf16x3 (PmtModel.force_shape = 5): the round-3 instances, six bf16 MFMAs per product; otherwise three f16 MFMAs
@@ -644,6 +647,7 @@ extern "C" int pmt_forward_launch_train_p0x(int groups, void* stream, const PmtM
     }
 #undef PMT_LAUNCH_FWD
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
+#endif
 }
 #else
 extern "C" int pmt_forward_launch_train_p0x(int groups, void* stream, const PmtModel* model_dev, const float* theta, const float* phi,

@@ -70,8 +70,13 @@ static bool mlp_ops_have_tiles(const PmtModel* m, const PmtMlp* mlp, int first, 
     }
     return true;
 }
+extern "C" int pmt_limits(int32_t* four) {  // the build's compile-time limits: widest activation, d_ffn / 2, floats of a stash slot, waves per group
+    const int32_t v[4] = {PMT_MAX_WIDTH, PMT_MAX_HALF_FFN, PMT_MAX_WIDTH * 16, PMT_GROUP_WAVES};
+    if (four) memcpy(four, v, sizeof(v));
+    return PMT_OK;
+}
 extern "C" int pmt_shape_id(const PmtModel* m) {
-    if (m->force_shape == 2) return 0;  // (5 = auto for every kernel but the forward, whose launchers read it themselves)
+    if (m->force_shape == 2 || PMT_GENERIC_ONLY) return 0;  // (5 = auto for every kernel but the forward, whose launchers read it themselves)
     const PmtMlp* rm = &m->read_mlp;
     const PmtMlp* red = &m->reducer;
     if (rm->n_ops < 1 || red->n_ops < 1 || m->num_blocks < 0) return 0;

@@ -11,6 +11,7 @@ the library whose tile counts the model fills:
   * a library under permutect_amd/instances/ with the model's tile counts (the widths compiled in when they are the model's, read at
     run time otherwise: pmt_shape_id 2 or 6): `make -C permutect_amd/csrc instances` builds the table of known shapes ahead of time
     (the reference's test configuration T0), `__graft_entry__.build()` calls it;
+  * the WIDE build (`make wide`: activations up to 128 features, generic instances only) for a model with a layer wider than 64;
   * a library built on the spot (`make instance SHAPE=...`, one to two minutes, kept for later runs) unless PMT_JIT=0 or there is no
     hipcc -- then, and for a model that cannot fill any tile shape (a read MLP that does not start, or a reducer that does not end,
     with a Linear; widths beyond 64), the default library's generic instance, with a warning that says so.
@@ -84,10 +85,41 @@ def build_instance(shape, log=print) -> Optional[str]:
     return path
 
 
+def widest_layer(desc: L.PmtModel) -> int:
+    """the widest activation of the read-set kernels and the row MLPs behind their inputs (what PMT_MAX_WIDTH bounds: pmt_host.hip,
+    pmt_model_check)"""
+    w = max(desc.num_read_features, desc.d_model, desc.feature_dim)
+    for i in range(desc.n_linear):
+        w = max(w, desc.lin[i].out_dim)
+    return w
+
+
+WIDE_LIB = os.path.join(_HERE, "libpermutect_amd_wide.so")
+
+
+def wide_library(log=print) -> C.CDLL:
+    """The WIDE build (activations up to 128 features, generic instances only), built once with `make wide` when it is missing"""
+    if not os.path.exists(WIDE_LIB):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        if os.environ.get("PMT_JIT", "1") == "0" or not (os.path.exists(hipcc) or shutil.which("hipcc")) or not shutil.which("make"):
+            raise L.PmtError(f"a layer of this model is wider than {L.MAX_WIDTH}: it needs the wide build of the library, "
+                             "`make -C permutect_amd/csrc wide` (not built here, and PMT_JIT=0 or no hipcc / make to build it now)")
+        log("permutect_amd: building the wide library (layers up to 128 features; once, ~3 minutes) ...")
+        res = subprocess.run(["make", "-C", CSRC, f"-j{min(8, os.cpu_count() or 1)}", "wide"], capture_output=True, text=True)
+        if res.returncode != 0 or not os.path.exists(WIDE_LIB):
+            raise L.PmtError("building the wide library failed:\n" + res.stderr[-2000:])
+    return L.load(WIDE_LIB)
+
+
 def library_for(desc: L.PmtModel, log=print) -> C.CDLL:
     default = L.load()
     if "PMT_LIB" in os.environ:  # a development build named explicitly: use it as it is
         return default
+    if widest_layer(desc) > L.limits_of(default)["max_width"]:
+        warnings.warn(f"permutect_amd: a layer of this model is wider than {L.limits_of(default)['max_width']} features: it runs the WIDE build "
+                      "of the library, GENERIC instances only (fp32 MFMAs, 8-tile register arrays with spills: several times slower per "
+                      "read than the exact-width kernels of the production widths)")
+        return wide_library(log)
     if default.pmt_shape_id(C.byref(desc)) != 0 or desc.force_shape == 2:
         return default
     shape = exact_shape_of(desc)

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("PMT_LIB", os.path.join(_HERE, "libpermutect_amd.so"))
 # ---- limits (must match the header) -------------------------------------------------------------------------------
 ABI_VERSION = 9
 MAX_WIDTH, MAX_HALF_FFN, MAX_CLUSTERS = 64, 16, 16
+MAX_WIDTH_WIDE = 128  # the wide build of the library (csrc/Makefile: `make wide`; engine/instances.py loads it for wider layers)
 MAX_ROW_INPUT = 128
 MAX_CNN_TAPS = 192
 ROWS_INFO, ROWS_ALT_COUNT, ROWS_SOURCE = 0, 1, 2
@@ -152,7 +153,7 @@ class PmtLossInputGrads(C.Structure):
     _fields_ = [("d_logits_b", vp), ("d_logits_bk", vp), ("d_alt_count_raw", vp), ("d_source_logits", vp)]
 
 
-EXPORTS = ["pmt_abi_version", "pmt_shape_info", "pmt_shape_id", "pmt_struct_bytes", "pmt_model_check", "pmt_plan_groups", "pmt_stash_bytes", "pmt_pack_params",
+EXPORTS = ["pmt_abi_version", "pmt_shape_info", "pmt_shape_id", "pmt_limits", "pmt_struct_bytes", "pmt_model_check", "pmt_plan_groups", "pmt_stash_bytes", "pmt_pack_params",
            "pmt_scan_counts", "pmt_forward", "pmt_backward", "pmt_clip_adamw",
            "pmt_dropout_mask", "pmt_rows_stash_bytes", "pmt_rows_forward", "pmt_rows_backward", "pmt_rows_workspace_floats", "pmt_cnn_forward", "pmt_cnn_backward", "pmt_cnn_stash_floats", "pmt_cnn_workspace_floats",
            "pmt_phi_forward", "pmt_phi_backward", "pmt_build_read_index", "pmt_losses_forward", "pmt_losses_backward",
@@ -255,6 +256,13 @@ def load(path: str = None) -> C.CDLL:
     if path == LIB_PATH:
         _lib = lib
     return lib
+
+
+def limits_of(lib: C.CDLL) -> dict:
+    """the compile-time limits of a build of the library (pmt_limits)"""
+    v = (i32 * 4)()
+    check(lib.pmt_limits(v), "pmt_limits")
+    return {"max_width": int(v[0]), "max_half_ffn": int(v[1]), "slot_floats": int(v[2]), "group_waves": int(v[3])}
 
 
 def shape_of(lib: C.CDLL):

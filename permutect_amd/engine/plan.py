@@ -195,7 +195,8 @@ class EnginePlan:
         d.cnn_debug = int(os.environ.get("PMT_CNN_DBG", "0"))
         d.dropout_p = max((float(getattr(m, "dropout_p", 0.0)) for m in model.modules() if isinstance(m, M.MLP)), default=0.0)
 
-        lib = L.load()
+        from permutect_amd.engine.instances import library_for
+        lib = self.lib = library_for(d)  # the build whose kernels run this model (the default one, a per-shape one, the wide one)
         L.check(lib.pmt_model_check(C.byref(d)), "pmt_model_check")
         self.packed = torch.zeros(d.packed_size, dtype=torch.float32, device=device)
         # private partial sums of the backward's weight-gradient blocks: one row per compute unit (pmt_backward: grad_partials;
@@ -230,11 +231,11 @@ class EnginePlan:
         return n
 
     def _add_raw_linear(self, in_dim: int, out_dim: int, w_src: int, b_src: int, has_bias: bool, out_split: int = 0,
-                        alloc: bool = True, extra_vectors=(), out=None, max_in: int = L.MAX_WIDTH) -> int:
+                        alloc: bool = True, extra_vectors=(), out=None, max_in: int = L.MAX_WIDTH_WIDE) -> int:
         if self._n_lin >= L.MAX_LINEAR:
             raise L.PmtError("too many linear layers for the kernel descriptor")
-        if in_dim > max_in or out_dim > L.MAX_WIDTH:
-            raise L.PmtError(f"layer width {in_dim}->{out_dim} exceeds the register-resident limit {L.MAX_WIDTH}")
+        if in_dim > max_in or out_dim > L.MAX_WIDTH_WIDE:  # (beyond 64: the wide build of the library, engine/instances.py)
+            raise L.PmtError(f"layer width {in_dim}->{out_dim} exceeds the register-resident limit {L.MAX_WIDTH_WIDE}")
         lin = self.desc.lin[self._n_lin]
         out_v = 16 + out_split if out_split else out_dim
         nmt, nkt = (out_v + 15) // 16, (in_dim + 15) // 16
@@ -270,7 +271,7 @@ class EnginePlan:
         lr.wt_frag = self._alloc_packed(nfl); la.wt_frag = self._alloc_packed(nfl)
         return ids[0], ids[1]
 
-    def _add_linear(self, layer: nn.Linear, out_split: int = 0, max_in: int = L.MAX_WIDTH, bn: Optional[nn.BatchNorm1d] = None) -> int:
+    def _add_linear(self, layer: nn.Linear, out_split: int = 0, max_in: int = L.MAX_WIDTH_WIDE, bn: Optional[nn.BatchNorm1d] = None) -> int:
         if bn is not None:
             # eval-mode BatchNorm1d in front of the Linear (reference mlp.py:52-53) is an affine map per input feature,
             # x -> s x + t with s = w / sqrt(running_var + eps), t = b - running_mean s: the Linear the kernels run is
@@ -284,7 +285,7 @@ class EnginePlan:
         return self._add_raw_linear(layer.in_features, layer.out_features, self.space.offset_of(layer.weight), b_src,
                                     layer.bias is not None, out_split, max_in=max_in)
 
-    def _lower_mlp(self, dst: L.PmtMlp, mlp: M.MLP, max_in: int = L.MAX_WIDTH):
+    def _lower_mlp(self, dst: L.PmtMlp, mlp: M.MLP, max_in: int = L.MAX_WIDTH_WIDE):
         # nn.Dropout (reference mlp.py:57-58: one behind every Linear when dropout_p > 0) becomes a flag of the MLP: the kernels
         # mask every Linear's output of a flagged MLP when the batch brings a seed (train mode), and ignore it otherwise (eval)
         dst.dropout = int(any(isinstance(c, nn.Dropout) for c in mlp._model.modules()))
@@ -329,7 +330,7 @@ class EnginePlan:
             o = dst.ops[j]
             if op[0] == "lin":
                 o.kind, o.n_layers, o.selu_after, o.alpha_src = L.OP_LINEAR, 1, int(op[2]), -1
-                o.lin[0] = self._add_linear(op[1], max_in=max_in if j == 0 else L.MAX_WIDTH, bn=bn_of.get(op[1]))
+                o.lin[0] = self._add_linear(op[1], max_in=max_in if j == 0 else L.MAX_WIDTH_WIDE, bn=bn_of.get(op[1]))
             else:
                 blk, lins = op[1], op[2]
                 if len(lins) > 2:

@@ -35,8 +35,7 @@ class ReadSetEngine:
         self.plan = EnginePlan(model, self.space, device)
         # the build of the library whose exact-width instances fit THIS model's tile counts (engine/instances.py): the default
         # library for the production shape, a per-shape build otherwise (found under permutect_amd/instances/, or built once)
-        from permutect_amd.engine.instances import library_for
-        self.lib = library_for(self.plan.desc)
+        self.lib = self.plan.lib  # (engine/instances.py: library_for, chosen when the model was lowered)
         self.shape_id = int(self.lib.pmt_shape_id(C.byref(self.plan.desc)))  # which read-set instance runs (pmt_host.hip: pmt_shape_id)
         self._trigger = torch.zeros(1, dtype=torch.float32, device=device, requires_grad=True)  # see RowsMlpFunction
         self._no_trigger = torch.zeros(1, dtype=torch.float32, device=device)

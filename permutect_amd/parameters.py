@@ -147,6 +147,12 @@ def t0_params() -> ModelParameters:
     return ModelParameters([10, 10, 10], 20, 2, [10, 10], [20, 20, 20], 4, [10, 10, 10], list(T0_CNN), 0.0, 0.3)
 
 
+def wide_params() -> ModelParameters:
+    """A configuration with layers wider than 64 (read width 48, info width 40: d_model 98; a 98-wide reducer; d_ffn 32): what a
+    `--read_layers` / `--info_layers` edit away from the defaults gives.  Runs the wide build of the library (engine/instances.py)."""
+    return ModelParameters([48, -2], 32, 2, [40, -1], [-1, 20], 4, [10, 10], list(P0_CNN), 0.0, 0.3)
+
+
 P0_DIMS = dict(num_read_features=61, num_info_features=71, haplotypes_length=42)
 
 

@@ -15,7 +15,7 @@ from permutect_amd.data.batch import Batch
 from permutect_amd.engine.lib import PmtError
 from permutect_amd.parameters import P0_DIMS, p0_params, t0_params
 from permutect_amd.training.optimizer import FusedClipAdamW
-from tests.helpers import CASES, CNN_CASES, CNN_STACKS, config_for, load_case
+from tests.helpers import CASES, CNN_CASES, CNN_STACKS, config_for, load_case, params_for
 from tests.test_forward_gpu import check_outputs
 
 pytestmark = pytest.mark.gpu
@@ -36,7 +36,7 @@ def build_cnn(name, sd, family, monkeypatch):
         monkeypatch.setenv("PMT_CNN_DBG", "256")
     elif family != "auto":
         monkeypatch.setenv("PMT_CNN", family)
-    params = t0_params() if name.startswith("t0") else p0_params()
+    params = params_for(name)
     if name in CNN_STACKS:
         params.ref_seq_layer_strings = list(CNN_STACKS[name])
     model = ArtifactModel(params, device=torch.device("cuda"), **P0_DIMS)

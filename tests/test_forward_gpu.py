@@ -9,7 +9,7 @@ from oracle import artifact_oracle as O
 from permutect_amd.architecture.artifact_model import ArtifactModel
 from permutect_amd.data.batch import Batch
 from permutect_amd.parameters import P0_DIMS, p0_params, t0_params
-from tests.helpers import CASES, config_for, load_case
+from tests.helpers import CASES, config_for, load_case, params_for
 
 pytestmark = pytest.mark.gpu
 
@@ -33,7 +33,7 @@ def kernel_shape(request, monkeypatch):
 
 def build(name, sd):
     dev = torch.device("cuda")
-    params = t0_params() if name.startswith("t0") else p0_params()
+    params = params_for(name)
     model = ArtifactModel(params, device=dev, **P0_DIMS)
     if name == "t0_two_sources":
         model.reset_source_predictor(2)
@@ -455,3 +455,57 @@ def test_a_model_with_the_production_tiles_but_other_widths_matches_the_oracle(m
     gref = np.concatenate([ref_grads[n].numpy().ravel() for n in names])
     gour = np.concatenate([p.grad.detach().cpu().numpy().ravel() for _, p in model.named_parameters()])
     assert np.all(np.isfinite(gour)) and np.linalg.norm(gour - gref) <= 1e-4 * np.linalg.norm(gref)
+
+
+def test_a_model_wider_than_64_runs_the_wide_build_and_matches_the_oracle(monkeypatch):
+    """Layer widths beyond 64 (refused until round 4; the reference takes any: architecture/mlp.py:32-67): read width 48, info width
+    40, d_model 98, a 98-wide reducer with a skip block, d_ffn 32, feature_dim 20.  engine/instances.py loads the WIDE build of the
+    library (`make wide`: 8-tile register arrays, generic instances only) for it; forward, losses and every gradient against the
+    oracle at the generic instances' tolerances."""
+    from permutect_amd.engine import lib as L
+    from permutect_amd.parameters import ModelParameters, P0_CNN
+    from permutect_amd.training.optimizer import FusedClipAdamW
+    if __import__("os").environ.get("PMT_SHAPE", "") != "" or "PMT_LIB" in __import__("os").environ:
+        pytest.skip("the library's own choice is what is tested")
+    params = ModelParameters([48, -2], 32, 2, [40, -1], [-1, 20], 4, [10, 10], list(P0_CNN), 0.0, 0.3)
+    cfg = O.Config([48, -2], [40, -1], [-1, 20], 32, 2, 4, list(P0_CNN), 61, 71, 42)
+    dev = torch.device("cuda")
+    torch.manual_seed(6)
+    with pytest.warns(UserWarning, match="WIDE build"):
+        model = ArtifactModel(params, device=dev, **P0_DIMS)
+        with torch.no_grad():
+            for q in model.parameters():
+                q.add_(0.05 * torch.randn_like(q))
+        eng = model.engine()
+    assert L.limits_of(eng.lib)["max_width"] == 128 and eng.shape_id == 0 and eng.plan.desc.d_model == 98
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    rng = np.random.default_rng(79)
+    nb = 120
+    nref, nalt = rng.integers(0, 11, nb), rng.integers(1, 16, nb)
+    nref[3], nalt[3] = 70, 40  # one set beyond a tile pair per side
+    ints, floats, packed = _arrays(nref, nalt, seed=80)
+    batch = Batch.from_arrays(ints, floats, packed).copy_to(dev)
+    model.train(True)
+    out = model.compute_batch_output(batch)
+    losses = model.compute_batch_losses(out, batch)
+    opt = FusedClipAdamW(model, lr=1e-3, weight_decay=0.01)
+    opt.zero_grad()
+    losses.total_loss.backward()
+    torch.cuda.synchronize()
+    i64 = torch.from_numpy(ints.astype(np.int64))
+    ob = dict(reads_re=torch.from_numpy(O.decode_packed_reads(packed).astype(np.float32)), nref=i64[:, O.REF_COUNT], nalt=i64[:, O.ALT_COUNT],
+              labels=i64[:, O.LABEL], sources=i64[:, O.SOURCE], info_be=torch.from_numpy(floats[:, O.INFO_START:].astype(np.float32)),
+              haplotypes_bh=i64[:, O.HAPLOTYPES_START:])
+    ref_out, ref_losses, ref_grads = O.train_step_grads(sd, cfg, ob)
+    check_outputs(out, {"out/" + k: v.detach().numpy() for k, v in ref_out.items()}, "wide_d98")
+    ref_total = ref_losses["total_losses_b"].detach().numpy()
+    np.testing.assert_allclose(losses.total_losses_b.detach().cpu().numpy(), ref_total, rtol=1e-4, atol=1e-4 + 1e-5 * np.abs(ref_total).max())
+    names = [n for n, _ in model.named_parameters()]
+    gref = np.concatenate([ref_grads[n].numpy().ravel() for n in names])
+    gour = np.concatenate([p.grad.detach().cpu().numpy().ravel() for _, p in model.named_parameters()])
+    assert np.all(np.isfinite(gour)) and np.linalg.norm(gour - gref) <= 1e-4 * np.linalg.norm(gref)
+    # and the filter forward (no stash) of the same model
+    model.train(False)
+    with torch.no_grad():
+        out_eval = model.compute_batch_output(batch)
+    check_outputs(out_eval, {"out/" + k: v.detach().numpy() for k, v in ref_out.items()}, "wide_d98_eval")

@@ -352,3 +352,18 @@ def test_kernel_instances_are_chosen_by_the_models_tile_shape(monkeypatch):
     odd.read_layers = [-2, 30]  # (the read MLP starts with a skip block over the 61 read features: no tile-exact instance)
     with pytest.warns(UserWarning, match="GENERIC"):
         assert I.exact_shape_of(desc_of(odd)) is None and I.library_for(desc_of(odd)) is default
+    # layers wider than 64: the wide build of the library (pmt_limits), the default one refuses them; beyond 128 nothing runs
+    from permutect_amd.parameters import wide_params
+    assert L.limits_of(default) == {"max_width": 64, "max_half_ffn": 16, "slot_floats": 1024, "group_waves": 8}
+    if os.path.exists(I.WIDE_LIB):  # built by __graft_entry__.build() (make wide)
+        with pytest.warns(UserWarning, match="WIDE build"):
+            wd = desc_of(wide_params())
+            wide = I.library_for(wd)
+        assert I.widest_layer(wd) == 98 and wd.d_model == 98 and wide is not default
+        assert L.limits_of(wide) == {"max_width": 128, "max_half_ffn": 16, "slot_floats": 2048, "group_waves": 8}
+        assert wide.pmt_shape_id(C.byref(wd)) == 0 and wide.pmt_model_check(C.byref(wd)) == 0
+        assert default.pmt_model_check(C.byref(wd)) == L.E_UNSUPPORTED
+    too_wide = wide_params()
+    too_wide.read_layers = [130]
+    with pytest.raises(L.PmtError, match="exceeds"):
+        desc_of(too_wide)
