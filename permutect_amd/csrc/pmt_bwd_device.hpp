@@ -640,31 +640,32 @@ template <int NTO, int NTI, int SIDES, int PIECES = 3>
 DEV void wgrad_exchange_bf(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, const f4 (&dy)[PMT_RT][NTO],
                            const f4 (&x)[PMT_RT][NTI], float scale) {
     static_assert(PMT_RT == 2, "a wave's two tiles are the 32 reads of one MFMA");
-    static_assert(SIDES == 2 || PMT_WAVES % NTI == 0, "one column of blocks per wave");
     if (c.dbg & 1) return;
     constexpr int P = NTO + NTI, NB = NTO * NTI;
+    constexpr bool COLS = SIDES == 1 && PMT_WAVES % NTI == 0;  // one linear whose columns of blocks divide the waves (1, 2, 4, 8 input tiles)
     constexpr int PW_CAP = (PMT_STAGE_PLANES * 1024) / (P * PMT_BF_PLANE_BYTES);          // waves whose operands fit the stage
     constexpr int PW = PW_CAP < PMT_WAVES ? PW_CAP : PMT_WAVES;
     static_assert(PW >= 1, "stage too small");
-    // Blocks of this wave.  One linear: the wave owns column `it` = wave % NTI and the rows wave / NTI + k * (waves / NTI): its
+    // Blocks of this wave.  One linear (COLS): the wave owns column `it` = wave % NTI and the rows wave / NTI + k * (waves / NTI): its
     // blocks share the x operand, loaded once per pair of tiles.  A ref / alt pair: task q = wave + waves * k of the
     // 2 NB blocks, side-major (a wave's k-th blocks of the two sides have equal coordinates: the work is balanced
-    // whatever the split of the group between the sides).
-    constexpr int ROWS = SIDES == 1 ? PMT_WAVES / NTI : 1;
-    constexpr int TPW = SIDES == 1 ? (NTO + ROWS - 1) / ROWS : (2 * NB + PMT_WAVES - 1) / PMT_WAVES;
+    // whatever the split of the group between the sides).  One linear with 3, 5, 6 or 7 input tiles (the wide build's shapes): the
+    // same task list over its NB blocks.
+    constexpr int ROWS = COLS ? PMT_WAVES / NTI : 1;
+    constexpr int TPW = COLS ? (NTO + ROWS - 1) / ROWS : (SIDES * NB + PMT_WAVES - 1) / PMT_WAVES;
     const int lane = pmt_tid() & 63, g = lane >> 4, wave = uniform((int)(pmt_tid() >> 6));
     int t_ot[TPW], t_it[TPW], t_side[TPW];
     f4 acc[TPW], accb[TPW];
 #pragma unroll
     for (int k = 0; k < TPW; ++k) {
         acc[k] = accb[k] = f4{0.f, 0.f, 0.f, 0.f};
-        if (SIDES == 1) {
+        if (COLS) {
             t_it[k] = wave % NTI;
             t_ot[k] = wave / NTI + ROWS * k;
             t_side[k] = t_ot[k] < NTO ? 0 : -1;
         } else {
             const int q = wave + PMT_WAVES * k;
-            t_side[k] = q >= 2 * NB ? -1 : (q >= NB ? 1 : 0);
+            t_side[k] = q >= SIDES * NB ? -1 : (q >= NB ? 1 : 0);
             const int rem = q - (q >= NB ? NB : 0);
             t_ot[k] = rem / NTI;
             t_it[k] = rem - t_ot[k] * NTI;
@@ -719,7 +720,7 @@ DEV void wgrad_exchange_bf(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, 
         const int whi_all = min(w0 + PW, PMT_WAVES);
         const char* rd = stage + c.rbase;
         if (PMT_ABL(c, 512)) continue;
-        if (SIDES == 1) {
+        if (COLS) {
             if (t_side[0] >= 0) {
 #pragma unroll
                 for (int w = 0; w < PW; ++w) {  // branch-free body: the scheduler overlaps the reads of one pair with the MFMAs of another
@@ -744,7 +745,7 @@ DEV void wgrad_exchange_bf(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, 
 #pragma unroll
             for (int k = 0; k < TPW; ++k) {
                 if (t_side[k] < 0) continue;
-                const int lo = max(t_side[k] == 1 ? c.wr : 0, w0), hi = min(t_side[k] == 0 ? c.wr : PMT_WAVES, whi_all);
+                const int lo = SIDES == 1 ? w0 : max(t_side[k] == 1 ? c.wr : 0, w0), hi = SIDES == 1 ? whi_all : min(t_side[k] == 0 ? c.wr : PMT_WAVES, whi_all);
                 const char* pa = rd + t_ot[k] * PMT_BF_PLANE_BYTES;
                 const char* pb = rd + (NTO + t_it[k]) * PMT_BF_PLANE_BYTES;
 #pragma unroll 2

@@ -625,7 +625,10 @@ DEV void linear_acc_f16(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], con
             } else {
                 ah = fp[128 * step]; al = fp[128 * step + 64];
             }
-            const bool half_block = 2 * kb + 1 >= NTI;  // a last k block with one tile only: the 16-deep MFMA on the lower halves
+            // a k block with one tile only (NTI == 1): the 16-deep MFMA on the lower halves.  The half-filled LAST block of 3, 5 or 7 input
+            // tiles (the wide build's shapes) takes the 32-deep one on its zero-padded operands instead: a 16-deep f16 MFMA chained
+            // behind 32-deep ones on the same accumulator gave wrong sums (measured, scripts/wide_debug.py)
+            const bool half_block = NKB == 1 && 2 * kb + 1 >= NTI;
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) {
                 if (half_block) {

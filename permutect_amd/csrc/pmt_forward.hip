@@ -100,7 +100,7 @@ struct FwdTrace {
 };
 
 template <bool TRAIN, typename S, bool LAYERED = false>
-__global__ __launch_bounds__(PMT_THREADS, (S::EXACT && !(LAYERED && PMT_LAYERED_WIDE)) ? 4 : 2) void pmt_forward_kernel(const PmtModel* __restrict__ M,
+__global__ __launch_bounds__(PMT_THREADS, (S::EXACT && PMT_NT <= 4 && !(LAYERED && PMT_LAYERED_WIDE)) ? 4 : 2) void pmt_forward_kernel(const PmtModel* __restrict__ M,
                                                                       const float* __restrict__ theta,
                                                                       const float* __restrict__ phi,
                                                                       const float* __restrict__ packed, PmtBatch bt,

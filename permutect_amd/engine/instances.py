@@ -59,7 +59,7 @@ def exact_shape_of(desc: L.PmtModel) -> Optional[Tuple[int, ...]]:
         return True
     ok = (_tiles(lf.in_dim) == ntf and ops_fill(rm, 1, rm.n_ops, ntr) and _tiles(desc.read_embed_dim) == ntr and desc.d_ffn >= 2
           and ops_fill(red, 0, red.n_ops - 1, ntd) and _tiles(ll.in_dim) == ntd and _tiles(ll.out_dim) == nte)
-    if not ok or max(ntf, ntr, ntd, nte) > 4:
+    if not ok or max(ntf, ntr, ntd, nte) > 8:  # (more than four tiles: built with the wide build's 8-tile register arrays, csrc/Makefile)
         return None
     return (ntf, ntr, ntd, nte, desc.num_read_features, lf.out_dim, desc.d_model, desc.d_ffn // 2, desc.feature_dim)
 
@@ -75,7 +75,7 @@ def build_instance(shape, log=print) -> Optional[str]:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not (os.path.exists(hipcc) or shutil.which("hipcc")) or not shutil.which("make"):
         return None
-    log(f"permutect_amd: building the kernel instances for model shape {shape} (once; ~1-2 minutes) ...")
+    log(f"permutect_amd: building the kernel instances for model shape {shape} (once; ~1-2 minutes, ~4 with more than four tiles) ...")
     cmd = ["make", "-C", CSRC, f"-j{min(8, os.cpu_count() or 1)}", "instance", "SHAPE=" + " ".join(str(int(v)) for v in shape)]
     res = subprocess.run(cmd, capture_output=True, text=True)
     path = os.path.join(INSTANCE_DIR, f"libpermutect_amd_{_tag(shape)}.so")
@@ -115,30 +115,39 @@ def library_for(desc: L.PmtModel, log=print) -> C.CDLL:
     default = L.load()
     if "PMT_LIB" in os.environ:  # a development build named explicitly: use it as it is
         return default
-    if widest_layer(desc) > L.limits_of(default)["max_width"]:
-        warnings.warn(f"permutect_amd: a layer of this model is wider than {L.limits_of(default)['max_width']} features: it runs the WIDE build "
-                      "of the library, GENERIC instances only (fp32 MFMAs, 8-tile register arrays with spills: several times slower per "
-                      "read than the exact-width kernels of the production widths)")
+    widest = widest_layer(desc)
+    wide = widest > L.limits_of(default)["max_width"]
+
+    def generic():
+        if not wide:
+            return default
+        warnings.warn(f"permutect_amd: a layer of this model is wider than {L.limits_of(default)['max_width']} features and there are no exact "
+                      "instances for its shape: it runs the WIDE build of the library, GENERIC instances (fp32 MFMAs, 8-tile register "
+                      "arrays with spills: several times slower per read than exact-width kernels)")
         return wide_library(log)
-    if default.pmt_shape_id(C.byref(desc)) != 0 or desc.force_shape == 2:
-        return default
+    if desc.force_shape == 2 or (not wide and default.pmt_shape_id(C.byref(desc)) != 0):
+        return generic()
     shape = exact_shape_of(desc)
     if shape is None:
         warnings.warn("permutect_amd: this model cannot run on tile-exact kernel instances (the read MLP must start and the reducer end with a "
                       "Linear, and each MLP keep one tile count); it runs the GENERIC instance (fp32 MFMAs, ~2x slower)")
-        return default
+        return generic()
     # a library with the model's tile counts: its widths first, then any other widths (pmt_shape_id 6: widths at run time)
     exact = os.path.join(INSTANCE_DIR, f"libpermutect_amd_{_tag(shape)}.so")
     candidates = ([exact] if os.path.exists(exact) else []) + sorted(glob.glob(os.path.join(INSTANCE_DIR, f"libpermutect_amd_{_tag(shape[:4])}_*.so")))
+    def fits(lib):
+        return L.limits_of(lib)["max_width"] >= widest and lib.pmt_shape_id(C.byref(desc)) != 0
     for path in candidates:
         lib = L.load(path)
-        if lib.pmt_shape_id(C.byref(desc)) != 0:
+        if fits(lib):
             return lib
     path = build_instance(shape, log)
     if path is not None:
         lib = L.load(path)
-        if lib.pmt_shape_id(C.byref(desc)) != 0:
+        if fits(lib):
             return lib
+    if wide:
+        return generic()
     warnings.warn(f"permutect_amd: no kernel instances for model shape {shape} and none could be built here (hipcc / make missing, or "
                   "PMT_JIT=0); the model runs the GENERIC instance (fp32 MFMAs, ~2x slower).  `make -C permutect_amd/csrc instance "
                   f"SHAPE=\"{' '.join(str(v) for v in shape)}\"` builds them")

@@ -459,25 +459,34 @@ def test_a_model_with_the_production_tiles_but_other_widths_matches_the_oracle(m
 
 def test_a_model_wider_than_64_runs_the_wide_build_and_matches_the_oracle(monkeypatch):
     """Layer widths beyond 64 (refused until round 4; the reference takes any: architecture/mlp.py:32-67): read width 48, info width
-    40, d_model 98, a 98-wide reducer with a skip block, d_ffn 32, feature_dim 20.  engine/instances.py loads the WIDE build of the
-    library (`make wide`: 8-tile register arrays, generic instances only) for it; forward, losses and every gradient against the
-    oracle at the generic instances' tolerances."""
+    40, d_model 98, a 98-wide reducer with a skip block, d_ffn 32, feature_dim 20.  engine/instances.py loads a build of the library
+    with 8-tile register arrays for it: the exact instances of its shape (4, 3, 7, 2 tiles; `make instances`), or -- PMT_SHAPE=any, and
+    for every wide model without an exact shape -- the generic instances of `make wide`.  Forward, losses and every gradient against
+    the oracle on fresh inputs (the reference fixture of this configuration, wide_d98, runs through the fixture tests)."""
     from permutect_amd.engine import lib as L
     from permutect_amd.parameters import ModelParameters, P0_CNN
     from permutect_amd.training.optimizer import FusedClipAdamW
-    if __import__("os").environ.get("PMT_SHAPE", "") != "" or "PMT_LIB" in __import__("os").environ:
+    import os
+    import warnings
+    if "PMT_LIB" in os.environ:
         pytest.skip("the library's own choice is what is tested")
+    forced = os.environ.get("PMT_SHAPE", "")
     params = ModelParameters([48, -2], 32, 2, [40, -1], [-1, 20], 4, [10, 10], list(P0_CNN), 0.0, 0.3)
     cfg = O.Config([48, -2], [40, -1], [-1, 20], 32, 2, 4, list(P0_CNN), 61, 71, 42)
     dev = torch.device("cuda")
     torch.manual_seed(6)
-    with pytest.warns(UserWarning, match="WIDE build"):
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
         model = ArtifactModel(params, device=dev, **P0_DIMS)
         with torch.no_grad():
             for q in model.parameters():
                 q.add_(0.05 * torch.randn_like(q))
         eng = model.engine()
-    assert L.limits_of(eng.lib)["max_width"] == 128 and eng.shape_id == 0 and eng.plan.desc.d_model == 98
+    assert L.limits_of(eng.lib)["max_width"] == 128 and eng.plan.desc.d_model == 98
+    if forced == "any":  # the generic instances of the wide build, with the warning that says so
+        assert eng.shape_id == 0 and any("WIDE build" in str(w.message) for w in caught)
+    else:  # the exact instances built around this shape (csrc/Makefile: INSTANCE_TABLE), 16-bit matrix pipes
+        assert L.shape_of(eng.lib)[:4] == (4, 3, 7, 2) and eng.shape_id == (1 if forced == "tile" else 2)
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     rng = np.random.default_rng(79)
     nb = 120

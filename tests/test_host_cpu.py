@@ -355,14 +355,18 @@ def test_kernel_instances_are_chosen_by_the_models_tile_shape(monkeypatch):
     # layers wider than 64: the wide build of the library (pmt_limits), the default one refuses them; beyond 128 nothing runs
     from permutect_amd.parameters import wide_params
     assert L.limits_of(default) == {"max_width": 64, "max_half_ffn": 16, "slot_floats": 1024, "group_waves": 8}
-    if os.path.exists(I.WIDE_LIB):  # built by __graft_entry__.build() (make wide)
+    wide_exact = os.path.join(I.INSTANCE_DIR, "libpermutect_amd_4_3_7_2_61_48_98_16_20.so")
+    if os.path.exists(I.WIDE_LIB) and os.path.exists(wide_exact):  # built by __graft_entry__.build() (make wide, make instances)
+        wd = desc_of(wide_params())
+        assert I.widest_layer(wd) == 98 and wd.d_model == 98 and I.exact_shape_of(wd) == (4, 3, 7, 2, 61, 48, 98, 16, 20)
+        lib = I.library_for(wd)  # the exact instances built around this shape, with 8-tile register arrays
+        assert L.limits_of(lib)["max_width"] == 128 and L.shape_of(lib) == (4, 3, 7, 2, 61, 48, 98, 16, 20) and lib.pmt_shape_id(C.byref(wd)) == 2
+        assert lib.pmt_model_check(C.byref(wd)) == 0 and default.pmt_model_check(C.byref(wd)) == L.E_UNSUPPORTED
+        wd.force_shape = 2  # (PMT_SHAPE=any; also what a wide model without an exact shape gets): the generic instances of the wide build
         with pytest.warns(UserWarning, match="WIDE build"):
-            wd = desc_of(wide_params())
             wide = I.library_for(wd)
-        assert I.widest_layer(wd) == 98 and wd.d_model == 98 and wide is not default
         assert L.limits_of(wide) == {"max_width": 128, "max_half_ffn": 16, "slot_floats": 2048, "group_waves": 8}
-        assert wide.pmt_shape_id(C.byref(wd)) == 0 and wide.pmt_model_check(C.byref(wd)) == 0
-        assert default.pmt_model_check(C.byref(wd)) == L.E_UNSUPPORTED
+        assert wide is not lib and wide.pmt_shape_id(C.byref(wd)) == 0 and wide.pmt_model_check(C.byref(wd)) == 0
     too_wide = wide_params()
     too_wide.read_layers = [130]
     with pytest.raises(L.PmtError, match="exceeds"):
