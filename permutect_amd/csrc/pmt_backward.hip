@@ -32,9 +32,9 @@
 #define PMT_BWD_PRIO 0
 #endif
 #ifndef PMT_BWD_FRAG_AHEAD
-#define PMT_BWD_FRAG_AHEAD 3
+#define PMT_BWD_FRAG_AHEAD 6
 #endif
-#define PMT_FRAG_AHEAD PMT_BWD_FRAG_AHEAD  // weight fragments three MFMA groups ahead (2 waves per SIMD do not hide an L2 round trip): 0 -> 1: 3.59 -> 3.52 ms; 1 -> 3: 3.31 -> 3.27 ms
+#define PMT_FRAG_AHEAD PMT_BWD_FRAG_AHEAD  // weight fragments six MFMA groups ahead (2 waves per SIMD do not hide an L2 round trip): 0 -> 1: 3.59 -> 3.52 ms; 1 -> 3: 3.31 -> 3.27 ms; round 4, 3 -> 6: 2.43 -> 2.40 ms (8: the same)
 #include "pmt_device.hpp"
 #include "pmt_mlp_device.hpp"
 #include "pmt_bwd_device.hpp"
