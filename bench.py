@@ -33,6 +33,7 @@ import glob
 import hashlib
 import json
 import os
+import warnings
 import subprocess
 import sys
 import time
@@ -661,17 +662,20 @@ def main():
     #      instances.py: the library built around its tile counts) against the generic instance every such model used to run ---------
     shapes = None
     if world == 1 and not args.no_extras and args.data == "resident" and args.depth == "wgs" and args.mode == "both" and args.dtype == "f32":
-        from permutect_amd.parameters import t0_params
+        from permutect_amd.parameters import t0_params, wide_params
         shapes = {}
-        for label, env in (("instance", None), ("generic", "any")):
+        for label, env in (("instance", None), ("generic", "any"), ("wide_instance", None), ("wide_generic", "any")):
+            make_params = wide_params if label.startswith("wide") else t0_params
             if env is None:
                 os.environ.pop("PMT_SHAPE", None)
             else:
                 os.environ["PMT_SHAPE"] = env  # read once, when the model is lowered
             torch.manual_seed(1)
-            tmodel = ArtifactModel(t0_params(), device=dev, **P0_DIMS)
-            topt = FusedClipAdamW(tmodel, lr=1e-3, weight_decay=0.01)
-            tmodel.engine()  # (lowered here, while the variable is set)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")  # (the generic legs are asked for: the library's warning about them is not news)
+                tmodel = ArtifactModel(make_params(), device=dev, **P0_DIMS)
+                topt = FusedClipAdamW(tmodel, lr=1e-3, weight_decay=0.01)
+                tmodel.engine()  # (lowered here, while the variable is set)
             os.environ.pop("PMT_SHAPE", None)
 
             def tstep(batch, train):
@@ -686,7 +690,7 @@ def main():
                 tmodel.train(mode == "train")
                 for i in range(4):
                     tstep(batches[i % len(batches)], mode == "train")
-                k = 20
+                k = 8 if label == "wide_generic" else 20
                 marks = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
                 tmodel.engine().timers = {"pmt_forward": [], "pmt_backward": []}
                 torch.cuda.synchronize()
@@ -703,7 +707,11 @@ def main():
             shapes[label] = rec
             del tmodel, topt
         shapes["workload"] = (f"the reference's test configuration T0 (read_layers [10,10,10], reducer [20,20,20], 2 gated blocks) on the headline's "
-                              f"{args.batch}-set batches: the library built around its tile counts against the generic instance")
+                              f"{args.batch}-set batches: the library built around its tile counts against the generic instance; wide_*: the same for "
+                              "parameters.wide_params (layers beyond 64: read width 48, d_model 98, d_ffn 32, 2 gated blocks, the production CNN): "
+                              "its exact instances with 8-tile register arrays against the generic instances of the wide build")
+        note(f"wide shape (d_model 98): train {shapes['wide_instance']['train_ms_per_step']:.2f} vs {shapes['wide_generic']['train_ms_per_step']:.2f} ms, "
+             f"filter {shapes['wide_instance']['filter_ms_per_step']:.2f} vs {shapes['wide_generic']['filter_ms_per_step']:.2f} ms (exact instances vs generic)")
         note(f"T0 shape, read-set kernels on its instances vs generic: forward {shapes['instance']['filter_pmt_forward_kernel_ms']:.3f} vs "
              f"{shapes['generic']['filter_pmt_forward_kernel_ms']:.3f} ms, training forward {shapes['instance']['train_pmt_forward_kernel_ms']:.3f} vs "
              f"{shapes['generic']['train_pmt_forward_kernel_ms']:.3f}, backward {shapes['instance']['train_pmt_backward_kernel_ms']:.3f} vs "
