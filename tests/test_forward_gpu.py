@@ -518,3 +518,31 @@ def test_a_model_wider_than_64_runs_the_wide_build_and_matches_the_oracle(monkey
     with torch.no_grad():
         out_eval = model.compute_batch_output(batch)
     check_outputs(out_eval, {"out/" + k: v.detach().numpy() for k, v in ref_out.items()}, "wide_d98_eval")
+    # read sets beyond one workgroup (split over groups, joined inside the launch): forward and gradients again
+    nref2, nalt2 = np.array([5, 330, 2, 40]), np.array([3, 280, 9, 600])
+    ints2, floats2, packed2 = _arrays(nref2, nalt2, seed=81)
+    batch2 = Batch.from_arrays(ints2, floats2, packed2).copy_to(dev)
+    model.train(True)
+    out2 = model.compute_batch_output(batch2)
+    opt.zero_grad()
+    model.compute_batch_losses(out2, batch2).total_loss.backward()
+    torch.cuda.synchronize()
+    eng.check_join_fault()
+    i64 = torch.from_numpy(ints2.astype(np.int64))
+    ob2 = dict(reads_re=torch.from_numpy(O.decode_packed_reads(packed2).astype(np.float32)), nref=i64[:, O.REF_COUNT], nalt=i64[:, O.ALT_COUNT],
+               labels=i64[:, O.LABEL], sources=i64[:, O.SOURCE], info_be=torch.from_numpy(floats2[:, O.INFO_START:].astype(np.float32)),
+               haplotypes_bh=i64[:, O.HAPLOTYPES_START:])
+    ref_out2, _, ref_grads2 = O.train_step_grads(sd, cfg, ob2)
+    check_outputs(out2, {"out/" + k: v.detach().numpy() for k, v in ref_out2.items()}, "wide_d98_split_sets", lk_ulps=32)
+    # (sums over 600 reads of a 98-wide model: the fp32 ORACLE is 2e-4 from an fp64 evaluation here -- the yardstick is fp64, and the
+    #  bound what the reference's own arithmetic reaches)
+    try:
+        O.COMPUTE_DTYPE = torch.float64
+        _, _, ref_grads64 = O.train_step_grads({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, cfg, ob2)
+    finally:
+        O.COMPUTE_DTYPE = torch.float32
+    g64 = np.concatenate([ref_grads64[n].numpy().ravel() for n in names])
+    g32 = np.concatenate([ref_grads2[n].numpy().ravel().astype(np.float64) for n in names])
+    gour2 = np.concatenate([p.grad.detach().cpu().numpy().ravel().astype(np.float64) for _, p in model.named_parameters()])
+    hip64, o32_64 = np.linalg.norm(gour2 - g64) / np.linalg.norm(g64), np.linalg.norm(g32 - g64) / np.linalg.norm(g64)
+    assert np.all(np.isfinite(gour2)) and hip64 <= max(2e-5, 1.5 * o32_64), (hip64, o32_64)
