@@ -17,7 +17,7 @@ from oracle import artifact_oracle as O
 from permutect_amd.architecture.artifact_model import ArtifactModel
 from permutect_amd.data.batch import Batch
 from permutect_amd.engine import lib as L
-from permutect_amd.parameters import P0_DIMS, p0_params, t0_params
+from permutect_amd.parameters import P0_DIMS, p0_params, t0_params, wide_params
 from permutect_amd.training.optimizer import FusedClipAdamW
 from tests.helpers import config_for
 from tests.test_forward_gpu import _arrays
@@ -28,7 +28,7 @@ P = 0.25
 
 def dropout_model(family, num_sources=2, seed=3):
     torch.manual_seed(seed)
-    params = t0_params() if family == "t0" else p0_params()
+    params = t0_params() if family == "t0" else wide_params() if family == "wide" else p0_params()
     params.dropout_p = P
     model = ArtifactModel(params, device=torch.device("cuda"), **P0_DIMS)
     if num_sources > 1:
@@ -118,7 +118,7 @@ def small_batch(seed, n=48):
     return ints, floats, packed
 
 
-@pytest.mark.parametrize("family", ["p0", "t0"])
+@pytest.mark.parametrize("family", ["p0", "t0", "wide"])  # (wide: layers beyond 64, the dropout instance of its own build of the library)
 def test_train_step_with_dropout_matches_oracle_given_the_masks(family):
     model = dropout_model(family)
     d = model.engine().plan.desc
