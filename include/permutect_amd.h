@@ -44,7 +44,10 @@ extern "C" {
 #define PMT_MAX_WIDTH 64        /* widest activation (features) kept register-resident: 4 tiles of 16.  The WIDE build of the
                                    library (csrc/Makefile: `make wide`, -DPMT_MAX_WIDTH=128) keeps 8: pmt_limits() reports it */
 #endif
-#define PMT_MAX_HALF_FFN 16     /* d_ffn / 2 */
+#ifndef PMT_MAX_HALF_FFN
+#define PMT_MAX_HALF_FFN 16     /* d_ffn / 2: one 16-feature tile per half of a gated block's hidden layer.  A build with 32 (csrc/Makefile:
+                                   `make wide32`) gives every half TWO tiles -- it runs models with d_ffn / 2 in 17 .. 32 only */
+#endif
 #define PMT_MAX_CLUSTERS 16
 #define PMT_MAX_OPS 8           /* top-level ops per MLP program */
 #define PMT_MAX_ROW_INPUT 128    /* widest input of a per-variant row MLP (info vector) */

@@ -22,7 +22,8 @@
 #define PMT_BWD_PIECES 3  // pieces of the products that keep the forward's precision (the head's recomputation); the input-gradient and
                           // recomputation products of the layers take PMT_DGRAD_PIECES / PMT_RECOMPUTE_PIECES (pmt_bwd_device.hpp)
 #endif
-#define PMT_STAGE_PLANES (16 * PMT_GROUP_WAVES)  // every wave's operands of a 4 + 4 tile linear at once (8 waves x 8 planes x (hi + mid))
+#include "permutect_amd.h"
+#define PMT_STAGE_PLANES ((16 - 2 * (PMT_MAX_HALF_FFN / 16 - 1)) * PMT_GROUP_WAVES)  // every wave's operands of a 4 + 4 tile linear at once (8 waves x 8 planes x (hi + mid)); a build with two-tile gate halves gives 16 KiB of it to the wider per-set tables
 #include "permutect_amd.h"
 #define PMT_OPAQUE_TID 1  // the kernel loops over groups (persistent launch): see pmt_tid
 #ifndef PMT_BWD_XH4_AT_P3
@@ -41,8 +42,8 @@
 
 struct BwdShared {
     int off[2][PMT_GROUP_MAX_SETS + 1];
-    float gsum[PMT_GROUP_MAX_SETS][2][16];                      // per-set sums of d(gate), current block
-    float dmean[PMT_GROUP_MAX_SETS][2][16];                     // d(m_ref), d(m_alt) already divided by (n + w)
+    float gsum[PMT_GROUP_MAX_SETS][2][16 * (PMT_MAX_HALF_FFN / 16)];   // per-set sums of d(gate), current block
+    float dmean[PMT_GROUP_MAX_SETS][2][16 * (PMT_MAX_HALF_FFN / 16)];                     // d(m_ref), d(m_alt) already divided by (n + w)
     float dl[PMT_GROUP_MAX_SETS][PMT_MAX_CLUSTERS + 2];         // d(loss)/d(Lambda[b][j]) incl. the logit path
     float aux[PMT_WAVES][PMT_AUX_CAP];                          // small-parameter gradient slabs (BwdCtx.aux)
     int aux_dst[PMT_AUX_CAP];
@@ -95,11 +96,12 @@ DEV void load_slot_tiles(const float* const (&stash_tile)[PMT_RT], unsigned mask
 #ifndef PMT_BWD_Z_F16
 #define PMT_BWD_Z_F16 1
 #endif
+#define PMT_BWD_PARK_TILES (5 * PMT_HT + 1)  // z1, z2, z2hat, d(gate), d(u) (PMT_HT tiles each) and the rstd of LayerNorm(h)
 struct PmtBwdLayered {
     int slice;
     float* dy_scratch;  // [total_tiles][PMT_SLOT_FLOATS] running gradient
-    float* park;        // [total_tiles][6][256]: z1, z2 (after SELU), z2hat, d(gate), d(u), rstd of LayerNorm(h)
-    float* gsum_g;      // [B][L][32] per-set sums of d(gate)
+    float* park;        // [total_tiles][PMT_BWD_PARK_TILES][256]: z1, z2 (after SELU), z2hat, d(gate), d(u), rstd of LayerNorm(h)
+    float* gsum_g;      // [B][L][PMT_ZW] per-set sums of d(gate)
     PmtJoin join;       // join.on: ONE launch; the groups of a split read set join their d(gate) sums through HBM (pmt_device.hpp)
 };
 
@@ -130,7 +132,7 @@ DEV void backward_group(
         sh.off[0][i] = bt.ref_offsets[gg.v0 + i] - gg.ref_base;
         sh.off[1][i] = bt.alt_offsets[gg.v0 + i] - gg.alt_base;
     }
-    for (int i = tid; i < PMT_GROUP_MAX_SETS * 32; i += PMT_THREADS) (&sh.gsum[0][0][0])[i] = 0.f;
+    for (int i = tid; i < PMT_GROUP_MAX_SETS * PMT_ZW; i += PMT_THREADS) (&sh.gsum[0][0][0])[i] = 0.f;
     lds_barrier();
     // per-set upstream gradients (reference feature_clustering.py:121-135 differentiated)
     for (int i = tid; i < gg.nsets; i += PMT_THREADS) {
@@ -454,48 +456,59 @@ DEV void backward_group(
         // ---- phase 1: z = selu(W1 n + b1).  The exact-width instances take it from the stash, where the forward left both halves
         // after their SELU (2 KiB per tile): recomputing it from xhat_l -- a stash read twice the size, a LayerNorm affine and the
         // 60 -> 2 x 10 projection with its splits -- was 6 % of the kernel.  The generic instance still recomputes.
-        f4 z[PMT_RT][2];
+        constexpr int HT = PMT_HT;  // tiles per half of the hidden layer: z[..][0 .. HT) = z1, z[..][HT .. 2 HT) = z2 (after its SELU)
+        constexpr int PARK = 5 * HT + 1;  // tiles a layered launch parks per read tile (PMT_BWD_PARK_TILES)
+        f4 z[PMT_RT][2 * HT];
         if (first_half) {
             if constexpr (EX && PMT_STASH_Z) {
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt) {
-                    z[rt][0] = z[rt][1] = f4{0.f, 0.f, 0.f, 0.f};
-                    if (mask_all & (1u << rt)) stash_load<2>(stash_tile[rt] + (size_t)(slot_z0 + l) * PMT_SLOT_FLOATS, z[rt]);
+#pragma unroll
+                    for (int t = 0; t < 2 * HT; ++t) z[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
+                    if (mask_all & (1u << rt)) stash_load<2 * HT>(stash_tile[rt] + (size_t)(slot_z0 + l) * PMT_SLOT_FLOATS, z[rt]);
                 }
             } else {
                 f4 n[PMT_RT][NTD], xq[PMT_RT][NTD];
                 load_xhat(xq, l);
                 affine_n(n, xq);
-                const f4 b0 = load_pvec(packed + uniform(P1.b_pvec), 0, g), b1 = load_pvec(packed + uniform(P1.b_pvec), 1, g);
 #pragma unroll
-                for (int rt = 0; rt < PMT_RT; ++rt) { z[rt][0] = b0; z[rt][1] = b1; }
+                for (int t = 0; t < 2 * HT; ++t) {
+                    const f4 b_t = load_pvec(packed + uniform(P1.b_pvec), t, g);
+#pragma unroll
+                    for (int rt = 0; rt < PMT_RT; ++rt) z[rt][t] = b_t;
+                }
                 // (the gate multiplies by this: fp32-equivalent products -- three f16 MFMAs on two-piece splits like the forward's, or
                 //  with PMT_BWD_Z_F16 = 0 the six bf16 MFMAs on three-piece splits of round 3)
-                if constexpr (S::BF16 && PMT_BWD_Z_F16) linear_acc_f16<NTD, 2, false>(z, n, packed + uniform(P1.wh_frag));
-                else if constexpr (S::BF16) linear_acc_bf16<NTD, 2, false, BFB>(z, n, packed + uniform(P1.wb_frag));
-                else linear_acc<NTD, 2, false, EX, S::DIM_D>(z, n, packed + uniform(P1.w_frag), D, 16 + h);
+                if constexpr (S::BF16 && PMT_BWD_Z_F16) linear_acc_f16<NTD, 2 * HT, false>(z, n, packed + uniform(P1.wh_frag));
+                else if constexpr (S::BF16) linear_acc_bf16<NTD, 2 * HT, false, BFB>(z, n, packed + uniform(P1.wb_frag));
+                else linear_acc<NTD, 2 * HT, false, EX, S::DIM_D>(z, n, packed + uniform(P1.w_frag), D, PMT_SPLIT0 + h);
 #pragma unroll
-                for (int rt = 0; rt < PMT_RT; ++rt) {
-                    z[rt][0] = selu4(z[rt][0]);
-                    z[rt][1] = selu4(z[rt][1]);
-                }
+                for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                    for (int t = 0; t < 2 * HT; ++t) z[rt][t] = selu4(z[rt][t]);
             }
         }
-        const f4 sw = load_pvec(packed + uniform(B.sgu_norm_w_pvec), 0, g), sb = load_pvec(packed + uniform(B.sgu_norm_b_pvec), 0, g);
+        f4 sw[HT], sb[HT], rho[HT];
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+            sw[t] = load_pvec(packed + uniform(B.sgu_norm_w_pvec), t, g);
+            sb[t] = load_pvec(packed + uniform(B.sgu_norm_b_pvec), t, g);
+        }
         const float w = uniform(phi[uniform(B.reg_weight_phi)]) + 0.25f;
-        const f4 rho = load_pvec(packed + uniform(B.ref_reg_pvec), 0, g);
+#pragma unroll
+        for (int t = 0; t < HT; ++t) rho[t] = load_pvec(packed + uniform(B.ref_reg_pvec), t, g);
         const float alpha = uniform(theta[uniform(B.alpha_src[side])]), beta = uniform(theta[uniform(B.beta_src[side])]);
         const float beta_ref = uniform(theta[uniform(B.beta_src[0])]), beta_alt = uniform(theta[uniform(B.beta_src[1])]);
         const float gamma = uniform(theta[uniform(B.gamma_src)]);
         // gate of one tile from z2hat (recomputed wherever it is needed)
-        auto gate_of = [&](int rt, f4 z2hat_rt, f4& z2_out, f4& m_ref, f4& m_alt) -> f4 {
+        auto gate_of = [&](int rt, int t, f4 z2hat_rt, f4& z2_out, f4& m_ref, f4& m_alt) -> f4 {  // tile t of the half
             const int set = tm[rt].set;
             const float n_ref = (float)(sh.off[0][set + 1] - sh.off[0][set]);
             const float n_alt = (float)(sh.off[1][set + 1] - sh.off[1][set]);
-            const float* zs = zsum_stash + ((size_t)(gg.v0 + set) * L + l) * 32;
-            m_ref = (*reinterpret_cast<const f4*>(zs + 4 * g) + w * rho) * fast_rcp(n_ref + w);
-            m_alt = *reinterpret_cast<const f4*>(zs + 16 + 4 * g) * fast_rcp(n_alt + 1e-4f);
-            z2_out = z2hat_rt * sw + sb;
+            const float* zs = zsum_stash + ((size_t)(gg.v0 + set) * L + l) * PMT_ZW + 16 * t;
+            m_ref = (*reinterpret_cast<const f4*>(zs + 4 * g) + w * rho[t]) * fast_rcp(n_ref + w);
+            m_alt = *reinterpret_cast<const f4*>(zs + 16 * HT + 4 * g) * fast_rcp(n_alt + 1e-4f);
+            z2_out = z2hat_rt * sw[t] + sb[t];
             const f4 gt = z2_out * alpha + 1.0f;
             return side == 0 ? gt + beta * m_ref : (gt + beta * m_alt) + gamma * m_ref;
         };
@@ -503,7 +516,7 @@ DEV void backward_group(
         trace_ev(c, 18);
         t_ph = prof_now();
         // ---- phase 2: d(u) = W2^T dy, d(gate), per-set sums of d(gate), proj2 weight gradient ------------------------------
-        f4 z2hat[PMT_RT], dgate[PMT_RT], du[PMT_RT][1];
+        f4 z2hat[PMT_RT][HT], dgate[PMT_RT][HT], du[PMT_RT][HT];
         float rstd2[PMT_RT];
         float d_alpha = 0.f, d_beta = 0.f, d_gamma = 0.f, d_reg_w = 0.f;
         // the block's scalar gradients in ONE push (zeros from the waves of the other side: the slab layout is workgroup-uniform)
@@ -515,66 +528,77 @@ DEV void backward_group(
             aux_push_scalars<8>(c, enc8, val8);
         };
 #pragma unroll
-        for (int rt = 0; rt < PMT_RT; ++rt) du[rt][0] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < HT; ++t) du[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
         if (first_half) {
-            if constexpr (S::BF16) linear_acc_bf16<NTD, 1, false, PMT_DG(BFB)>(du, dy, packed + uniform(P2.wtb_frag));
-            else linear_acc<NTD, 1, false, EX, S::DIM_D>(du, dy, packed + uniform(P2.wt_frag), D, h);
+            if constexpr (S::BF16) linear_acc_bf16<NTD, HT, false, PMT_DG(BFB)>(du, dy, packed + uniform(P2.wtb_frag));
+            else linear_acc<NTD, HT, false, EX, S::DIM_D>(du, dy, packed + uniform(P2.wt_frag), D, h);
         }
         if (first_half) {
-            f4 u[PMT_RT][1];
+            f4 u[PMT_RT][HT];
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) {
-                f4 zin[1] = {z[rt][1]}, zo[1], zh[1], sw1[1] = {sw}, sb1[1] = {sb};
-                layernorm_tile<1>(zo, zh, rstd2[rt], zin, h, sw1, sb1, g);
-                z2hat[rt] = zh[0];
-                f4 z2v, m_ref, m_alt;
-                const f4 gt = gate_of(rt, z2hat[rt], z2v, m_ref, m_alt);
-                u[rt][0] = z[rt][0] * gt;
+                f4 zin[HT], zo[HT];
+#pragma unroll
+                for (int t = 0; t < HT; ++t) zin[t] = z[rt][HT + t];
+                layernorm_tile<HT>(zo, z2hat[rt], rstd2[rt], zin, h, sw, sb, g);
                 const int set = tm[rt].set;
                 const bool ok = tm[rt].valid;
-                const SegPlan sp = seg_plan(ok ? set : -1);  // per-set sums of d(gate): segmented reduce over the tile's reads
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float dg = (ok && feat_of(0, j, g) < h) ? du[rt][0][j] * z[rt][0][j] : 0.f;
-                    dgate[rt][j] = dg;
-                    d_alpha += dg * z2v[j];
-                    d_beta += dg * (side == 0 ? m_ref[j] : m_alt[j]);
-                    if (side == 1) d_gamma += dg * m_ref[j];
+                for (int t = 0; t < HT; ++t) {
+                    f4 z2v, m_ref, m_alt;
+                    const f4 gt = gate_of(rt, t, z2hat[rt][t], z2v, m_ref, m_alt);
+                    u[rt][t] = z[rt][t] * gt;
+                    const SegPlan sp = seg_plan(ok ? set : -1);  // per-set sums of d(gate): segmented reduce over the tile's reads
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float dg = (ok && feat_of(t, j, g) < h) ? du[rt][t][j] * z[rt][t][j] : 0.f;
+                        dgate[rt][t][j] = dg;
+                        d_alpha += dg * z2v[j];
+                        d_beta += dg * (side == 0 ? m_ref[j] : m_alt[j]);
+                        if (side == 1) d_gamma += dg * m_ref[j];
+                    }
+                    const f4 sg4 = seg_sum4<!S::BF16>(dgate[rt][t], sp);  // (guarded in the fp32 instances only: pmt_device.hpp, seg_sum)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (sp.last && feat_of(t, j, g) < h) atomicAdd(&sh.gsum[set][side][16 * t + 4 * g + j], sg4[j]);
                 }
-                const f4 sg4 = seg_sum4<!S::BF16>(dgate[rt], sp);  // (guarded in the fp32 instances only: pmt_device.hpp, seg_sum)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (sp.last && feat_of(0, j, g) < h) atomicAdd(&sh.gsum[set][side][4 * g + j], sg4[j]);
             }
             prof_add(c, 9, t_ph);
             trace_ev(c, 19);
             t_ph = prof_now();
             // proj2 weight gradients of both sides in one exchange round
-            if constexpr (S::BF16 != 0) wgrad_exchange_bf<NTD, 1, 2, BFB>(c, M->lin[uniform(B.proj2[0])], M->lin[uniform(B.proj2[1])], dy, u, 1.0f);
-            else wgrad_exchange<NTD, 1, 2>(c, M->lin[uniform(B.proj2[0])], M->lin[uniform(B.proj2[1])], dy, u, 1.0f);
+            if constexpr (S::BF16 != 0) wgrad_exchange_bf<NTD, HT, 2, BFB>(c, M->lin[uniform(B.proj2[0])], M->lin[uniform(B.proj2[1])], dy, u, 1.0f);
+            else wgrad_exchange<NTD, HT, 2>(c, M->lin[uniform(B.proj2[0])], M->lin[uniform(B.proj2[1])], dy, u, 1.0f);
         }
         if (c.dbg & 1) __syncthreads();  // (the exchange's barriers, skipped by that switch, complete gsum)
         if constexpr (LAYERED) {
             float* pk[PMT_RT];
 #pragma unroll
-            for (int rt = 0; rt < PMT_RT; ++rt) pk[rt] = lay.park + (tile_global + rt) * (6 * 256);
+            for (int rt = 0; rt < PMT_RT; ++rt) pk[rt] = lay.park + (tile_global + rt) * (PARK * 256);
             if (joined) {  // publish this group's part of the block's d(gate) sums, wait for the other groups of its split sets
                 lds_barrier();
-                pmt_join_sets(lay.join, &sh.gsum[0][0][0], lay.gsum_g + ((size_t)gg.v0 * L + l) * 32, L * 32,
+                pmt_join_sets(lay.join, &sh.gsum[0][0][0], lay.gsum_g + ((size_t)gg.v0 * L + l) * PMT_ZW, L * PMT_ZW,
                               lay.join.arrivals + (size_t)gg.v0 * L + l, L, bt.set_groups + gg.v0, gg.nsets);
                 lds_barrier();
                 push_gate_scalars(0.f, -1);
             } else if (first_half) {  // end of this launch: join the global sums, park the per-read state and the running gradient
-                for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS) {
+                for (int i = tid; i < gg.nsets * PMT_ZW; i += PMT_THREADS) {
                     const float v = (&sh.gsum[0][0][0])[i];
-                    if (v != 0.f) atomicAdd(&lay.gsum_g[((size_t)(gg.v0 + (i >> 5)) * L + l) * 32 + (i & 31)], v);
+                    if (v != 0.f) atomicAdd(&lay.gsum_g[((size_t)(gg.v0 + (i / PMT_ZW)) * L + l) * PMT_ZW + (i % PMT_ZW)], v);
                 }
                 push_gate_scalars(0.f, -1);
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
                     if (mask_all & (1u << rt)) {
-                        f4 st[6] = {z[rt][0], z[rt][1], z2hat[rt], dgate[rt], du[rt][0], f4{rstd2[rt], rstd2[rt], rstd2[rt], rstd2[rt]}};
-                        stash_store<6>(pk[rt], st);
+                        f4 st[PARK];  // [z1 | z2 | z2hat | d(gate) | d(u): HT tiles each][rstd]
+#pragma unroll
+                        for (int t = 0; t < HT; ++t) {
+                            st[t] = z[rt][t]; st[HT + t] = z[rt][HT + t]; st[2 * HT + t] = z2hat[rt][t]; st[3 * HT + t] = dgate[rt][t]; st[4 * HT + t] = du[rt][t];
+                        }
+                        st[5 * HT] = f4{rstd2[rt], rstd2[rt], rstd2[rt], rstd2[rt]};
+                        stash_store<PARK>(pk[rt], st);
                         stash_store<NTD>(lay.dy_scratch + (tile_global + rt) * PMT_SLOT_FLOATS, dy[rt]);
                     }
                 aux_flush(c);
@@ -582,14 +606,18 @@ DEV void backward_group(
             } else {
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) {
-                f4 st[6];
+                f4 st[PARK];
 #pragma unroll
-                for (int q = 0; q < 6; ++q) st[q] = f4{0.f, 0.f, 0.f, 0.f};
-                if (mask_all & (1u << rt)) stash_load<6>(pk[rt], st);
-                z[rt][0] = st[0]; z[rt][1] = st[1]; z2hat[rt] = st[2]; dgate[rt] = st[3]; du[rt][0] = st[4]; rstd2[rt] = st[5][0];
+                for (int q = 0; q < PARK; ++q) st[q] = f4{0.f, 0.f, 0.f, 0.f};
+                if (mask_all & (1u << rt)) stash_load<PARK>(pk[rt], st);
+#pragma unroll
+                for (int t = 0; t < HT; ++t) {
+                    z[rt][t] = st[t]; z[rt][HT + t] = st[HT + t]; z2hat[rt][t] = st[2 * HT + t]; dgate[rt][t] = st[3 * HT + t]; du[rt][t] = st[4 * HT + t];
+                }
+                rstd2[rt] = st[5 * HT][0];
             }
-            for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS)
-                (&sh.gsum[0][0][0])[i] = lay.gsum_g[((size_t)(gg.v0 + (i >> 5)) * L + l) * 32 + (i & 31)];
+            for (int i = tid; i < gg.nsets * PMT_ZW; i += PMT_THREADS)
+                (&sh.gsum[0][0][0])[i] = lay.gsum_g[((size_t)(gg.v0 + (i / PMT_ZW)) * L + l) * PMT_ZW + (i % PMT_ZW)];
             lds_barrier();
             }
         }
@@ -601,61 +629,72 @@ DEV void backward_group(
         // d(reg_weight) are sums over the sets: summed over the passes per lane, over the 4 sets of a pass across the
         // lane groups, over the waves and into global memory through the small-parameter slab.
         {
-            const int p = lane & 15, f = pos_to_feat(p);
-            const float rho_f = f < h ? theta[B.ref_reg_src + f] : 0.f;
-            float a_rho = 0.f, a_w = 0.f;
-            for (int i = tid; i < gg.nsets * 16; i += PMT_THREADS) {
-                const int set = i >> 4;
-                const float n_ref = (float)(sh.off[0][set + 1] - sh.off[0][set]);
-                const float n_alt = (float)(sh.off[1][set + 1] - sh.off[1][set]);
-                const float gr = sh.gsum[set][0][p], ga = sh.gsum[set][1][p];
-                const float dm_ref = beta_ref * gr + gamma * ga, dm_alt = beta_alt * ga;
-                const float inv_ref = fast_rcp(n_ref + w);
-                sh.dmean[set][0][p] = dm_ref * inv_ref;
-                sh.dmean[set][1][p] = dm_alt * fast_rcp(n_alt + 1e-4f);
-                if (f < h && owns(set)) {
-                    const float zs = zsum_stash[((size_t)(gg.v0 + set) * L + l) * 32 + p];
-                    const float m_ref = (zs + w * rho_f) * inv_ref;
-                    a_rho += dm_ref * w * inv_ref;
-                    a_w += dm_ref * (rho_f - m_ref) * inv_ref;
+            float a_w = 0.f;
+#pragma unroll
+            for (int t = 0; t < HT; ++t) {  // (one pass per tile of the half: position 16 t + p)
+                const int p = 16 * t + (lane & 15), f = pos_to_feat(p);
+                const float rho_f = f < h ? theta[B.ref_reg_src + f] : 0.f;
+                float a_rho = 0.f;
+                for (int i = tid; i < gg.nsets * 16; i += PMT_THREADS) {
+                    const int set = i >> 4;
+                    const float n_ref = (float)(sh.off[0][set + 1] - sh.off[0][set]);
+                    const float n_alt = (float)(sh.off[1][set + 1] - sh.off[1][set]);
+                    const float gr = sh.gsum[set][0][p], ga = sh.gsum[set][1][p];
+                    const float dm_ref = beta_ref * gr + gamma * ga, dm_alt = beta_alt * ga;
+                    const float inv_ref = fast_rcp(n_ref + w);
+                    sh.dmean[set][0][p] = dm_ref * inv_ref;
+                    sh.dmean[set][1][p] = dm_alt * fast_rcp(n_alt + 1e-4f);
+                    if (f < h && owns(set)) {
+                        const float zs = zsum_stash[((size_t)(gg.v0 + set) * L + l) * PMT_ZW + p];
+                        const float m_ref = (zs + w * rho_f) * inv_ref;
+                        a_rho += dm_ref * w * inv_ref;
+                        a_w += dm_ref * (rho_f - m_ref) * inv_ref;
+                    }
                 }
+                aux_push_row16(c, uniform(B.ref_reg_src) + 16 * t, group_sum(a_rho), h - 16 * t);
             }
-            aux_push_row16(c, uniform(B.ref_reg_src), group_sum(a_rho), h);
             if constexpr (LAYERED) aux_push_scalar(c, enc_phi(uniform(B.reg_weight_phi)), a_w);
             else d_reg_w = a_w;  // (pushed with the block's other scalars, phase 3)
         }
         lds_barrier();
-        for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS) (&sh.gsum[0][0][0])[i] = 0.f;
+        for (int i = tid; i < gg.nsets * PMT_ZW; i += PMT_THREADS) (&sh.gsum[0][0][0])[i] = 0.f;
         prof_add(c, 11, t_ph);
         trace_ev(c, 21);
         t_ph = prof_now();
         // ---- phase 3: finish d(z2), LayerNorm(h) backward, SELU backward -> d(zpre) ---------------------------------------
         if (PMT_BWD_XH4_AT_P3 == 1) load_xh4();  // phase 4's stash read, requested here: phase 3 is ~3.6 k cycles of arithmetic to hide it under
-        f4 dz[PMT_RT][2];
+        f4 dz[PMT_RT][2 * HT];
         {
-            f4 dsw[1] = {f4{0.f, 0.f, 0.f, 0.f}}, dsb[1] = {f4{0.f, 0.f, 0.f, 0.f}};
+            f4 dsw[HT], dsb[HT];
+#pragma unroll
+            for (int t = 0; t < HT; ++t) dsw[t] = dsb[t] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) {
                 const int set = tm[rt].set;
                 const bool ok = tm[rt].valid;
-                f4 z2v, m_ref, m_alt;
-                const f4 gt = gate_of(rt, z2hat[rt], z2v, m_ref, m_alt);
-                f4 dz2 = dgate[rt] * alpha;
-                const f4 dm = *reinterpret_cast<const f4*>(&sh.dmean[set][side][4 * g]);
-                if (ok) dz2 = dz2 + dm;
-                f4 dz2v[1] = {dz2}, zh[1] = {z2hat[rt]}, sw1[1] = {sw}, dxr[1];
-                layernorm_bwd_tile<1>(dxr, dz2v, zh, rstd2[rt], h, sw1, dsw, dsb, g);
-                const f4 dz1 = ok ? du[rt][0] * gt : f4{0.f, 0.f, 0.f, 0.f};
-                dz[rt][0] = selu_bwd4(dz1, z[rt][0]);
-                dz[rt][1] = selu_bwd4(dxr[0], z[rt][1]);
+                f4 dz2v[HT], dxr[HT];
+#pragma unroll
+                for (int t = 0; t < HT; ++t) {
+                    f4 z2v, m_ref, m_alt;
+                    const f4 gt = gate_of(rt, t, z2hat[rt][t], z2v, m_ref, m_alt);
+                    f4 dz2 = dgate[rt][t] * alpha;
+                    const f4 dm = *reinterpret_cast<const f4*>(&sh.dmean[set][side][16 * t + 4 * g]);
+                    if (ok) dz2 = dz2 + dm;
+                    dz2v[t] = dz2;
+                    const f4 dz1 = ok ? du[rt][t] * gt : f4{0.f, 0.f, 0.f, 0.f};
+                    dz[rt][t] = selu_bwd4(dz1, z[rt][t]);
+                }
+                layernorm_bwd_tile<HT>(dxr, dz2v, z2hat[rt], rstd2[rt], h, sw, dsw, dsb, g);
+#pragma unroll
+                for (int t = 0; t < HT; ++t) dz[rt][HT + t] = selu_bwd4(dxr[t], z[rt][HT + t]);
             }
             if (PMT_BWD_XH4_AT_P3 == 2) {  // behind the phase's last global load, ahead of its cross-lane sums (LDS only)
                 __builtin_amdgcn_sched_barrier(0);
                 load_xh4();
                 __builtin_amdgcn_sched_barrier(0);
             }
-            aux_push_vec_x<1, EX>(c, uniform(B.sgu_norm_w_src), dsw, h);
-            aux_push_vec_x<1, EX>(c, uniform(B.sgu_norm_b_src), dsb, h);
+            aux_push_vec_x<HT, EX>(c, uniform(B.sgu_norm_w_src), dsw, h);
+            aux_push_vec_x<HT, EX>(c, uniform(B.sgu_norm_b_src), dsb, h);
             if constexpr (!LAYERED) push_gate_scalars(d_reg_w, enc_phi(uniform(B.reg_weight_phi)));  // (layered: pushed at the end of the launch that computed them)
         }
         prof_add(c, 12, t_ph);
@@ -666,8 +705,8 @@ DEV void backward_group(
             f4 n[PMT_RT][NTD];
             if (PMT_BWD_XH4_AT_P3 == 0) load_xh4();
             affine_n(n, xh4);
-            if constexpr (S::BF16 != 0) wgrad_exchange_bf<2, NTD, 2, BFB>(c, M->lin[uniform(B.proj1[0])], M->lin[uniform(B.proj1[1])], dz, n, 1.0f);
-            else wgrad_exchange<2, NTD, 2>(c, M->lin[uniform(B.proj1[0])], M->lin[uniform(B.proj1[1])], dz, n, 1.0f);
+            if constexpr (S::BF16 != 0) wgrad_exchange_bf<2 * HT, NTD, 2, BFB>(c, M->lin[uniform(B.proj1[0])], M->lin[uniform(B.proj1[1])], dz, n, 1.0f);
+            else wgrad_exchange<2 * HT, NTD, 2>(c, M->lin[uniform(B.proj1[0])], M->lin[uniform(B.proj1[1])], dz, n, 1.0f);
         }
         prof_add(c, 13, t_ph);
         trace_ev(c, 23);
@@ -675,8 +714,8 @@ DEV void backward_group(
         {
             f4 dn[PMT_RT][NTD];
             init_bias<NTD>(dn, nullptr, D, g);
-            if constexpr (S::BF16) linear_acc_bf16<2, NTD, false, PMT_DG(BFB)>(dn, dz, packed + uniform(P1.wtb_frag));
-            else linear_acc<2, NTD, false, EX, 0, S::DIM_H>(dn, dz, packed + uniform(P1.wt_frag), 16 + h, D);
+            if constexpr (S::BF16) linear_acc_bf16<2 * HT, NTD, false, PMT_DG(BFB)>(dn, dz, packed + uniform(P1.wtb_frag));
+            else linear_acc<2 * HT, NTD, false, EX, 0, S::DIM_H>(dn, dz, packed + uniform(P1.wt_frag), PMT_SPLIT0 + h, D);
             f4 lw[NTD], dlw[NTD], dlb[NTD];
 #pragma unroll
             for (int t = 0; t < NTD; ++t) {
@@ -832,7 +871,7 @@ __global__ __launch_bounds__(256) void pmt_grad_fold_kernel(const PmtModel* __re
     const PmtLinear& L = M->lin[blockIdx.y];
     const int tab = L.emit_tab;
     if (tab < 0) return;
-    const int out_v = L.out_split > 0 ? 16 + L.out_split : L.out_dim;
+    const int out_v = L.out_split > 0 ? PMT_SPLIT0 + L.out_split : L.out_dim;
     const int nmt = (out_v + 15) >> 4, nkt = (L.in_dim + 15) >> 4, nw = nmt * nkt * 256, n = nw + nmt * 16;  // (multiples of 4)
     const int q = threadIdx.x & 31, slice = threadIdx.x >> 5, i = (blockIdx.x * 32 + q) * 4;
     if (blockIdx.x * 128 >= n) return;
@@ -884,7 +923,7 @@ extern "C" int pmt_backward(const PmtModel* model_host, const PmtModel* model_de
         batch->total_tiles <= 0 || !out->logits_b || !out->logits_bk)
         return PMT_E_INVALID;
     const float* zsum_stash = stash + (size_t)batch->total_tiles * (size_t)pmt_stash_slots(model_host) * PMT_SLOT_FLOATS;
-    const float* rstd_stash = zsum_stash + (size_t)batch->num_variants * (size_t)(model_host->num_blocks > 0 ? model_host->num_blocks : 1) * 32;
+    const float* rstd_stash = zsum_stash + (size_t)batch->num_variants * (size_t)(model_host->num_blocks > 0 ? model_host->num_blocks : 1) * PMT_ZW;
     const int shape = pmt_shape_for(model_host, batch);
     const bool part = use_partials(model_host, shape, grad_partials, num_partials);
     const int grid = part && num_partials < batch->num_groups ? num_partials : batch->num_groups;
@@ -902,7 +941,7 @@ extern "C" size_t pmt_layered_backward_scratch_floats(const PmtModel* m, int64_t
     if (!m) return 0;
     const size_t nb = (size_t)(m->num_blocks > 0 ? m->num_blocks : 1);
     // parked state (layered launches only) | per-set d(gate) sums | joined execution: arrival counters [B][L], ticket, fault word
-    return (size_t)total_tiles * (PMT_SLOT_FLOATS + 6 * 256) + (size_t)num_variants * nb * 32 + (size_t)num_variants * nb + 8;
+    return (size_t)total_tiles * (PMT_SLOT_FLOATS + PMT_BWD_PARK_TILES * 256) + (size_t)num_variants * nb * PMT_ZW + (size_t)num_variants * nb + 8;
 }
 
 extern "C" int pmt_backward_layered(const PmtModel* model_host, const PmtModel* model_dev, const float* theta, const float* phi,
@@ -921,17 +960,17 @@ extern "C" int pmt_backward_layered(const PmtModel* model_host, const PmtModel* 
     const int L = model_host->num_blocks;
     const size_t nb = (size_t)(L > 0 ? L : 1), B = (size_t)batch->num_variants;
     const float* zsum_stash = stash + (size_t)batch->total_tiles * (size_t)pmt_stash_slots(model_host) * PMT_SLOT_FLOATS;
-    const float* rstd_stash = zsum_stash + B * nb * 32;
+    const float* rstd_stash = zsum_stash + B * nb * PMT_ZW;
     PmtBwdLayered lay;
     lay.dy_scratch = scratch;
     lay.park = lay.dy_scratch + (size_t)batch->total_tiles * PMT_SLOT_FLOATS;
-    lay.gsum_g = lay.park + (size_t)batch->total_tiles * 6 * 256;
-    if (hipMemsetAsync(lay.gsum_g, 0, B * nb * 32 * sizeof(float), s) != hipSuccess) return PMT_E_LAUNCH;
+    lay.gsum_g = lay.park + (size_t)batch->total_tiles * PMT_BWD_PARK_TILES * 256;
+    if (hipMemsetAsync(lay.gsum_g, 0, B * nb * PMT_ZW * sizeof(float), s) != hipSuccess) return PMT_E_LAUNCH;
     const int shape = pmt_shape_for(model_host, batch, true);
     const bool part = use_partials(model_host, shape, grad_partials, num_partials);
     const int grid = part && num_partials < batch->num_groups ? num_partials : batch->num_groups;
     auto kernel = (shape >= 2 && shape != 6) ? pmt_backward_kernel<ShapeP0X, true> : (shape == 1 || shape == 6) ? pmt_backward_kernel<ShapeP0, true> : pmt_backward_kernel<ShapeAny, true>;
-    int* join_words = reinterpret_cast<int*>(lay.gsum_g + B * nb * 32);
+    int* join_words = reinterpret_cast<int*>(lay.gsum_g + B * nb * PMT_ZW);
     lay.join = PmtJoin{0, join_words + B * nb, join_words, batch->join_fault ? batch->join_fault : join_words + B * nb + 1};
     if (batch->set_groups != nullptr && L > 0) {  // ONE launch: the groups of a split read set join their sums through HBM
         lay.join.on = 1;

@@ -63,8 +63,8 @@ DEV void stage_store_transposed(f4* __restrict__ plane, f4 v) {
 DEV int pos_to_feat(int p) { return 16 * (p >> 4) + 4 * (p & 3) + ((p & 15) >> 2); }
 DEV int split_row_dev(int v, int h) {
     if (h <= 0) return v;
-    if (v < 16) return v < h ? v : -1;
-    return (v - 16) < h ? h + (v - 16) : -1;
+    if (v < PMT_SPLIT0) return v < h ? v : -1;
+    return (v - PMT_SPLIT0) < h ? h + (v - PMT_SPLIT0) : -1;
 }
 
 // LayerNorm backward for one read tile: given d(y) with y = xhat*w + b, returns d(x); accumulates dw, db partials.
@@ -430,7 +430,7 @@ template <int NTO, int NTI, int SIDES>
 DEV void wgrad_init(WgradAcc<NTO, NTI, SIDES>& a, const PmtLinear& L0) {
     const int wave = uniform((int)(pmt_tid() >> 6));
     a.h = uniform(L0.out_split); a.out_dim = uniform(L0.out_dim); a.in_dim = uniform(L0.in_dim);
-    a.out_v = a.h > 0 ? 16 + a.h : a.out_dim;
+    a.out_v = a.h > 0 ? PMT_SPLIT0 + a.h : a.out_dim;
     a.nmt = (a.out_v + 15) >> 4; a.nkt = (a.in_dim + 15) >> 4;
     const int per_side = a.nmt * a.nkt, ntask = SIDES * per_side;
     a.any[0] = a.any[1] = false;

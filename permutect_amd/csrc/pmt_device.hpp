@@ -22,6 +22,9 @@
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 #define PMT_NT (PMT_MAX_WIDTH / 16)  // feature tiles per activation: 4 (the wide build of the library: 8)
+#define PMT_HT (PMT_MAX_HALF_FFN / 16)  // tiles of ONE half of a gated block's hidden layer (z1 | z2): 1 (a build for d_ffn / 2 in 17 .. 32: 2)
+#define PMT_SPLIT0 (16 * PMT_HT)        // positions of the first half in proj1's virtual output (out_split): the second half starts here
+#define PMT_ZW (32 * PMT_HT)            // floats of a read set's per-block sums (z2 / d(gate)): [ref | alt][16 PMT_HT]
 #ifndef PMT_RT
 #define PMT_RT 2                 // read tiles per wave (a translation unit may choose its own wave shape)
 #endif
@@ -92,11 +95,16 @@ using ShapeAny = Shape<PMT_NT, PMT_NT, PMT_NT, PMT_NT, false>;   // any supporte
 #define PMT_SH_H 10
 #define PMT_SH_E 10
 #endif
+#ifdef PMT_GENERIC_ONLY
+#define PMT_GENERIC_ONLY_BUILD PMT_GENERIC_ONLY  // (a build without exact instances: the shape above is not used)
+#else
+#define PMT_GENERIC_ONLY_BUILD 0
+#endif
 #define PMT_SH_TILES PMT_SH_NTF, PMT_SH_NTR, PMT_SH_NTD, PMT_SH_NTE
 #define PMT_SH_DIMS PMT_SH_F, PMT_SH_R, PMT_SH_D, PMT_SH_H, PMT_SH_E
 static_assert(PMT_SH_F <= 16 * PMT_SH_NTF && PMT_SH_F > 16 * (PMT_SH_NTF - 1) && PMT_SH_R <= 16 * PMT_SH_NTR && PMT_SH_R > 16 * (PMT_SH_NTR - 1) &&
               PMT_SH_D <= 16 * PMT_SH_NTD && PMT_SH_D > 16 * (PMT_SH_NTD - 1) && PMT_SH_E <= 16 * PMT_SH_NTE && PMT_SH_E > 16 * (PMT_SH_NTE - 1) &&
-              PMT_SH_H >= 1 && PMT_SH_H <= 16, "SHAPE: the widths must fill exactly the tile counts given");
+              PMT_SH_H >= 1 && PMT_SH_H <= PMT_MAX_HALF_FFN && (PMT_SH_H > 16 * (PMT_HT - 1) || PMT_GENERIC_ONLY_BUILD), "SHAPE: the widths must fill exactly the tile counts given");
 #ifndef PMT_GENERIC_ONLY
 #define PMT_GENERIC_ONLY 0  // 1 (the WIDE build, csrc/Makefile): no exact instances -- every shape below is the generic one, pmt_shape_id is 0
 #endif
@@ -325,7 +333,7 @@ DEV f4 load_pvec(const float* __restrict__ p, int t, int g) { return *reinterpre
 // but padding are not issued (d_model 60: 15 of 16; d_ffn / 2 = 10: 3 of 4).
 template <int KDIM, int KSPLIT>
 DEV constexpr bool kstep_live(int kt, int j) {
-    return KSPLIT > 0 ? 4 * j < KSPLIT : (KDIM > 0 ? 16 * kt + 4 * j < KDIM : true);
+    return KSPLIT > 0 ? 16 * (kt % PMT_HT) + 4 * j < KSPLIT : (KDIM > 0 ? 16 * kt + 4 * j < KDIM : true);
 }
 template <int NTI, int NTO, bool SELU_IN, bool EXACT, int KDIM = 0, int KSPLIT = 0>
 DEV void linear_acc_impl(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], const float* __restrict__ frag, int in_dim,
@@ -553,8 +561,13 @@ DEV void split_pair_f16(float a, float b, unsigned& h, unsigned& l, float k4096)
             "v_fma_mix_f32 %1, %0, -1.0, %3 op_sel_hi:[1,0,0]\n\t"
             "v_fma_mix_f32 %2, %0, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
             : "=&v"(h), "=&v"(ra), "=&v"(rb) : "v"(a), "v"(b));
+        // (s_nop 1: the packed low pieces go straight into an MFMA as its B operand, and v_fma_mixhi_f16 -- a 16-bit write that keeps the
+        //  other half -- is not home when an MFMA issued right behind it reads the register: wrong low pieces, a 1e-4-relative
+        //  error, in ONE instance (filter forward, 7 + 2 x 2 tiles) until the wait states went in; the compiler does not look for
+        //  hazards behind inline asm.  One wait state was enough on the hardware; two are issued.)
         asm("v_fma_mixlo_f16 %0, %1, %3, 0\n\t"
-            "v_fma_mixhi_f16 %0, %2, %3, 0"
+            "v_fma_mixhi_f16 %0, %2, %3, 0\n\t"
+            "s_nop 1"
             : "=&v"(l) : "v"(ra), "v"(rb), "v"(k4096));
         return;
     }
@@ -563,6 +576,9 @@ DEV void split_pair_f16(float a, float b, unsigned& h, unsigned& l, float k4096)
     h = __builtin_bit_cast(unsigned, hh);
     l = __builtin_bit_cast(unsigned, ll);
 }
+#ifndef PMT_F16_K16_TAIL
+#define PMT_F16_K16_TAIL 0  // 1: the 16-deep MFMA for the half-filled last k block of 3, 5, 7 input tiles too (see linear_acc_f16)
+#endif
 #ifndef PMT_F16_AHEAD
 #define PMT_F16_AHEAD 0  // weight fragments of the next (out tile, k block) step requested one step ahead (8 more registers)
 #endif
@@ -628,7 +644,7 @@ DEV void linear_acc_f16(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], con
             // a k block with one tile only (NTI == 1): the 16-deep MFMA on the lower halves.  The half-filled LAST block of 3, 5 or 7 input
             // tiles (the wide build's shapes) takes the 32-deep one on its zero-padded operands instead: a 16-deep f16 MFMA chained
             // behind 32-deep ones on the same accumulator gave wrong sums (measured, scripts/wide_debug.py)
-            const bool half_block = NKB == 1 && 2 * kb + 1 >= NTI;
+            const bool half_block = (NKB == 1 || PMT_F16_K16_TAIL) && 2 * kb + 1 >= NTI;
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) {
                 if (half_block) {
@@ -907,9 +923,9 @@ DEV int pmt_join_ticket(const PmtJoin& j, int* lds_slot) {
 // of every set (the caller's next LDS barrier publishes them to the workgroup).
 DEV void pmt_join_sets(const PmtJoin& j, float* lds, float* glob, int set_stride, int* arrivals, int arr_stride, const int* expected, int nsets) {
     const int tid = pmt_tid();
-    for (int i = tid; i < nsets * 32; i += PMT_THREADS) {
+    for (int i = tid; i < nsets * PMT_ZW; i += PMT_THREADS) {
         const float v = lds[i];
-        if (v != 0.f) atomicAdd(&glob[(size_t)(i >> 5) * set_stride + (i & 31)], v);
+        if (v != 0.f) atomicAdd(&glob[(size_t)(i / PMT_ZW) * set_stride + (i % PMT_ZW)], v);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's atomics have been acknowledged ...
     __syncthreads();                                  // ... and every other wave's
@@ -929,9 +945,9 @@ DEV void pmt_join_sets(const PmtJoin& j, float* lds, float* glob, int set_stride
         }
     }
     __syncthreads();
-    for (int i = tid; i < nsets * 32; i += PMT_THREADS)
-        if (expected[i >> 5] > 1)
-            lds[i] = __hip_atomic_fetch_add(&glob[(size_t)(i >> 5) * set_stride + (i & 31)], 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = tid; i < nsets * PMT_ZW; i += PMT_THREADS)
+        if (expected[i / PMT_ZW] > 1)
+            lds[i] = __hip_atomic_fetch_add(&glob[(size_t)(i / PMT_ZW) * set_stride + (i % PMT_ZW)], 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- dropout in training (pmt_dropout.hpp: the mask is a function of (seed, linear, row, feature)) --------------------------
@@ -978,6 +994,6 @@ static inline int pmt_shape_for(const PmtModel* m, const PmtBatch* b, bool layer
 
 DEV int frag_floats_dev(const PmtLinear& L) {
     const int h = uniform(L.out_split);
-    const int out_v = h > 0 ? 16 + h : uniform(L.out_dim);
+    const int out_v = h > 0 ? PMT_SPLIT0 + h : uniform(L.out_dim);
     return ((out_v + 15) >> 4) * ((uniform(L.in_dim) + 15) >> 4) * 256;
 }

@@ -14,7 +14,7 @@
 #define PMT_F16_X1 1  // the first read-MLP linear on one-piece inputs (0: two pieces like every other layer; A/B switch)
 #endif
 struct FwdShared {  // (the float tables first: their rows are read and cleared 16 bytes at a time)
-    float zsum[3][PMT_GROUP_MAX_SETS][2][16];
+    float zsum[3][PMT_GROUP_MAX_SETS][2][16 * PMT_HT];
     float fsum[PMT_GROUP_MAX_SETS][2][PMT_MAX_WIDTH];
     float hsum[PMT_GROUP_MAX_SETS][PMT_MAX_CLUSTERS + 2];
     int off[2][PMT_GROUP_MAX_SETS + 1];
@@ -74,8 +74,8 @@ DEV float logerfc_dev(float z) {
 struct PmtLayeredArgs {
     int slice;
     float* x_scratch;   // [total_tiles][PMT_SLOT_FLOATS]
-    float* z_scratch;   // [total_tiles][512]: z1 (after SELU) and z2 (after SELU + LayerNorm)
-    float* zsum_g;      // [B][L][32] (the training stash's per-set z2 sums have the same layout and ARE this buffer)
+    float* z_scratch;   // [total_tiles][512 PMT_HT]: z1 (after SELU) and z2 (after SELU + LayerNorm)
+    float* zsum_g;      // [B][L][PMT_ZW] (the training stash's per-set z2 sums have the same layout and ARE this buffer)
     float* fsum_g;      // [B][2][PMT_MAX_WIDTH]
     float* hsum_g;      // [B][PMT_MAX_CLUSTERS + 2]
     PmtJoin join;       // join.on: ONE launch, all blocks, the groups of a split read set join their sums through HBM (pmt_device.hpp)
@@ -136,8 +136,8 @@ __global__ __launch_bounds__(PMT_THREADS, (S::EXACT && PMT_NT <= 4 && !(LAYERED 
     }
     {   // only the rows of the group's sets (typically a third of the capacity), 16 bytes per store
         const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
-        for (int i = tid; i < 3 * gg.nsets * 8; i += PMT_THREADS) {
-            const int b = i / (gg.nsets * 8), r = i - b * (gg.nsets * 8);
+        for (int i = tid; i < 3 * gg.nsets * (PMT_ZW / 4); i += PMT_THREADS) {
+            const int b = i / (gg.nsets * (PMT_ZW / 4)), r = i - b * (gg.nsets * (PMT_ZW / 4));
             reinterpret_cast<f4*>(&sh.zsum[b][0][0][0])[r] = zero;
         }
         for (int i = tid; i < gg.nsets * (2 * PMT_MAX_WIDTH / 4); i += PMT_THREADS) reinterpret_cast<f4*>(&sh.fsum[0][0][0])[i] = zero;
@@ -263,7 +263,8 @@ __global__ __launch_bounds__(PMT_THREADS, (S::EXACT && PMT_NT <= 4 && !(LAYERED 
         }
         const PmtBlock& B = M->blocks[l];
         const bool first_half = !LAYERED || joined || l == lay.slice;  // LayerNorm, proj1, SELU, per-set sums of z2
-        f4 z[PMT_RT][2];
+        constexpr int HT = PMT_HT;  // tiles per half of the hidden layer: z[..][0 .. HT) = z1, z[..][HT .. 2 HT) = z2
+        f4 z[PMT_RT][2 * HT];
         // packed region A of this block: [W1_ref | W1_alt | b1_ref | b1_alt | LN(D) w,b | LN(h) w,b | rho]
         const PmtLinear& P1r = M->lin[uniform(B.proj1[0])];
         const int baseA = uniform(P1r.w_frag);
@@ -291,99 +292,118 @@ __global__ __launch_bounds__(PMT_THREADS, (S::EXACT && PMT_NT <= 4 && !(LAYERED 
             }
             if (TRAIN) ++slot;
             const float* bp = stA + (uniform(M->lin[uniform(B.proj1[side])].b_pvec) - baseA);
-            const f4 b0 = load_pvec(bp, 0, g), b1 = load_pvec(bp, 1, g);
 #pragma unroll
-            for (int rt = 0; rt < PMT_RT; ++rt) { z[rt][0] = b0; z[rt][1] = b1; }
-            if constexpr (S::BF16) linear_acc_mx<NTD, 2, false, S::BF16>(z, n, packed, M->lin[uniform(B.proj1[side])]);
-            else linear_acc<NTD, 2, false, EX, S::DIM_D>(z, n, stA + side * frag_floats_dev(P1r), D, 16 + h);
+            for (int t = 0; t < 2 * HT; ++t) {
+                const f4 bt_ = load_pvec(bp, t, g);
+#pragma unroll
+                for (int rt = 0; rt < PMT_RT; ++rt) z[rt][t] = bt_;
+            }
+            if constexpr (S::BF16) linear_acc_mx<NTD, 2 * HT, false, S::BF16>(z, n, packed, M->lin[uniform(B.proj1[side])]);
+            else linear_acc<NTD, 2 * HT, false, EX, S::DIM_D>(z, n, stA + side * frag_floats_dev(P1r), D, PMT_SPLIT0 + h);
         // SELU, LayerNorm(h) on z2, per-set sums (reference gated_mlp.py:228-239)
-        f4 sw[1], sb[1];  // (loaded here, behind the first projection: eight registers less across it)
-        sw[0] = load_pvec(stA + (uniform(B.sgu_norm_w_pvec) - baseA), 0, g);
-        sb[0] = load_pvec(stA + (uniform(B.sgu_norm_b_pvec) - baseA), 0, g);
+        f4 sw[HT], sb[HT];  // (loaded here, behind the first projection: eight registers less across it)
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+            sw[t] = load_pvec(stA + (uniform(B.sgu_norm_w_pvec) - baseA), t, g);
+            sb[t] = load_pvec(stA + (uniform(B.sgu_norm_b_pvec) - baseA), t, g);
+        }
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt) {
-            z[rt][0] = selu4(z[rt][0]);
-            f4 zin[1] = {selu4(z[rt][1])}, zo[1], zh[1];
+            f4 zin[HT], zo[HT], zh[HT];
+#pragma unroll
+            for (int t = 0; t < HT; ++t) {
+                z[rt][t] = selu4(z[rt][t]);
+                zin[t] = selu4(z[rt][HT + t]);
+            }
             if (TRAIN && EX && PMT_STASH_Z && (mask_all & (1u << rt))) {  // the (exact-width) backward starts the block from these instead of recomputing them
-                const f4 zs[2] = {z[rt][0], zin[0]};
-                stash_store<2>(stash_tile[rt] + (size_t)(slot_z0 + l) * PMT_SLOT_FLOATS, zs);
+                f4 zs[2 * HT];
+#pragma unroll
+                for (int t = 0; t < HT; ++t) { zs[t] = z[rt][t]; zs[HT + t] = zin[t]; }
+                stash_store<2 * HT>(stash_tile[rt] + (size_t)(slot_z0 + l) * PMT_SLOT_FLOATS, zs);
             }
             float rstd;
-            layernorm_tile<1>(zo, zh, rstd, zin, h, sw, sb, g);
-            z[rt][1] = zo[0];
+            layernorm_tile<HT>(zo, zh, rstd, zin, h, sw, sb, g);
             {   // per-set sums of z2: segmented reduce over the tile's reads, one LDS add per set and value
                 const SegPlan sp = seg_plan(tmb[rt].valid ? tmb[rt].set : -1);
-                float* dst = &sh.zsum[buf][tmb[rt].set][side][4 * g];
-                const f4 s4 = seg_sum4<SEG_GUARD>(tmb[rt].valid ? z[rt][1] : f4{0.f, 0.f, 0.f, 0.f}, sp);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (sp.last && feat_of(0, j, g) < h) atomicAdd(dst + j, s4[j]);
+                for (int t = 0; t < HT; ++t) {
+                    z[rt][HT + t] = zo[t];
+                    float* dst = &sh.zsum[buf][tmb[rt].set][side][16 * t + 4 * g];
+                    const f4 s4 = seg_sum4<SEG_GUARD>(tmb[rt].valid ? zo[t] : f4{0.f, 0.f, 0.f, 0.f}, sp);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (sp.last && feat_of(t, j, g) < h) atomicAdd(dst + j, s4[j]);
+                }
             }
         }
         }
         if constexpr (LAYERED) {
             if (joined) {  // publish this group's part of the block's sums, wait for the other groups of its split sets, read the totals
                 lds_barrier();
-                pmt_join_sets(lay.join, &sh.zsum[buf][0][0][0], lay.zsum_g + ((size_t)gg.v0 * L + l) * 32, L * 32,
+                pmt_join_sets(lay.join, &sh.zsum[buf][0][0][0], lay.zsum_g + ((size_t)gg.v0 * L + l) * PMT_ZW, L * PMT_ZW,
                               lay.join.arrivals + (size_t)gg.v0 * L + l, L, bt.set_groups + gg.v0, gg.nsets);
             } else if (first_half) {  // end of this launch: the group's partial sums join the global ones; park x and z
                 lds_barrier();
-                for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS) {
+                for (int i = tid; i < gg.nsets * PMT_ZW; i += PMT_THREADS) {
                     const float v = (&sh.zsum[buf][0][0][0])[i];
-                    if (v != 0.f) atomicAdd(&lay.zsum_g[((size_t)(gg.v0 + (i >> 5)) * L + l) * 32 + (i & 31)], v);
+                    if (v != 0.f) atomicAdd(&lay.zsum_g[((size_t)(gg.v0 + (i / PMT_ZW)) * L + l) * PMT_ZW + (i % PMT_ZW)], v);
                 }
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
                     if (mask_all & (1u << rt)) {
                         stash_store<NTD>(lay.x_scratch + (tile_global + rt) * PMT_SLOT_FLOATS, x[rt]);
-                        stash_store<2>(lay.z_scratch + (tile_global + rt) * 512, z[rt]);
+                        stash_store<2 * HT>(lay.z_scratch + (tile_global + rt) * (512 * HT), z[rt]);
                     }
                 return;
             } else {
             // second half of block l = slice - 1: z from the previous launch, the COMPLETE per-set sums from HBM
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt) {
-                z[rt][0] = z[rt][1] = f4{0.f, 0.f, 0.f, 0.f};
-                if (mask_all & (1u << rt)) stash_load<2>(lay.z_scratch + (tile_global + rt) * 512, z[rt]);
+#pragma unroll
+                for (int t = 0; t < 2 * HT; ++t) z[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
+                if (mask_all & (1u << rt)) stash_load<2 * HT>(lay.z_scratch + (tile_global + rt) * (512 * HT), z[rt]);
             }
-            for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS)
-                (&sh.zsum[buf][0][0][0])[i] = lay.zsum_g[((size_t)(gg.v0 + (i >> 5)) * L + l) * 32 + (i & 31)];
+            for (int i = tid; i < gg.nsets * PMT_ZW; i += PMT_THREADS)
+                (&sh.zsum[buf][0][0][0])[i] = lay.zsum_g[((size_t)(gg.v0 + (i / PMT_ZW)) * L + l) * PMT_ZW + (i % PMT_ZW)];
             }
         }
         tr.ev(10);
         lds_barrier();
         tr.ev(11);
         if (TRAIN && !LAYERED) {
-            for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS)
-                zsum_stash[((size_t)(gg.v0 + (i >> 5)) * L + l) * 32 + (i & 31)] = (&sh.zsum[buf][0][0][0])[i];
+            for (int i = tid; i < gg.nsets * PMT_ZW; i += PMT_THREADS)
+                zsum_stash[((size_t)(gg.v0 + (i / PMT_ZW)) * L + l) * PMT_ZW + (i % PMT_ZW)] = (&sh.zsum[buf][0][0][0])[i];
         }
         {
             const int zb = (l + 2) % 3;
-            for (int i = tid; i < gg.nsets * 32; i += PMT_THREADS) (&sh.zsum[zb][0][0][0])[i] = 0.f;
+            for (int i = tid; i < gg.nsets * PMT_ZW; i += PMT_THREADS) (&sh.zsum[zb][0][0][0])[i] = 0.f;
         }
         // gate and second projection with the residual as the accumulator input
         {
             const float w = uniform(phi[uniform(B.reg_weight_phi)]) + 0.25f;
             const float alpha = uniform(theta[uniform(B.alpha_src[side])]), beta = uniform(theta[uniform(B.beta_src[side])]);
             const float gamma = uniform(theta[uniform(B.gamma_src)]);
-            const f4 rho = load_pvec(stA + (uniform(B.ref_reg_pvec) - baseA), 0, g);  // (loaded here, not at the top of the block: four registers less across its first half)
-            f4 u[PMT_RT][1];
+            f4 u[PMT_RT][HT];
 #pragma unroll
-            for (int rt = 0; rt < PMT_RT; ++rt) {
-                const int set = tmb[rt].set;
-                const float n_ref = (float)(sh.off[0][set + 1] - sh.off[0][set]);
-                const float n_alt = (float)(sh.off[1][set + 1] - sh.off[1][set]);
-                const f4 s_ref = *reinterpret_cast<const f4*>(&sh.zsum[buf][set][0][4 * g]);
-                const f4 m_ref = (s_ref + w * rho) * fast_rcp(n_ref + w);
-                f4 gate = z[rt][1] * alpha + 1.0f;
-                if (side == 0) {
-                    gate = gate + beta * m_ref;
-                } else {
-                    const f4 s_alt = *reinterpret_cast<const f4*>(&sh.zsum[buf][set][1][4 * g]);
-                    const f4 m_alt = s_alt * fast_rcp(n_alt + 1e-4f);
-                    gate = (gate + beta * m_alt) + gamma * m_ref;
+            for (int t = 0; t < HT; ++t) {
+                const f4 rho = load_pvec(stA + (uniform(B.ref_reg_pvec) - baseA), t, g);  // (loaded here, not at the top of the block: four registers less across its first half)
+#pragma unroll
+                for (int rt = 0; rt < PMT_RT; ++rt) {
+                    const int set = tmb[rt].set;
+                    const float n_ref = (float)(sh.off[0][set + 1] - sh.off[0][set]);
+                    const float n_alt = (float)(sh.off[1][set + 1] - sh.off[1][set]);
+                    const f4 s_ref = *reinterpret_cast<const f4*>(&sh.zsum[buf][set][0][16 * t + 4 * g]);
+                    const f4 m_ref = (s_ref + w * rho) * fast_rcp(n_ref + w);
+                    f4 gate = z[rt][HT + t] * alpha + 1.0f;
+                    if (side == 0) {
+                        gate = gate + beta * m_ref;
+                    } else {
+                        const f4 s_alt = *reinterpret_cast<const f4*>(&sh.zsum[buf][set][1][16 * t + 4 * g]);
+                        const f4 m_alt = s_alt * fast_rcp(n_alt + 1e-4f);
+                        gate = (gate + beta * m_alt) + gamma * m_ref;
+                    }
+                    u[rt][t] = z[rt][t] * gate;
                 }
-                u[rt][0] = z[rt][0] * gate;
             }
             const PmtLinear& P2r = M->lin[uniform(B.proj2[0])];
             const int baseB = uniform(P2r.w_frag);
@@ -395,8 +415,8 @@ __global__ __launch_bounds__(PMT_THREADS, (S::EXACT && PMT_NT <= 4 && !(LAYERED 
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt) x[rt][t] = x[rt][t] + b;
             }
-            if constexpr (S::BF16) linear_acc_mx<1, NTD, false, S::BF16>(x, u, packed, M->lin[uniform(B.proj2[side])]);
-            else linear_acc<1, NTD, false, EX, S::DIM_H>(x, u, p2_frags + side * frag_floats_dev(P2r), h, D);
+            if constexpr (S::BF16) linear_acc_mx<HT, NTD, false, S::BF16>(x, u, packed, M->lin[uniform(B.proj2[side])]);
+            else linear_acc<HT, NTD, false, EX, S::DIM_H>(x, u, p2_frags + side * frag_floats_dev(P2r), h, D);
         }
         tr.ev(12);
     }
@@ -687,7 +707,7 @@ extern "C" size_t pmt_layered_scratch_floats(const PmtModel* m, int64_t total_ti
     if (!m) return 0;
     const size_t nb = (size_t)(m->num_blocks > 0 ? m->num_blocks : 1);
     // parked activations (layered launches only) | per-set sums | joined execution: arrival counters [B][L], ticket, fault word
-    return (size_t)total_tiles * (PMT_SLOT_FLOATS + 512) + (size_t)num_variants * (nb * 32 + 2 * PMT_MAX_WIDTH + PMT_MAX_CLUSTERS + 2) +
+    return (size_t)total_tiles * (PMT_SLOT_FLOATS + 512 * PMT_HT) + (size_t)num_variants * (nb * PMT_ZW + 2 * PMT_MAX_WIDTH + PMT_MAX_CLUSTERS + 2) +
            (size_t)num_variants * nb + 8;
 }
 
@@ -709,17 +729,17 @@ extern "C" int pmt_forward_layered(const PmtModel* model_host, const PmtModel* m
     PmtLayeredArgs lay;
     lay.x_scratch = scratch;
     lay.z_scratch = lay.x_scratch + (size_t)batch->total_tiles * PMT_SLOT_FLOATS;
-    float* sums = lay.z_scratch + (size_t)batch->total_tiles * 512;
+    float* sums = lay.z_scratch + (size_t)batch->total_tiles * (512 * PMT_HT);
     float* zsum_stash = nullptr;
     float* rstd_stash = nullptr;
     if (stash) {
         zsum_stash = stash + (size_t)batch->total_tiles * (size_t)pmt_stash_slots(model_host) * PMT_SLOT_FLOATS;
-        rstd_stash = zsum_stash + B * nb * 32;
+        rstd_stash = zsum_stash + B * nb * PMT_ZW;
     }
     lay.zsum_g = stash ? zsum_stash : sums;  // training: the stash's per-set sums ARE the global sums
-    lay.fsum_g = sums + B * nb * 32;
+    lay.fsum_g = sums + B * nb * PMT_ZW;
     lay.hsum_g = lay.fsum_g + B * 2 * PMT_MAX_WIDTH;
-    if (hipMemsetAsync(lay.zsum_g, 0, B * nb * 32 * sizeof(float), s) != hipSuccess) return PMT_E_LAUNCH;
+    if (hipMemsetAsync(lay.zsum_g, 0, B * nb * PMT_ZW * sizeof(float), s) != hipSuccess) return PMT_E_LAUNCH;
     if (hipMemsetAsync(lay.fsum_g, 0, B * (2 * PMT_MAX_WIDTH + PMT_MAX_CLUSTERS + 2) * sizeof(float), s) != hipSuccess) return PMT_E_LAUNCH;
     auto kernel = stash ? (p0 ? pmt_forward_kernel<true, ShapeP0, true> : pmt_forward_kernel<true, ShapeAny, true>)
                         : (p0 ? pmt_forward_kernel<false, ShapeP0, true> : pmt_forward_kernel<false, ShapeAny, true>);
@@ -768,7 +788,7 @@ extern "C" int pmt_forward(const PmtModel* model_host, const PmtModel* model_dev
         if (!batch->group_tile_base || batch->total_tiles <= 0) return PMT_E_INVALID;
         // per-set z2 sums follow the per-tile activation slots (layout: pmt_stash_bytes)
         zsum_stash = stash + (size_t)batch->total_tiles * (size_t)pmt_stash_slots(model_host) * PMT_SLOT_FLOATS;
-        rstd_stash = zsum_stash + (size_t)batch->num_variants * (size_t)(model_host->num_blocks > 0 ? model_host->num_blocks : 1) * 32;
+        rstd_stash = zsum_stash + (size_t)batch->num_variants * (size_t)(model_host->num_blocks > 0 ? model_host->num_blocks : 1) * PMT_ZW;
     }
     auto kernel = stash ? (p0 ? pmt_forward_kernel<true, ShapeP0> : pmt_forward_kernel<true, ShapeAny>)
                         : (p0 ? pmt_forward_kernel<false, ShapeP0> : pmt_forward_kernel<false, ShapeAny>);

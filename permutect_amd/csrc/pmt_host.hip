@@ -145,6 +145,7 @@ extern "C" int pmt_model_check(const PmtModel* m) {
     if (m->num_read_features < 1 || m->num_read_features > PMT_MAX_WIDTH) return PMT_E_UNSUPPORTED;
     if (m->d_model != m->read_embed_dim + m->variant_embed_dim || m->d_model > PMT_MAX_WIDTH) return PMT_E_UNSUPPORTED;
     if (m->d_ffn < 2 || (m->d_ffn & 1) || m->d_ffn / 2 > PMT_MAX_HALF_FFN) return PMT_E_UNSUPPORTED;
+    if (m->num_blocks > 0 && (m->d_ffn / 2 + 15) / 16 != PMT_HT) return PMT_E_UNSUPPORTED;  // (the two-tile layout of a PMT_MAX_HALF_FFN = 32 build is not the one-tile model's)
     if (m->num_blocks < 0 || m->num_blocks > PMT_MAX_BLOCKS) return PMT_E_UNSUPPORTED;
     if (m->feature_dim < 2 || m->feature_dim > PMT_MAX_WIDTH) return PMT_E_UNSUPPORTED;
     if (m->num_clusters < 1 || m->num_clusters > PMT_MAX_CLUSTERS) return PMT_E_UNSUPPORTED;
@@ -497,7 +498,7 @@ extern "C" size_t pmt_stash_bytes(const PmtModel* m, int64_t total_tiles, int32_
     if (!m) return 0;
     const size_t tile_part = (size_t)total_tiles * (size_t)pmt_stash_slots(m) * PMT_SLOT_FLOATS;
     const size_t nb = (size_t)(m->num_blocks > 0 ? m->num_blocks : 1);
-    const size_t zsum_part = (size_t)num_variants * nb * 32;   // per-set z2 sums of every block
+    const size_t zsum_part = (size_t)num_variants * nb * PMT_ZW;   // per-set z2 sums of every block
     const size_t rstd_part = (size_t)total_tiles * nb * 16;    // LayerNorm(D) rstd of every read of every block
     return (tile_part + zsum_part + rstd_part) * sizeof(float);
 }
@@ -508,8 +509,8 @@ extern "C" size_t pmt_stash_bytes(const PmtModel* m, int64_t total_tiles, int32_
 // virtual row -> source row for a linear whose output rows are split into two 16-row tiles (out_split = h)
 DEV int split_row(int v, int h) {
     if (h <= 0) return v;
-    if (v < 16) return v < h ? v : -1;
-    return (v - 16) < h ? h + (v - 16) : -1;
+    if (v < PMT_SPLIT0) return v < h ? v : -1;
+    return (v - PMT_SPLIT0) < h ? h + (v - PMT_SPLIT0) : -1;
 }
 
 // one job per workgroup: (lin, 0) forward frags, (lin, 1) transposed frags, (lin, 2) bias, (lin, 3 / 4) the same two matrices
@@ -523,7 +524,7 @@ __global__ void pmt_pack_kernel(const PmtModel* __restrict__ M, const float* __r
         const PmtLinear& L = M->lin[job / PMT_PACK_KINDS];
         const int kind = job % PMT_PACK_KINDS;
         const int h = L.out_split;
-        const int out_v = h > 0 ? 16 + h : L.out_dim;  // virtual output rows
+        const int out_v = h > 0 ? PMT_SPLIT0 + h : L.out_dim;  // virtual output rows
         if (kind == 5) {
             // PmtLinear.emit_tab: destination of every element of every 16 x 16 block of dW as the matrix core leaves it
             // (C layout: lane (g, c) register j = row position 4 g + j, column position c; position p of a tile = feature

@@ -95,36 +95,44 @@ def widest_layer(desc: L.PmtModel) -> int:
 
 
 WIDE_LIB = os.path.join(_HERE, "libpermutect_amd_wide.so")
+WIDE32_LIB = os.path.join(_HERE, "libpermutect_amd_wide32.so")  # the same with two tiles per half of a gated block's hidden layer (d_ffn / 2 in 17 .. 32)
 
 
-def wide_library(log=print) -> C.CDLL:
-    """The WIDE build (activations up to 128 features, generic instances only), built once with `make wide` when it is missing"""
-    if not os.path.exists(WIDE_LIB):
+def half_tiles(desc: L.PmtModel) -> int:
+    """tiles of one half of the gated blocks' hidden layer: 1, or 2 for d_ffn / 2 in 17 .. 32 (pmt_device.hpp: PMT_HT of the build that runs it)"""
+    return 2 if desc.num_blocks > 0 and desc.d_ffn // 2 > 16 else 1
+
+
+def wide_library(log=print, half32: bool = False) -> C.CDLL:
+    """The WIDE build (activations up to 128 features, generic instances only; `half32`: with two-tile gate halves), built once with
+    `make wide` / `make wide32` when it is missing"""
+    path, target = (WIDE32_LIB, "wide32") if half32 else (WIDE_LIB, "wide")
+    if not os.path.exists(path):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         if os.environ.get("PMT_JIT", "1") == "0" or not (os.path.exists(hipcc) or shutil.which("hipcc")) or not shutil.which("make"):
-            raise L.PmtError(f"a layer of this model is wider than {L.MAX_WIDTH}: it needs the wide build of the library, "
-                             "`make -C permutect_amd/csrc wide` (not built here, and PMT_JIT=0 or no hipcc / make to build it now)")
-        log("permutect_amd: building the wide library (layers up to 128 features; once, ~3 minutes) ...")
-        res = subprocess.run(["make", "-C", CSRC, f"-j{min(8, os.cpu_count() or 1)}", "wide"], capture_output=True, text=True)
-        if res.returncode != 0 or not os.path.exists(WIDE_LIB):
-            raise L.PmtError("building the wide library failed:\n" + res.stderr[-2000:])
-    return L.load(WIDE_LIB)
+            raise L.PmtError(f"this model (a layer wider than {L.MAX_WIDTH}, or d_ffn / 2 beyond {L.MAX_HALF_FFN}) needs the {target} build of the "
+                             f"library, `make -C permutect_amd/csrc {target}` (not built here, and PMT_JIT=0 or no hipcc / make to build it now)")
+        log(f"permutect_amd: building the {target} library (once, ~3 minutes) ...")
+        res = subprocess.run(["make", "-C", CSRC, f"-j{min(8, os.cpu_count() or 1)}", target], capture_output=True, text=True)
+        if res.returncode != 0 or not os.path.exists(path):
+            raise L.PmtError(f"building the {target} library failed:\n" + res.stderr[-2000:])
+    return L.load(path)
 
 
 def library_for(desc: L.PmtModel, log=print) -> C.CDLL:
     default = L.load()
     if "PMT_LIB" in os.environ:  # a development build named explicitly: use it as it is
         return default
-    widest = widest_layer(desc)
-    wide = widest > L.limits_of(default)["max_width"]
+    widest, ht = widest_layer(desc), half_tiles(desc)
+    wide = widest > L.limits_of(default)["max_width"] or ht > 1  # (beyond the default build's compile-time limits)
 
     def generic():
         if not wide:
             return default
-        warnings.warn(f"permutect_amd: a layer of this model is wider than {L.limits_of(default)['max_width']} features and there are no exact "
-                      "instances for its shape: it runs the WIDE build of the library, GENERIC instances (fp32 MFMAs, 8-tile register "
-                      "arrays with spills: several times slower per read than exact-width kernels)")
-        return wide_library(log)
+        warnings.warn(f"permutect_amd: this model (a layer wider than {L.limits_of(default)['max_width']} features, or d_ffn / 2 beyond "
+                      f"{L.limits_of(default)['max_half_ffn']}) has no exact instances for its shape: it runs the WIDE build of the library, GENERIC "
+                      "instances (fp32 MFMAs, 8-tile register arrays with spills: several times slower per read than exact-width kernels)")
+        return wide_library(log, half32=ht > 1)
     if desc.force_shape == 2 or (not wide and default.pmt_shape_id(C.byref(desc)) != 0):
         return generic()
     shape = exact_shape_of(desc)
@@ -136,7 +144,8 @@ def library_for(desc: L.PmtModel, log=print) -> C.CDLL:
     exact = os.path.join(INSTANCE_DIR, f"libpermutect_amd_{_tag(shape)}.so")
     candidates = ([exact] if os.path.exists(exact) else []) + sorted(glob.glob(os.path.join(INSTANCE_DIR, f"libpermutect_amd_{_tag(shape[:4])}_*.so")))
     def fits(lib):
-        return L.limits_of(lib)["max_width"] >= widest and lib.pmt_shape_id(C.byref(desc)) != 0
+        lim = L.limits_of(lib)
+        return lim["max_width"] >= widest and lim["max_half_ffn"] // 16 == ht and lib.pmt_shape_id(C.byref(desc)) != 0
     for path in candidates:
         lib = L.load(path)
         if fits(lib):

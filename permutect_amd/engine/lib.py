@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("PMT_LIB", os.path.join(_HERE, "libpermutect_amd.so"))
 # ---- limits (must match the header) -------------------------------------------------------------------------------
 ABI_VERSION = 9
 MAX_WIDTH, MAX_HALF_FFN, MAX_CLUSTERS = 64, 16, 16
+MAX_HALF_FFN_WIDE = 32  # d_ffn / 2 of the wide32 build (two tiles per half of a gated block's hidden layer)
 MAX_WIDTH_WIDE = 128  # the wide build of the library (csrc/Makefile: `make wide`; engine/instances.py loads it for wider layers)
 MAX_ROW_INPUT = 128
 MAX_CNN_TAPS = 192

@@ -24,6 +24,12 @@ from permutect_amd.architecture import modules as M
 from permutect_amd.engine import lib as L
 
 
+def _split0(h: int) -> int:
+    """positions of the FIRST half in the virtual output of a gated block's first projection (PmtLinear.out_split = h = d_ffn / 2): one
+    16-feature tile, two for h in 17 .. 32 (pmt_device.hpp: PMT_SPLIT0 of the build that runs such a model, PMT_MAX_HALF_FFN = 32)"""
+    return 16 * ((h + 15) // 16)
+
+
 def _ceil16(n: int) -> int:
     return (n + 15) // 16 * 16
 
@@ -168,7 +174,7 @@ class EnginePlan:
         # 16-row tile, piece), one more fragment of slack behind each range
         for i in range(self._n_lin):
             lin = d.lin[i]
-            out_v = 16 + lin.out_split if lin.out_split else lin.out_dim
+            out_v = _split0(lin.out_split) + lin.out_split if lin.out_split else lin.out_dim
             nmt, nkt = (out_v + 15) // 16, (lin.in_dim + 15) // 16
             lin.wb_frag = self._alloc_packed(nmt * ((nkt + 1) // 2) * 3 * 256 + 256)
             lin.wtb_frag = self._alloc_packed(nkt * ((nmt + 1) // 2) * 3 * 256 + 256)
@@ -183,7 +189,7 @@ class EnginePlan:
             lin.emit_tab = -1
             if i >= n_readset_lin and i != d.rotation_lin:
                 continue
-            out_v = 16 + lin.out_split if lin.out_split > 0 else lin.out_dim
+            out_v = _split0(lin.out_split) + lin.out_split if lin.out_split > 0 else lin.out_dim
             nmt, nkt = (out_v + 15) // 16, (lin.in_dim + 15) // 16
             lin.emit_tab = self._alloc_packed(nmt * nkt * 256 + nmt * 16)
         d.emit_len = self._packed_off - d.emit_base
@@ -237,7 +243,7 @@ class EnginePlan:
         if in_dim > max_in or out_dim > L.MAX_WIDTH_WIDE:  # (beyond 64: the wide build of the library, engine/instances.py)
             raise L.PmtError(f"layer width {in_dim}->{out_dim} exceeds the register-resident limit {L.MAX_WIDTH_WIDE}")
         lin = self.desc.lin[self._n_lin]
-        out_v = 16 + out_split if out_split else out_dim
+        out_v = _split0(out_split) + out_split if out_split else out_dim
         nmt, nkt = (out_v + 15) // 16, (in_dim + 15) // 16
         lin.in_dim, lin.out_dim, lin.out_split = in_dim, out_dim, out_split
         if alloc:
@@ -259,7 +265,7 @@ class EnginePlan:
             ids.append(self._add_raw_linear(layer.in_features, layer.out_features, self.space.offset_of(layer.weight),
                                             self.space.offset_of(layer.bias), True, out_split, alloc=False))
         lr, la = self.desc.lin[ids[0]], self.desc.lin[ids[1]]
-        out_v = 16 + out_split if out_split else lr.out_dim
+        out_v = _split0(out_split) + out_split if out_split else lr.out_dim
         nfl = ((out_v + 15) // 16) * ((lr.in_dim + 15) // 16) * 256
         nb = ((out_v + 15) // 16) * 16
         self._packed_off = (self._packed_off + 255) // 256 * 256

@@ -153,6 +153,13 @@ def wide_params() -> ModelParameters:
     return ModelParameters([48, -2], 32, 2, [40, -1], [-1, 20], 4, [10, 10], list(P0_CNN), 0.0, 0.3)
 
 
+def wide64_params() -> ModelParameters:
+    """wide_params with d_ffn = 64: the gated blocks' hidden halves take two 16-feature tiles (the wide32 build of the library)"""
+    p = wide_params()
+    p.self_attention_hidden_dimension = 64
+    return p
+
+
 P0_DIMS = dict(num_read_features=61, num_info_features=71, haplotypes_length=42)
 
 

@@ -11,14 +11,17 @@ from permutect_amd.parameters import P0_DIMS, P0_CNN, ModelParameters
 dev = torch.device("cuda:0")
 ints, floats, packed = synth_arrays(np.random.default_rng(0), 256, "wgs")
 batch = Batch.from_arrays(ints, floats, packed).copy_to(dev)
+DFFN = int(os.environ.get("DFFN", 32))
 CASES = {
-    "full": ([48, -2], 32, 2, [40, -1], [-1, 20]),
+    "p0h24": ([30, -2, -2, -2], 48, 6, [20, -2, -2, -2], [-2, -2, 10]),
+    "p0h24 no skips 2 blocks": ([30], 48, 2, [20], [10]),
+    "full": ([48, -2], DFFN, 2, [40, -1], [-1, 20]),
     "no blocks": ([48, -2], 32, 0, [40, -1], [-1, 20]),
-    "no skips": ([48], 32, 2, [40], [20]),
+    "no skips": ([48], DFFN, 2, [40], [20]),
     "no skips no blocks": ([48], 32, 0, [40], [20]),
     "read skip only": ([48, -2], 32, 0, [40], [20]),
     "reducer skip only": ([48], 32, 0, [40], [-1, 20]),
-    "blocks only": ([48], 32, 1, [40], [20]),
+    "blocks only": ([48], DFFN, 1, [40], [20]),
 }
 for name, (rl, dffn, nb, il, al) in CASES.items():
     res = {}

@@ -14,6 +14,12 @@ which = sys.argv[1] if len(sys.argv) > 1 else "wide"
 if which == "wide":
     params = ModelParameters([48, -2], 32, 2, [40, -1], [-1, 20], 4, [10, 10], list(P0_CNN), 0.0, 0.3)
     cfg = O.Config([48, -2], [40, -1], [-1, 20], 32, 2, 4, list(P0_CNN), 61, 71, 42)
+elif which == "wide64":
+    params = ModelParameters([48, -2], 64, 2, [40, -1], [-1, 20], 4, [10, 10], list(P0_CNN), 0.0, 0.3)
+    cfg = O.Config([48, -2], [40, -1], [-1, 20], 64, 2, 4, list(P0_CNN), 61, 71, 42)
+elif which == "p0h24":
+    params = ModelParameters([30, -2, -2, -2], 48, 6, [20, -2, -2, -2], [-2, -2, 10], 4, [10, 10], list(P0_CNN), 0.0, 0.3)
+    cfg = O.Config([30, -2, -2, -2], [20, -2, -2, -2], [-2, -2, 10], 48, 6, 4, list(P0_CNN), 61, 71, 42)
 else:
     params = ModelParameters([30, -2, -2, -2], 20, 6, [20, -2, -2, -2], [-2, -2, 10], 4, [10, 10], list(P0_CNN), 0.0, 0.3)
     cfg = O.Config([30, -2, -2, -2], [20, -2, -2, -2], [-2, -2, 10], 20, 6, 4, list(P0_CNN), 61, 71, 42)
@@ -23,7 +29,7 @@ with torch.no_grad():
     for q in model.parameters():
         q.add_(0.05 * torch.randn_like(q))
 sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-nref2, nalt2 = np.array([5, 330, 2, 40]), np.array([3, 280, 9, 600])
+nref2, nalt2 = (np.array([5, 330, 2, 40]), np.array([3, 280, 9, 600])) if os.environ.get('DEEP', '1') == '1' else (np.array([5, 33, 2, 40, 0, 7]), np.array([3, 28, 9, 60, 4, 1]))
 ints2, floats2, packed2 = _arrays(nref2, nalt2, seed=81)
 batch2 = Batch.from_arrays(ints2, floats2, packed2).copy_to(dev)
 model.train(True)

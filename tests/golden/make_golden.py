@@ -51,8 +51,8 @@ def make_model(kind, seed, perturb=0.05, num_sources=1, cnn=None):
     torch.manual_seed(seed)
     if kind == "T0":
         p = ModelParameters([10, 10, 10], 20, 2, [10, 10], [20, 20, 20], 4, [10, 10, 10], list(cnn or T0_CNN), 0.0, 0.3, False)
-    elif kind == "WIDE":  # layers beyond 64: read width 48, info width 40 -> d_model 98, a 98-wide reducer, d_ffn 32, feature_dim 20
-        p = ModelParameters([48, -2], 32, 2, [40, -1], [-1, 20], 4, [10, 10], list(cnn or P0_CNN), 0.0, 0.3, False)
+    elif kind in ("WIDE", "WIDE64"):  # layers beyond 64: read width 48, info width 40 -> d_model 98, a 98-wide reducer, d_ffn 32 (64), feature_dim 20
+        p = ModelParameters([48, -2], 64 if kind == "WIDE64" else 32, 2, [40, -1], [-1, 20], 4, [10, 10], list(cnn or P0_CNN), 0.0, 0.3, False)
     else:
         p = ModelParameters([30, -2, -2, -2], 20, 6, [20, -2, -2, -2], [-2, -2, 10], 4, [10, 10], list(cnn or P0_CNN), 0.0, 0.3, False)
     m = ArtifactModel(p, 61, 71, 42, device=CPU)
@@ -527,6 +527,10 @@ def make_wide_fixture():
     random.seed(98)
     counts = [(int(rng.integers(0, 11)), int(rng.integers(1, 16))) for _ in range(10)] + [(40, 37), (0, 21)]
     run_case("wide_d98", make_model("WIDE", 98), make_data(rng, counts))
+    if "--wide-only" in sys.argv and "--no-wide64" in sys.argv:
+        return
+    counts = [(int(rng.integers(0, 11)), int(rng.integers(1, 16))) for _ in range(10)] + [(33, 41), (0, 18)]
+    run_case("wide64_d98", make_model("WIDE64", 99), make_data(rng, counts))
 
 
 if __name__ == "__main__":

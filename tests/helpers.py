@@ -8,22 +8,23 @@ from oracle import artifact_oracle as O
 from permutect_amd.parameters import P0_CNN, P0_CNN_BATCHNORM, P0_CNN_LEGACY, T0_CNN, T0_CNN_OPTIONS
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["t0_b8", "p0_b16", "p0_zero_ref", "p0_saturated", "p0_deep", "t0_two_sources", "wide_d98"]  # wide_d98: layers beyond 64 (the wide build of the library)
+CASES = ["t0_b8", "p0_b16", "p0_zero_ref", "p0_saturated", "p0_deep", "t0_two_sources", "wide_d98", "wide64_d98"]
+# wide_d98: layers beyond 64 (the wide builds of the library); wide64_d98: the same with d_ffn = 64 (two tiles per half of the gated blocks' hidden layer)
 CNN_CASES = ["p0_cnn_legacy", "t0_cnn_options"]  # haplotype-CNN stacks beyond the two of CASES (tests/golden/make_golden.py: make_cnn_fixtures)
 CNN_STACKS = {"p0_cnn_legacy": P0_CNN_LEGACY, "t0_cnn_options": T0_CNN_OPTIONS, "p0_cnn_batchnorm_eval": P0_CNN_BATCHNORM}
 
 
 def params_for(name: str):
     """the model hyperparameters of a fixture (tests/golden/make_golden.py: make_model)"""
-    from permutect_amd.parameters import p0_params, t0_params, wide_params
-    return t0_params() if name.startswith("t0") else wide_params() if name.startswith("wide") else p0_params()
+    from permutect_amd.parameters import p0_params, t0_params, wide64_params, wide_params
+    return t0_params() if name.startswith("t0") else wide64_params() if name.startswith("wide64") else wide_params() if name.startswith("wide") else p0_params()
 
 
 def config_for(name: str) -> O.Config:
     if name.startswith("t0"):
         cfg = O.Config([10, 10, 10], [10, 10], [20, 20, 20], 20, 2, 4, list(T0_CNN), 61, 71, 42)
     elif name.startswith("wide"):
-        cfg = O.Config([48, -2], [40, -1], [-1, 20], 32, 2, 4, list(P0_CNN), 61, 71, 42)
+        cfg = O.Config([48, -2], [40, -1], [-1, 20], 64 if name.startswith("wide64") else 32, 2, 4, list(P0_CNN), 61, 71, 42)
     else:
         cfg = O.Config([30, -2, -2, -2], [20, -2, -2, -2], [-2, -2, 10], 20, 6, 4, list(P0_CNN), 61, 71, 42)
     if name == "t0_two_sources":

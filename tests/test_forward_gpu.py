@@ -546,3 +546,68 @@ def test_a_model_wider_than_64_runs_the_wide_build_and_matches_the_oracle(monkey
     gour2 = np.concatenate([p.grad.detach().cpu().numpy().ravel().astype(np.float64) for _, p in model.named_parameters()])
     hip64, o32_64 = np.linalg.norm(gour2 - g64) / np.linalg.norm(g64), np.linalg.norm(g32 - g64) / np.linalg.norm(g64)
     assert np.all(np.isfinite(gour2)) and hip64 <= max(2e-5, 1.5 * o32_64), (hip64, o32_64)
+
+
+def test_a_model_with_d_ffn_beyond_32_runs_two_tile_gate_halves_and_matches_the_oracle(monkeypatch):
+    """d_ffn / 2 in 17 .. 32 (refused until round 4): the gated blocks' hidden halves take TWO 16-feature tiles (PMT_MAX_HALF_FFN = 32 builds
+    of the library).  The production widths with d_ffn 48 run the exact instances built around that shape (`make instances`: f16 forward,
+    bf16 backward, or what PMT_SHAPE asks for); forward, losses and every gradient against the oracle, on ordinary read sets and on sets
+    split over workgroups.  (wide64_d98, the reference fixture with d_ffn 64 and 98-wide layers, runs through the fixture tests.)"""
+    import os
+    from permutect_amd.engine import lib as L
+    from permutect_amd.parameters import ModelParameters, P0_CNN
+    from permutect_amd.training.optimizer import FusedClipAdamW
+    if "PMT_LIB" in os.environ:
+        pytest.skip("the library's own choice is what is tested")
+    forced = os.environ.get("PMT_SHAPE", "")
+    params = ModelParameters([30, -2, -2, -2], 48, 6, [20, -2, -2, -2], [-2, -2, 10], 4, [10, 10], list(P0_CNN), 0.0, 0.3)
+    cfg = O.Config([30, -2, -2, -2], [20, -2, -2, -2], [-2, -2, 10], 48, 6, 4, list(P0_CNN), 61, 71, 42)
+    dev = torch.device("cuda")
+    torch.manual_seed(8)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = ArtifactModel(params, device=dev, **P0_DIMS)
+        with torch.no_grad():
+            for q in model.parameters():
+                q.add_(0.05 * torch.randn_like(q))
+        eng = model.engine()
+    assert L.limits_of(eng.lib)["max_half_ffn"] == 32 and eng.plan.desc.d_ffn == 48
+    if forced == "any":
+        assert eng.shape_id == 0
+    else:
+        assert L.shape_of(eng.lib) == (4, 2, 4, 1, 61, 30, 60, 24, 10) and eng.shape_id == (1 if forced == "tile" else 2)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    names = [n for n, _ in model.named_parameters()]
+    opt = FusedClipAdamW(model, lr=1e-3, weight_decay=0.01)
+    rng = np.random.default_rng(83)
+    for which, (nref, nalt) in enumerate(((rng.integers(0, 11, 150), rng.integers(1, 16, 150)), (np.array([4, 310, 1, 25]), np.array([2, 270, 11, 520])))):
+        ints, floats, packed = _arrays(nref, nalt, seed=84 + which)
+        batch = Batch.from_arrays(ints, floats, packed).copy_to(dev)
+        model.train(True)
+        out = model.compute_batch_output(batch)
+        losses = model.compute_batch_losses(out, batch)
+        opt.zero_grad()
+        losses.total_loss.backward()
+        torch.cuda.synchronize()
+        eng.check_join_fault()
+        i64 = torch.from_numpy(ints.astype(np.int64))
+        ob = dict(reads_re=torch.from_numpy(O.decode_packed_reads(packed).astype(np.float32)), nref=i64[:, O.REF_COUNT], nalt=i64[:, O.ALT_COUNT],
+                  labels=i64[:, O.LABEL], sources=i64[:, O.SOURCE], info_be=torch.from_numpy(floats[:, O.INFO_START:].astype(np.float32)),
+                  haplotypes_bh=i64[:, O.HAPLOTYPES_START:])
+        ref_out, ref_losses, ref_grads = O.train_step_grads(sd, cfg, ob)
+        check_outputs(out, {"out/" + k: v.detach().numpy() for k, v in ref_out.items()}, "p0_d_ffn_48" + ("_split_sets" if which else ""), lk_ulps=32 if which else 8)
+        try:  # the yardstick for the gradients: an fp64 evaluation, the bound what the reference's fp32 arithmetic reaches (deep sets: see the wide test)
+            O.COMPUTE_DTYPE = torch.float64
+            _, _, g64d = O.train_step_grads({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, cfg, ob)
+        finally:
+            O.COMPUTE_DTYPE = torch.float32
+        g64 = np.concatenate([g64d[n].numpy().ravel() for n in names])
+        g32 = np.concatenate([ref_grads[n].numpy().ravel().astype(np.float64) for n in names])
+        ours = np.concatenate([p.grad.detach().cpu().numpy().ravel().astype(np.float64) for _, p in model.named_parameters()])
+        hip64, o32_64 = np.linalg.norm(ours - g64) / np.linalg.norm(g64), np.linalg.norm(g32 - g64) / np.linalg.norm(g64)
+        assert np.all(np.isfinite(ours)) and hip64 <= max(2e-5, 1.5 * o32_64), (which, hip64, o32_64)
+        model.train(False)
+        with torch.no_grad():
+            out_eval = model.compute_batch_output(batch)
+        check_outputs(out_eval, {"out/" + k: v.detach().numpy() for k, v in ref_out.items()}, "p0_d_ffn_48_eval", lk_ulps=32 if which else 8)

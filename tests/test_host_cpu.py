@@ -367,6 +367,22 @@ def test_kernel_instances_are_chosen_by_the_models_tile_shape(monkeypatch):
             wide = I.library_for(wd)
         assert L.limits_of(wide) == {"max_width": 128, "max_half_ffn": 16, "slot_floats": 2048, "group_waves": 8}
         assert wide is not lib and wide.pmt_shape_id(C.byref(wd)) == 0 and wide.pmt_model_check(C.byref(wd)) == 0
+    # d_ffn / 2 beyond 16: builds with two 16-feature tiles per half of the gated blocks' hidden layer (pmt_limits: max_half_ffn 32) -- the
+    # exact instances around the production widths with d_ffn 48 (make instances), the wide32 build for everything else
+    half = p0_params()
+    half.self_attention_hidden_dimension = 48
+    p0h_lib = os.path.join(I.INSTANCE_DIR, "libpermutect_amd_4_2_4_1_61_30_60_24_10.so")
+    if os.path.exists(p0h_lib) and os.path.exists(I.WIDE32_LIB):
+        hd = desc_of(half)
+        assert I.half_tiles(hd) == 2 and I.exact_shape_of(hd) == (4, 2, 4, 1, 61, 30, 60, 24, 10) and default.pmt_model_check(C.byref(hd)) == L.E_UNSUPPORTED
+        lib = I.library_for(hd)
+        assert L.limits_of(lib) == {"max_width": 64, "max_half_ffn": 32, "slot_floats": 1024, "group_waves": 8} and lib.pmt_shape_id(C.byref(hd)) == 2
+        from permutect_amd.parameters import wide64_params
+        with pytest.warns(UserWarning, match="WIDE build"):  # (no exact instances prebuilt for this shape, and PMT_JIT = 0 here)
+            w64 = desc_of(wide64_params())
+            lib64 = I.library_for(w64)
+        assert L.limits_of(lib64)["max_half_ffn"] == 32 and L.limits_of(lib64)["max_width"] == 128 and lib64.pmt_shape_id(C.byref(w64)) == 0
+        assert I.wide_library().pmt_model_check(C.byref(w64)) == L.E_UNSUPPORTED  # (the one-tile wide build does not take it)
     too_wide = wide_params()
     too_wide.read_layers = [130]
     with pytest.raises(L.PmtError, match="exceeds"):
