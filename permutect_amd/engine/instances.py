@@ -64,6 +64,23 @@ def exact_shape_of(desc: L.PmtModel) -> Optional[Tuple[int, ...]]:
     return (ntf, ntr, ntd, nte, desc.num_read_features, lf.out_dim, desc.d_model, desc.d_ffn // 2, desc.feature_dim)
 
 
+class _BuildLock:
+    """One build at a time per tree (the ranks of a data-parallel job lower the same model at the same moment: they would all run `make` in
+    the same object directory).  An advisory lock on a file next to the sources; whoever gets it second finds the library built."""
+
+    def __enter__(self):
+        import fcntl
+        self.f = open(os.path.join(CSRC, ".build.lock"), "w")
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+        fcntl.flock(self.f, fcntl.LOCK_UN)
+        self.f.close()
+        return False
+
+
 def _tag(shape) -> str:
     return "_".join(str(int(v)) for v in shape)
 
@@ -75,10 +92,13 @@ def build_instance(shape, log=print) -> Optional[str]:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not (os.path.exists(hipcc) or shutil.which("hipcc")) or not shutil.which("make"):
         return None
-    log(f"permutect_amd: building the kernel instances for model shape {shape} (once; ~1-2 minutes, ~4 with more than four tiles) ...")
-    cmd = ["make", "-C", CSRC, f"-j{min(8, os.cpu_count() or 1)}", "instance", "SHAPE=" + " ".join(str(int(v)) for v in shape)]
-    res = subprocess.run(cmd, capture_output=True, text=True)
     path = os.path.join(INSTANCE_DIR, f"libpermutect_amd_{_tag(shape)}.so")
+    with _BuildLock():
+        if os.path.exists(path):  # (another process built it while this one waited for the lock)
+            return path
+        log(f"permutect_amd: building the kernel instances for model shape {shape} (once; ~1-2 minutes, ~4 with more than four tiles) ...")
+        cmd = ["make", "-C", CSRC, f"-j{min(8, os.cpu_count() or 1)}", "instance", "SHAPE=" + " ".join(str(int(v)) for v in shape)]
+        res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0 or not os.path.exists(path):
         warnings.warn("permutect_amd: building the kernel instances failed:\n" + res.stderr[-2000:])
         return None
@@ -112,10 +132,12 @@ def wide_library(log=print, half32: bool = False) -> C.CDLL:
         if os.environ.get("PMT_JIT", "1") == "0" or not (os.path.exists(hipcc) or shutil.which("hipcc")) or not shutil.which("make"):
             raise L.PmtError(f"this model (a layer wider than {L.MAX_WIDTH}, or d_ffn / 2 beyond {L.MAX_HALF_FFN}) needs the {target} build of the "
                              f"library, `make -C permutect_amd/csrc {target}` (not built here, and PMT_JIT=0 or no hipcc / make to build it now)")
-        log(f"permutect_amd: building the {target} library (once, ~3 minutes) ...")
-        res = subprocess.run(["make", "-C", CSRC, f"-j{min(8, os.cpu_count() or 1)}", target], capture_output=True, text=True)
-        if res.returncode != 0 or not os.path.exists(path):
-            raise L.PmtError(f"building the {target} library failed:\n" + res.stderr[-2000:])
+        with _BuildLock():
+            if not os.path.exists(path):  # (else: another process built it while this one waited for the lock)
+                log(f"permutect_amd: building the {target} library (once, ~3 minutes) ...")
+                res = subprocess.run(["make", "-C", CSRC, f"-j{min(8, os.cpu_count() or 1)}", target], capture_output=True, text=True)
+                if res.returncode != 0 or not os.path.exists(path):
+                    raise L.PmtError(f"building the {target} library failed:\n" + res.stderr[-2000:])
     return L.load(path)
 
 
