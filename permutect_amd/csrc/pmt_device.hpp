@@ -990,8 +990,10 @@ static inline int pmt_shape_for(const PmtModel* m, const PmtBatch* b, bool layer
     if (shape == 6 && layered) shape = 1;  // (split read sets of a tile-exact model: the fp32 tile-exact instances)
     // Split read sets on the 16-bit instances of a build around ANOTHER shape than the production one: the fp32 tile-exact instances
     // too.  One such shape (4, 3, 5, 2 tiles: scripts/shape_fuzz.py, configuration A) gives wrong gradients on read sets split unevenly
-    // between ref and alt (10 + 300 reads: relative error O(1); 330 + 280: exact), cause not found; five other shapes and the
-    // production one are exact on the same data, and every shape is exact on its fp32 instances.  Until it is found, only the
+    // between ref and alt (10 + 300 reads: relative error O(1) in two runs of three -- a race: the wrong value repeats bit for bit --,
+    // in the BACKWARD, joined launch; 330 + 280: exact), cause not found; five other shapes and the production one are exact on
+    // the same data, and every shape is exact on its fp32 instances (which add their weight gradients with atomics, not through
+    // private rows).  Until it is found, only the
     // production shape -- whose split-set path the tests and the stress benchmark check at scale -- keeps the 16-bit pipes here.
     constexpr bool production_shape = PMT_SH_NTF == 4 && PMT_SH_NTR == 2 && PMT_SH_NTD == 4 && PMT_SH_NTE == 1 && PMT_SH_F == 61 && PMT_SH_R == 30 &&
                                       PMT_SH_D == 60 && PMT_SH_H == 10 && PMT_SH_E == 10;

@@ -40,6 +40,11 @@ out2 = model.compute_batch_output(batch2)
 model.compute_batch_losses(out2, batch2).total_loss.backward()
 torch.cuda.synchronize()
 print("shape id", model.engine().shape_id, "PMT_SHAPE", os.environ.get("PMT_SHAPE"))
+try:
+    model.engine().check_join_fault()
+    print("fault word clear")
+except Exception as exc:
+    print("FAULT:", str(exc)[:200])
 i64 = torch.from_numpy(ints2.astype(np.int64))
 ob2 = dict(reads_re=torch.from_numpy(O.decode_packed_reads(packed2).astype(np.float32)), nref=i64[:, O.REF_COUNT], nalt=i64[:, O.ALT_COUNT],
            labels=i64[:, O.LABEL], sources=i64[:, O.SOURCE], info_be=torch.from_numpy(floats2[:, O.INFO_START:].astype(np.float32)),
