@@ -67,3 +67,6 @@ for n, p in model.named_parameters():
     if e > 2e-4 * max(np.linalg.norm(r), 1e-3):
         print(f"{n:70s} |ref| {np.linalg.norm(r):10.4f} err {e:10.3e} rel {e / max(np.linalg.norm(r), 1e-12):.2e}")
 print("total rel", (tot / tn) ** 0.5)
+if os.environ.get("DUMP_GRADS"):
+    np.save(os.environ["DUMP_GRADS"], gh)
+    open(os.environ["DUMP_GRADS"] + ".names", "w").write("\n".join(f"{n} {p.numel()}" for n, p in model.named_parameters()))
