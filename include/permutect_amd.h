@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PMT_ABI_VERSION 9
+#define PMT_ABI_VERSION 10
 
 /* bits of the fault word (PmtBatch.join_fault) */
 #define PMT_FAULT_JOIN 1
@@ -68,7 +68,7 @@ extern "C" {
 /* read-row formats accepted at the boundary (reference data/batch.py:41-62, data/datum.py:35) */
 #define PMT_READS_PACKED_U8 0   /* [R][7 + nf] uint8: 7 MSB-first bit-packed bytes, then nf quantile bytes */
 #define PMT_READS_F16 1         /* [R][F] float16 (Batch.reads_re as the reference collates it) */
-#define PMT_READS_F32 2         /* [R][F] float32 (Batch.copy_to(device, float32)); values within +-65504 (the reference's are < 8) */
+#define PMT_READS_F32 2         /* [R][F] float32 (Batch.copy_to(device, float32)); any values: float16 / float32 rows run the wide-range, guarded instances (pmt_forward.hip) */
 
 /* One nn.Linear.  Weights are consumed in MFMA fragment order from the packed buffer. */
 typedef struct PmtLinear {
@@ -295,6 +295,11 @@ int pmt_shape_id(const struct PmtModel* m);
  * one stash slot, [3] waves per workgroup of the read-set kernels.  permutect_amd/engine/instances.py loads the wide build for a
  * model with a layer wider than the default build's limit (the reference takes any width: architecture/mlp.py:32-67). */
 int pmt_limits(int32_t* four);
+
+/* A hash of the sources THIS build of the library was compiled from (16 hex digits and a terminating 0 into `out`; returns the
+ * number of characters written, PMT_E_INVALID if `capacity` < 17).  The default library and every per-shape / wide build of one tree
+ * carry the same id; permutect_amd/engine/instances.py refuses (and rebuilds) a per-shape library left over from other sources. */
+int pmt_build_id(char* out, int32_t capacity);
 
 /* sizeof() of the ABI structs as compiled into the library, for binding self-checks:
  * 0 PmtModel, 1 PmtBatch, 2 PmtOutputs, 3 PmtOutputGrads, 4 PmtAdamW, 5 PmtLinear, 6 PmtOp, 7 PmtMlp, 8 PmtBlock, 9 PmtHead */

@@ -459,6 +459,9 @@ DEV void split_kblock(const f4 (&in)[PMT_RT][NTI], int kb, float in_scale, bf8 (
 #ifndef PMT_TWO_PIECE_MFMAS
 #define PMT_TWO_PIECE_MFMAS 3  // MFMAs of a product with two-piece activations: 5 (all but a_hi b_lo) or 3 (first order only)
 #endif
+#ifndef PMT_BF16_K16_TAIL
+#define PMT_BF16_K16_TAIL 0  // 1 (development: reproduces the hazard): the 16-deep MFMA for the half-filled last k block of 3, 5, 7 input tiles
+#endif
 #ifndef PMT_FRAG_AHEAD
 #define PMT_FRAG_AHEAD 0  // the forward (4 waves per SIMD hide the latency; no registers to spare): 1.15 ms -> 1.18 with 1
 #endif
@@ -482,7 +485,13 @@ DEV void linear_acc_bf16(f4 (&acc)[PMT_RT][NTO], const f4 (&in)[PMT_RT][NTI], co
     for (int kb = 0; kb < NKB; ++kb) {
         bf8 bh[PMT_RT], bm[PMT_RT], bl[PMT_RT];
         split_kblock<NTI, SELU_IN, PIECES>(in, kb, in_scale, bh, bm, bl);
-        const bool half_block = 2 * kb + 1 >= NTI;  // a last k block with one tile only: the 16-deep MFMA on the lower halves
+        // A k block with one tile only: the 16-deep MFMA on the lower halves -- when it is the ONLY k block (NTI == 1).  The half-filled
+        // LAST block of 3, 5 or 7 input tiles takes the 32-deep MFMA on its zero-padded operands (the fragments' upper halves are zeros,
+        // pmt_pack_kernel): `v_mfma_f32_16x16x16_bf16 D, a, b, D` straight behind a `v_mfma_f32_16x16x32_bf16` that writes D reads the
+        // accumulator before the longer instruction has written it back -- the hardware interlocks an accumulation chain of ONE opcode
+        // only, and hipcc 7.2 puts no wait state between the two (scripts/microbench/mfma_chain_hazard.hip).  Wrong sums whenever
+        // the two issue back to back, i.e. depending on what the SIMD's other wave does: the "race" of round 4's split read sets.
+        const bool half_block = (NKB == 1 || PMT_BF16_K16_TAIL) && 2 * kb + 1 >= NTI;
 #pragma unroll
         for (int mt = 0; mt < NTO; ++mt) {
             const int step = kb * NTO + mt;
@@ -988,16 +997,6 @@ extern "C" int pmt_shape_id(const PmtModel* m);     // host: 2 = ShapeP0X (exact
 static inline int pmt_shape_for(const PmtModel* m, const PmtBatch* b, bool layered = false) {
     int shape = pmt_shape_id(m);
     if (shape == 6 && layered) shape = 1;  // (split read sets of a tile-exact model: the fp32 tile-exact instances)
-    // Split read sets on the 16-bit instances of a build around ANOTHER shape than the production one: the fp32 tile-exact instances
-    // too.  One such shape (4, 3, 5, 2 tiles: scripts/shape_fuzz.py, configuration A) gives wrong gradients on read sets split unevenly
-    // between ref and alt (10 + 300 reads: relative error O(1) in two runs of three -- a race: the wrong value repeats bit for bit --,
-    // in the BACKWARD, joined launch; 330 + 280: exact), cause not found; five other shapes and the production one are exact on
-    // the same data, and every shape is exact on its fp32 instances (which add their weight gradients with atomics, not through
-    // private rows).  Until it is found, only the
-    // production shape -- whose split-set path the tests and the stress benchmark check at scale -- keeps the 16-bit pipes here.
-    constexpr bool production_shape = PMT_SH_NTF == 4 && PMT_SH_NTR == 2 && PMT_SH_NTD == 4 && PMT_SH_NTE == 1 && PMT_SH_F == 61 && PMT_SH_R == 30 &&
-                                      PMT_SH_D == 60 && PMT_SH_H == 10 && PMT_SH_E == 10;
-    if (layered && shape >= 2 && !production_shape) shape = 1;
     if (!(m->dropout_p > 0.f && b->dropout_seed != 0)) return shape;
     return (shape == 2 && !layered) ? 4 : 0;
 }

@@ -40,9 +40,8 @@ DEV float read_feature(const unsigned char* __restrict__ row, int fmt, int f, in
 // an activation array about to become a pair of f16 operand pieces: any value beyond their range goes into the caller's fault word
 // (v_max3 over the registers, one compare, one ballot; NaN compares false: a non-finite stream shows in the outputs themselves)
 #ifndef PMT_F16_RANGE_CHECK
-#define PMT_F16_RANGE_CHECK 6  // bits: 1 float32 read rows (off: that branch in the prologue costs the filter instance 14 spilled registers
-                               // = 6 % of its time, and the reference's read rows are bits and (uint8 +- 128) / 32 < 8 in every format),
-                               // 2 the residual stream at the reducer, 4 the reducer's output (both free)
+#define PMT_F16_RANGE_CHECK 6  // bits: 2 the residual stream at the reducer, 4 the reducer's output (both free).  (Read rows need no check:
+                               // the f16 instances run packed rows only, whose values are below 8 -- wide_range_operands.)
 #endif
 template <int NT, int WHICH>
 DEV void f16_range_check(const f4 (&v)[PMT_RT][NT], int* __restrict__ fault) {
@@ -197,9 +196,8 @@ __global__ __launch_bounds__(PMT_THREADS, (S::EXACT && PMT_NT <= 4 && !(LAYERED 
                 for (int j = 0; j < 4; ++j) xf[rt][t][j] = rowp ? read_feature(rowp, fmt, feat_of(t, j, g), F) : 0.f;
         }
         tr.ev(5);
-        if constexpr (S::BF16 == PMT_F16X2) {  // read rows given as float32 can hold anything (packed rows are bytes, float16 rows in range)
-            if (fmt == PMT_READS_F32) f16_range_check<NTF, 1>(xf, bt.join_fault);
-        }
+        // (the f16 instances only ever see PACKED rows -- bits and k / 32 quantiles: pmt_forward picks the wide-range instances for float16 /
+        //  float32 read rows, wide_range_operands below)
         if constexpr (EX) {
             f4 xr[PMT_RT][NTR];
             PmtDrop drop;  // (only the dropout instance, ShapeP0XD, touches it)
@@ -674,6 +672,15 @@ extern "C" int pmt_forward_launch_train_p0x(int groups, void* stream, const PmtM
                                             const float* packed, const PmtBatch* batch, const PmtOutputs* out, float* stash,
                                             float* zsum_stash, float* rstd_stash, const PmtLayeredArgs* lay, int bf16x3);
 
+// Which instances of an exact-width shape run a batch.  The f16 instances (two f16 pieces per operand, MODE.FP16_OVFL, segmented
+// scans without the non-finite guard) are built on what PACKED read rows guarantee: bits and k / 32 quantiles, nothing beyond 8,
+// nothing non-finite.  float16 / float32 read rows (PMT_READS_F16 / _F32: a caller's own tensors) can hold anything -- an inf
+// would be clamped to finite garbage without a trace, a NaN would pass v_cvt and leak through the unguarded scans into the sets
+// that share its row of 16 lanes -- so they take the instances whose operands carry fp32's range and whose scans are
+// guarded: three bf16 pieces (round 3's form, 1.3 x the time) or, for a tile-exact model, fp32 MFMAs.  The reference's semantics then
+// hold: a non-finite read makes ITS variant's outputs non-finite and no other's (sets/ragged_sets.py:144-158).
+static bool wide_range_operands(const PmtModel* m, const PmtBatch* b) { return m->force_shape == 5 || b->read_format != PMT_READS_PACKED_U8; }
+
 // per-set outputs from the global sums of a layered forward (same arithmetic as the finalisation above)
 __global__ __launch_bounds__(256) void pmt_finalize_kernel(const PmtModel* __restrict__ M, const float* __restrict__ phi, PmtBatch bt,
                                                            PmtOutputs out, const float* __restrict__ fsum_g, const float* __restrict__ hsum_g) {
@@ -754,7 +761,7 @@ extern "C" int pmt_forward_layered(const PmtModel* model_host, const PmtModel* m
         lay.slice = slice;
         if (shape >= 2) {  // the layered instances of the production shape: pmt_forward_train.hip  (layered: no plain-bf16 instance)
             const int rct = pmt_forward_launch_train_p0x(batch->num_groups, stream, model_dev, theta, phi, packed, batch, out, stash, zsum_stash,
-                                                         rstd_stash, &lay, model_host->force_shape == 5);
+                                                         rstd_stash, &lay, wide_range_operands(model_host, batch));
             if (rct != PMT_OK) return rct;
             continue;
         }
@@ -792,11 +799,14 @@ extern "C" int pmt_forward(const PmtModel* model_host, const PmtModel* model_dev
     }
     auto kernel = stash ? (p0 ? pmt_forward_kernel<true, ShapeP0> : pmt_forward_kernel<true, ShapeAny>)
                         : (p0 ? pmt_forward_kernel<false, ShapeP0> : pmt_forward_kernel<false, ShapeAny>);
+    const bool wide_range = wide_range_operands(model_host, batch);
     if ((shape == 2 || shape == 4) && stash)  // its own translation unit (pmt_forward_train.hip); 4: with the step's dropout masks
         return pmt_forward_launch_train_p0x(batch->num_groups, stream, model_dev, theta, phi, packed, batch, out, stash, zsum_stash, rstd_stash, nullptr,
-                                            model_host->force_shape == 5);
-    if (shape == 2) kernel = model_host->force_shape == 5 ? pmt_forward_kernel<false, ShapeP0X> : pmt_forward_kernel<false, ShapeP0XH>;
-    if (shape == 6) kernel = stash ? pmt_forward_kernel<true, ShapeP0TH> : pmt_forward_kernel<false, ShapeP0TH>;  // the shape's tiles, widths at run time
+                                            wide_range);
+    if (shape == 2) kernel = wide_range ? pmt_forward_kernel<false, ShapeP0X> : pmt_forward_kernel<false, ShapeP0XH>;
+    // the shape's tiles, widths at run time: f16 pieces -- or, for read rows that can hold anything, the fp32 tile-exact instance (`kernel` above)
+    if (shape == 6 && !wide_range) kernel = stash ? pmt_forward_kernel<true, ShapeP0TH> : pmt_forward_kernel<false, ShapeP0TH>;
+    if (shape == 6 && wide_range) kernel = stash ? pmt_forward_kernel<true, ShapeP0> : pmt_forward_kernel<false, ShapeP0>;
     if (shape == 3) kernel = stash ? pmt_forward_kernel<true, ShapeP0XB> : pmt_forward_kernel<false, ShapeP0XB>;  // plain bf16 products
     hipLaunchKernelGGL(kernel, dim3(batch->num_groups), dim3(PMT_THREADS), 0, s, model_dev, theta, phi, packed, *batch, *out,
                        stash, zsum_stash, rstd_stash, PmtLayeredArgs{});

@@ -10,6 +10,17 @@
 #include "pmt_device.hpp"
 
 extern "C" int pmt_abi_version(void) { return PMT_ABI_VERSION; }
+#ifndef PMT_BUILD_ID
+#define PMT_BUILD_ID "0000000000000000"  // (csrc/Makefile passes the hash of the sources)
+#endif
+extern "C" int pmt_build_id(char* out, int32_t capacity) {
+    static const char tagged[] = "PMT_BUILD_ID=" PMT_BUILD_ID;  // (the tag: engine/instances.py reads the id out of the FILE of a library it has not mapped)
+    const char* id = tagged + 13;
+    const int n = (int)sizeof(tagged) - 13;
+    if (!out || capacity < n) return PMT_E_INVALID;
+    memcpy(out, id, n);
+    return n - 1;
+}
 
 extern "C" int pmt_struct_bytes(int which) {
     switch (which) {

@@ -96,11 +96,15 @@ class ReadsDataset:
         per_read = self._reads.shape[1] * self._reads.itemsize if self._reads is not None else 0
         return int(self._ints[: self._size].nbytes + self._floats[: self._size].nbytes + nreads * per_read + np.asarray(self._starts).nbytes)
 
-    def pin_memory_if_it_fits(self, max_fraction: float = 0.4) -> bool:
+    def pin_memory_if_it_fits(self, max_fraction: float = 0.25) -> bool:
         """What the tools call before they stream a dataset (train_artifact_model, make_posterior_mmap): page-lock it (pin_memory)
-        when it takes at most `max_fraction` of the host memory that is available right now; otherwise (or with
-        PMT_PIN_DATASET=0 in the environment) the dataset stays where it is -- a memory map of a file, typically -- and chunks go
-        through the staging copies.  Returns whether the dataset is page-locked."""
+        when it takes at most this process's SHARE of `max_fraction` of the host memory that is available right now; otherwise (or
+        with PMT_PIN_DATASET=0 in the environment) the dataset stays where it is -- a memory map of a file, typically -- and chunks
+        go through the staging copies.  The share: every rank of a data-parallel job on this node (LOCAL_WORLD_SIZE, set by torchrun)
+        makes the same decision at the same moment and page-locks its OWN copy, so the budget is divided by their number (ADVICE r4:
+        eight ranks each taking 40 % of "available" is three times the machine); pinned memory cannot be swapped, hence a quarter,
+        not more.  A pin that fails all the same (hipHostMalloc refused: another process got there first) leaves the staged path.
+        Returns whether the dataset is page-locked."""
         if self._pinned is not None:
             return True
         if os.environ.get("PMT_PIN_DATASET", "1") == "0" or not torch.cuda.is_available():
@@ -110,9 +114,19 @@ class ReadsDataset:
             available = psutil.virtual_memory().available
         except Exception:  # noqa: BLE001 -- no way to tell: leave the dataset alone
             return False
-        if self.host_bytes() > max_fraction * available:
+        try:
+            local_ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+        except ValueError:
+            local_ranks = 1
+        if self.host_bytes() > max_fraction * available / local_ranks:
             return False
-        self.pin_memory()
+        try:
+            self.pin_memory()
+        except (RuntimeError, MemoryError) as exc:  # page-locking refused: nothing was replaced (pin_memory assigns at its end)
+            import warnings
+            warnings.warn(f"permutect_amd: page-locking the dataset failed ({str(exc)[:120]}); chunks go through the staging copies")
+            self._pinned = None
+            return False
         return self._pinned is not None
 
     # ---- reference accessors (reference :95-112, :198-221) ---------------------------------------------------------------
@@ -483,10 +497,8 @@ class DeviceChunkLoader:
         #  they put the first batch's seven small copies behind the other chunks' large ones on the one upload stream, and the first
         #  batch of a pass left the loader after 6.5 ms instead of ~1.5)
         first_lo, first_hi = self.ranges[0]
-        self._staged_start = 0
-        if len(self.ranges) > 1 and first_hi - first_lo >= 4 * batch_size:
+        if len(self.ranges) > 1 and first_hi - first_lo >= 4 * batch_size:  # (measured: loading the short piece ALONE first made the SECOND batch late: all prefetch threads start at once)
             self.ranges = [(first_lo, first_lo + batch_size), (first_lo + batch_size, first_hi)] + self.ranges[1:]
-            self._staged_start = 0  # (measured: loading the first piece alone first made the SECOND batch late; 0 = all prefetch threads at once)
         self.bytes_uploaded = 0
         self._stages = None  # borrowed from _STAGES while iterating: one PinnedStage per chunk in flight
         self._slot_events = [None] * _PREFETCH  # per staging slot: the event behind the last chunk enqueued out of it
@@ -687,23 +699,19 @@ class DeviceChunkLoader:
                 def submit(i):
                     if i < len(order_c):
                         pending.append(pool.submit(self._load, int(order_c[i]), int(seeds[i]), i % _PREFETCH))
-                # the first pieces of an unshuffled pass one after the other (each load's copies enqueued before the next one's), then
                 # _PREFETCH loads in flight
-                staged = self._staged_start if not self.shuffle else 0
                 submitted = 0
-                for i in range(max(1, min(_PREFETCH, len(order_c)) if staged == 0 else 1)):
+                for i in range(max(1, min(_PREFETCH, len(order_c)))):
                     submit(i)
                     submitted += 1
                 ahead = None
                 if _timing:
                     print(f"[loader] iteration set up and first loads submitted after {1e3 * (_time.perf_counter() - _t_iter):.2f} ms", flush=True)
                 for i in range(len(order_c)):
-                    if i < staged:
-                        pending[0].result()  # (this piece's copies are on the upload stream: the next piece may enqueue its own)
                     chunk, batches, done = pending.popleft().result()
                     if _timing and i < 3:
                         print(f"[loader] chunk {i} ({len(batches)} batches) in hand after {1e3 * (_time.perf_counter() - _t_iter):.2f} ms", flush=True)
-                    want = i + 2 if i + 1 < staged else i + 1 + _PREFETCH
+                    want = i + 1 + _PREFETCH
                     while submitted < min(want, len(order_c)):
                         submit(submitted)
                         submitted += 1

@@ -33,6 +33,12 @@ INSTANCE_DIR = os.path.join(_HERE, "instances")
 CSRC = os.path.join(_HERE, "csrc")
 
 
+def cache_dir() -> Optional[str]:
+    """PMT_INSTANCE_DIR: where per-shape libraries built on the spot go (and are looked for) instead of the package directory -- an
+    installation whose package directory is read-only, or one shared by the nodes of a job (a local directory per node then)"""
+    return os.environ.get("PMT_INSTANCE_DIR") or None
+
+
 def _tiles(n: int) -> int:
     return (n + 15) // 16
 
@@ -66,11 +72,16 @@ def exact_shape_of(desc: L.PmtModel) -> Optional[Tuple[int, ...]]:
 
 class _BuildLock:
     """One build at a time per tree (the ranks of a data-parallel job lower the same model at the same moment: they would all run `make` in
-    the same object directory).  An advisory lock on a file next to the sources; whoever gets it second finds the library built."""
+    the same object directory).  An advisory lock on a file next to the objects; whoever gets it second finds the library built.
+    (flock does not serialise the nodes of a job on a shared file system: give each node its own PMT_INSTANCE_DIR there.)"""
+
+    def __init__(self, directory: str):
+        self.directory = directory
 
     def __enter__(self):
         import fcntl
-        self.f = open(os.path.join(CSRC, ".build.lock"), "w")
+        os.makedirs(self.directory, exist_ok=True)
+        self.f = open(os.path.join(self.directory, ".build.lock"), "w")  # (OSError on a read-only tree: the caller falls back)
         fcntl.flock(self.f, fcntl.LOCK_EX)
         return self
 
@@ -85,20 +96,43 @@ def _tag(shape) -> str:
     return "_".join(str(int(v)) for v in shape)
 
 
+def file_build_id(path: str) -> Optional[str]:
+    """pmt_build_id of a library FILE, read without mapping it (a mapped library cannot be replaced by a rebuilt one in this process)"""
+    import re
+    try:
+        m = re.search(rb"PMT_BUILD_ID=([0-9a-f]{16})", open(path, "rb").read())
+    except OSError:
+        return None
+    return m.group(1).decode() if m else None
+
+
+def is_current(path: str) -> bool:
+    """built from the same sources as the default library?  A per-shape library kept from an earlier state of the tree carries that
+    state's kernels: it is rebuilt, or refused when it cannot be."""
+    return file_build_id(path) == L.build_id(L.load())
+
+
 def build_instance(shape, log=print) -> Optional[str]:
-    """`make instance SHAPE=...` (csrc/Makefile); returns the library's path, None when it cannot be built here"""
+    """`make instance SHAPE=...` (csrc/Makefile) -- a no-op when the library is up to date with the sources; returns the library's path,
+    None when it cannot be built here (PMT_JIT=0, no hipcc / make, a read-only tree without PMT_INSTANCE_DIR)"""
     if os.environ.get("PMT_JIT", "1") == "0":
         return None
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not (os.path.exists(hipcc) or shutil.which("hipcc")) or not shutil.which("make"):
         return None
-    path = os.path.join(INSTANCE_DIR, f"libpermutect_amd_{_tag(shape)}.so")
-    with _BuildLock():
-        if os.path.exists(path):  # (another process built it while this one waited for the lock)
-            return path
-        log(f"permutect_amd: building the kernel instances for model shape {shape} (once; ~1-2 minutes, ~4 with more than four tiles) ...")
-        cmd = ["make", "-C", CSRC, f"-j{min(8, os.cpu_count() or 1)}", "instance", "SHAPE=" + " ".join(str(int(v)) for v in shape)]
-        res = subprocess.run(cmd, capture_output=True, text=True)
+    out = cache_dir()
+    path = os.path.join(out or INSTANCE_DIR, f"libpermutect_amd_{_tag(shape)}.so")
+    cmd = ["make", "-C", CSRC, f"-j{min(8, os.cpu_count() or 1)}", "instance", "SHAPE=" + " ".join(str(int(v)) for v in shape)]
+    if out:  # objects and library outside the package (command-line variables override the Makefile's)
+        cmd += [f"IDIR={os.path.join(out, 'inst_' + _tag(shape))}", f"ILIB={path}"]
+    try:
+        with _BuildLock(out or CSRC):
+            if not os.path.exists(path):
+                log(f"permutect_amd: building the kernel instances for model shape {shape} (once; ~1-2 minutes, ~4 with more than four tiles) ...")
+            res = subprocess.run(cmd, capture_output=True, text=True)
+    except OSError as exc:
+        warnings.warn(f"permutect_amd: cannot build kernel instances here ({exc}); set PMT_INSTANCE_DIR to a writable directory")
+        return None
     if res.returncode != 0 or not os.path.exists(path):
         warnings.warn("permutect_amd: building the kernel instances failed:\n" + res.stderr[-2000:])
         return None
@@ -132,7 +166,7 @@ def wide_library(log=print, half32: bool = False) -> C.CDLL:
         if os.environ.get("PMT_JIT", "1") == "0" or not (os.path.exists(hipcc) or shutil.which("hipcc")) or not shutil.which("make"):
             raise L.PmtError(f"this model (a layer wider than {L.MAX_WIDTH}, or d_ffn / 2 beyond {L.MAX_HALF_FFN}) needs the {target} build of the "
                              f"library, `make -C permutect_amd/csrc {target}` (not built here, and PMT_JIT=0 or no hipcc / make to build it now)")
-        with _BuildLock():
+        with _BuildLock(CSRC):
             if not os.path.exists(path):  # (else: another process built it while this one waited for the lock)
                 log(f"permutect_amd: building the {target} library (once, ~3 minutes) ...")
                 res = subprocess.run(["make", "-C", CSRC, f"-j{min(8, os.cpu_count() or 1)}", target], capture_output=True, text=True)
@@ -163,20 +197,30 @@ def library_for(desc: L.PmtModel, log=print) -> C.CDLL:
                       "Linear, and each MLP keep one tile count); it runs the GENERIC instance (fp32 MFMAs, ~2x slower)")
         return generic()
     # a library with the model's tile counts: its widths first, then any other widths (pmt_shape_id 6: widths at run time)
-    exact = os.path.join(INSTANCE_DIR, f"libpermutect_amd_{_tag(shape)}.so")
-    candidates = ([exact] if os.path.exists(exact) else []) + sorted(glob.glob(os.path.join(INSTANCE_DIR, f"libpermutect_amd_{_tag(shape[:4])}_*.so")))
+    dirs = ([cache_dir()] if cache_dir() else []) + [INSTANCE_DIR]
+    candidates = []
+    for d in dirs:
+        exact = os.path.join(d, f"libpermutect_amd_{_tag(shape)}.so")
+        candidates += ([exact] if os.path.exists(exact) else []) + sorted(glob.glob(os.path.join(d, f"libpermutect_amd_{_tag(shape[:4])}_*.so")))
     def fits(lib):
         lim = L.limits_of(lib)
         return lim["max_width"] >= widest and lim["max_half_ffn"] // 16 == ht and lib.pmt_shape_id(C.byref(desc)) != 0
-    for path in candidates:
+    stale = []
+    for path in dict.fromkeys(candidates):
+        if not is_current(path):
+            stale.append(path)
+            continue
         lib = L.load(path)
         if fits(lib):
             return lib
-    path = build_instance(shape, log)
-    if path is not None:
+    path = build_instance(shape, log)  # (make: rebuilds a stale library of this shape, a no-op for a current one)
+    if path is not None and is_current(path):
         lib = L.load(path)
         if fits(lib):
             return lib
+    if stale:
+        warnings.warn("permutect_amd: kernel-instance libraries built from OTHER sources than the default library were ignored ("
+                      + ", ".join(os.path.basename(p) for p in stale) + "); rebuild them: `python -c 'import __graft_entry__ as g; g.build()'`")
     if wide:
         return generic()
     warnings.warn(f"permutect_amd: no kernel instances for model shape {shape} and none could be built here (hipcc / make missing, or "

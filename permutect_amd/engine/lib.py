@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("PMT_LIB", os.path.join(_HERE, "libpermutect_amd.so"))  # (PMT_LIB: development builds for A/B runs)
 
 # ---- limits (must match the header) -------------------------------------------------------------------------------
-ABI_VERSION = 9
+ABI_VERSION = 10
 MAX_WIDTH, MAX_HALF_FFN, MAX_CLUSTERS = 64, 16, 16
 MAX_HALF_FFN_WIDE = 32  # d_ffn / 2 of the wide32 build (two tiles per half of a gated block's hidden layer)
 MAX_WIDTH_WIDE = 128  # the wide build of the library (csrc/Makefile: `make wide`; engine/instances.py loads it for wider layers)
@@ -154,7 +154,7 @@ class PmtLossInputGrads(C.Structure):
     _fields_ = [("d_logits_b", vp), ("d_logits_bk", vp), ("d_alt_count_raw", vp), ("d_source_logits", vp)]
 
 
-EXPORTS = ["pmt_abi_version", "pmt_shape_info", "pmt_shape_id", "pmt_limits", "pmt_struct_bytes", "pmt_model_check", "pmt_plan_groups", "pmt_stash_bytes", "pmt_pack_params",
+EXPORTS = ["pmt_abi_version", "pmt_build_id", "pmt_shape_info", "pmt_shape_id", "pmt_limits", "pmt_struct_bytes", "pmt_model_check", "pmt_plan_groups", "pmt_stash_bytes", "pmt_pack_params",
            "pmt_scan_counts", "pmt_forward", "pmt_backward", "pmt_clip_adamw",
            "pmt_dropout_mask", "pmt_rows_stash_bytes", "pmt_rows_forward", "pmt_rows_backward", "pmt_rows_workspace_floats", "pmt_cnn_forward", "pmt_cnn_backward", "pmt_cnn_stash_floats", "pmt_cnn_workspace_floats",
            "pmt_phi_forward", "pmt_phi_backward", "pmt_build_read_index", "pmt_losses_forward", "pmt_losses_backward",
@@ -253,6 +253,11 @@ def load(path: str = None) -> C.CDLL:
                            f"({lib.pmt_struct_bytes(which)} B)")
     lib.pmt_shape_info.argtypes = [P(i32)]
     lib.pmt_shape_id.argtypes = [P(PmtModel)]
+    lib.pmt_build_id.argtypes = [C.c_char_p, i32]
+    # the planner's constants below are this module's; the kernels' are the library's: they must be the same numbers
+    if limits_of(lib)["group_waves"] != GROUP_WAVES:
+        raise PmtError(f"{path} is built for {limits_of(lib)['group_waves']} waves per workgroup, the host side plans for {GROUP_WAVES} "
+                       "(PMT_GROUP_WAVES in the environment must match a development build loaded through PMT_LIB)")
     _libs[path] = lib
     if path == LIB_PATH:
         _lib = lib
@@ -264,6 +269,13 @@ def limits_of(lib: C.CDLL) -> dict:
     v = (i32 * 4)()
     check(lib.pmt_limits(v), "pmt_limits")
     return {"max_width": int(v[0]), "max_half_ffn": int(v[1]), "slot_floats": int(v[2]), "group_waves": int(v[3])}
+
+
+def build_id(lib: C.CDLL) -> str:
+    """the hash of the sources a build of the library was compiled from (pmt_build_id)"""
+    buf = C.create_string_buffer(32)
+    check(lib.pmt_build_id(buf, 32), "pmt_build_id")
+    return buf.value.decode()
 
 
 def shape_of(lib: C.CDLL):

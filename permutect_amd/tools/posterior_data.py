@@ -60,8 +60,15 @@ def device_posterior_rows(float_tensor: torch.Tensor, logits_b: torch.Tensor, fe
 
 @torch.inference_mode()
 def make_posterior_mmap(dataset: ReadsDataset, model, batch_size: int, device: Optional[torch.device] = None,
-                        chunk_variants: Optional[int] = None) -> MemoryMappedData:
+                        chunk_variants: Optional[int] = None, rank: int = 0, world_size: int = 1) -> Optional[MemoryMappedData]:
     """`MemoryMappedData.from_generator(generate_posterior_data(...))` of the reference, in dataset order.
+
+    `rank`, `world_size` (one process per GPU, torch.distributed initialised by the caller: tools/filter_variants.py under torchrun):
+    the candidate index range is cut into `world_size` contiguous shards (the reference's loader partitions its workers
+    the same way, data/reads_dataset.py:141-142), every rank runs the forward over ITS shard with no collective on the data path, and
+    the shards' rows are concatenated on rank 0 in dataset order (point-to-point over a host-side gloo group, straight into their
+    place in the result: the rows are already in host memory).  Rank 0 returns the whole result -- bit for bit the single-process one
+    (tests/test_distributed_cpu.py) -- the other ranks None.
 
     Nothing waits for the device inside the loop.  The float rows (six scalars with the logit stored through float16, then the
     float32 embedding: `posterior_rows`) are assembled on the device and scattered to their place inside a per-CHUNK device
@@ -77,7 +84,11 @@ def make_posterior_mmap(dataset: ReadsDataset, model, batch_size: int, device: O
     device = model._device if device is None else torch.device(device)
     if device.type == "cuda":
         dataset.pin_memory_if_it_fits()  # (chunks by DMA straight from the dataset when it fits host memory; else staged copies)
-    n = len(dataset)
+    n_total = len(dataset)
+    loader = dataset.device_loader(batch_size, device, chunk_variants=chunk_variants, shuffle=False, rank=rank, world_size=world_size)
+    shard_lo, shard_hi = loader.lo, loader.hi  # this rank's contiguous share of the candidates
+    # rank 0 holds the whole result (its shard is the first), the others their shard only; `base`: dataset index of row 0
+    base, n = (0, n_total) if rank == 0 else (shard_lo, shard_hi - shard_lo)
     e = model.reducer.output_dimension()
     width = INFO_START_IDX + e
     ints_out = np.empty((n, dataset._ints.shape[-1]), dtype=np.int16)
@@ -102,10 +113,11 @@ def make_posterior_mmap(dataset: ReadsDataset, model, batch_size: int, device: O
     def ints_worker():  # the integer rows: the dataset's own, counts zeroed (never on the device)
         t0 = time.perf_counter()
         try:
-            src = np.ascontiguousarray(dataset._ints[:n]) if not dataset._ints[:n].flags["C_CONTIGUOUS"] else dataset._ints[:n]
+            mine = dataset._ints[shard_lo:shard_hi]
+            src = mine if mine.flags["C_CONTIGUOUS"] else np.ascontiguousarray(mine)
             assert Data.ALT_COUNT.idx == Data.REF_COUNT.idx + 1
-            L.check(lib.pmt_host_copy_rows(ints_out.ctypes.data, src.ctypes.data, n, ints_out.shape[1] * 2, Data.REF_COUNT.idx * 2, 4, 8),
-                    "pmt_host_copy_rows")  # one pass: the rows and the two zeroed counts
+            L.check(lib.pmt_host_copy_rows(ints_out[shard_lo - base:].ctypes.data, src.ctypes.data, shard_hi - shard_lo, ints_out.shape[1] * 2,
+                                           Data.REF_COUNT.idx * 2, 4, 8), "pmt_host_copy_rows")  # one pass: the rows and the two zeroed counts
             t_ints[0] = time.perf_counter() - t0
         except Exception as exc:
             errors.append(exc)
@@ -120,7 +132,7 @@ def make_posterior_mmap(dataset: ReadsDataset, model, batch_size: int, device: O
                 if event is not None:
                     event.synchronize()
                 t0 = time.perf_counter()
-                host_copy(floats_out[lo:hi], pinned.data_ptr(), (hi - lo) * width * 4)
+                host_copy(floats_out[lo - base:hi - base], pinned.data_ptr(), (hi - lo) * width * 4)
                 t_floats[0] += time.perf_counter() - t0
                 free.append(pinned)
         except Exception as exc:  # surfaced by the caller after join
@@ -161,7 +173,7 @@ def make_posterior_mmap(dataset: ReadsDataset, model, batch_size: int, device: O
             jobs.put((None, block, lo, hi, deque()))
         block = None
 
-    for batch in dataset.device_loader(batch_size, device, chunk_variants=chunk_variants, shuffle=False):
+    for batch in loader:
         out = model.compute_batch_output(batch)
         lo, hi = batch.chunk_range
         if block_range != (lo, hi):
@@ -180,6 +192,22 @@ def make_posterior_mmap(dataset: ReadsDataset, model, batch_size: int, device: O
               f"(copies {1e3 * t_floats[0]:.1f}), integer rows {1e3 * t_ints[0]:.1f} ms, all {1e3 * (time.perf_counter() - t_start):.1f} ms", flush=True)
     if errors:
         raise errors[0]
-    assert done == n
+    assert done == shard_hi - shard_lo
     model.engine().check_join_fault()  # (every float row is home: the device has finished; a timed-out join means wrong logits -> raise)
+    if world_size > 1:  # the shards' rows, in dataset order, on rank 0 (no collective on the data path: this is the hand-over of results)
+        import torch.distributed as dist
+        from permutect_amd.training.distributed import host_group
+        group = host_group()
+        per = n_total // world_size
+        if rank == 0:
+            for r in range(1, world_size):
+                lo, hi = r * per, ((r + 1) * per if r < world_size - 1 else n_total)
+                if hi > lo:
+                    dist.recv(torch.from_numpy(ints_out[lo:hi]), src=r, group=group)
+                    dist.recv(torch.from_numpy(floats_out[lo:hi]), src=r, group=group)
+        else:
+            if n > 0:
+                dist.send(torch.from_numpy(ints_out), dst=0, group=group)
+                dist.send(torch.from_numpy(floats_out), dst=0, group=group)
+            return None
     return MemoryMappedData(ints_out, floats_out, n, None, 0)

@@ -137,6 +137,54 @@ class BucketedGradAllReduce:
             torch.cuda.current_stream(flat_grad.device).wait_stream(self._side)
 
 
+_HOST_GROUP = None
+
+
+def host_group():
+    """A gloo process group over the ranks of the default one, for moving HOST arrays between ranks (the filter's per-shard result rows
+    to rank 0): RCCL moves device memory only.  Created once, collectively -- every rank must reach the first call together; None
+    (= the default group) when the default backend is gloo already."""
+    global _HOST_GROUP
+    if dist.get_backend() == "gloo":
+        return None
+    if _HOST_GROUP is None:
+        _HOST_GROUP = dist.new_group(backend="gloo")
+    return _HOST_GROUP
+
+
+def init_from_env(device_type: str = "cuda"):
+    """What the command-line tools call FIRST, before anything touches the GPU: under torchrun (WORLD_SIZE > 1 in the environment; one
+    process per GPU) pick this rank's card by LOCAL_RANK, then join the job's process group -- backend "nccl" (= RCCL over xGMI on
+    ROCm) for device tensors, gloo without a GPU.  Returns (torch.distributed or None, rank, world_size, device).  MASTER_ADDR /
+    MASTER_PORT come from the launcher (use 127.0.0.1 on one node)."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    cuda = device_type == "cuda" and torch.cuda.device_count() > 0  # (device_count does not initialise the GPU)
+    if world <= 1:
+        return None, 0, 1, torch.device("cuda", torch.cuda.current_device()) if cuda else torch.device("cpu")
+    rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    if cuda:
+        torch.cuda.set_device(local % torch.cuda.device_count())
+    if not dist.is_initialized():
+        # (PMT_DIST_BACKEND=gloo: a rehearsal of N ranks on ONE card -- RCCL wants a device per rank; tests/test_dp_gpu.py)
+        backend = os.environ.get("PMT_DIST_BACKEND") or ("nccl" if cuda else "gloo")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return dist, rank, world, torch.device("cuda", torch.cuda.current_device()) if cuda else torch.device("cpu")
+
+
+def assert_replicas_identical(flat: torch.Tensor, what: str = "parameters", group: Optional[dist.ProcessGroup] = None) -> None:
+    """Data parallel rests on every rank taking the identical step: the element-wise MAX and MIN of a buffer over the ranks must be the
+    same bits.  Two small all-reduces; the training loop calls it once, at the end (a replica that drifted means every step since was
+    a different model on each card: fail loudly rather than save rank 0's)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    hi, lo = flat.detach().clone(), flat.detach().clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    if not torch.equal(hi, lo):
+        raise RuntimeError(f"data-parallel replicas diverged: {int((hi != lo).sum())} of {flat.numel()} {what} differ between ranks")
+
+
 def all_reduce_sum_(t: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)

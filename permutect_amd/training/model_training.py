@@ -19,7 +19,7 @@ from permutect_amd.data.reads_dataset import ReadsDataset
 from permutect_amd.enums import Epoch
 from permutect_amd.parameters import TrainingParameters
 from permutect_amd.training.balancer import Balancer
-from permutect_amd.training.distributed import BucketedGradAllReduce, rank0_decides
+from permutect_amd.training.distributed import BucketedGradAllReduce, assert_replicas_identical, rank0_decides
 from permutect_amd.training.downsampler import Downsampler
 from permutect_amd.training.loss_recorder import PRIMARY, LossRecorder, collect_evaluation_data
 from permutect_amd.training.optimizer import FusedClipAdamW, backpropagate  # noqa: F401  (backpropagate: re-exported, reference misc_utils.py:125)
@@ -204,4 +204,6 @@ def train_artifact_model(model, train_dataset: ReadsDataset, valid_dataset: Opti
                         rollback = rank0_decides(rollback, device)
                     if rollback and checkpoint.load_checkpoint():
                         log(f"epoch {epoch}: loss diverged, restored the best checkpoint")
+    if dist is not None:
+        assert_replicas_identical(model.engine().space.theta)
     return history

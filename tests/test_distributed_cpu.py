@@ -113,3 +113,84 @@ def test_bucketed_all_reduce_equals_flat_sum():
         for r in range(2):
             res = torch.load(result_file + f".{r}")
             assert all(res.values()), res
+
+
+class _FakeArtifactModel:
+    """What make_posterior_mmap asks of a model, with a forward that is a pure function of each variant's OWN rows (torch on the CPU):
+    the rows it produces cannot depend on how the candidates were cut into shards, chunks or batches -- which is the property under
+    test.  (The real forward is the HIP kernels: tests/test_dp_gpu.py runs the same comparison through them.)"""
+
+    class _Reducer:
+        @staticmethod
+        def output_dimension():
+            return 10
+
+    class _Engine:
+        @staticmethod
+        def check_join_fault():
+            return None
+
+    class _Out:
+        pass
+
+    def __init__(self):
+        self._device, self.reducer = torch.device("cpu"), self._Reducer()
+
+    def train(self, mode):
+        return self
+
+    def engine(self):
+        return self._Engine()
+
+    def compute_batch_output(self, batch):
+        from permutect_amd.data.datum import INFO_START_IDX
+        out = self._Out()
+        info = batch.float_tensor[:, INFO_START_IDX:].float()
+        out.logits_b = info.sum(dim=1) * 0.37 + batch.int_tensor[:, 0].float() - 0.5 * batch.int_tensor[:, 1].float()
+        out.features_be = torch.tanh(info[:, :10]) * 3.0 + batch.int_tensor[:, 16:26].float()
+        return out
+
+
+def _posterior_worker(rank, world, init_file, result_file, batch_size, chunk_variants):
+    from permutect_amd.data.memory_mapped_data import MemoryMappedData
+    from permutect_amd.data.reads_dataset import ReadsDataset
+    from permutect_amd.tools.posterior_data import make_posterior_mmap
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ds = ReadsDataset(MemoryMappedData.load_from_tarfile(os.path.join(root, "tests", "golden", "tiny_dataset.tar")))
+    res = make_posterior_mmap(ds, _FakeArtifactModel(), batch_size, device=torch.device("cpu"), chunk_variants=chunk_variants, rank=rank, world_size=world)
+    assert (res is None) == (rank != 0)
+    if rank == 0:
+        np.savez(result_file, ints=np.asarray(res.int_mmap[: len(res)]), floats=np.asarray(res.float_mmap[: len(res)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_posterior_rows_are_bit_identical_to_the_single_process_ones():
+    """SURVEY 8e, the filter: the candidates cut into contiguous shards, one rank each, no collective on the data path, the rows
+    concatenated on rank 0 in dataset order (tools/posterior_data.py: make_posterior_mmap(..., rank, world_size)) -- against the same
+    function in ONE process, for two and three ranks, batches that do and do not divide the shards."""
+    from permutect_amd.data.memory_mapped_data import MemoryMappedData
+    from permutect_amd.data.reads_dataset import ReadsDataset
+    from permutect_amd.tools.posterior_data import make_posterior_mmap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ds = ReadsDataset(MemoryMappedData.load_from_tarfile(os.path.join(root, "tests", "golden", "tiny_dataset.tar")))
+    single = make_posterior_mmap(ds, _FakeArtifactModel(), 7, device=torch.device("cpu"))
+    n = len(single)
+    assert n == len(ds) and n > 20
+    for world, batch_size, chunk in ((2, 7, None), (3, 5, 11)):
+        with tempfile.TemporaryDirectory() as d:
+            init_file, result_file = os.path.join(d, "init"), os.path.join(d, "res.npz")
+            mp.spawn(_posterior_worker, args=(world, init_file, result_file, batch_size, chunk), nprocs=world, join=True)
+            z = np.load(result_file)
+            assert z["ints"].shape[0] == n
+            assert np.array_equal(z["ints"], np.asarray(single.int_mmap[:n]))
+            assert np.array_equal(z["floats"].view(np.uint32), np.asarray(single.float_mmap[:n]).view(np.uint32))  # bit for bit
+
+
+def test_init_from_env_single_process_is_a_no_op(monkeypatch):
+    from permutect_amd.training.distributed import init_from_env
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    d, rank, world, device = init_from_env(device_type="cpu")
+    assert d is None and (rank, world) == (0, 1) and device.type == "cpu"

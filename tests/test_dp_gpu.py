@@ -92,3 +92,64 @@ def test_bench_two_rank_path(extra):
     assert c["world_size"] == 2 and c["backend"] == "gloo" and c["op"] == "SUM"
     assert c["early_buckets_per_step"] == 1.0 and c["early_bytes"] > c["late_bytes"] > 0 and c["early_bucket_on_side_stream"]
     assert "cpu_baseline" not in line and line["filter"]["value"] > 0
+
+
+def _torchrun(module, args, nproc, timeout=300):
+    """`python -m torch.distributed.run --nproc-per-node N -m <module> ...` the way a user launches the tools; N ranks share this box's
+    one card (PMT_DIST_BACKEND=gloo: RCCL wants a device per rank)"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", PMT_DIST_BACKEND="gloo", PMT_JIT="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), "-m", module, *args]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    return res.stdout
+
+
+def test_filter_tool_two_ranks_writes_the_single_process_rows():
+    """`filter_variants` under torchrun -- the candidates in two contiguous shards, one process each through the HIP
+    forward, rank 0 concatenating in dataset order -- writes the posterior tar of the single-process run."""
+    from permutect_amd.architecture.artifact_model import ArtifactModel
+    from permutect_amd.data.memory_mapped_data import MemoryMappedData
+    from permutect_amd.parameters import P0_DIMS, p0_params
+    tar = os.path.join(ROOT, "tests", "golden", "tiny_dataset.tar")
+    with tempfile.TemporaryDirectory() as d:
+        torch.manual_seed(11)
+        model = ArtifactModel(p0_params(), device=torch.device("cuda"), **P0_DIMS)
+        model.save_model(os.path.join(d, "model.pt"))
+        common = ["--test_dataset_tar", tar, "--artifact_model", os.path.join(d, "model.pt"), "--batch_size", "16"]
+        env = dict(os.environ, PMT_JIT="0")
+        one = subprocess.run([sys.executable, "-m", "permutect_amd.tools.filter_variants", *common, "--output", os.path.join(d, "one.tar")],
+                             cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+        assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-4000:]
+        out = _torchrun("permutect_amd.tools.filter_variants", [*common, "--output", os.path.join(d, "two.tar")], 2)
+        assert "on 2 GPU(s)" in out
+        a, b = (MemoryMappedData.load_from_tarfile(os.path.join(d, f)) for f in ("one.tar", "two.tar"))
+        n = len(a)
+        assert n == len(b) and n > 20
+        assert np.array_equal(np.asarray(a.int_mmap[:n]), np.asarray(b.int_mmap[:n]))
+        # the rows' PLACES are exact (integer rows bit for bit; tests/test_distributed_cpu.py shows the concatenation itself bit-identical
+        # with a deterministic forward); the HIP forward's per-set sums are float atomics whose order changes with the batch a variant
+        # sits in, so its numbers agree to the last bits only: the logit through its float16 store, the embedding to 1e-5
+        fa, fb = np.asarray(a.float_mmap[:n]).astype(np.float32), np.asarray(b.float_mmap[:n]).astype(np.float32)
+        assert fa.shape == fb.shape and np.isfinite(fa).all() and np.abs(fa[:, 6:]).max() > 0  # embeddings, not zeros
+        np.testing.assert_allclose(fb[:, :6], fa[:, :6], rtol=1e-3, atol=1e-3)   # (one float16 ulp of a logit of ~12)
+        np.testing.assert_allclose(fb[:, 6:], fa[:, 6:], rtol=1e-5, atol=1e-5)
+
+
+def test_train_tool_two_ranks_keeps_replicas_identical():
+    """`train_artifact_model` under torchrun: the tool itself initialises the process group (training/distributed.py: init_from_env),
+    trains data parallel and ends with the replica check (assert_replicas_identical raises -- a non-zero exit -- when the ranks'
+    parameters differ in a single bit); rank 0 writes a loadable model."""
+    from permutect_amd.architecture.artifact_model import load_model
+    tar = os.path.join(ROOT, "tests", "golden", "tiny_dataset.tar")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "model.pt")
+        args = ["--train_tar", tar, "--output", out, "--read_layers", "30", "-2", "--info_layers", "20", "-2", "--aggregation_layers", "-2", "10",
+                "--self_attention_hidden_dimension", "20", "--num_self_attention_layers", "2", "--num_artifact_clusters", "4",
+                "--calibration_layers", "10", "10", "--ref_seq_layer_strings", "convolution/kernel_size=3/out_channels=32", "pool/kernel_size=2",
+                "leaky_relu", "convolution/kernel_size=3/out_channels=32", "leaky_relu", "flatten", "linear/out_features=10", "--dropout_p", "0.0", "--batch_size", "8", "--num_epochs", "2",
+                "--num_calibration_epochs", "1", "--inference_batch_size", "16", "--learning_rate", "0.001"]
+        stdout = _torchrun("permutect_amd.tools.train_artifact_model", args, 2, timeout=600)
+        assert "epoch 2 TRAIN" in stdout and stdout.count("epoch 1 TRAIN") == 1  # rank 0 alone reports
+        model, _, _ = load_model(out, device=torch.device("cuda"))
+        assert all(torch.isfinite(p).all() for p in model.parameters())
