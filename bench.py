@@ -54,6 +54,10 @@ def note(msg):
 
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_16BIT_MFMA_TFLOPS = 2500.0  # the same guide: bf16 / f16 MFMA, dense (the 5 PF figure includes 2:1 sparsity): the pipe the kernels issue on
+MFMAS_PER_PRODUCT = 3  # an fp32-grade product = three 16-bit MFMAs on two-piece splits of both operands (forward f16, backward bf16)
+MFMA_16x16x32_FLOPS = 2 * 16 * 16 * 32
+SIMDS, SHADER_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs; the nominal shader clock SQ_VALU_MFMA_BUSY_CYCLES is set against
 PEAK_HBM_GBS = 8000.0
 
 
@@ -105,6 +109,25 @@ def committed_parity_sweep():
                             "max_logit_err": rec.get("max_logit_err"), "max_hip_vs_fp64": rec.get("max_hip_vs_fp64"),
                             "max_fp32_oracle_vs_fp64": rec.get("max_fp32_oracle_vs_fp64")}
     return best
+
+
+def pmc_record(kernel, batch, depth):
+    """The committed rocprofv3 --pmc record of `kernel` (profiles/*pmc_traffic*.json, written by scripts/pmc_traffic.py): HBM bytes per
+    launch and, when the SQ pass was given to the script, what the matrix pipe did (SQ_INSTS_MFMA, SQ_VALU_MFMA_BUSY_CYCLES, ...).  The
+    same staleness rule as pmc_traffic: this build of the kernels, this workload, or None."""
+    sha = kernels_sha()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if rec.get("kernels_sha") != sha or rec.get("batch_read_sets") != batch or rec.get("depth") != depth:
+            continue
+        k = rec.get("kernels", {}).get(kernel)
+        if k is not None:
+            return dict(k, source=os.path.relpath(path, ROOT))
+    return None
 
 
 def pmc_traffic(kernel, batch, depth):
@@ -450,13 +473,31 @@ def main():
     fwd_flops = 2.0 * macs * reads_per_batch
 
     def roofline(kernel, flops, ms):
+        """`peak` / `frac`: the dense fp32 MFMA rate -- the roof of the ARITHMETIC the contract asks for (fp32-grade products), and the
+        scale earlier rounds are quoted on.  It is not the roof of the pipe the kernels issue on: they run three 16-bit MFMAs per
+        product, so the scheme's own ceiling is pipe_peak / 3 fp32-equivalent TFLOP/s (`scheme_ceiling`, `frac_of_scheme_ceiling`),
+        and what the matrix pipe really did comes from the committed SQ counters of this build (`executed_mfma_flops`: every MFMA
+        issued, pieces, tile padding and in-kernel recomputation included; `mfma_busy_frac`: the pipe's busy cycles over SIMDs x launch
+        time x the nominal clock).  The counters are a profiled run's (scripts/collect_profiles.sh); None when no record matches this
+        tree's kernels."""
         achieved = flops / (ms * 1e-3) / 1e12
-        traffic = pmc_traffic(kernel, args.batch, args.depth)
+        pmc = pmc_record(kernel, args.batch, args.depth) or {}
+        traffic = pmc.get("hbm_bytes_per_launch")
+        ceiling = PEAK_16BIT_MFMA_TFLOPS / MFMAS_PER_PRODUCT
+        n_mfma, busy = pmc.get("SQ_INSTS_MFMA"), pmc.get("SQ_VALU_MFMA_BUSY_CYCLES")
+        wait, wave = pmc.get("SQ_WAIT_ANY"), pmc.get("SQ_WAVE_CYCLES")
         return {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "kernel": kernel, "kernel_ms": ms,
                 "algorithmic_flops_per_launch": flops, "padded_flops_per_launch": flops * pad_ratio,
                 "frac_padded": achieved * pad_ratio / PEAK_FP32_MFMA_TFLOPS,
-                "hbm_frac": None if traffic is None else traffic / (ms * 1e-3) / (PEAK_HBM_GBS * 1e9)}
+                "hbm_frac": None if traffic is None else traffic / (ms * 1e-3) / (PEAK_HBM_GBS * 1e9),
+                "pipe_peak": PEAK_16BIT_MFMA_TFLOPS, "mfmas_per_product": MFMAS_PER_PRODUCT, "scheme_ceiling": ceiling,
+                "frac_of_scheme_ceiling": achieved / ceiling,
+                "executed_mfma_flops": None if n_mfma is None else n_mfma * MFMA_16x16x32_FLOPS,
+                "executed_over_algorithmic": None if n_mfma is None else n_mfma * MFMA_16x16x32_FLOPS / flops,
+                "mfma_busy_frac": None if busy is None else busy / (SIMDS * ms * 1e-3 * SHADER_GHZ * 1e9),
+                "wait_any_frac": None if not (wait and wave) else wait / wave,
+                "pmc_source": pmc.get("source")}
 
     results = {}
     if args.mode in ("both", "train"):
@@ -647,6 +688,29 @@ def main():
         ep = time.perf_counter() - t
         resident_train = args.batch * args.steps / results["train"][0]
         resident_filter = args.batch * args.steps / results["filter"][0]
+        # ---- the loop the CLI runs: training/model_training.train_artifact_model itself on the 2^20 dataset --
+        # every parent batch downsampled twice on the device, balancer weights, loss recorder, ONE host sync per epoch.  Three training
+        # epochs (the first one warms up: allocator, clocks, loader threads), timed by the epoch lines the loop logs right after its
+        # per-epoch sync; no validation set, no evaluation pass; the downsampler's balance fit (a one-off ~15 s of CPU work in front of
+        # the loop) is skipped: uniform mixture weights.
+        from permutect_amd.parameters import TrainingParameters
+        from permutect_amd.training.model_training import train_artifact_model
+        emodel = ArtifactModel(p0_params(), device=dev, **P0_DIMS)
+        stamps = []
+        train_artifact_model(emodel, ds1, None, TrainingParameters(batch_size=bsz, num_epochs=3, learning_rate=1e-3, weight_decay=0.01, fit_downsampler=False),
+                             chunk_variants=chunk, seed=9, log=lambda msg: stamps.append((time.perf_counter(), msg)), evaluate_every_epoch=False)
+        epoch_s = [b[0] - a[0] for a, b in zip(stamps, stamps[1:])]  # epochs 2 and 3
+        steps_per_epoch = 2 * (-(-(1 << 20) // bsz))
+        epoch_rate = steps_per_epoch * bsz / min(epoch_s)
+        epoch = {"what": "training.model_training.train_artifact_model (the loop tools/train_artifact_model.py runs) on the 2^20-variant dataset: two device "
+                         "downsamplings of every parent batch, balancer, loss recorder, one host sync per epoch; H2D inclusive; read sets counted as "
+                         "optimizer-step batches (2 per parent batch, like the reference's loop: model_training.py:153); best of epochs 2 and 3",
+                 "value": epoch_rate, "unit": "read-sets/s", "epoch_s": epoch_s, "steps_per_epoch": steps_per_epoch,
+                 "ms_per_step": 1e3 * min(epoch_s) / steps_per_epoch, "vs_resident": epoch_rate / resident_train,
+                 "note": "a downsampled batch keeps a Beta-distributed fraction of its parent's reads, so a loop step holds fewer reads than a resident "
+                         "bench step of the same read-set count; vs_resident compares read sets per second"}
+        note(f"epoch loop: {epoch['ms_per_step']:.3f} ms per optimizer step = {epoch['vs_resident']:.2f} x the resident rate (epochs {epoch_s})")
+        del emodel
         loader = {"workload": "batches composed on the device from 2^18-variant chunks that the device chunk loader streams out of a synthetic dataset "
                               "in host memory (H2D inside the timed region); page-locked by ReadsDataset.pin_memory_if_it_fits exactly as "
                               "train_artifact_model / make_posterior_mmap do it", "dataset_page_locked": bool(pinned),
@@ -662,6 +726,34 @@ def main():
              f"{loader['filter']['ms_per_step']:.3f} ms/step = {loader['filter']['vs_resident']:.2f} x resident; with the posterior hand-off "
              f"{n5 / ep / 1e6:.1f} M read-sets/s = {loader['filter_with_posterior_handoff']['vs_resident']:.2f} x")
         del ds1, ds5, post, li, lf, lp
+
+    # ---- N > 1: filter_variants as it is split over GPUs -- the candidates of ONE dataset in N contiguous shards, a rank each,
+    #      no collective on the data path, the shards' posterior rows concatenated on rank 0 (tools/posterior_data.make_posterior_mmap) ----
+    sharded_filter = None
+    if world > 1 and not args.no_extras and args.data == "resident" and args.depth == "wgs" and args.mode == "both":
+        from permutect_amd.data.memory_mapped_data import MemoryMappedData
+        from permutect_amd.data.reads_dataset import ReadsDataset
+        from permutect_amd.tools.posterior_data import make_posterior_mmap
+        n_cand = (1 << 18) * world if not args.rehearse else 1 << 15
+        fi, ff, fp = synth_arrays(np.random.default_rng(6060), n_cand, "wgs")  # the SAME dataset on every rank: each takes its shard
+        dsf = ReadsDataset(MemoryMappedData.from_arrays(fi, ff, fp))
+        fb = min(args.batch, max(1, n_cand // world))
+        make_posterior_mmap(dsf, model, fb, chunk_variants=1 << 18, rank=rank, world_size=world)  # warm-up pass
+        torch.cuda.synchronize()
+        dist.barrier()
+        t = time.perf_counter()
+        post = make_posterior_mmap(dsf, model, fb, chunk_variants=1 << 18, rank=rank, world_size=world)
+        dist.barrier()
+        tt = torch.tensor([time.perf_counter() - t], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            assert post is not None and len(post) == n_cand
+            sharded_filter = {"what": f"make_posterior_mmap over ONE dataset of {n_cand} candidates cut into {world} contiguous shards (a rank each, no "
+                                      "collective on the data path), disk-order rows home on rank 0: loader + forward + posterior rows + the "
+                                      "concatenation, H2D and the host-side gather inclusive",
+                              "value": n_cand / float(tt.item()), "unit": "read-sets/s", "timed_s": float(tt.item()), "candidates": n_cand, "rows_on_rank0": int(len(post))}
+            note(f"sharded filter pass: {n_cand} candidates over {world} ranks in {float(tt.item()):.3f} s")
+        del dsf, post, fi, ff, fp
 
     # ---- a model that is NOT the production shape: the reference's test configuration T0 on its own kernel instances (engine/
     #      instances.py: the library built around its tile counts) against the generic instance every such model used to run ---------
@@ -817,12 +909,15 @@ def main():
                               "step": "compute_batch_output under inference_mode, same resident batches", "roofline": rf}
         if reduce_grads is not None:  # what RCCL saw: the driver can check that N ranks took part and the overlap hook fired
             line["collective"] = reduce_grads.describe()
+        if sharded_filter is not None:
+            line["filter_sharded_dataset"] = sharded_filter
         if small is not None:
             line["small_batch"] = small
         if stress is not None:
             line["stress"] = stress
         if loader is not None:
             line["loader"] = loader
+            line["epoch"] = epoch
         if dropout is not None:
             line["dropout"] = dropout
         if six is not None:

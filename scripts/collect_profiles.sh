@@ -20,6 +20,6 @@ echo "traffic done" >> $out/${tag}_progress.log
 cd $root
 python scripts/pmc_report.py $out/${tag}_pmc_a $out/${tag}_pmc_b > $out/${tag}_pmc_sq_counters.txt
 python scripts/pmc_report.py $out/${tag}_pmc_fetch $out/${tag}_pmc_write > $out/${tag}_pmc_traffic.txt
-python scripts/pmc_traffic.py $out/${tag}_pmc_fetch $out/${tag}_pmc_write 65536 wgs $out/${tag}_pmc_traffic.json > /dev/null
+python scripts/pmc_traffic.py $out/${tag}_pmc_fetch $out/${tag}_pmc_write 65536 wgs $out/${tag}_pmc_traffic.json $out/${tag}_pmc_a > /dev/null
 cp $(ls $out/${tag}_kt/*/*kernel_stats.csv | head -1) $out/${tag}_train_kernel_stats.csv
 echo "all done" >> $out/${tag}_progress.log

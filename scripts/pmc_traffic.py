@@ -35,9 +35,14 @@ def short(name):
     return None
 
 
+SQ_COUNTERS = ("SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_BUSY_CYCLES")
+
+
 def main():
     fetch_dir, write_dir, batch, depth, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    sq_dir = sys.argv[6] if len(sys.argv) > 6 else None  # the SQ pass of scripts/collect_profiles.sh (<tag>_pmc_a): what the matrix pipe did
     fetch, write = means(fetch_dir, "FETCH_SIZE"), means(write_dir, "WRITE_SIZE")
+    sq = {c: means(sq_dir, c) for c in SQ_COUNTERS} if sq_dir else {}
     kernels = {}
     for name in sorted(set(fetch) | set(write)):
         s = short(name)
@@ -45,6 +50,9 @@ def main():
             continue
         f_kb, w_kb = fetch.get(name, 0.0), write.get(name, 0.0)
         kernels[s] = {"fetch_size_kb": f_kb, "write_size_kb": w_kb, "hbm_bytes_per_launch": int(2 * f_kb * 1024 + w_kb * 1024)}
+        for c in SQ_COUNTERS:  # per launch, summed over the chip as rocprofv3 reports them
+            if name in sq.get(c, {}):
+                kernels[s][c] = sq[c][name]
     rec = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 scripts/one_step.py "
                      f"{batch} 3 (batches packed as bench.py packs them), MI355X",
            "correction": "FETCH_SIZE (KB) x 2 for 16-byte-per-lane streaming reads on gfx950 (MI355X_MICROARCH.md, HBM section); "

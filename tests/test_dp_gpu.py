@@ -94,6 +94,14 @@ def test_bench_two_rank_path(extra):
     assert "cpu_baseline" not in line and line["filter"]["value"] > 0
 
 
+def test_bench_two_rank_sharded_filter_pass():
+    """bench.py's N > 1 line also carries the filter as it is split over GPUs: one dataset, a contiguous shard per rank, the posterior
+    rows concatenated on rank 0 (`filter_sharded_dataset`)."""
+    line = _bench_line("--gpus", "2", "--rehearse", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--batch", "4096")
+    f = line["filter_sharded_dataset"]
+    assert line["n_gpus"] == 2 and f["rows_on_rank0"] == f["candidates"] > 0 and f["value"] > 0
+
+
 def _torchrun(module, args, nproc, timeout=300):
     """`python -m torch.distributed.run --nproc-per-node N -m <module> ...` the way a user launches the tools; N ranks share this box's
     one card (PMT_DIST_BACKEND=gloo: RCCL wants a device per rank)"""
