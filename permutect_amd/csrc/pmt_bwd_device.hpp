@@ -843,6 +843,82 @@ DEV void linear_op_backward(BwdCtx& c, const PmtOp& o, f4 (&dy)[PMT_RT][NTO], co
     }
 }
 
+// Backward of a skip block of THREE or FOUR layers (generic instances; the reference takes any depth, mlp.py:15-22):
+//   p_0 = x,  p_k = D_k(b_k + W_k selu(p_{k-1})),  y = x + alpha p_n        (D_k: the step's dropout mask behind Linear k, if any)
+// walked from the last layer to the first.  Layer k needs s_{k-1} = selu(p_{k-1}) twice -- as the input of its weight gradient and for
+// the SELU derivative that carries d(s_{k-1}) on to layer k - 1 -- and gets it by re-running layers 1 .. k - 1 from the stashed x:
+// n (n - 1) / 2 recomputed products per block (the two-layer path's one), no intermediate of the block in the stash.  Four register
+// arrays at most: dy, the running d(p_k), the chain's two.
+template <int NT, bool DROP, typename LoadInput>
+DEV void skip_block_backward_deep(BwdCtx& c, const PmtOp& o, int op, f4 (&dy)[PMT_RT][NT], LoadInput load_input) {
+    const PmtModel* M = c.M;
+    const int nl = uniform(o.n_layers);
+    const bool dropping = DROP && c.drop != nullptr && c.drop->on != 0;
+    const int width = uniform(M->lin[uniform(o.lin[0])].in_dim);
+    const float alpha = uniform(c.theta[uniform(o.alpha_src)]);
+    f4 d[PMT_RT][NT];  // gradient w.r.t. Linear k's own output: for k = n per unit of alpha (the weight gradient takes alpha as its scale)
+#pragma unroll
+    for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) d[rt][t] = dy[rt][t];
+    if (dropping) drop_apply<NT>(*c.drop, uniform(o.lin[nl - 1]), d, c.g);
+    for (int k = nl; k >= 1; --k) {
+        const PmtLinear& Lk = M->lin[uniform(o.lin[k - 1])];
+        f4 p[PMT_RT][NT];
+        load_input(op, p);
+        for (int j = 1; j < k; ++j) {
+            const PmtLinear& Lj = M->lin[uniform(o.lin[j - 1])];
+            f4 q[PMT_RT][NT];
+            init_bias<NT>(q, c.packed + uniform(Lj.b_pvec), width, c.g);
+            linear_acc<NT, NT, true, false>(q, p, c.packed + uniform(Lj.w_frag), width, width);
+            if (dropping) drop_apply<NT>(*c.drop, uniform(o.lin[j - 1]), q, c.g);
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) p[rt][t] = q[rt][t];
+        }
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) p[rt][t] = selu4(p[rt][t]);  // s_{k-1}
+        linear_wgrad<NT, NT, 0>(c, Lk, d, p, k == nl ? alpha : 1.0f);
+        f4 ds[PMT_RT][NT];
+        init_bias<NT>(ds, nullptr, width, c.g);
+        linear_acc<NT, NT, false, false>(ds, d, c.packed + uniform(Lk.wt_frag), width, width);
+        if (k == nl) {  // d(alpha) = sum dy . p_n = sum (W_n^T d) . s_{n-1} + sum d . b_n  (the forward product is never formed)
+            float da = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f4 bn = load_pvec(c.packed + uniform(Lk.b_pvec), t, c.g);
+#pragma unroll
+                for (int rt = 0; rt < PMT_RT; ++rt) {
+                    const f4 v = ds[rt][t] * p[rt][t] + d[rt][t] * bn;
+                    da += (v[0] + v[1]) + (v[2] + v[3]);
+                }
+            }
+            aux_push_scalar(c, uniform(o.alpha_src), da);
+        }
+        const float sc = k == nl ? alpha : 1.0f;
+#pragma unroll
+        for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) ds[rt][t] = sc * selu_bwd4(ds[rt][t], p[rt][t]);  // d(p_{k-1})
+        if (k > 1) {
+            if (dropping) drop_apply<NT>(*c.drop, uniform(o.lin[k - 2]), ds, c.g);
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) d[rt][t] = ds[rt][t];
+        } else {
+#pragma unroll
+            for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) dy[rt][t] = dy[rt][t] + ds[rt][t];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // backward of one MLP program.  dy (in/out): gradient w.r.t. the MLP output on entry, w.r.t. its input on exit
 // (not computed for op 0 when need_input_grad is false).  in_slot(op) gives the stash slot of op's input.
 template <int NT, bool EXACT, int W = 0, int BF = 0, bool DROP = !EXACT, typename LoadInput>
@@ -886,6 +962,12 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
             // Register discipline: at most three width-sized arrays are live at once (dy + two); s0 = selu(x) is
             // recomputed from a second read of the stashed x instead of being kept across the L2 phase.
             const int nl = uniform(o.n_layers);
+            if constexpr (!EXACT) {
+                if (nl > 2) {  // three and four layers: generic instances only (pmt_shape_id)
+                    skip_block_backward_deep<NT, DROP>(c, o, op, dy, load_input);
+                    continue;
+                }
+            }
             const PmtLinear& L1 = M->lin[uniform(o.lin[0])];
             const PmtLinear& L2 = M->lin[uniform(o.lin[nl - 1])];
             const int width = W ? W : uniform(L1.in_dim);

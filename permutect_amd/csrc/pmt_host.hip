@@ -74,6 +74,7 @@ static bool mlp_ops_have_tiles(const PmtModel* m, const PmtMlp* mlp, int first, 
     for (int i = first; i < last; ++i) {
         const PmtOp* o = &mlp->ops[i];
         const int nl = o->kind == PMT_OP_SKIP ? o->n_layers : 1;
+        if (nl > 2) return false;  // (skip blocks of three and four layers: the generic instances' interpreter only)
         for (int k = 0; k < nl; ++k) {
             const PmtLinear* L = &m->lin[o->lin[k]];
             if (tiles_of(L->in_dim) != nt || tiles_of(L->out_dim) != nt) return false;
@@ -136,7 +137,7 @@ static int check_mlp(const PmtModel* m, const PmtMlp* mlp, int max_in = PMT_MAX_
             if (rc) return rc;
             width = out;
         } else if (o->kind == PMT_OP_SKIP) {
-            if (o->n_layers < 1 || o->n_layers > 2) return PMT_E_UNSUPPORTED;  /* two live register arrays */
+            if (o->n_layers < 1 || o->n_layers > PMT_MAX_SKIP_LAYERS) return PMT_E_UNSUPPORTED;  /* (three and four: the generic instances, pmt_shape_id) */
             if (o->alpha_src < 0) return PMT_E_INVALID;
             for (int k = 0; k < o->n_layers; ++k) {
                 const int rc = check_linear(m, o->lin[k], width, width);

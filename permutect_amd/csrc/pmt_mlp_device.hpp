@@ -75,12 +75,24 @@ DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_
             const int width = W ? W : uniform(M->lin[uniform(o.lin[0])].in_dim);
             const float alpha = uniform(theta[uniform(o.alpha_src)]);
             f4 f[PMT_RT][NT];
-            if (nl == 2) {
+            if (nl >= 2) {
                 const PmtLinear& L1 = M->lin[uniform(o.lin[0])];
                 init_bias<NT>(y, packed + uniform(L1.b_pvec), width, g);
                 if constexpr (BF) linear_acc_mx<NT, NT, true, BF>(y, x, packed, L1);
                 else linear_acc<NT, NT, true, EXACT, W>(y, x, packed + uniform(L1.w_frag), width, width);
                 drop_apply<NT>(*drop, uniform(o.lin[0]), y, g);
+                if constexpr (!EXACT) {  // blocks of three and four layers (generic instances only: pmt_shape_id): the layers in between
+                    for (int k = 1; k < nl - 1; ++k) {
+                        const PmtLinear& Lk = M->lin[uniform(o.lin[k])];
+                        init_bias<NT>(f, packed + uniform(Lk.b_pvec), width, g);
+                        linear_acc<NT, NT, true, false>(f, y, packed + uniform(Lk.w_frag), width, width);
+                        drop_apply<NT>(*drop, uniform(o.lin[k]), f, g);
+#pragma unroll
+                        for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) y[rt][t] = f[rt][t];
+                    }
+                }
             } else {
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
@@ -97,7 +109,7 @@ DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_
 #pragma unroll
                 for (int t = 0; t < NT; ++t) x[rt][t] = x[rt][t] + alpha * f[rt][t];
         } else {
-            // x + alpha * f(x) with one or two (SELU, Linear) layers.  Only two register arrays are live: the last
+            // x + alpha * f(x) with one or two (generic instances: up to four) (SELU, Linear) layers.  Two register arrays are live: the last
             // layer accumulates straight into x, with alpha folded into its B operand and bias.
             const int nl = uniform(o.n_layers);
             const int width = W ? W : uniform(M->lin[uniform(o.lin[0])].in_dim);
@@ -112,6 +124,21 @@ DEV void run_mlp(const PmtModel* __restrict__ M, const PmtMlp& mlp, f4 (&x)[PMT_
                 init_bias<NT>(y, st1 + (uniform(L1.b_pvec) - uniform(L1.w_frag)), width, g);
                 if constexpr (BF) linear_acc_mx<NT, NT, true, BF>(y, x, packed, L1);
                 else linear_acc<NT, NT, true, EXACT, W>(y, x, st1, width, width);
+                if constexpr (!EXACT) {
+                    // Blocks of three and four (SELU, Linear) layers (reference mlp.py:15-22 takes any depth): the layers between the first
+                    // and the last, one more register array while they run.  Generic instances only -- a model with such a block has
+                    // pmt_shape_id 0 -- so that the exact instances keep their two live arrays (and their register budget).
+                    for (int k = 1; k < nl - 1; ++k) {
+                        const PmtLinear& Lk = M->lin[uniform(o.lin[k])];
+                        f4 y2[PMT_RT][NT];
+                        init_bias<NT>(y2, packed + uniform(Lk.b_pvec), width, g);
+                        linear_acc<NT, NT, true, false>(y2, y, packed + uniform(Lk.w_frag), width, width);
+#pragma unroll
+                        for (int rt = 0; rt < PMT_RT; ++rt)
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) y[rt][t] = y2[rt][t];
+                    }
+                }
             }
             const PmtLinear& L2 = M->lin[uniform(o.lin[nl - 1])];
             const float alpha = uniform(theta[uniform(o.alpha_src)]);

@@ -58,6 +58,8 @@ def exact_shape_of(desc: L.PmtModel) -> Optional[Tuple[int, ...]]:
     def ops_fill(mlp, lo, hi, nt):
         for i in range(lo, hi):
             o = mlp.ops[i]
+            if o.kind == L.OP_SKIP and o.n_layers > 2:  # (skip blocks of three and four layers run the generic instances: pmt_shape_id)
+                return False
             for k in range(o.n_layers if o.kind == L.OP_SKIP else 1):
                 ln = desc.lin[o.lin[k]]
                 if _tiles(ln.in_dim) != nt or _tiles(ln.out_dim) != nt:
@@ -194,7 +196,8 @@ def library_for(desc: L.PmtModel, log=print) -> C.CDLL:
     shape = exact_shape_of(desc)
     if shape is None:
         warnings.warn("permutect_amd: this model cannot run on tile-exact kernel instances (the read MLP must start and the reducer end with a "
-                      "Linear, and each MLP keep one tile count); it runs the GENERIC instance (fp32 MFMAs, ~2x slower)")
+                      "Linear, each MLP keep one tile count, skip blocks hold at most two layers); it runs the GENERIC instance (fp32 MFMAs, "
+                      "~2x slower)")
         return generic()
     # a library with the model's tile counts: its widths first, then any other widths (pmt_shape_id 6: widths at run time)
     dirs = ([cache_dir()] if cache_dir() else []) + [INSTANCE_DIR]

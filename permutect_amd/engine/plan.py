@@ -339,8 +339,8 @@ class EnginePlan:
                 o.lin[0] = self._add_linear(op[1], max_in=max_in if j == 0 else L.MAX_WIDTH_WIDE, bn=bn_of.get(op[1]))
             else:
                 blk, lins = op[1], op[2]
-                if len(lins) > 2:
-                    raise L.PmtError("skip blocks deeper than 2 layers are not supported by the gfx950 kernels")
+                if len(lins) > L.MAX_SKIP_LAYERS:  # (three and four layers: the generic instances' interpreter, pmt_shape_id 0)
+                    raise L.PmtError(f"skip blocks deeper than {L.MAX_SKIP_LAYERS} layers are not supported by the gfx950 kernels")
                 o.kind, o.n_layers, o.selu_after = L.OP_SKIP, len(lins), 0
                 o.alpha_src = self.space.offset_of(blk.alpha)
                 for t, lin in enumerate(lins):

@@ -51,6 +51,8 @@ def make_model(kind, seed, perturb=0.05, num_sources=1, cnn=None):
     torch.manual_seed(seed)
     if kind == "T0":
         p = ModelParameters([10, 10, 10], 20, 2, [10, 10], [20, 20, 20], 4, [10, 10, 10], list(cnn or T0_CNN), 0.0, 0.3, False)
+    elif kind == "SKIP34":  # skip blocks of three and four layers (the reference takes any depth: architecture/mlp.py:15-22)
+        p = ModelParameters([30, -3, -2], 20, 2, [20, -3], [-4, 10], 4, [10, 10], list(cnn or P0_CNN), 0.0, 0.3, False)
     elif kind in ("WIDE", "WIDE64"):  # layers beyond 64: read width 48, info width 40 -> d_model 98, a 98-wide reducer, d_ffn 32 (64), feature_dim 20
         p = ModelParameters([48, -2], 64 if kind == "WIDE64" else 32, 2, [40, -1], [-1, 20], 4, [10, 10], list(cnn or P0_CNN), 0.0, 0.3, False)
     else:
@@ -533,8 +535,18 @@ def make_wide_fixture():
     run_case("wide64_d98", make_model("WIDE64", 99), make_data(rng, counts))
 
 
+def make_skip_depth_fixture():
+    """p0_skip34: skip blocks of three and four layers in the read MLP, the info MLP and the reducer (its own random streams)"""
+    rng = np.random.default_rng(34)
+    random.seed(34)
+    counts = [(int(rng.integers(0, 11)), int(rng.integers(1, 16))) for _ in range(12)] + [(25, 30), (0, 9)]
+    run_case("p0_skip34", make_model("SKIP34", 34), make_data(rng, counts))
+
+
 if __name__ == "__main__":
-    if "--wide-only" in sys.argv:
+    if "--skip-depth-only" in sys.argv:
+        make_skip_depth_fixture()
+    elif "--wide-only" in sys.argv:
         make_wide_fixture()
     elif "--cnn-batchnorm-only" in sys.argv:
         make_cnn_batchnorm_eval_fixture()

@@ -8,20 +8,24 @@ from oracle import artifact_oracle as O
 from permutect_amd.parameters import P0_CNN, P0_CNN_BATCHNORM, P0_CNN_LEGACY, T0_CNN, T0_CNN_OPTIONS
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["t0_b8", "p0_b16", "p0_zero_ref", "p0_saturated", "p0_deep", "t0_two_sources", "wide_d98", "wide64_d98"]
-# wide_d98: layers beyond 64 (the wide builds of the library); wide64_d98: the same with d_ffn = 64 (two tiles per half of the gated blocks' hidden layer)
+CASES = ["t0_b8", "p0_b16", "p0_zero_ref", "p0_saturated", "p0_deep", "t0_two_sources", "wide_d98", "wide64_d98", "p0_skip34"]
+# p0_skip34: skip blocks of three and four layers (generic instances); wide_d98: layers beyond 64 (the wide builds of the library); wide64_d98: the same with d_ffn = 64 (two tiles per half of the gated blocks' hidden layer)
 CNN_CASES = ["p0_cnn_legacy", "t0_cnn_options"]  # haplotype-CNN stacks beyond the two of CASES (tests/golden/make_golden.py: make_cnn_fixtures)
 CNN_STACKS = {"p0_cnn_legacy": P0_CNN_LEGACY, "t0_cnn_options": T0_CNN_OPTIONS, "p0_cnn_batchnorm_eval": P0_CNN_BATCHNORM}
 
 
 def params_for(name: str):
     """the model hyperparameters of a fixture (tests/golden/make_golden.py: make_model)"""
-    from permutect_amd.parameters import p0_params, t0_params, wide64_params, wide_params
+    from permutect_amd.parameters import ModelParameters, P0_CNN as _CNN, p0_params, t0_params, wide64_params, wide_params
+    if name == "p0_skip34":
+        return ModelParameters([30, -3, -2], 20, 2, [20, -3], [-4, 10], 4, [10, 10], list(_CNN), 0.0, 0.3)
     return t0_params() if name.startswith("t0") else wide64_params() if name.startswith("wide64") else wide_params() if name.startswith("wide") else p0_params()
 
 
 def config_for(name: str) -> O.Config:
-    if name.startswith("t0"):
+    if name == "p0_skip34":
+        cfg = O.Config([30, -3, -2], [20, -3], [-4, 10], 20, 2, 4, list(P0_CNN), 61, 71, 42)
+    elif name.startswith("t0"):
         cfg = O.Config([10, 10, 10], [10, 10], [20, 20, 20], 20, 2, 4, list(T0_CNN), 61, 71, 42)
     elif name.startswith("wide"):
         cfg = O.Config([48, -2], [40, -1], [-1, 20], 64 if name.startswith("wide64") else 32, 2, 4, list(P0_CNN), 61, 71, 42)
