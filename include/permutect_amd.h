@@ -30,6 +30,7 @@ extern "C" {
 /* bits of the fault word (PmtBatch.join_fault) */
 #define PMT_FAULT_JOIN 1
 #define PMT_FAULT_F16_RANGE 2
+#define PMT_FAULT_PLAN 4        /* pmt_plan_groups_device: more groups than the capacity given, or a read set beyond one workgroup */
 
 /* error codes */
 #define PMT_OK 0
@@ -302,7 +303,8 @@ int pmt_limits(int32_t* four);
 int pmt_build_id(char* out, int32_t capacity);
 
 /* sizeof() of the ABI structs as compiled into the library, for binding self-checks:
- * 0 PmtModel, 1 PmtBatch, 2 PmtOutputs, 3 PmtOutputGrads, 4 PmtAdamW, 5 PmtLinear, 6 PmtOp, 7 PmtMlp, 8 PmtBlock, 9 PmtHead */
+ * 0 PmtModel, 1 PmtBatch, 2 PmtOutputs, 3 PmtOutputGrads, 4 PmtAdamW, 5 PmtLinear, 6 PmtOp, 7 PmtMlp, 8 PmtBlock, 9 PmtHead,
+ * 10 PmtPhiProgram, 11 PmtLossArgs, 12 PmtDownsample, 13 PmtRecordArgs, 14 PmtBalanceArgs */
 int pmt_struct_bytes(int which);
 
 /* Validates a descriptor against the kernels' limits. */
@@ -339,6 +341,20 @@ int pmt_phi_forward(const PmtPhiProgram* prog, const float* theta, float* phi, v
 int pmt_phi_backward(const PmtPhiProgram* prog, const float* theta, const float* phi, const float* grad_phi,
                      float* grad_theta, void* stream);
 
+/* One integer column of a batch as the caller holds it: element i at ptr + i * stride elements of elem_bytes (4: int32, 8: int64)
+ * -- a column of Batch.int_tensor (int64, row stride), a DownsampledBatch's own counts (int32, dense).  ptr NULL = all zeros. */
+typedef struct PmtIntColumn {
+    const void* ptr;
+    int64_t stride;
+    int32_t elem_bytes, reserved;
+} PmtIntColumn;
+
+/* The (source, label, variant type, ref-count bin, alt-count bin) cell of a variant (reference data/batch.py:228-230,
+ * data/count_binning.py:9-26): what the balancer's and the downsampler's tables are indexed by. */
+typedef struct PmtBinning {
+    int32_t num_sources, num_variant_types, num_ref_bins, num_alt_bins, count_bin_skip, max_ref_count, max_alt_count, reserved;
+} PmtBinning;
+
 /* Read downsampling of a training batch (reference data/batch.py:389-439, training/downsampler.py:105-123). */
 typedef struct PmtDownsample {
     int32_t num_variants;
@@ -351,6 +367,13 @@ typedef struct PmtDownsample {
     const float* alt_weights_b4;
     const float* ref_fracs_in;      /* [B] keep fractions given by the caller (then no fractions are drawn), or NULL */
     const float* alt_fracs_in;
+    /* The mixture weights looked up by the kernel itself (then *_weights_b4 are NULL): the Downsampler's tables [S][3][V][R][A][4]
+     * (exp of its log-weights, reference training/downsampler.py:105-112) indexed by the variant's cell -- its label, variant type and
+     * source columns and the bins of its PARENT counts (the offsets above).  Replaces ~25 torch launches per training step. */
+    const float* ref_weight_table;
+    const float* alt_weight_table;
+    PmtIntColumn labels, variant_types, sources;
+    PmtBinning bins;
 } PmtDownsample;
 /* Launch 1: draw the keep fractions (unless given) and count the kept reads per variant. */
 int pmt_downsample_counts(const PmtDownsample* args, float* ref_fracs, float* alt_fracs, int32_t* new_ref_counts,
@@ -403,11 +426,7 @@ int pmt_losses_backward(const PmtLossArgs* args, const PmtLossOutputs* grad_out,
 typedef struct PmtRecordArgs {
     int32_t num_variants, num_bins;                 /* num_bins = S * 3 * V * R * A */
     int32_t num_variant_types, num_ref_bins, num_alt_bins, count_bin_skip, max_ref_count, max_alt_count;
-    const int64_t* labels;        int64_t label_stride;
-    const int64_t* variant_types; int64_t variant_type_stride;
-    const int64_t* sources;       int64_t source_stride;        /* NULL = source 0 */
-    const int64_t* ref_counts;    int64_t ref_count_stride;
-    const int64_t* alt_counts;    int64_t alt_count_stride;
+    PmtIntColumn labels, variant_types, sources, ref_counts, alt_counts;   /* (sources.ptr NULL = source 0; int32 or int64 columns as the batch holds them) */
     const float* weights;         /* [B] BatchOutput.weights */
     const float* source_weights;  /* [B] */
     const float* supervised_b;    /* [B] the four loss vectors of pmt_losses_forward */
@@ -416,6 +435,37 @@ typedef struct PmtRecordArgs {
     const float* source_b;
 } PmtRecordArgs;
 int pmt_record_losses(const PmtRecordArgs* args, float* histograms, void* stream);
+
+/* The balancer's step (reference training/balancer.py:55-119 `process_batch_and_compute_weights`): running counts per cell, pseudo-counts
+ * of the unlabeled data from the model's artifact probability, the weight tables re-derived from them (when `recompute`: the reference
+ * does it every DATA_BEFORE_RECOMPUTE variants) and this batch's weights looked up -- ~60 torch launches per training step in two:
+ *   launch 1: counts[cell] += 1; unlabeled variants: pseudo_counts[cell as artifact] += p, [cell as variant] += 1 - p
+ *             (p = sigmoid(logits_b); a workgroup's additions are joined in LDS first);
+ *   launch 2: tables_out = recompute ? att * tables_in + (1 - att) * clip((1 + ratio^-+1) / 2, 0.01, 100) : tables_in with
+ *             ratio = (counts[artifact] + 0.01) / (counts[variant] + 0.01) per cell (every workgroup derives the tables it reads from,
+ *             workgroup 0 stores them), then weights_b = labeled ? weights[cell] : p * unlabeled_weights[cell as artifact] +
+ *             (1 - p) * unlabeled_weights[cell as variant], and source_weights_b = weights_b * source_weights[source]
+ *             (BatchOutput.weights / .source_weights of reference artifact_model.py:285-288).
+ * tables_in and tables_out must be different buffers when recompute != 0 (the caller swaps them). */
+typedef struct PmtBalanceArgs {
+    int32_t num_variants, recompute;
+    float attenuation;                  /* ATTENUATION_PER_DATUM ^ (variants since the last recomputation) */
+    int32_t reserved;
+    PmtBinning bins;
+    PmtIntColumn labels, variant_types, sources, ref_counts, alt_counts;
+    const float* logits_b;              /* [B] capped artifact logits of this batch */
+    float* counts;                      /* [S][3][V][R][A] running counts (added to) */
+    float* pseudo_counts;
+    const float* weights_in;            /* the three tables before this step: [S][3][V][R][A], the same, [S] */
+    const float* unlabeled_weights_in;
+    const float* source_weights_in;
+    float* weights_out;                 /* ... after it */
+    float* unlabeled_weights_out;
+    float* source_weights_out;
+    float* weights_b;                   /* [B] out */
+    float* source_weights_b;            /* [B] out: weights_b * the source's weight */
+} PmtBalanceArgs;
+int pmt_balance_step(const PmtBalanceArgs* args, void* stream);
 
 /* The float rows of the posterior hand-off, one launch per batch (reference tools/filter_variants.py:302-320 builds a Datum per
  * variant in Python: `set(CACHED_ARTIFACT_LOGIT, logit)` stores the logit through the float16 scalar array, `set_info_1d(embedding)`
@@ -434,6 +484,17 @@ int pmt_posterior_rows(const float* float_rows, int64_t float_stride, int32_t n_
  * (*bad_variant receives its index). */
 int pmt_plan_groups(const int32_t* ref_counts, const int32_t* alt_counts, int32_t num_variants,
                     int32_t* group_start, int32_t* group_tile_base, int32_t* bad_variant);
+
+/* pmt_plan_groups on the DEVICE, from exclusive scans of the counts that live there (a DownsampledBatch's: how many reads it keeps is
+ * decided by pmt_downsample_counts and never comes to the host): one launch, stream-ordered.  The batch is cut into
+ * pmt_plan_device_chunks(num_variants) chunks of consecutive variants, each packed next-fit like pmt_plan_groups (a chunk boundary closes
+ * a group).  group_start / group_tile_base: device, capacity + 1 ints; num_groups_dev: device, [1] -- PmtBatch.num_groups_dev of the
+ * launches that use the plan, whose PmtBatch.num_groups is then `capacity` (the grid).  capacity >= the groups of ANY plan of larger
+ * counts in the same order + the number of chunks is always enough; an overflow, or a read set beyond one workgroup, sets
+ * PMT_FAULT_PLAN in *fault (may be NULL).  The reference has no counterpart (its ATen kernels need no plan). */
+int pmt_plan_groups_device(const int32_t* ref_offsets, const int32_t* alt_offsets, int32_t num_variants, int32_t* group_start,
+                           int32_t* group_tile_base, int32_t capacity, int32_t* num_groups_dev, int32_t* fault, void* stream);
+int pmt_plan_device_chunks(int32_t num_variants);
 
 /* An order of the batch's variants in which pmt_plan_groups packs fuller groups (a workgroup costs the same full or not, so
  * the number of groups is what a batch costs): the group under construction takes, out of the next `window` unplaced

@@ -202,6 +202,8 @@ class ArtifactModel(nn.Module):
         (logits_b, logits_bk, feats, ref_feats), _ = self._encode(batch)
         if balancer is None:
             weights_b = source_weights = torch.ones_like(logits_b)  # (1 * 1: one fill instead of two and a product)
+        elif logits_b.is_cuda and hasattr(balancer, "weights_from_logits"):
+            weights_b, source_weights = balancer.weights_from_logits(batch, logits_b)  # two launches (pmt_balance_step)
         else:
             weights_b, source_weights_b = balancer.process_batch_and_compute_weights(
                 batch, artifact_probs_b=torch.sigmoid(logits_b).detach())

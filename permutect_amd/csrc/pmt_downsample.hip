@@ -56,30 +56,58 @@ __device__ __forceinline__ bool keep_alt(const PmtDownsample& a, long long alt_r
 // the reference forces alt read  alt_end - (random_int % alt_count) - 1  of every variant (data/batch.py:418-421)
 __device__ __forceinline__ long long forced_alt(const PmtDownsample& a, int a0, int na) { return na > 0 ? (long long)a0 + na - 1 - (a.force_random % na) : -1; }
 
-__global__ __launch_bounds__(64) void pmt_downsample_counts_kernel(PmtDownsample a, float* __restrict__ ref_fracs,
-                                                                   float* __restrict__ alt_fracs, int* __restrict__ new_ref,
-                                                                   int* __restrict__ new_alt) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    float fr, fa;
-    if (a.ref_fracs_in != nullptr) {
-        fr = a.ref_fracs_in[b];
-        fa = a.alt_fracs_in[b];
-    } else {
-        const int kr = pick_component(a.ref_weights_b4 ? a.ref_weights_b4 + 4 * (size_t)b : nullptr, uniform01(a.seed, 0, b));
-        const int ka = pick_component(a.alt_weights_b4 ? a.alt_weights_b4 + 4 * (size_t)b : nullptr, uniform01(a.seed, 1, b));
-        fr = beta_sample(kr, a.seed, 32, b);
-        fa = beta_sample(ka, a.seed, 64, b);
+__device__ __forceinline__ long long ds_col_at(const PmtIntColumn& c, int i) {
+    if (c.ptr == nullptr) return 0;
+    return c.elem_bytes == 8 ? reinterpret_cast<const long long*>(c.ptr)[(size_t)i * c.stride]
+                             : (long long)reinterpret_cast<const int*>(c.ptr)[(size_t)i * c.stride];
+}
+
+// SIXTEEN lanes per variant (a WGS read set has at most 10 + 15 reads; deeper ones loop), sixteen variants per workgroup of 256.  The
+// first version spent a whole 64-lane workgroup on every variant and drew the two Beta fractions in all 64 lanes: 119 us per
+// 65 536-variant step for 850 K keep decisions.  The random STREAMS are unchanged (a decision is a function of (seed, stream, row)).
+#define DS_THREADS 256
+#define DS_LANES 16
+__global__ __launch_bounds__(DS_THREADS) void pmt_downsample_counts_kernel(PmtDownsample a, float* __restrict__ ref_fracs,
+                                                                           float* __restrict__ alt_fracs, int* __restrict__ new_ref,
+                                                                           int* __restrict__ new_alt) {
+    const int sub = threadIdx.x & (DS_LANES - 1);
+    const int b = blockIdx.x * (DS_THREADS / DS_LANES) + threadIdx.x / DS_LANES;
+    const bool live = b < a.num_variants;
+    const int bb = live ? b : 0;
+    const int r0 = a.ref_offsets[bb], nr = a.ref_offsets[bb + 1] - r0, a0 = a.alt_offsets[bb], na = a.alt_offsets[bb + 1] - a0;
+    float fr = 0.f, fa = 0.f;
+    if (sub < 2 && live) {  // lane 0 draws the ref fraction, lane 1 the alt fraction
+        if (a.ref_fracs_in != nullptr) {
+            fr = sub == 0 ? a.ref_fracs_in[b] : a.alt_fracs_in[b];
+        } else {
+            const float* w4 = sub == 0 ? a.ref_weights_b4 : a.alt_weights_b4;
+            if (w4 != nullptr) {
+                w4 += 4 * (size_t)b;
+            } else if (a.ref_weight_table != nullptr) {  // the variant's cell of the Downsampler's tables: PARENT counts (data/batch.py:228-230)
+                const PmtBinning& g = a.bins;
+                const int rbin = min(nr, g.max_ref_count) / g.count_bin_skip, abin = (min(na, g.max_alt_count) - 1) / g.count_bin_skip;
+                const long long cell = (((ds_col_at(a.sources, b) * 3 + ds_col_at(a.labels, b)) * g.num_variant_types + ds_col_at(a.variant_types, b)) *
+                                        g.num_ref_bins + rbin) * g.num_alt_bins + abin;
+                w4 = (sub == 0 ? a.ref_weight_table : a.alt_weight_table) + 4 * cell;
+            }
+            const int k = pick_component(w4, uniform01(a.seed, sub, b));
+            fr = beta_sample(k, a.seed, sub == 0 ? 32 : 64, b);
+        }
     }
-    const int r0 = a.ref_offsets[b], nr = a.ref_offsets[b + 1] - r0, a0 = a.alt_offsets[b], na = a.alt_offsets[b + 1] - a0;
+    // (sub-groups of 16 lanes inside a wave: width-16 shuffles)
+    fa = __shfl(fr, 1, DS_LANES);
+    fr = __shfl(fr, 0, DS_LANES);
     const long long forced = forced_alt(a, a0, na);
     int cr = 0, ca = 0;
-    for (int i = lane; i < nr; i += 64) cr += keep_ref(a, (long long)r0 + i, fr) ? 1 : 0;
-    for (int i = lane; i < na; i += 64) ca += keep_alt(a, (long long)a0 + i, fa, forced) ? 1 : 0;
-    for (int d = 32; d > 0; d >>= 1) {
-        cr += __shfl_xor(cr, d);
-        ca += __shfl_xor(ca, d);
+    if (live) {
+        for (int i = sub; i < nr; i += DS_LANES) cr += keep_ref(a, (long long)r0 + i, fr) ? 1 : 0;
+        for (int i = sub; i < na; i += DS_LANES) ca += keep_alt(a, (long long)a0 + i, fa, forced) ? 1 : 0;
     }
-    if (lane == 0) {
+    for (int d = DS_LANES / 2; d > 0; d >>= 1) {
+        cr += __shfl_xor(cr, d, DS_LANES);
+        ca += __shfl_xor(ca, d, DS_LANES);
+    }
+    if (sub == 0 && live) {
         ref_fracs[b] = fr;
         alt_fracs[b] = fa;
         new_ref[b] = cr;
@@ -130,8 +158,17 @@ extern "C" int pmt_downsample_counts(const PmtDownsample* args, float* ref_fracs
     if (rc) return rc;
     if (!ref_fracs || !alt_fracs || !new_ref_counts || !new_alt_counts) return PMT_E_INVALID;
     if (args->num_variants == 0) return PMT_OK;
-    hipLaunchKernelGGL(pmt_downsample_counts_kernel, dim3(args->num_variants), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), *args,
-                       ref_fracs, alt_fracs, new_ref_counts, new_alt_counts);
+    if (args->ref_weight_table != nullptr || args->alt_weight_table != nullptr) {
+        const PmtBinning& g = args->bins;
+        if (!args->ref_weight_table || !args->alt_weight_table || !args->labels.ptr || !args->variant_types.ptr || g.count_bin_skip < 1 ||
+            g.num_variant_types < 1 || g.num_ref_bins < 1 || g.num_alt_bins < 1)
+            return PMT_E_INVALID;
+        for (const PmtIntColumn* c : {&args->labels, &args->variant_types, &args->sources})
+            if (c->ptr != nullptr && c->elem_bytes != 4 && c->elem_bytes != 8) return PMT_E_INVALID;
+    }
+    const int per_block = DS_THREADS / DS_LANES;
+    hipLaunchKernelGGL(pmt_downsample_counts_kernel, dim3((args->num_variants + per_block - 1) / per_block), dim3(DS_THREADS), 0,
+                       reinterpret_cast<hipStream_t>(stream), *args, ref_fracs, alt_fracs, new_ref_counts, new_alt_counts);
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }
 

@@ -38,6 +38,7 @@ extern "C" int pmt_struct_bytes(int which) {
         case 11: return (int)sizeof(PmtLossArgs);
         case 12: return (int)sizeof(PmtDownsample);
         case 13: return (int)sizeof(PmtRecordArgs);
+        case 14: return (int)sizeof(PmtBalanceArgs);
         default: return PMT_E_INVALID;
     }
 }
@@ -231,6 +232,90 @@ extern "C" int pmt_plan_groups(const int32_t* ref_counts, const int32_t* alt_cou
         group_tile_base[groups] = (int32_t)tile_base;
     }
     return groups;
+}
+
+// ---- pmt_plan_groups ON THE DEVICE ---------------------------------------------------------------------------------------
+// A DownsampledBatch keeps about half of its parent's reads (reference training/downsampler.py: a mixture of Beta fractions with mean
+// one half), and how many is decided on the device (pmt_downsample_counts).  Until round 5 it ran on its PARENT's plan -- the parent's
+// counts bound its own -- so every training step of the real loop launched the parent's ~3 400 workgroups with half-empty tiles and
+// took the parent's time (a workgroup costs the same full or not).  Planning from the downsampled counts needs them where the
+// planner runs; bringing them to the host would be a synchronisation per step, so the planner goes to the device instead:
+// the batch is cut into chunks of consecutive variants, one thread packs a chunk exactly like pmt_plan_groups (next-fit over
+// consecutive variants, the same group_fits and set limit; a chunk boundary closes a group: ~1 / 13 of a group per 256 variants
+// lost), an exclusive scan over the chunks' group and tile counts places their groups, and a second pass writes them.  One launch of
+// one workgroup; the kernels take the group count from the device (PmtBatch.num_groups_dev) under a grid sized for a capacity.
+// Next-fit over the same order never makes MORE groups when the items shrink (by induction the k-th boundary does not move left),
+// so capacity = the parent's groups + the number of chunks; an overflow (a caller's wrong capacity) raises the fault word.
+#define PLAN_DEV_THREADS 1024
+__device__ __forceinline__ bool group_fits_reads(int ref_reads, int alt_reads) {
+    const int per = PMT_GROUP_TILES / PMT_GROUP_WAVES;
+    const int tr = (ref_reads + 15) >> 4, ta = (alt_reads + 15) >> 4;
+    return (tr + per - 1) / per + (ta + per - 1) / per <= PMT_GROUP_WAVES;
+}
+template <bool WRITE>
+__device__ void plan_chunk(const int* __restrict__ ro, const int* __restrict__ ao, int v0, int v1, int g0, int t0, int* __restrict__ group_start,
+                           int* __restrict__ group_tile_base, int capacity, int& groups, int& tiles, int& bad) {
+    int ref = 0, alt = 0, sets = 0, g = g0, t = t0;
+    for (int b = v0; b < v1; ++b) {
+        const int r = ro[b + 1] - ro[b], a = ao[b + 1] - ao[b];
+        if (!group_fits_reads(r, a)) bad = 1;  // (a read set beyond one workgroup: the caller's batch is not one for this planner)
+        if (sets > 0 && (!group_fits_reads(ref + r, alt + a) || sets + 1 > PMT_GROUP_MAX_SETS)) {
+            t += ((ref + 15) >> 4) + ((alt + 15) >> 4);
+            ++g;
+            if (WRITE && g <= capacity) { group_start[g] = b; group_tile_base[g] = t; }
+            ref = alt = 0;
+            sets = 0;
+        }
+        ref += r; alt += a; ++sets;
+    }
+    if (sets > 0) {
+        t += ((ref + 15) >> 4) + ((alt + 15) >> 4);
+        ++g;
+        if (WRITE && g <= capacity) { group_start[g] = v1; group_tile_base[g] = t; }
+    }
+    groups = g - g0;
+    tiles = t - t0;
+}
+__global__ __launch_bounds__(PLAN_DEV_THREADS) void pmt_plan_groups_device_kernel(const int* __restrict__ ro, const int* __restrict__ ao, int n, int chunk,
+                                                                                  int* __restrict__ group_start, int* __restrict__ group_tile_base,
+                                                                                  int capacity, int* __restrict__ num_groups_dev, int* __restrict__ fault) {
+    __shared__ int sg[PLAN_DEV_THREADS], st[PLAN_DEV_THREADS];
+    const int c = threadIdx.x, v0 = min(n, c * chunk), v1 = min(n, v0 + chunk);
+    int groups = 0, tiles = 0, bad = 0;
+    if (v0 < v1) plan_chunk<false>(ro, ao, v0, v1, 0, 0, nullptr, nullptr, 0, groups, tiles, bad);
+    sg[c] = groups;
+    st[c] = tiles;
+    __syncthreads();
+    for (int d = 1; d < PLAN_DEV_THREADS; d <<= 1) {  // inclusive scans (Hillis-Steele; 1 024 entries)
+        const int a = c >= d ? sg[c - d] : 0, b = c >= d ? st[c - d] : 0;
+        __syncthreads();
+        sg[c] += a;
+        st[c] += b;
+        __syncthreads();
+    }
+    const int g0 = sg[c] - groups, t0 = st[c] - tiles, total = sg[PLAN_DEV_THREADS - 1];
+    if (c == 0) {
+        group_start[0] = 0;
+        group_tile_base[0] = 0;
+        num_groups_dev[0] = min(total, capacity);
+    }
+    if ((total > capacity || bad) && fault != nullptr) atomicOr(fault, PMT_FAULT_PLAN);
+    if (v0 < v1) plan_chunk<true>(ro, ao, v0, v1, g0, t0, group_start, group_tile_base, capacity, groups, tiles, bad);
+}
+
+extern "C" int pmt_plan_groups_device(const int32_t* ref_offsets, const int32_t* alt_offsets, int32_t num_variants, int32_t* group_start,
+                                      int32_t* group_tile_base, int32_t capacity, int32_t* num_groups_dev, int32_t* fault, void* stream) {
+    if (!ref_offsets || !alt_offsets || !group_start || !group_tile_base || !num_groups_dev || num_variants < 1 || capacity < 1) return PMT_E_INVALID;
+    int chunk = 256;
+    while ((long long)chunk * PLAN_DEV_THREADS < num_variants) chunk *= 2;
+    hipLaunchKernelGGL(pmt_plan_groups_device_kernel, dim3(1), dim3(PLAN_DEV_THREADS), 0, reinterpret_cast<hipStream_t>(stream), ref_offsets, alt_offsets,
+                       num_variants, chunk, group_start, group_tile_base, capacity, num_groups_dev, fault);
+    return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
+}
+extern "C" int pmt_plan_device_chunks(int32_t num_variants) {  // how many chunks pmt_plan_groups_device cuts a batch into (capacity = the parent's groups + this)
+    int chunk = 256;
+    while ((long long)chunk * PLAN_DEV_THREADS < num_variants) chunk *= 2;
+    return (num_variants + chunk - 1) / chunk;
 }
 
 // An ORDER of the batch's variants in which pmt_plan_groups packs fuller groups.  A workgroup costs the same whether its

@@ -143,6 +143,12 @@ extern "C" int pmt_losses_backward(const PmtLossArgs* args, const PmtLossOutputs
 #define REC_THREADS 256
 #define REC_MAX_BINS 2048  // S * 3 * 5 * 4 * 5 = 300 S floats per histogram: up to 6 sources
 
+__device__ __forceinline__ long long rec_col_at(const PmtIntColumn& c, int i) {
+    if (c.ptr == nullptr) return 0;
+    return c.elem_bytes == 8 ? reinterpret_cast<const long long*>(c.ptr)[(size_t)i * c.stride]
+                             : (long long)reinterpret_cast<const int*>(c.ptr)[(size_t)i * c.stride];
+}
+
 __global__ __launch_bounds__(REC_THREADS) void pmt_record_losses_kernel(PmtRecordArgs a, float* __restrict__ hist) {
     __shared__ float sh[6][REC_MAX_BINS];
     const int nb = a.num_bins;
@@ -150,9 +156,8 @@ __global__ __launch_bounds__(REC_THREADS) void pmt_record_losses_kernel(PmtRecor
     __syncthreads();
     const int b = blockIdx.x * REC_THREADS + threadIdx.x;
     if (b < a.num_variants) {
-        const long long label = a.labels[(size_t)b * a.label_stride], vt = a.variant_types[(size_t)b * a.variant_type_stride];
-        const long long src = a.sources ? a.sources[(size_t)b * a.source_stride] : 0;
-        const long long nr = a.ref_counts[(size_t)b * a.ref_count_stride], na = a.alt_counts[(size_t)b * a.alt_count_stride];
+        const long long label = rec_col_at(a.labels, b), vt = rec_col_at(a.variant_types, b), src = rec_col_at(a.sources, b);
+        const long long nr = rec_col_at(a.ref_counts, b), na = rec_col_at(a.alt_counts, b);
         const int rbin = (int)min(nr, (long long)a.max_ref_count) / a.count_bin_skip;
         const int abin = ((int)min(na, (long long)a.max_alt_count) - 1) / a.count_bin_skip;
         const int idx = (int)((((src * 3 + label) * a.num_variant_types + vt) * a.num_ref_bins + rbin) * a.num_alt_bins + abin);
@@ -179,7 +184,9 @@ __global__ __launch_bounds__(REC_THREADS) void pmt_record_losses_kernel(PmtRecor
 extern "C" int pmt_record_losses(const PmtRecordArgs* args, float* histograms, void* stream) {
     if (!args || !histograms || args->num_variants < 0 || args->num_bins < 1 || args->num_bins > REC_MAX_BINS) return PMT_E_INVALID;
     if (args->num_variants == 0) return PMT_OK;
-    if (!args->labels || !args->variant_types || !args->ref_counts || !args->alt_counts || !args->weights || !args->source_weights ||
+    for (const PmtIntColumn* c : {&args->labels, &args->variant_types, &args->sources, &args->ref_counts, &args->alt_counts})
+        if (c->ptr != nullptr && c->elem_bytes != 4 && c->elem_bytes != 8) return PMT_E_INVALID;
+    if (!args->labels.ptr || !args->variant_types.ptr || !args->ref_counts.ptr || !args->alt_counts.ptr || !args->weights || !args->source_weights ||
         !args->supervised_b || !args->unsupervised_b || !args->alt_count_b || !args->source_b || args->count_bin_skip < 1)
         return PMT_E_INVALID;
     hipLaunchKernelGGL(pmt_record_losses_kernel, dim3((args->num_variants + REC_THREADS - 1) / REC_THREADS), dim3(REC_THREADS), 0,

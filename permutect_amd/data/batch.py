@@ -13,6 +13,7 @@ The two reference quirks at this boundary are reproduced bit-exactly: the uint8 
 from __future__ import annotations
 
 import copy
+import os
 import ctypes as C
 from random import randint
 from typing import List, Optional
@@ -138,6 +139,34 @@ class GroupPlan:
         return self._dev[key]
 
 
+class DevicePlan:
+    """A DownsampledBatch's own plan, made ON THE DEVICE from the counts it kept (pmt_plan_groups_device: they are decided there and
+    never come to the host).  `num_groups` / `total_tiles` are CAPACITIES -- the launch grid, the stash size -- the kernels read the
+    real group count from `num_groups_dev` (PmtBatch.num_groups_dev).  Capacity: next-fit packing of smaller counts in the same order
+    never makes more groups than the parent's plan, plus one per chunk boundary of the device planner; tiles: every read in a tile of
+    its own side and group, i.e. reads / 16 + 2 per group at most -- bounded by the parent's tiles + 2 per group of capacity."""
+    layered, span, set_groups = False, None, None
+
+    def __init__(self, parent_plan: GroupPlan, ref_offsets: Tensor, alt_offsets: Tensor, num_variants: int, fault: Optional[Tensor]):
+        lib, dev = L.load(), ref_offsets.device
+        self.num_groups = parent_plan.num_groups + int(lib.pmt_plan_device_chunks(num_variants))
+        self.total_tiles = parent_plan.total_tiles + 2 * self.num_groups
+        self._gs = torch.empty(self.num_groups + 1, dtype=torch.int32, device=dev)
+        self._gt = torch.empty(self.num_groups + 1, dtype=torch.int32, device=dev)
+        self.num_groups_dev = torch.empty(1, dtype=torch.int32, device=dev)
+        L.check(lib.pmt_plan_groups_device(ref_offsets.data_ptr(), alt_offsets.data_ptr(), num_variants, self._gs.data_ptr(), self._gt.data_ptr(),
+                                           self.num_groups, self.num_groups_dev.data_ptr(), None if fault is None else fault.data_ptr(),
+                                           torch.cuda.current_stream(dev).cuda_stream), "pmt_plan_groups_device")
+        self._keep = (ref_offsets, alt_offsets, fault)
+
+    def on(self, device: torch.device):
+        assert self._gs.device == torch.device(device) or str(self._gs.device) == str(device)
+        return self._gs, self._gt, None
+
+    def set_groups_on(self, device: torch.device):
+        return None
+
+
 class Batch:
     order = None  # set by from_arrays(pack=True): batch position -> row of the arrays the batch was built from
 
@@ -250,9 +279,9 @@ class Batch:
             self._host_counts = (ints[:, 0].astype(np.int32), ints[:, 1].astype(np.int32))
         return self._host_counts
 
-    def plan(self, allow_split: bool = False) -> GroupPlan:
+    def plan(self, allow_split: bool = False, fault: Optional[Tensor] = None) -> GroupPlan:
         """`allow_split`: read sets beyond one workgroup are split over several groups instead of refused
-        (pmt_forward_layered / pmt_backward_layered run such a plan)."""
+        (pmt_forward_layered / pmt_backward_layered run such a plan).  `fault`: see DownsampledBatch.plan."""
         if self._plan is None:
             self._plan = GroupPlan(*self.host_counts(), allow_split=allow_split)
         return self._plan
@@ -316,7 +345,8 @@ class DownsampledBatch(Batch):
     @classmethod
     def on_device(cls, original_batch: Batch, seed: int, ref_fracs_b: Optional[Tensor] = None,
                   alt_fracs_b: Optional[Tensor] = None, ref_weights_b4: Optional[Tensor] = None,
-                  alt_weights_b4: Optional[Tensor] = None, fix_alt_gather: bool = False, force_random: Optional[int] = None):
+                  alt_weights_b4: Optional[Tensor] = None, fix_alt_gather: bool = False, force_random: Optional[int] = None,
+                  weight_tables=None, num_sources: int = 1):
         """The same sampling scheme in two launches and no host sync (pmt_downsample_*): fractions from the Downsampler's
         Beta mixture (or given), Bernoulli keep per read from a counter-based generator, one forced alt read per variant."""
         self = cls.__new__(cls)
@@ -345,6 +375,17 @@ class DownsampledBatch(Batch):
         a.ref_offsets, a.alt_offsets = pro.data_ptr(), pao.data_ptr()
         keep = [t if t is None else t.contiguous().float() for t in (ref_weights_b4, alt_weights_b4, ref_fracs_b, alt_fracs_b)]
         a.ref_weights_b4, a.alt_weights_b4, a.ref_fracs_in, a.alt_fracs_in = [None if t is None else t.data_ptr() for t in keep]
+        if weight_tables is not None:  # (ref table, alt table) [S 3 V R A][4]: the kernel looks the variant's cell up itself
+            from permutect_amd.enums import Variation
+            from permutect_amd.training import downsampler as D
+            assert ref_weights_b4 is None and alt_weights_b4 is None and ref_fracs_b is None
+            a.ref_weight_table, a.alt_weight_table = weight_tables[0].data_ptr(), weight_tables[1].data_ptr()
+            cols = [Batch.get(p, f) for f in (Data.LABEL, Data.VARIANT_TYPE, Data.SOURCE)]  # (the PARENT's columns and counts)
+            a.labels, a.variant_types, a.sources = [L.int_column(t) for t in cols]
+            g = a.bins
+            g.num_sources, g.num_variant_types, g.num_ref_bins, g.num_alt_bins = num_sources, len(Variation), D.NUM_REF_COUNT_BINS, D.NUM_ALT_COUNT_BINS
+            g.count_bin_skip, g.max_ref_count, g.max_alt_count = D.COUNT_BIN_SKIP, D.MAX_REF_COUNT, D.MAX_ALT_COUNT
+            keep = keep + [weight_tables, cols]
         self.ref_fracs = torch.empty(b, dtype=torch.float32, device=dev)
         self.alt_fracs = torch.empty(b, dtype=torch.float32, device=dev)
         self.ref_counts = torch.empty(b, dtype=torch.int32, device=dev)
@@ -373,10 +414,18 @@ class DownsampledBatch(Batch):
     def get_reads_re(self) -> Tensor:
         return self._parent.get_reads_re()[self.read_indices]
 
-    def plan(self, allow_split: bool = False) -> GroupPlan:
+    def plan(self, allow_split: bool = False, fault: Optional[Tensor] = None):
+        """The batch's own plan.  Its counts live on the device; so does its planner (DevicePlan / pmt_plan_groups_device): about half
+        the parent's workgroups, hence about half its time -- on the parent's plan (what rounds 1 - 4 did: the parent's counts bound
+        these) every group ran half empty at full cost.  `fault`: the engine's fault word, raised by the planner if its capacity
+        argument were ever wrong.  PMT_DEVICE_PLAN=0, a CPU batch, or a parent with split read sets: the earlier paths."""
         parent = self._parent.plan(allow_split=allow_split)  # parent counts are upper bounds of the downsampled counts
         if not parent.layered:
-            return parent
+            if not self.int_tensor.is_cuda or os.environ.get("PMT_DEVICE_PLAN", "1") == "0" or getattr(self, "_offsets", None) is None or self._size < 1:
+                return parent
+            if getattr(self, "_device_plan", None) is None:
+                self._device_plan = DevicePlan(parent, self._offsets[0], self._offsets[1], self._size, fault)
+            return self._device_plan
         if getattr(self, "_own_plan", None) is None:  # split groups name explicit rows: plan from the downsampled counts
             self._own_plan = GroupPlan(*self.host_counts(), allow_split=True)
         return self._own_plan

@@ -123,18 +123,46 @@ class PmtPhiProgram(C.Structure):
     _fields_ = [("n_segs", i32), ("reserved", i32), ("seg", PmtPhiSeg * MAX_PHI_SEGS)]
 
 
+class PmtIntColumn(C.Structure):
+    _fields_ = [("ptr", vp), ("stride", i64), ("elem_bytes", i32), ("reserved", i32)]
+
+
+class PmtBinning(C.Structure):
+    _fields_ = [("num_sources", i32), ("num_variant_types", i32), ("num_ref_bins", i32), ("num_alt_bins", i32),
+                ("count_bin_skip", i32), ("max_ref_count", i32), ("max_alt_count", i32), ("reserved", i32)]
+
+
+def int_column(t) -> PmtIntColumn:
+    """a 1-D int32 / int64 tensor (any stride: a column of Batch.int_tensor, a DownsampledBatch's counts) as the kernels read it"""
+    c = PmtIntColumn()
+    if t is None:
+        return c
+    assert t.dim() == 1 and t.element_size() in (4, 8) and not t.is_floating_point(), (t.shape, t.dtype)
+    c.ptr, c.stride, c.elem_bytes = t.data_ptr(), (t.stride(0) if t.numel() > 1 else 1), t.element_size()
+    return c
+
+
 class PmtDownsample(C.Structure):
     _fields_ = [("num_variants", i32), ("reference_alt_gather", i32), ("seed", C.c_uint64), ("force_random", i64),
                 ("ref_offsets", vp), ("alt_offsets", vp), ("ref_weights_b4", vp), ("alt_weights_b4", vp),
-                ("ref_fracs_in", vp), ("alt_fracs_in", vp)]
+                ("ref_fracs_in", vp), ("alt_fracs_in", vp), ("ref_weight_table", vp), ("alt_weight_table", vp),
+                ("labels", PmtIntColumn), ("variant_types", PmtIntColumn), ("sources", PmtIntColumn), ("bins", PmtBinning)]
+
+
+class PmtBalanceArgs(C.Structure):
+    _fields_ = [("num_variants", i32), ("recompute", i32), ("attenuation", C.c_float), ("reserved", i32), ("bins", PmtBinning),
+                ("labels", PmtIntColumn), ("variant_types", PmtIntColumn), ("sources", PmtIntColumn), ("ref_counts", PmtIntColumn),
+                ("alt_counts", PmtIntColumn), ("logits_b", vp), ("counts", vp), ("pseudo_counts", vp),
+                ("weights_in", vp), ("unlabeled_weights_in", vp), ("source_weights_in", vp),
+                ("weights_out", vp), ("unlabeled_weights_out", vp), ("source_weights_out", vp),
+                ("weights_b", vp), ("source_weights_b", vp)]
 
 
 class PmtRecordArgs(C.Structure):
     _fields_ = [("num_variants", i32), ("num_bins", i32), ("num_variant_types", i32), ("num_ref_bins", i32),
                 ("num_alt_bins", i32), ("count_bin_skip", i32), ("max_ref_count", i32), ("max_alt_count", i32),
-                ("labels", vp), ("label_stride", i64), ("variant_types", vp), ("variant_type_stride", i64),
-                ("sources", vp), ("source_stride", i64), ("ref_counts", vp), ("ref_count_stride", i64),
-                ("alt_counts", vp), ("alt_count_stride", i64), ("weights", vp), ("source_weights", vp),
+                ("labels", PmtIntColumn), ("variant_types", PmtIntColumn), ("sources", PmtIntColumn), ("ref_counts", PmtIntColumn),
+                ("alt_counts", PmtIntColumn), ("weights", vp), ("source_weights", vp),
                 ("supervised_b", vp), ("unsupervised_b", vp), ("alt_count_b", vp), ("source_b", vp)]
 
 
@@ -154,11 +182,11 @@ class PmtLossInputGrads(C.Structure):
     _fields_ = [("d_logits_b", vp), ("d_logits_bk", vp), ("d_alt_count_raw", vp), ("d_source_logits", vp)]
 
 
-EXPORTS = ["pmt_abi_version", "pmt_build_id", "pmt_shape_info", "pmt_shape_id", "pmt_limits", "pmt_struct_bytes", "pmt_model_check", "pmt_plan_groups", "pmt_stash_bytes", "pmt_pack_params",
+EXPORTS = ["pmt_abi_version", "pmt_build_id", "pmt_shape_info", "pmt_shape_id", "pmt_limits", "pmt_struct_bytes", "pmt_model_check", "pmt_plan_groups", "pmt_plan_groups_device", "pmt_plan_device_chunks", "pmt_stash_bytes", "pmt_pack_params",
            "pmt_scan_counts", "pmt_forward", "pmt_backward", "pmt_clip_adamw",
            "pmt_dropout_mask", "pmt_rows_stash_bytes", "pmt_rows_forward", "pmt_rows_backward", "pmt_rows_workspace_floats", "pmt_cnn_forward", "pmt_cnn_backward", "pmt_cnn_stash_floats", "pmt_cnn_workspace_floats",
            "pmt_phi_forward", "pmt_phi_backward", "pmt_build_read_index", "pmt_losses_forward", "pmt_losses_backward",
-           "pmt_downsample_counts", "pmt_downsample_index", "pmt_record_losses", "pmt_posterior_rows",
+           "pmt_downsample_counts", "pmt_downsample_index", "pmt_record_losses", "pmt_balance_step", "pmt_posterior_rows",
            "pmt_plan_groups_split", "pmt_layered_scratch_floats", "pmt_forward_layered",
            "pmt_layered_backward_scratch_floats", "pmt_backward_layered", "pmt_host_copy", "pmt_pack_order", "pmt_pack_order_batches", "pmt_prepare_chunk", "pmt_host_copy_rows", "pmt_compose_batch", "pmt_compose_batch_planned"]
 
@@ -193,6 +221,8 @@ def load(path: str = None) -> C.CDLL:
     lib.pmt_abi_version.restype = i32
     lib.pmt_model_check.argtypes = [P(PmtModel)]
     lib.pmt_plan_groups.argtypes = [vp, vp, i32, vp, vp, P(i32)]
+    lib.pmt_plan_groups_device.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, vp]
+    lib.pmt_plan_device_chunks.argtypes = [i32]
     lib.pmt_stash_bytes.argtypes = [P(PmtModel), i64, i32]
     lib.pmt_stash_bytes.restype = C.c_size_t
     lib.pmt_pack_params.argtypes = [P(PmtModel), vp, vp, vp, vp, vp]
@@ -232,6 +262,7 @@ def load(path: str = None) -> C.CDLL:
                                          vp, vp, vp, i32, vp]
     lib.pmt_downsample_counts.argtypes = [P(PmtDownsample), vp, vp, vp, vp, vp]
     lib.pmt_downsample_index.argtypes = [P(PmtDownsample), vp, vp, vp, vp, vp, vp]
+    lib.pmt_balance_step.argtypes = [P(PmtBalanceArgs), vp]
     lib.pmt_posterior_rows.argtypes = [vp, i64, i32, i32, vp, vp, i32, vp, i32, vp, i64, vp]
     lib.pmt_losses_forward.argtypes = [P(PmtLossArgs), P(PmtLossOutputs), vp]
     lib.pmt_losses_backward.argtypes = [P(PmtLossArgs), P(PmtLossOutputs), P(PmtLossInputGrads), vp]
@@ -247,7 +278,7 @@ def load(path: str = None) -> C.CDLL:
     if lib.pmt_abi_version() != ABI_VERSION:
         raise PmtError("libpermutect_amd.so ABI version mismatch; rebuild it")
     for which, st in enumerate([PmtModel, PmtBatch, PmtOutputs, PmtOutputGrads, PmtAdamW, PmtLinear, PmtOp, PmtMlp,
-                                PmtBlock, PmtHead, PmtPhiProgram, PmtLossArgs, PmtDownsample, PmtRecordArgs]):
+                                PmtBlock, PmtHead, PmtPhiProgram, PmtLossArgs, PmtDownsample, PmtRecordArgs, PmtBalanceArgs]):
         if lib.pmt_struct_bytes(which) != C.sizeof(st):
             raise PmtError(f"ctypes layout of {st.__name__} ({C.sizeof(st)} B) does not match the library "
                            f"({lib.pmt_struct_bytes(which)} B)")

@@ -89,6 +89,8 @@ class ReadSetEngine:
             if word & 2:
                 what.append("an activation left the range of the forward's f16 operand pieces (|x| > 65504 where the residual stream enters the "
                             "reducer or its output the rotation): those operands saturate (PMT_SHAPE=bf16x3 runs the bf16-piece forward, which has no such limit)")
+            if word & 4:
+                what.append("the device-side group planner of a downsampled batch ran out of its group capacity (pmt_plan_groups_device)")
             raise L.PmtError("; ".join(what) + ": the logits / gradients computed since the last check are wrong")
 
     # ---- parameters -------------------------------------------------------------------------------------------------
@@ -172,7 +174,7 @@ class ReadSetEngine:
         return self.dropout_seed
 
     def batch_view(self, batch, variant_embed: Tensor, allow_split: bool = True, dropout_seed: int = 0):
-        plan = batch.plan(allow_split=allow_split)
+        plan = batch.plan(allow_split=allow_split, fault=self.join_fault)
         gs, gt, span = plan.on(self.device)
         ref_off, alt_off = self.offsets(batch)
         reads, fmt, row_bytes, index = batch.read_rows()

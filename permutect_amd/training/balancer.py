@@ -30,6 +30,48 @@ class Balancer:
         self.count_since_last_recomputation = 0
         self._label_stride = len(Variation) * NUM_REF_COUNT_BINS * NUM_ALT_COUNT_BINS
 
+    def weights_from_logits(self, batch: Batch, logits_b: Tensor):
+        """`process_batch_and_compute_weights(batch, sigmoid(logits_b))` and the product BatchOutput.source_weights = weights *
+        source weight (reference artifact_model.py:285-288) in TWO launches (pmt_balance_step) instead of ~60: counts and pseudo-counts
+        added, the tables re-derived when due, the batch's weights looked up.  Returns (weights_b, weights_b * source_weights_b).
+        The tables are double-buffered: a recomputation reads one set and writes the other."""
+        import ctypes as C
+
+        from permutect_amd.engine import lib as L
+        from permutect_amd.training.downsampler import COUNT_BIN_SKIP, MAX_ALT_COUNT, MAX_REF_COUNT
+        b = batch.size()
+        logits_b = logits_b.detach().contiguous().float()
+        self.count_since_last_recomputation += b
+        recompute = self.count_since_last_recomputation > Balancer.DATA_BEFORE_RECOMPUTE
+        a = L.PmtBalanceArgs()
+        a.num_variants, a.recompute = b, int(recompute)
+        a.attenuation = math.pow(Balancer.ATTENUATION_PER_DATUM, self.count_since_last_recomputation) if recompute else 1.0
+        g = a.bins
+        g.num_sources, g.num_variant_types, g.num_ref_bins, g.num_alt_bins = self.num_sources, len(Variation), NUM_REF_COUNT_BINS, NUM_ALT_COUNT_BINS
+        g.count_bin_skip, g.max_ref_count, g.max_alt_count = COUNT_BIN_SKIP, MAX_REF_COUNT, MAX_ALT_COUNT
+        cols = [batch.get(f) for f in (Data.LABEL, Data.VARIANT_TYPE, Data.SOURCE, Data.REF_COUNT, Data.ALT_COUNT)]
+        a.labels, a.variant_types, a.sources, a.ref_counts, a.alt_counts = [L.int_column(t) for t in cols]
+        a.logits_b, a.counts, a.pseudo_counts = logits_b.data_ptr(), self.counts_slvra.data_ptr(), self.pseudo_counts_slvra.data_ptr()
+        ins = (self.weights_slvra, self.unlabeled_weights_slvra, self.source_weights_s)
+        if recompute:
+            if getattr(self, "_spare", None) is None:
+                self._spare = tuple(torch.empty_like(t) for t in ins)
+            outs = self._spare
+        else:
+            outs = ins
+        a.weights_in, a.unlabeled_weights_in, a.source_weights_in = [t.data_ptr() for t in ins]
+        a.weights_out, a.unlabeled_weights_out, a.source_weights_out = [t.data_ptr() for t in outs]
+        weights_b = torch.empty(b, dtype=torch.float32, device=self.device)
+        source_weights_b = torch.empty(b, dtype=torch.float32, device=self.device)
+        a.weights_b, a.source_weights_b = weights_b.data_ptr(), source_weights_b.data_ptr()
+        L.check(L.load().pmt_balance_step(C.byref(a), torch.cuda.current_stream(self.device).cuda_stream), "pmt_balance_step")
+        if recompute:
+            self._spare = ins
+            self.weights_slvra, self.unlabeled_weights_slvra, self.source_weights_s = outs
+            self.count_since_last_recomputation = 0
+        self._keep = (cols, logits_b)  # (alive until the launches have read them: the next step replaces the references)
+        return weights_b, source_weights_b
+
     def process_batch_and_compute_weights(self, batch: Batch, artifact_probs_b: Tensor):
         idx = flattened_slvra_index(batch)
         labels = batch.get(Data.LABEL).long()

@@ -142,7 +142,24 @@ class Downsampler(nn.Module):
         beta = torch.distributions.Beta
         return beta(rs[:, 0], rs[:, 1]).sample().view(-1), beta(as_[:, 0], as_[:, 1]).sample().view(-1)
 
+    def weight_tables(self):
+        """exp of the two log-weight tables as flat [S L V R A][4] device arrays, made once per state of the weights (they stand still
+        while a model trains: `optimize_downsampling_balance` runs before, reference model_training.py:58-60); each access of the
+        parametrized attributes is a log_softmax launch, and the per-variant lookup was ~25 more per training step"""
+        o_r, o_a = self.weights_parameters()
+        key = (o_r._version, o_a._version, o_r.device, o_r.data_ptr(), o_a.data_ptr())
+        if getattr(self, "_tables_key", None) != key:
+            k = len(BETA_BASIS_SHAPES)
+            with torch.no_grad():
+                self._tables = (torch.exp(self.log_ref_weights_slvrak).reshape(-1, k).contiguous().float(),
+                                torch.exp(self.log_alt_weights_slvrah).reshape(-1, k).contiguous().float())
+            self._tables_key = key
+        return self._tables
+
     def downsample(self, batch: Batch, seed: int, fix_alt_gather: bool = False) -> DownsampledBatch:
-        """The training step's `DownsampledBatch(batch, *calculate_downsampling_fractions(batch))` in two device launches."""
-        ref_w, alt_w = self._weights_bk(batch)
-        return DownsampledBatch.on_device(batch, seed=seed, ref_weights_b4=ref_w, alt_weights_b4=alt_w, fix_alt_gather=fix_alt_gather)
+        """The training step's `DownsampledBatch(batch, *calculate_downsampling_fractions(batch))` in two device launches: the
+        mixture weights of a variant's (source, label, variant type, count bins) cell are looked up inside the first."""
+        if not batch.int_tensor.is_cuda:
+            ref_w, alt_w = self._weights_bk(batch)
+            return DownsampledBatch.on_device(batch, seed=seed, ref_weights_b4=ref_w, alt_weights_b4=alt_w, fix_alt_gather=fix_alt_gather)
+        return DownsampledBatch.on_device(batch, seed=seed, weight_tables=self.weight_tables(), num_sources=self.num_sources, fix_alt_gather=fix_alt_gather)

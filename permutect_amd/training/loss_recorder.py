@@ -38,17 +38,14 @@ class LossRecorder:
         a.count_bin_skip, a.max_ref_count, a.max_alt_count = COUNT_BIN_SKIP, MAX_REF_COUNT, MAX_ALT_COUNT
         keep = []
 
-        def col(field):
+        def col(field):  # int64 columns of the batch's integer tensor, a DownsampledBatch's int32 counts: read as they are
             t = batch.get(field)
-            t = t if t.dtype == torch.int64 else t.long()
+            t = t if t.dtype in (torch.int64, torch.int32) else t.long()
             keep.append(t)
-            return t.data_ptr(), t.stride(0)
+            return L.int_column(t)
 
-        a.labels, a.label_stride = col(Data.LABEL)
-        a.variant_types, a.variant_type_stride = col(Data.VARIANT_TYPE)
-        a.sources, a.source_stride = col(Data.SOURCE)
-        a.ref_counts, a.ref_count_stride = col(Data.REF_COUNT)
-        a.alt_counts, a.alt_count_stride = col(Data.ALT_COUNT)
+        a.labels, a.variant_types, a.sources = col(Data.LABEL), col(Data.VARIANT_TYPE), col(Data.SOURCE)
+        a.ref_counts, a.alt_counts = col(Data.REF_COUNT), col(Data.ALT_COUNT)
         vecs = [output.weights, output.source_weights, losses.supervised_losses_b, losses.unsupervised_losses_b,
                 losses.alt_count_losses_b, losses.source_prediction_losses_b]
         vecs = [v.detach().contiguous().float() for v in vecs]

@@ -75,7 +75,7 @@ class StaticBatch(Batch):
         self._host_counts = None
         self._stage = {}
 
-    def plan(self, allow_split: bool = False):
+    def plan(self, allow_split: bool = False, fault=None):
         return self._plan
 
     def host_counts(self):

@@ -387,3 +387,37 @@ def test_kernel_instances_are_chosen_by_the_models_tile_shape(monkeypatch):
     too_wide.read_layers = [130]
     with pytest.raises(L.PmtError, match="exceeds"):
         desc_of(too_wide)
+
+
+def test_no_mfma_accumulates_onto_another_opcodes_result_without_wait_states():
+    """Round 4's "race" was a hardware hazard the compiler does not know: a `v_mfma_f32_16x16x16_bf16 D, a, b, D` right behind a
+    `v_mfma_f32_16x16x32_bf16` that writes D reads a stale accumulator (profiles/r05_mfma_chain_hazard.txt).  The kernels no longer chain
+    the two shapes; this test keeps it that way for every library the build made: scripts/check_mfma_chains.py disassembles their gfx950
+    code and fails on any MFMA whose SrcC is the result of an MFMA of another opcode issued fewer than ten issue slots before."""
+    import glob
+    import importlib.util
+    from concurrent.futures import ThreadPoolExecutor
+    spec = importlib.util.spec_from_file_location("check_mfma_chains", os.path.join(ROOT, "scripts", "check_mfma_chains.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    # the scanner itself, on the two shapes of the hazard and on what must pass
+    bad = """0000000000001000 <kernel_a>:
+\tv_mfma_f32_16x16x32_bf16 v[0:3], v[8:11], v[12:15], v[0:3]
+\ts_nop 1
+\tv_mfma_f32_16x16x16_bf16 v[0:3], v[16:17], v[18:19], v[0:3]
+"""
+    good = """0000000000001000 <kernel_b>:
+\tv_mfma_f32_16x16x32_bf16 v[0:3], v[8:11], v[12:15], v[0:3]
+\tv_mfma_f32_16x16x32_bf16 v[0:3], v[8:11], v[12:15], v[0:3]
+\tv_mfma_f32_16x16x16_bf16 v[4:7], v[16:17], v[18:19], v[4:7]
+\ts_nop 7
+\ts_nop 1
+\tv_mfma_f32_16x16x16_bf16 v[0:3], v[16:17], v[18:19], v[0:3]
+"""
+    assert len(chk.scan(bad)) == 1 and chk.scan(bad)[0][1:] == ("v_mfma_f32_16x16x32_bf16", "v_mfma_f32_16x16x16_bf16", 2)
+    assert chk.scan(good) == []
+    libs = sorted(glob.glob(os.path.join(ROOT, "permutect_amd", "*.so")) + glob.glob(os.path.join(ROOT, "permutect_amd", "instances", "*.so")))
+    assert len(libs) >= 5, libs  # the default library, alt6, the wide builds, the per-shape instances
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        found = [f for per_lib in pool.map(lambda p: chk.check([p]), libs) for f in per_lib]
+    assert found == [], found[:5]
