@@ -9,7 +9,7 @@
 // workgroup.  Only the final linear layer's dW is cooperative: after each round (one variant per wave, two workgroup
 // barriers) every wave accumulates its slice of input columns over all the round's variants.
 //
-// Covers: <= 2 convolutions with out_ch <= 32 and in_ch * kernel <= 96, pooling / activations, FLATTEN + one final LINEAR
+// Covers: <= 2 convolutions with out_ch <= 64 (instances for <= 32 and <= 64 output channels) and in_ch * kernel <= 96, pooling / activations, FLATTEN + one final LINEAR
 // with <= 16 outputs (the P0 and T0 configurations); anything else runs the general kernels of pmt_cnn.hip.
 #define PMT_OWN_WAVE_SHAPE
 #define PMT_WAVES 8
@@ -21,7 +21,8 @@
 #include "pmt_bwd_device.hpp"
 
 #define C2_MAX_CONVS 2
-#define C2_NTO 2
+#define C2_MAX_NTO 4  // out-channel tiles of a convolution: the kernels are instantiated for 2 (<= 32 channels) and 4 (<= 64: the reference's
+                      // test configuration T0, one convolution 10 -> 64, which ran the general kernels at 13 x the time until round 5)
 #define C2_NTI 6
 #define C2_MAX_LIN_OUT 16
 #define C2_LIN_REGS 16
@@ -134,6 +135,7 @@ DEV C2Weights c2_stage_weights(const PmtModel* __restrict__ M, const float* __re
     return W;
 }
 
+template <int NTO>
 DEV void c2_conv_forward(const PmtModel* __restrict__ M, const PmtCnnLayer& L, const float* __restrict__ w_frag, const float* __restrict__ b_pvec,
                          const float* __restrict__ in, float* __restrict__ out, const int* __restrict__ tap) {
     const int lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15;
@@ -142,13 +144,13 @@ DEV void c2_conv_forward(const PmtModel* __restrict__ M, const PmtCnnLayer& L, c
     for (int tile = 0; tile * 16 < out_len; ++tile) {
         const int so = tile * 16 + r;
         const bool valid = so < out_len;
-        f4 x[1][C2_NTI], y[1][C2_NTO];
+        f4 x[1][C2_NTI], y[1][NTO];
         c2_gather(x, in, tap, L, so, valid, nkt, g);
-        init_bias<C2_NTO>(y, b_pvec, OC, g);
-        linear_acc<C2_NTI, C2_NTO, false>(y, x, w_frag, K, OC);
+        init_bias<NTO>(y, b_pvec, OC, g);
+        linear_acc<C2_NTI, NTO, false>(y, x, w_frag, K, OC);
         if (valid) {
 #pragma unroll
-            for (int t = 0; t < C2_NTO; ++t)
+            for (int t = 0; t < NTO; ++t)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int co = feat_of(t, j, g);
@@ -159,6 +161,7 @@ DEV void c2_conv_forward(const PmtModel* __restrict__ M, const PmtCnnLayer& L, c
 }
 
 // every layer of one variant, activations at acts + in_off / out_off (this wave's LDS region)
+template <int NTO>
 DEV void c2_forward_variant(const PmtModel* __restrict__ M, const float* __restrict__ theta, const C2Weights& cw,
                             float* __restrict__ acts, const long long* __restrict__ hap_row, const int (*taps)[PMT_MAX_ROW_INPUT]) {
     const PmtCnn& C = M->cnn;
@@ -173,7 +176,7 @@ DEV void c2_forward_variant(const PmtModel* __restrict__ M, const float* __restr
         const float* in = acts + uniform(L.in_off);
         float* out = acts + uniform(L.out_off);
         if (kind == PMT_CNN_CONV) {
-            c2_conv_forward(M, L, conv == 0 ? cw.w[0] : cw.w[1], conv == 0 ? cw.b[0] : cw.b[1], in, out, taps[conv]);
+            c2_conv_forward<NTO>(M, L, conv == 0 ? cw.w[0] : cw.w[1], conv == 0 ? cw.b[0] : cw.b[1], in, out, taps[conv]);
             ++conv;
         } else if (kind == PMT_CNN_POOL) {
             const int per = L.out_ch * L.out_len;
@@ -204,7 +207,8 @@ DEV void c2_forward_variant(const PmtModel* __restrict__ M, const float* __restr
     }
 }
 
-extern "C" __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_forward_kernel(
+template <int NTO>
+__global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_forward_kernel(
     const PmtModel* __restrict__ M, const float* __restrict__ theta, const float* __restrict__ packed,
     const long long* __restrict__ hap, long long hap_stride, int n, int per_wave, int stage_floats, float* __restrict__ out,
     long long out_stride, float* __restrict__ stash) {
@@ -222,7 +226,7 @@ extern "C" __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_forward_ke
     int last_off = 0;
     for (int l = 0; l < C.n_layers; ++l) last_off = C.layers[l].out_off;
     for (long long v = (long long)blockIdx.x * nw + wave; v < n; v += (long long)gridDim.x * nw) {
-        c2_forward_variant(M, theta, cw, acts, hap + (size_t)v * hap_stride, taps);
+        c2_forward_variant<NTO>(M, theta, cw, acts, hap + (size_t)v * hap_stride, taps);
         for (int o = lane; o < od; o += 64) out[(size_t)v * out_stride + o] = acts[last_off + o];
         if (stash) {  // every layer output (the one-hot input is rebuilt by the backward: 10 S floats it need not read)
             const int first = 10 * uniform(C.seq_len), per = uniform(C.sum_act) - first;
@@ -235,8 +239,8 @@ extern "C" __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_forward_ke
 
 // dW of one convolution for one variant, straight from LDS in the MFMA operand layout: for k-step s of tile `tile`, lane
 // (m = lane & 15, kg = lane >> 4) supplies A = dY[16 ot + m][col] and B = im2col[16 it + m][col], col = 16 tile + 4 s + kg.
-template <int NTI>
-DEV void c2_conv_wgrad(f4 (&acc)[C2_NTO][NTI], float (&bsum)[C2_NTO], const PmtCnnLayer& L, const float* __restrict__ gout,
+template <int NTO, int NTI>
+DEV void c2_conv_wgrad(f4 (&acc)[NTO][NTI], float (&bsum)[NTO], const PmtCnnLayer& L, const float* __restrict__ gout,
                        const float* __restrict__ xin, const int* __restrict__ tap, int K, int OC) {
     const int lane = threadIdx.x & 63, m = lane & 15, kg = lane >> 4;
     const int out_len = L.out_len, nmt = (OC + 15) >> 4, nkt = (K + 15) >> 4;
@@ -248,9 +252,9 @@ DEV void c2_conv_wgrad(f4 (&acc)[C2_NTO][NTI], float (&bsum)[C2_NTO], const PmtC
         for (int s = 0; s < 4; ++s) {
             const int col = tile * 16 + 4 * s + kg;
             const bool cv = col < out_len;
-            float a[C2_NTO];
+            float a[NTO];
 #pragma unroll
-            for (int ot = 0; ot < C2_NTO; ++ot) {
+            for (int ot = 0; ot < NTO; ++ot) {
                 const int oc = 16 * ot + m;
                 a[ot] = (cv && ot < nmt && oc < OC) ? gout[oc * out_len + col] : 0.f;
                 bsum[ot] += a[ot];
@@ -261,7 +265,7 @@ DEV void c2_conv_wgrad(f4 (&acc)[C2_NTO][NTI], float (&bsum)[C2_NTO], const PmtC
                     const int pos = col * L.stride + (tp[it] >> 16) - 64;
                     const float b = (cv && tp[it] >= 0 && pos >= 0 && pos < L.in_len) ? xin[(tp[it] & 0xFFFF) + pos] : 0.f;
 #pragma unroll
-                    for (int ot = 0; ot < C2_NTO; ++ot)
+                    for (int ot = 0; ot < NTO; ++ot)
                         if (ot < nmt) acc[ot][it] = mfma16(a[ot], b, acc[ot][it]);
                 }
             }
@@ -272,7 +276,7 @@ DEV void c2_conv_wgrad(f4 (&acc)[C2_NTO][NTI], float (&bsum)[C2_NTO], const PmtC
 // NTI0 / NTI1: 16-wide k-tiles (in_ch * kernel) of the first / second convolution.  Their weight gradients live in
 // registers for the whole kernel, so the instance is sized to the model (P0: 30 and 96 inputs = 2 and 6 tiles; sizing
 // both for 6 cost 153 spilled VGPRs).
-template <int NTI0, int NTI1>
+template <int NTO, int NTI0, int NTI1>
 __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_backward_kernel(
     const PmtModel* __restrict__ M, const float* __restrict__ theta, const float* __restrict__ packed,
     const long long* __restrict__ hap, long long hap_stride, int n, int per_wave, int stage_floats, const float* __restrict__ d_out,
@@ -301,10 +305,10 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_backward_kernel(
     float* gA = acts + sa;
     float* gB = gA + ma;
 
-    f4 cacc0[C2_NTO][NTI0], cacc1[C2_NTO][NTI1];
-    float cb[C2_MAX_CONVS][C2_NTO];
+    f4 cacc0[NTO][NTI0], cacc1[NTO][NTI1];
+    float cb[C2_MAX_CONVS][NTO];
 #pragma unroll
-    for (int ot = 0; ot < C2_NTO; ++ot) {
+    for (int ot = 0; ot < NTO; ++ot) {
         cb[0][ot] = cb[1][ot] = 0.f;
 #pragma unroll
         for (int it = 0; it < NTI0; ++it) cacc0[ot][it] = f4{0.f, 0.f, 0.f, 0.f};
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_backward_kernel(
                 for (int i = lane; i < per; i += 64) acts[first + i] = src[i];
                 wave_sync();
             } else if (!(dbg & 1)) {
-                c2_forward_variant(M, theta, cw, acts, hap + (size_t)v * hap_stride, taps);
+                c2_forward_variant<NTO>(M, theta, cw, acts, hap + (size_t)v * hap_stride, taps);
             }
             for (int o = lane; o < od; o += 64) {
                 const float d = d_out[(size_t)v * d_out_stride + o];
@@ -389,8 +393,8 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_backward_kernel(
                     const PmtLinear& Wl = M->lin[uniform(L.lin)];
                     const int K = uniform(Wl.in_dim), OC = uniform(Wl.out_dim), out_len = uniform(L.out_len);
                     if (dbg & 4) {
-                    } else if (conv == 0) c2_conv_wgrad<NTI0>(cacc0, cb[0], L, gout, xin, taps[0], K, OC);
-                    else c2_conv_wgrad<NTI1>(cacc1, cb[1], L, gout, xin, taps[1], K, OC);
+                    } else if (conv == 0) c2_conv_wgrad<NTO, NTI0>(cacc0, cb[0], L, gout, xin, taps[0], K, OC);
+                    else c2_conv_wgrad<NTO, NTI1>(cacc1, cb[1], L, gout, xin, taps[1], K, OC);
                     if (need_din && !(dbg & 2)) {
                         for (int i = lane; i < nin; i += 64) gin[i] = 0.f;
                         wave_sync();
@@ -399,16 +403,16 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_backward_kernel(
                         for (int tile = 0; tile * 16 < out_len; ++tile) {
                             const int so = tile * 16 + r;
                             const bool valid = so < out_len;
-                            f4 dy[1][C2_NTO], dx[1][C2_NTI];
+                            f4 dy[1][NTO], dx[1][C2_NTI];
 #pragma unroll
-                            for (int t = 0; t < C2_NTO; ++t)
+                            for (int t = 0; t < NTO; ++t)
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) {
                                     const int co = feat_of(t, j, g);
                                     dy[0][t][j] = (valid && co < OC) ? gout[co * out_len + so] : 0.f;
                                 }
                             init_bias<C2_NTI>(dx, nullptr, K, g);
-                            linear_acc<C2_NTO, C2_NTI, false>(dx, dy, conv == 0 ? cw.wt[0] : cw.wt[1], OC, K);
+                            linear_acc<NTO, C2_NTI, false>(dx, dy, conv == 0 ? cw.wt[0] : cw.wt[1], OC, K);
 #pragma unroll
                             for (int t = 0; t < C2_NTI; ++t)
                                 if (t < nkt) {
@@ -459,7 +463,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_cnn2_backward_kernel(
         float* gw = gtheta + uniform(Wl.w_src);
         float* gb = gtheta + uniform(Wl.b_src);
 #pragma unroll
-        for (int ot = 0; ot < C2_NTO; ++ot) {
+        for (int ot = 0; ot < NTO; ++ot) {
 #pragma unroll
             for (int it = 0; it < C2_NTI; ++it)
 #pragma unroll
@@ -497,7 +501,7 @@ static int cnn2_supported(const PmtModel* m) {
         const PmtCnnLayer* L = &c->layers[l];
         if (L->kind == PMT_CNN_CONV) {
             const PmtLinear* w = &m->lin[L->lin];
-            if (++nconv > C2_MAX_CONVS || w->out_dim > 16 * C2_NTO || w->in_dim > 16 * C2_NTI) return 0;
+            if (++nconv > C2_MAX_CONVS || w->out_dim > 16 * C2_MAX_NTO || w->in_dim > 16 * C2_NTI) return 0;
             if (L->in_ch * L->in_len >= 65536 || L->kernel * L->dilation >= 64 || L->padding >= 64) return 0;
         } else if (L->kind == PMT_CNN_LINEAR) {
             if (++nlin > 1 || l != c->n_layers - 1 || L->out_ch > C2_MAX_LIN_OUT) return 0;
@@ -505,7 +509,23 @@ static int cnn2_supported(const PmtModel* m) {
             if (L->padding != 0 || L->dilation != 1) return 0;
         }
     }
+    // more than 32 output channels: ONE convolution of at most 32 im2col columns (the four-out-tile instance holds 4 x 2 tiles of dW)
+    for (int l = 0; l < c->n_layers; ++l) {
+        const PmtCnnLayer* L = &c->layers[l];
+        if (L->kind == PMT_CNN_CONV && m->lin[L->lin].out_dim > 32 && (nconv != 1 || m->lin[L->lin].in_dim > 32)) return 0;
+    }
     return 1;
+}
+
+// out-channel tiles of the widest convolution (the kernel instance: 2 or C2_MAX_NTO)
+static int cnn2_out_tiles(const PmtModel* m) {
+    int t = 1;
+    for (int l = 0; l < m->cnn.n_layers; ++l)
+        if (m->cnn.layers[l].kind == PMT_CNN_CONV) {
+            const int ot = (m->lin[m->cnn.layers[l].lin].out_dim + 15) / 16;
+            t = ot > t ? ot : t;
+        }
+    return t;
 }
 
 // floats of LDS the weights take when staged (c2_stage_weights)
@@ -571,7 +591,8 @@ extern "C" int pmt_cnn2_try_forward(const PmtModel* model_host, const PmtModel* 
     cus *= per_cu;
     const int blocks = (int)(((long long)n + nw - 1) / nw < cus ? ((long long)n + nw - 1) / nw : cus);
     const size_t lds_bytes = ((size_t)nw * per + 4 + stage) * sizeof(float);  // (+4: the weights start 16-byte aligned)
-    hipLaunchKernelGGL(pmt_cnn2_forward_kernel, dim3(blocks), dim3(64 * nw), lds_bytes, reinterpret_cast<hipStream_t>(stream), model_dev,
+    auto kernel = cnn2_out_tiles(model_host) <= 2 ? pmt_cnn2_forward_kernel<2> : pmt_cnn2_forward_kernel<C2_MAX_NTO>;
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64 * nw), lds_bytes, reinterpret_cast<hipStream_t>(stream), model_dev,
                        theta, packed, (const long long*)haplotypes, (long long)hap_stride, n, (int)per, (int)stage, out, (long long)out_stride, stash);
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }
@@ -606,7 +627,10 @@ extern "C" int pmt_cnn2_try_backward(const PmtModel* model_host, const PmtModel*
     int kt[C2_MAX_CONVS] = {0, 0}, nc = 0;  // k-tiles of the convolutions: the instance that holds their dW in registers
     for (int l = 0; l < model_host->cnn.n_layers; ++l)
         if (model_host->cnn.layers[l].kind == PMT_CNN_CONV) kt[nc++] = (model_host->lin[model_host->cnn.layers[l].lin].in_dim + 15) / 16;
-    auto kernel = (kt[0] <= 2) ? pmt_cnn2_backward_kernel<2, C2_NTI> : pmt_cnn2_backward_kernel<C2_NTI, C2_NTI>;
+    // (more than 32 output channels: the instance with four out tiles -- only for a SINGLE convolution of at most 32 im2col columns, the
+    //  reference's test configuration T0: its dW alone is 4 x 2 tiles of registers; wider two-convolution stacks stay with the general kernels)
+    auto kernel = (kt[0] <= 2) ? pmt_cnn2_backward_kernel<2, 2, C2_NTI> : pmt_cnn2_backward_kernel<2, C2_NTI, C2_NTI>;
+    if (cnn2_out_tiles(model_host) > 2) kernel = pmt_cnn2_backward_kernel<C2_MAX_NTO, 2, 1>;
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64 * nw), lds_bytes, reinterpret_cast<hipStream_t>(stream), model_dev,
                        theta, packed, (const long long*)haplotypes, (long long)hap_stride, n, (int)per, (int)stage, d_out, (long long)d_out_stride,
                        stash, grad_theta, model_host->cnn_debug);

@@ -26,7 +26,7 @@ ACCEPTS = {
     "p0_cnn_legacy": {"auto", "general"},
     "t0_cnn_options": {"auto", "general"},
     "p0_b16": {"auto", "general", "wave", "batched", "batched_fp32"},
-    "t0_b8": {"auto", "general"},  # (64 output channels)
+    "t0_b8": {"auto", "general", "wave"},  # (one convolution 10 -> 64: the wave family's four-out-tile instance since round 5)
 }
 
 
