@@ -20,7 +20,7 @@ from tests.test_forward_gpu import check_outputs
 
 pytestmark = pytest.mark.gpu
 
-# which family runs which stack.  wave: at most two convolutions, at most 32 output channels, im2col columns <= 96 wide;
+# which family runs which stack.  wave: at most two convolutions of at most 32 output channels (or ONE of at most 64 with <= 32 im2col columns), im2col columns <= 96 wide;
 # batched: exactly conv k3 -> pool 2 -> act -> conv k3 -> act -> flatten -> linear on 21 positions (P0_CNN); general: everything.
 ACCEPTS = {
     "p0_cnn_legacy": {"auto", "general"},
