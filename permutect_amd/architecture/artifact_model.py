@@ -161,8 +161,15 @@ class ArtifactModel(nn.Module):
         eng = self.engine()
         return VariantEmbedFunction.apply(eng, batch.get_info_be(), batch.get_haplotypes_bs(), eng.trigger)
 
+    def _cnn_has_batchnorm(self) -> bool:
+        """(asked on every training forward; the module tree does not change under a model: looked at once)"""
+        flag = self.__dict__.get("_cnn_bn_flag")
+        if flag is None:
+            flag = self.__dict__["_cnn_bn_flag"] = any(isinstance(m, nn.BatchNorm1d) for m in self.haplotypes_cnn.modules())
+        return flag
+
     def _encode(self, batch: Batch):
-        if self.training and any(isinstance(m, nn.BatchNorm1d) for m in self.haplotypes_cnn.modules()):
+        if self.training and self._cnn_has_batchnorm():
             # the reference's `batch_norm` token of the haplotype CNN (dna_sequence_convolution.py:82-83): same story as below
             raise NotImplementedError("permutect_amd runs a haplotype CNN with batch_norm tokens in eval mode only (model.eval() under "
                                       "no_grad / inference_mode: filter_variants, evaluation); training with BatchNorm statistics is not built")
@@ -180,8 +187,8 @@ class ArtifactModel(nn.Module):
             return (z(0), z(0, d.num_clusters + 2), z(0, d.feature_dim), z(0, d.feature_dim)), z(0, d.variant_embed_dim)
         # weights -> parametrizations (phi) -> MFMA fragment order (packed).  While the parameters do not change -- every forward
         # of filter_variants and of an evaluation pass -- both are reused: two launches and their gaps off every step.
-        key = eng.params_key()
-        if key is not None and not torch.is_grad_enabled() and eng.packed_for is not None and eng.packed_for[0] == key:
+        key = None if torch.is_grad_enabled() else eng.params_key()  # (a training forward re-packs anyway: no need to prove anything unchanged)
+        if key is not None and eng.packed_for is not None and eng.packed_for[0] == key:
             phi = eng.packed_for[1]
         else:
             prog = eng.plan.phi_program(self)

@@ -156,7 +156,7 @@ class DevicePlan:
         self.num_groups_dev = torch.empty(1, dtype=torch.int32, device=dev)
         L.check(lib.pmt_plan_groups_device(ref_offsets.data_ptr(), alt_offsets.data_ptr(), num_variants, self._gs.data_ptr(), self._gt.data_ptr(),
                                            self.num_groups, self.num_groups_dev.data_ptr(), None if fault is None else fault.data_ptr(),
-                                           torch.cuda.current_stream(dev).cuda_stream), "pmt_plan_groups_device")
+                                           L.raw_stream(dev)), "pmt_plan_groups_device")
         self._keep = (ref_offsets, alt_offsets, fault)
 
     def on(self, device: torch.device):
@@ -356,7 +356,7 @@ class DownsampledBatch(Batch):
         self.packed_reads, self.reads_re = p.packed_reads, p.reads_re
         self._num_read_features, self._size, self._parent = p._num_read_features, p._size, p
         lib = L.load()
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = L.raw_stream(dev)
         b = p._size
 
         def scan(ref_c, alt_c, elem, stride):

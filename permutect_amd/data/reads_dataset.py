@@ -426,7 +426,7 @@ class ChunkBatch(Batch):
             L.check(L.load().pmt_compose_batch_planned(chunk.ints.data_ptr(), chunk.ints.shape[1], chunk.floats.data_ptr(), chunk.floats.shape[1],
                                                        chunk.row_start.data_ptr(), ids_dev.data_ptr(), n, ref_off.data_ptr(), alt_off.data_ptr(),
                                                        ints.data_ptr(), floats.data_ptr(), row_start.data_ptr(), index.data_ptr(),
-                                                       torch.cuda.current_stream(dev).cuda_stream), "pmt_compose_batch_planned")
+                                                       L.raw_stream(dev)), "pmt_compose_batch_planned")
             return ints, floats, row_start, ref_off, alt_off, index
         ref_off = torch.empty(n + 1, dtype=torch.int32, device=dev)
         alt_off = torch.empty(n + 1, dtype=torch.int32, device=dev)
@@ -434,7 +434,7 @@ class ChunkBatch(Batch):
         L.check(L.load().pmt_compose_batch(chunk.ints.data_ptr(), chunk.ints.shape[1], chunk.floats.data_ptr(), chunk.floats.shape[1],
                                            chunk.row_start.data_ptr(), ids_dev.data_ptr(), n, Data.REF_COUNT.idx, Data.ALT_COUNT.idx,
                                            ints.data_ptr(), floats.data_ptr(), row_start.data_ptr(), ref_off.data_ptr(), alt_off.data_ptr(),
-                                           index.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "pmt_compose_batch")
+                                           index.data_ptr(), L.raw_stream(dev)), "pmt_compose_batch")
         return ints, floats, row_start, ref_off, alt_off, index
 
     def read_index(self) -> torch.Tensor:

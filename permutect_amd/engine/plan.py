@@ -74,13 +74,15 @@ class ParamSpace:
                 p.data = self.theta[o:o + n].view(p.shape)
         self.bind_grads()
 
-    def bind_grads(self):
+    def bind_grads(self, quick: bool = False):
         """Every parameter's .grad is a view into the flat gradient buffer (the kernels accumulate there; torch's
         AccumulateGrad adds in place and keeps the tensor object).  Called once per step: the common case -- nothing was
         re-bound -- is ~130 identity checks."""
         views = getattr(self, "_grad_views", None)
         if views is None:
             views = self._grad_views = [self.gtheta[self.offsets[id(p)]:self.offsets[id(p)] + p.numel()].view(p.shape) for p in self.params]
+        if quick and self.params and self.params[0].grad is views[0] and self.params[-1].grad is views[-1]:
+            return  # (the backward nodes of ONE step: zero_grad has just checked every parameter; whoever drops gradients drops all of them)
         for p, v in zip(self.params, views):
             if p.grad is not v:
                 p.grad = v

@@ -22,7 +22,10 @@ def _ptr(t: Optional[Tensor]) -> Optional[int]:
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """the current HIP stream's handle.  torch.cuda.current_stream() builds a Stream object and resolves the device through four Python
+    layers every time -- 10 us a call, eight calls per training step, a tenth of the host time of a B = 64 step (which is host-bound:
+    scripts/small_step_profile.py); the raw getter is one C call."""
+    return L.raw_stream()
 
 
 class ReadSetEngine:
@@ -361,7 +364,7 @@ class ReadSetFunction(torch.autograd.Function):
         if not ctx.train:
             return None, None, None, None
         phi, ve, stash, *outs = ctx.saved_tensors
-        ctx.engine.space.bind_grads()
+        ctx.engine.space.bind_grads(quick=True)
         gphi, gvar = ctx.engine.backward(ctx.batch, phi, ve, stash, outs, (d_logits_b, d_logits_bk, d_feats, d_ref_feats),
                                          ctx.dropout_seed)
         return None, None, gphi, gvar
@@ -400,7 +403,7 @@ class HaplotypeCnnFunction(torch.autograd.Function):
         if not ctx.train:
             return None, None, None
         eng, d, hap = ctx.engine, ctx.engine.plan.desc, ctx.hap
-        eng.space.bind_grads()
+        eng.space.bind_grads(quick=True)
         if d_out.dtype != torch.float32 or d_out.stride(-1) != 1:
             d_out = d_out.float().contiguous()
         ws = eng.cnn_workspace()
@@ -458,7 +461,7 @@ class VariantEmbedFunction(torch.autograd.Function):
             return None, None, None, None
         x, rows_stash = ctx.saved_tensors
         eng, d, hap = ctx.engine, ctx.engine.plan.desc, ctx.hap
-        eng.space.bind_grads()
+        eng.space.bind_grads(quick=True)
         if d_ve.dtype != torch.float32 or d_ve.stride(-1) != 1:
             d_ve = d_ve.float().contiguous()
         n = x.shape[0]
@@ -514,7 +517,7 @@ class RowsMlpFunction(torch.autograd.Function):
             return None, None, None, None, None
         x, stash = ctx.saved_tensors
         eng, d = ctx.engine, ctx.engine.plan.desc
-        eng.space.bind_grads()
+        eng.space.bind_grads(quick=True)
         if d_out.dtype != torch.float32 or d_out.stride(-1) != 1:
             d_out = d_out.float().contiguous()
         n = x.shape[0]

@@ -64,7 +64,7 @@ class Balancer:
         weights_b = torch.empty(b, dtype=torch.float32, device=self.device)
         source_weights_b = torch.empty(b, dtype=torch.float32, device=self.device)
         a.weights_b, a.source_weights_b = weights_b.data_ptr(), source_weights_b.data_ptr()
-        L.check(L.load().pmt_balance_step(C.byref(a), torch.cuda.current_stream(self.device).cuda_stream), "pmt_balance_step")
+        L.check(L.load().pmt_balance_step(C.byref(a), L.raw_stream(self.device)), "pmt_balance_step")
         if recompute:
             self._spare = ins
             self.weights_slvra, self.unlabeled_weights_slvra, self.source_weights_s = outs

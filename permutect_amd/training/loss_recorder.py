@@ -51,7 +51,7 @@ class LossRecorder:
         vecs = [v.detach().contiguous().float() for v in vecs]
         keep.extend(vecs)
         (a.weights, a.source_weights, a.supervised_b, a.unsupervised_b, a.alt_count_b, a.source_b) = [v.data_ptr() for v in vecs]
-        L.check(L.load().pmt_record_losses(C.byref(a), self.hist.data_ptr(), torch.cuda.current_stream().cuda_stream),
+        L.check(L.load().pmt_record_losses(C.byref(a), self.hist.data_ptr(), L.raw_stream()),
                 "pmt_record_losses")
 
     # ---- read-out (one device -> host copy, at the end of the epoch) -----------------------------------------------------

@@ -56,7 +56,7 @@ class FusedClipAdamW:
                         L.STEP_ON_DEVICE if step_on_device else self.step_count, 0)
         L.check(L.load().pmt_clip_adamw(space.theta.data_ptr(), space.gtheta.data_ptr(), self.exp_avg.data_ptr(),
                                         self.exp_avg_sq.data_ptr(), space.size, C.byref(hp), self.scratch.data_ptr(),
-                                        self.grad_norm.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                                        self.grad_norm.data_ptr(), L.raw_stream()),
                 "pmt_clip_adamw")
         eng = getattr(self.model, "_engine", None)
         if eng is not None:
