@@ -304,7 +304,7 @@ int pmt_build_id(char* out, int32_t capacity);
 
 /* sizeof() of the ABI structs as compiled into the library, for binding self-checks:
  * 0 PmtModel, 1 PmtBatch, 2 PmtOutputs, 3 PmtOutputGrads, 4 PmtAdamW, 5 PmtLinear, 6 PmtOp, 7 PmtMlp, 8 PmtBlock, 9 PmtHead,
- * 10 PmtPhiProgram, 11 PmtLossArgs, 12 PmtDownsample, 13 PmtRecordArgs, 14 PmtBalanceArgs */
+ * 10 PmtPhiProgram, 11 PmtLossArgs, 12 PmtDownsample, 13 PmtRecordArgs, 14 PmtBalanceArgs, 15 PmtEvalArgs */
 int pmt_struct_bytes(int which);
 
 /* Validates a descriptor against the kernels' limits. */
@@ -436,6 +436,22 @@ typedef struct PmtRecordArgs {
 } PmtRecordArgs;
 int pmt_record_losses(const PmtRecordArgs* args, float* histograms, void* stream);
 
+/* The tallies of an evaluation step (reference metrics/evaluation_metrics.py:49-66 -> AccuracyMetrics, metrics/loss_metrics.py:226-243;
+ * training/model_training.py:204-228 runs it three times per parent batch after every validation epoch): the weights of the LABELED
+ * variants over (source, label, variant type, ref-count bin, alt-count bin, LOGIT bin) and, per label, the weight called artifact / not
+ * and the weighted logit sum -- one launch for ~30 tensor ops.  `flat`: [2 epoch types][nhist] histograms, then [2][3 labels][3] statistics
+ * (training/loss_recorder.py: EvaluationCounts.flat). */
+typedef struct PmtEvalArgs {
+    int32_t num_variants, epoch_index;              /* 0: training data, 1: validation data */
+    int32_t num_logit_bins, min_logit, max_logit, logit_bin_skip;   /* reference data/count_binning.py:14-26 */
+    PmtBinning bins;
+    PmtIntColumn labels, variant_types, sources, ref_counts, alt_counts;
+    const float* logits_b;
+    const float* weights_b;
+    int64_t nhist;                                  /* S * 3 * V * R * A * num_logit_bins */
+} PmtEvalArgs;
+int pmt_record_evaluation(const PmtEvalArgs* args, float* flat, void* stream);
+
 /* The balancer's step (reference training/balancer.py:55-119 `process_batch_and_compute_weights`): running counts per cell, pseudo-counts
  * of the unlabeled data from the model's artifact probability, the weight tables re-derived from them (when `recompute`: the reference
  * does it every DATA_BEFORE_RECOMPUTE variants) and this batch's weights looked up -- ~60 torch launches per training step in two:
@@ -486,14 +502,15 @@ int pmt_plan_groups(const int32_t* ref_counts, const int32_t* alt_counts, int32_
                     int32_t* group_start, int32_t* group_tile_base, int32_t* bad_variant);
 
 /* pmt_plan_groups on the DEVICE, from exclusive scans of the counts that live there (a DownsampledBatch's: how many reads it keeps is
- * decided by pmt_downsample_counts and never comes to the host): one launch, stream-ordered.  The batch is cut into
+ * decided by pmt_downsample_counts and never comes to the host): two small launches, stream-ordered.  The batch is cut into
  * pmt_plan_device_chunks(num_variants) chunks of consecutive variants, each packed next-fit like pmt_plan_groups (a chunk boundary closes
  * a group).  group_start / group_tile_base: device, capacity + 1 ints; num_groups_dev: device, [1] -- PmtBatch.num_groups_dev of the
  * launches that use the plan, whose PmtBatch.num_groups is then `capacity` (the grid).  capacity >= the groups of ANY plan of larger
  * counts in the same order + the number of chunks is always enough; an overflow, or a read set beyond one workgroup, sets
  * PMT_FAULT_PLAN in *fault (may be NULL).  The reference has no counterpart (its ATen kernels need no plan). */
 int pmt_plan_groups_device(const int32_t* ref_offsets, const int32_t* alt_offsets, int32_t num_variants, int32_t* group_start,
-                           int32_t* group_tile_base, int32_t capacity, int32_t* num_groups_dev, int32_t* fault, void* stream);
+                           int32_t* group_tile_base, int32_t capacity, int32_t* num_groups_dev, int32_t* fault, int32_t* scratch,
+                           void* stream);   /* scratch: device, 2 * pmt_plan_device_chunks(num_variants) ints (contents irrelevant) */
 int pmt_plan_device_chunks(int32_t num_variants);
 
 /* An order of the batch's variants in which pmt_plan_groups packs fuller groups (a workgroup costs the same full or not, so

@@ -144,3 +144,56 @@ extern "C" int pmt_balance_step(const PmtBalanceArgs* args, void* stream) {
     hipLaunchKernelGGL(pmt_balance_weights_kernel, grid, dim3(BAL_THREADS), 0, s, *args);
     return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }
+
+// ---- the evaluation pass's tallies (PmtEvalArgs) -------------------------------------------------------------------------------
+#define EVAL_LDS_BINS 8192  // floats of LDS for a workgroup's share of the histogram (one source: 6 300 bins); beyond it: global atomics
+__global__ __launch_bounds__(BAL_THREADS) void pmt_record_evaluation_kernel(PmtEvalArgs a, float* __restrict__ flat) {
+    __shared__ float hist[EVAL_LDS_BINS];
+    __shared__ float stats[9];
+    const bool in_lds = a.nhist <= EVAL_LDS_BINS;
+    if (in_lds)
+        for (int i = threadIdx.x; i < (int)a.nhist; i += BAL_THREADS) hist[i] = 0.f;
+    if (threadIdx.x < 9) stats[threadIdx.x] = 0.f;
+    __syncthreads();
+    float* ghist = flat + (size_t)a.epoch_index * (size_t)a.nhist;
+    float* gstats = flat + 2 * (size_t)a.nhist + (size_t)a.epoch_index * 9;
+    const int b = blockIdx.x * BAL_THREADS + threadIdx.x;
+    if (b < a.num_variants) {
+        const long long label = col_at(a.labels, b);
+        const float w = a.weights_b[b], logit = a.logits_b[b];
+        if (label >= 0 && label < 3) {
+            atomicAdd(&stats[label * 3 + (logit > 0.f ? 1 : 0)], w);
+            atomicAdd(&stats[label * 3 + 2], w * logit);
+        }
+        if (label == BAL_LABEL_ARTIFACT || label == BAL_LABEL_VARIANT) {  // (unlabeled data are not tallied: reference evaluation_metrics.py:58-66)
+            const int cell = cell_of(a.bins, col_at(a.sources, b), label, col_at(a.variant_types, b), col_at(a.ref_counts, b), col_at(a.alt_counts, b));
+            const float clamped = fminf(fmaxf(logit, (float)a.min_logit), (float)a.max_logit);
+            const int lbin = (int)floorf((clamped - (float)a.min_logit) / (float)a.logit_bin_skip);
+            const long long idx = (long long)cell * a.num_logit_bins + lbin;
+            if (cell >= 0 && idx < a.nhist && lbin >= 0 && lbin < a.num_logit_bins) {
+                if (in_lds) atomicAdd(&hist[idx], w); else atomicAdd(&ghist[idx], w);
+            }
+        }
+    }
+    __syncthreads();
+    if (in_lds)
+        for (int i = threadIdx.x; i < (int)a.nhist; i += BAL_THREADS)
+            if (hist[i] != 0.f) atomicAdd(&ghist[i], hist[i]);
+    if (threadIdx.x < 9 && stats[threadIdx.x] != 0.f) atomicAdd(&gstats[threadIdx.x], stats[threadIdx.x]);
+}
+
+extern "C" int pmt_record_evaluation(const PmtEvalArgs* args, float* flat, void* stream) {
+    if (!args || !flat || args->num_variants < 0 || args->epoch_index < 0 || args->epoch_index > 1 || args->num_logit_bins < 1 ||
+        args->logit_bin_skip < 1 || args->nhist < 1)
+        return PMT_E_INVALID;
+    const PmtBinning& g = args->bins;
+    if (g.num_sources < 1 || g.num_variant_types < 1 || g.num_ref_bins < 1 || g.num_alt_bins < 1 || g.count_bin_skip < 1) return PMT_E_INVALID;
+    if ((int64_t)g.num_sources * 3 * g.num_variant_types * g.num_ref_bins * g.num_alt_bins * args->num_logit_bins != args->nhist) return PMT_E_INVALID;
+    if (args->num_variants == 0) return PMT_OK;
+    if (!args->labels.ptr || !args->variant_types.ptr || !args->ref_counts.ptr || !args->alt_counts.ptr || !args->logits_b || !args->weights_b) return PMT_E_INVALID;
+    for (const PmtIntColumn* c : {&args->labels, &args->variant_types, &args->sources, &args->ref_counts, &args->alt_counts})
+        if (c->ptr != nullptr && c->elem_bytes != 4 && c->elem_bytes != 8) return PMT_E_INVALID;
+    hipLaunchKernelGGL(pmt_record_evaluation_kernel, dim3((args->num_variants + BAL_THREADS - 1) / BAL_THREADS), dim3(BAL_THREADS), 0,
+                       reinterpret_cast<hipStream_t>(stream), *args, flat);
+    return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
+}

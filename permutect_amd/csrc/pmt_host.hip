@@ -39,6 +39,7 @@ extern "C" int pmt_struct_bytes(int which) {
         case 12: return (int)sizeof(PmtDownsample);
         case 13: return (int)sizeof(PmtRecordArgs);
         case 14: return (int)sizeof(PmtBalanceArgs);
+        case 15: return (int)sizeof(PmtEvalArgs);
         default: return PMT_E_INVALID;
     }
 }
@@ -242,80 +243,113 @@ extern "C" int pmt_plan_groups(const int32_t* ref_counts, const int32_t* alt_cou
 // planner runs; bringing them to the host would be a synchronisation per step, so the planner goes to the device instead:
 // the batch is cut into chunks of consecutive variants, one thread packs a chunk exactly like pmt_plan_groups (next-fit over
 // consecutive variants, the same group_fits and set limit; a chunk boundary closes a group: ~1 / 13 of a group per 256 variants
-// lost), an exclusive scan over the chunks' group and tile counts places their groups, and a second pass writes them.  One launch of
-// one workgroup; the kernels take the group count from the device (PmtBatch.num_groups_dev) under a grid sized for a capacity.
+// lost), a prefix over the chunks' group and tile counts places their groups, and a second pass writes them.  The kernels take the
+// group count from the device (PmtBatch.num_groups_dev) under a grid sized for a capacity.
 // Next-fit over the same order never makes MORE groups when the items shrink (by induction the k-th boundary does not move left),
 // so capacity = the parent's groups + the number of chunks; an overflow (a caller's wrong capacity) raises the fault word.
-#define PLAN_DEV_THREADS 1024
+// One WAVE per chunk of 256 consecutive variants: its lanes load the chunk's counts coalesced (four registers per side), and the
+// packing itself -- sequential by nature -- runs on the scalar unit, every lane in step, reading one variant's counts at a time out
+// of the registers with v_readlane (~15 scalar instructions per variant: ~2 us per chunk).  Two launches: the chunks' group and
+// tile counts, then (after a prefix over them, which every wave takes for itself) the groups written out.  The first version gave a
+// chunk to one THREAD of a single workgroup, whose 256 dependent, uncoalesced loads took 174 us per 65 536-variant batch.
+#define PLAN_CHUNK 256
+#define PLAN_WAVES 4
 __device__ __forceinline__ bool group_fits_reads(int ref_reads, int alt_reads) {
     const int per = PMT_GROUP_TILES / PMT_GROUP_WAVES;
     const int tr = (ref_reads + 15) >> 4, ta = (alt_reads + 15) >> 4;
     return (tr + per - 1) / per + (ta + per - 1) / per <= PMT_GROUP_WAVES;
 }
+// next-fit over the chunk [v0, v1); WRITE: groups g0 + 1 .. go to group_start / group_tile_base (lane 0 stores).  Wave-uniform throughout.
 template <bool WRITE>
-__device__ void plan_chunk(const int* __restrict__ ro, const int* __restrict__ ao, int v0, int v1, int g0, int t0, int* __restrict__ group_start,
-                           int* __restrict__ group_tile_base, int capacity, int& groups, int& tiles, int& bad) {
+__device__ void plan_chunk_wave(const int* __restrict__ ro, const int* __restrict__ ao, int v0, int v1, int g0, int t0, int* __restrict__ group_start,
+                                int* __restrict__ group_tile_base, int capacity, int& groups, int& tiles, int& bad) {
+    const int lane = threadIdx.x & 63;
+    int rc[PLAN_CHUNK / 64], ac[PLAN_CHUNK / 64];
+#pragma unroll
+    for (int k = 0; k < PLAN_CHUNK / 64; ++k) {
+        const int b = v0 + 64 * k + lane;
+        rc[k] = b < v1 ? ro[b + 1] - ro[b] : 0;
+        ac[k] = b < v1 ? ao[b + 1] - ao[b] : 0;
+    }
     int ref = 0, alt = 0, sets = 0, g = g0, t = t0;
-    for (int b = v0; b < v1; ++b) {
-        const int r = ro[b + 1] - ro[b], a = ao[b + 1] - ao[b];
-        if (!group_fits_reads(r, a)) bad = 1;  // (a read set beyond one workgroup: the caller's batch is not one for this planner)
-        if (sets > 0 && (!group_fits_reads(ref + r, alt + a) || sets + 1 > PMT_GROUP_MAX_SETS)) {
-            t += ((ref + 15) >> 4) + ((alt + 15) >> 4);
-            ++g;
-            if (WRITE && g <= capacity) { group_start[g] = b; group_tile_base[g] = t; }
-            ref = alt = 0;
-            sets = 0;
+    const int n = v1 - v0;
+#pragma unroll
+    for (int k = 0; k < PLAN_CHUNK / 64; ++k) {
+        const int m = min(64, n - 64 * k);
+        for (int l = 0; l < m; ++l) {
+            const int r = __builtin_amdgcn_readlane(rc[k], l), a = __builtin_amdgcn_readlane(ac[k], l);
+            if (!group_fits_reads(r, a)) bad = 1;  // (a read set beyond one workgroup: the caller's batch is not one for this planner)
+            if (sets > 0 && (!group_fits_reads(ref + r, alt + a) || sets + 1 > PMT_GROUP_MAX_SETS)) {
+                t += ((ref + 15) >> 4) + ((alt + 15) >> 4);
+                ++g;
+                if (WRITE && g <= capacity && lane == 0) { group_start[g] = v0 + 64 * k + l; group_tile_base[g] = t; }
+                ref = alt = 0;
+                sets = 0;
+            }
+            ref += r; alt += a; ++sets;
         }
-        ref += r; alt += a; ++sets;
     }
     if (sets > 0) {
         t += ((ref + 15) >> 4) + ((alt + 15) >> 4);
         ++g;
-        if (WRITE && g <= capacity) { group_start[g] = v1; group_tile_base[g] = t; }
+        if (WRITE && g <= capacity && lane == 0) { group_start[g] = v1; group_tile_base[g] = t; }
     }
     groups = g - g0;
     tiles = t - t0;
 }
-__global__ __launch_bounds__(PLAN_DEV_THREADS) void pmt_plan_groups_device_kernel(const int* __restrict__ ro, const int* __restrict__ ao, int n, int chunk,
-                                                                                  int* __restrict__ group_start, int* __restrict__ group_tile_base,
-                                                                                  int capacity, int* __restrict__ num_groups_dev, int* __restrict__ fault) {
-    __shared__ int sg[PLAN_DEV_THREADS], st[PLAN_DEV_THREADS];
-    const int c = threadIdx.x, v0 = min(n, c * chunk), v1 = min(n, v0 + chunk);
+// launch 1: per chunk (groups, tiles) -> counts[2 c], counts[2 c + 1]
+__global__ __launch_bounds__(64 * PLAN_WAVES) void pmt_plan_count_kernel(const int* __restrict__ ro, const int* __restrict__ ao, int n, int nchunks,
+                                                                          int* __restrict__ counts) {
+    const int c = blockIdx.x * PLAN_WAVES + (threadIdx.x >> 6);
+    if (c >= nchunks) return;
     int groups = 0, tiles = 0, bad = 0;
-    if (v0 < v1) plan_chunk<false>(ro, ao, v0, v1, 0, 0, nullptr, nullptr, 0, groups, tiles, bad);
-    sg[c] = groups;
-    st[c] = tiles;
-    __syncthreads();
-    for (int d = 1; d < PLAN_DEV_THREADS; d <<= 1) {  // inclusive scans (Hillis-Steele; 1 024 entries)
-        const int a = c >= d ? sg[c - d] : 0, b = c >= d ? st[c - d] : 0;
-        __syncthreads();
-        sg[c] += a;
-        st[c] += b;
-        __syncthreads();
+    plan_chunk_wave<false>(ro, ao, c * PLAN_CHUNK, min(n, (c + 1) * PLAN_CHUNK), 0, 0, nullptr, nullptr, 0, groups, tiles, bad);
+    if ((threadIdx.x & 63) == 0) {
+        counts[2 * c] = groups;
+        counts[2 * c + 1] = tiles | (bad ? (1 << 30) : 0);
     }
-    const int g0 = sg[c] - groups, t0 = st[c] - tiles, total = sg[PLAN_DEV_THREADS - 1];
-    if (c == 0) {
+}
+// launch 2: every wave sums the chunks in front of its own (coalesced, a wave reduction), then packs its chunk again, writing
+__global__ __launch_bounds__(64 * PLAN_WAVES) void pmt_plan_write_kernel(const int* __restrict__ ro, const int* __restrict__ ao, int n, int nchunks,
+                                                                          const int* __restrict__ counts, int* __restrict__ group_start,
+                                                                          int* __restrict__ group_tile_base, int capacity,
+                                                                          int* __restrict__ num_groups_dev, int* __restrict__ fault) {
+    const int c = blockIdx.x * PLAN_WAVES + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= nchunks) return;
+    int g0 = 0, t0 = 0, total = 0, bad = 0;
+    for (int i = lane; i < nchunks; i += 64) {
+        const int gi = counts[2 * i], ti = counts[2 * i + 1];
+        bad |= ti >> 30;
+        total += gi;
+        if (i < c) { g0 += gi; t0 += ti & ((1 << 30) - 1); }
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        g0 += __shfl_xor(g0, d); t0 += __shfl_xor(t0, d); total += __shfl_xor(total, d); bad |= __shfl_xor(bad, d);
+    }
+    if (c == 0 && lane == 0) {
         group_start[0] = 0;
         group_tile_base[0] = 0;
         num_groups_dev[0] = min(total, capacity);
+        if ((total > capacity || bad) && fault != nullptr) atomicOr(fault, PMT_FAULT_PLAN);
     }
-    if ((total > capacity || bad) && fault != nullptr) atomicOr(fault, PMT_FAULT_PLAN);
-    if (v0 < v1) plan_chunk<true>(ro, ao, v0, v1, g0, t0, group_start, group_tile_base, capacity, groups, tiles, bad);
+    int groups = 0, tiles = 0, bad2 = 0;
+    plan_chunk_wave<true>(ro, ao, c * PLAN_CHUNK, min(n, (c + 1) * PLAN_CHUNK), g0, t0, group_start, group_tile_base, capacity, groups, tiles, bad2);
 }
 
-extern "C" int pmt_plan_groups_device(const int32_t* ref_offsets, const int32_t* alt_offsets, int32_t num_variants, int32_t* group_start,
-                                      int32_t* group_tile_base, int32_t capacity, int32_t* num_groups_dev, int32_t* fault, void* stream) {
-    if (!ref_offsets || !alt_offsets || !group_start || !group_tile_base || !num_groups_dev || num_variants < 1 || capacity < 1) return PMT_E_INVALID;
-    int chunk = 256;
-    while ((long long)chunk * PLAN_DEV_THREADS < num_variants) chunk *= 2;
-    hipLaunchKernelGGL(pmt_plan_groups_device_kernel, dim3(1), dim3(PLAN_DEV_THREADS), 0, reinterpret_cast<hipStream_t>(stream), ref_offsets, alt_offsets,
-                       num_variants, chunk, group_start, group_tile_base, capacity, num_groups_dev, fault);
-    return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
-}
 extern "C" int pmt_plan_device_chunks(int32_t num_variants) {  // how many chunks pmt_plan_groups_device cuts a batch into (capacity = the parent's groups + this)
-    int chunk = 256;
-    while ((long long)chunk * PLAN_DEV_THREADS < num_variants) chunk *= 2;
-    return (num_variants + chunk - 1) / chunk;
+    return (num_variants + PLAN_CHUNK - 1) / PLAN_CHUNK;
+}
+extern "C" int pmt_plan_groups_device(const int32_t* ref_offsets, const int32_t* alt_offsets, int32_t num_variants, int32_t* group_start,
+                                      int32_t* group_tile_base, int32_t capacity, int32_t* num_groups_dev, int32_t* fault, int32_t* scratch,
+                                      void* stream) {
+    if (!ref_offsets || !alt_offsets || !group_start || !group_tile_base || !num_groups_dev || !scratch || num_variants < 1 || capacity < 1) return PMT_E_INVALID;
+    const int nchunks = pmt_plan_device_chunks(num_variants);
+    const hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((nchunks + PLAN_WAVES - 1) / PLAN_WAVES), block(64 * PLAN_WAVES);
+    hipLaunchKernelGGL(pmt_plan_count_kernel, grid, block, 0, s, ref_offsets, alt_offsets, num_variants, nchunks, scratch);
+    hipLaunchKernelGGL(pmt_plan_write_kernel, grid, block, 0, s, ref_offsets, alt_offsets, num_variants, nchunks, scratch, group_start, group_tile_base,
+                       capacity, num_groups_dev, fault);
+    return hipGetLastError() == hipSuccess ? PMT_OK : PMT_E_LAUNCH;
 }
 
 // An ORDER of the batch's variants in which pmt_plan_groups packs fuller groups.  A workgroup costs the same whether its

@@ -154,10 +154,11 @@ class DevicePlan:
         self._gs = torch.empty(self.num_groups + 1, dtype=torch.int32, device=dev)
         self._gt = torch.empty(self.num_groups + 1, dtype=torch.int32, device=dev)
         self.num_groups_dev = torch.empty(1, dtype=torch.int32, device=dev)
+        scratch = torch.empty(2 * int(lib.pmt_plan_device_chunks(num_variants)), dtype=torch.int32, device=dev)
         L.check(lib.pmt_plan_groups_device(ref_offsets.data_ptr(), alt_offsets.data_ptr(), num_variants, self._gs.data_ptr(), self._gt.data_ptr(),
                                            self.num_groups, self.num_groups_dev.data_ptr(), None if fault is None else fault.data_ptr(),
-                                           L.raw_stream(dev)), "pmt_plan_groups_device")
-        self._keep = (ref_offsets, alt_offsets, fault)
+                                           scratch.data_ptr(), L.raw_stream(dev)), "pmt_plan_groups_device")
+        self._keep = (ref_offsets, alt_offsets, fault, scratch)
 
     def on(self, device: torch.device):
         assert self._gs.device == torch.device(device) or str(self._gs.device) == str(device)
@@ -440,5 +441,10 @@ class DownsampledBatch(Batch):
 
     def read_rows(self):
         t, fmt, row_bytes, parent_index = self._parent.read_rows()
-        # a parent that is itself a gather (a batch composed from a device-resident chunk): compose the two indices
-        return t, fmt, row_bytes, self.read_indices if parent_index is None else parent_index[self.read_indices]
+        # a parent that is itself a gather (a batch composed from a device-resident chunk): compose the two indices -- once per batch
+        # (the forward and the backward both ask)
+        if parent_index is None:
+            return t, fmt, row_bytes, self.read_indices
+        if getattr(self, "_composed_index", None) is None:
+            self._composed_index = parent_index[self.read_indices]
+        return t, fmt, row_bytes, self._composed_index

@@ -158,6 +158,13 @@ class PmtBalanceArgs(C.Structure):
                 ("weights_b", vp), ("source_weights_b", vp)]
 
 
+class PmtEvalArgs(C.Structure):
+    _fields_ = [("num_variants", i32), ("epoch_index", i32), ("num_logit_bins", i32), ("min_logit", i32), ("max_logit", i32),
+                ("logit_bin_skip", i32), ("bins", PmtBinning), ("labels", PmtIntColumn), ("variant_types", PmtIntColumn),
+                ("sources", PmtIntColumn), ("ref_counts", PmtIntColumn), ("alt_counts", PmtIntColumn), ("logits_b", vp), ("weights_b", vp),
+                ("nhist", i64)]
+
+
 class PmtRecordArgs(C.Structure):
     _fields_ = [("num_variants", i32), ("num_bins", i32), ("num_variant_types", i32), ("num_ref_bins", i32),
                 ("num_alt_bins", i32), ("count_bin_skip", i32), ("max_ref_count", i32), ("max_alt_count", i32),
@@ -186,7 +193,7 @@ EXPORTS = ["pmt_abi_version", "pmt_build_id", "pmt_shape_info", "pmt_shape_id", 
            "pmt_scan_counts", "pmt_forward", "pmt_backward", "pmt_clip_adamw",
            "pmt_dropout_mask", "pmt_rows_stash_bytes", "pmt_rows_forward", "pmt_rows_backward", "pmt_rows_workspace_floats", "pmt_cnn_forward", "pmt_cnn_backward", "pmt_cnn_stash_floats", "pmt_cnn_workspace_floats",
            "pmt_phi_forward", "pmt_phi_backward", "pmt_build_read_index", "pmt_losses_forward", "pmt_losses_backward",
-           "pmt_downsample_counts", "pmt_downsample_index", "pmt_record_losses", "pmt_balance_step", "pmt_posterior_rows",
+           "pmt_downsample_counts", "pmt_downsample_index", "pmt_record_losses", "pmt_record_evaluation", "pmt_balance_step", "pmt_posterior_rows",
            "pmt_plan_groups_split", "pmt_layered_scratch_floats", "pmt_forward_layered",
            "pmt_layered_backward_scratch_floats", "pmt_backward_layered", "pmt_host_copy", "pmt_pack_order", "pmt_pack_order_batches", "pmt_prepare_chunk", "pmt_host_copy_rows", "pmt_compose_batch", "pmt_compose_batch_planned"]
 
@@ -221,7 +228,7 @@ def load(path: str = None) -> C.CDLL:
     lib.pmt_abi_version.restype = i32
     lib.pmt_model_check.argtypes = [P(PmtModel)]
     lib.pmt_plan_groups.argtypes = [vp, vp, i32, vp, vp, P(i32)]
-    lib.pmt_plan_groups_device.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, vp]
+    lib.pmt_plan_groups_device.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, vp, vp]
     lib.pmt_plan_device_chunks.argtypes = [i32]
     lib.pmt_stash_bytes.argtypes = [P(PmtModel), i64, i32]
     lib.pmt_stash_bytes.restype = C.c_size_t
@@ -263,6 +270,7 @@ def load(path: str = None) -> C.CDLL:
     lib.pmt_downsample_counts.argtypes = [P(PmtDownsample), vp, vp, vp, vp, vp]
     lib.pmt_downsample_index.argtypes = [P(PmtDownsample), vp, vp, vp, vp, vp, vp]
     lib.pmt_balance_step.argtypes = [P(PmtBalanceArgs), vp]
+    lib.pmt_record_evaluation.argtypes = [P(PmtEvalArgs), vp, vp]
     lib.pmt_posterior_rows.argtypes = [vp, i64, i32, i32, vp, vp, i32, vp, i32, vp, i64, vp]
     lib.pmt_losses_forward.argtypes = [P(PmtLossArgs), P(PmtLossOutputs), vp]
     lib.pmt_losses_backward.argtypes = [P(PmtLossArgs), P(PmtLossOutputs), P(PmtLossInputGrads), vp]
@@ -278,7 +286,7 @@ def load(path: str = None) -> C.CDLL:
     if lib.pmt_abi_version() != ABI_VERSION:
         raise PmtError("libpermutect_amd.so ABI version mismatch; rebuild it")
     for which, st in enumerate([PmtModel, PmtBatch, PmtOutputs, PmtOutputGrads, PmtAdamW, PmtLinear, PmtOp, PmtMlp,
-                                PmtBlock, PmtHead, PmtPhiProgram, PmtLossArgs, PmtDownsample, PmtRecordArgs, PmtBalanceArgs]):
+                                PmtBlock, PmtHead, PmtPhiProgram, PmtLossArgs, PmtDownsample, PmtRecordArgs, PmtBalanceArgs, PmtEvalArgs]):
         if lib.pmt_struct_bytes(which) != C.sizeof(st):
             raise PmtError(f"ctypes layout of {st.__name__} ({C.sizeof(st)} B) does not match the library "
                            f"({lib.pmt_struct_bytes(which)} B)")

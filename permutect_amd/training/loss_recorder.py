@@ -144,6 +144,25 @@ class EvaluationCounts:
         return self.stats[:, :, 2]
 
     def record_batch(self, epoch_index: int, batch, logits: torch.Tensor, weights: torch.Tensor):
+        if self.flat.is_cuda:  # one launch (pmt_record_evaluation) for the ~30 tensor ops below
+            a = L.PmtEvalArgs()
+            a.num_variants, a.epoch_index = batch.size(), epoch_index
+            a.num_logit_bins, a.min_logit, a.max_logit, a.logit_bin_skip = NUM_LOGIT_BINS, MIN_LOGIT, MAX_LOGIT, LOGIT_BIN_SKIP
+            g = a.bins
+            g.num_sources, g.num_variant_types, g.num_ref_bins, g.num_alt_bins = self.num_sources, len(Variation), NUM_REF_COUNT_BINS, NUM_ALT_COUNT_BINS
+            g.count_bin_skip, g.max_ref_count, g.max_alt_count = COUNT_BIN_SKIP, MAX_REF_COUNT, MAX_ALT_COUNT
+            cols = [batch.get(f) for f in (Data.LABEL, Data.VARIANT_TYPE, Data.SOURCE, Data.REF_COUNT, Data.ALT_COUNT)]
+            a.labels, a.variant_types, a.sources, a.ref_counts, a.alt_counts = [L.int_column(t) for t in cols]
+            lg, wt = logits.detach().contiguous().float(), weights.detach().contiguous().float()
+            a.logits_b, a.weights_b, a.nhist = lg.data_ptr(), wt.data_ptr(), self._nhist
+            L.check(L.load().pmt_record_evaluation(C.byref(a), self.flat.data_ptr(), L.raw_stream(self.flat.device)), "pmt_record_evaluation")
+            self._keep = (cols, lg, wt)
+            self.batches += 1
+            return
+        self.record_batch_torch(epoch_index, batch, logits, weights)
+
+    def record_batch_torch(self, epoch_index: int, batch, logits: torch.Tensor, weights: torch.Tensor):
+        """the same tallies composed from torch ops (the CPU path, and the test reference of the fused launch)"""
         from permutect_amd.training.downsampler import flattened_slvra_index
         labels = batch.get(Data.LABEL).long()
         weights, logits = weights.float(), logits.float()

@@ -86,9 +86,9 @@ def test_device_planner_is_the_host_planner_chunk_by_chunk(n):
     parent_ref, parent_alt = rng.integers(0, 11, n).astype(np.int32), rng.integers(1, 16, n).astype(np.int32)
     ref = rng.binomial(parent_ref, rng.beta(1, 1, n)).astype(np.int32)  # what a downsampling keeps
     alt = np.maximum(rng.binomial(parent_alt, rng.beta(1, 1, n)), 1).astype(np.int32)
-    chunks = lib.pmt_plan_device_chunks(n)
-    chunk = 256 if n <= 256 * 1024 else 512  # (one thread of a 1 024-thread workgroup per chunk: the chunks double beyond 262 144 variants)
+    chunks, chunk = lib.pmt_plan_device_chunks(n), 256  # (one wave per chunk of 256 consecutive variants)
     assert chunks == -(-n // chunk)
+    scratch = torch.empty(2 * chunks, dtype=torch.int32, device=DEV)
     pgs, _ = _host_plan(parent_ref, parent_alt)
     capacity = (len(pgs) - 1) + chunks
     ro = torch.from_numpy(np.concatenate([[0], np.cumsum(ref)]).astype(np.int32)).to(DEV)
@@ -98,7 +98,7 @@ def test_device_planner_is_the_host_planner_chunk_by_chunk(n):
     ng = torch.zeros(1, dtype=torch.int32, device=DEV)
     fault = torch.zeros(1, dtype=torch.int32, device=DEV)
     L.check(lib.pmt_plan_groups_device(ro.data_ptr(), ao.data_ptr(), n, gs.data_ptr(), gt.data_ptr(), capacity, ng.data_ptr(), fault.data_ptr(),
-                                       torch.cuda.current_stream().cuda_stream), "pmt_plan_groups_device")
+                                       scratch.data_ptr(), torch.cuda.current_stream().cuda_stream), "pmt_plan_groups_device")
     torch.cuda.synchronize()
     want_gs, want_gt = [0], [0]
     for lo in range(0, n, chunk):
@@ -111,7 +111,7 @@ def test_device_planner_is_the_host_planner_chunk_by_chunk(n):
     # a capacity one short raises the fault word (and the kernels' group count stays inside what was allocated)
     if g > 1:
         L.check(lib.pmt_plan_groups_device(ro.data_ptr(), ao.data_ptr(), n, gs.data_ptr(), gt.data_ptr(), g - 1, ng.data_ptr(), fault.data_ptr(),
-                                           torch.cuda.current_stream().cuda_stream), "pmt_plan_groups_device")
+                                           scratch.data_ptr(), torch.cuda.current_stream().cuda_stream), "pmt_plan_groups_device")
         assert int(fault.item()) == 4 and int(ng.item()) == g - 1
 
 
@@ -151,3 +151,26 @@ def test_a_downsampled_training_step_on_its_own_plan_equals_the_step_on_its_pare
     assert np.median(np.abs(l1 - l0)) < 2e-6
     np.testing.assert_allclose(f1, f0, rtol=1e-5, atol=1e-5)
     assert np.linalg.norm(g1 - g0) <= 2e-5 * np.linalg.norm(g0)
+
+
+@pytest.mark.parametrize("num_sources", [1, 3])  # (one source: the histogram joined in LDS; three: global atomics)
+def test_fused_evaluation_tallies_match_the_torch_form(num_sources):
+    """pmt_record_evaluation against the torch composition it replaces (EvaluationCounts.record_batch_torch; the reference's tallies
+    themselves are pinned through it by tests/test_metrics_gpu.py): histogram over (source, label, type, count bins, logit bin) of the
+    LABELED variants' weights, and per label the weight called artifact / not and the weighted logit sum -- both epoch types."""
+    from permutect_amd.training.loss_recorder import EvaluationCounts
+    rng = np.random.default_rng(17 + num_sources)
+    fused, ref = EvaluationCounts(DEV, num_sources), EvaluationCounts(DEV, num_sources)
+    for step, n in enumerate((5000, 37, 9000)):
+        batch = _batch(rng, n, num_sources)
+        b = batch if step != 1 else DownsampledBatch.on_device(batch, seed=9)
+        logits = torch.from_numpy(rng.normal(0, 6, n).astype(np.float32)).to(DEV)  # (beyond +-10 on both sides: the clamped end bins)
+        logits[:4] = torch.tensor([-10.0, 10.0, 0.0, 9.999], device=DEV)
+        weights = torch.from_numpy(rng.uniform(0.1, 3.0, n).astype(np.float32)).to(DEV)
+        fused.record_batch(step % 2, b, logits, weights)
+        ref.record_batch_torch(step % 2, b, logits, weights)
+    torch.cuda.synchronize()
+    assert fused.batches == 3
+    np.testing.assert_allclose(fused.hist.cpu().numpy(), ref.hist.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(fused.stats.cpu().numpy(), ref.stats.cpu().numpy(), rtol=2e-5, atol=1e-3)
+    assert float(ref.hist.sum()) > 0 and abs(fused.accuracy(0) - ref.accuracy(0)) < 1e-6
