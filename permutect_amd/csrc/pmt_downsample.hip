@@ -76,27 +76,47 @@ __global__ __launch_bounds__(DS_THREADS) void pmt_downsample_counts_kernel(PmtDo
     const int bb = live ? b : 0;
     const int r0 = a.ref_offsets[bb], nr = a.ref_offsets[bb + 1] - r0, a0 = a.alt_offsets[bb], na = a.alt_offsets[bb + 1] - a0;
     float fr = 0.f, fa = 0.f;
-    if (sub < 2 && live) {  // lane 0 draws the ref fraction, lane 1 the alt fraction
-        if (a.ref_fracs_in != nullptr) {
-            fr = sub == 0 ? a.ref_fracs_in[b] : a.alt_fracs_in[b];
-        } else {
+    if (a.ref_fracs_in != nullptr) {
+        fr = live ? a.ref_fracs_in[bb] : 0.f;
+        fa = live ? a.alt_fracs_in[bb] : 0.f;
+    } else {
+        // The two fractions: a Beta(a, b) of the basis shapes is the a-th smallest of a + b - 1 <= 9 uniforms.  Lanes 0 - 8 of the variant's
+        // sixteen draw ONE uniform each (per side) and rank it among the nine with eight shuffles; the lane of rank a - 1 holds the
+        // fraction.  The same uniforms (stream 32 / 64 + 16 + i) as beta_sample's sort, hence the same fractions bit for bit -- without two
+        // lanes of sixteen sorting nine hashes each while fourteen wait (that was most of this kernel's 42 us).
+        int comp[2] = {0, 0};
+        if (sub < 2) {  // lane 0 picks the ref component, lane 1 the alt component
             const float* w4 = sub == 0 ? a.ref_weights_b4 : a.alt_weights_b4;
             if (w4 != nullptr) {
-                w4 += 4 * (size_t)b;
+                w4 += 4 * (size_t)bb;
             } else if (a.ref_weight_table != nullptr) {  // the variant's cell of the Downsampler's tables: PARENT counts (data/batch.py:228-230)
                 const PmtBinning& g = a.bins;
                 const int rbin = min(nr, g.max_ref_count) / g.count_bin_skip, abin = (min(na, g.max_alt_count) - 1) / g.count_bin_skip;
-                const long long cell = (((ds_col_at(a.sources, b) * 3 + ds_col_at(a.labels, b)) * g.num_variant_types + ds_col_at(a.variant_types, b)) *
+                const long long cell = (((ds_col_at(a.sources, bb) * 3 + ds_col_at(a.labels, bb)) * g.num_variant_types + ds_col_at(a.variant_types, bb)) *
                                         g.num_ref_bins + rbin) * g.num_alt_bins + abin;
                 w4 = (sub == 0 ? a.ref_weight_table : a.alt_weight_table) + 4 * cell;
             }
-            const int k = pick_component(w4, uniform01(a.seed, sub, b));
-            fr = beta_sample(k, a.seed, sub == 0 ? 32 : 64, b);
+            comp[0] = pick_component(w4, uniform01(a.seed, sub, bb));
+        }
+        comp[1] = __shfl(comp[0], 1, DS_LANES);
+        comp[0] = __shfl(comp[0], 0, DS_LANES);
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int k = comp[side];
+            const int sa = (k == 2 || k == 3) ? 5 : 1, sb = (k == 1 || k == 3) ? 5 : 1, n = sa + sb - 1;
+            const float u = sub < n ? uniform01(a.seed, (side == 0 ? 32 : 64) + 16 + sub, bb) : 2.0f;  // (lanes beyond n: above every uniform)
+            int rank = 0;  // how many of the n uniforms sort before this lane's (ties: the lower lane first, like the stable insertion sort)
+#pragma unroll
+            for (int o = 0; o < 9; ++o) {
+                const float v = __shfl(u, o, DS_LANES);
+                rank += (o < n && (v < u || (v == u && o < sub))) ? 1 : 0;
+            }
+            const unsigned long long holder = __ballot(sub < n && rank == sa - 1);  // one lane of each sub-group
+            const int src = __ffsll((long long)((holder >> (threadIdx.x & 48)) & 0xFFFFull)) - 1;
+            const float f = __shfl(u, src < 0 ? 0 : src, DS_LANES);
+            if (side == 0) fr = f; else fa = f;
         }
     }
-    // (sub-groups of 16 lanes inside a wave: width-16 shuffles)
-    fa = __shfl(fr, 1, DS_LANES);
-    fr = __shfl(fr, 0, DS_LANES);
     const long long forced = forced_alt(a, a0, na);
     int cr = 0, ca = 0;
     if (live) {
