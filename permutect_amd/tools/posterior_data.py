@@ -198,6 +198,10 @@ def make_posterior_mmap(dataset: ReadsDataset, model, batch_size: int, device: O
         import torch.distributed as dist
         from permutect_amd.training.distributed import host_group
         group = host_group()
+        # (every rank got here, i.e. its shard went through: a rank that raised above has left the others at this all-reduce, which fails
+        #  with it -- instead of rank 0 waiting for rows that will never be sent)
+        done_everywhere = torch.ones(1, dtype=torch.int32)
+        dist.all_reduce(done_everywhere, op=dist.ReduceOp.MIN, group=group)
         per = n_total // world_size
         if rank == 0:
             for r in range(1, world_size):

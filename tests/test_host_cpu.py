@@ -421,3 +421,35 @@ def test_no_mfma_accumulates_onto_another_opcodes_result_without_wait_states():
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
         found = [f for per_lib in pool.map(lambda p: chk.check([p]), libs) for f in per_lib]
     assert found == [], found[:5]
+
+
+def test_instance_libraries_carry_the_default_librarys_build_id(tmp_path, monkeypatch):
+    """a per-shape library kept from an earlier state of the tree must not be reused.  Every build of the library carries a hash
+    of the sources (pmt_build_id); engine/instances.py reads it out of the FILE (a library it has mapped cannot be replaced by a rebuilt
+    one) and takes only libraries whose id is the default library's."""
+    import glob
+    import shutil
+    import warnings
+    from permutect_amd.engine import instances as I
+    default_id = L.build_id(L.load())
+    assert re.fullmatch(r"[0-9a-f]{16}", default_id) and default_id != "0" * 16
+    libs = sorted(glob.glob(os.path.join(I.INSTANCE_DIR, "*.so")))
+    assert libs and all(I.file_build_id(p) == default_id and I.is_current(p) for p in libs)
+    # a library from other sources: the same file with another id
+    stale = tmp_path / os.path.basename(libs[0])
+    blob = open(libs[0], "rb").read()
+    assert blob.count(b"PMT_BUILD_ID=" + default_id.encode()) >= 1
+    stale.write_bytes(blob.replace(b"PMT_BUILD_ID=" + default_id.encode(), b"PMT_BUILD_ID=" + b"0123456789abcdef"))
+    assert I.file_build_id(str(stale)) == "0123456789abcdef" and not I.is_current(str(stale))
+    assert I.file_build_id(str(tmp_path / "missing.so")) is None
+    # ... is ignored by library_for (PMT_JIT=0: nothing is rebuilt; the model runs the generic instance, loudly)
+    monkeypatch.setenv("PMT_JIT", "0")
+    monkeypatch.setenv("PMT_INSTANCE_DIR", str(tmp_path))
+    monkeypatch.setattr(I, "INSTANCE_DIR", str(tmp_path / "nothing_here"))
+    model = ArtifactModel(t0_params(), device=CPU, **P0_DIMS)
+    from permutect_amd.engine.plan import EnginePlan, ParamSpace
+    desc = EnginePlan(model, ParamSpace(model, CPU), CPU).desc
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        lib = I.library_for(desc)
+    assert lib is L.load() and any("OTHER sources" in str(w.message) for w in caught), [str(w.message)[:80] for w in caught]
