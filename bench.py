@@ -710,6 +710,23 @@ def main():
                  "note": "a downsampled batch keeps a Beta-distributed fraction of its parent's reads, so a loop step holds fewer reads than a resident "
                          "bench step of the same read-set count; vs_resident compares read sets per second"}
         note(f"epoch loop: {epoch['ms_per_step']:.3f} ms per optimizer step = {epoch['vs_resident']:.2f} x the resident rate (epochs {epoch_s})")
+        # ... and the evaluation pass the loop runs after every validation epoch (reference model_training.py:204-228): three downsamplings of
+        # every parent batch, forward with the balancer's weights, the tallies of EvaluationMetrics -- here over the training data only
+        from permutect_amd.training.balancer import Balancer
+        from permutect_amd.training.downsampler import Downsampler
+        from permutect_amd.training.loss_recorder import collect_evaluation_data
+        ebal, edown = Balancer(1, dev), Downsampler(1).to(dev)
+        for timed_pass in (False, True):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            ev = collect_evaluation_data(emodel, ebal, edown, ds1.device_loader(bsz, dev, chunk_variants=chunk, shuffle=False), None, seed=3)
+            acc = ev.accuracy(0)  # (the pass's one host sync)
+            eval_s = time.perf_counter() - t
+        eval_steps = 3 * (-(-(1 << 20) // bsz))
+        epoch["evaluation"] = {"what": "collect_evaluation_data over the same dataset: 3 downsamplings per parent batch, filter forward, balancer, tallies; H2D inclusive",
+                               "value": eval_steps * bsz / eval_s, "unit": "read-sets/s", "ms_per_step": 1e3 * eval_s / eval_steps, "steps": eval_steps,
+                               "accuracy_of_the_untrained_model": acc}
+        note(f"evaluation pass: {epoch['evaluation']['ms_per_step']:.3f} ms per forward step ({eval_steps} steps)")
         del emodel
         loader = {"workload": "batches composed on the device from 2^18-variant chunks that the device chunk loader streams out of a synthetic dataset "
                               "in host memory (H2D inside the timed region); page-locked by ReadsDataset.pin_memory_if_it_fits exactly as "

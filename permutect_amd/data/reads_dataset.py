@@ -484,6 +484,8 @@ class DeviceChunkLoader:
     def __init__(self, dataset: ReadsDataset, batch_size: int, device: torch.device, chunk_variants: Optional[int],
                  rng: Optional[np.random.Generator], shuffle: bool, rank: int, world_size: int):
         self.dataset, self.batch_size, self.device = dataset, batch_size, torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:  # (`torch.device("cuda")`: the prefetch threads need the card spelled out)
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.rng = np.random.default_rng() if rng is None else rng
         self.shuffle = shuffle
         n = len(dataset)
