@@ -27,7 +27,10 @@
 #include "permutect_amd.h"
 #define PMT_OPAQUE_TID 1  // the kernel loops over groups (persistent launch): see pmt_tid
 #ifndef PMT_BWD_XH4_AT_P3
-#define PMT_BWD_XH4_AT_P3 0  // (measured: 2.94 -> 3.04 ms: the in-order memory counter makes the phase's small loads wait for it)
+#define PMT_BWD_XH4_AT_P3 3  // where phase 4's stash read of xhat_l is requested: 0 in phase 4 itself; 1 / 2 in phase 3 (round 2: 2.94 -> 3.04 ms: the
+                             // in-order memory counter makes the phase's small loads wait for it); 3 (round 5) together with z in phase 1, pinned by
+                             // scheduling barriers: the block's two HBM round trips are requested at once -- 2.42 -> 2.39 ms, no more: every product
+                             // in between waits for weight fragments through the same in-order counter, so the latency is moved, not hidden
 #endif
 #ifndef PMT_BWD_PRIO
 #define PMT_BWD_PRIO 0
@@ -446,6 +449,7 @@ DEV void backward_group(
         };
         f4 xh4[PMT_RT][NTD];  // phase 4's xhat_l and rstd
         float rs4[PMT_RT];
+        bool xh4_requested = false;
         auto load_xh4 = [&]() {
             load_xhat(xh4, l);
 #pragma unroll
@@ -466,6 +470,14 @@ DEV void backward_group(
 #pragma unroll
                     for (int t = 0; t < 2 * HT; ++t) z[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
                     if (mask_all & (1u << rt)) stash_load<2 * HT>(stash_tile[rt] + (size_t)(slot_z0 + l) * PMT_SLOT_FLOATS, z[rt]);
+                }
+                // (3: phase 4's xhat_l requested TOGETHER with z -- the two HBM round trips of a block overlap instead of following each
+                //  other; the 32 registers it holds through phases 2 - 3 are paid for with a shallower fragment prefetch)
+                if (PMT_BWD_XH4_AT_P3 == 3) {
+                    __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks the request down to its use)
+                    load_xh4();
+                    __builtin_amdgcn_sched_barrier(0);
+                    xh4_requested = true;
                 }
             } else {
                 f4 n[PMT_RT][NTD], xq[PMT_RT][NTD];
@@ -662,7 +674,7 @@ DEV void backward_group(
         trace_ev(c, 21);
         t_ph = prof_now();
         // ---- phase 3: finish d(z2), LayerNorm(h) backward, SELU backward -> d(zpre) ---------------------------------------
-        if (PMT_BWD_XH4_AT_P3 == 1) load_xh4();  // phase 4's stash read, requested here: phase 3 is ~3.6 k cycles of arithmetic to hide it under
+        if (PMT_BWD_XH4_AT_P3 == 1) { load_xh4(); xh4_requested = true; }  // phase 4's stash read, requested here: phase 3 is ~3.6 k cycles of arithmetic to hide it under
         f4 dz[PMT_RT][2 * HT];
         {
             f4 dsw[HT], dsb[HT];
@@ -692,6 +704,7 @@ DEV void backward_group(
                 __builtin_amdgcn_sched_barrier(0);
                 load_xh4();
                 __builtin_amdgcn_sched_barrier(0);
+                xh4_requested = true;
             }
             aux_push_vec_x<HT, EX>(c, uniform(B.sgu_norm_w_src), dsw, h);
             aux_push_vec_x<HT, EX>(c, uniform(B.sgu_norm_b_src), dsb, h);
@@ -703,7 +716,7 @@ DEV void backward_group(
         // ---- phase 4: proj1 weight gradient (needs n again), d(n) = W1^T d(zpre), LayerNorm(D) backward ---------------------
         {
             f4 n[PMT_RT][NTD];
-            if (PMT_BWD_XH4_AT_P3 == 0) load_xh4();
+            if (!xh4_requested) load_xh4();  // (the generic instances and the later slices of a layered backward: no early request)
             affine_n(n, xh4);
             if constexpr (S::BF16 != 0) wgrad_exchange_bf<2 * HT, NTD, 2, BFB>(c, M->lin[uniform(B.proj1[0])], M->lin[uniform(B.proj1[1])], dz, n, 1.0f);
             else wgrad_exchange<2 * HT, NTD, 2>(c, M->lin[uniform(B.proj1[0])], M->lin[uniform(B.proj1[1])], dz, n, 1.0f);
