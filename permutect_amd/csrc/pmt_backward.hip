@@ -16,8 +16,25 @@
 // Replaces autograd over reference artifact_model.py:239-297 (misc_utils.py:127 `loss.backward()`).
 // Wave shape: 8 waves x 2 read tiles (2 waves per SIMD, 256 VGPRs each).  VALU instructions only address the 256
 // architectural VGPRs, so a 512-register "fat wave" (4 x 4) just shuffles values through AGPRs: measured slower.
+// PMT_BWD_RT = 1 (experimental build, `make EXTRA=-DPMT_BWD_RT=1`): the same 16-tile groups on SIXTEEN waves of one tile each, 128 registers,
+// four waves per SIMD -- twice the waves to hide a phase's latency behind; the weight-gradient exchange pairs neighbouring waves' tiles
+// into the 32 reads of one MFMA (16-bit stores into the halves of the dwords the two-tile form writes whole).
+#ifndef PMT_BWD_RT
+#define PMT_BWD_RT 2
+#endif
+#if PMT_BWD_RT == 1
+#define PMT_WAVES (2 * PMT_GROUP_WAVES)
+#define PMT_RT 1
+#define PMT_AUX_CAP 160  // (16 slabs: the LDS budget)
+#define PMT_BWD_WAVES_PER_SIMD 4
+#ifndef PMT_BWD_FRAG_AHEAD
+#define PMT_BWD_FRAG_AHEAD 2
+#endif
+#else
 #define PMT_WAVES PMT_GROUP_WAVES
 #define PMT_RT 2
+#define PMT_BWD_WAVES_PER_SIMD 2
+#endif
 #ifndef PMT_BWD_PIECES
 #define PMT_BWD_PIECES 3  // pieces of the products that keep the forward's precision (the head's recomputation); the input-gradient and
                           // recomputation products of the layers take PMT_DGRAD_PIECES / PMT_RECOMPUTE_PIECES (pmt_bwd_device.hpp)
@@ -42,6 +59,12 @@
 #include "pmt_device.hpp"
 #include "pmt_mlp_device.hpp"
 #include "pmt_bwd_device.hpp"
+// The development switches of PmtBatch.debug_flags[1] (BwdCtx.dbg) are compiled OUT of a production build: the word is a dependent global
+// load at the top of every group, ~25 uniform branches on its bits cut the scheduler's regions (one in front of every exchange), and it
+// holds a scalar register the kernel spills for.  The trace / profile / knock-out builds (scripts/bwd_trace.py, bwd_ablate.py) turn it on.
+#ifndef PMT_BWD_DEBUG
+#define PMT_BWD_DEBUG (PMT_BWD_PROF || PMT_BWD_ABLATE)  // (the event log of -DPMT_BWD_TRACE=1 has its own word, debug_flags[2])
+#endif
 
 struct BwdShared {
     int off[2][PMT_GROUP_MAX_SETS + 1];
@@ -84,12 +107,10 @@ template <int NT>
 DEV void load_slot_tiles(const float* const (&stash_tile)[PMT_RT], unsigned mask, int slot, f4 (&v)[PMT_RT][NT], float* sink = nullptr) {
 #pragma unroll
     for (int rt = 0; rt < PMT_RT; ++rt) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) v[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
-        if (mask & (1u << rt)) {
-            stash_load<NT>(stash_tile[rt] + slot * PMT_SLOT_FLOATS, v[rt]);
-            if (sink != nullptr && slot > 0) stash_prefetch(stash_tile[rt] + (slot - 1) * PMT_SLOT_FLOATS, sink);
-        }
+        // (a tile the wave does not have reads the group's FIRST tile -- stash_tile[] points there: finite values under a gradient that
+        //  is zero in every lane, like the padding reads of a tile it has; no zero fill, no branch around the load)
+        stash_load<NT>(stash_tile[rt] + slot * PMT_SLOT_FLOATS, v[rt]);
+        if (sink != nullptr && slot > 0 && (mask & (1u << rt))) stash_prefetch(stash_tile[rt] + (slot - 1) * PMT_SLOT_FLOATS, sink);
     }
 }
 
@@ -110,7 +131,7 @@ struct PmtBwdLayered {
 
 // One group (blockIdx.x of the one-group-per-workgroup launch; `grp` of the persistent one).  priv: this workgroup's private
 // row of weight-gradient partial sums, biased so that a PmtLinear.emit_tab offset indexes it directly; nullptr = atomics.
-template <typename S, bool LAYERED>
+template <typename S, bool LAYERED, bool PRIV>
 DEV void backward_group(
     const PmtModel* __restrict__ M, const float* __restrict__ theta, const float* __restrict__ phi,
     const float* __restrict__ packed, const PmtBatch& bt, const PmtOutputs& out, const PmtOutputGrads& dout, const float* __restrict__ stash,
@@ -118,9 +139,16 @@ DEV void backward_group(
     float* __restrict__ gvar, const PmtBwdLayered& lay, const int grp, BwdShared& sh, float* __restrict__ priv) {
     constexpr int NTF = S::NTF, NTR = S::NTR, NTD = S::NTD, NTE = S::NTE;
     constexpr bool EX = S::EXACT;
+    // Small-parameter pushes of a gated block between two exchanges (an exchange empties the slab): the set coupling's rows, LayerNorm(h)'s
+    // two vectors and the gate scalars in front of the proj1 exchange; LayerNorm(D)'s two vectors behind it (+ 8: a skip block's alpha
+    // left by the MLP before).  When both fit, the block's pushes skip the capacity check (pmt_bwd_device.hpp: CHECK).
+    constexpr bool AUXCHK = !(EX && 3 * 16 * PMT_HT + 8 + 8 <= PMT_AUX_CAP && 2 * 16 * NTD + 8 <= PMT_AUX_CAP);
     // Pieces of the activations / gradients in the backward's products: BFB (three, like the forward) where PMT_DG / PMT_RC do not
     // apply; the layers' input-gradient and recomputation products run on two (pmt_bwd_device.hpp, with the fp64 yardstick).
-    constexpr int BFB = S::BF16 == 3 ? PMT_BWD_PIECES : S::BF16;
+    // BFP: the pieces, for the products called from here; BFB: the same + the PRIV bit, for everything that reaches an exchange.
+    constexpr int BFP = S::BF16 == 3 ? PMT_BWD_PIECES : S::BF16;
+    constexpr int BFB = BFP | ((PRIV && S::BF16 != 0) ? PMT_BF_PRIV : 0);
+    static_assert(!PRIV || S::BF16 != 0, "private rows: the bf16-exchange instances only");
     static_assert(EX || (NTF == NTD && NTR == NTD && NTE == NTD), "the generic shape keeps one array width");
     const int tid = pmt_tid(), lane = tid & 63, g = lane >> 4, wave = uniform((int)(tid >> 6));
     const GroupGeom gg = group_geometry(bt, grp);
@@ -166,23 +194,25 @@ DEV void backward_group(
     TileMeta tm[PMT_RT];
     unsigned mask_all = 0;
     const float* stash_tile[PMT_RT];
+    int tile_of[PMT_RT];
     const int nslots = stash_num_slots(M);
 #pragma unroll
     for (int rt = 0; rt < PMT_RT; ++rt) {
         tm[rt] = tile_meta(gg, rt, &sh.off[0][0]);
         if (tm[rt].present) mask_all |= 1u << rt;
-        stash_tile[rt] = stash + (size_t)(bt.group_tile_base[grp] + gg.tile_begin + rt) * (size_t)(nslots * PMT_SLOT_FLOATS);
-        if (bt.debug_flags && (uniform(bt.debug_flags[1]) & 256)) stash_tile[rt] = stash + (size_t)rt * (size_t)(nslots * PMT_SLOT_FLOATS);  // timing experiment: every read hits L2
+        tile_of[rt] = bt.group_tile_base[grp] + (tm[rt].present ? gg.tile_begin + rt : 0);  // (an absent tile: the group's first, see load_slot_tiles)
+        stash_tile[rt] = stash + (size_t)tile_of[rt] * (size_t)(nslots * PMT_SLOT_FLOATS);
+        if (PMT_BWD_DEBUG && bt.debug_flags && (uniform(bt.debug_flags[1]) & 256)) stash_tile[rt] = stash + (size_t)rt * (size_t)(nslots * PMT_SLOT_FLOATS);  // timing experiment: every read hits L2
     }
     BwdCtx c{M, theta, phi, packed, gtheta, gphi, &sh.stage[0], &sh.aux[0][0], &sh.aux_dst[0], g, mask_all,
              gg.tile_begin, gg.ntiles, gg.tiles_ref, 0,
-             bt.debug_flags ? uniform(bt.debug_flags[1]) : 0,
-             bt.debug_flags ? reinterpret_cast<unsigned long long*>(bt.debug_flags + 8) : nullptr};
+             (PMT_BWD_DEBUG && bt.debug_flags) ? uniform(bt.debug_flags[1]) : 0,
+             (PMT_BWD_DEBUG && bt.debug_flags) ? reinterpret_cast<unsigned long long*>(bt.debug_flags + 8) : nullptr};
     c.wr = gg.wr;
     c.priv = priv;
     if (PMT_BWD_TRACE && bt.debug_flags && uniform(bt.debug_flags[2]) == grp + 1) c.trace = bt.debug_flags + 64 + wave * 512;
     trace_ev(c, 1);
-    c.wbase = stage_wbase(lane);
+    c.wbase = stage_wbase(lane) + (PMT_RT == 1 ? 2 * (wave & 1) : 0);  // (one tile per wave: the odd wave of a pair writes the upper halves)
     c.rbase = stage_rbase(lane);
     c.pf_sink = (c.dbg & 64) ? &sh.pf_sink[0] : nullptr;  // stash prefetch: OFF (measured slower, see DESIGN)
     const unsigned long long t_kernel0 = prof_now();
@@ -229,7 +259,7 @@ DEV void backward_group(
             if constexpr (EX) {
                 const PmtLinear& Lr = M->lin[uniform(red_last.lin[0])];
                 init_bias<NTE>(e, uniform(Lr.b_pvec) >= 0 ? packed + uniform(Lr.b_pvec) : nullptr, E, g);
-                if constexpr (S::BF16) linear_acc_bf16<NTD, NTE, false, BFB>(e, r, packed + uniform(Lr.wb_frag));
+                if constexpr (S::BF16) linear_acc_bf16<NTD, NTE, false, BFP>(e, r, packed + uniform(Lr.wb_frag));
                 else linear_acc<NTD, NTE, false, true, S::DIM_D>(e, r, packed + uniform(Lr.w_frag), D, E);
                 if constexpr (S::DROP) {
                     if (drop.on != 0) drop_apply<NTE>(drop, uniform(red_last.lin[0]), e, g);
@@ -261,7 +291,7 @@ DEV void backward_group(
                 a[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        if constexpr (S::BF16) linear_acc_bf16<NTE, NTE, false, BFB>(a, e, packed + uniform(R.wb_frag));
+        if constexpr (S::BF16) linear_acc_bf16<NTE, NTE, false, BFP>(a, e, packed + uniform(R.wb_frag));
         else linear_acc<NTE, NTE, false, EX, S::DIM_E>(a, e, packed + uniform(R.w_frag), E, E);
 
         // ---- head backward (alt reads) + set-mean gradients -> d(a) in da ------------------------------------------
@@ -420,9 +450,7 @@ DEV void backward_group(
     auto load_xhat = [&](f4 (&xh)[PMT_RT][NTD], int l) {
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt) {
-#pragma unroll
-            for (int t = 0; t < NTD; ++t) xh[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
-            if (mask_all & (1u << rt)) stash_load<NTD>(stash_tile[rt] + (slot_x0 + l) * PMT_SLOT_FLOATS, xh[rt]);
+            stash_load<NTD>(stash_tile[rt] + (slot_x0 + l) * PMT_SLOT_FLOATS, xh[rt]);
         }
     };
     const bool joined = LAYERED && lay.join.on != 0;
@@ -454,7 +482,7 @@ DEV void backward_group(
             load_xhat(xh4, l);
 #pragma unroll
             for (int rt = 0; rt < PMT_RT; ++rt)
-                rs4[rt] = (mask_all & (1u << rt)) ? rstd_stash[((size_t)(bt.group_tile_base[grp] + gg.tile_begin + rt) * L + l) * 16 + (lane & 15)] : 0.f;
+                rs4[rt] = rstd_stash[((size_t)tile_of[rt] * L + l) * 16 + (lane & 15)];
         };
         t_ph = prof_now();
         // ---- phase 1: z = selu(W1 n + b1).  The exact-width instances take it from the stash, where the forward left both halves
@@ -467,9 +495,7 @@ DEV void backward_group(
             if constexpr (EX && PMT_STASH_Z) {
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt) {
-#pragma unroll
-                    for (int t = 0; t < 2 * HT; ++t) z[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
-                    if (mask_all & (1u << rt)) stash_load<2 * HT>(stash_tile[rt] + (size_t)(slot_z0 + l) * PMT_SLOT_FLOATS, z[rt]);
+                    stash_load<2 * HT>(stash_tile[rt] + (size_t)(slot_z0 + l) * PMT_SLOT_FLOATS, z[rt]);
                 }
                 // (3: phase 4's xhat_l requested TOGETHER with z -- the two HBM round trips of a block overlap instead of following each
                 //  other; the 32 registers it holds through phases 2 - 3 are paid for with a shallower fragment prefetch)
@@ -492,7 +518,7 @@ DEV void backward_group(
                 // (the gate multiplies by this: fp32-equivalent products -- three f16 MFMAs on two-piece splits like the forward's, or
                 //  with PMT_BWD_Z_F16 = 0 the six bf16 MFMAs on three-piece splits of round 3)
                 if constexpr (S::BF16 && PMT_BWD_Z_F16) linear_acc_f16<NTD, 2 * HT, false>(z, n, packed + uniform(P1.wh_frag));
-                else if constexpr (S::BF16) linear_acc_bf16<NTD, 2 * HT, false, BFB>(z, n, packed + uniform(P1.wb_frag));
+                else if constexpr (S::BF16) linear_acc_bf16<NTD, 2 * HT, false, BFP>(z, n, packed + uniform(P1.wb_frag));
                 else linear_acc<NTD, 2 * HT, false, EX, S::DIM_D>(z, n, packed + uniform(P1.w_frag), D, PMT_SPLIT0 + h);
 #pragma unroll
                 for (int rt = 0; rt < PMT_RT; ++rt)
@@ -537,7 +563,7 @@ DEV void backward_group(
                                  uniform(B.gamma_src), extra_enc, -1, -1};
             const float val8[8] = {side == 0 ? d_alpha : 0.f, side == 1 ? d_alpha : 0.f, side == 0 ? d_beta : 0.f, side == 1 ? d_beta : 0.f,
                                    d_gamma, extra, 0.f, 0.f};
-            aux_push_scalars<8>(c, enc8, val8);
+            aux_push_scalars<8, AUXCHK>(c, enc8, val8);
         };
 #pragma unroll
         for (int rt = 0; rt < PMT_RT; ++rt)
@@ -663,7 +689,7 @@ DEV void backward_group(
                         a_w += dm_ref * (rho_f - m_ref) * inv_ref;
                     }
                 }
-                aux_push_row16(c, uniform(B.ref_reg_src) + 16 * t, group_sum(a_rho), h - 16 * t);
+                aux_push_row16<AUXCHK>(c, uniform(B.ref_reg_src) + 16 * t, group_sum(a_rho), h - 16 * t);
             }
             if constexpr (LAYERED) aux_push_scalar(c, enc_phi(uniform(B.reg_weight_phi)), a_w);
             else d_reg_w = a_w;  // (pushed with the block's other scalars, phase 3)
@@ -706,8 +732,8 @@ DEV void backward_group(
                 __builtin_amdgcn_sched_barrier(0);
                 xh4_requested = true;
             }
-            aux_push_vec_x<HT, EX>(c, uniform(B.sgu_norm_w_src), dsw, h);
-            aux_push_vec_x<HT, EX>(c, uniform(B.sgu_norm_b_src), dsb, h);
+            aux_push_vec_x<HT, EX, AUXCHK>(c, uniform(B.sgu_norm_w_src), dsw, h);
+            aux_push_vec_x<HT, EX, AUXCHK>(c, uniform(B.sgu_norm_b_src), dsb, h);
             if constexpr (!LAYERED) push_gate_scalars(d_reg_w, enc_phi(uniform(B.reg_weight_phi)));  // (layered: pushed at the end of the launch that computed them)
         }
         prof_add(c, 12, t_ph);
@@ -743,8 +769,8 @@ DEV void backward_group(
                 layernorm_bwd_inplace_tile<NTD>(dy[rt], dn[rt], xh4[rt], rs4[rt], D, lw, dlw, dlb, g);
             }
             __builtin_amdgcn_sched_barrier(0);
-            aux_push_vec_x<NTD, EX>(c, uniform(B.norm_w_src), dlw, D);
-            aux_push_vec_x<NTD, EX>(c, uniform(B.norm_b_src), dlb, D);
+            aux_push_vec_x<NTD, EX, AUXCHK>(c, uniform(B.norm_w_src), dlw, D);
+            aux_push_vec_x<NTD, EX, AUXCHK>(c, uniform(B.norm_b_src), dlb, D);
         }
         prof_add(c, 14, t_ph);
         trace_ev(c, 24);
@@ -839,15 +865,15 @@ DEV void backward_group(
 // emit-table region of `packed`) and adds its weight-gradient blocks there with plain 16-byte loads and stores -- the ~250 M
 // float atomics per step this replaces are throughput-bound in L2 and cost a tenth of the kernel.
 // pmt_grad_fold_kernel sums the rows into the gradient buffers afterwards.
-template <typename S, bool LAYERED = false>
-__global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
+template <typename S, bool LAYERED = false, bool PRIV = false>
+__global__ __launch_bounds__(PMT_THREADS, PMT_BWD_WAVES_PER_SIMD) void pmt_backward_kernel(
     const PmtModel* __restrict__ M, const float* __restrict__ theta, const float* __restrict__ phi,
     const float* __restrict__ packed, PmtBatch bt, PmtOutputs out, PmtOutputGrads dout, const float* __restrict__ stash,
     const float* __restrict__ zsum_stash, const float* __restrict__ rstd_stash, float* __restrict__ gtheta, float* __restrict__ gphi,
     float* __restrict__ gvar, PmtBwdLayered lay, float* __restrict__ partials, int emit_base, int emit_len) {
     __shared__ __attribute__((aligned(16))) BwdShared sh;
     const int ngroups = bt.num_groups_dev != nullptr ? uniform(bt.num_groups_dev[0]) : bt.num_groups;  // (device count: graph replay)
-    float* priv = partials != nullptr ? partials + (size_t)blockIdx.x * (size_t)emit_len - emit_base : nullptr;
+    float* priv = PRIV ? partials + (size_t)blockIdx.x * (size_t)emit_len - emit_base : nullptr;  // (the host picks PRIV = (partials != nullptr))
 #if PMT_BWD_PRIO
     // the second-dispatched half of the workgroup loses every arbitration for its SIMD's issue slots to the older half
     // (MI355X_MICROARCH.md, two waves per SIMD, item 4): one static priority for it, set once
@@ -859,7 +885,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
         for (;;) {
             const int grp = pmt_join_ticket(lay.join, &sh.ticket);
             if (grp >= ngroups) break;
-            backward_group<S, LAYERED>(M, theta, phi, packed, bt, out, dout, stash, zsum_stash, rstd_stash, gtheta, gphi, gvar, lay, grp, sh, priv);
+            backward_group<S, LAYERED, PRIV>(M, theta, phi, packed, bt, out, dout, stash, zsum_stash, rstd_stash, gtheta, gphi, gvar, lay, grp, sh, priv);
             lds_barrier();
         }
         return;
@@ -870,7 +896,7 @@ __global__ __launch_bounds__(PMT_THREADS, 2) void pmt_backward_kernel(
 #else
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
 #endif
-        backward_group<S, LAYERED>(M, theta, phi, packed, bt, out, dout, stash, zsum_stash, rstd_stash, gtheta, gphi, gvar, lay, grp, sh, priv);
+        backward_group<S, LAYERED, PRIV>(M, theta, phi, packed, bt, out, dout, stash, zsum_stash, rstd_stash, gtheta, gphi, gvar, lay, grp, sh, priv);
         lds_barrier();  // the next group reuses the LDS
     }
 }
@@ -941,7 +967,10 @@ extern "C" int pmt_backward(const PmtModel* model_host, const PmtModel* model_de
     const bool part = use_partials(model_host, shape, grad_partials, num_partials);
     const int grid = part && num_partials < batch->num_groups ? num_partials : batch->num_groups;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    auto kernel = shape == 4 ? pmt_backward_kernel<ShapeP0XD> : shape == 3 ? pmt_backward_kernel<ShapeP0XB> : shape == 2 ? pmt_backward_kernel<ShapeP0X>
+    // (private rows are a compile-time property of the bf16-exchange instances: use_partials is false for the others)
+    auto kernel = part ? (shape == 4 ? pmt_backward_kernel<ShapeP0XD, false, true> : shape == 3 ? pmt_backward_kernel<ShapeP0XB, false, true>
+                          : shape == 2 ? pmt_backward_kernel<ShapeP0X, false, true> : pmt_backward_kernel<ShapeP0T, false, true>)
+                  : shape == 4 ? pmt_backward_kernel<ShapeP0XD> : shape == 3 ? pmt_backward_kernel<ShapeP0XB> : shape == 2 ? pmt_backward_kernel<ShapeP0X>
                   : shape == 6 ? pmt_backward_kernel<ShapeP0T> : shape == 1 ? pmt_backward_kernel<ShapeP0> : pmt_backward_kernel<ShapeAny>;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(PMT_THREADS), 0, s, model_dev,
                        theta, phi, packed, *batch, *out, *dout, stash, zsum_stash, rstd_stash, grad_theta, grad_phi, grad_variant_embed,
@@ -982,7 +1011,8 @@ extern "C" int pmt_backward_layered(const PmtModel* model_host, const PmtModel* 
     const int shape = pmt_shape_for(model_host, batch, true);
     const bool part = use_partials(model_host, shape, grad_partials, num_partials);
     const int grid = part && num_partials < batch->num_groups ? num_partials : batch->num_groups;
-    auto kernel = (shape >= 2 && shape != 6) ? pmt_backward_kernel<ShapeP0X, true> : (shape == 1 || shape == 6) ? pmt_backward_kernel<ShapeP0, true> : pmt_backward_kernel<ShapeAny, true>;
+    auto kernel = (shape >= 2 && shape != 6) ? (part ? pmt_backward_kernel<ShapeP0X, true, true> : pmt_backward_kernel<ShapeP0X, true>)
+                  : (shape == 1 || shape == 6) ? pmt_backward_kernel<ShapeP0, true> : pmt_backward_kernel<ShapeAny, true>;
     int* join_words = reinterpret_cast<int*>(lay.gsum_g + B * nb * PMT_ZW);
     lay.join = PmtJoin{0, join_words + B * nb, join_words, batch->join_fault ? batch->join_fault : join_words + B * nb + 1};
     if (batch->set_groups != nullptr && L > 0) {  // ONE launch: the groups of a split read set join their sums through HBM

@@ -13,16 +13,25 @@
 #ifndef PMT_DGRAD_PIECES
 #define PMT_DGRAD_PIECES 2
 #endif
-#define PMT_DG(BF) ((BF) == 3 ? PMT_DGRAD_PIECES : (BF))
+// The BF template argument threaded through the backward's helpers: bits 0-2 = the bf16 pieces of the activations (0: the fp32 instances),
+// bit 3 (PMT_BF_PRIV) = the weight-gradient exchange adds into the workgroup's PRIVATE row (pmt_backward: partials), known at COMPILE time: the
+// choice between the row's one store and the atomics' forest of lane branches used to be a run-time branch in every exchange, and a
+// branch ends a scheduling region (2.10 -> 2.05 ms).
+#define PMT_BF_PRIV 8
+#define PMT_BF_PIECES(BF) ((BF) & 7)
+#define PMT_DG(BF) (PMT_BF_PIECES(BF) == 3 ? PMT_DGRAD_PIECES : PMT_BF_PIECES(BF))
 #ifndef PMT_RECOMPUTE_PIECES
 #define PMT_RECOMPUTE_PIECES 2
 #endif
-#define PMT_RC(BF) ((BF) == 3 ? PMT_RECOMPUTE_PIECES : (BF))
+#define PMT_RC(BF) (PMT_BF_PIECES(BF) == 3 ? PMT_RECOMPUTE_PIECES : PMT_BF_PIECES(BF))
 #ifndef PMT_STAGE_PLANES
 #define PMT_STAGE_PLANES 96  // LDS operand-exchange capacity in planes of 64 x float4 (1 KiB each); a TU may shrink it
 #endif
 #ifndef PMT_AUX_CAP
 #define PMT_AUX_CAP 256      // floats per wave of the small-parameter gradient slab
+#endif
+#ifndef PMT_BWD_ABLATE
+#define PMT_BWD_ABLATE 0  // development build (scripts/bwd_ablate.py): knock-outs of the exchange's parts through PmtBatch.debug_flags[1]
 #endif
 
 DEV float read_lanes_sum(float v) {  // sum over the 16 reads of a tile (lanes with equal lane >> 4)
@@ -239,16 +248,14 @@ DEV int enc_at(int enc, int f) { return enc >= 0 ? enc + f : enc - f; }
 
 // sum the slabs over the waves and add to global memory; callers bracket it with workgroup barriers
 DEV void aux_reduce(BwdCtx& c) {
-    for (int i = pmt_tid(); i < c.aux_n; i += PMT_THREADS) {
+    static_assert(PMT_AUX_CAP <= PMT_THREADS, "one slab entry per thread");
+    if (const int i = pmt_tid(); i < c.aux_n) {
         const int d = c.aux_dst[i];
         if (d != -1) {
             float s = 0.f;
 #pragma unroll
             for (int w = 0; w < PMT_WAVES; ++w) s += c.aux[w * PMT_AUX_CAP + i];
-#if defined(PMT_BWD_ABLATE) && PMT_BWD_ABLATE
-            if (c.dbg & 16384) continue;
-#endif
-            atomicAdd(grad_ptr(d, c.gtheta, c.gphi), s);
+            if (!(PMT_BWD_ABLATE && (c.dbg & 16384))) atomicAdd(grad_ptr(d, c.gtheta, c.gphi), s);
         }
     }
     c.aux_n = 0;
@@ -259,10 +266,12 @@ DEV void aux_flush(BwdCtx& c) {
     lds_barrier();
 }
 // per-feature parameter gradient (tile-position registers, summed here over this wave's reads)
-template <int NT>
+// CHECK = false (every push helper): the caller has shown at compile time that the slab has room -- the check is a uniform branch around two
+// barriers and a loop, inlined at every push, and each one ends a scheduling region.
+template <int NT, bool CHECK = true>
 DEV void aux_push_vec(BwdCtx& c, int enc, const f4 (&v)[NT], int dim) {
     const int nt = (dim + 15) >> 4, lane = pmt_tid() & 63, wave = pmt_tid() >> 6;
-    if (c.aux_n + 16 * nt > PMT_AUX_CAP) aux_flush(c);
+    if (CHECK && c.aux_n + 16 * nt > PMT_AUX_CAP) aux_flush(c);
     if (c.dbg & 16) return;
     // all the cross-lane sums first, then ONE region with a sixteenth of the lanes enabled that stores them
     // (a region per element costs an exec save / restore and a branch each, and runs at full instruction cost)
@@ -326,11 +335,11 @@ DEV float row_halving_sum(const float (&v)[N], int lane) {  // returns the total
         return row_halving_sum<N / 2, STEP + 1>(h, lane);
     }
 }
-template <int NT>
+template <int NT, bool CHECK = true>
 DEV void aux_push_vec_full(BwdCtx& c, int enc, const f4 (&v)[NT], int dim) {
     static_assert(NT == 1 || NT == 2 || NT == 4, "4, 8 or 16 values per lane");
     const int lane = pmt_tid() & 63, wave = pmt_tid() >> 6;
-    if (c.aux_n + 16 * NT > PMT_AUX_CAP) aux_flush(c);
+    if (CHECK && c.aux_n + 16 * NT > PMT_AUX_CAP) aux_flush(c);
     if (c.dbg & 16) return;
     float vals[4 * NT];
 #pragma unroll
@@ -355,15 +364,16 @@ DEV void aux_push_vec_full(BwdCtx& c, int enc, const f4 (&v)[NT], int dim) {
     }
     c.aux_n += 16 * NT;
 }
-template <int NT, bool FULL>
+template <int NT, bool FULL, bool CHECK = true>
 DEV void aux_push_vec_x(BwdCtx& c, int enc, const f4 (&v)[NT], int dim) {
-    if constexpr (FULL && (NT == 1 || NT == 2 || NT == 4)) aux_push_vec_full<NT>(c, enc, v, dim);
-    else aux_push_vec<NT>(c, enc, v, dim);
+    if constexpr (FULL && (NT == 1 || NT == 2 || NT == 4)) aux_push_vec_full<NT, CHECK>(c, enc, v, dim);
+    else aux_push_vec<NT, CHECK>(c, enc, v, dim);
 }
 // one 16-position row (tile 0) whose per-position totals already sit in every lane group: lane (g, p) holds position p
+template <bool CHECK = true>
 DEV void aux_push_row16(BwdCtx& c, int enc, float v, int dim) {
     const int lane = pmt_tid() & 63, wave = pmt_tid() >> 6;
-    if (c.aux_n + 16 > PMT_AUX_CAP) aux_flush(c);
+    if (CHECK && c.aux_n + 16 > PMT_AUX_CAP) aux_flush(c);
     if (c.dbg & 16) return;
     if (lane < 16) {
         const int f = pos_to_feat(lane);
@@ -375,11 +385,11 @@ DEV void aux_push_row16(BwdCtx& c, int enc, float v, int dim) {
 // N scalar gradients at once (4 or 8; enc -1 = none): the halving butterfly of aux_push_vec_full over the 16 lanes of a row, then the
 // four rows -- N + 5 exchange-adds instead of 6 N (a scalar's wave_sum is six exchange steps; the head and the gated blocks push
 // ~60 scalars per group, 6 % of the kernel's vector instructions before this)
-template <int N>
+template <int N, bool CHECK = true>
 DEV void aux_push_scalars(BwdCtx& c, const int (&enc)[N], const float (&v)[N]) {
     static_assert(N == 4 || N == 8, "4 or 8 scalars");
     const int lane = pmt_tid() & 63, wave = pmt_tid() >> 6;
-    if (c.aux_n + N > PMT_AUX_CAP) aux_flush(c);
+    if (CHECK && c.aux_n + N > PMT_AUX_CAP) aux_flush(c);
     if (c.dbg & 16) return;
     const float total = group_sum(row_halving_sum<N, 0>(v, lane));
     constexpr int STEPS = N == 8 ? 3 : 2;
@@ -401,8 +411,9 @@ DEV void aux_push_scalars(BwdCtx& c, const int (&enc)[N], const float (&v)[N]) {
     }
     c.aux_n += N;
 }
+template <bool CHECK = true>
 DEV void aux_push_scalar(BwdCtx& c, int enc, float v) {
-    if (c.aux_n + 1 > PMT_AUX_CAP) aux_flush(c);
+    if (CHECK && c.aux_n + 1 > PMT_AUX_CAP) aux_flush(c);
     if (c.dbg & 16) return;
     const float s = wave_sum(v);
     if ((pmt_tid() & 63) == 0) {
@@ -583,6 +594,8 @@ DEV char* lds_ptr(unsigned byte_address) {  // an LDS address back as a pointer 
 #ifndef PMT_STAGE_BLOCK
 #define PMT_STAGE_BLOCK 1
 #endif
+// (Round 5: forming the residuals of one TILE's two neighbouring values with one v_pk_add_f32 -- ten operations per four values instead of
+//  twelve -- was built and measured EQUAL, 2.16 ms: the staging is not bound by its vector instructions.)
 // Two pairs as ONE instruction block: the same six operations per pair, but interleaved two deep (every result is consumed two
 // instructions later) and without the wait state the compiler puts behind every separate
 // inline-asm instruction whose result the next one reads (`s_nop 0`, twice per pair: a fifth of the staging's issue slots).
@@ -631,20 +644,40 @@ DEV void stage_pair_bf16(char* const (&pj)[4], int off, f4 v0, f4 v1) {
     }
 }
 
+// One tile per wave (PMT_RT == 1): the wave writes ITS half of every dword of the pair's plane -- the same addresses, 16-bit stores (pj
+// carries the + 2 bytes of the odd wave).  Two positions share a conversion: the packed pair's low half goes out with ds_write_b16, its
+// high half with ds_write_b16_d16_hi.
+DEV void lds_store16(char* p, unsigned v) { *reinterpret_cast<unsigned short*>(p) = (unsigned short)v; }
+template <int PIECES = 3>
+DEV void stage_half_bf16(char* const (&pj)[4], int off, f4 v) {
+#pragma unroll
+    for (int j = 0; j < 4; j += 2) {
+        const unsigned hi = cvt_pk_bf16(v[j], v[j + 1]);
+        lds_store16(pj[j] + off, hi);
+        lds_store16(pj[j + 1] + off, hi >> 16);
+        if constexpr (PIECES != 1) {
+            const float h0 = __builtin_bit_cast(float, hi << 16), h1 = __builtin_bit_cast(float, hi & 0xFFFF0000u);
+            const unsigned mid = cvt_pk_bf16(sub_f32(v[j], h0), sub_f32(v[j + 1], h1));
+            lds_store16(pj[j] + off + 1024, mid);
+            lds_store16(pj[j + 1] + off + 1024, mid >> 16);
+        }
+    }
+}
+
 #define PMT_BF_PLANE_BYTES 2048  // hi + mid piece of one (wave, plane)
-#ifndef PMT_BWD_ABLATE
-#define PMT_BWD_ABLATE 0  // development build (scripts/bwd_ablate.py): knock-outs of the exchange's parts through PmtBatch.debug_flags[1]
-#endif
 #define PMT_ABL(c, bit) (PMT_BWD_ABLATE && ((c).dbg & (bit)))
-template <int NTO, int NTI, int SIDES, int PIECES = 3>
+template <int NTO, int NTI, int SIDES, int BF = 3>
 DEV void wgrad_exchange_bf(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, const f4 (&dy)[PMT_RT][NTO],
                            const f4 (&x)[PMT_RT][NTI], float scale) {
-    static_assert(PMT_RT == 2, "a wave's two tiles are the 32 reads of one MFMA");
+    static_assert(PMT_RT == 2 || PMT_RT == 1, "a wave's two tiles, or the tiles of a pair of waves, are the 32 reads of one MFMA");
     if (c.dbg & 1) return;
+    constexpr int PIECES = PMT_BF_PIECES(BF);
+    constexpr bool PRIV = (BF & PMT_BF_PRIV) != 0;  // c.priv != nullptr, as a compile-time fact
     constexpr int P = NTO + NTI, NB = NTO * NTI;
+    constexpr int NSLOT = PMT_WG_TILES / 2;  // operand slots of the stage: one per 32 reads (a wave; with one tile per wave a pair of waves)
     constexpr bool COLS = SIDES == 1 && PMT_WAVES % NTI == 0;  // one linear whose columns of blocks divide the waves (1, 2, 4, 8 input tiles)
     constexpr int PW_CAP = (PMT_STAGE_PLANES * 1024) / (P * PMT_BF_PLANE_BYTES);          // waves whose operands fit the stage
-    constexpr int PW = PW_CAP < PMT_WAVES ? PW_CAP : PMT_WAVES;
+    constexpr int PW = PW_CAP < NSLOT ? PW_CAP : NSLOT;
     static_assert(PW >= 1, "stage too small");
     // Blocks of this wave.  One linear (COLS): the wave owns column `it` = wave % NTI and the rows wave / NTI + k * (waves / NTI): its
     // blocks share the x operand, loaded once per pair of tiles.  A ref / alt pair: task q = wave + waves * k of the
@@ -653,7 +686,9 @@ DEV void wgrad_exchange_bf(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, 
     // same task list over its NB blocks.
     constexpr int ROWS = COLS ? PMT_WAVES / NTI : 1;
     constexpr int TPW = COLS ? (NTO + ROWS - 1) / ROWS : (SIDES * NB + PMT_WAVES - 1) / PMT_WAVES;
+    constexpr bool ALL_TASKS = COLS ? NTO % ROWS == 0 : (SIDES * NB) % PMT_WAVES == 0;  // every wave has TPW blocks: no "is there a block" branches
     const int lane = pmt_tid() & 63, g = lane >> 4, wave = uniform((int)(pmt_tid() >> 6));
+    const int my_slot = PMT_RT == 2 ? wave : wave >> 1, wr_s = PMT_RT == 2 ? c.wr : c.wr >> 1;  // (GroupGeom.wr is even with one tile per wave)
     int t_ot[TPW], t_it[TPW], t_side[TPW];
     f4 acc[TPW], accb[TPW];
 #pragma unroll
@@ -681,17 +716,17 @@ DEV void wgrad_exchange_bf(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, 
     for (int k = 0; k < TPW; ++k) {
         e[k] = eb[k] = i4{-1, -1, -1, -1};
         with_bias[k] = false;
-        if (t_side[k] < 0) continue;
+        if (!ALL_TASKS && t_side[k] < 0) continue;
         const PmtLinear& L = (SIDES == 2 && t_side[k] == 1) ? L1 : L0;
         // (private partial sums: the same 16 bytes are this lane's running sums of the block instead of its destinations)
-        const int* tab = reinterpret_cast<const int*>(c.priv != nullptr ? c.priv + uniform(L.emit_tab) : c.packed + uniform(L.emit_tab));
+        const int* tab = reinterpret_cast<const int*>(PRIV ? c.priv + uniform(L.emit_tab) : c.packed + uniform(L.emit_tab));
         e[k] = *reinterpret_cast<const i4*>(tab + ((t_ot[k] * NTI + t_it[k]) * 64 + lane) * 4);
         with_bias[k] = t_it[k] == t_ot[k] % NTI;  // the one block of row ot that also sums the bias gradient (dy x ones)
         if (with_bias[k]) eb[k] = *reinterpret_cast<const i4*>(tab + NB * 256 + t_ot[k] * 16 + 4 * g);
     }
     char* stage = reinterpret_cast<char*>(c.stage);
     unsigned long long t0c = prof_now();
-    for (int w0 = 0; w0 < PMT_WAVES; w0 += PW) {
+    for (int w0 = 0; w0 < NSLOT; w0 += PW) {
         unsigned long long t1 = prof_now();
         trace_ev(c, 100);
         if (PMT_ABL(c, 8192)) {} else if (c.dbg & 128) __syncthreads(); else lds_barrier();  // the stage (and the slabs) of the previous round have been consumed
@@ -699,17 +734,24 @@ DEV void wgrad_exchange_bf(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, 
         prof_add(c, 17, t1);
         if (w0 == 0) aux_reduce(c);
         t1 = prof_now();
-        if (!PMT_ABL(c, 1024) && (PW == PMT_WAVES || (wave >= w0 && wave < w0 + PW))) {
-            char* mine = stage + (wave - w0) * (P * PMT_BF_PLANE_BYTES);
+        if (!PMT_ABL(c, 1024) && (PW == NSLOT || (my_slot >= w0 && my_slot < w0 + PW))) {
+            char* mine = stage + (my_slot - w0) * (P * PMT_BF_PLANE_BYTES);
             // (through an empty asm: computed ONCE per exchange; the compiler otherwise rebuilds each address at every store)
             unsigned a0 = (unsigned)(size_t)(mine + c.wbase), a1 = (unsigned)(size_t)(mine + (c.wbase ^ 16)),
                      a2 = (unsigned)(size_t)(mine + (c.wbase ^ 32)), a3 = (unsigned)(size_t)(mine + (c.wbase ^ 48));
             asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
             char* const pj[4] = {lds_ptr(a0), lds_ptr(a1), lds_ptr(a2), lds_ptr(a3)};
+            if constexpr (PMT_RT == 2) {
 #pragma unroll
-            for (int ot = 0; ot < NTO; ++ot) stage_pair_bf16<PIECES>(pj, ot * PMT_BF_PLANE_BYTES, dy[0][ot], dy[1][ot]);
+                for (int ot = 0; ot < NTO; ++ot) stage_pair_bf16<PIECES>(pj, ot * PMT_BF_PLANE_BYTES, dy[0][ot], dy[PMT_RT - 1][ot]);
 #pragma unroll
-            for (int it = 0; it < NTI; ++it) stage_pair_bf16<PIECES>(pj, (NTO + it) * PMT_BF_PLANE_BYTES, x[0][it], x[1][it]);
+                for (int it = 0; it < NTI; ++it) stage_pair_bf16<PIECES>(pj, (NTO + it) * PMT_BF_PLANE_BYTES, x[0][it], x[PMT_RT - 1][it]);
+            } else {
+#pragma unroll
+                for (int ot = 0; ot < NTO; ++ot) stage_half_bf16<PIECES>(pj, ot * PMT_BF_PLANE_BYTES, dy[0][ot]);
+#pragma unroll
+                for (int it = 0; it < NTI; ++it) stage_half_bf16<PIECES>(pj, (NTO + it) * PMT_BF_PLANE_BYTES, x[0][it]);
+            }
         }
         prof_add(c, 18, t1);
         t1 = prof_now();
@@ -717,14 +759,14 @@ DEV void wgrad_exchange_bf(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, 
         if (PMT_ABL(c, 8192)) {} else if (c.dbg & 128) __syncthreads(); else lds_barrier();
         trace_ev(c, 103);
         prof_add(c, 19, t1);
-        const int whi_all = min(w0 + PW, PMT_WAVES);
+        const int whi_all = min(w0 + PW, NSLOT);
         const char* rd = stage + c.rbase;
         if (PMT_ABL(c, 512)) continue;
         if (COLS) {
-            if (t_side[0] >= 0) {
+            if (ALL_TASKS || t_side[0] >= 0) {
 #pragma unroll
                 for (int w = 0; w < PW; ++w) {  // branch-free body: the scheduler overlaps the reads of one pair with the MFMAs of another
-                    if (w0 + w >= PMT_WAVES) break;
+                    if (w0 + w >= NSLOT) break;
                     const char* pw = rd + w * (P * PMT_BF_PLANE_BYTES);
                     const bf8 bh = *reinterpret_cast<const bf8*>(pw + (NTO + t_it[0]) * PMT_BF_PLANE_BYTES);
                     const bf8 bm = *reinterpret_cast<const bf8*>(pw + (NTO + t_it[0]) * PMT_BF_PLANE_BYTES + 1024);
@@ -736,16 +778,18 @@ DEV void wgrad_exchange_bf(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, 
                         if constexpr (PIECES != 1) {
                             acc[k] = mfma_bf16(am, bh, acc[k]);
                             acc[k] = mfma_bf16(ah, bm, acc[k]);
+                            accb[k] = mfma_bf16(am, ones, accb[k]);
                         }
                         acc[k] = mfma_bf16(ah, bh, acc[k]);
+                        accb[k] = mfma_bf16(ah, ones, accb[k]);
                     }
                 }
             }
         } else {
 #pragma unroll
             for (int k = 0; k < TPW; ++k) {
-                if (t_side[k] < 0) continue;
-                const int lo = SIDES == 1 ? w0 : max(t_side[k] == 1 ? c.wr : 0, w0), hi = SIDES == 1 ? whi_all : min(t_side[k] == 0 ? c.wr : PMT_WAVES, whi_all);
+                if (!ALL_TASKS && t_side[k] < 0) continue;
+                const int lo = SIDES == 1 ? w0 : max(t_side[k] == 1 ? wr_s : 0, w0), hi = SIDES == 1 ? whi_all : min(t_side[k] == 0 ? wr_s : NSLOT, whi_all);
                 const char* pa = rd + t_ot[k] * PMT_BF_PLANE_BYTES;
                 const char* pb = rd + (NTO + t_it[k]) * PMT_BF_PLANE_BYTES;
 #pragma unroll 2
@@ -756,52 +800,49 @@ DEV void wgrad_exchange_bf(BwdCtx& c, const PmtLinear& L0, const PmtLinear& L1, 
                     if constexpr (PIECES != 1) {
                         acc[k] = mfma_bf16(am, bh, acc[k]);
                         acc[k] = mfma_bf16(ah, bm, acc[k]);
+                        accb[k] = mfma_bf16(am, ones, accb[k]);
                     }
                     acc[k] = mfma_bf16(ah, bh, acc[k]);
+                    accb[k] = mfma_bf16(ah, ones, accb[k]);
                 }
             }
         }
-        // bias gradients: the row sums of dy, by one block per row (its A operand once more against a plane of ones)
-#pragma unroll
-        for (int k = 0; k < TPW; ++k) {
-            if (!with_bias[k]) continue;
-            const int lo = SIDES == 1 ? w0 : max(t_side[k] == 1 ? c.wr : 0, w0);
-            const int hi = SIDES == 1 ? whi_all : min(t_side[k] == 0 ? c.wr : PMT_WAVES, whi_all);
-            const char* pa = rd + t_ot[k] * PMT_BF_PLANE_BYTES;
-            for (int w = lo; w < hi; ++w) {
-                const int o = (w - w0) * (P * PMT_BF_PLANE_BYTES);
-                const bf8 ah = *reinterpret_cast<const bf8*>(pa + o), am = *reinterpret_cast<const bf8*>(pa + o + 1024);
-                if constexpr (PIECES != 1) accb[k] = mfma_bf16(am, ones, accb[k]);
-                accb[k] = mfma_bf16(ah, ones, accb[k]);
-            }
-        }
+        // (bias gradients = the row sums of dy: EVERY block multiplies its A operand once more against a plane of ones -- the matrix pipe has
+        //  the room -- and the one block per row that owns the bias emits them: no second pass over the stage by half the waves)
     }
     prof_add(c, 0, t0c);
     trace_ev(c, 104);
     if (c.dbg & 2) return;
     t0c = prof_now();
-    // emit: four atomics per block at the tabulated offsets; no index arithmetic here
+    // emit.  ONE branch on the destination kind around the blocks (not one per block: a branch ends a scheduling region)
+    if constexpr (PRIV) {  // running sums + this group's block, back to the private row (one 16-byte store per lane)
 #pragma unroll
-    for (int k = 0; k < TPW; ++k) {
-        if (t_side[k] < 0) continue;
-        const bool side1 = SIDES == 2 && t_side[k] == 1;
-        if (SIDES == 2 && (side1 ? c.ntiles <= c.tiles_ref : c.tiles_ref <= 0)) continue;  // no tiles on that side
-        const PmtLinear& L = side1 ? L1 : L0;
-        if (c.priv != nullptr) {  // running sums + this group's block, back to the private row (one 16-byte store per lane)
+        for (int k = 0; k < TPW; ++k) {
+            if (!ALL_TASKS && t_side[k] < 0) continue;
+            const bool side1 = SIDES == 2 && t_side[k] == 1;
+            // (a side without tiles: its blocks' sums are zero, the row gets its own value back)
+            const PmtLinear& L = side1 ? L1 : L0;
             float* row = c.priv + uniform(L.emit_tab);
             *reinterpret_cast<f4*>(row + ((t_ot[k] * NTI + t_it[k]) * 64 + lane) * 4) = __builtin_bit_cast(f4, e[k]) + scale * acc[k];
             if (with_bias[k] && (lane & 15) == 0)
                 *reinterpret_cast<f4*>(row + NB * 256 + t_ot[k] * 16 + 4 * g) = __builtin_bit_cast(f4, eb[k]) + scale * accb[k];
-            continue;
         }
-        float* gw = uniform(L.w_src) >= 0 ? c.gtheta : c.gphi;
+    } else {  // four atomics per block at the tabulated offsets; no index arithmetic here
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (e[k][j] >= 0) atomicAdd(gw + e[k][j], scale * acc[k][j]);
-        if (with_bias[k] && (lane & 15) == 0) {  // every column of accb holds the row sums: the lanes of column 0 add them
+        for (int k = 0; k < TPW; ++k) {
+            if (t_side[k] < 0) continue;
+            const bool side1 = SIDES == 2 && t_side[k] == 1;
+            if (SIDES == 2 && (side1 ? c.ntiles <= c.tiles_ref : c.tiles_ref <= 0)) continue;
+            const PmtLinear& L = side1 ? L1 : L0;
+            float* gw = uniform(L.w_src) >= 0 ? c.gtheta : c.gphi;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (eb[k][j] >= 0) atomicAdd(c.gtheta + eb[k][j], scale * accb[k][j]);
+                if (e[k][j] >= 0) atomicAdd(gw + e[k][j], scale * acc[k][j]);
+            if (with_bias[k] && (lane & 15) == 0) {  // every column of accb holds the row sums: the lanes of column 0 add them
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (eb[k][j] >= 0) atomicAdd(c.gtheta + eb[k][j], scale * accb[k][j]);
+            }
         }
     }
     prof_add(c, 2, t0c);
@@ -1006,7 +1047,7 @@ DEV void mlp_backward(BwdCtx& c, const PmtMlp& mlp, f4 (&dy)[PMT_RT][NT], bool n
                         da += (p[0] + p[1]) + (p[2] + p[3]);
                     }
                 }
-                aux_push_scalar(c, uniform(o.alpha_src), da);
+                aux_push_scalar<!EXACT>(c, uniform(o.alpha_src), da);  // (right behind an exchange, which empties the slab)
             };
             if (dropping) {
                 f4 dm[PMT_RT][NT];

@@ -852,6 +852,11 @@ DEV GroupGeom group_geometry(const PmtBatch& bt, int group) {
     const int need_r = (gg.tiles_ref + PMT_RT - 1) / PMT_RT, need_a = (gg.tiles_alt + PMT_RT - 1) / PMT_RT;
     int wr = gg.ntiles > 0 ? (PMT_WAVES * gg.tiles_ref + gg.ntiles / 2) / gg.ntiles : 0;
     wr = min(max(wr, need_r), PMT_WAVES - need_a);
+    if (PMT_RT == 1) {  // one tile per wave: PAIRS of waves are side-homogeneous (a pair's two tiles are the 32 reads of one weight-gradient
+                        // MFMA, pmt_bwd_device.hpp); the planner's rule ceil(ref / 2) + ceil(alt / 2) <= waves / 2 leaves room for the rounding
+        const int pr = (gg.tiles_ref + 1) >> 1, pa = (gg.tiles_alt + 1) >> 1;
+        wr = 2 * min(max((wr + 1) >> 1, pr), PMT_WAVES / 2 - pa);
+    }
     gg.wr = wr;
     gg.side = wave < wr ? 0 : 1;
     const int nw = gg.side == 0 ? wr : PMT_WAVES - wr, i = gg.side == 0 ? wave : wave - wr;
