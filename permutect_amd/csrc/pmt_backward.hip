@@ -44,10 +44,11 @@
 #include "permutect_amd.h"
 #define PMT_OPAQUE_TID 1  // the kernel loops over groups (persistent launch): see pmt_tid
 #ifndef PMT_BWD_XH4_AT_P3
-#define PMT_BWD_XH4_AT_P3 3  // where phase 4's stash read of xhat_l is requested: 0 in phase 4 itself; 1 / 2 in phase 3 (round 2: 2.94 -> 3.04 ms: the
-                             // in-order memory counter makes the phase's small loads wait for it); 3 (round 5) together with z in phase 1, pinned by
-                             // scheduling barriers: the block's two HBM round trips are requested at once -- 2.42 -> 2.39 ms, no more: every product
-                             // in between waits for weight fragments through the same in-order counter, so the latency is moved, not hidden
+#define PMT_BWD_XH4_AT_P3 0  // where phase 4's stash read of xhat_l is requested: 0 in phase 4 itself; 1 / 2 in phase 3 (round 2: 2.94 -> 3.04 ms: the
+                             // in-order memory counter makes the phase's small loads wait for it); 3 together with z in phase 1, pinned by
+                             // scheduling barriers (round 5, on the kernel with run-time debug branches: 2.42 -> 2.39 ms).  Measured again on the
+                             // kernel WITHOUT those branches (the scheduler now moves loads across whole phases by itself): 0 / 2: 2.03 - 2.04 ms,
+                             // 3: 2.06, 1: 2.09 -- the 32 registers an early request holds cost more than the overlap gives; back to 0
 #endif
 #ifndef PMT_BWD_PRIO
 #define PMT_BWD_PRIO 0
@@ -148,7 +149,7 @@ DEV void backward_group(
     // BFP: the pieces, for the products called from here; BFB: the same + the PRIV bit, for everything that reaches an exchange.
     constexpr int BFP = S::BF16 == 3 ? PMT_BWD_PIECES : S::BF16;
     constexpr int BFB = BFP | ((PRIV && S::BF16 != 0) ? PMT_BF_PRIV : 0);
-    static_assert(!PRIV || S::BF16 != 0, "private rows: the bf16-exchange instances only");
+    static_assert(!PRIV || S::BF16 != 0, "private rows: the bf16-exchange instances only (priv_kernel picks)");
     static_assert(EX || (NTF == NTD && NTR == NTD && NTE == NTD), "the generic shape keeps one array width");
     const int tid = pmt_tid(), lane = tid & 63, g = lane >> 4, wave = uniform((int)(tid >> 6));
     const GroupGeom gg = group_geometry(bt, grp);
@@ -937,6 +938,12 @@ __global__ __launch_bounds__(256) void pmt_grad_fold_kernel(const PmtModel* __re
     }
 }
 
+// the instance that adds into private rows, where the shape has one (a generic-only build aliases every shape to the fp32 instances)
+template <typename S, bool LAYERED>
+static auto priv_kernel() {
+    if constexpr (S::BF16 != 0) return pmt_backward_kernel<S, LAYERED, true>;
+    else return pmt_backward_kernel<S, LAYERED, false>;
+}
 // persistent launch with private partial sums: only the bf16-exchange instances know them
 static bool use_partials(const PmtModel* m, int shape, const float* partials, int rows) {
     return partials != nullptr && rows > 0 && m->emit_len > 0 && shape >= 2;  // (2, 3, 4, 6: the instances with the bf16 exchange)
@@ -968,8 +975,8 @@ extern "C" int pmt_backward(const PmtModel* model_host, const PmtModel* model_de
     const int grid = part && num_partials < batch->num_groups ? num_partials : batch->num_groups;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     // (private rows are a compile-time property of the bf16-exchange instances: use_partials is false for the others)
-    auto kernel = part ? (shape == 4 ? pmt_backward_kernel<ShapeP0XD, false, true> : shape == 3 ? pmt_backward_kernel<ShapeP0XB, false, true>
-                          : shape == 2 ? pmt_backward_kernel<ShapeP0X, false, true> : pmt_backward_kernel<ShapeP0T, false, true>)
+    auto kernel = part ? (shape == 4 ? priv_kernel<ShapeP0XD, false>() : shape == 3 ? priv_kernel<ShapeP0XB, false>()
+                          : shape == 2 ? priv_kernel<ShapeP0X, false>() : priv_kernel<ShapeP0T, false>())
                   : shape == 4 ? pmt_backward_kernel<ShapeP0XD> : shape == 3 ? pmt_backward_kernel<ShapeP0XB> : shape == 2 ? pmt_backward_kernel<ShapeP0X>
                   : shape == 6 ? pmt_backward_kernel<ShapeP0T> : shape == 1 ? pmt_backward_kernel<ShapeP0> : pmt_backward_kernel<ShapeAny>;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(PMT_THREADS), 0, s, model_dev,
@@ -1011,7 +1018,7 @@ extern "C" int pmt_backward_layered(const PmtModel* model_host, const PmtModel* 
     const int shape = pmt_shape_for(model_host, batch, true);
     const bool part = use_partials(model_host, shape, grad_partials, num_partials);
     const int grid = part && num_partials < batch->num_groups ? num_partials : batch->num_groups;
-    auto kernel = (shape >= 2 && shape != 6) ? (part ? pmt_backward_kernel<ShapeP0X, true, true> : pmt_backward_kernel<ShapeP0X, true>)
+    auto kernel = (shape >= 2 && shape != 6) ? (part ? priv_kernel<ShapeP0X, true>() : pmt_backward_kernel<ShapeP0X, true>)
                   : (shape == 1 || shape == 6) ? pmt_backward_kernel<ShapeP0, true> : pmt_backward_kernel<ShapeAny, true>;
     int* join_words = reinterpret_cast<int*>(lay.gsum_g + B * nb * PMT_ZW);
     lay.join = PmtJoin{0, join_words + B * nb, join_words, batch->join_fault ? batch->join_fault : join_words + B * nb + 1};
