@@ -1,5 +1,8 @@
 """Backward-kernel ablation timing (development aid): runs the train step with parts of pmt_backward_kernel disabled
-through PmtBatch.debug_flags[1] (results are wrong when a bit is set; only the kernel time matters)."""
+through PmtBatch.debug_flags[1] (results are wrong when a bit is set; only the kernel time matters).
+
+The production build compiles these switches OUT (pmt_backward.hip: PMT_BWD_DEBUG): build a development library first, e.g.
+`make -C permutect_amd/csrc EXTRA="-DPMT_BWD_ABLATE=1 -DPMT_BWD_PROF=1"` into a scratch copy, and load it through PMT_LIB."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
